@@ -1,0 +1,313 @@
+"""Integer-exact numpy interpreter for the reference's INT8 `.tflite` graphs.
+
+ORACLE — test infrastructure only (see oracle/__init__.py).  **Parity unpinned** against a
+real ``tf.lite.Interpreter`` (TensorFlow cannot be imported here): the arithmetic below
+restates the published TFLite *reference kernels* (tensorflow 2.19.0, requirements.txt:2,
+not vendored in the reference) and is anchored on the reference's call sites
+(birdnet_stm32/models/runners.py:51-95 — ``TFLiteRunner``: set_tensor / invoke /
+get_tensor with float32 I/O; birdnet_stm32/conversion/quantize.py:131-152 — full-integer
+per-channel PTQ with float I/O).  The graph itself (every scale, zero point, stride,
+padding and fused activation) is read from the flatbuffer, nothing is hard-coded.
+
+Conventions restated:
+* QUANTIZE   q = clamp(round_half_away(x / s) + zp)           (float32 divide)
+* CONV / DW / FC   acc32 = sum((x - zp_x) * w) + bias ; per-channel
+      M = double(s_x) * double(s_w[c]) / double(s_y)  ->  QuantizeMultiplier (Q31 mantissa, exponent)
+      y = clamp(MultiplyByQuantizedMultiplier(acc, M0, shift) + zp_y, act_min, act_max)
+* MultiplyByQuantizedMultiplier = RoundingDivideByPOT(SaturatingRoundingDoublingHighMul(acc << left, M0), right)
+* ADD   left_shift 20, twice_max = 2 max(s1, s2), inputs rescaled by s_i / twice_max, sum rescaled by
+      twice_max / (2^20 s_y), broadcasting allowed
+* MEAN  int32 sum - N zp_x ; multiplier (s_x / s_y) with the 1/N folded in as in reduce.h
+* LOGISTIC  256-entry float32 LUT ; DEQUANTIZE (q - zp) * s
+* TRANSPOSE / STRIDED_SLICE / SHAPE / PACK / FILL / CONCATENATION are exact data movement.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+INT32_MIN = -(1 << 31)
+INT32_MAX = (1 << 31) - 1
+
+
+# ----------------------------------------------------------------------------- fixed point
+def round_half_away(x):
+    """C ``round()``: halves away from zero (numpy's ``rint`` rounds halves to even)."""
+    x = np.asarray(x)
+    return np.sign(x) * np.floor(np.abs(x) + x.dtype.type(0.5))
+
+
+def quantize_multiplier(real: float) -> tuple[int, int]:
+    """``QuantizeMultiplier``: real = M0 * 2^(shift-31) with M0 in [2^30, 2^31)."""
+    if real == 0.0:
+        return 0, 0
+    frac, shift = math.frexp(real)
+    q = int(math.floor(abs(frac) * (1 << 31) + 0.5)) * (1 if frac >= 0 else -1)
+    if q == (1 << 31):
+        q //= 2
+        shift += 1
+    if shift < -31:
+        return 0, 0
+    if shift > 30:
+        return INT32_MAX, 30
+    return q, shift
+
+
+def srdhm(a, b):
+    """``SaturatingRoundingDoublingHighMul`` on int64 arrays holding int32 values."""
+    a = np.asarray(a, dtype=np.int64)
+    b = np.asarray(b, dtype=np.int64)
+    ab = a * b
+    nudge = np.where(ab >= 0, 1 << 30, 1 - (1 << 30))
+    v = ab + nudge
+    res = np.sign(v) * (np.abs(v) >> 31)  # C++ integer division truncates toward zero
+    overflow = (a == INT32_MIN) & (b == INT32_MIN)
+    return np.where(overflow, INT32_MAX, res)
+
+
+def rounding_divide_by_pot(x, exponent):
+    """``RoundingDivideByPOT``: arithmetic shift with round-half-away-from-zero."""
+    x = np.asarray(x, dtype=np.int64)
+    exponent = np.asarray(exponent, dtype=np.int64)
+    mask = (np.int64(1) << exponent) - 1
+    remainder = x & mask
+    threshold = (mask >> 1) + (x < 0)
+    return (x >> exponent) + (remainder > threshold)
+
+
+def mbqm(x, multiplier, shift):
+    """``MultiplyByQuantizedMultiplier(x, M0, shift)`` (shift > 0 = left shift)."""
+    shift = np.asarray(shift, dtype=np.int64)
+    left = np.maximum(shift, 0)
+    right = np.maximum(-shift, 0)
+    return rounding_divide_by_pot(srdhm(np.asarray(x, dtype=np.int64) << left, multiplier), right)
+
+
+def activation_range(act: str, scale: float, zp: int, qmin=-128, qmax=127) -> tuple[int, int]:
+    """``CalculateActivationRangeQuantized`` for int8 outputs."""
+    s = np.float32(scale)
+
+    def q(v):
+        return int(zp + int(round_half_away(np.float32(v) / s)))
+
+    if act == "relu":
+        return max(qmin, q(0.0)), qmax
+    if act == "relu6":
+        return max(qmin, q(0.0)), min(qmax, q(6.0))
+    if act == "relu_n1_to_1":
+        return max(qmin, q(-1.0)), min(qmax, q(1.0))
+    if act == "none":
+        return qmin, qmax
+    raise ValueError(act)
+
+
+def _per_channel_multipliers(s_in: float, w_scales: np.ndarray, s_out: float, n: int):
+    scales = np.asarray(w_scales, dtype=np.float32)
+    if scales.size == 1:
+        scales = np.repeat(scales, n)
+    mult = np.zeros(n, np.int64)
+    shift = np.zeros(n, np.int64)
+    for c in range(n):
+        real = float(np.float32(s_in)) * float(scales[c]) / float(np.float32(s_out))
+        mult[c], shift[c] = quantize_multiplier(real)
+    return mult, shift
+
+
+def _same(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2, total - total // 2
+
+
+# ----------------------------------------------------------------------------- interpreter
+class Int8Interpreter:
+    """Executes a decoded ``TfliteModel`` on float32 batches, like ``TFLiteRunner.predict``."""
+
+    def __init__(self, model):
+        self.model = model
+        self._prep: dict[int, dict] = {}
+
+    # -- helpers ---------------------------------------------------------------
+    def _q(self, ti):
+        t = self.model.tensors[ti]
+        return float(t.scale[0]), int(t.zero_point[0])
+
+    def _value(self, env, ti):
+        if ti in env:
+            return env[ti]
+        t = self.model.tensors[ti]
+        if t.data is None:
+            raise KeyError(f"tensor {ti} ({t.name}) has no value")
+        return t.data
+
+    # -- ops ------------------------------------------------------------------
+    def _conv(self, op, env, depthwise: bool):
+        x = self._value(env, op.inputs[0]).astype(np.int64)
+        wt = self.model.tensors[op.inputs[1]]
+        w = wt.data.astype(np.int64)
+        bias = self.model.tensors[op.inputs[2]].data.astype(np.int64) if len(op.inputs) > 2 and op.inputs[2] >= 0 else None
+        s_in, zp_in = self._q(op.inputs[0])
+        s_out, zp_out = self._q(op.outputs[0])
+        o = op.options
+        if o["padding"] != "SAME" or o.get("dilation_w", 1) != 1 or o.get("dilation_h", 1) != 1:
+            raise ValueError("only SAME, undilated convolutions occur in the reference graphs")
+        sh, sw = o["stride_h"], o["stride_w"]
+        B, H, W, Cin = x.shape
+        if depthwise:
+            _, kh, kw, cout = w.shape
+            if o.get("depth_multiplier", 1) != 1:
+                raise ValueError("depth_multiplier != 1")
+        else:
+            cout, kh, kw, _ = w.shape
+        key = op.index
+        if key not in self._prep:
+            mult, shift = _per_channel_multipliers(s_in, wt.scale, s_out, cout)
+            self._prep[key] = {"mult": mult, "shift": shift, "act": activation_range(o["activation"], s_out, zp_out)}
+        p = self._prep[key]
+        oh, pt, pb = _same(H, kh, sh)
+        ow, pl, pr = _same(W, kw, sw)
+        xc = x - zp_in  # padded cells contribute (zp - zp) = 0, as the reference kernels skip them
+        xp = np.pad(xc, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+        acc = np.zeros((B, oh, ow, cout), dtype=np.int64)
+        for i in range(kh):
+            for j in range(kw):
+                patch = xp[:, i : i + (oh - 1) * sh + 1 : sh, j : j + (ow - 1) * sw + 1 : sw, :]
+                if depthwise:
+                    acc += patch * w[0, i, j, :]
+                else:
+                    acc += patch @ w[:, i, j, :].T
+        if bias is not None:
+            acc += bias
+        y = mbqm(acc, p["mult"], p["shift"]) + zp_out
+        return np.clip(y, *p["act"]).astype(np.int8)
+
+    def _add(self, op, env):
+        a = self._value(env, op.inputs[0]).astype(np.int64)
+        b = self._value(env, op.inputs[1]).astype(np.int64)
+        s1, z1 = self._q(op.inputs[0])
+        s2, z2 = self._q(op.inputs[1])
+        so, zo = self._q(op.outputs[0])
+        key = op.index
+        if key not in self._prep:
+            twice_max = 2.0 * max(float(np.float32(s1)), float(np.float32(s2)))
+            m1 = quantize_multiplier(float(np.float32(s1)) / twice_max)
+            m2 = quantize_multiplier(float(np.float32(s2)) / twice_max)
+            mo = quantize_multiplier(twice_max / ((1 << 20) * float(np.float32(so))))
+            self._prep[key] = {"m1": m1, "m2": m2, "mo": mo, "act": activation_range(op.options["activation"], so, zo)}
+        p = self._prep[key]
+        sa = mbqm((a - z1) << 20, *p["m1"])
+        sb = mbqm((b - z2) << 20, *p["m2"])
+        y = mbqm(sa + sb, *p["mo"]) + zo
+        return np.clip(y, *p["act"]).astype(np.int8)
+
+    def _mean(self, op, env):
+        x = self._value(env, op.inputs[0]).astype(np.int64)
+        axes = tuple(int(a) % x.ndim for a in np.atleast_1d(self._value(env, op.inputs[1])))
+        s_in, zp_in = self._q(op.inputs[0])
+        s_out, zp_out = self._q(op.outputs[0])
+        n = int(np.prod([x.shape[a] for a in axes]))
+        mult, shift = quantize_multiplier(float(np.float32(s_in)) / float(np.float32(s_out)))
+        fold = min(n.bit_length() - 1, 32, 31 + shift)  # 63 - clz(n), clamped as in reduce.h
+        mult = int((mult << fold) // n)
+        shift -= fold
+        total = x.sum(axis=axes, keepdims=bool(op.options.get("keep_dims"))) - zp_in * n
+        y = mbqm(total, mult, shift) + zp_out
+        return np.clip(y, -128, 127).astype(np.int8)
+
+    def _fully_connected(self, op, env):
+        x = self._value(env, op.inputs[0]).astype(np.int64)
+        wt = self.model.tensors[op.inputs[1]]
+        w = wt.data.astype(np.int64)  # [out, in]
+        bias = self.model.tensors[op.inputs[2]].data.astype(np.int64) if len(op.inputs) > 2 and op.inputs[2] >= 0 else 0
+        s_in, zp_in = self._q(op.inputs[0])
+        s_out, zp_out = self._q(op.outputs[0])
+        key = op.index
+        if key not in self._prep:
+            mult, shift = _per_channel_multipliers(s_in, wt.scale, s_out, w.shape[0])
+            self._prep[key] = {"mult": mult, "shift": shift, "act": activation_range(op.options["activation"], s_out, zp_out)}
+        p = self._prep[key]
+        acc = (x.reshape(-1, w.shape[1]) - zp_in) @ w.T + bias
+        y = mbqm(acc, p["mult"], p["shift"]) + zp_out
+        return np.clip(y, *p["act"]).astype(np.int8)
+
+    def logistic_lut(self, op) -> np.ndarray:
+        """int8->int8 table indexed by ``q + 128`` (LUTPopulate in float32)."""
+        s_in, zp_in = self._q(op.inputs[0])
+        s_out, zp_out = self._q(op.outputs[0])
+        q = np.arange(-128, 128, dtype=np.int32)
+        deq = np.float32(s_in) * (q - zp_in).astype(np.float32)
+        sig = (np.float32(1.0) / (np.float32(1.0) + np.exp(-deq, dtype=np.float32))).astype(np.float32)
+        resc = round_half_away((sig / np.float32(s_out)).astype(np.float32))
+        return np.clip(resc.astype(np.int64) + zp_out, -128, 127).astype(np.int8)
+
+    def _strided_slice(self, op, env):
+        x = self._value(env, op.inputs[0])
+        begin = np.asarray(self._value(env, op.inputs[1])).astype(np.int64)
+        end = np.asarray(self._value(env, op.inputs[2])).astype(np.int64)
+        strides = np.asarray(self._value(env, op.inputs[3])).astype(np.int64)
+        o = op.options
+        if o["ellipsis_mask"] or o["new_axis_mask"]:
+            raise ValueError("ellipsis/new-axis masks unsupported")
+        sl = []
+        for d in range(len(begin)):
+            if o["shrink_axis_mask"] >> d & 1:
+                sl.append(int(begin[d]))
+                continue
+            b = None if o["begin_mask"] >> d & 1 else int(begin[d])
+            e = None if o["end_mask"] >> d & 1 else int(end[d])
+            sl.append(slice(b, e, int(strides[d])))
+        return x[tuple(sl)]
+
+    # -- graph walk ---------------------------------------------------------------
+    def invoke(self, x: np.ndarray, return_all: bool = False):
+        """float32 batch in -> float32 ``[B, C]`` out; optionally every intermediate tensor."""
+        m = self.model
+        env: dict[int, np.ndarray] = {m.inputs[0]: np.asarray(x, dtype=np.float32)}
+        for op in m.ops:
+            n = op.name
+            if n == "QUANTIZE":
+                s, zp = self._q(op.outputs[0])
+                xin = self._value(env, op.inputs[0]).astype(np.float32)
+                q = round_half_away((xin / np.float32(s)).astype(np.float32)).astype(np.int64) + zp
+                y = np.clip(q, -128, 127).astype(np.int8)
+            elif n == "DEQUANTIZE":
+                s, zp = self._q(op.inputs[0])
+                y = ((self._value(env, op.inputs[0]).astype(np.int32) - zp).astype(np.float32) * np.float32(s)).astype(np.float32)
+            elif n == "TRANSPOSE":
+                y = np.transpose(self._value(env, op.inputs[0]), [int(v) for v in self._value(env, op.inputs[1])])
+            elif n == "STRIDED_SLICE":
+                y = self._strided_slice(op, env)
+            elif n == "SHAPE":
+                y = np.asarray(self._value(env, op.inputs[0]).shape, dtype=np.int32)
+            elif n == "PACK":
+                y = np.stack([np.asarray(self._value(env, i)) for i in op.inputs], axis=op.options["axis"]).astype(np.int32)
+            elif n == "FILL":
+                dims = [int(v) for v in self._value(env, op.inputs[0])]
+                val = self._value(env, op.inputs[1])
+                y = np.full(dims, np.asarray(val).reshape(-1)[0], dtype=np.asarray(val).dtype)
+            elif n == "CONCATENATION":
+                parts = [self._value(env, i) for i in op.inputs]
+                qs = {self._q(i) for i in op.inputs} | {self._q(op.outputs[0])}
+                if len(qs) != 1:
+                    raise ValueError("CONCATENATION with differing quantisation needs requantisation")
+                y = np.concatenate(parts, axis=op.options["axis"])
+            elif n == "CONV_2D":
+                y = self._conv(op, env, depthwise=False)
+            elif n == "DEPTHWISE_CONV_2D":
+                y = self._conv(op, env, depthwise=True)
+            elif n == "ADD":
+                y = self._add(op, env)
+            elif n == "MEAN":
+                y = self._mean(op, env)
+            elif n == "FULLY_CONNECTED":
+                y = self._fully_connected(op, env)
+            elif n == "LOGISTIC":
+                lut = self.logistic_lut(op)
+                y = lut[self._value(env, op.inputs[0]).astype(np.int32) + 128]
+            else:
+                raise ValueError(f"operator {n} not handled by the oracle")
+            env[op.outputs[0]] = y
+        out = env[m.outputs[0]]
+        return (out, env) if return_all else out

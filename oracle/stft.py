@@ -1,0 +1,63 @@
+"""Linear-magnitude STFT of the evaluate path, restated in numpy.
+
+ORACLE — test infrastructure only (see oracle/__init__.py).  **Parity unpinned** for the
+framing: librosa cannot be imported here, so the framing below is librosa 0.11's
+documented ``stft`` default behaviour, anchored on the reference's call site.
+
+Reference: birdnet_stm32/audio/spectrogram.py:12-21 (``normalize``), :61 (hop =
+len(audio) // spec_width), :106-115 (``np.abs(librosa.stft(y, n_fft, hop_length,
+win_length=n_fft, window='hann'))``), :133 (keep the first ``spec_width`` columns), :149
+(min-max normalise); caller birdnet_stm32/evaluation/metrics.py:55-61.
+
+librosa.stft defaults restated: ``center=True`` with ``pad_mode='constant'`` (n_fft//2
+zeros each side), periodic Hann (``scipy.signal.get_window('hann', n, fftbins=True)`` =
+``0.5 - 0.5 cos(2 pi k / n)``), frame *t* covers padded samples ``[t*hop, t*hop + n_fft)``,
+``1 + len(y)//hop`` frames, window*frame and the real FFT evaluated in float64, the
+result stored as complex64, and ``np.abs`` of complex64 returning float32.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def hann_periodic(n: int) -> np.ndarray:
+    """Periodic Hann window in float64."""
+    k = np.arange(n, dtype=np.float64)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
+
+
+def stft_magnitude(y: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
+    """``abs(librosa.stft(y, n_fft, hop, win_length=n_fft, window='hann'))`` -> float32 ``[1+n_fft//2, 1+len(y)//hop]``."""
+    y = np.asarray(y, dtype=np.float32)
+    if hop <= 0:
+        raise ValueError("hop must be positive")
+    pad = n_fft // 2
+    yp = np.concatenate([np.zeros(pad, np.float32), y, np.zeros(pad, np.float32)])
+    n_frames = 1 + len(y) // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = yp[idx].astype(np.float64) * hann_periodic(n_fft)[None, :]
+    spec = np.fft.rfft(frames, axis=1).astype(np.complex64)  # stored as complex64 like librosa
+    return np.abs(spec).T.astype(np.float32, copy=False)
+
+
+def minmax_normalize(S: np.ndarray) -> np.ndarray:
+    """``(S - S.min()) / (S.max() - S.min() + 1e-10)`` (spectrogram.py:12-21), float32 result."""
+    S = np.asarray(S, dtype=np.float32)
+    lo = S.min()
+    rng = np.float32(np.float64(S.max() - lo) + 1e-10)
+    return ((S - lo) / rng).astype(np.float32)
+
+
+def hybrid_spectrogram(audio: np.ndarray, n_fft: int = 512, spec_width: int = 256) -> np.ndarray:
+    """``get_spectrogram_from_audio(audio, n_fft=n_fft, mel_bins=-1, spec_width=spec_width)``.
+
+    Returns the normalised ``[n_fft//2+1, spec_width]`` float32 model input of the hybrid
+    frontend.  If the chunk yields fewer than ``spec_width`` frames the result is narrower,
+    exactly as the reference's slicing leaves it.
+    """
+    audio = np.asarray(audio, dtype=np.float32)
+    hop = (len(audio) // spec_width) if spec_width > 0 else n_fft // 2
+    S = stft_magnitude(audio, n_fft, hop)
+    S = S[:, :spec_width]
+    return minmax_normalize(S)
