@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the per-chunk inference hot path on MI355X.
+
+One *step* = one pass of the whole path over one batch of synthetic 3 s @ 24 kHz chunks that are
+already resident in HBM:  windowed STFT magnitude -> hybrid mel mixer -> PWL -> DS-CNN -> scores.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|i8] [--batch B]
+
+* N = 1 (default): BASELINE.json configs[1] — the shipped birdnet_stm32n6_100 float32 DS-CNN with the
+  hybrid+pwl frontend at batch 1024 (``--dtype i8 --batch 4096`` gives configs[2]).
+* N > 1: launched by ``python -m torch.distributed.run --nproc-per-node N``; every rank runs the same
+  per-GPU batch on its own shard of the chunk stream (weak scaling, no data-path collective) and the
+  job ends with the single RCCL all-gather of the scores named by the north star, inside the timed region.
+
+Rank 0 prints ONE JSON line: the throughput contract fields plus ``roofline`` (dominant kernel, timed
+with HIP events on the launch stream during the timed region) and ``cpu_baseline`` (the numpy oracle of
+``oracle/`` timed on this host on a bounded sample — a reported baseline, not a target).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "birdnet-stm32_amd")
+for _p in (REPO, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+SR, SECONDS, W, NFFT = 24000, 3.0, 256, 512
+T = int(SR * SECONDS)
+HOP = T // W
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 / 16x16x4 = vector FP32 rate
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 = 2x bf16
+
+
+def synth_audio_device(torch, batch: int, rank: int, device):
+    """peaknorm(0.3 N(0,1) + sin(2 pi f_b t)), f_b = 500 + 37 (g mod 200), g = global chunk index."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(42 + rank)
+    t = torch.arange(T, device=device, dtype=torch.float64) / SR
+    g = torch.arange(batch, device=device, dtype=torch.float64) + rank * batch
+    f = 500.0 + 37.0 * torch.remainder(g, 200.0)
+    tone = torch.sin(2.0 * np.pi * f[:, None] * t[None, :]).to(torch.float32)
+    x = 0.3 * torch.randn((batch, T), generator=gen, device=device, dtype=torch.float32) + tone
+    x = x / x.abs().amax(dim=1, keepdim=True)
+    return x.contiguous()
+
+
+def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
+    """(bytes, ops) one launch of plan operator ``row`` must move / execute for ``batch`` chunks."""
+    k, p = row["kind"], row["p"]
+    e = 4 if dtype == "f32" else 1
+    if k == "stft512":
+        return batch * (T * 4 + (NFFT // 2 + 1) * W * 4), batch * 3.35e6
+    if k == "f32_mel":
+        return batch * (p[0] * p[1] * 4 + p[2] * p[1] * 4), batch * 2.0 * p[0] * p[1] * p[2]
+    if k == "i8_quant":
+        return batch * (p[0] * p[1] * 4 + p[1] * p[2]), batch * 2.0 * p[0] * p[1]
+    if k == "i8_mel":
+        return batch * (p[0] * p[1] + p[2] * p[0]), batch * 2.0 * p[0] * p[1] * p[2]
+    if k in ("f32_stem", "i8_stem"):
+        return batch * (p[0] * p[1] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2]
+    if k in ("f32_dw", "i8_dw"):
+        return batch * (p[0] * p[1] * p[2] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2]
+    if k == "f32_pw":
+        return batch * (p[0] * p[1] * 4 + p[0] * p[2] * 4 * (2 if p[4] else 1)), batch * 2.0 * p[0] * p[1] * p[2]
+    if k == "i8_pw":
+        return batch * (p[0] * p[1] + p[0] * p[2] * (2 if p[6] else 1)), batch * 2.0 * p[0] * p[1] * p[2]
+    if k in ("f32_gap", "i8_mean"):
+        return batch * (p[0] * p[1] * e + p[1] * e), batch * 1.0 * p[0] * p[1]
+    if k in ("f32_dense", "i8_fc"):
+        return batch * (p[0] * e + p[1] * 4), batch * 2.0 * p[0] * p[1]
+    return 0.0, 0.0
+
+
+def roofline_of(rows: list[dict], batch: int, dtype: str) -> tuple[dict, list[dict]]:
+    stages = []
+    for r in rows:
+        if not r["launches"]:
+            continue
+        avg_ms = r["ms"] / r["launches"]
+        nbytes, nops = algorithmic_work(r, batch, dtype)
+        stages.append({"kernel": r["kind"], "layer": r["name"], "avg_ms": round(avg_ms, 4), "GBps": round(nbytes / avg_ms / 1e6, 1),
+                       "Tops": round(nops / avg_ms / 1e9, 2), "bytes": nbytes, "ops": nops})
+    dom = max(stages, key=lambda s: s["avg_ms"])
+    peak_compute = F32_MFMA_PEAK_TFLOPS if dtype == "f32" else I8_MFMA_PEAK_TOPS
+    ridge = peak_compute * 1e12 / (HBM_PEAK_GBS * 1e9)
+    intensity = dom["ops"] / max(dom["bytes"], 1.0)
+    if intensity > ridge and dom["kernel"].endswith("_pw"):
+        roof = {"bound": "mfma", "achieved": dom["Tops"], "peak": peak_compute, "unit": "TFLOP/s" if dtype == "f32" else "TOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["traffic"] = None  # PMC-measured HBM bytes live in profiles/ (separate rocprofv3 --pmc passes)
+    roof["kernel"] = dom["kernel"] + "_kernel" if dom["kernel"] != "stft512" else "stft512_mag_kernel"
+    roof["layer"] = dom["layer"]
+    roof["avg_launch_ms"] = dom["avg_ms"]
+    roof["algorithmic_bytes_per_launch"] = dom["bytes"]
+    for s in stages:
+        s.pop("bytes"), s.pop("ops")
+    return roof, stages
+
+
+def cpu_baseline(dtype: str, seconds_budget: float = 20.0) -> dict:
+    """Time the numpy oracle (the CPU restatement of the reference path) on a bounded sample."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    from oracle import float_graph, stft
+    from oracle.int8_graph import Int8Interpreter
+
+    from birdnet_stm32.models._keras_loader import load_keras_archive
+    from birdnet_stm32.models._tflite_reader import load_tflite
+
+    ckpt = os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100")
+    rng = np.random.default_rng(42)
+    t = np.arange(T) / SR
+
+    def chunk(b):
+        x = 0.3 * rng.standard_normal(T) + np.sin(2 * np.pi * (500 + 37 * (b % 200)) * t)
+        return (x / np.abs(x).max()).astype(np.float32)
+
+    if dtype == "f32":
+        spec = load_keras_archive(ckpt + ".keras")
+        run = lambda S: float_graph.forward(spec, S, np.float32)  # noqa: E731
+    else:
+        interp = Int8Interpreter(load_tflite(ckpt + ".tflite"))
+        run = lambda S: interp.invoke(S)  # noqa: E731
+
+    def work(n):
+        xs = [chunk(b) for b in range(n)]
+        t0 = time.perf_counter()
+        S = np.stack([stft.hybrid_spectrogram(a, NFFT, W) for a in xs])[..., None]
+        run(S)
+        return time.perf_counter() - t0
+
+    import contextlib
+
+    with threadpool_limits(limits=1) if threadpool_limits else contextlib.nullcontext():
+        per8 = work(8)  # also warms caches/imports
+        n = int(max(8, min(256, (seconds_budget / max(per8 / 8, 1e-4)) // 8 * 8)))
+        dt = work(n)
+    return {"value": round(n / dt, 2), "unit": "chunks/s", "cores": 1, "kind": "port",
+            "sample": f"{n} synthetic 3 s @ 24 kHz chunks, numpy oracle (oracle/stft.py + "
+                      f"{'float_graph' if dtype == 'f32' else 'int8_graph'}.py), 1 thread, {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", choices=["f32", "i8"], default="f32")
+    ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (default 1024 f32, 4096 i8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from birdnet_stm32.models.runners import load_model_runner
+
+    batch = args.batch or (1024 if args.dtype == "f32" else 4096)
+    ckpt = os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100" + (".keras" if args.dtype == "f32" else ".tflite"))
+    runner = load_model_runner(ckpt, device=local_rank, max_batch=batch)
+    audio = synth_audio_device(torch, batch, rank, device)
+    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
+    gathered = torch.empty((world * batch, runner.num_classes), dtype=torch.float32, device=device) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        runner.infer_audio_device(audio, hop=HOP, out=scores)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, scores)  # warm the RCCL communicator outside the timed region
+    torch.cuda.synchronize(device)
+
+    runner.profile(True)
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.infer_audio_device(audio, hop=HOP, out=scores)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, scores)  # the one collective of the path: scores of all shards
+    torch.cuda.synchronize(device)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    runner.profile(False)
+    rows = runner.profile_collect()
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        roof, stages = roofline_of(rows, batch, args.dtype)
+        total_chunks = world * batch * args.steps
+        out = {
+            "metric": "audio chunks/sec (3 s @ 24 kHz)",
+            "value": round(total_chunks / elapsed, 1),
+            "unit": "chunks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (peak-normalised tone + gaussian noise, generated on device); shipped birdnet_stm32n6_100 weights",
+            "config": {
+                "workload": ("birdnet_stm32n6_100 float32 DS-CNN, hybrid+pwl frontend" if args.dtype == "f32"
+                             else "birdnet_stm32n6_100 INT8 DS-CNN, hybrid+pwl frontend"),
+                "batch_per_gpu": batch,
+                "global_batch": world * batch,
+                "chunk": "3 s @ 24 kHz (72000 samples), n_fft 512, hop 281, 257x256 spectrogram",
+                "path": "audio in HBM -> STFT -> mel+PWL -> DS-CNN -> scores in HBM" + (" -> RCCL all-gather" if world > 1 else ""),
+            },
+            "roofline": roof,
+            "stages": stages,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.dtype)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    runner.close()
+
+
+if __name__ == "__main__":
+    main()

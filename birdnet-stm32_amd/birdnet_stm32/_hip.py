@@ -1,0 +1,154 @@
+"""ctypes binding of ``libbirdnet_hip.so`` (C ABI: ``include/birdnet_hip.h``).
+
+The reference binds its accelerated path through ``tf.lite.Interpreter`` (reference:
+birdnet_stm32/models/runners.py:57); here the same role is played by a plain C ABI loaded
+with ``ctypes`` (``cffi`` is not installed on the target image).  PyTorch is imported first on
+purpose: it loads the process's HIP runtime (``libamdhip64.so``), and ``libbirdnet_hip.so``
+must bind to that same runtime instance so that device pointers and ``hipStream_t`` handles
+coming from torch tensors are valid inside the library.
+
+There is no fallback: if the shared object is missing or no gfx950 device is present, loading
+or context creation raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # .../birdnet-stm32_amd
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libbirdnet_hip.so")
+
+ABI_VERSION = 1
+
+# every symbol include/birdnet_hip.h declares
+EXPORTS = (
+    "bn_version", "bn_last_error", "bn_device_count", "bn_ctx_create", "bn_ctx_destroy", "bn_model_load",
+    "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
+    "bn_kernel_names", "bn_profile_enable", "bn_profile_collect",
+)  # fmt: skip
+
+
+class BnModelInfo(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int32), ("input_kind", c_int32), ("input_elems", c_int32), ("fft_bins", c_int32),
+        ("spec_width", c_int32), ("num_classes", c_int32), ("n_ops", c_int32), ("max_batch", c_int32),
+        ("workspace_bytes", c_int64), ("const_bytes", c_int64),
+    ]  # fmt: skip
+
+
+class HipError(RuntimeError):
+    """A libbirdnet_hip call returned a negative status."""
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load (once) and type the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("BIRDNET_HIP_LIB", LIB_PATH)
+    if not os.path.isfile(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C birdnet-stm32_amd/csrc`). There is no CPU fallback for this path."
+        )
+    import torch  # noqa: F401  (brings in the HIP runtime this library must share)
+
+    lib = ctypes.CDLL(path)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f"{path} does not export {name}")
+    lib.bn_version.restype = c_int
+    lib.bn_last_error.restype = c_char_p
+    lib.bn_device_count.restype = c_int
+    lib.bn_ctx_create.argtypes = [c_int, c_int, POINTER(c_void_p)]
+    lib.bn_ctx_destroy.argtypes = [c_void_p]
+    lib.bn_ctx_destroy.restype = None
+    lib.bn_model_load.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]
+    lib.bn_model_free.argtypes = [c_void_p]
+    lib.bn_model_free.restype = None
+    lib.bn_model_get_info.argtypes = [c_void_p, POINTER(BnModelInfo)]
+    lib.bn_stft_mag.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.bn_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+    lib.bn_infer_audio.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.bn_debug_op_output.argtypes = [c_void_p, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]
+    lib.bn_kernel_names.restype = c_char_p
+    lib.bn_profile_enable.argtypes = [c_void_p, c_int]
+    lib.bn_profile_collect.argtypes = [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int]
+    if lib.bn_version() != ABI_VERSION:
+        raise RuntimeError(f"libbirdnet_hip ABI {lib.bn_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().bn_last_error()
+        raise HipError(f"libbirdnet_hip error {rc}: {msg.decode('utf-8', 'replace') if msg else ''}")
+
+
+def loaded_hip_runtimes() -> list[str]:
+    """Paths of every libamdhip64 mapped in this process (must be exactly one)."""
+    seen = set()
+    with open("/proc/self/maps") as fh:
+        for line in fh:
+            if "libamdhip64" in line:
+                seen.add(line.split()[-1])
+    return sorted(seen)
+
+
+class Context:
+    """Owns a ``bn_ctx`` on one device."""
+
+    def __init__(self, device: int = 0, max_batch: int = 1024):
+        self.lib = load_library()
+        self.device, self.max_batch = int(device), int(max_batch)
+        h = c_void_p()
+        check(self.lib.bn_ctx_create(self.device, self.max_batch, byref(h)))
+        self.handle = h
+        rts = loaded_hip_runtimes()
+        if len(rts) != 1:
+            raise RuntimeError(f"expected one HIP runtime in the process, found {rts}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.bn_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Model:
+    """Owns a ``bn_model`` (constants in HBM + activation workspace)."""
+
+    def __init__(self, ctx: Context, blob: bytes):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        h = c_void_p()
+        check(self.lib.bn_model_load(ctx.handle, blob, len(blob), byref(h)))
+        self.handle = h
+        info = BnModelInfo()
+        check(self.lib.bn_model_get_info(h, byref(info)))
+        self.info = info
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.bn_model_free(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["load_library", "check", "Context", "Model", "HipError", "BnModelInfo", "EXPORTS", "LIB_PATH", "c_float"]

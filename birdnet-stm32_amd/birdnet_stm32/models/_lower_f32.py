@@ -1,0 +1,252 @@
+"""Lower a :class:`NetSpec` (Keras layer list) to the float32 device plan.
+
+Fusions performed here, all algebraically exact up to float rounding:
+
+* ``Conv2D/DepthwiseConv2D -> BatchNormalization`` becomes one convolution with
+  ``w' = w * gamma / sqrt(var + eps)`` and ``b' = beta - mean * gamma / sqrt(var + eps)``
+  (folded in float64, stored float32);
+* a following ``Add`` (residual) and ``ReLU(max_value=6)`` ride in the pointwise kernel's epilogue;
+* squeeze-excite (reference: birdnet_stm32/models/blocks.py:27-46) becomes a gate vector that
+  the next pointwise convolution multiplies into its input channels (inverted-residual
+  blocks) or an explicit scale pass (DS blocks, where the scaled tensor is also a residual);
+* the hybrid frontend's mel mixer is stored band-sparse: every Slaney triangle touches only a
+  few FFT bins (reference seeds the mixer from ``librosa.filters.mel`` and freezes it,
+  birdnet_stm32/models/frontend.py:121-129,257-276); exact zeros are skipped, any other
+  weight is kept, so a dense mixer degrades to full-length bands, never to a wrong result.
+
+Layer semantics follow birdnet_stm32/models/dscnn.py:28-84,198-261 and blocks.py:49-133.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from birdnet_stm32.models import _netspec as ns
+from birdnet_stm32.models import _pack as pk
+
+
+def fold_bn(kernel: np.ndarray, bn: ns.Layer | None, cout_axis_last: bool = True):
+    """Return (kernel', bias') in float32 with the BatchNorm folded in (float64 arithmetic)."""
+    k = kernel.astype(np.float64)
+    cout = k.shape[-1]
+    if bn is None:
+        return k.astype(np.float32), np.zeros(cout, np.float32)
+    g = bn.weights["gamma"].astype(np.float64)
+    b = bn.weights["beta"].astype(np.float64)
+    mu = bn.weights["mean"].astype(np.float64)
+    var = bn.weights["var"].astype(np.float64)
+    s = g / np.sqrt(var + float(bn.attrs["eps"]))
+    return (k * s).astype(np.float32), (b - mu * s).astype(np.float32)
+
+
+def mel_bands(mel: np.ndarray, n_bins: int):
+    """Band-sparse form of a ``[F_pad, M]`` mixer: (values, int32 [3, M] = start, len, offset)."""
+    M = mel.shape[1]
+    vals: list[np.ndarray] = []
+    bands = np.zeros((3, M), np.int32)
+    off = 0
+    for m in range(M):
+        col = mel[:n_bins, m]
+        nz = np.nonzero(col)[0]
+        if nz.size == 0:
+            start, length = 0, 0
+        else:
+            start, length = int(nz[0]), int(nz[-1] - nz[0] + 1)
+        bands[:, m] = (start, length, off)
+        vals.append(col[start : start + length])
+        off += length
+    flat = np.concatenate(vals) if off else np.zeros(1, np.float32)
+    return flat.astype(np.float32), bands
+
+
+def mag_params(front: ns.Layer) -> np.ndarray:
+    """Pack magnitude-scaling weights as rows of ``[NP][M]`` in the order the kernels index them."""
+    w, M = front.weights, int(front.attrs["mel_bins"])
+    kind = front.attrs.get("mag_scale", "none")
+    if kind == "pwl":
+        rows = [w["pwl_k0"], *w["pwl_k"], *w["pwl_w"], *w["pwl_b"]]
+    elif kind == "pcen":
+        rows = [w["pcen_agc"], w["pcen_k1"], w["pcen_sw"], w["pcen_sb"], w["pcen_k2"]]
+    else:
+        rows = [np.zeros(M, np.float32)]
+    return np.stack([np.asarray(r, np.float32).reshape(M) for r in rows])
+
+
+def lower_f32(spec: ns.NetSpec, keep_all: bool = False) -> pk.Plan:
+    """Build the float32 plan for ``spec``.  ``keep_all`` disables slot reuse (debug/tests)."""
+    layers = spec.layers
+    consumers: dict[str, list[int]] = {}
+    index_of = {ly.name: i for i, ly in enumerate(layers)}
+    for i, ly in enumerate(layers):
+        for src in ly.inputs:
+            consumers.setdefault(src, []).append(i)
+
+    front = spec.frontend
+    fa = front.attrs
+    if fa["mode"] == "hybrid":
+        in_kind, F, W = pk.INPUT_SPECTROGRAM, layers[0].out_shape[0], int(fa["spec_width"])
+        in_elems = int(np.prod(layers[0].out_shape))
+    elif fa["mode"] == "raw":
+        raise NotImplementedError("raw-waveform frontend is not lowered to HIP yet")
+    else:
+        raise NotImplementedError(f"frontend mode {fa['mode']!r} is not lowered to HIP yet")
+
+    plan = pk.Plan(pk.DTYPE_F32, in_kind, in_elems, F, W, spec.num_classes, meta={"source": spec.meta.get("source", "")})
+    pb = pk.PlanBuilder(plan)
+    val: dict[str, int] = {}  # layer name -> value id holding its output
+    shape: dict[str, tuple] = {}
+    gate_of: dict[str, tuple[int, int]] = {}  # multiply output name -> (value of x, value of gate)
+    done: set[int] = set()
+
+    def only_consumer(name: str):
+        c = consumers.get(name, [])
+        return c[0] if len(c) == 1 else None
+
+    def chain_after(i: int, produced: str):
+        """Follow BN / identity / Add / ReLU after layer i; return (bn, res_name, act, last_idx)."""
+        bn = res = None
+        act = "none"
+        cur, j = produced, i
+        nxt = only_consumer(cur)
+        if nxt is not None and layers[nxt].kind == ns.BN:
+            bn, cur, j = layers[nxt], layers[nxt].name, nxt
+            nxt = only_consumer(cur)
+        while nxt is not None and layers[nxt].kind == ns.IDENTITY:
+            cur, j = layers[nxt].name, nxt
+            nxt = only_consumer(cur)
+        if nxt is not None and layers[nxt].kind == ns.ADD:
+            other = [n for n in layers[nxt].inputs if n != cur]
+            if len(other) == 1:
+                res, cur, j = other[0], layers[nxt].name, nxt
+                nxt = only_consumer(cur)
+        if nxt is not None and layers[nxt].kind == ns.RELU:
+            mv = layers[nxt].attrs.get("max_value")
+            act = "relu6" if mv is not None and float(mv) == 6.0 else "relu"
+            if mv is not None and float(mv) != 6.0:
+                raise NotImplementedError("ReLU max_value other than 6")
+            cur, j = layers[nxt].name, nxt
+        return bn, res, act, cur
+
+    for i, ly in enumerate(layers):
+        if i in done:
+            continue
+        k = ly.kind
+        if k == ns.INPUT:
+            val[ly.name] = pk.SLOT_INPUT
+            shape[ly.name] = ly.out_shape
+        elif k == ns.FRONTEND:
+            M = int(fa["mel_bins"])
+            wv, bands = mel_bands(ly.weights["mel"], F)
+            t_w, t_b = pb.tensor(wv, np.float32), pb.tensor(bands, np.int32)
+            t_m = pb.tensor(mag_params(ly), np.float32)
+            mag, norm = pk.MAG_CODES[fa.get("mag_scale", "none")], int(bool(fa.get("norm", False)))
+            v = pb.value(M * W * 4)
+            pb.op(pk.F32_MEL, val[ly.inputs[0]], v, p=[F, W, M, mag, norm], t=[t_w, t_b, t_m],
+                  name=ly.name if not norm else ly.name + ":mel", out_shape=(M, W, 1))
+            if norm:
+                pb.op(pk.F32_MAG, v, v, p=[M, W, mag], t=[-1, -1, t_m], name=ly.name, out_shape=(M, W, 1))
+            val[ly.name], shape[ly.name] = v, (M, W, 1)
+        elif k in (ns.CONV, ns.DWCONV):
+            src = ly.inputs[0]
+            H, Wd, Cin = shape[src]
+            kh, kw = ly.attrs["kernel"]
+            sh, sw = ly.attrs["strides"]
+            bn, res, act, last = chain_after(i, ly.name)
+            OH, pt, _ = ns.same_pad(H, kh, sh)
+            OW, pl, _ = ns.same_pad(Wd, kw, sw)
+            if k == ns.DWCONV:
+                if (kh, kw) != (3, 3) or res is not None:
+                    raise NotImplementedError(f"{ly.name}: only 3x3 depthwise convolutions without residual")
+                w, b = fold_bn(ly.weights["kernel"], bn)  # [3,3,C]
+                C = Cin
+                if C % 4:
+                    raise NotImplementedError("channel counts must be multiples of 4")
+                v = pb.value(OH * OW * C * 4)
+                pb.op(pk.F32_DW, val[src], v, p=[H, Wd, C, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl],
+                      t=[pb.tensor(w, np.float32), pb.tensor(b, np.float32)], name=last, out_shape=(OH, OW, C))
+                out_shape = (OH, OW, C)
+            elif (kh, kw) == (3, 3):
+                if Cin != 1 or res is not None:
+                    raise NotImplementedError(f"{ly.name}: 3x3 convolutions are only lowered for the 1-channel stem")
+                w, b = fold_bn(ly.weights["kernel"], bn)  # [3,3,1,Cout]
+                Cout = w.shape[-1]
+                v = pb.value(OH * OW * Cout * 4)
+                pb.op(pk.F32_STEM, val[src], v, p=[H, Wd, Cout, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl],
+                      t=[pb.tensor(w[:, :, 0, :], np.float32), pb.tensor(b, np.float32)], name=last, out_shape=(OH, OW, Cout))
+                out_shape = (OH, OW, Cout)
+            elif (kh, kw) == (1, 1) and (sh, sw) == (1, 1):
+                w, b = fold_bn(ly.weights["kernel"], bn)  # [1,1,Cin,Cout]
+                Cout = w.shape[-1]
+                P = H * Wd
+                x_val, gate_val = val[src], None
+                if src in gate_of:
+                    x_val, gate_val = gate_of[src]
+                v = pb.value(P * Cout * 4)
+                p = [P, Cin, Cout, pk.ACT_CODES[act], int(res is not None), int(gate_val is not None),
+                     gate_val if gate_val is not None else 0]
+                pb.op(pk.F32_PW, x_val, v, p=p, t=[pb.tensor(w[0, 0], np.float32), pb.tensor(b, np.float32)],
+                      in1=val[res] if res is not None else pk.SLOT_NONE, name=last, out_shape=(H, Wd, Cout),
+                      value_params=(6,) if gate_val is not None else ())
+                out_shape = (H, Wd, Cout)
+            else:
+                raise NotImplementedError(f"{ly.name}: kernel {kh}x{kw} stride {sh}x{sw}")
+            # every layer swallowed by the fusion aliases the fused output
+            j = i
+            names = [ly.name]
+            cur = ly.name
+            while cur != last:
+                j = only_consumer(cur)
+                cur = layers[j].name
+                names.append(cur)
+                done.add(j)
+            for n in names:
+                val[n], shape[n] = v, out_shape
+        elif k == ns.GAP and ly.attrs.get("keepdims"):
+            # squeeze-excite: GAP(keepdims) -> Dense(relu) -> Dense(sigmoid) -> Multiply
+            x = ly.inputs[0]
+            d1 = layers[only_consumer(ly.name)]
+            d2 = layers[only_consumer(d1.name)]
+            mul_i = only_consumer(d2.name)
+            mul = layers[mul_i]
+            if not (d1.kind == ns.DENSE and d2.kind == ns.DENSE and mul.kind == ns.MUL and x in mul.inputs):
+                raise NotImplementedError("unrecognised squeeze-excite pattern")
+            H, Wd, C = shape[x]
+            Cr = int(d1.attrs["units"])
+            g = pb.value(C * 4)
+            pb.op(pk.F32_SEGATE, val[x], g, p=[H * Wd, C, Cr],
+                  t=[pb.tensor(d1.weights["kernel"], np.float32), pb.tensor(d2.weights["kernel"], np.float32)],
+                  name=d2.name, out_shape=(C,))
+            done.update({index_of[d1.name], index_of[d2.name], mul_i})
+            nxt = only_consumer(mul.name)
+            if nxt is not None and layers[nxt].kind == ns.CONV and tuple(layers[nxt].attrs["kernel"]) == (1, 1):
+                gate_of[mul.name] = (val[x], g)
+                shape[mul.name] = shape[x]
+            else:
+                v = pb.value(H * Wd * C * 4)
+                pb.op(pk.F32_SCALE, val[x], v, p=[H * Wd, C], in1=g, name=mul.name, out_shape=(H, Wd, C))
+                val[mul.name], shape[mul.name] = v, shape[x]
+        elif k == ns.GAP:
+            H, Wd, C = shape[ly.inputs[0]]
+            v = pb.value(C * 4)
+            pb.op(pk.F32_GAP, val[ly.inputs[0]], v, p=[H * Wd, C], name=ly.name, out_shape=(C,))
+            val[ly.name], shape[ly.name] = v, (C,)
+        elif k == ns.ATTNPOOL:
+            H, Wd, C = shape[ly.inputs[0]]
+            v = pb.value(C * 4)
+            pb.op(pk.F32_ATTNPOOL, val[ly.inputs[0]], v, p=[H * Wd, C], t=[pb.tensor(ly.weights["score"], np.float32)],
+                  name=ly.name, out_shape=(C,))
+            val[ly.name], shape[ly.name] = v, (C,)
+        elif k == ns.IDENTITY:
+            val[ly.name], shape[ly.name] = val[ly.inputs[0]], shape[ly.inputs[0]]
+        elif k == ns.DENSE:
+            if ly is not layers[-1]:
+                raise NotImplementedError("Dense layers are only lowered as the classifier head or inside squeeze-excite")
+            (cin,) = shape[ly.inputs[0]]
+            cout = int(ly.attrs["units"])
+            act = {"linear": 0, "sigmoid": 1, "softmax": 2}[ly.attrs.get("activation", "linear")]
+            bias = ly.weights.get("bias", np.zeros(cout, np.float32))
+            pb.op(pk.F32_DENSE, val[ly.inputs[0]], pk.SLOT_SCORES, p=[cin, cout, act],
+                  t=[pb.tensor(ly.weights["kernel"], np.float32), pb.tensor(bias, np.float32)], name=ly.name, out_shape=(cout,))
+        else:
+            raise NotImplementedError(f"layer {ly.name} of kind {k} cannot be lowered on its own")
+    return pb.finalize(reuse=not keep_all)

@@ -1,0 +1,300 @@
+"""Lower a decoded INT8 `.tflite` graph to the INT8 device plan.
+
+The reference executes the flatbuffer operator by operator through ``tf.lite.Interpreter``
+(reference: birdnet_stm32/models/runners.py:51-95).  The graphs its converter emits for
+hybrid-frontend DS-CNNs (reference: birdnet_stm32/conversion/quantize.py:131-152) all have
+the shape decoded in SURVEY.md Appendix B:
+
+    QUANTIZE -> TRANSPOSE -> STRIDED_SLICE -> [SHAPE, STRIDED_SLICE, PACK, FILL, CONCATENATION]
+    -> CONV_2D (mel mixer, ReLU) -> element-wise PWL sub-graph (1x1 DEPTHWISE_CONV_2D / ADD)
+    -> TRANSPOSE -> STRIDED_SLICE -> CONV_2D 3x3 (stem)
+    -> { DEPTHWISE_CONV_2D 3x3 -> CONV_2D 1x1 [-> ADD residual] } * n
+    -> MEAN -> FULLY_CONNECTED -> LOGISTIC -> DEQUANTIZE
+
+This pass walks that shape, checks every assumption it relies on (tensor shapes, permutations,
+quantisation of both sides of data-movement operators) and raises ``NotImplementedError`` on
+anything else.  Data movement is absorbed into kernel addressing; the PWL sub-graph is
+evaluated once for all 256 int8 inputs per channel and stored as a table, which is exact.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from birdnet_stm32.models import _pack as pk
+from birdnet_stm32.models import _quant as qz
+from birdnet_stm32.models._netspec import same_pad
+
+K_ALIGN = 64  # int8 MFMA contracts 64 channels per instruction
+
+
+class _Graph:
+    def __init__(self, model):
+        self.m = model
+        self.t = model.tensors
+        self.consumers: dict[int, list[int]] = {}
+        for op in model.ops:
+            for ti in op.inputs:
+                if ti >= 0:
+                    self.consumers.setdefault(ti, []).append(op.index)
+
+    def q(self, ti: int) -> tuple[float, int]:
+        t = self.t[ti]
+        if t.scale.size != 1:
+            raise NotImplementedError(f"tensor {ti} ({t.name}) is not per-tensor quantised")
+        return float(t.scale[0]), int(t.zero_point[0])
+
+    def const(self, ti: int) -> np.ndarray:
+        d = self.t[ti].data
+        if d is None:
+            raise NotImplementedError(f"tensor {ti} ({self.t[ti].name}) is expected to be constant")
+        return d
+
+
+def _expect(cond: bool, what: str) -> None:
+    if not cond:
+        raise NotImplementedError(f"unsupported INT8 graph: {what}")
+
+
+def _pwl_table(g: _Graph, ops: list, src: int, dst: int, channels: int) -> np.ndarray:
+    """Evaluate the element-wise sub-graph ``ops`` for every int8 value of ``src``: int8 [C][256]."""
+    env = {src: np.repeat(np.arange(-128, 128, dtype=np.int64)[:, None], channels, axis=1)}  # [256, C]
+
+    def value(ti: int) -> np.ndarray:
+        if ti in env:
+            return env[ti]
+        return g.const(ti).astype(np.int64).reshape(1, -1)  # per-channel constant, broadcast over the 256 rows
+
+    for op in ops:
+        if op.name == "DEPTHWISE_CONV_2D":
+            w = g.t[op.inputs[1]]
+            _expect(tuple(w.shape[1:3]) == (1, 1) and op.options["stride_w"] == 1 and op.options["stride_h"] == 1, "PWL depthwise must be 1x1")
+            s_in, z_in = g.q(op.inputs[0])
+            s_out, z_out = g.q(op.outputs[0])
+            mult, shift = qz.channel_multipliers(s_in, w.scale, s_out, channels)
+            bias = g.const(op.inputs[2]).astype(np.int64) if len(op.inputs) > 2 and op.inputs[2] >= 0 else 0
+            acc = (value(op.inputs[0]) - z_in) * w.data.astype(np.int64).reshape(1, channels) + bias
+            lo, hi = qz.activation_bounds(op.options["activation"], s_out, z_out)
+            env[op.outputs[0]] = np.clip(qz.requantize(acc, mult, shift) + z_out, lo, hi)
+        elif op.name == "ADD":
+            s1, z1 = g.q(op.inputs[0])
+            s2, z2 = g.q(op.inputs[1])
+            so, zo = g.q(op.outputs[0])
+            ap = qz.AddParams(s1, z1, s2, z2, so, zo, op.options["activation"])
+            a, b = np.broadcast_arrays(value(op.inputs[0]), value(op.inputs[1]))
+            env[op.outputs[0]] = ap.apply(a, b)
+        else:
+            _expect(False, f"{op.name} inside the element-wise frontend region")
+    return env[dst].T.astype(np.int8).copy()  # [C][256]
+
+
+def lower_i8(model, keep_all: bool = False) -> pk.Plan:
+    """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse."""
+    g = _Graph(model)
+    ops = model.ops
+    t = g.t
+    _expect(len(model.inputs) == 1 and len(model.outputs) == 1, "single input / single output")
+    in_shape = t[model.inputs[0]].shape
+    _expect(len(in_shape) == 4 and in_shape[3] == 1, "input must be [B, F, W, 1]")
+    F, W = int(in_shape[1]), int(in_shape[2])
+
+    i = 0
+    _expect(ops[i].name == "QUANTIZE" and ops[i].inputs[0] == model.inputs[0], "graph must start with QUANTIZE of the input")
+    q_scale, q_zp = g.q(ops[i].outputs[0])
+    cur = ops[i].outputs[0]
+    i += 1
+    _expect(ops[i].name == "TRANSPOSE" and list(g.const(ops[i].inputs[1])) == [0, 3, 2, 1], "TRANSPOSE [0,3,2,1] after QUANTIZE")
+    cur = ops[i].outputs[0]
+    i += 1
+    if ops[i].name == "STRIDED_SLICE":
+        _expect(tuple(t[ops[i].outputs[0]].shape[1:]) == (1, W, F), "frontend STRIDED_SLICE must keep [1, W, F]")
+        cur = ops[i].outputs[0]
+        i += 1
+    fill_value = q_zp
+    k_graph = F
+    if ops[i].name == "SHAPE":
+        j = i
+        while ops[j].name != "CONCATENATION":
+            _expect(ops[j].name in ("SHAPE", "STRIDED_SLICE", "PACK", "FILL"), f"{ops[j].name} in the channel-padding block")
+            if ops[j].name == "FILL":
+                fill_value = int(np.asarray(g.const(ops[j].inputs[1])).reshape(-1)[0])
+            j += 1
+        cat = ops[j]
+        _expect(cat.inputs[0] == cur and cat.options["axis"] in (-1, 3), "CONCATENATION must pad the channel axis")
+        _expect(g.q(cat.inputs[0]) == g.q(cat.inputs[1]) == g.q(cat.outputs[0]), "CONCATENATION operands must share quantisation")
+        k_graph = int(t[cat.outputs[0]].shape[3])
+        cur = cat.outputs[0]
+        i = j + 1
+
+    # ---- mel mixer ------------------------------------------------------------------------
+    mel = ops[i]
+    _expect(mel.name == "CONV_2D" and mel.inputs[0] == cur, "mel mixer CONV_2D")
+    wt = t[mel.inputs[1]]
+    M = int(wt.shape[0])
+    _expect(tuple(wt.shape[1:3]) == (1, 1) and int(wt.shape[3]) == k_graph, "mel mixer must be 1x1 over the padded bins")
+    s_in, z_in = g.q(mel.inputs[0])
+    _expect((s_in, z_in) == (q_scale, q_zp), "mel mixer input quantisation")
+    s_mel, z_mel = g.q(mel.outputs[0])
+    Kp = (k_graph + K_ALIGN - 1) // K_ALIGN * K_ALIGN
+    w_mel = np.zeros((M, Kp), np.int8)
+    w_mel[:, :k_graph] = wt.data.reshape(M, k_graph)
+    bias = g.const(mel.inputs[2]).astype(np.int64) - z_in * w_mel.astype(np.int64).sum(axis=1)
+    _expect(np.abs(bias).max() < 2**31, "folded bias overflows int32")
+    mult, shift = qz.channel_multipliers(s_in, wt.scale, s_mel, M)
+    lo, hi = qz.activation_bounds(mel.options["activation"], s_mel, z_mel)
+    cur = mel.outputs[0]
+    i += 1
+
+    # ---- element-wise region up to the TRANSPOSE back ---------------------------------------
+    j = i
+    while ops[j].name != "TRANSPOSE":
+        j += 1
+    region = ops[i:j]
+    lut = None
+    front_out = cur
+    if region:
+        front_out = ops[j].inputs[0]
+        lut = _pwl_table(g, region, cur, front_out, M)
+    _expect(list(g.const(ops[j].inputs[1])) == [0, 3, 2, 1], "TRANSPOSE [0,3,2,1] after the frontend")
+    cur = ops[j].outputs[0]
+    i = j + 1
+    if ops[i].name == "STRIDED_SLICE":
+        _expect(tuple(t[ops[i].outputs[0]].shape[1:]) == (M, W, 1), "post-frontend STRIDED_SLICE must keep [M, W, 1]")
+        cur = ops[i].outputs[0]
+        i += 1
+
+    plan = pk.Plan(pk.DTYPE_I8, pk.INPUT_SPECTROGRAM, F * W, F, W, int(t[model.outputs[0]].shape[-1]), meta={"tflite_ops": len(ops)})
+    pb = pk.PlanBuilder(plan)
+    v_q = pb.value(W * Kp)
+    pb.op(pk.I8_QUANT, pk.SLOT_INPUT, v_q, p=[F, W, Kp, q_zp, fill_value], f=[q_scale], name=f"t{mel.inputs[0]}",
+          out_shape=(W, Kp), out_dtype="int8")
+    v = pb.value(M * W)
+    tens = [pb.tensor(w_mel, np.int8), pb.tensor(bias, np.int32), pb.tensor(mult, np.int32), pb.tensor(shift, np.int32)]
+    if lut is not None:
+        tens.append(pb.tensor(lut, np.int8))
+    pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
+          out_shape=(M, W, 1), out_dtype="int8")
+    val = {cur: v}
+    shape = {cur: (M, W, 1)}
+
+    def conv_common(op):
+        s_i, z_i = g.q(op.inputs[0])
+        s_o, z_o = g.q(op.outputs[0])
+        wt_ = t[op.inputs[1]]
+        n = int(wt_.shape[3] if op.name == "DEPTHWISE_CONV_2D" else wt_.shape[0])
+        mu, sh = qz.channel_multipliers(s_i, wt_.scale, s_o, n)
+        a_lo, a_hi = qz.activation_bounds(op.options["activation"], s_o, z_o)
+        b = g.const(op.inputs[2]).astype(np.int64) if len(op.inputs) > 2 and op.inputs[2] >= 0 else np.zeros(n, np.int64)
+        _expect(op.options["padding"] == "SAME" and op.options.get("dilation_w", 1) == 1, "SAME, undilated convolutions")
+        return s_i, z_i, s_o, z_o, wt_, n, mu, sh, a_lo, a_hi, b
+
+    # ---- backbone ---------------------------------------------------------------------------
+    while i < len(ops):
+        op = ops[i]
+        src = op.inputs[0]
+        if op.name == "CONV_2D" and tuple(t[op.inputs[1]].shape[1:3]) == (3, 3):
+            H, Wd, Cin = shape[src]
+            _expect(Cin == 1, "3x3 CONV_2D is only lowered for the single-channel stem")
+            s_i, z_i, s_o, z_o, wt_, Cout, mu, sh, a_lo, a_hi, b = conv_common(op)
+            sh_, sw_ = op.options["stride_h"], op.options["stride_w"]
+            OH, pt, _ = same_pad(H, 3, sh_)
+            OW, pl, _ = same_pad(Wd, 3, sw_)
+            w = np.transpose(wt_.data[:, :, :, 0], (1, 2, 0))  # [3][3][Cout]
+            v = pb.value(OH * OW * Cout)
+            pb.op(pk.I8_STEM, val[src], v, p=[H, Wd, Cout, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi],
+                  t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                  name=f"t{op.outputs[0]}", out_shape=(OH, OW, Cout), out_dtype="int8")
+            val[op.outputs[0]], shape[op.outputs[0]] = v, (OH, OW, Cout)
+            i += 1
+        elif op.name == "DEPTHWISE_CONV_2D":
+            H, Wd, C = shape[src]
+            s_i, z_i, s_o, z_o, wt_, n, mu, sh, a_lo, a_hi, b = conv_common(op)
+            _expect(tuple(wt_.shape[1:3]) == (3, 3) and n == C and op.options["depth_multiplier"] == 1, "3x3 depthwise, multiplier 1")
+            sh_, sw_ = op.options["stride_h"], op.options["stride_w"]
+            OH, pt, _ = same_pad(H, 3, sh_)
+            OW, pl, _ = same_pad(Wd, 3, sw_)
+            v = pb.value(OH * OW * C)
+            pb.op(pk.I8_DW, val[src], v, p=[H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi],
+                  t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                  name=f"t{op.outputs[0]}", out_shape=(OH, OW, C), out_dtype="int8")
+            val[op.outputs[0]], shape[op.outputs[0]] = v, (OH, OW, C)
+            i += 1
+        elif op.name == "CONV_2D":
+            H, Wd, Cin = shape[src]
+            s_i, z_i, s_o, z_o, wt_, Cout, mu, sh, a_lo, a_hi, b = conv_common(op)
+            _expect(tuple(wt_.shape[1:3]) == (1, 1) and op.options["stride_h"] == 1 and op.options["stride_w"] == 1, "1x1 stride-1 CONV_2D")
+            w = wt_.data.reshape(Cout, Cin)
+            b = b - z_i * w.astype(np.int64).sum(axis=1)
+            _expect(np.abs(b).max() < 2**31, "folded bias overflows int32")
+            add_p = [0] * 11
+            res_val = pk.SLOT_NONE
+            out_t = op.outputs[0]
+            nxt = ops[i + 1] if i + 1 < len(ops) else None
+            cons = g.consumers.get(op.outputs[0], [])
+            if nxt is not None and nxt.name == "ADD" and cons == [nxt.index] and op.outputs[0] in nxt.inputs:
+                other = [x for x in nxt.inputs if x != op.outputs[0]]
+                _expect(len(other) == 1 and other[0] in val and shape[other[0]] == (H, Wd, Cout), "residual ADD operand")
+                first_is_res = nxt.inputs[0] == other[0]
+                s_r, z_r = g.q(other[0])
+                s_a, z_a = g.q(nxt.outputs[0])
+                if first_is_res:
+                    ap = qz.AddParams(s_r, z_r, s_o, z_o, s_a, z_a, nxt.options["activation"])
+                    add_p = [1, ap.z1, ap.m1, ap.sh1, ap.m2, ap.sh2, ap.mo, ap.sho, ap.zo, ap.amin, ap.amax]
+                else:  # ADD is commutative in exact integer arithmetic; keep the operand roles
+                    ap = qz.AddParams(s_o, z_o, s_r, z_r, s_a, z_a, nxt.options["activation"])
+                    add_p = [1, ap.z2, ap.m2, ap.sh2, ap.m1, ap.sh1, ap.mo, ap.sho, ap.zo, ap.amin, ap.amax]
+                res_val = val[other[0]]
+                out_t = nxt.outputs[0]
+                i += 1
+            v = pb.value(H * Wd * Cout)
+            pb.op(pk.I8_PW, val[src], v, p=[H * Wd, Cin, Cout, z_o, a_lo, a_hi, *add_p], in1=res_val,
+                  t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                  name=f"t{out_t}", out_shape=(H, Wd, Cout), out_dtype="int8")
+            val[out_t], shape[out_t] = v, (H, Wd, Cout)
+            i += 1
+        elif op.name == "MEAN":
+            H, Wd, C = shape[src]
+            axes = sorted(int(a) % 4 for a in np.atleast_1d(g.const(op.inputs[1])))
+            _expect(axes == [1, 2], "MEAN over the spatial axes")
+            s_i, z_i = g.q(src)
+            s_o, z_o = g.q(op.outputs[0])
+            mu, sh = qz.mean_multiplier(s_i, s_o, H * Wd)
+            v = pb.value(C)
+            pb.op(pk.I8_MEAN, val[src], v, p=[H * Wd, C, z_i, mu, sh, z_o], name=f"t{op.outputs[0]}", out_shape=(C,), out_dtype="int8")
+            val[op.outputs[0]], shape[op.outputs[0]] = v, (C,)
+            i += 1
+        elif op.name == "FULLY_CONNECTED":
+            (Cin,) = shape[src]
+            s_i, z_i = g.q(src)
+            s_o, z_o = g.q(op.outputs[0])
+            wt_ = t[op.inputs[1]]
+            Cout = int(wt_.shape[0])
+            mu, sh = qz.channel_multipliers(s_i, wt_.scale, s_o, Cout)
+            a_lo, a_hi = qz.activation_bounds(op.options["activation"], s_o, z_o)
+            b = g.const(op.inputs[2]).astype(np.int64) if len(op.inputs) > 2 and op.inputs[2] >= 0 else np.zeros(Cout, np.int64)
+            b = b - z_i * wt_.data.astype(np.int64).sum(axis=1)
+            v = pb.value(Cout)
+            pb.op(pk.I8_FC, val[src], v, p=[Cin, Cout, z_o, a_lo, a_hi],
+                  t=[pb.tensor(wt_.data, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                  name=f"t{op.outputs[0]}", out_shape=(Cout,), out_dtype="int8")
+            val[op.outputs[0]], shape[op.outputs[0]] = v, (Cout,)
+            fc_out = op.outputs[0]
+            i += 1
+            # head: [LOGISTIC] -> DEQUANTIZE
+            s_fc, z_fc = g.q(fc_out)
+            lut_t, s_h, z_h, has = -1, s_fc, z_fc, 0
+            if i < len(ops) and ops[i].name == "LOGISTIC":
+                s_h, z_h = g.q(ops[i].outputs[0])
+                lut_t, has = pb.tensor(qz.logistic_table(s_fc, z_fc, s_h, z_h), np.int8), 1
+                last = ops[i].outputs[0]
+                i += 1
+            else:
+                last = fc_out
+            _expect(i < len(ops) and ops[i].name == "DEQUANTIZE" and ops[i].inputs[0] == last, "DEQUANTIZE must end the graph")
+            pb.op(pk.I8_HEAD, v, pk.SLOT_SCORES, p=[Cout, z_fc, z_h, has], f=[s_fc, s_h], t=[lut_t], name=f"t{ops[i].outputs[0]}",
+                  out_shape=(Cout,))
+            i += 1
+            _expect(i == len(ops), "operators after DEQUANTIZE")
+        else:
+            _expect(False, f"operator #{op.index} {op.name} in the backbone")
+    return pb.finalize(reuse=not keep_all)

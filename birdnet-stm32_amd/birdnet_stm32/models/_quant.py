@@ -1,0 +1,140 @@
+"""Host-side fixed-point helpers used while lowering an INT8 `.tflite` graph.
+
+At model-load time the lowering pass has to do what ``tf.lite.Interpreter.allocate_tensors``
+does in the reference (reference: birdnet_stm32/models/runners.py:62-68): turn every
+``(input_scale * weight_scale[c] / output_scale)`` into a Q31 multiplier and an exponent,
+compute fused-activation clamp ranges, and — specific to this implementation — collapse the
+frontend's element-wise PWL sub-graph (1x1 depthwise convolutions and ADDs on int8 tensors,
+SURVEY.md Appendix B ops #9-#19) into one 256-entry table per channel by evaluating those
+operators once for every possible int8 input.
+
+The arithmetic follows the public TFLite conventions (gemmlowp-style
+``SaturatingRoundingDoublingHighMul`` + ``RoundingDivideByPOT``); the device kernels in
+``csrc/bn_i8.hip`` implement the same functions for the per-sample work.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+_I32_MIN, _I32_MAX = -(2**31), 2**31 - 1
+
+
+def quantize_multiplier(real: float) -> tuple[int, int]:
+    """Split ``real`` into a Q31 mantissa in [2^30, 2^31) and a power-of-two exponent."""
+    if real == 0.0:
+        return 0, 0
+    mant, exp = math.frexp(real)
+    q = int(math.floor(abs(mant) * (1 << 31) + 0.5))  # halves away from zero; exact in double (< 2^32)
+    if mant < 0:
+        q = -q
+    if abs(q) == 1 << 31:
+        q //= 2
+        exp += 1
+    if exp < -31:
+        return 0, 0
+    if exp > 30:
+        return _I32_MAX, 30
+    return q, exp
+
+
+def channel_multipliers(s_in: float, w_scales, s_out: float, n: int) -> tuple[np.ndarray, np.ndarray]:
+    """Per-output-channel (multiplier, shift) int32 arrays; a single weight scale is broadcast."""
+    ws = np.asarray(w_scales, dtype=np.float32).reshape(-1)
+    if ws.size == 1:
+        ws = np.repeat(ws, n)
+    if ws.size != n:
+        raise ValueError(f"{ws.size} weight scales for {n} channels")
+    mult = np.empty(n, np.int32)
+    shift = np.empty(n, np.int32)
+    for c in range(n):
+        m, e = quantize_multiplier(float(np.float32(s_in)) * float(ws[c]) / float(np.float32(s_out)))
+        mult[c], shift[c] = m, e
+    return mult, shift
+
+
+def _c_round(x: float) -> int:
+    """C ``round``: nearest, halves away from zero."""
+    t = math.trunc(x)
+    if abs(x - t) >= 0.5:
+        t += 1 if x > 0 else -1
+    return int(t)
+
+
+def activation_bounds(act: str, scale: float, zero_point: int) -> tuple[int, int]:
+    """int8 clamp range of a fused activation (``CalculateActivationRangeQuantized``)."""
+    s = np.float32(scale)
+
+    def q(v: float) -> int:
+        return zero_point + _c_round(float(np.float32(v) / s))
+
+    if act == "none":
+        return -128, 127
+    if act == "relu":
+        return max(-128, q(0.0)), 127
+    if act == "relu6":
+        return max(-128, q(0.0)), min(127, q(6.0))
+    if act == "relu_n1_to_1":
+        return max(-128, q(-1.0)), min(127, q(1.0))
+    raise NotImplementedError(f"fused activation {act!r}")
+
+
+# -- vectorised integer ops for building tables ---------------------------------------------
+def _high_mul(a: np.ndarray, b) -> np.ndarray:
+    a = a.astype(np.int64)
+    prod = a * np.asarray(b, dtype=np.int64)
+    nudged = prod + np.where(prod >= 0, 1 << 30, 1 - (1 << 30))
+    out = np.where(nudged >= 0, nudged >> 31, -((-nudged) >> 31))  # truncating division by 2^31
+    return np.where((a == _I32_MIN) & (np.asarray(b) == _I32_MIN), _I32_MAX, out)
+
+
+def _round_shift(x: np.ndarray, exponent) -> np.ndarray:
+    e = np.asarray(exponent, dtype=np.int64)
+    mask = (np.int64(1) << e) - 1
+    rem = x & mask
+    return (x >> e) + (rem > ((mask >> 1) + (x < 0)))
+
+
+def requantize(acc: np.ndarray, mult, shift) -> np.ndarray:
+    """``MultiplyByQuantizedMultiplier`` applied element-wise (int64 holding int32 values)."""
+    sh = np.asarray(shift, dtype=np.int64)
+    left, right = np.maximum(sh, 0), np.maximum(-sh, 0)
+    return _round_shift(_high_mul(acc.astype(np.int64) << left, mult), right)
+
+
+class AddParams:
+    """Multipliers of one TFLite int8 ADD (left shift 20)."""
+
+    def __init__(self, s1: float, z1: int, s2: float, z2: int, so: float, zo: int, act: str):
+        s1, s2, so = float(np.float32(s1)), float(np.float32(s2)), float(np.float32(so))
+        twice_max = 2.0 * max(s1, s2)
+        self.z1, self.z2, self.zo = int(z1), int(z2), int(zo)
+        self.m1, self.sh1 = quantize_multiplier(s1 / twice_max)
+        self.m2, self.sh2 = quantize_multiplier(s2 / twice_max)
+        self.mo, self.sho = quantize_multiplier(twice_max / ((1 << 20) * so))
+        self.amin, self.amax = activation_bounds(act, so, zo)
+
+    def apply(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        sa = requantize((a.astype(np.int64) - self.z1) << 20, self.m1, self.sh1)
+        sb = requantize((b.astype(np.int64) - self.z2) << 20, self.m2, self.sh2)
+        return np.clip(requantize(sa + sb, self.mo, self.sho) + self.zo, self.amin, self.amax)
+
+
+def mean_multiplier(s_in: float, s_out: float, n: int) -> tuple[int, int]:
+    """Multiplier of the int8 MEAN with 1/n folded in the way TFLite's reduce kernel folds it."""
+    mult, shift = quantize_multiplier(float(np.float32(s_in)) / float(np.float32(s_out)))
+    fold = min(int(n).bit_length() - 1, 32, 31 + shift)
+    return int((mult << fold) // n), shift - fold
+
+
+def logistic_table(s_in: float, z_in: int, s_out: float, z_out: int) -> np.ndarray:
+    """int8 -> int8 sigmoid table indexed by ``q + 128`` (float32 evaluation, like LUTPopulate)."""
+    q = np.arange(-128, 128, dtype=np.int32)
+    x = np.float32(s_in) * (q - z_in).astype(np.float32)
+    y = (np.float32(1.0) / (np.float32(1.0) + np.exp(-x).astype(np.float32))).astype(np.float32)
+    r = (y / np.float32(s_out)).astype(np.float32)
+    t = np.trunc(r)
+    r = np.where(np.abs(r - t) >= 0.5, t + np.sign(r), t)
+    return np.clip(r.astype(np.int64) + z_out, -128, 127).astype(np.int8)

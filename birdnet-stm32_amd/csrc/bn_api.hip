@@ -1,0 +1,506 @@
+// bn_api.hip — the C ABI of libbirdnet_hip.so (include/birdnet_hip.h): context and model
+// lifetime, packed-blob parsing, workspace planning and the device-plan executor that turns one
+// bn_forward()/bn_infer_audio() call into a sequence of kernel launches on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/birdnet_hip.h"
+#include "bn_blob.h"
+#include "bn_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(BN_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kFft = 512;
+constexpr int kMaxGridBatch = 32768;  // chunks per launch group (gridDim.y/z limit is 65535)
+
+}  // namespace
+
+struct bn_ctx {
+    int device = 0;
+    int max_batch = 0;
+    float* d_window = nullptr;
+    float2* d_tw256 = nullptr;
+    float2* d_tw512 = nullptr;
+    bn::StftTables tables{};
+};
+
+struct bn_model {
+    bn_ctx* ctx = nullptr;
+    BlobHeader hdr{};
+    std::vector<OpRec> ops;
+    std::vector<TensorRec> tensors;
+    std::vector<SlotRec> slots;
+    char* d_consts = nullptr;            // one allocation, tensors at their blob offsets
+    size_t consts_base = 0;              // blob offset of the first payload byte
+    size_t consts_bytes = 0;
+    std::vector<char*> d_slots;          // max_batch * bytes_per_chunk each
+    float* d_spec = nullptr;             // [max_batch][F][W] for bn_infer_audio
+    float* d_minmax = nullptr;           // [max_batch][2]
+    float* d_smax = nullptr;             // [max_batch] per-sample maxima of the frontend
+    size_t workspace_bytes = 0;
+    // per-operator HIP-event timing (bn_profile_*): one (start, stop) pair per launch group
+    bool profiling = false;
+    struct EvRec {
+        int op;
+        hipEvent_t start, stop;
+    };
+    std::vector<EvRec> ev_used;
+    std::vector<hipEvent_t> ev_free;
+
+    hipEvent_t take_event() {
+        if (!ev_free.empty()) {
+            hipEvent_t e = ev_free.back();
+            ev_free.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+
+    const void* tensor(int id) const {
+        if (id < 0) return nullptr;
+        return d_consts + (tensors[id].offset - consts_base);
+    }
+};
+
+namespace {
+
+int check_device(bn_ctx* ctx) {
+    if (!ctx) return fail(BN_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return BN_OK;
+}
+
+// Brackets the launches of one plan operator with HIP events on the launch stream when profiling.
+struct ProfScope {
+    bn_model* m;
+    hipStream_t s;
+    hipEvent_t stop = nullptr;
+    ProfScope(bn_model* m_, int op, hipStream_t s_) : m(m_), s(s_) {
+        if (!m->profiling) return;
+        hipEvent_t start = m->take_event();
+        stop = m->take_event();
+        (void)hipEventRecord(start, s);
+        m->ev_used.push_back({op, start, stop});
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, s);
+    }
+};
+
+// Executes the plan for a batch slice.
+int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, float* d_scores, float* d_logits,
+             hipStream_t s) {
+    auto slot_ptr = [&](int id) -> char* {
+        if (id == BN_SLOT_INPUT) return (char*)d_input;
+        if (id == BN_SLOT_SCORES) return (char*)d_scores;
+        if (id == BN_SLOT_LOGITS) return (char*)d_logits;
+        if (id < 0 || id >= (int)m->d_slots.size()) return nullptr;
+        return m->d_slots[id];
+    };
+    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+        const OpRec& o = m->ops[oi];
+        const int* p = o.p;
+        ProfScope prof(m, (int)oi, s);
+        char* in0 = slot_ptr(o.in0);
+        char* in1 = slot_ptr(o.in1);
+        char* out = slot_ptr(o.out);
+        const float* mm = (o.in0 == BN_SLOT_INPUT) ? d_minmax : nullptr;
+        switch (o.kind) {
+            case BN_OP_F32_MEL: {
+                if (p[4]) bn::launch_u32_fill((uint32_t*)m->d_smax, 0u, B, s);
+                bn::launch_f32_mel((const float*)in0, mm, (float*)out, m->d_smax, B, p[0], p[1], p[2],
+                                   (const float*)m->tensor(o.t[0]), (const int*)m->tensor(o.t[1]),
+                                   (const float*)m->tensor(o.t[2]), p[3], p[4], s);
+                break;
+            }
+            case BN_OP_F32_MAG:
+                bn::launch_f32_mag((float*)out, m->d_smax, B, p[0], p[1], (const float*)m->tensor(o.t[2]), p[2], s);
+                break;
+            case BN_OP_F32_STEM:
+                bn::launch_f32_stem((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
+                                    p[8], p[9], (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
+                break;
+            case BN_OP_F32_DW:
+                bn::launch_f32_dw((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
+                                  p[8], p[9], (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
+                break;
+            case BN_OP_F32_PW:
+                bn::launch_f32_pw((const float*)in0, p[4] ? (const float*)in1 : nullptr,
+                                  p[5] ? (const float*)slot_ptr(p[6]) : nullptr, (float*)out, B, p[0], p[1], p[2], p[3],
+                                  (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
+                break;
+            case BN_OP_F32_SEGATE:
+                bn::launch_f32_segate((const float*)in0, (float*)out, B, p[0], p[1], p[2],
+                                      (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
+                break;
+            case BN_OP_F32_SCALE:
+                bn::launch_f32_scale((const float*)in0, (const float*)in1, (float*)out, B, p[0], p[1], s);
+                break;
+            case BN_OP_F32_GAP:
+                bn::launch_f32_gap((const float*)in0, (float*)out, B, p[0], p[1], s);
+                break;
+            case BN_OP_F32_ATTNPOOL:
+                bn::launch_f32_attnpool((const float*)in0, (float*)out, B, p[0], p[1], (const float*)m->tensor(o.t[0]),
+                                        s);
+                break;
+            case BN_OP_F32_DENSE:
+                bn::launch_f32_dense((const float*)in0, (float*)out, d_logits, B, p[0], p[1], p[2],
+                                     (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
+                break;
+            case BN_OP_I8_QUANT:
+                bn::launch_i8_quant((const float*)in0, mm, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], o.f[0], s);
+                break;
+            case BN_OP_I8_MEL:
+                bn::launch_i8_mel((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5],
+                                  (const int8_t*)m->tensor(o.t[0]), (const int32_t*)m->tensor(o.t[1]),
+                                  (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]),
+                                  p[6] ? (const int8_t*)m->tensor(o.t[4]) : nullptr, s);
+                break;
+            case BN_OP_I8_STEM:
+            case BN_OP_I8_DW: {
+                bn::I8ConvGeom g{p[0], p[1], p[2], p[3], p[4], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13]};
+                auto fn = o.kind == BN_OP_I8_STEM ? bn::launch_i8_stem : bn::launch_i8_dw;
+                fn((const int8_t*)in0, (int8_t*)out, B, g, (const int8_t*)m->tensor(o.t[0]),
+                   (const int32_t*)m->tensor(o.t[1]), (const int32_t*)m->tensor(o.t[2]),
+                   (const int32_t*)m->tensor(o.t[3]), s);
+                break;
+            }
+            case BN_OP_I8_PW: {
+                bn::I8AddParams add{p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15], p[16]};
+                bn::launch_i8_pw((const int8_t*)in0, (const int8_t*)in1, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4],
+                                 p[5], add, (const int8_t*)m->tensor(o.t[0]), (const int32_t*)m->tensor(o.t[1]),
+                                 (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]), s);
+                break;
+            }
+            case BN_OP_I8_MEAN:
+                bn::launch_i8_mean((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], s);
+                break;
+            case BN_OP_I8_FC:
+                bn::launch_i8_fc((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4],
+                                 (const int8_t*)m->tensor(o.t[0]), (const int32_t*)m->tensor(o.t[1]),
+                                 (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]), s);
+                break;
+            case BN_OP_I8_HEAD:
+                bn::launch_i8_head((const int8_t*)in0, d_scores, d_logits, B, p[0], p[1], p[2], o.f[0], o.f[1],
+                                   p[3] ? (const int8_t*)m->tensor(o.t[0]) : nullptr, s);
+                break;
+            default:
+                return fail(BN_ERR_UNSUPPORTED, "plan operator %zu has unknown kind %d", oi, o.kind);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bn_version(void) { return BN_ABI_VERSION; }
+
+const char* bn_last_error(void) { return g_err.c_str(); }
+
+int bn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
+    if (!out) return fail(BN_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (max_batch <= 0) return fail(BN_ERR_ARG, "max_batch must be positive, got %d", max_batch);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(BN_ERR_DEVICE, "no HIP device is visible; libbirdnet_hip has no CPU fallback");
+    if (device < 0 || device >= n) return fail(BN_ERR_ARG, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BN_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+
+    bn_ctx* c = new bn_ctx();
+    c->device = device;
+    c->max_batch = max_batch;
+    // STFT tables in double, rounded once to float32
+    std::vector<float> win(kFft);
+    std::vector<float2> t256(256), t512(257);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int i = 0; i < kFft; ++i) win[i] = (float)(0.5 - 0.5 * cos(two_pi * i / kFft));
+    for (int i = 0; i < 256; ++i) t256[i] = make_float2((float)cos(two_pi * i / 256.0), (float)-sin(two_pi * i / 256.0));
+    for (int i = 0; i < 257; ++i) t512[i] = make_float2((float)cos(two_pi * i / 512.0), (float)-sin(two_pi * i / 512.0));
+    HIP_TRY(hipMalloc(&c->d_window, win.size() * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->d_tw256, t256.size() * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->d_tw512, t512.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(c->d_window, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tw256, t256.data(), t256.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tw512, t512.data(), t512.size() * sizeof(float2), hipMemcpyHostToDevice));
+    c->tables = bn::StftTables{c->d_window, c->d_tw256, c->d_tw512};
+    *out = c;
+    return BN_OK;
+}
+
+void bn_ctx_destroy(bn_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_window);
+    (void)hipFree(c->d_tw256);
+    (void)hipFree(c->d_tw512);
+    delete c;
+}
+
+int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) {
+    if (!out) return fail(BN_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (int rc = check_device(ctx)) return rc;
+    if (!blob || nbytes < sizeof(BlobHeader)) return fail(BN_ERR_FORMAT, "blob too small (%zu bytes)", nbytes);
+    const char* base = (const char*)blob;
+    BlobHeader h;
+    memcpy(&h, base, sizeof h);
+    if (memcmp(h.magic, BN_BLOB_MAGIC, 8) != 0) return fail(BN_ERR_FORMAT, "bad blob magic");
+    if (h.version != BN_BLOB_VERSION)
+        return fail(BN_ERR_FORMAT, "blob version %u, library expects %u", h.version, BN_BLOB_VERSION);
+    auto in_range = [&](uint64_t off, uint64_t len) { return off <= nbytes && len <= nbytes - off; };
+    if (!in_range(h.slots_off, (uint64_t)h.n_slots * sizeof(SlotRec)) ||
+        !in_range(h.tensors_off, (uint64_t)h.n_tensors * sizeof(TensorRec)) ||
+        !in_range(h.ops_off, (uint64_t)h.n_ops * sizeof(OpRec)))
+        return fail(BN_ERR_FORMAT, "blob tables exceed the blob size");
+
+    bn_model* m = new bn_model();
+    m->ctx = ctx;
+    m->hdr = h;
+    m->slots.resize(h.n_slots);
+    m->tensors.resize(h.n_tensors);
+    m->ops.resize(h.n_ops);
+    if (h.n_slots) memcpy(m->slots.data(), base + h.slots_off, h.n_slots * sizeof(SlotRec));
+    if (h.n_tensors) memcpy(m->tensors.data(), base + h.tensors_off, h.n_tensors * sizeof(TensorRec));
+    if (h.n_ops) memcpy(m->ops.data(), base + h.ops_off, h.n_ops * sizeof(OpRec));
+
+    size_t lo = nbytes, hi = 0;
+    for (const TensorRec& t : m->tensors) {
+        if (!in_range(t.offset, t.nbytes) || (t.offset & 255)) {
+            delete m;
+            return fail(BN_ERR_FORMAT, "tensor payload out of range or misaligned");
+        }
+        if (t.nbytes) {
+            lo = t.offset < lo ? (size_t)t.offset : lo;
+            hi = t.offset + t.nbytes > hi ? (size_t)(t.offset + t.nbytes) : hi;
+        }
+    }
+    for (const OpRec& o : m->ops) {
+        for (int k = 0; k < BN_OP_NT; ++k)
+            if (o.t[k] >= (int)h.n_tensors) {
+                delete m;
+                return fail(BN_ERR_FORMAT, "operator references tensor %d of %u", o.t[k], h.n_tensors);
+            }
+        const int ids[3] = {o.in0, o.in1, o.out};
+        for (int id : ids)
+            if (id >= (int)h.n_slots) {
+                delete m;
+                return fail(BN_ERR_FORMAT, "operator references slot %d of %u", id, h.n_slots);
+            }
+    }
+    auto cleanup_fail = [&](int code) {
+        bn_model_free(m);
+        return code;
+    };
+    if (hi > lo) {
+        m->consts_base = lo;
+        m->consts_bytes = hi - lo;
+        if (hipMalloc(&m->d_consts, m->consts_bytes) != hipSuccess)
+            return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu constant bytes failed", m->consts_bytes));
+        if (hipMemcpy(m->d_consts, base + lo, m->consts_bytes, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup_fail(fail(BN_ERR_DEVICE, "copying constants to the device failed"));
+    }
+    const size_t mb = (size_t)ctx->max_batch;
+    m->d_slots.assign(h.n_slots, nullptr);
+    for (uint32_t i = 0; i < h.n_slots; ++i) {
+        const size_t bytes = mb * m->slots[i].bytes_per_chunk;
+        if (bytes == 0) continue;
+        if (hipMalloc(&m->d_slots[i], bytes) != hipSuccess)
+            return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu workspace bytes (slot %u) failed", bytes, i));
+        m->workspace_bytes += bytes;
+    }
+    if (h.input_kind == BN_INPUT_SPECTROGRAM) {
+        const size_t bytes = mb * h.input_elems * sizeof(float);
+        if (hipMalloc(&m->d_spec, bytes) != hipSuccess)
+            return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu spectrogram workspace bytes failed", bytes));
+        m->workspace_bytes += bytes;
+    }
+    if (hipMalloc(&m->d_minmax, mb * 2 * sizeof(float)) != hipSuccess ||
+        hipMalloc(&m->d_smax, mb * sizeof(float)) != hipSuccess)
+        return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of reduction scratch failed"));
+    m->workspace_bytes += mb * 3 * sizeof(float);
+    *out = m;
+    return BN_OK;
+}
+
+void bn_model_free(bn_model* m) {
+    if (!m) return;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    (void)hipFree(m->d_consts);
+    for (char* p : m->d_slots) (void)hipFree(p);
+    (void)hipFree(m->d_spec);
+    (void)hipFree(m->d_minmax);
+    (void)hipFree(m->d_smax);
+    for (auto& r : m->ev_used) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    for (hipEvent_t e : m->ev_free) (void)hipEventDestroy(e);
+    delete m;
+}
+
+int bn_model_get_info(const bn_model* m, bn_model_info* out) {
+    if (!m || !out) return fail(BN_ERR_ARG, "null argument");
+    out->dtype = (int32_t)m->hdr.dtype;
+    out->input_kind = (int32_t)m->hdr.input_kind;
+    out->input_elems = (int32_t)m->hdr.input_elems;
+    out->fft_bins = (int32_t)m->hdr.fft_bins;
+    out->spec_width = (int32_t)m->hdr.spec_width;
+    out->num_classes = (int32_t)m->hdr.num_classes;
+    out->n_ops = (int32_t)m->hdr.n_ops;
+    out->max_batch = m->ctx->max_batch;
+    out->workspace_bytes = (int64_t)m->workspace_bytes;
+    out->const_bytes = (int64_t)m->consts_bytes;
+    return BN_OK;
+}
+
+int bn_stft_mag(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize,
+                float* d_spec, float* d_minmax, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (!d_audio || !d_spec || !d_minmax) return fail(BN_ERR_ARG, "null device pointer");
+    if (n_fft != kFft) return fail(BN_ERR_UNSUPPORTED, "n_fft=%d: only 512 is implemented", n_fft);
+    if (B < 0 || T <= 0 || W <= 0 || hop <= 0) return fail(BN_ERR_ARG, "bad shape B=%d T=%d hop=%d W=%d", B, T, hop, W);
+    if (1 + T / hop < W)
+        return fail(BN_ERR_ARG, "T=%d hop=%d gives %d frames, fewer than spec_width=%d", T, hop, 1 + T / hop, W);
+    if (B == 0) return BN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per_chunk = (size_t)(kFft / 2 + 1) * W;
+    for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
+        const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+        bn::launch_minmax_init(d_minmax + 2 * (size_t)b0, nb, s);
+        bn::launch_stft512(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, d_spec + b0 * per_chunk,
+                           d_minmax + 2 * (size_t)b0, s);
+        if (normalize)
+            bn::launch_spec_normalize(d_spec + b0 * per_chunk, d_minmax + 2 * (size_t)b0, nb, (int)per_chunk, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
+int bn_forward(bn_model* m, const float* d_input, const float* d_minmax, int B, float* d_scores, float* d_logits,
+               void* stream) {
+    if (!m) return fail(BN_ERR_ARG, "null model");
+    if (int rc = check_device(m->ctx)) return rc;
+    if (!d_input || !d_scores) return fail(BN_ERR_ARG, "null device pointer");
+    if (B < 0 || B > m->ctx->max_batch)
+        return fail(BN_ERR_ARG, "batch %d exceeds the context's max_batch %d", B, m->ctx->max_batch);
+    if (B == 0) return BN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t in_stride = m->hdr.input_elems, C = m->hdr.num_classes;
+    for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
+        const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+        if (int rc = run_plan(m, d_input + b0 * in_stride, d_minmax ? d_minmax + 2 * (size_t)b0 : nullptr, nb,
+                              d_scores + b0 * C, d_logits ? d_logits + b0 * C : nullptr, s))
+            return rc;
+    }
+    return BN_OK;
+}
+
+int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, float* d_scores, float* d_logits,
+                   void* stream) {
+    if (!m) return fail(BN_ERR_ARG, "null model");
+    if (m->hdr.input_kind != BN_INPUT_SPECTROGRAM)
+        return fail(BN_ERR_UNSUPPORTED, "bn_infer_audio needs a hybrid-frontend model; feed waveforms to bn_forward");
+    if (B < 0 || B > m->ctx->max_batch)
+        return fail(BN_ERR_ARG, "batch %d exceeds the context's max_batch %d", B, m->ctx->max_batch);
+    const int F = (int)m->hdr.fft_bins, W = (int)m->hdr.spec_width;
+    if (F != kFft / 2 + 1) return fail(BN_ERR_UNSUPPORTED, "model expects %d frequency bins; the STFT kernel gives 257", F);
+    // un-normalised magnitudes + per-chunk min/max; the plan's first operator normalises while loading
+    {
+        ProfScope prof(m, (int)m->ops.size(), (hipStream_t)stream);
+        if (int rc = bn_stft_mag(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream))
+            return rc;
+    }
+    return bn_forward(m, m->d_spec, m->d_minmax, B, d_scores, d_logits, stream);
+}
+
+int bn_debug_op_output(bn_model* m, int op_index, int B, void* d_dst, size_t dst_bytes, size_t* bytes_per_chunk,
+                       void* stream) {
+    if (!m) return fail(BN_ERR_ARG, "null model");
+    if (op_index < 0 || op_index >= (int)m->ops.size()) return fail(BN_ERR_ARG, "op_index %d out of range", op_index);
+    const int sid = m->ops[op_index].out;
+    if (sid < 0) return fail(BN_ERR_ARG, "operator %d writes a caller buffer, not a workspace slot", op_index);
+    const size_t per = m->slots[sid].bytes_per_chunk;
+    if (bytes_per_chunk) *bytes_per_chunk = per;
+    if (!d_dst) return BN_OK;
+    if (B < 0 || B > m->ctx->max_batch || dst_bytes < per * (size_t)B) return fail(BN_ERR_ARG, "destination too small");
+    if (int rc = check_device(m->ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, m->d_slots[sid], per * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BN_OK;
+}
+
+int bn_profile_enable(bn_model* m, int enable) {
+    if (!m) return fail(BN_ERR_ARG, "null model");
+    m->profiling = enable != 0;
+    return BN_OK;
+}
+
+int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) {
+    if (!m || !total_ms || !launches) return fail(BN_ERR_ARG, "null argument");
+    if (n < (int)m->ops.size() + 1) return fail(BN_ERR_ARG, "need room for n_ops + 1 entries");
+    if (int rc = check_device(m->ctx)) return rc;
+    for (int i = 0; i < n; ++i) {
+        total_ms[i] = 0.0;
+        launches[i] = 0;
+    }
+    for (auto& r : m->ev_used) {
+        HIP_TRY(hipEventSynchronize(r.stop));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+        total_ms[r.op] += ms;
+        launches[r.op] += 1;
+        m->ev_free.push_back(r.start);
+        m->ev_free.push_back(r.stop);
+    }
+    m->ev_used.clear();
+    return BN_OK;
+}
+
+const char* bn_kernel_names(void) {
+    return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_mag_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
+           "f32_pw_kernel\nf32_gap_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
+           "i8_head_kernel";
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// bn_blob.h — layout of the packed model blob handed to bn_model_load().
+//
+// Written by birdnet_stm32/models/_pack.py (which mirrors every constant below) from a
+// .keras archive (float32 plan) or a .tflite flatbuffer (INT8 plan).  All integers are
+// little-endian; every tensor payload starts on a 256-byte boundary.
+//
+//   BlobHeader | SlotRec[n_slots] | TensorRec[n_tensors] | OpRec[n_ops] | payloads
+//
+// A "slot" is an activation buffer; its size is given per chunk and the library allocates
+// max_batch times that.  Operators address slots by id; BN_SLOT_INPUT is the caller's input
+// tensor, BN_SLOT_SCORES / BN_SLOT_LOGITS the caller's output tensors.
+#pragma once
+#include <stdint.h>
+
+#define BN_BLOB_MAGIC "BNHIPM01"
+#define BN_BLOB_VERSION 2u
+
+#define BN_SLOT_INPUT (-1)
+#define BN_SLOT_SCORES (-2)
+#define BN_SLOT_LOGITS (-3)
+#define BN_SLOT_NONE (-9)
+
+struct BlobHeader {
+    char magic[8];
+    uint32_t version;
+    uint32_t dtype;        // BN_DTYPE_*
+    uint32_t input_kind;   // BN_INPUT_*
+    uint32_t input_elems;  // float32 elements per chunk at the runner boundary
+    uint32_t fft_bins;
+    uint32_t spec_width;
+    uint32_t num_classes;
+    uint32_t n_slots;
+    uint32_t n_tensors;
+    uint32_t n_ops;
+    uint32_t slots_off;
+    uint32_t tensors_off;
+    uint32_t ops_off;
+    uint32_t reserved;
+};
+static_assert(sizeof(BlobHeader) == 64, "BlobHeader must be 64 bytes");
+
+struct SlotRec {
+    uint64_t bytes_per_chunk;
+};
+
+struct TensorRec {
+    uint64_t offset;  // from the start of the blob, multiple of 256
+    uint64_t nbytes;
+};
+
+#define BN_OP_NP 24
+#define BN_OP_NT 8
+#define BN_OP_NF 8
+
+struct OpRec {
+    int32_t kind;
+    int32_t in0;   // slot id
+    int32_t in1;   // slot id (residual / gate) or BN_SLOT_NONE
+    int32_t out;   // slot id
+    int32_t p[BN_OP_NP];
+    int32_t t[BN_OP_NT];  // tensor ids, -1 = absent
+    float f[BN_OP_NF];
+};
+static_assert(sizeof(OpRec) == 16 + 4 * BN_OP_NP + 4 * BN_OP_NT + 4 * BN_OP_NF, "OpRec packing");
+
+// ---------------------------------------------------------------------------------------
+// Operator kinds.  Activations are NHWC per chunk (C innermost); P = H*W positions.
+// act codes: 0 none, 1 relu, 2 relu6.   mag codes: 0 none, 1 pwl, 2 pcen, 3 db.
+// ---------------------------------------------------------------------------------------
+enum BnOpKind : int32_t {
+    // ---- float32 plan --------------------------------------------------------------
+    // spec [F][W] -> mel [M][W]   p: F W M mag norm   t: wvals(f32) bands(i32 [3][M]: start,len,off) magp(f32 [NP][M])
+    BN_OP_F32_MEL = 1,
+    // in place [M][W]: x/(max+1e-6) then magnitude scaling   p: M W mag   t: - - magp
+    BN_OP_F32_MAG = 2,
+    // wave [T] -> [M][W]  p: T W M stride pad_left mag   t: fb(f32 [16][M] BN-folded) bias magp
+    BN_OP_F32_RAWFE = 3,
+    // [H][W] (C=1) -> [OH][OW][Cout]  p: H W Cout sh sw act OH OW pad_top pad_left   t: w[3][3][Cout] bias[Cout]
+    BN_OP_F32_STEM = 4,
+    // [H][W][C] -> [OH][OW][C]        p: H W C sh sw act OH OW pad_top pad_left      t: w[3][3][C] bias[C]
+    BN_OP_F32_DW = 5,
+    // [P][Cin] -> [P][Cout]  p: P Cin Cout act has_res has_gate   in1: residual slot, p6: gate slot   t: w[Cin][Cout] bias
+    BN_OP_F32_PW = 6,
+    // [P][C] -> gate [C]  p: P C Cr   t: w1[C][Cr] w2[Cr][C]
+    BN_OP_F32_SEGATE = 7,
+    // [P][C] * gate(in1)[C] -> [P][C]  p: P C
+    BN_OP_F32_SCALE = 8,
+    // [P][C] -> [C]   p: P C
+    BN_OP_F32_GAP = 9,
+    // [Cin] -> scores [Cout] (+ logits)  p: Cin Cout act(0 linear,1 sigmoid,2 softmax)   t: w[Cin][Cout] bias
+    BN_OP_F32_DENSE = 10,
+    // [P][C] -> [C]  p: P C   t: score[C]
+    BN_OP_F32_ATTNPOOL = 11,
+
+    // ---- INT8 plan -----------------------------------------------------------------
+    // spec f32 [F][W] -> q int8 [W][Kp]   p: F W Kp zp fill   f: scale
+    BN_OP_I8_QUANT = 20,
+    // [W][Kp] -> [M][W]  p: W Kp M zp_out act_min act_max has_lut   t: w[M][Kp] bias(zp-folded) mult shift lut[M][256]
+    BN_OP_I8_MEL = 21,
+    // [H][W] -> [OH][OW][Cout]  p: H W Cout sh sw - OH OW pad_top pad_left zp_in zp_out act_min act_max   t: w[3][3][Cout] bias mult shift
+    BN_OP_I8_STEM = 22,
+    // [H][W][C] -> [OH][OW][C]  p: as STEM with C                                     t: w[3][3][C] bias mult shift
+    BN_OP_I8_DW = 23,
+    // [P][Cin] -> [P][Cout]  p: P Cin Cout zp_out act_min act_max has_add | z1 m1 s1 m2 s2 mo so zo amin amax   t: w[Cout][Cin] bias(zp-folded) mult shift
+    BN_OP_I8_PW = 24,
+    // [P][C] -> [C]  p: P C zp_in mult shift zp_out
+    BN_OP_I8_MEAN = 25,
+    // [Cin] -> [Cout]  p: Cin Cout zp_out act_min act_max   t: w[Cout][Cin] bias(zp-folded) mult shift
+    BN_OP_I8_FC = 26,
+    // [C] int8 -> scores f32 (+ logits f32)  p: C zp_fc zp_out has_lut   f: s_fc s_out   t: lut[256]
+    BN_OP_I8_HEAD = 27,
+};

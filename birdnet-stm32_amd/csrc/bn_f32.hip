@@ -1,0 +1,381 @@
+// bn_f32.hip — float32 DS-CNN kernels for gfx950 (baseline generation: one thread per small
+// output vector, float4 channel vectors, weights served from L1/L2).
+//
+// Graph semantics follow the reference's Keras layers with BatchNorm folded into the
+// preceding convolution by the packer:
+//   hybrid frontend  birdnet_stm32/models/frontend.py:299-345, magnitude.py:166-192
+//   stem / ds block  birdnet_stm32/models/dscnn.py:28-84,198-202
+//   inverted residual + squeeze-excite  birdnet_stm32/models/blocks.py:27-133
+//   head             birdnet_stm32/models/dscnn.py:248-261
+// Layout: NHWC per chunk, C innermost.  TensorFlow SAME padding (pad_top/pad_left come from the
+// packer; the odd cell is after).
+#include "bn_kernels.h"
+
+namespace bn {
+namespace {
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return fminf(fmaxf(v, 0.0f), 6.0f);
+    return v;
+}
+
+// channel-wise magnitude scaling (reference: magnitude.py:166-192); magp is [NP][M]
+__device__ __forceinline__ float mag_scale(float y, int m, int M, const float* __restrict__ magp, int mag) {
+    if (mag == 1) {  // pwl: k0 y + sum_i k_i relu(w_i y + b_i); rows: k0, k1..3, w1..3, b1..3
+        float out = y * magp[m];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            out += magp[(1 + i) * M + m] * fmaxf(magp[(4 + i) * M + m] * y + magp[(7 + i) * M + m], 0.0f);
+        return out;
+    }
+    if (mag == 2) {  // pcen-like: rows agc, k1, sw, sb, k2
+        const float y0 = fmaxf(y - magp[m] * y, 0.0f);
+        const float b1 = magp[M + m] * y0;
+        const float b2 = magp[4 * M + m] * fmaxf(magp[2 * M + m] * y0 + magp[3 * M + m], 0.0f);
+        return fmaxf(b1 + b2, 0.0f);
+    }
+    if (mag == 3) return 10.0f * logf(fmaxf(y, 1e-6f)) / logf(10.0f);
+    return y;
+}
+
+__global__ void u32_fill_kernel(uint32_t* p, uint32_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// spec [F][W] -> relu(mel) [M][W].  Each mel row is a band [start, start+len) of frequency bins
+// (the Slaney triangles touch a few bins each; a dense mixer is just len = F).
+// One thread per frame t, blockIdx.y = mel bin, blockIdx.z = chunk.
+__global__ void f32_mel_kernel(const float* __restrict__ spec, const float* __restrict__ minmax, float* __restrict__ out,
+                               float* smax, int F, int W, int M, const float* __restrict__ wvals,
+                               const int* __restrict__ bands, const float* __restrict__ magp, int mag, int norm) {
+    const int b = blockIdx.z, m = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int start = bands[m], len = bands[M + m], off = bands[2 * M + m];
+    const float* S = spec + (size_t)b * F * W;
+    float mn = 0.0f, rng = 1.0f;
+    const bool renorm = minmax != nullptr;
+    if (renorm) {
+        mn = minmax[2 * b];
+        rng = (float)((double)(minmax[2 * b + 1] - mn) + 1e-10);
+    }
+    float acc = 0.0f;
+    if (t < W) {
+        for (int i = 0; i < len; ++i) {
+            float v = S[(size_t)(start + i) * W + t];
+            if (renorm) v = (v - mn) / rng;
+            acc = fmaf(v, wvals[off + i], acc);
+        }
+    }
+    acc = fmaxf(acc, 0.0f);
+    if (!norm) {
+        if (t < W) out[((size_t)b * M + m) * W + t] = mag_scale(acc, m, M, magp, mag);
+        return;
+    }
+    if (t < W) out[((size_t)b * M + m) * W + t] = acc;
+    float v = (t < W) ? acc : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(smax + b), __float_as_uint(v));
+}
+
+// per-sample max normalisation y / (max + 1e-6) followed by magnitude scaling, in place on [M][W]
+__global__ void f32_mag_kernel(float* x, const float* __restrict__ smax, int M, int W, const float* __restrict__ magp,
+                               int mag) {
+    const int b = blockIdx.y;
+    const float inv_d = smax[b] + 1e-6f;
+    float* p = x + (size_t)b * M * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * W; i += gridDim.x * blockDim.x) {
+        const int m = i / W;
+        p[i] = mag_scale(p[i] / inv_d, m, M, magp, mag);
+    }
+}
+
+// stem: [H][W] (one channel) -> [OH][OW][Cout], 3x3.  One thread = 4 output channels of one pixel.
+__global__ void f32_stem_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Cout, int sh,
+                                int sw, int act, int OH, int OW, int pt, int pl, const float* __restrict__ w,
+                                const float* __restrict__ bias, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c4 = Cout >> 2;
+    const int cg = (int)(gid % c4);
+    long r = gid / c4;
+    const int ow = (int)(r % OW);
+    r /= OW;
+    const int oh = (int)(r % OH);
+    const long b = r / OH;
+    const float* xin = x + b * H * W;
+    float4 acc = *reinterpret_cast<const float4*>(bias + 4 * cg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ih = oh * sh + i - pt;
+        if (ih < 0 || ih >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int iw = ow * sw + j - pl;
+            if (iw < 0 || iw >= W) continue;
+            const float v = xin[ih * W + iw];
+            const float4 k = *reinterpret_cast<const float4*>(w + (i * 3 + j) * Cout + 4 * cg);
+            acc.x = fmaf(v, k.x, acc.x);
+            acc.y = fmaf(v, k.y, acc.y);
+            acc.z = fmaf(v, k.z, acc.z);
+            acc.w = fmaf(v, k.w, acc.w);
+        }
+    }
+    acc.x = apply_act(acc.x, act);
+    acc.y = apply_act(acc.y, act);
+    acc.z = apply_act(acc.z, act);
+    acc.w = apply_act(acc.w, act);
+    *reinterpret_cast<float4*>(y + ((b * OH + oh) * OW + ow) * Cout + 4 * cg) = acc;
+}
+
+// depthwise 3x3: [H][W][C] -> [OH][OW][C].  One thread = 4 channels of one output pixel.
+__global__ void f32_dw_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int sh, int sw,
+                              int act, int OH, int OW, int pt, int pl, const float* __restrict__ w,
+                              const float* __restrict__ bias, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c4 = C >> 2;
+    const int cg = (int)(gid % c4);
+    long r = gid / c4;
+    const int ow = (int)(r % OW);
+    r /= OW;
+    const int oh = (int)(r % OH);
+    const long b = r / OH;
+    const float* xin = x + b * H * W * C;
+    float4 acc = *reinterpret_cast<const float4*>(bias + 4 * cg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ih = oh * sh + i - pt;
+        if (ih < 0 || ih >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int iw = ow * sw + j - pl;
+            if (iw < 0 || iw >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(xin + ((long)ih * W + iw) * C + 4 * cg);
+            const float4 k = *reinterpret_cast<const float4*>(w + (i * 3 + j) * C + 4 * cg);
+            acc.x = fmaf(v.x, k.x, acc.x);
+            acc.y = fmaf(v.y, k.y, acc.y);
+            acc.z = fmaf(v.z, k.z, acc.z);
+            acc.w = fmaf(v.w, k.w, acc.w);
+        }
+    }
+    acc.x = apply_act(acc.x, act);
+    acc.y = apply_act(acc.y, act);
+    acc.z = apply_act(acc.z, act);
+    acc.w = apply_act(acc.w, act);
+    *reinterpret_cast<float4*>(y + ((b * OH + oh) * OW + ow) * C + 4 * cg) = acc;
+}
+
+// pointwise 1x1: [P][Cin] -> [P][Cout] (+gate on the input channels, +residual, activation).
+// One thread = 4 output channels of one position; rows = B*P.
+__global__ void f32_pw_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gate,
+                              float* __restrict__ y, int P, int Cin, int Cout, int act, const float* __restrict__ w,
+                              const float* __restrict__ bias, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int n4 = Cout >> 2;
+    const int ng = (int)(gid % n4);
+    const long row = gid / n4;
+    const float* xr = x + row * Cin;
+    const float* g = gate ? gate + (row / P) * Cin : nullptr;
+    float4 acc = *reinterpret_cast<const float4*>(bias + 4 * ng);
+    for (int k = 0; k < Cin; k += 4) {
+        float4 v = *reinterpret_cast<const float4*>(xr + k);
+        if (g) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + k);
+            v.x *= gg.x;
+            v.y *= gg.y;
+            v.z *= gg.z;
+            v.w *= gg.w;
+        }
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float4 kk = *reinterpret_cast<const float4*>(w + (long)(k + e) * Cout + 4 * ng);
+            acc.x = fmaf(vv[e], kk.x, acc.x);
+            acc.y = fmaf(vv[e], kk.y, acc.y);
+            acc.z = fmaf(vv[e], kk.z, acc.z);
+            acc.w = fmaf(vv[e], kk.w, acc.w);
+        }
+    }
+    if (res) {
+        const float4 rr = *reinterpret_cast<const float4*>(res + row * Cout + 4 * ng);
+        acc.x += rr.x;
+        acc.y += rr.y;
+        acc.z += rr.z;
+        acc.w += rr.w;
+    }
+    acc.x = apply_act(acc.x, act);
+    acc.y = apply_act(acc.y, act);
+    acc.z = apply_act(acc.z, act);
+    acc.w = apply_act(acc.w, act);
+    *reinterpret_cast<float4*>(y + row * Cout + 4 * ng) = acc;
+}
+
+// global average pool [P][C] -> [C]; blockIdx.x = chunk, thread = channel
+__global__ void f32_gap_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int C) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float* p = x + (size_t)b * P * C + c;
+        float s = 0.0f;
+        for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
+        y[(size_t)b * C + c] = s / (float)P;
+    }
+}
+
+// squeeze-excite gate: mean over positions -> Dense(Cr, relu) -> Dense(C, sigmoid); one block per chunk
+__global__ void f32_segate_kernel(const float* __restrict__ x, float* __restrict__ gate, int P, int C, int Cr,
+                                  const float* __restrict__ w1, const float* __restrict__ w2) {
+    extern __shared__ float sm[];  // [C] means, [Cr] hidden
+    float* mean = sm;
+    float* hid = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float* p = x + (size_t)b * P * C + c;
+        float s = 0.0f;
+        for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
+        mean[c] = s / (float)P;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < Cr; r += blockDim.x) {
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s = fmaf(mean[c], w1[c * Cr + r], s);
+        hid[r] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.0f;
+        for (int r = 0; r < Cr; ++r) s = fmaf(hid[r], w2[r * C + c], s);
+        gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
+    }
+}
+
+__global__ void f32_scale_kernel(const float* __restrict__ x, const float* __restrict__ gate, float* __restrict__ y,
+                                 int P, int C, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % C);
+    const long b = gid / ((long)P * C);
+    y[gid] = x[gid] * gate[b * C + c];
+}
+
+// attention pooling over positions (reference: blocks.py:136-159); one block per chunk
+__global__ void f32_attnpool_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int C,
+                                    const float* __restrict__ score) {
+    extern __shared__ float sm[];  // [P] attention weights
+    const int b = blockIdx.x;
+    const float* xb = x + (size_t)b * P * C;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s = fmaf(xb[(size_t)p * C + c], score[c], s);
+        sm[p] = s;
+    }
+    __syncthreads();
+    float mx = -3.4e38f;
+    for (int p = 0; p < P; ++p) mx = fmaxf(mx, sm[p]);
+    float den = 0.0f;
+    for (int p = 0; p < P; ++p) den += expf(sm[p] - mx);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.0f;
+        for (int p = 0; p < P; ++p) s = fmaf(xb[(size_t)p * C + c], expf(sm[p] - mx) / den, s);
+        y[(size_t)b * C + c] = s;
+    }
+}
+
+// classifier head: Dense + sigmoid / softmax; one block per chunk
+__global__ void f32_dense_kernel(const float* __restrict__ x, float* __restrict__ scores, float* __restrict__ logits,
+                                 int Cin, int Cout, int act, const float* __restrict__ w,
+                                 const float* __restrict__ bias) {
+    extern __shared__ float sm[];  // [Cin] input, [Cout] logits
+    float* xin = sm;
+    float* z = sm + Cin;
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < Cin; k += blockDim.x) xin[k] = x[(size_t)b * Cin + k];
+    __syncthreads();
+    for (int n = threadIdx.x; n < Cout; n += blockDim.x) {
+        float s = bias ? bias[n] : 0.0f;
+        for (int k = 0; k < Cin; ++k) s = fmaf(xin[k], w[(size_t)k * Cout + n], s);
+        z[n] = s;
+        if (logits) logits[(size_t)b * Cout + n] = s;
+    }
+    __syncthreads();
+    if (act == 2) {
+        float mx = -3.4e38f;
+        for (int n = 0; n < Cout; ++n) mx = fmaxf(mx, z[n]);
+        float den = 0.0f;
+        for (int n = 0; n < Cout; ++n) den += expf(z[n] - mx);
+        for (int n = threadIdx.x; n < Cout; n += blockDim.x) scores[(size_t)b * Cout + n] = expf(z[n] - mx) / den;
+    } else {
+        for (int n = threadIdx.x; n < Cout; n += blockDim.x) {
+            const float v = z[n];
+            scores[(size_t)b * Cout + n] = act == 1 ? 1.0f / (1.0f + expf(-v)) : v;
+        }
+    }
+}
+
+inline dim3 grid1d(long total, int block) { return dim3((unsigned)((total + block - 1) / block)); }
+
+}  // namespace
+
+void launch_u32_fill(uint32_t* p, uint32_t v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(u32_fill_kernel, grid1d(n, 256), dim3(256), 0, s, p, v, n);
+}
+
+void launch_f32_mel(const float* spec, const float* minmax, float* out, float* smax, int B, int F, int W, int M,
+                    const float* wvals, const int* bands, const float* magp, int mag, int norm, hipStream_t s) {
+    hipLaunchKernelGGL(f32_mel_kernel, dim3((W + 255) / 256, M, B), dim3(256), 0, s, spec, minmax, out, smax, F, W, M,
+                       wvals, bands, magp, mag, norm);
+}
+
+void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const float* magp, int mag, hipStream_t s) {
+    hipLaunchKernelGGL(f32_mag_kernel, dim3(16, B), dim3(256), 0, s, x, smax, M, W, magp, mag);
+}
+
+void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, int sh, int sw, int act, int OH, int OW,
+                     int pt, int pl, const float* w, const float* bias, hipStream_t s) {
+    const long total = (long)B * OH * OW * (Cout / 4);
+    hipLaunchKernelGGL(f32_stem_kernel, grid1d(total, 256), dim3(256), 0, s, x, y, H, W, Cout, sh, sw, act, OH, OW, pt,
+                       pl, w, bias, total);
+}
+
+void launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW,
+                   int pt, int pl, const float* w, const float* bias, hipStream_t s) {
+    const long total = (long)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(f32_dw_kernel, grid1d(total, 256), dim3(256), 0, s, x, y, H, W, C, sh, sw, act, OH, OW, pt, pl,
+                       w, bias, total);
+}
+
+void launch_f32_pw(const float* x, const float* res, const float* gate, float* y, int B, int P, int Cin, int Cout,
+                   int act, const float* w, const float* bias, hipStream_t s) {
+    const long total = (long)B * P * (Cout / 4);
+    hipLaunchKernelGGL(f32_pw_kernel, grid1d(total, 256), dim3(256), 0, s, x, res, gate, y, P, Cin, Cout, act, w, bias,
+                       total);
+}
+
+void launch_f32_segate(const float* x, float* gate, int B, int P, int C, int Cr, const float* w1, const float* w2,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(f32_segate_kernel, dim3(B), dim3(256), (C + Cr) * sizeof(float), s, x, gate, P, C, Cr, w1, w2);
+}
+
+void launch_f32_scale(const float* x, const float* gate, float* y, int B, int P, int C, hipStream_t s) {
+    const long total = (long)B * P * C;
+    hipLaunchKernelGGL(f32_scale_kernel, grid1d(total, 256), dim3(256), 0, s, x, gate, y, P, C, total);
+}
+
+void launch_f32_gap(const float* x, float* y, int B, int P, int C, hipStream_t s) {
+    hipLaunchKernelGGL(f32_gap_kernel, dim3(B), dim3(256), 0, s, x, y, P, C);
+}
+
+void launch_f32_dense(const float* x, float* scores, float* logits, int B, int Cin, int Cout, int act, const float* w,
+                      const float* bias, hipStream_t s) {
+    hipLaunchKernelGGL(f32_dense_kernel, dim3(B), dim3(128), (Cin + Cout) * sizeof(float), s, x, scores, logits, Cin,
+                       Cout, act, w, bias);
+}
+
+void launch_f32_attnpool(const float* x, float* y, int B, int P, int C, const float* score, hipStream_t s) {
+    hipLaunchKernelGGL(f32_attnpool_kernel, dim3(B), dim3(256), P * sizeof(float), s, x, y, P, C, score);
+}
+
+}  // namespace bn

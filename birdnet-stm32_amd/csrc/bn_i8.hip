@@ -1,0 +1,327 @@
+// bn_i8.hip — bit-faithful INT8 DS-CNN kernels for gfx950 (baseline generation: dot4 on the
+// vector ALU; the MFMA pointwise kernels build on the same requantisation helpers).
+//
+// Integer semantics are those of the TFLite reference kernels that execute the reference's
+// shipped birdnet_stm32n6_100.tflite through tf.lite.Interpreter
+// (reference: birdnet_stm32/models/runners.py:51-95; graph: SURVEY.md Appendix B):
+//   acc32 = sum((x - zp_x) * w) + bias
+//   y = clamp(MultiplyByQuantizedMultiplier(acc32, M0[c], shift[c]) + zp_y, act_min, act_max)
+// with MultiplyByQuantizedMultiplier = RoundingDivideByPOT(SaturatingRoundingDoublingHighMul(.)).
+// Where a layer has no spatial padding (1x1 convs, mel mixer, FC) the packer folds -zp_x*sum(w)
+// into the bias, which is the same int32 arithmetic re-associated (exact).
+#include "bn_kernels.h"
+
+namespace bn {
+namespace {
+
+__device__ __forceinline__ int32_t srdhm(int32_t a, int32_t b) {
+    const bool overflow = (a == b) && (a == INT32_MIN);
+    const int64_t ab = (int64_t)a * (int64_t)b;
+    const int64_t nudge = ab >= 0 ? (1ll << 30) : (1ll - (1ll << 30));
+    const int32_t r = (int32_t)((ab + nudge) / (1ll << 31));  // C++ division truncates toward zero
+    return overflow ? INT32_MAX : r;
+}
+
+__device__ __forceinline__ int32_t rounding_divide_by_pot(int32_t x, int exponent) {
+    const int32_t mask = (int32_t)((1u << exponent) - 1u);
+    const int32_t remainder = x & mask;
+    const int32_t threshold = (mask >> 1) + (x < 0 ? 1 : 0);
+    return (x >> exponent) + (remainder > threshold ? 1 : 0);
+}
+
+__device__ __forceinline__ int32_t mbqm(int32_t x, int32_t mult, int shift) {
+    const int left = shift > 0 ? shift : 0;
+    const int right = shift > 0 ? 0 : -shift;
+    return rounding_divide_by_pot(srdhm(x * (1 << left), mult), right);
+}
+
+__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ int32_t dot4(int32_t a, int32_t b, int32_t c) {
+#if __has_builtin(__builtin_amdgcn_sdot4)
+    return __builtin_amdgcn_sdot4(a, b, c, false);
+#else
+    c += (int32_t)(int8_t)(a) * (int32_t)(int8_t)(b);
+    c += (int32_t)(int8_t)(a >> 8) * (int32_t)(int8_t)(b >> 8);
+    c += (int32_t)(int8_t)(a >> 16) * (int32_t)(int8_t)(b >> 16);
+    c += (int32_t)(int8_t)(a >> 24) * (int32_t)(int8_t)(b >> 24);
+    return c;
+#endif
+}
+
+// TFLite int8 ADD (left_shift = 20); a = first ADD input, b = second
+struct AddQ {
+    int z1, m1, s1, z2, m2, s2, mo, so, zo, amin, amax;
+};
+__device__ __forceinline__ int32_t add_q(int32_t a, int32_t b, const AddQ& q) {
+    const int32_t sa = mbqm((a - q.z1) * (1 << 20), q.m1, q.s1);
+    const int32_t sb = mbqm((b - q.z2) * (1 << 20), q.m2, q.s2);
+    return clampi(mbqm(sa + sb, q.mo, q.so) + q.zo, q.amin, q.amax);
+}
+
+// QUANTIZE + TRANSPOSE + zero-pad: spec f32 [F][W] -> int8 [W][Kp].  64x64 tile through LDS so that
+// both the float loads (along t) and the byte stores (along f) are contiguous.
+__global__ __launch_bounds__(256) void i8_quant_kernel(const float* __restrict__ spec, const float* __restrict__ minmax,
+                                                       int8_t* __restrict__ out, int F, int W, int Kp, int zp,
+                                                       int fill, float scale) {
+    __shared__ int8_t tile[64][68];
+    const int b = blockIdx.z;
+    const int f0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    const float* S = spec + (size_t)b * F * W;
+    float mn = 0.0f, rng = 1.0f;
+    const bool renorm = minmax != nullptr;
+    if (renorm) {
+        mn = minmax[2 * b];
+        rng = (float)((double)(minmax[2 * b + 1] - mn) + 1e-10);
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int f = f0 + r, t = t0 + tx;
+        int q = fill;  // padded frequency columns: the graph's FILL constant (the zero point = real 0.0)
+        if (f < F && t < W) {
+            float v = S[(size_t)f * W + t];
+            if (renorm) v = (v - mn) / rng;
+            q = clampi((int32_t)roundf(v / scale) + zp, -128, 127);  // roundf: halves away from zero
+        }
+        tile[tx][r] = (int8_t)q;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int t = t0 + r, f = f0 + tx;
+        if (t < W && f < Kp) out[((size_t)b * W + t) * Kp + f] = tile[r][tx];
+    }
+}
+
+// mel mixer (CONV_2D 1x1 over Kp frequency columns) + ReLU clamp + the PWL chain as a per-channel
+// 256-entry table; output transposed to [M][W].  One thread = one (t, m); lanes run along t.
+__global__ void i8_mel_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int W, int Kp, int M, int zp_out,
+                              int amin, int amax, const int8_t* __restrict__ w, const int32_t* __restrict__ bias,
+                              const int32_t* __restrict__ mult, const int32_t* __restrict__ shift,
+                              const int8_t* __restrict__ lut) {
+    const int b = blockIdx.z, m = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W) return;
+    const int32_t* xr = reinterpret_cast<const int32_t*>(x + ((size_t)b * W + t) * Kp);
+    const int32_t* wr = reinterpret_cast<const int32_t*>(w + (size_t)m * Kp);
+    int32_t acc = bias[m];
+    for (int k = 0; k < Kp / 4; ++k) acc = dot4(xr[k], wr[k], acc);
+    int32_t q = clampi(mbqm(acc, mult[m], shift[m]) + zp_out, amin, amax);
+    if (lut) q = lut[m * 256 + q + 128];
+    y[((size_t)b * M + m) * W + t] = (int8_t)q;
+}
+
+// stem 3x3 on a single input channel: [H][W] -> [OH][OW][Cout]; one thread = 4 output channels
+__global__ void i8_stem_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, I8ConvGeom g,
+                               const int8_t* __restrict__ w, const int32_t* __restrict__ bias,
+                               const int32_t* __restrict__ mult, const int32_t* __restrict__ shift, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c4 = g.C >> 2;
+    const int cg = (int)(gid % c4);
+    long r = gid / c4;
+    const int ow = (int)(r % g.OW);
+    r /= g.OW;
+    const int oh = (int)(r % g.OH);
+    const long b = r / g.OH;
+    const int8_t* xin = x + b * g.H * g.W;
+    int32_t acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = bias[4 * cg + e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ih = oh * g.sh + i - g.pt;
+        if (ih < 0 || ih >= g.H) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int iw = ow * g.sw + j - g.pl;
+            if (iw < 0 || iw >= g.W) continue;
+            const int32_t v = (int32_t)xin[ih * g.W + iw] - g.zp_in;
+            const int32_t k4 = *reinterpret_cast<const int32_t*>(w + (i * 3 + j) * g.C + 4 * cg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v * (int32_t)(int8_t)(k4 >> (8 * e));
+        }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * cg + e;
+        const int32_t q = clampi(mbqm(acc[e], mult[c], shift[c]) + g.zp_out, g.amin, g.amax);
+        packed |= ((uint32_t)(uint8_t)(int8_t)q) << (8 * e);
+    }
+    *reinterpret_cast<uint32_t*>(y + ((b * g.OH + oh) * g.OW + ow) * g.C + 4 * cg) = packed;
+}
+
+// depthwise 3x3: [H][W][C] -> [OH][OW][C]; one thread = 4 channels of one output pixel
+__global__ void i8_dw_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, I8ConvGeom g,
+                             const int8_t* __restrict__ w, const int32_t* __restrict__ bias,
+                             const int32_t* __restrict__ mult, const int32_t* __restrict__ shift, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c4 = g.C >> 2;
+    const int cg = (int)(gid % c4);
+    long r = gid / c4;
+    const int ow = (int)(r % g.OW);
+    r /= g.OW;
+    const int oh = (int)(r % g.OH);
+    const long b = r / g.OH;
+    const int8_t* xin = x + b * g.H * g.W * g.C;
+    int32_t acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = bias[4 * cg + e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ih = oh * g.sh + i - g.pt;
+        if (ih < 0 || ih >= g.H) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int iw = ow * g.sw + j - g.pl;
+            if (iw < 0 || iw >= g.W) continue;
+            const int32_t v4 = *reinterpret_cast<const int32_t*>(xin + ((long)ih * g.W + iw) * g.C + 4 * cg);
+            const int32_t k4 = *reinterpret_cast<const int32_t*>(w + (i * 3 + j) * g.C + 4 * cg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[e] += ((int32_t)(int8_t)(v4 >> (8 * e)) - g.zp_in) * (int32_t)(int8_t)(k4 >> (8 * e));
+        }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * cg + e;
+        const int32_t q = clampi(mbqm(acc[e], mult[c], shift[c]) + g.zp_out, g.amin, g.amax);
+        packed |= ((uint32_t)(uint8_t)(int8_t)q) << (8 * e);
+    }
+    *reinterpret_cast<uint32_t*>(y + ((b * g.OH + oh) * g.OW + ow) * g.C + 4 * cg) = packed;
+}
+
+// pointwise 1x1 (+ TFLite ADD with the residual): [P][Cin] -> [P][Cout]; one thread = 4 output channels
+__global__ void i8_pw_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ res, int8_t* __restrict__ y,
+                             int Cin, int Cout, int zp_out, int amin, int amax, I8AddParams add,
+                             const int8_t* __restrict__ w, const int32_t* __restrict__ bias,
+                             const int32_t* __restrict__ mult, const int32_t* __restrict__ shift, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int n4 = Cout >> 2;
+    const int ng = (int)(gid % n4);
+    const long row = gid / n4;
+    const int32_t* xr = reinterpret_cast<const int32_t*>(x + row * Cin);
+    int32_t acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = bias[4 * ng + e];
+    for (int k = 0; k < Cin / 4; ++k) {
+        const int32_t v = xr[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc[e] = dot4(v, reinterpret_cast<const int32_t*>(w + (size_t)(4 * ng + e) * Cin)[k], acc[e]);
+    }
+    AddQ aq{add.z1, add.m1, add.s1, zp_out, add.m2, add.s2, add.mo, add.so, add.zo, add.amin, add.amax};
+    uint32_t r4 = 0;
+    if (add.enabled) r4 = *reinterpret_cast<const uint32_t*>(res + row * Cout + 4 * ng);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * ng + e;
+        int32_t q = clampi(mbqm(acc[e], mult[c], shift[c]) + zp_out, amin, amax);
+        if (add.enabled) q = add_q((int32_t)(int8_t)(r4 >> (8 * e)), q, aq);
+        packed |= ((uint32_t)(uint8_t)(int8_t)q) << (8 * e);
+    }
+    *reinterpret_cast<uint32_t*>(y + row * Cout + 4 * ng) = packed;
+}
+
+// MEAN over positions: int32 sum - P*zp, then the folded multiplier; blockIdx.x = chunk
+__global__ void i8_mean_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int P, int C, int zp_in, int mult,
+                               int shift, int zp_out) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int8_t* p = x + (size_t)b * P * C + c;
+        int32_t s = 0;
+        for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
+        s -= zp_in * P;
+        y[(size_t)b * C + c] = (int8_t)clampi(mbqm(s, mult, shift) + zp_out, -128, 127);
+    }
+}
+
+__global__ void i8_fc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int Cin, int Cout, int zp_out,
+                             int amin, int amax, const int8_t* __restrict__ w, const int32_t* __restrict__ bias,
+                             const int32_t* __restrict__ mult, const int32_t* __restrict__ shift) {
+    const int b = blockIdx.x;
+    const int32_t* xr = reinterpret_cast<const int32_t*>(x + (size_t)b * Cin);
+    for (int n = threadIdx.x; n < Cout; n += blockDim.x) {
+        const int32_t* wr = reinterpret_cast<const int32_t*>(w + (size_t)n * Cin);
+        int32_t acc = bias[n];
+        for (int k = 0; k < Cin / 4; ++k) acc = dot4(xr[k], wr[k], acc);
+        y[(size_t)b * Cout + n] = (int8_t)clampi(mbqm(acc, mult[n], shift[n]) + zp_out, amin, amax);
+    }
+}
+
+// LOGISTIC (table) + DEQUANTIZE -> float32 scores; dequantised FC output -> float32 logits
+__global__ void i8_head_kernel(const int8_t* __restrict__ x, float* __restrict__ scores, float* __restrict__ logits,
+                               int C, int zp_fc, int zp_out, float s_fc, float s_out, const int8_t* __restrict__ lut,
+                               long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int32_t q = x[gid];
+    if (logits) logits[gid] = (float)(q - zp_fc) * s_fc;
+    if (lut) {
+        const int32_t o = lut[q + 128];
+        scores[gid] = (float)(o - zp_out) * s_out;
+    } else {
+        scores[gid] = (float)(q - zp_fc) * s_fc;
+    }
+}
+
+inline dim3 grid1d(long total, int block) { return dim3((unsigned)((total + block - 1) / block)); }
+
+}  // namespace
+
+void launch_i8_quant(const float* spec, const float* minmax, int8_t* out, int B, int F, int W, int Kp, int zp,
+                     int fill, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(i8_quant_kernel, dim3((W + 63) / 64, (Kp + 63) / 64, B), dim3(256), 0, s, spec, minmax, out, F,
+                       W, Kp, zp, fill, scale);
+}
+
+void launch_i8_mel(const int8_t* x, int8_t* y, int B, int W, int Kp, int M, int zp_out, int amin, int amax,
+                   const int8_t* w, const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(i8_mel_kernel, dim3((W + 255) / 256, M, B), dim3(256), 0, s, x, y, W, Kp, M, zp_out, amin, amax,
+                       w, bias, mult, shift, lut);
+}
+
+void launch_i8_stem(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias,
+                    const int32_t* mult, const int32_t* shift, hipStream_t s) {
+    const long total = (long)B * g.OH * g.OW * (g.C / 4);
+    hipLaunchKernelGGL(i8_stem_kernel, grid1d(total, 256), dim3(256), 0, s, x, y, g, w, bias, mult, shift, total);
+}
+
+void launch_i8_dw(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias,
+                  const int32_t* mult, const int32_t* shift, hipStream_t s) {
+    const long total = (long)B * g.OH * g.OW * (g.C / 4);
+    hipLaunchKernelGGL(i8_dw_kernel, grid1d(total, 256), dim3(256), 0, s, x, y, g, w, bias, mult, shift, total);
+}
+
+void launch_i8_pw(const int8_t* x, const int8_t* res, int8_t* y, int B, int P, int Cin, int Cout, int zp_out, int amin,
+                  int amax, const I8AddParams& add, const int8_t* w, const int32_t* bias, const int32_t* mult,
+                  const int32_t* shift, hipStream_t s) {
+    const long total = (long)B * P * (Cout / 4);
+    hipLaunchKernelGGL(i8_pw_kernel, grid1d(total, 256), dim3(256), 0, s, x, res, y, Cin, Cout, zp_out, amin, amax, add,
+                       w, bias, mult, shift, total);
+}
+
+void launch_i8_mean(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, int mult, int shift, int zp_out,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(i8_mean_kernel, dim3(B), dim3(256), 0, s, x, y, P, C, zp_in, mult, shift, zp_out);
+}
+
+void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_out, int amin, int amax, const int8_t* w,
+                  const int32_t* bias, const int32_t* mult, const int32_t* shift, hipStream_t s) {
+    hipLaunchKernelGGL(i8_fc_kernel, dim3(B), dim3(128), 0, s, x, y, Cin, Cout, zp_out, amin, amax, w, bias, mult,
+                       shift);
+}
+
+void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,
+                    float s_out, const int8_t* lut, hipStream_t s) {
+    const long total = (long)B * C;
+    hipLaunchKernelGGL(i8_head_kernel, grid1d(total, 256), dim3(256), 0, s, x, scores, logits, C, zp_fc, zp_out, s_fc,
+                       s_out, lut, total);
+}
+
+}  // namespace bn

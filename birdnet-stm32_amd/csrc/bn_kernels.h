@@ -1,0 +1,66 @@
+// bn_kernels.h — host-callable launchers of the gfx950 kernels (internal, not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bn {
+
+// Read-only tables every STFT launch needs (built once per context, in double, stored f32).
+struct StftTables {
+    const float* window;    // [512] periodic Hann
+    const float2* tw256;    // [256] exp(-2 pi i p / 256)
+    const float2* tw512;    // [257] exp(-2 pi i k / 512)
+};
+
+// ---- STFT ------------------------------------------------------------------------------
+void launch_minmax_init(float* minmax, int B, hipStream_t s);
+void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec,
+                    float* minmax, hipStream_t s);
+void launch_spec_normalize(float* spec, const float* minmax, int B, int per_chunk, hipStream_t s);
+
+// ---- float32 plan ------------------------------------------------------------------------
+void launch_f32_mel(const float* spec, const float* minmax, float* out, float* smax, int B, int F, int W, int M,
+                    const float* wvals, const int* bands, const float* magp, int mag, int norm, hipStream_t s);
+void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const float* magp, int mag, hipStream_t s);
+void launch_u32_fill(uint32_t* p, uint32_t v, int n, hipStream_t s);
+void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, int sh, int sw, int act, int OH, int OW,
+                     int pt, int pl, const float* w, const float* bias, hipStream_t s);
+void launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW,
+                   int pt, int pl, const float* w, const float* bias, hipStream_t s);
+void launch_f32_pw(const float* x, const float* res, const float* gate, float* y, int B, int P, int Cin, int Cout,
+                   int act, const float* w, const float* bias, hipStream_t s);
+void launch_f32_segate(const float* x, float* gate, int B, int P, int C, int Cr, const float* w1, const float* w2,
+                       hipStream_t s);
+void launch_f32_scale(const float* x, const float* gate, float* y, int B, int P, int C, hipStream_t s);
+void launch_f32_gap(const float* x, float* y, int B, int P, int C, hipStream_t s);
+void launch_f32_dense(const float* x, float* scores, float* logits, int B, int Cin, int Cout, int act, const float* w,
+                      const float* bias, hipStream_t s);
+void launch_f32_attnpool(const float* x, float* y, int B, int P, int C, const float* score, hipStream_t s);
+
+// ---- INT8 plan -----------------------------------------------------------------------------
+void launch_i8_quant(const float* spec, const float* minmax, int8_t* out, int B, int F, int W, int Kp, int zp,
+                     int fill, float scale, hipStream_t s);
+void launch_i8_mel(const int8_t* x, int8_t* y, int B, int W, int Kp, int M, int zp_out, int amin, int amax,
+                   const int8_t* w, const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut,
+                   hipStream_t s);
+struct I8ConvGeom {
+    int H, W, C, sh, sw, OH, OW, pt, pl, zp_in, zp_out, amin, amax;
+};
+void launch_i8_stem(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias,
+                    const int32_t* mult, const int32_t* shift, hipStream_t s);
+void launch_i8_dw(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias,
+                  const int32_t* mult, const int32_t* shift, hipStream_t s);
+struct I8AddParams {
+    int enabled, z1, m1, s1, m2, s2, mo, so, zo, amin, amax;
+};
+void launch_i8_pw(const int8_t* x, const int8_t* res, int8_t* y, int B, int P, int Cin, int Cout, int zp_out, int amin,
+                  int amax, const I8AddParams& add, const int8_t* w, const int32_t* bias, const int32_t* mult,
+                  const int32_t* shift, hipStream_t s);
+void launch_i8_mean(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, int mult, int shift, int zp_out,
+                    hipStream_t s);
+void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_out, int amin, int amax, const int8_t* w,
+                  const int32_t* bias, const int32_t* mult, const int32_t* shift, hipStream_t s);
+void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,
+                    float s_out, const int8_t* lut, hipStream_t s);
+
+}  // namespace bn

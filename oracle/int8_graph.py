@@ -36,7 +36,8 @@ INT32_MAX = (1 << 31) - 1
 def round_half_away(x):
     """C ``round()``: halves away from zero (numpy's ``rint`` rounds halves to even)."""
     x = np.asarray(x)
-    return np.sign(x) * np.floor(np.abs(x) + x.dtype.type(0.5))
+    t = np.trunc(x)
+    return np.where(np.abs(x - t) >= 0.5, t + np.sign(x), t).astype(x.dtype)
 
 
 def quantize_multiplier(real: float) -> tuple[int, int]:
