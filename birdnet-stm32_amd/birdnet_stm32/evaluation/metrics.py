@@ -1,0 +1,216 @@
+"""Per-file evaluation loop: chunk -> predict -> pool -> metrics (reference: birdnet_stm32/evaluation/metrics.py:18-207).
+
+``make_chunks_for_file`` and ``evaluate`` keep the reference's signatures, skip rules (unknown label
+directory or unreadable/empty file -> skipped), metric keys (``roc-auc``, ``f1``, ``precision``, ``recall``,
+``ap_per_class``, ``cmAP``, ``mAP``; with ``measure_latency`` also ``latency_mean_ms``, ``latency_median_ms``,
+``latency_p95_ms``, ``latency_p99_ms``, ``total_chunks``; with ``profile_memory`` ``peak_rss_mb``,
+``rss_delta_mb``) and latency accounting (wall time of one ``predict`` divided by the batch size, replicated
+per chunk, reference :130-136).
+
+Two execution modes:
+
+* any object with ``predict(x_batch)`` (the reference's duck-typed runner, e.g. the tests' ``FakeRunner``):
+  the reference loop, one file at a time, batches never crossing files (reference :117-141);
+* a :class:`HipRunner` on a hybrid-frontend model: the *device pipeline* — chunks of many files are
+  packed into batches of ``batch_size`` (the reference never batches across files, SURVEY.md finding 10),
+  uploaded once as waveforms and turned into scores by ``bn_infer_audio`` (STFT + frontend + network on the
+  GPU); scores are then pooled per file exactly as above.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+import resource
+import time
+
+import numpy as np
+
+from birdnet_stm32.audio.io import load_audio_file
+from birdnet_stm32.evaluation.pooling import pool_scores
+from birdnet_stm32.models.frontend import normalize_frontend_name
+
+
+def make_chunks_for_file(path: str, cfg: dict, frontend: str, mag_scale: str, n_fft: int, chunk_overlap: float,
+                         spectrogram_fn=None) -> list[np.ndarray]:
+    """Model-ready inputs for one file: a list of per-chunk float32 arrays (reference :18-72).
+
+    ``spectrogram_fn(chunks [N,T], n_fft, spec_width) -> [N, F, W]`` replaces the GPU STFT (tests inject the
+    CPU oracle there; the default is ``birdnet_stm32.audio.spectrogram.spectrograms_from_chunks``).
+    """
+    sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
+    width = int(cfg["spec_width"])
+    chunks = load_audio_file(path, sample_rate=sr, max_duration=60, chunk_duration=cd, random_offset=False,
+                             chunk_overlap=chunk_overlap)
+    if len(chunks) == 0:
+        return []
+    if frontend == "hybrid":
+        if spectrogram_fn is None:
+            from birdnet_stm32.audio.spectrogram import spectrograms_from_chunks as spectrogram_fn
+        specs = np.asarray(spectrogram_fn(np.asarray(chunks, np.float32), n_fft, width), np.float32)
+        bins = n_fft // 2 + 1
+        return [s[:bins, :width, None] for s in specs]
+    if frontend == "raw":
+        size = int(cfg["chunk_duration"] * cfg["sample_rate"])
+        out = []
+        for ch in chunks:
+            x = np.zeros(size, np.float32)
+            x[: min(size, ch.shape[0])] = ch[:size]
+            out.append((x / (np.max(np.abs(x)) + 1e-6))[:, None].astype(np.float32))
+        return out
+    if frontend in ("librosa", "mfcc", "log_mel"):
+        raise NotImplementedError(f"precomputed frontend '{frontend}' has no MI355X path in this build (SURVEY.md §8f)")
+    raise ValueError(f"Invalid audio_frontend: {frontend}")
+
+
+def _label_of(path: str) -> str:
+    return os.path.basename(os.path.dirname(path))
+
+
+def _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scale, n_fft, overlap, batch_size, measure_latency,
+                           spectrogram_fn):
+    """The reference loop: per file, batches of at most ``batch_size`` chunks, never across files."""
+    lat: list[float] = []
+    for path in files:
+        if _label_of(path) not in classes:
+            continue
+        chunks = make_chunks_for_file(path, cfg, frontend, mag_scale, n_fft, overlap, spectrogram_fn=spectrogram_fn)
+        if not chunks:
+            continue
+        preds = []
+        for i in range(0, len(chunks), batch_size):
+            batch = np.stack(chunks[i : i + batch_size], axis=0)
+            t0 = time.perf_counter()
+            preds.append(model_runner.predict(batch))
+            if measure_latency:
+                lat.extend([(time.perf_counter() - t0) * 1000.0 / batch.shape[0]] * batch.shape[0])
+        yield path, np.concatenate(preds, axis=0), lat
+
+
+def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measure_latency):
+    """Device pipeline: waveform chunks of many files per batch, ``bn_infer_audio`` per batch."""
+    import torch
+
+    sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
+    pending: list[tuple[str, int]] = []  # (path, n_chunks) in arrival order
+    stash: list[np.ndarray] = []
+    scores_ready: list[np.ndarray] = []
+    lat: list[float] = []
+
+    def flush(n):
+        nonlocal stash
+        block = np.concatenate(stash, axis=0)
+        take, rest = block[:n], block[n:]
+        stash = [rest] if len(rest) else []
+        t0 = time.perf_counter()
+        d = torch.from_numpy(np.ascontiguousarray(take)).to(runner.device)
+        s = runner.infer_audio_device(d).cpu().numpy()
+        if measure_latency:
+            lat.extend([(time.perf_counter() - t0) * 1000.0 / n] * n)
+        scores_ready.append(s)
+
+    def drain():
+        have = np.concatenate(scores_ready, axis=0) if scores_ready else np.zeros((0, runner.num_classes), np.float32)
+        done = []
+        while pending and pending[0][1] <= len(have):
+            path, n = pending.pop(0)
+            done.append((path, have[:n]))
+            have = have[n:]
+        scores_ready.clear()
+        if len(have):
+            scores_ready.append(have)
+        return done
+
+    for path in files:
+        if _label_of(path) not in classes:
+            continue
+        chunks = load_audio_file(path, sample_rate=sr, max_duration=60, chunk_duration=cd, random_offset=False, chunk_overlap=overlap)
+        if len(chunks) == 0:
+            continue
+        pending.append((path, len(chunks)))
+        stash.append(np.asarray(chunks, np.float32))
+        while sum(len(s) for s in stash) >= batch_size:
+            flush(batch_size)
+        for item in drain():
+            yield (*item, lat)
+    left = sum(len(s) for s in stash)
+    if left:
+        flush(left)
+    for item in drain():
+        yield (*item, lat)
+
+
+def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pooling: str = "average", batch_size: int = 64,
+             overlap: float = 0.0, mep_beta: float = 10.0, measure_latency: bool = False, profile_memory: bool = False,
+             spectrogram_fn=None, device_pipeline: bool | None = None):
+    """Run inference per chunk, pool to file level and compute metrics (reference :75-207).
+
+    Returns ``(metrics, per_file, y_true [N, C], y_scores [N, C])``.
+    """
+    from sklearn.metrics import average_precision_score, roc_auc_score
+
+    frontend = normalize_frontend_name(cfg["audio_frontend"])
+    mag_scale = cfg.get("mag_scale", "none")
+    n_fft = int(cfg["fft_length"])
+    n_cls = len(classes)
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss if profile_memory else 0
+
+    if device_pipeline is None:
+        device_pipeline = frontend == "hybrid" and hasattr(model_runner, "infer_audio_device") and spectrogram_fn is None
+    if device_pipeline:
+        stream = _score_files_device(model_runner, files, classes, cfg, overlap, batch_size, measure_latency)
+    else:
+        stream = _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scale, n_fft, overlap, batch_size,
+                                        measure_latency, spectrogram_fn)
+
+    y_true, y_scores, per_file, lat = [], [], [], []
+    total_chunks = 0
+    for path, chunk_scores, lat in stream:
+        label = _label_of(path)
+        target = np.zeros(n_cls, np.float32)
+        target[classes.index(label)] = 1.0
+        pooled = pool_scores(chunk_scores, method=pooling, beta=mep_beta)
+        total_chunks += chunk_scores.shape[0]
+        y_true.append(target)
+        y_scores.append(pooled)
+        per_file.append({"file": path, "label": label, "scores": pooled.tolist()})
+    if not y_true:
+        raise RuntimeError("No valid test samples found for the provided class set.")
+
+    yt = np.asarray(y_true, np.float32)
+    ys = np.asarray(y_scores, np.float32)
+    metrics: dict = {}
+    try:
+        metrics["roc-auc"] = float(roc_auc_score(yt, ys, average="micro"))
+    except Exception:
+        metrics["roc-auc"] = float("nan")
+    hit = (ys >= 0.5).astype(np.float32)
+    tp, fp, fn = float((yt * hit).sum()), float(((1 - yt) * hit).sum()), float((yt * (1 - hit)).sum())
+    precision, recall = tp / (tp + fp + 1e-12), tp / (tp + fn + 1e-12)
+    metrics["f1"] = float(2 * precision * recall / (precision + recall)) if precision + recall > 0 else 0.0
+    metrics["precision"], metrics["recall"] = float(precision), float(recall)
+    aps = []
+    for c in range(n_cls):
+        try:
+            aps.append(average_precision_score(yt[:, c], ys[:, c]))
+        except Exception:
+            aps.append(np.nan)
+    good = [a for a in aps if not (a is None or (isinstance(a, float) and math.isnan(a)))]
+    metrics["ap_per_class"] = aps
+    metrics["cmAP"] = float(np.mean(good)) if good else float("nan")
+    try:
+        metrics["mAP"] = float(average_precision_score(yt, ys, average="micro"))
+    except Exception:
+        metrics["mAP"] = float("nan")
+    if measure_latency and lat:
+        arr = np.asarray(lat)
+        metrics["latency_mean_ms"] = float(arr.mean())
+        metrics["latency_median_ms"] = float(np.median(arr))
+        metrics["latency_p95_ms"] = float(np.percentile(arr, 95))
+        metrics["latency_p99_ms"] = float(np.percentile(arr, 99))
+        metrics["total_chunks"] = total_chunks
+    if profile_memory:
+        rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        metrics["peak_rss_mb"] = round(rss1 / 1024, 1)
+        metrics["rss_delta_mb"] = round((rss1 - rss0) / 1024, 1)
+    return metrics, per_file, yt, ys

@@ -178,9 +178,10 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False) -> pk.Plan:
                 w, b = fold_bn(ly.weights["kernel"], bn)  # [1,1,Cin,Cout]
                 Cout = w.shape[-1]
                 P = H * Wd
-                x_val, gate_val = val[src], None
                 if src in gate_of:
                     x_val, gate_val = gate_of[src]
+                else:
+                    x_val, gate_val = val[src], None
                 v = pb.value(P * Cout * 4)
                 p = [P, Cin, Cout, pk.ACT_CODES[act], int(res is not None), int(gate_val is not None),
                      gate_val if gate_val is not None else 0]
