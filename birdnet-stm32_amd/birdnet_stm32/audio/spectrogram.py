@@ -41,8 +41,9 @@ def spectrograms_from_chunks(chunks: np.ndarray, n_fft: int = 512, spec_width: i
     x = np.ascontiguousarray(np.asarray(chunks, np.float32))
     if x.ndim != 2:
         raise ValueError("chunks must be [B, T]")
+    ctx = _context()  # raises when no MI355X is present: there is no CPU fallback
     d = torch.from_numpy(x).cuda()
-    out = stft_device(_context(), d, n_fft=n_fft, spec_width=spec_width, normalize=normalize_out)
+    out = stft_device(ctx, d, n_fft=n_fft, spec_width=spec_width, normalize=normalize_out)
     return out.cpu().numpy()
 
 

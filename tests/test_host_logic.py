@@ -1,0 +1,292 @@
+"""Host-side logic on CPU: registries, config, audio ingest, pooling, the evaluate loop with a FakeRunner
+(BASELINE configs[0]: 16 synthetic chunks through evaluate --benchmark_latency plumbing, no GPU), CLI surface."""
+
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import CONFIG_PATH, synth_chunks
+
+
+# ---------------------------------------------------------------------------------------- registries
+def test_frontend_registry_api():
+    from birdnet_stm32.models.registry import FrontendInfo, get_frontend_info, is_n6_compatible, is_precomputed, list_frontends, register_frontend
+
+    assert list_frontends() == ["hybrid", "librosa", "log_mel", "mfcc", "raw"]
+    info = get_frontend_info("librosa")
+    assert (info.name, info.mode, info.precomputed) == ("librosa", "precomputed", True)
+    assert [is_precomputed(n) for n in ("librosa", "mfcc", "log_mel", "hybrid", "raw")] == [True, True, True, False, False]
+    assert all(is_n6_compatible(n) for n in list_frontends())
+    assert get_frontend_info("hybrid").hip_path is True
+    with pytest.raises(KeyError, match="not registered"):
+        get_frontend_info("nonexistent_frontend")
+    with pytest.raises(ValueError, match="already registered"):
+        register_frontend(FrontendInfo(name="librosa", mode="precomputed", precomputed=True, n6_compatible=True))
+
+
+def test_frontend_names_and_aliases():
+    from birdnet_stm32.models.frontend import VALID_FRONTENDS, normalize_frontend_name
+
+    for n in VALID_FRONTENDS:
+        assert normalize_frontend_name(n) == n
+    with pytest.warns(DeprecationWarning, match="deprecated"):
+        assert normalize_frontend_name("precomputed") == "librosa"
+    with pytest.warns(DeprecationWarning):
+        assert normalize_frontend_name("tf") == "raw"
+    with pytest.raises(ValueError, match="Invalid audio frontend"):
+        normalize_frontend_name("fft")
+
+
+def test_model_registry_and_builder():
+    from birdnet_stm32.models import build_model, list_models, register_model
+    from birdnet_stm32.models.blocks import _make_divisible
+
+    assert list_models() == ["dscnn"]
+    with pytest.raises(KeyError, match="Unknown model"):
+        build_model("resnet")
+    with pytest.raises(ValueError, match="already registered"):
+        register_model("dscnn")(lambda **kw: None)
+    # reference tests/test_dscnn.py:11-30
+    assert [_make_divisible(v, 8) for v in (32, 30, 28, 1, 0, 33.5)] == [32, 32, 32, 8, 8, 32]
+    kw = dict(num_mels=64, spec_width=256, sample_rate=22050, chunk_duration=3, embeddings_size=256, num_classes=10)
+    for fe, shape in (("hybrid", (None, 257, 256, 1)), ("librosa", (None, 64, 256, 1)), ("mfcc", (None, 20, 256, 1)), ("raw", (None, 44100 * 0 + 66150, 1))):
+        if fe == "raw":
+            with pytest.raises(ValueError, match="STM32N6 constraint"):
+                build_model("dscnn", audio_frontend=fe, **kw)
+            m = build_model("dscnn", audio_frontend=fe, **{**kw, "sample_rate": 16000, "chunk_duration": 2})
+            assert m.input_shape == (None, 32000, 1)
+        else:
+            m = build_model("dscnn", audio_frontend=fe, **kw)
+            assert m.input_shape == shape
+        assert m.output_shape == (None, 10)
+        for ly in m.layers:
+            if ly.filters is not None:
+                assert ly.filters % 8 == 0
+    small = build_model("dscnn", alpha=0.5, **kw).count_params()
+    big = build_model("dscnn", alpha=1.5, **kw).count_params()
+    deep = build_model("dscnn", depth_multiplier=2, **kw).count_params()
+    base = build_model("dscnn", **kw).count_params()
+    assert small < base < big and base < deep
+    legacy = build_model("dscnn", **{**kw, "num_classes": 100}, use_se=False, use_inverted_residual=False)
+    assert legacy.count_params() == 229508  # the shipped checkpoint's topology
+
+
+# ---------------------------------------------------------------------------------------- audio ingest
+def test_chunking_rules():
+    from birdnet_stm32.audio.io import estimate_num_chunks, split_audio_into_chunks
+
+    sr, cd = 1000, 3.0
+    ramp = np.arange(7500, dtype=np.float32)
+    ch = split_audio_into_chunks(ramp, sr, cd, 0.0)
+    assert ch.shape == (3, 3000)
+    assert ch[1, 0] == 3000 and ch[2, 0] == 4500  # tail chunk starts at len - chunk
+    ch = split_audio_into_chunks(ramp, sr, cd, 1.0)  # step 2000: starts 0,2000,4000 + tail 4500
+    assert [int(c[0]) for c in ch] == [0, 2000, 4000, 4500]
+    short = split_audio_into_chunks(np.ones(1200, np.float32), sr, cd)
+    assert short.shape == (1, 3000) and short[0, :1200].min() == 1 and short[0, 1200:].max() == 0
+    assert split_audio_into_chunks(np.zeros(0, np.float32), sr, cd).shape == (0, 3000)
+    exact = split_audio_into_chunks(np.ones(6000, np.float32), sr, cd)
+    assert exact.shape == (2, 3000)
+    # an overlap above chunk_duration - 0.1 is clamped (step = 0.1 s)
+    assert split_audio_into_chunks(np.ones(3300, np.float32), sr, cd, 5.0).shape[0] == estimate_num_chunks(3300, sr, cd, 5.0) == 4
+    for n in (1, 2999, 3000, 3001, 5999, 6000, 7500, 60000):
+        for ov in (0.0, 0.5, 1.5):
+            assert split_audio_into_chunks(np.ones(n, np.float32), sr, cd, ov).shape[0] == estimate_num_chunks(n, sr, cd, ov)
+
+
+def test_wav_decode_mix_resample_normalise(tmp_path):
+    import struct
+
+    from birdnet_stm32.audio.io import fast_resample, load_audio_file, load_audio_window, save_wav
+
+    sr = 16000
+    x = np.linspace(-1.0, 1.0, sr, dtype=np.float32) * 0.5
+    p = tmp_path / "a.wav"
+    save_wav(x, str(p), sr, subtype="FLOAT")
+    chunks = load_audio_file(str(p), sample_rate=sr, chunk_duration=3.0)  # reference tests/test_audio_io.py:36-48
+    assert chunks.shape == (1, 3 * sr)
+    np.testing.assert_allclose(chunks[0, :sr], x / np.abs(x).max(), rtol=1e-6, atol=1e-6)
+    assert np.all(chunks[0, sr:] == 0)
+    # PCM16: libsndfile scaling x/32768; peak-normalised afterwards
+    save_wav(x, str(tmp_path / "b.wav"), sr)
+    y = load_audio_window(str(tmp_path / "b.wav"), sample_rate=sr)
+    q = np.clip(np.rint(x * 32768), -32768, 32767) / 32768.0
+    np.testing.assert_allclose(y, (q / np.abs(q).max()).astype(np.float32), atol=1e-7)
+    # stereo PCM16 -> channel mean; 24-bit PCM; resampling on load
+    l, r = (np.sin(np.arange(8000) * 0.01) * 12000).astype("<i2"), (np.cos(np.arange(8000) * 0.02) * 9000).astype("<i2")
+    inter = np.stack([l, r], axis=1).tobytes()
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(inter), b"WAVE", b"fmt ", 16, 1, 2, 8000, 8000 * 4, 4, 16, b"data", len(inter))
+    (tmp_path / "st.wav").write_bytes(hdr + inter)
+    y = load_audio_window(str(tmp_path / "st.wav"), sample_rate=8000)
+    mono = (l.astype(np.float32) / 32768 + r.astype(np.float32) / 32768) / 2
+    np.testing.assert_allclose(y, mono / np.abs(mono).max(), atol=1e-6)
+    y16 = load_audio_window(str(tmp_path / "st.wav"), sample_rate=16000)
+    assert abs(len(y16) - 16000) <= 1 and abs(np.abs(y16).max() - 1.0) < 1e-6
+    v = np.array([0, 1, -1, 8388607, -8388608], np.int32)
+    raw24 = b"".join(int(s & 0xFFFFFF).to_bytes(3, "little") for s in v)
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(raw24), b"WAVE", b"fmt ", 16, 1, 1, 8000, 24000, 3, 24, b"data", len(raw24))
+    (tmp_path / "p24.wav").write_bytes(hdr + raw24)
+    y = load_audio_window(str(tmp_path / "p24.wav"), sample_rate=8000)
+    np.testing.assert_allclose(y, v / 8388608.0 / 1.0, atol=1e-7)
+    # unreadable / empty files -> empty result, like the reference's blanket except
+    (tmp_path / "junk.wav").write_bytes(b"not a wave file")
+    assert load_audio_file(str(tmp_path / "junk.wav")) == []
+    assert load_audio_file(str(tmp_path / "missing.wav")) == []
+    up = fast_resample(np.sin(np.linspace(0, 6.28, 1000, dtype=np.float32)), 16000, 22050)
+    assert abs(len(up) - int(1000 * 22050 / 16000)) <= 1
+    same = np.ones(100, np.float32)
+    assert fast_resample(same, 22050, 22050) is same
+
+
+def test_pooling_exact_values():
+    from birdnet_stm32.evaluation.pooling import lme_pooling, pool_scores
+
+    np.testing.assert_allclose(pool_scores(np.array([[0.2, 0.8], [0.6, 0.4]], np.float32), "avg"), [0.4, 0.6])
+    np.testing.assert_allclose(pool_scores(np.array([[0.1, 0.9], [0.7, 0.3]], np.float32), "max"), [0.7, 0.9])
+    assert np.array_equal(pool_scores(np.zeros((0, 5), np.float32), "avg"), np.zeros(5))
+    with pytest.raises(ValueError, match="Unsupported"):
+        pool_scores(np.ones((3, 2), np.float32), "invalid")
+    with pytest.raises(ValueError, match="must be"):
+        pool_scores(np.ones(5), "avg")
+    np.testing.assert_allclose(lme_pooling(np.array([[0.5, 0.3]], np.float32), 10.0), [0.5, 0.3], atol=1e-5)
+    np.testing.assert_allclose(lme_pooling(np.array([[0.1, 0.9], [0.8, 0.2]], np.float32), 100.0), [0.8, 0.9], atol=0.05)
+    np.testing.assert_allclose(lme_pooling(np.array([[0.1, 0.9], [0.8, 0.2]], np.float32), 1e-4), [0.45, 0.55], atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------- evaluate plumbing
+class FakeRunner:
+    """The reference's mock backend (tests/test_metrics.py:11-22): any object with predict(x) -> [B, C]."""
+
+    def __init__(self, n_classes, key_fn):
+        self.n, self.key_fn, self.calls = n_classes, key_fn, []
+
+    def predict(self, x):
+        self.calls.append(x.shape)
+        out = np.zeros((x.shape[0], self.n), np.float32)
+        for i in range(x.shape[0]):
+            out[i, self.key_fn(x[i])] = 1.0
+        return out
+
+
+@pytest.fixture
+def tiny_dataset(tmp_path):
+    """16 synthetic 3 s @ 24 kHz chunks as WAV files under <root>/<class>/ (BASELINE configs[0])."""
+    from birdnet_stm32.audio.io import save_wav
+    from birdnet_stm32.training.config import ModelConfig
+
+    cfg = ModelConfig.load(CONFIG_PATH).to_dict()
+    cfg.update(sample_rate=24000, hop_length=281)
+    classes = cfg["class_names"]
+    pool = synth_chunks(160)
+    x = np.stack([pool[i // 2] if i % 2 == 0 else pool[150 + i // 2] for i in range(16)])  # even files: low tone, odd: high
+    files = []
+    for i in range(16):
+        d = tmp_path / classes[i % 2]
+        d.mkdir(exist_ok=True)
+        save_wav(x[i], str(d / f"clip_{i}.wav"), 24000, subtype="FLOAT")
+        files.append(str(d / f"clip_{i}.wav"))
+    long = tmp_path / classes[0] / "long.wav"
+    save_wav(np.concatenate([x[0], x[2], x[4][:30000]]), str(long), 24000, subtype="FLOAT")  # 2 full chunks + tail
+    files.append(str(long))
+    (tmp_path / "not_a_class").mkdir()
+    save_wav(x[1], str(tmp_path / "not_a_class" / "x.wav"), 24000)
+    files.append(str(tmp_path / "not_a_class" / "x.wav"))
+    (tmp_path / classes[1] / "broken.wav").write_bytes(b"junk")
+    files.append(str(tmp_path / classes[1] / "broken.wav"))
+    return tmp_path, files, classes, cfg
+
+
+def _oracle_specs(chunks, n_fft, width):
+    from oracle import stft
+
+    return np.stack([stft.hybrid_spectrogram(c, n_fft, width) for c in chunks])
+
+
+def test_evaluate_with_fake_runner_cpu_plumbing(tiny_dataset):
+    from birdnet_stm32.evaluation.metrics import evaluate, make_chunks_for_file
+
+    root, files, classes, cfg = tiny_dataset
+    chunks = make_chunks_for_file(files[0], cfg, "hybrid", "pwl", 512, 0.0, spectrogram_fn=_oracle_specs)
+    assert len(chunks) == 1 and chunks[0].shape == (257, 256, 1) and chunks[0].dtype == np.float32
+    assert 0.0 <= chunks[0].min() and chunks[0].max() <= 1.0
+    assert len(make_chunks_for_file(files[16], cfg, "hybrid", "pwl", 512, 0.0, spectrogram_fn=_oracle_specs)) == 3
+    # the tone's FFT bin tells the class: files of class 0 carry a 0.5-0.8 kHz tone, class 1 a ~6 kHz tone
+    def key(spec):
+        return int(spec[:, :, 0].mean(axis=1)[5:].argmax() + 5 > 60)
+
+    runner = FakeRunner(len(classes), key)
+    metrics, per_file, y_true, y_scores = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=2, measure_latency=True,
+                                                   spectrogram_fn=_oracle_specs)
+    assert len(per_file) == 17 and y_true.shape == y_scores.shape == (17, 100)  # unknown label + broken file skipped
+    assert metrics["total_chunks"] == 16 + 3
+    assert max(s[0] for s in runner.calls) <= 2 and (2, 257, 256, 1) in runner.calls  # batches never cross files
+    assert metrics["precision"] == pytest.approx(1.0) and metrics["recall"] == pytest.approx(1.0) and metrics["f1"] == pytest.approx(1.0)
+    for k in ("latency_mean_ms", "latency_median_ms", "latency_p95_ms", "latency_p99_ms", "total_chunks"):
+        assert k in metrics
+    for k in ("roc-auc", "cmAP", "mAP", "ap_per_class"):
+        assert k in metrics
+    m2, *_ = evaluate(FakeRunner(len(classes), key), files, classes, cfg, spectrogram_fn=_oracle_specs, profile_memory=True)
+    assert "latency_mean_ms" not in m2 and "total_chunks" not in m2 and "peak_rss_mb" in m2
+    with pytest.raises(RuntimeError, match="No valid test samples"):
+        evaluate(runner, [files[17]], classes, cfg, spectrogram_fn=_oracle_specs)
+    with pytest.raises(NotImplementedError):
+        make_chunks_for_file(files[0], cfg, "librosa", "none", 512, 0.0)
+
+
+def test_cli_surface(tiny_dataset, tmp_path, capsys):
+    from birdnet_stm32.cli.evaluate import build_parser, main, resolve_config_path
+    from birdnet_stm32.data.dataset import load_file_paths_from_directory
+
+    root, files, classes, cfg = tiny_dataset
+    flags = {a.dest for a in build_parser()._actions}
+    for f in ("model_path", "model_config", "data_path_test", "max_files", "batch_size", "overlap", "pooling", "save_csv", "confusion_matrix",
+              "save_cm_plot", "optimize_thresholds", "benchmark", "benchmark_latency", "species_report", "n_bootstrap", "det_curve",
+              "save_det_plot", "report_html", "profile_memory"):
+        assert f in flags, f
+    args = build_parser().parse_args(["--model_path", "m.tflite", "--data_path_test", "d"])
+    assert (args.batch_size, args.pooling, args.overlap, args.max_files, args.n_bootstrap) == (16, "avg", 0.0, -1, 1000)
+    with pytest.raises(FileNotFoundError, match="Model config JSON not found"):
+        resolve_config_path(str(tmp_path / "nope.tflite"))
+    assert resolve_config_path(CONFIG_PATH.replace("_model_config.json", ".tflite")) == CONFIG_PATH
+    found, cls_out = load_file_paths_from_directory(str(root), classes=classes)
+    assert len(found) == 18 and sorted(cls_out) == sorted(classes[:2])  # broken.wav is discovered, skipped later
+    capped, _ = load_file_paths_from_directory(str(root), classes=classes, max_samples=3)
+    assert len(capped) == 6
+
+    class Const:
+        def predict(self, x):
+            return np.full((x.shape[0], 100), 0.25, np.float32)
+
+    # CLI flow with an injected runner; the hybrid spectrograms need the GPU, so only the raw-frontend plumbing runs here
+    rawcfg = dict(cfg, audio_frontend="raw")
+    cfgp = tmp_path / "m_model_config.json"
+    cfgp.write_text(json.dumps(rawcfg))
+    out_json, out_csv = tmp_path / "bench.json", tmp_path / "pred.csv"
+    main(["--model_path", str(tmp_path / "m.keras"), "--data_path_test", str(root), "--benchmark_latency", "--benchmark", str(out_json),
+          "--save_csv", str(out_csv), "--confusion_matrix"], runner=Const())
+    rep = json.loads(out_json.read_text())
+    assert set(rep) == {"model_path", "num_classes", "num_files", "metrics", "config"} and rep["num_classes"] == 100
+    assert rep["num_files"] == rep["metrics"]["total_chunks"] == 19
+    assert out_csv.read_text().count("\n") == 18
+    assert "presentation report not included" in capsys.readouterr().out
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from birdnet_stm32.audio.spectrogram import get_spectrogram_from_audio
+    from birdnet_stm32.models.runners import load_model_runner
+
+    from conftest import TFLITE_PATH
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        load_model_runner(TFLITE_PATH)
+    with pytest.raises(Exception, match="(?i)no HIP device|no CPU fallback|not found"):
+        get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=-1)
+    with pytest.raises(NotImplementedError):
+        get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=64)

@@ -1,0 +1,203 @@
+"""Readers, lowering, blob layout and the C-ABI surface — all on CPU (no compute calls without a GPU)."""
+
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import KERAS_PATH, REPO, TFLITE_PATH
+
+
+def _plans(keep_all=False):
+    from birdnet_stm32.models.runners import lower_model_file
+
+    return lower_model_file(KERAS_PATH, keep_all=keep_all), lower_model_file(TFLITE_PATH, keep_all=keep_all)
+
+
+def test_plan_structure():
+    from birdnet_stm32.models import _pack as pk
+
+    f32, i8 = _plans()
+    kinds = [pk.KIND_NAMES[o.kind] for o in f32.ops]
+    assert kinds[:2] == ["f32_mel", "f32_stem"] and kinds[-2:] == ["f32_gap", "f32_dense"]
+    assert kinds.count("f32_dw") == 11 and kinds.count("f32_pw") == 11 and len(f32.ops) == 26
+    assert sum(1 for o in f32.ops if o.kind == pk.F32_PW and o.p[4]) == 7  # residual blocks
+    kinds = [pk.KIND_NAMES[o.kind] for o in i8.ops]
+    assert kinds[:3] == ["i8_quant", "i8_mel", "i8_stem"] and kinds[-3:] == ["i8_mean", "i8_fc", "i8_head"]
+    assert kinds.count("i8_dw") == 11 and kinds.count("i8_pw") == 11 and len(i8.ops) == 28  # 56 TFLite ops -> 28 launches
+    assert sum(1 for o in i8.ops if o.kind == pk.I8_PW and o.p[6]) == 7
+    assert (f32.dtype, i8.dtype) == (pk.DTYPE_F32, pk.DTYPE_I8)
+    assert f32.input_elems == i8.input_elems == 257 * 256 and f32.num_classes == i8.num_classes == 100
+    # shapes of the SURVEY §8d per-layer table
+    shapes = [o.out_shape for o in f32.ops if o.kind in (pk.F32_STEM, pk.F32_PW)]
+    assert shapes[0] == (64, 128, 16) and shapes[1] == (32, 64, 32) and shapes[-1] == (4, 8, 256)
+    # TensorFlow SAME padding is asymmetric for stride 2: stem pads W 0/1, stride-2 depthwise pads 0/1 on both axes
+    stem = f32.ops[1]
+    assert (stem.p[8], stem.p[9]) == (1, 0)
+    dws = [o for o in f32.ops if o.kind == pk.F32_DW]
+    assert all((o.p[8], o.p[9]) == ((0, 0) if o.p[3] == 2 else (1, 1)) for o in dws)
+
+
+def test_slots_never_alias_live_values():
+    """Liveness check of the packer: an operator's output slot differs from every slot still to be read."""
+    f32, i8 = _plans()
+    for plan in (f32, i8):
+        assert len(plan.slot_bytes) <= 4
+        for i, o in enumerate(plan.ops):
+            if o.out < 0:
+                continue
+            for later in plan.ops[i + 1 :]:
+                reads = {later.in0, later.in1}
+                if o.out in reads:
+                    break  # consumed; may be recycled afterwards
+            live_inputs = {o.in0, o.in1} - {-9, -1}
+            assert o.out not in live_inputs or o.kind == 2, f"op {i} writes its own input slot"
+    keep, _ = _plans(keep_all=True)
+    outs = [o.out for o in keep.ops if o.out >= 0]
+    assert len(outs) == len(set(outs))  # debug plans keep every activation
+
+
+def test_residual_source_survives_until_the_add():
+    from birdnet_stm32.models import _pack as pk
+
+    f32, _ = _plans()
+    for i, o in enumerate(f32.ops):
+        if o.kind == pk.F32_PW and o.p[4]:
+            res = o.in1
+            # the producer of `res` is the last writer of that slot before op i
+            writers = [j for j in range(i) if f32.ops[j].out == res]
+            assert writers, "residual slot has no producer"
+            last = writers[-1]
+            assert all(f32.ops[j].out != res for j in range(last + 1, i)), "residual overwritten before its add"
+
+
+def test_blob_layout_roundtrip():
+    from birdnet_stm32.models import _pack as pk
+
+    _, i8 = _plans()
+    blob = i8.to_blob()
+    magic, ver, dtype, kind, elems, F, W, C, n_slots, n_tensors, n_ops, so, to, oo, _ = struct.unpack_from("<8s14I", blob, 0)
+    assert magic == pk.BLOB_MAGIC and ver == pk.BLOB_VERSION and (dtype, kind, elems, F, W, C) == (1, 0, 257 * 256, 257, 256, 100)
+    assert (n_slots, n_tensors, n_ops) == (len(i8.slot_bytes), len(i8.tensors), len(i8.ops))
+    op_size = 16 + 4 * (pk.OP_NP + pk.OP_NT + pk.OP_NF)
+    for t in range(n_tensors):
+        off, nb = struct.unpack_from("<QQ", blob, to + 16 * t)
+        assert off % 256 == 0 and off + nb <= len(blob)
+        assert blob[off : off + nb] == i8.tensors[t].tobytes()
+    k0 = struct.unpack_from("<4i", blob, oo)
+    assert k0[0] == pk.I8_QUANT and k0[1] == pk.SLOT_INPUT
+    assert oo + op_size * n_ops <= min(struct.unpack_from("<Q", blob, to)[0], len(blob))
+    # the header constants mirror csrc/bn_blob.h
+    hdr = open(os.path.join(REPO, "birdnet-stm32_amd", "csrc", "bn_blob.h")).read()
+    assert f'"{pk.BLOB_MAGIC.decode()}"' in hdr and f"BN_BLOB_VERSION {pk.BLOB_VERSION}u" in hdr
+    assert f"BN_OP_NP {pk.OP_NP}" in hdr and f"BN_OP_NT {pk.OP_NT}" in hdr and f"BN_OP_NF {pk.OP_NF}" in hdr
+    for name, val in pk.KIND_NAMES.items():
+        assert re.search(rf"BN_OP_{val.upper()} = {name}\b", hdr), val
+
+
+def test_band_sparse_mel_equals_dense():
+    from birdnet_stm32.models._keras_loader import load_keras_archive
+    from birdnet_stm32.models._lower_f32 import mel_bands
+
+    mel = load_keras_archive(KERAS_PATH).frontend.weights["mel"]
+    vals, bands = mel_bands(mel, 257)
+    dense = np.zeros((257, 64), np.float32)
+    for m in range(64):
+        s, n, off = bands[:, m]
+        dense[s : s + n, m] = vals[off : off + n]
+    assert np.array_equal(dense, mel[:257])
+    assert vals.size < 0.05 * mel.size  # the Slaney triangles are narrow
+    full = np.random.default_rng(0).uniform(0.1, 1, (264, 8)).astype(np.float32)
+    v2, b2 = mel_bands(full, 257)
+    assert np.all(b2[1] == 257) and v2.size == 257 * 8  # a dense mixer degrades to full-length bands
+
+
+def test_pwl_table_and_folded_biases_match_the_oracle():
+    """The lowering's own integer arithmetic (tables, multipliers, zero-point folding) against the oracle's."""
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models import _quant as qz
+    from birdnet_stm32.models._tflite_reader import load_tflite
+    from oracle import int8_graph as og
+
+    model = load_tflite(TFLITE_PATH)
+    _, i8 = _plans()
+    mel = i8.ops[1]
+    lut = i8.tensors[mel.t[4]]  # [64][256]
+    interp = og.Int8Interpreter(model)
+    q = np.repeat(np.arange(-128, 128, dtype=np.int8)[None, None, :, None], 64, axis=3)  # [1,1,256,64]: every value in every channel
+    env = {83: q}
+    for op in model.ops[9:20]:
+        env[op.outputs[0]] = interp._conv(op, env, True) if op.name == "DEPTHWISE_CONV_2D" else interp._add(op, env)
+    assert np.array_equal(env[94][0, 0].T, lut)
+    rng = np.random.default_rng(1)
+    for real in list(rng.uniform(1e-6, 0.9, 50)) + [0.5, 0.25, 1e-9, 0.999999999]:
+        assert qz.quantize_multiplier(float(real)) == og.quantize_multiplier(float(real))
+    acc = rng.integers(-(2**26), 2**26, 4096)
+    for m, s in ((1518500250, -7), (1073741824, 0), (2147483647, -1), (1385918850, -2), (1200000000, 1)):
+        assert np.array_equal(qz.requantize(acc, m, s), og.mbqm(acc, m, s))
+    for act in ("none", "relu", "relu6"):
+        for sc, zp in ((0.0235294, -128), (0.20542, -34), (1.23353e-3, -128)):
+            assert qz.activation_bounds(act, sc, zp) == og.activation_range(act, sc, zp)
+    head = i8.ops[-1]
+    assert np.array_equal(i8.tensors[head.t[0]], interp.logistic_lut(model.ops[54]))
+    # zero-point folding: bias' = bias - zp_in * sum_k w
+    pw = next(o for o in i8.ops if o.kind == pk.I8_PW)
+    op = model.ops[24]
+    w = model.tensors[op.inputs[1]].data.reshape(32, 16).astype(np.int64)
+    zp_in = int(model.tensors[op.inputs[0]].zero_point[0])
+    assert np.array_equal(i8.tensors[pw.t[1]], (model.tensors[op.inputs[2]].data - zp_in * w.sum(axis=1)).astype(np.int32))
+
+
+def test_unsupported_graphs_are_rejected():
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._h5_reader import H5File
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models._tflite_reader import parse_tflite
+
+    with pytest.raises(ValueError, match="TFL3"):
+        parse_tflite(b"\x00" * 64)
+    with pytest.raises(ValueError, match="HDF5"):
+        H5File(b"\x00" * 128)
+    kw = dict(num_mels=64, spec_width=256, sample_rate=22050, chunk_duration=3, embeddings_size=256, num_classes=10)
+    with pytest.raises(NotImplementedError):
+        lower_f32(build_model("dscnn", audio_frontend="librosa", **kw))
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+def _declared_symbols():
+    hdr = open(os.path.join(REPO, "include", "birdnet_hip.h")).read()
+    return sorted(set(re.findall(r"BN_API [\w\s\*]+?(bn_\w+)\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from birdnet_stm32 import _hip
+
+    assert os.path.isfile(_hip.LIB_PATH), "libbirdnet_hip.so missing: run __graft_entry__.build()"
+    declared = _declared_symbols()
+    assert len(declared) >= 15 and sorted(_hip.EXPORTS) == declared
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.bn_version.restype = ctypes.c_int
+    assert lib.bn_version() == _hip.ABI_VERSION
+    lib.bn_kernel_names.restype = ctypes.c_char_p
+    names = lib.bn_kernel_names().decode().split("\n")
+    assert "stft512_mag_kernel" in names and "i8_pw_kernel" in names
+
+
+def test_context_creation_fails_loudly_without_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from birdnet_stm32 import _hip
+
+    lib = _hip.load_library()
+    assert lib.bn_device_count() == 0
+    with pytest.raises(_hip.HipError, match="no HIP device|no CPU fallback"):
+        _hip.Context(0, 4)
+    h = ctypes.c_void_p()
+    assert lib.bn_ctx_create(0, 0, ctypes.byref(h)) < 0 and b"max_batch" in lib.bn_last_error()

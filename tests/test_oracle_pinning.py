@@ -1,0 +1,261 @@
+"""Pins the CPU oracle: known answers from the shipped artefacts, the reference's own importable modules
+(fixtures), the reference's firmware C (oracle/_ref) and the committed oracle vectors.  CPU only."""
+
+import json
+import os
+import zipfile
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, KERAS_PATH, TFLITE_PATH, cosine, fixture_signals, synth_chunks
+
+
+@pytest.fixture(scope="module")
+def keras_vars():
+    from birdnet_stm32.models._h5_reader import read_h5_datasets
+
+    with zipfile.ZipFile(KERAS_PATH) as z:
+        return read_h5_datasets(z.read("model.weights.h5"))
+
+
+@pytest.fixture(scope="module")
+def netspec():
+    from birdnet_stm32.models._keras_loader import load_keras_archive
+
+    return load_keras_archive(KERAS_PATH)
+
+
+@pytest.fixture(scope="module")
+def tfl():
+    from birdnet_stm32.models._tflite_reader import load_tflite
+
+    return load_tflite(TFLITE_PATH)
+
+
+# ---------------------------------------------------------------- known answers in the shipped artefacts
+def test_mel_bank_equals_checkpoint_mixer(keras_vars):
+    """SURVEY §8c KAT 1: the Slaney restatement == the checkpoint's frozen mel_mixer (librosa-seeded)."""
+    from oracle.melbank import hybrid_mel_mixer
+
+    w = keras_vars["/layers/audio_frontend_layer/mel_mixer/vars/0"][0, 0]
+    ours = hybrid_mel_mixer(22050, 512, 64, fmin=150.0)
+    assert w.shape == ours.shape == (264, 64)
+    assert np.abs(w - ours).max() <= 2e-9
+    assert np.all(w[257:] == 0.0)
+
+
+def test_pwl_constants(keras_vars, tfl):
+    """KAT 2: PWL break points / slopes exactly as the reference initialises them (magnitude.py:99-130)."""
+    base = "/layers/audio_frontend_layer"
+    for sfx, t in zip(("", "_1", "_2"), (0.10, 0.35, 0.65)):
+        assert np.all(keras_vars[f"{base}/_pwl_shift_dws/depthwise_conv2d{sfx}/vars/0"] == 1.0)
+        assert np.allclose(keras_vars[f"{base}/_pwl_shift_dws/depthwise_conv2d{sfx}/vars/1"], -t, atol=1e-7)
+    for sfx, k in zip(("", "_1", "_2"), (0.25, 0.15, 0.08)):
+        assert np.allclose(keras_vars[f"{base}/_pwl_k_dws/depthwise_conv2d{sfx}/vars/0"], k, atol=1e-7)
+    for ti, t in ((65, -0.10), (63, -0.35), (61, -0.65)):
+        tt = tfl.tensors[ti]
+        deq = (tt.data.astype(np.float64) - tt.zero_point[0]) * tt.scale[0]
+        assert np.allclose(deq, t, atol=float(tt.scale[0]))
+
+
+def test_parameter_count_matches_keras(netspec):
+    """229 508 stored parameters, 17 536 of them in the frontend."""
+    assert netspec.count_params() == 229508
+    assert netspec.frontend.n_params() == 17536
+    assert netspec.input_shape == (None, 257, 256, 1) and netspec.output_shape == (None, 100)
+    assert netspec.frontend.attrs["norm"] is False  # legacy checkpoint: no per-sample max normalisation
+
+
+def test_int8_weights_are_folded_keras_weights(netspec, tfl):
+    """KAT 3: the .tflite's int8 weights / int32 biases re-derived from the .keras file (two independent readers)."""
+    L = {ly.name: ly for ly in netspec.layers}
+
+    def folded(conv, bn):
+        s = L[bn].weights["gamma"].astype(np.float64) / np.sqrt(L[bn].weights["var"].astype(np.float64) + 1e-3)
+        w = L[conv].weights["kernel"].astype(np.float64) * s
+        b = L[bn].weights["beta"].astype(np.float64) - L[bn].weights["mean"].astype(np.float64) * s
+        return w, b
+
+    checks = [(22, "stem_conv", "stem_bn", "conv"), (23, "stage1_ds1_dw", "stage1_ds1_dw_bn", "dw"),
+              (24, "stage1_ds1_pw", "stage1_ds1_pw_bn", "conv"), (50, "stage4_ds2_pw", "stage4_ds2_pw_bn", "conv")]
+    for op_i, conv, bn, kind in checks:
+        op = tfl.ops[op_i]
+        wt, bt = tfl.tensors[op.inputs[1]], tfl.tensors[op.inputs[2]]
+        s_in = float(tfl.tensors[op.inputs[0]].scale[0])
+        w, b = folded(conv, bn)
+        wq = np.transpose(wt.data, (1, 2, 3, 0)).astype(np.float64) if kind == "conv" else np.transpose(wt.data, (1, 2, 3, 0))[..., 0, :].astype(np.float64)
+        if kind == "dw":
+            wq = wt.data[0].astype(np.float64)  # [3,3,C]
+        sc = wt.scale.astype(np.float64)
+        assert np.allclose(sc, np.abs(w).reshape(-1, w.shape[-1]).max(axis=0) / 127.0, rtol=1e-5)
+        assert np.abs(wq - w / sc).max() <= 0.5 + 1e-3, conv
+        assert np.allclose(bt.scale.astype(np.float64), s_in * sc, rtol=1e-6)
+        assert np.abs(bt.data * (s_in * sc) - b).max() <= 0.51 * (s_in * sc).max() + 1e-7
+    dense = tfl.tensors[tfl.ops[53].inputs[1]]
+    wd = L["pred"].weights["kernel"].astype(np.float64)  # [256,100]
+    assert np.allclose(dense.scale, np.abs(wd).max(axis=0) / 127.0, rtol=1e-6)
+    assert np.abs(dense.data.T - wd / dense.scale.astype(np.float64)).max() <= 0.5 + 1e-3
+
+
+def test_float_and_int8_oracles_agree(netspec, tfl):
+    """KAT 4: float(norm off) vs INT8 logit cosine ~0.9999 on tone+noise chunks; same top-1."""
+    from oracle import float_graph, stft
+    from oracle.int8_graph import Int8Interpreter
+
+    x = np.stack([stft.hybrid_spectrogram(a) for a in synth_chunks(3)])[..., None]
+    _, lf = float_graph.forward(netspec, x, np.float32, return_logits=True)
+    _, env = Int8Interpreter(tfl).invoke(x, return_all=True)
+    t = tfl.tensors[128]
+    lq = (env[128].astype(np.float32) - t.zero_point[0]) * t.scale[0]
+    for b in range(3):
+        assert cosine(lf[b], lq[b]) > 0.9995
+        assert lf[b].argmax() == lq[b].argmax()
+
+
+def test_tflite_graph_shape(tfl):
+    """Appendix B: 131 tensors, 56 operators, 231 309 constant bytes, the documented operator census."""
+    assert len(tfl.tensors) == 131 and len(tfl.ops) == 56 and tfl.constant_bytes() == 231309
+    names = [o.name for o in tfl.ops]
+    assert names.count("CONV_2D") == 13 and names.count("DEPTHWISE_CONV_2D") == 16 and names.count("ADD") == 13
+    assert names[0] == "QUANTIZE" and names[-3:] == ["FULLY_CONNECTED", "LOGISTIC", "DEQUANTIZE"]
+    assert abs(tfl.tensors[tfl.ops[0].outputs[0]].scale[0] - 1 / 255) < 1e-9
+
+
+# ---------------------------------------------------------------- oracle vs its committed vectors
+@pytest.mark.parametrize("sr", [22050, 24000])
+def test_oracle_reproduces_golden_vectors(netspec, tfl, sr):
+    from oracle import float_graph, stft
+    from oracle.int8_graph import Int8Interpreter
+
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    sig = fixture_signals(sr)
+    interp = Int8Interpreter(tfl)
+    for name in ("sine", "noise", "chirp"):
+        key = f"{name}_{sr}"
+        S = stft.hybrid_spectrogram(sig[name])
+        assert S.shape == (257, 256) and S.dtype == np.float32 and S.min() >= 0.0 and S.max() <= 1.0
+        assert np.abs(S[::16] - g[key + "/spec_rows"]).max() < 1e-6
+        assert abs(S.astype(np.float64).sum() - float(g[key + "/spec_sum"])) < 1e-2
+        x = S[None, :, :, None]
+        probs, logits, acts = float_graph.forward(netspec, x, np.float64, return_all=True, return_logits=True)
+        assert np.abs(acts["audio_frontend"][0, :, ::8, 0] - g[key + "/frontend"]).max() < 1e-6
+        assert np.abs(logits[0] - g[key + "/logits"]).max() < 1e-4
+        assert np.abs(probs[0] - g[key + "/probs"]).max() < 1e-6
+        qp, env = interp.invoke(x, return_all=True)
+        assert np.array_equal(env[128][0], g[key + "/i8_fc"])
+        assert np.array_equal(qp[0], g[key + "/i8_probs"])
+        sums = [int(env[t].astype(np.int64).sum()) for t in (83, 96, 97, 102, 110, 121, 126, 127)]
+        assert sums == g[key + "/i8_sums"].tolist()
+
+
+def test_stft_properties():
+    """Reference tests/test_spectrogram.py: shape, dtype, silence -> 0, range [0,1]; plus linearity of the raw STFT."""
+    from oracle import stft
+
+    sig = fixture_signals(22050)
+    assert np.all(stft.hybrid_spectrogram(sig["silence"]) == 0.0)
+    a, b = sig["sine"], sig["noise"]
+    Sa, Sb = stft.stft_magnitude(a, 512, 258), stft.stft_magnitude(b, 512, 258)
+    assert Sa.shape == (257, 1 + len(a) // 258)
+    assert np.abs(stft.stft_magnitude(2 * a, 512, 258) - 2 * Sa).max() < 1e-4  # homogeneity
+    assert np.all(stft.stft_magnitude(a + b, 512, 258) <= Sa + Sb + 1e-4)  # triangle inequality per bin
+    k = int(round(1000 * 512 / 22050))
+    assert abs(int(Sa[:, 100].argmax()) - k) <= 1  # the 1 kHz tone sits in its bin
+
+
+# ---------------------------------------------------------------- the reference's own importable modules
+def test_pooling_matches_reference_outputs():
+    from birdnet_stm32.evaluation.pooling import lme_pooling, pool_scores
+
+    ref = json.load(open(os.path.join(GOLDEN, "reference_pooling_config.json")))["pooling"]
+    for name, row in ref.items():
+        if name == "empty":
+            assert pool_scores(np.zeros((0, 3), np.float32), "avg").tolist() == row
+            continue
+        x = np.asarray(row["x"], np.float32)
+        for method in ("avg", "mean", "average", "max", "lme", "log_mean_exp"):
+            np.testing.assert_allclose(pool_scores(x, method=method), row[method], rtol=1e-6, atol=1e-7)
+        for beta in (0.5, 10.0, 50.0):
+            np.testing.assert_allclose(lme_pooling(x, beta=beta), row[f"lme_beta_{beta:g}"], rtol=1e-6, atol=1e-7)
+
+
+def test_model_config_matches_reference_outputs(tmp_path):
+    from birdnet_stm32.training.config import ModelConfig
+
+    from conftest import CONFIG_PATH
+
+    ref = json.load(open(os.path.join(GOLDEN, "reference_pooling_config.json")))["config"]
+    assert ModelConfig().to_dict() == ref["defaults"]
+    assert ModelConfig.load(CONFIG_PATH).to_dict() == ref["shipped"]
+    legacy = {"sample_rate": 22050, "num_mels": 64, "spec_width": 256, "fft_length": 512, "chunk_duration": 3, "hop_length": 258,
+              "audio_frontend": "hybrid", "mag_scale": "pwl", "embeddings_size": 256, "alpha": 1.0, "depth_multiplier": 1,
+              "num_classes": 2, "class_names": ["a", "b"], "some_unknown_key": 1}
+    assert ModelConfig.from_dict(legacy).to_dict() == ref["legacy_dict"]
+    cases = {"neg_sr": {"sample_rate": -1}, "bad_frontend": {"audio_frontend": "nope"}, "bad_mag": {"mag_scale": "log"},
+             "dm0": {"depth_multiplier": 0}, "drop1": {"dropout_rate": 1.0}, "names": {"num_classes": 3, "class_names": ["a"]}}
+    for label, kw in cases.items():
+        with pytest.raises(ValueError) as e:
+            ModelConfig(**kw)
+        assert str(e.value) == ref["errors"][label]
+
+
+# ---------------------------------------------------------------- the reference's firmware C (oracle/_ref)
+def _firmware():
+    from oracle import cport
+
+    if not os.path.isfile(cport.FW_LIB):
+        pytest.skip("oracle/_ref/libfw_ref.so not built (needs /root/reference at build time)")
+    return cport.FirmwareRef()
+
+
+def test_fft_against_reference_firmware():
+    """KAT 7: firmware fft_512_real == numpy rfft (butterfly-level pin of the FFT restatement)."""
+    fw = _firmware()
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        x = rng.standard_normal(512).astype(np.float32)
+        ref = np.fft.rfft(x.astype(np.float64))
+        assert np.abs(fw.fft_512_real(x) - ref).max() < 2e-6 * np.abs(ref).max() + 2e-5
+
+
+def test_firmware_stft_is_a_different_framing():
+    """SURVEY finding 9: the firmware STFT (no centre pad, symmetric Hann) matches a numpy STFT with ITS framing,
+    and differs from the evaluate-path framing the oracle implements."""
+    fw = _firmware()
+    from oracle import stft
+
+    x = fixture_signals(22050)["noise"]
+    hop, W = 258, 256
+    got = fw.stft_magnitude(x, hop, W)
+    win = 0.5 * (1 - np.cos(2 * np.pi * np.arange(512) / 511))
+    idx = np.arange(512)[None, :] + hop * np.arange(W)[:, None]
+    xp = np.concatenate([x, np.zeros(512, np.float32)])
+    own = np.abs(np.fft.rfft(xp[idx] * win, axis=1)).T
+    assert np.abs(got - own).max() < 5e-6 * own.max() + 1e-5
+    ev = stft.stft_magnitude(x, 512, hop)[:, :W]
+    assert cosine(got, ev) < 0.95
+
+
+def test_mel_against_reference_firmware():
+    fw = _firmware()
+    from oracle.melbank import mel_filterbank
+
+    for sr in (22050, 24000):
+        ref = fw.mel_matrix(64, sr, 150.0, float(sr // 2))
+        ours = mel_filterbank(sr, 512, 64, 150.0, float(sr // 2))
+        assert np.abs(ref - ours).max() < 5e-7
+
+
+def test_c_port_matches_numpy_oracle(netspec):
+    from oracle import cport, float_graph, stft
+
+    if not os.path.isfile(cport.CPU_LIB):
+        pytest.skip("oracle/_build/liboracle_cpu.so not built")
+    x = synth_chunks(4)
+    scores, logits, S = cport.CpuFloatPath(netspec)(x)
+    Sref = np.stack([stft.hybrid_spectrogram(a) for a in x])
+    assert np.abs(S - Sref).max() < 2e-6
+    p, l = float_graph.forward(netspec, Sref[..., None], np.float64, return_logits=True)
+    assert np.abs(scores - p).max() < 1e-5
+    assert min(cosine(logits[b], l[b]) for b in range(4)) > 1 - 1e-6
