@@ -185,3 +185,145 @@ def test_i8_from_audio_top1_and_cosine(torch_mod, audio24, oracle_specs):
         assert cosine(logits[b], ref_logits[b]) >= 0.999
         assert logits[b].argmax() == ref_logits[b].argmax()
     runner.close()
+
+
+# ------------------------------------------------------------------- topologies built by current reference code
+@pytest.mark.parametrize(
+    "kw",
+    [
+        dict(),  # defaults: inverted residual + SE, softmax head, per-sample max-normalised hybrid frontend
+        dict(use_inverted_residual=False, use_se=True, embeddings_size=128, use_attention_pooling=True, class_activation="sigmoid"),
+        dict(alpha=1.5, mag_scale="pcen", num_classes=37),
+        dict(use_se=False, depth_multiplier=2, alpha=0.5, mag_scale="none"),
+    ],
+    ids=["ir_se_default", "ds_se_attnpool_emb", "alpha1.5_pcen", "ir_nose_deep_narrow"],
+)
+def test_f32_current_code_topologies(torch_mod, oracle_specs, kw):
+    """SE, inverted residuals, embedding conv, attention pooling, PCEN/none scaling, frontend max-norm: per layer vs the oracle."""
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle import float_graph
+
+    args = dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=10, randomize_bn=True, seed=7)
+    args.update(kw)
+    spec = build_model("dscnn", **args)
+    x = oracle_specs[:4, ..., None]
+    ref_scores, ref_logits, acts = float_graph.forward(spec, x, np.float64, return_all=True, return_logits=True)
+    runner = HipRunner(lower_f32(spec, keep_all=True), max_batch=4)
+    got = runner.predict(x)
+    for oi, op in enumerate(runner.plan.ops):
+        if op.out < 0 or op.name not in acts:
+            continue
+        a = runner.op_output(oi, 4)
+        r = acts[op.name].reshape(a.shape)
+        err = np.abs(a - r).max() / (np.abs(r).max() + 1e-12)
+        assert err < 5e-4, f"layer {op.name}: relative-to-peak error {err:.3e}"
+    assert np.abs(got - ref_scores).max() < 1e-4
+    for b in range(4):
+        assert 1.0 - cosine(got[b], ref_scores[b]) < 1e-5
+    runner.close()
+    # the production plan (slots recycled) gives the same scores as the keep-everything debug plan
+    runner = HipRunner(lower_f32(spec), max_batch=4)
+    assert np.array_equal(runner.predict(x), got)
+    runner.close()
+
+
+# --------------------------------------------------------------------------------- full-size properties
+def test_full_batch_properties(torch_mod):
+    """BASELINE sizes (B=1024 float32, B=4096 INT8) through size-independent properties: the result of a chunk does not
+    depend on its batch neighbours, position or batch slicing, and repeated runs are bit-identical."""
+    torch = torch_mod
+    from birdnet_stm32.models.runners import load_model_runner
+
+    base = torch.from_numpy(synth_chunks(64)).cuda()
+    for path, B in ((KERAS_PATH, 1024), (TFLITE_PATH, 4096)):
+        runner = load_model_runner(path, max_batch=B)
+        idx = torch.randint(0, 64, (B,), generator=torch.Generator().manual_seed(1)).cuda()
+        audio = base[idx].contiguous()
+        s1 = runner.infer_audio_device(audio).clone()
+        s2 = runner.infer_audio_device(audio)
+        assert torch.equal(s1, s2), "run-to-run determinism"
+        small = load_model_runner(path, max_batch=96)  # different workspace, batch processed in slices of 96
+        ref64 = small.infer_audio_device(base)
+        assert torch.equal(s1, ref64[idx]), "a chunk's scores depend on its batch position / neighbours"
+        assert torch.isfinite(s1).all() and float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+        small.close()
+        runner.close()
+
+
+def test_empty_and_single_batches(torch_mod):
+    torch = torch_mod
+    from birdnet_stm32.models.runners import load_model_runner
+
+    runner = load_model_runner(TFLITE_PATH, max_batch=8)
+    assert runner.predict(np.zeros((0, 257, 256, 1), np.float32)).shape == (0, 100)
+    one = runner.predict(np.zeros((1, 257, 256, 1), np.float32))
+    assert one.shape == (1, 100) and one.dtype == np.float32
+    with pytest.raises(ValueError, match="expected input of shape"):
+        runner.predict(np.zeros((2, 128, 256, 1), np.float32))
+    big = runner.predict(np.tile(np.zeros((1, 257, 256, 1), np.float32), (19, 1, 1, 1)))  # > max_batch: sliced like resize_tensor_input
+    assert np.array_equal(big, np.tile(one, (19, 1)))
+    runner.close()
+
+
+# ------------------------------------------------------------------------------------ evaluate on the GPU
+def test_evaluate_device_pipeline_matches_reference_loop(torch_mod, tmp_path):
+    """evaluate(): the cross-file device pipeline gives the per-file scores of the reference-style per-file loop."""
+    from birdnet_stm32.audio.io import save_wav
+    from birdnet_stm32.evaluation.metrics import evaluate
+    from birdnet_stm32.models.runners import load_model_runner
+    from birdnet_stm32.training.config import ModelConfig
+
+    from conftest import CONFIG_PATH
+
+    cfg = ModelConfig.load(CONFIG_PATH).to_dict()
+    cfg.update(sample_rate=24000, hop_length=281)
+    classes = cfg["class_names"]
+    x = synth_chunks(16)
+    files = []
+    for i in range(16):
+        d = tmp_path / classes[i % 3]
+        d.mkdir(exist_ok=True)
+        n = 72000 if i % 4 else 72000 * 2 + 30000  # some files hold 3 chunks (2 full + tail)
+        wav = np.concatenate([x[i], x[(i + 1) % 16], x[(i + 2) % 16]])[:n]
+        save_wav(wav, str(d / f"f{i}.wav"), 24000, subtype="FLOAT")
+        files.append(str(d / f"f{i}.wav"))
+    runner = load_model_runner(TFLITE_PATH, max_batch=16)
+    m_dev, pf_dev, yt, ys_dev = evaluate(runner, files, classes, cfg, pooling="lme", batch_size=5, measure_latency=True)
+    m_ref, pf_ref, _, ys_ref = evaluate(runner, files, classes, cfg, pooling="lme", batch_size=5, measure_latency=True, device_pipeline=False)
+    assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
+    assert m_dev["total_chunks"] == m_ref["total_chunks"] == 12 + 4 * 3
+    np.testing.assert_allclose(ys_dev, ys_ref, atol=1.5 / 256)  # host-normalised float spectrograms vs normalise-at-load: <= 1 LSB of the int8 sigmoid
+    assert (ys_dev.argmax(axis=1) == ys_ref.argmax(axis=1)).mean() >= 0.9
+    for k in ("latency_mean_ms", "latency_p99_ms"):
+        assert m_dev[k] > 0 and m_ref[k] > 0
+    runner.close()
+
+
+def test_cli_evaluate_benchmark_latency(torch_mod, tmp_path):
+    """`python -m birdnet_stm32 evaluate --benchmark_latency` on 16 synthetic 3 s @ 24 kHz WAVs (BASELINE configs[0], on the GPU)."""
+    import json
+    import subprocess
+    import sys
+
+    from birdnet_stm32.audio.io import save_wav
+
+    from conftest import CONFIG_PATH, PKG
+
+    cfg = json.load(open(CONFIG_PATH))
+    cfg.update(sample_rate=24000, hop_length=281)
+    (tmp_path / "model_cfg.json").write_text(json.dumps(cfg))
+    x = synth_chunks(16)
+    for i in range(16):
+        d = tmp_path / "data" / cfg["class_names"][i % 4]
+        d.mkdir(parents=True, exist_ok=True)
+        save_wav(x[i], str(d / f"c{i}.wav"), 24000)
+    out = tmp_path / "bench.json"
+    cmd = [sys.executable, "-m", "birdnet_stm32", "evaluate", "--model_path", TFLITE_PATH, "--model_config", str(tmp_path / "model_cfg.json"),
+           "--data_path_test", str(tmp_path / "data"), "--benchmark_latency", "--benchmark", str(out), "--batch_size", "16"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(__import__("os").environ, PYTHONPATH=PKG), timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "latency_mean_ms" in res.stdout and "Evaluated 16 files across 100 classes." in res.stdout
+    rep = json.loads(out.read_text())
+    assert rep["num_files"] == 16 and rep["metrics"]["total_chunks"] == 16 and rep["metrics"]["latency_p95_ms"] > 0
