@@ -71,6 +71,10 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
         return batch * (p[0] * p[1] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2]
     if k in ("f32_dw", "i8_dw"):
         return batch * (p[0] * p[1] * p[2] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2]
+    if k == "f32_dwpw":
+        n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[10]
+        macs = p[6] * p[7] * p[2] * (p[10] + (9 if p[15] else 0))
+        return batch * 4.0 * (n_in + n_out * (2 if p[12] else 1)), batch * 2.0 * macs
     if k == "f32_pw":
         return batch * (p[0] * p[1] * 4 + p[0] * p[2] * 4 * (2 if p[4] else 1)), batch * 2.0 * p[0] * p[1] * p[2]
     if k == "i8_pw":
@@ -95,7 +99,7 @@ def roofline_of(rows: list[dict], batch: int, dtype: str) -> tuple[dict, list[di
     peak_compute = F32_MFMA_PEAK_TFLOPS if dtype == "f32" else I8_MFMA_PEAK_TOPS
     ridge = peak_compute * 1e12 / (HBM_PEAK_GBS * 1e9)
     intensity = dom["ops"] / max(dom["bytes"], 1.0)
-    if intensity > ridge and dom["kernel"].endswith("_pw"):
+    if intensity > ridge and dom["kernel"].endswith("pw"):
         roof = {"bound": "mfma", "achieved": dom["Tops"], "peak": peak_compute, "unit": "TFLOP/s" if dtype == "f32" else "TOP/s"}
     else:
         roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"}

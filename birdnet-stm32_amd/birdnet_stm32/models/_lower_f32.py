@@ -72,8 +72,29 @@ def mag_params(front: ns.Layer) -> np.ndarray:
     return np.stack([np.asarray(r, np.float32).reshape(M) for r in rows])
 
 
-def lower_f32(spec: ns.NetSpec, keep_all: bool = False) -> pk.Plan:
-    """Build the float32 plan for ``spec``.  ``keep_all`` disables slot reuse (debug/tests)."""
+def pick_tile(oh: int, ow: int):
+    """64 output positions per workgroup: a TH x TW tile of one chunk, or whole small maps of NB chunks."""
+    if oh * ow >= 64:
+        for th, tw in ((8, 8), (4, 16), (16, 4), (2, 32), (32, 2), (1, 64), (64, 1)):
+            if oh % th == 0 and ow % tw == 0:
+                return th, tw, 1
+        return None
+    if 64 % (oh * ow) == 0:
+        return oh, ow, 64 // (oh * ow)
+    return None
+
+
+def pack_pw_fragments(w: np.ndarray) -> np.ndarray:
+    """``[Cin][Cout]`` -> ``[Cin/16][Cout/16][64 lanes][4]``: lane (q = l >> 4, c = l & 15) of k-step j holds
+    ``W[16 j + 4 q + e][16 ct + c]`` for e = 0..3 — the B operands of four consecutive ``mfma_f32_16x16x4``."""
+    cin, cout = w.shape
+    t = w.reshape(cin // 16, 4, 4, cout // 16, 16)  # [j][q][e][ct][c]
+    return np.ascontiguousarray(t.transpose(0, 3, 1, 4, 2)).reshape(cin // 16, cout // 16, 64, 4).astype(np.float32)
+
+
+def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
+    """Build the float32 plan for ``spec``.  ``keep_all`` disables slot reuse (debug/tests); ``fuse=False`` keeps
+    depthwise and pointwise convolutions as separate baseline kernels instead of the fused matrix-core block."""
     layers = spec.layers
     consumers: dict[str, list[int]] = {}
     index_of = {ly.name: i for i, ly in enumerate(layers)}
@@ -161,10 +182,29 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False) -> pk.Plan:
                 C = Cin
                 if C % 4:
                     raise NotImplementedError("channel counts must be multiples of 4")
-                v = pb.value(OH * OW * C * 4)
-                pb.op(pk.F32_DW, val[src], v, p=[H, Wd, C, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl],
-                      t=[pb.tensor(w, np.float32), pb.tensor(b, np.float32)], name=last, out_shape=(OH, OW, C))
-                out_shape = (OH, OW, C)
+                nxt_i = only_consumer(last)
+                nxt = layers[nxt_i] if nxt_i is not None else None
+                tile = pick_tile(OH, OW)
+                fusable = (fuse and nxt is not None and nxt.kind == ns.CONV and tuple(nxt.attrs["kernel"]) == (1, 1)
+                           and tuple(nxt.attrs["strides"]) == (1, 1) and tile is not None and C % 16 == 0
+                           and int(nxt.attrs["filters"]) % 16 == 0)
+                if fusable:
+                    bn2, res2, act2, last2 = chain_after(nxt_i, nxt.name)
+                    w2, b2 = fold_bn(nxt.weights["kernel"], bn2)
+                    Cout = w2.shape[-1]
+                    v = pb.value(OH * OW * Cout * 4)
+                    p = [H, Wd, C, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl, Cout, pk.ACT_CODES[act2], int(res2 is not None), 0, 0, 1, *tile]
+                    pb.op(pk.F32_DWPW, val[src], v, p=p,
+                          t=[pb.tensor(w, np.float32), pb.tensor(b, np.float32), pb.tensor(pack_pw_fragments(w2[0, 0]), np.float32),
+                             pb.tensor(b2, np.float32)],
+                          in1=val[res2] if res2 is not None else pk.SLOT_NONE, name=last2, out_shape=(OH, OW, Cout))
+                    out_shape = (OH, OW, Cout)
+                    last = last2
+                else:
+                    v = pb.value(OH * OW * C * 4)
+                    pb.op(pk.F32_DW, val[src], v, p=[H, Wd, C, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl],
+                          t=[pb.tensor(w, np.float32), pb.tensor(b, np.float32)], name=last, out_shape=(OH, OW, C))
+                    out_shape = (OH, OW, C)
             elif (kh, kw) == (3, 3):
                 if Cin != 1 or res is not None:
                     raise NotImplementedError(f"{ly.name}: 3x3 convolutions are only lowered for the 1-channel stem")
@@ -183,11 +223,20 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False) -> pk.Plan:
                 else:
                     x_val, gate_val = val[src], None
                 v = pb.value(P * Cout * 4)
-                p = [P, Cin, Cout, pk.ACT_CODES[act], int(res is not None), int(gate_val is not None),
-                     gate_val if gate_val is not None else 0]
-                pb.op(pk.F32_PW, x_val, v, p=p, t=[pb.tensor(w[0, 0], np.float32), pb.tensor(b, np.float32)],
-                      in1=val[res] if res is not None else pk.SLOT_NONE, name=last, out_shape=(H, Wd, Cout),
-                      value_params=(6,) if gate_val is not None else ())
+                tile = pick_tile(H, Wd)
+                if fuse and tile is not None and Cin % 16 == 0 and Cout % 16 == 0:
+                    p = [H, Wd, Cin, 1, 1, 0, H, Wd, 0, 0, Cout, pk.ACT_CODES[act], int(res is not None), int(gate_val is not None),
+                         gate_val if gate_val is not None else 0, 0, *tile]
+                    zero = pb.tensor(np.zeros(4, np.float32), np.float32)
+                    pb.op(pk.F32_DWPW, x_val, v, p=p, t=[zero, zero, pb.tensor(pack_pw_fragments(w[0, 0]), np.float32), pb.tensor(b, np.float32)],
+                          in1=val[res] if res is not None else pk.SLOT_NONE, name=last, out_shape=(H, Wd, Cout),
+                          value_params=(14,) if gate_val is not None else ())
+                else:
+                    p = [P, Cin, Cout, pk.ACT_CODES[act], int(res is not None), int(gate_val is not None),
+                         gate_val if gate_val is not None else 0]
+                    pb.op(pk.F32_PW, x_val, v, p=p, t=[pb.tensor(w[0, 0], np.float32), pb.tensor(b, np.float32)],
+                          in1=val[res] if res is not None else pk.SLOT_NONE, name=last, out_shape=(H, Wd, Cout),
+                          value_params=(6,) if gate_val is not None else ())
                 out_shape = (H, Wd, Cout)
             else:
                 raise NotImplementedError(f"{ly.name}: kernel {kh}x{kw} stride {sh}x{sw}")

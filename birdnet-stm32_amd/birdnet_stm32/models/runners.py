@@ -182,7 +182,7 @@ def stft_device(ctx: _hip.Context, audio, n_fft: int = 512, hop: int | None = No
     return (spec, minmax) if return_minmax else spec
 
 
-def lower_model_file(model_path: str, keep_all: bool = False, frontend_norm: bool | None = None) -> pk.Plan:
+def lower_model_file(model_path: str, keep_all: bool = False, frontend_norm: bool | None = None, fuse: bool = True) -> pk.Plan:
     """Read a `.tflite` or `.keras` file and lower it to a device plan (no GPU needed)."""
     if model_path.lower().endswith(".tflite"):
         from birdnet_stm32.models._lower_i8 import lower_i8
@@ -192,10 +192,11 @@ def lower_model_file(model_path: str, keep_all: bool = False, frontend_norm: boo
     from birdnet_stm32.models._keras_loader import load_keras_archive
     from birdnet_stm32.models._lower_f32 import lower_f32
 
-    return lower_f32(load_keras_archive(model_path, frontend_norm=frontend_norm), keep_all=keep_all)
+    return lower_f32(load_keras_archive(model_path, frontend_norm=frontend_norm), keep_all=keep_all, fuse=fuse)
 
 
 def load_model_runner(model_path: str, device: int = 0, max_batch: int = 1024, keep_all: bool = False,
-                      frontend_norm: bool | None = None) -> HipRunner:
+                      frontend_norm: bool | None = None, fuse: bool = True) -> HipRunner:
     """Load a `.keras` or `.tflite` model and return a runner with ``predict()`` (reference :98-114)."""
-    return HipRunner(lower_model_file(model_path, keep_all=keep_all, frontend_norm=frontend_norm), device=device, max_batch=max_batch)
+    plan = lower_model_file(model_path, keep_all=keep_all, frontend_norm=frontend_norm, fuse=fuse)
+    return HipRunner(plan, device=device, max_batch=max_batch)

@@ -156,6 +156,24 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                   p[5] ? (const float*)slot_ptr(p[6]) : nullptr, (float*)out, B, p[0], p[1], p[2], p[3],
                                   (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
                 break;
+            case BN_OP_F32_DWPW: {
+                bn::DwPwArgs a{};
+                a.x = (const float*)in0;
+                a.res = p[12] ? (const float*)in1 : nullptr;
+                a.gate = p[13] ? (const float*)slot_ptr(p[14]) : nullptr;
+                a.y = (float*)out;
+                a.dw_w = (const float*)m->tensor(o.t[0]);
+                a.dw_b = (const float*)m->tensor(o.t[1]);
+                a.pw_w = (const float*)m->tensor(o.t[2]);
+                a.pw_b = (const float*)m->tensor(o.t[3]);
+                a.B = B; a.H = p[0]; a.W = p[1]; a.Cin = p[2]; a.sh = p[3]; a.sw = p[4]; a.dw_act = p[5];
+                a.OH = p[6]; a.OW = p[7]; a.pt = p[8]; a.pl = p[9]; a.Cout = p[10]; a.pw_act = p[11];
+                a.has_dw = p[15]; a.TH = p[16]; a.TW = p[17]; a.NB = p[18];
+                if (!bn::f32_dwpw_supported(a.Cin, a.Cout) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
+                    return fail(BN_ERR_FORMAT, "operator %zu: unsupported fused block geometry", oi);
+                bn::launch_f32_dwpw(a, s);
+                break;
+            }
             case BN_OP_F32_SEGATE:
                 bn::launch_f32_segate((const float*)in0, (float*)out, B, p[0], p[1], p[2],
                                       (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
@@ -498,7 +516,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 
 const char* bn_kernel_names(void) {
     return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_mag_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
-           "f32_pw_kernel\nf32_gap_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
+           "f32_pw_kernel\nf32_dwpw_kernel\nf32_gap_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";
 }

@@ -91,6 +91,10 @@ enum BnOpKind : int32_t {
     BN_OP_F32_DENSE = 10,
     // [P][C] -> [C]  p: P C   t: score[C]
     BN_OP_F32_ATTNPOOL = 11,
+    // fused [depthwise 3x3 ->] pointwise 1x1 on the matrix cores; has_dw = 0: plain 1x1 conv of in0
+    // p: H W Cin sh sw dw_act OH OW pad_top pad_left | Cout pw_act has_res has_gate gate_slot has_dw TH TW NB
+    // in1: residual slot   t: dw_w[3][3][Cin] dw_b[Cin] pw_w(fragment order [Cin/16][Cout/16][64][4]) pw_b[Cout]
+    BN_OP_F32_DWPW = 12,
 
     // ---- INT8 plan -----------------------------------------------------------------
     // spec f32 [F][W] -> q int8 [W][Kp]   p: F W Kp zp fill   f: scale

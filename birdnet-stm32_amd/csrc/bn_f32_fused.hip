@@ -1,0 +1,268 @@
+// bn_f32_fused.hip — float32 depthwise-separable block as ONE kernel on gfx950:
+//
+//     [depthwise 3x3 (+folded BN bias, ReLU6)]  ->  LDS tile  ->  pointwise 1x1 on the matrix cores
+//                                                    (+folded BN bias, +residual, ReLU6)
+//
+// Reference semantics: ds_conv_block of birdnet_stm32/models/dscnn.py:28-84 (DW -> BN -> ReLU6 -> PW -> BN
+// [-> Add] -> ReLU6), and any plain 1x1 convolution (inverted-residual expand/project, embedding conv:
+// birdnet_stm32/models/blocks.py:88-131, dscnn.py:248-253) with the depthwise stage switched off.
+//
+// One 256-thread workgroup owns 64 output positions (a TH x TW spatial tile of NB chunks, TH*TW*NB = 64)
+// and all Cout channels:
+//   phase 1 (vector ALU): the depthwise outputs of the tile, [64][Cin] float32, are computed straight
+//           from the NHWC input (float4 over channels) into LDS — they never touch HBM;
+//   phase 2 (matrix cores): v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).  A fragments come from the LDS tile
+//           as one ds_read_b128 per 16 contraction channels; B fragments come from the weight matrix that
+//           the packer stored in fragment order, so each wave-instruction reads 1 KiB contiguous from L2.
+// The contraction index inside each group of 16 channels is permuted identically for A and B
+// (k = 16 j + 4 (lane >> 4) + e for the e-th MFMA), which only re-orders the float32 summation.
+#include "bn_kernels.h"
+
+namespace bn {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_f(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return fminf(fmaxf(v, 0.0f), 6.0f);
+    return v;
+}
+
+constexpr int kKC = 256;  // contraction channels staged in LDS at a time
+
+// Per-position bookkeeping, computed once per workgroup (integer divisions are costly on the vector ALU).
+struct PosInfo {
+    int in_base;   // element offset of tap (0,0) of this position in x (may point outside the image: see mask)
+    int out_base;  // element offset of channel 0 of this position in y / res, or -1 if the chunk is out of range
+    int mask;      // bit t set = tap t (t = 3 i + j) lies inside the image
+    int pad;
+};
+
+template <int RG, int CT, bool HAS_DW>
+__global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    __shared__ PosInfo pos[64];
+    f32x4* lds4 = reinterpret_cast<f32x4*>(lds_raw);  // activation tile [64][kc/4 + 1] float4, later the output tile
+    const int K = a.Cin, N = a.Cout;
+    const int tid = threadIdx.x;
+
+    // ---- which 64 positions -------------------------------------------------------------------------
+    if (tid < 64) {
+        const int tiles_x = a.OW / a.TW, tiles_y = a.OH / a.TH;
+        int bid = blockIdx.x;
+        const int tx0 = (bid % tiles_x) * a.TW;
+        bid /= tiles_x;
+        const int ty0 = (bid % tiles_y) * a.TH;
+        const int chunk0 = (bid / tiles_y) * a.NB;
+        const int tile_hw = a.TH * a.TW;
+        const int nb = tid / tile_hw, rr = tid - nb * tile_hw;
+        const int oh = ty0 + rr / a.TW, ow = tx0 + rr % a.TW;
+        const int chunk = chunk0 + nb;
+        PosInfo pi;
+        pi.pad = 0;
+        pi.out_base = chunk < a.B ? ((chunk * a.OH + oh) * a.OW + ow) * N : -1;
+        const int ih0 = oh * a.sh - a.pt, iw0 = ow * a.sw - a.pl;
+        pi.in_base = ((chunk * a.H + ih0) * a.W + iw0) * K;
+        int mask = 0;
+        if (chunk < a.B) {
+            if (HAS_DW) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (ih0 + i >= 0 && ih0 + i < a.H && iw0 + j >= 0 && iw0 + j < a.W) mask |= 1 << (i * 3 + j);
+            } else {
+                mask = 1;
+            }
+        }
+        pi.mask = mask;
+        pos[tid] = pi;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    constexpr int WM = 4 / RG;  // waves along the 64 rows (RG row groups of 16 per wave), RG waves along the columns
+    const int wm = wave % WM, wn = wave / WM;
+    const int row0 = wm * RG * 16;
+    const int ct0 = blockIdx.y * (RG * CT) + wn * CT;  // first 16-column tile of this wave (blockIdx.y = column slice)
+    const int n_ct = N >> 4;                           // column tiles in the packed weights
+
+    f32x4 acc[RG][CT];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.pw_w);  // [K/16][N/16][64 lanes] float4
+
+    for (int k0 = 0; k0 < K; k0 += kKC) {
+        const int kc = (K - k0) < kKC ? (K - k0) : kKC;
+        const int kq = kc >> 2;   // float4 groups per position
+        const int S4 = kq + 1;    // row stride of the tile in float4 units (one float4 of padding)
+        if (k0) __syncthreads();  // the previous slice's fragments have been read
+
+        // ---- phase 1: fill the LDS tile [64][kc] ---------------------------------------------------------
+        // 256 % kq == 0 (kc in {16,32,64,128,256}): a thread keeps one channel quad and walks positions, so the
+        // nine depthwise weights stay in registers; otherwise items are dealt round-robin.
+        const bool fixed_cq = (256 % kq) == 0;
+        const int items = 64 * kq;
+        const int cq_fixed = tid % kq;
+        float4 wgt[9];
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HAS_DW && fixed_cq) {
+            bias = *reinterpret_cast<const float4*>(a.dw_b + k0 + 4 * cq_fixed);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wgt[t] = *reinterpret_cast<const float4*>(a.dw_w + t * K + k0 + 4 * cq_fixed);
+        }
+        for (int item = tid; item < items; item += 256) {
+            const int p = item / kq;  // power-of-two kq in the fixed case: a shift
+            const int cq = fixed_cq ? cq_fixed : item - p * kq;
+            const PosInfo pi = pos[p];
+            float4 accv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HAS_DW) {
+                if (!fixed_cq) {
+                    bias = *reinterpret_cast<const float4*>(a.dw_b + k0 + 4 * cq);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) wgt[t] = *reinterpret_cast<const float4*>(a.dw_w + t * K + k0 + 4 * cq);
+                }
+                const float* xin = a.x + (long)pi.in_base + k0 + 4 * cq;
+                float4 v9[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int t = i * 3 + j;
+                        v9[t] = (pi.mask >> t) & 1 ? *reinterpret_cast<const float4*>(xin + (i * a.W + j) * K)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                accv = bias;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    accv.x = fmaf(v9[t].x, wgt[t].x, accv.x);
+                    accv.y = fmaf(v9[t].y, wgt[t].y, accv.y);
+                    accv.z = fmaf(v9[t].z, wgt[t].z, accv.z);
+                    accv.w = fmaf(v9[t].w, wgt[t].w, accv.w);
+                }
+                accv.x = act_f(accv.x, a.dw_act);
+                accv.y = act_f(accv.y, a.dw_act);
+                accv.z = act_f(accv.z, a.dw_act);
+                accv.w = act_f(accv.w, a.dw_act);
+                if (pi.mask == 0) accv = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (pi.mask) {
+                accv = *reinterpret_cast<const float4*>(a.x + (long)pi.in_base + k0 + 4 * cq);
+                if (a.gate) {
+                    const int chunk = pi.in_base / (a.H * a.W * K);
+                    const float4 g = *reinterpret_cast<const float4*>(a.gate + (size_t)chunk * K + k0 + 4 * cq);
+                    accv.x *= g.x;
+                    accv.y *= g.y;
+                    accv.z *= g.z;
+                    accv.w *= g.w;
+                }
+            }
+            lds4[p * S4 + cq] = (f32x4){accv.x, accv.y, accv.z, accv.w};
+        }
+        __syncthreads();
+
+        // ---- phase 2: [64 x kc] x [kc x N] on the matrix cores, B fragments one k-step ahead -------------
+        const int ksteps = kc >> 4, j0 = k0 >> 4;
+        f32x4 bf[CT], bnext[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) bf[c] = wp[((size_t)j0 * n_ct + ct0 + c) * 64 + lane];
+        for (int j = 0; j < ksteps; ++j) {
+            if (j + 1 < ksteps) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) bnext[c] = wp[((size_t)(j0 + j + 1) * n_ct + ct0 + c) * 64 + lane];
+            }
+            f32x4 af[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) af[g] = lds4[(row0 + 16 * g + r) * S4 + 4 * j + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bf[c][e], acc[g][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) bf[c] = bnext[c];
+        }
+    }
+
+    // ---- epilogue: accumulators -> LDS [64][NS + 4] -> bias, residual, activation -> whole-row stores --------
+    constexpr int NS = RG * CT * 16;  // columns of this workgroup's slice
+    constexpr int SO = NS + 4;
+    __syncthreads();                  // everyone is done reading the activation tile
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) lds_raw[(row0 + 16 * g + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[g][c][reg];
+    __syncthreads();
+    const int n_base = blockIdx.y * NS;
+    constexpr int Q4 = NS / 4;  // float4 per row
+    for (int item = tid; item < 64 * Q4; item += 256) {
+        const int p = item / Q4, c4 = item - p * Q4;
+        const int ob = pos[p].out_base;
+        if (ob < 0) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds_raw + p * SO + 4 * c4);
+        const float4 b = *reinterpret_cast<const float4*>(a.pw_b + n_base + 4 * c4);
+        float4 o = make_float4(v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w);
+        const long off = (long)ob + n_base + 4 * c4;
+        if (a.res) {
+            const float4 rv = *reinterpret_cast<const float4*>(a.res + off);
+            o.x += rv.x;
+            o.y += rv.y;
+            o.z += rv.z;
+            o.w += rv.w;
+        }
+        o.x = act_f(o.x, a.pw_act);
+        o.y = act_f(o.y, a.pw_act);
+        o.z = act_f(o.z, a.pw_act);
+        o.w = act_f(o.w, a.pw_act);
+        *reinterpret_cast<float4*>(a.y + off) = o;
+    }
+}
+
+template <int RG, int CT>
+void launch_cfg(const DwPwArgs& a, hipStream_t s) {
+    const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * ((a.B + a.NB - 1) / a.NB);
+    const int slices = (a.Cout / 16) / (RG * CT);
+    const int kc = a.Cin < kKC ? a.Cin : kKC, ns = RG * CT * 16;
+    const size_t smem = (size_t)64 * ((kc > ns ? kc : ns) + 4) * sizeof(float);
+    if (a.has_dw)
+        hipLaunchKernelGGL((f32_dwpw_kernel<RG, CT, true>), dim3(tiles, slices), dim3(256), smem, s, a);
+    else
+        hipLaunchKernelGGL((f32_dwpw_kernel<RG, CT, false>), dim3(tiles, slices), dim3(256), smem, s, a);
+}
+
+}  // namespace
+
+bool f32_dwpw_supported(int Cin, int Cout) { return Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 16 && Cin <= 2048; }
+
+// Each workgroup covers RG*CT column tiles of 16 (4 waves = (4/RG) along the 64 rows x RG along the columns);
+// wider layers are cut into column slices (grid.y), each recomputing the cheap depthwise stage.
+void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s) {
+    const int ct_total = a.Cout / 16;
+    static const int kSlices[] = {24, 16, 12, 8, 6, 4, 3, 2, 1};
+    int slice = 1;
+    for (int v : kSlices)
+        if (ct_total % v == 0) {
+            slice = v;
+            break;
+        }
+    switch (slice) {
+        case 24: launch_cfg<4, 6>(a, s); break;
+        case 16: launch_cfg<4, 4>(a, s); break;
+        case 12: launch_cfg<4, 3>(a, s); break;
+        case 8: launch_cfg<4, 2>(a, s); break;
+        case 6: launch_cfg<2, 3>(a, s); break;
+        case 4: launch_cfg<4, 1>(a, s); break;
+        case 3: launch_cfg<1, 3>(a, s); break;
+        case 2: launch_cfg<2, 1>(a, s); break;
+        default: launch_cfg<1, 1>(a, s); break;
+    }
+}
+
+}  // namespace bn

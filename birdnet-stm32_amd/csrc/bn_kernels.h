@@ -37,6 +37,21 @@ void launch_f32_dense(const float* x, float* scores, float* logits, int B, int C
                       const float* bias, hipStream_t s);
 void launch_f32_attnpool(const float* x, float* y, int B, int P, int C, const float* score, hipStream_t s);
 
+// Fused depthwise 3x3 -> pointwise 1x1 block (bn_f32_fused.hip); has_dw = 0 gives a plain 1x1 convolution.
+struct DwPwArgs {
+    const float* x;      // [B][H][W][Cin]
+    const float* res;    // [B][OH][OW][Cout] or null
+    const float* gate;   // [B][Cin] or null (squeeze-excite gate; only without the depthwise stage)
+    float* y;            // [B][OH][OW][Cout]
+    const float* dw_w;   // [3][3][Cin]
+    const float* dw_b;   // [Cin]
+    const float* pw_w;   // fragment order [Cin/16][Cout/16][64][4]
+    const float* pw_b;   // [Cout]
+    int B, H, W, Cin, Cout, sh, sw, pt, pl, OH, OW, TH, TW, NB, dw_act, pw_act, has_dw;
+};
+bool f32_dwpw_supported(int Cin, int Cout);
+void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s);
+
 // ---- INT8 plan -----------------------------------------------------------------------------
 void launch_i8_quant(const float* spec, const float* minmax, int8_t* out, int B, int F, int W, int Kp, int zp,
                      int fill, float scale, hipStream_t s);
