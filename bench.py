@@ -75,6 +75,10 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
         n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[10]
         macs = p[6] * p[7] * p[2] * (p[10] + (9 if p[15] else 0))
         return batch * 4.0 * (n_in + n_out * (2 if p[12] else 1)), batch * 2.0 * macs
+    if k == "i8_dwpw":
+        n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[14]
+        macs = p[6] * p[7] * p[2] * (p[14] + (9 if p[29] else 0))
+        return batch * 1.0 * (n_in + n_out * (2 if p[18] else 1)), batch * 2.0 * macs
     if k == "f32_pw":
         return batch * (p[0] * p[1] * 4 + p[0] * p[2] * 4 * (2 if p[4] else 1)), batch * 2.0 * p[0] * p[1] * p[2]
     if k == "i8_pw":

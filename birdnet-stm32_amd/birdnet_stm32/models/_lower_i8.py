@@ -88,8 +88,22 @@ def _pwl_table(g: _Graph, ops: list, src: int, dst: int, channels: int) -> np.nd
     return env[dst].T.astype(np.int8).copy()  # [C][256]
 
 
-def lower_i8(model, keep_all: bool = False) -> pk.Plan:
-    """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse."""
+def pack_i8_fragments(w: np.ndarray) -> np.ndarray:
+    """``[Cout][Cin]`` int8 -> ``[Kp/64][Cout/16][64 lanes][16]``: lane (q = l >> 4, c = l & 15) of k-step s holds the 16
+    bytes ``W[16 ct + c][64 s + 16 q : +16]`` — the B operand of one ``v_mfma_i32_16x16x64_i8`` (K zero-padded to 64)."""
+    cout, cin = w.shape
+    kp = (cin + 63) // 64 * 64
+    wz = np.zeros((cout, kp), np.int8)
+    wz[:, :cin] = w
+    t = wz.reshape(cout // 16, 16, kp // 64, 4, 16)  # [ct][c][s][q][16]
+    return np.ascontiguousarray(t.transpose(2, 0, 3, 1, 4)).reshape(kp // 64, cout // 16, 64, 16)
+
+
+def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
+    """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse; ``fuse=False`` keeps the
+    baseline one-kernel-per-operator plan instead of the fused matrix-core blocks."""
+    from birdnet_stm32.models._lower_f32 import pick_tile
+
     g = _Graph(model)
     ops = model.ops
     t = g.t
@@ -172,8 +186,17 @@ def lower_i8(model, keep_all: bool = False) -> pk.Plan:
     tens = [pb.tensor(w_mel, np.int8), pb.tensor(bias, np.int32), pb.tensor(mult, np.int32), pb.tensor(shift, np.int32)]
     if lut is not None:
         tens.append(pb.tensor(lut, np.int8))
-    pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
-          out_shape=(M, W, 1), out_dtype="int8")
+    mel_tile = pick_tile(1, W)
+    if fuse and mel_tile is not None and M % 16 == 0:
+        zero = pb.tensor(np.zeros(4, np.int32), np.int32)
+        p = [1, W, Kp, 1, 1, 0, 1, W, 0, 0, 0, 0, 0, 0, M, z_mel, lo, hi, *([0] * 11), 0, 1, *mel_tile, int(lut is not None)]
+        tt = [zero, zero, zero, zero, pb.tensor(pack_i8_fragments(w_mel), np.int8), tens[1], tens[2], tens[3]]
+        if lut is not None:
+            tt.append(tens[4])
+        pb.op(pk.I8_DWPW, v_q, v, p=p, t=tt, name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
+    else:
+        pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
+              out_shape=(M, W, 1), out_dtype="int8")
     val = {cur: v}
     shape = {cur: (M, W, 1)}
 
@@ -213,12 +236,52 @@ def lower_i8(model, keep_all: bool = False) -> pk.Plan:
             sh_, sw_ = op.options["stride_h"], op.options["stride_w"]
             OH, pt, _ = same_pad(H, 3, sh_)
             OW, pl, _ = same_pad(Wd, 3, sw_)
-            v = pb.value(OH * OW * C)
-            pb.op(pk.I8_DW, val[src], v, p=[H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi],
-                  t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
-                  name=f"t{op.outputs[0]}", out_shape=(OH, OW, C), out_dtype="int8")
-            val[op.outputs[0]], shape[op.outputs[0]] = v, (OH, OW, C)
-            i += 1
+            nxt = ops[i + 1] if i + 1 < len(ops) else None
+            tile = pick_tile(OH, OW)
+            cons = g.consumers.get(op.outputs[0], [])
+            fusable = (fuse and nxt is not None and nxt.name == "CONV_2D" and cons == [nxt.index] and nxt.inputs[0] == op.outputs[0]
+                       and tuple(t[nxt.inputs[1]].shape[1:3]) == (1, 1) and nxt.options["stride_h"] == 1 and nxt.options["stride_w"] == 1
+                       and tile is not None and C % 4 == 0 and int(t[nxt.inputs[1]].shape[0]) % 16 == 0)
+            if fusable:
+                s2, z2, so2, zo2, wt2, Cout, mu2, sh2, lo2, hi2, b2 = conv_common(nxt)
+                w2 = wt2.data.reshape(Cout, C)
+                b2 = b2 - z2 * w2.astype(np.int64).sum(axis=1)
+                bdw = b - z_i * wt_.data[0].astype(np.int64).sum(axis=(0, 1))  # padded taps load zp_in, so the fold is uniform
+                _expect(np.abs(b2).max() < 2**31 and np.abs(bdw).max() < 2**31, "folded bias overflows int32")
+                add_p = [0] * 11
+                res_val = pk.SLOT_NONE
+                out_t = nxt.outputs[0]
+                nn = ops[i + 2] if i + 2 < len(ops) else None
+                cons2 = g.consumers.get(nxt.outputs[0], [])
+                if nn is not None and nn.name == "ADD" and cons2 == [nn.index] and nxt.outputs[0] in nn.inputs:
+                    other = [x for x in nn.inputs if x != nxt.outputs[0]]
+                    _expect(len(other) == 1 and other[0] in val and shape[other[0]] == (OH, OW, Cout), "residual ADD operand")
+                    s_r, z_r = g.q(other[0])
+                    s_a, z_a = g.q(nn.outputs[0])
+                    if nn.inputs[0] == other[0]:
+                        ap = qz.AddParams(s_r, z_r, so2, zo2, s_a, z_a, nn.options["activation"])
+                        add_p = [1, ap.z1, ap.m1, ap.sh1, ap.m2, ap.sh2, ap.mo, ap.sho, ap.zo, ap.amin, ap.amax]
+                    else:
+                        ap = qz.AddParams(so2, zo2, s_r, z_r, s_a, z_a, nn.options["activation"])
+                        add_p = [1, ap.z2, ap.m2, ap.sh2, ap.m1, ap.sh1, ap.mo, ap.sho, ap.zo, ap.amin, ap.amax]
+                    res_val = val[other[0]]
+                    out_t = nn.outputs[0]
+                    i += 1
+                v = pb.value(OH * OW * Cout)
+                p = [H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi, Cout, zo2, lo2, hi2, *add_p, 1, 0, *tile, 0]
+                pb.op(pk.I8_DWPW, val[src], v, p=p, in1=res_val,
+                      t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(bdw, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
+                         pb.tensor(pack_i8_fragments(w2), np.int8), pb.tensor(b2, np.int32), pb.tensor(mu2, np.int32), pb.tensor(sh2, np.int32)],
+                      name=f"t{out_t}", out_shape=(OH, OW, Cout), out_dtype="int8")
+                val[out_t], shape[out_t] = v, (OH, OW, Cout)
+                i += 2
+            else:
+                v = pb.value(OH * OW * C)
+                pb.op(pk.I8_DW, val[src], v, p=[H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi],
+                      t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                      name=f"t{op.outputs[0]}", out_shape=(OH, OW, C), out_dtype="int8")
+                val[op.outputs[0]], shape[op.outputs[0]] = v, (OH, OW, C)
+                i += 1
         elif op.name == "CONV_2D":
             H, Wd, Cin = shape[src]
             s_i, z_i, s_o, z_o, wt_, Cout, mu, sh, a_lo, a_hi, b = conv_common(op)

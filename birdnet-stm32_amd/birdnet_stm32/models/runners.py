@@ -188,7 +188,7 @@ def lower_model_file(model_path: str, keep_all: bool = False, frontend_norm: boo
         from birdnet_stm32.models._lower_i8 import lower_i8
         from birdnet_stm32.models._tflite_reader import load_tflite
 
-        return lower_i8(load_tflite(model_path), keep_all=keep_all)
+        return lower_i8(load_tflite(model_path), keep_all=keep_all, fuse=fuse)
     from birdnet_stm32.models._keras_loader import load_keras_archive
     from birdnet_stm32.models._lower_f32 import lower_f32
 

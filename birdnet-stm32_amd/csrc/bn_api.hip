@@ -217,6 +217,30 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                  (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]), s);
                 break;
             }
+            case BN_OP_I8_DWPW: {
+                bn::DwPw8Args a{};
+                a.x = (const int8_t*)in0;
+                a.res = p[18] ? (const int8_t*)in1 : nullptr;
+                a.y = (int8_t*)out;
+                a.dw_w = (const int8_t*)m->tensor(o.t[0]);
+                a.dw_b = (const int32_t*)m->tensor(o.t[1]);
+                a.dw_mult = (const int32_t*)m->tensor(o.t[2]);
+                a.dw_shift = (const int32_t*)m->tensor(o.t[3]);
+                a.pw_w = (const int8_t*)m->tensor(o.t[4]);
+                a.pw_b = (const int32_t*)m->tensor(o.t[5]);
+                a.pw_mult = (const int32_t*)m->tensor(o.t[6]);
+                a.pw_shift = (const int32_t*)m->tensor(o.t[7]);
+                a.lut = p[34] ? (const int8_t*)m->tensor(o.t[8]) : nullptr;
+                a.B = B; a.H = p[0]; a.W = p[1]; a.Cin = p[2]; a.sh = p[3]; a.sw = p[4]; a.OH = p[6]; a.OW = p[7];
+                a.pt = p[8]; a.pl = p[9]; a.dw_zp_in = p[10]; a.dw_zp_out = p[11]; a.dw_amin = p[12]; a.dw_amax = p[13];
+                a.Cout = p[14]; a.pw_zp_out = p[15]; a.pw_amin = p[16]; a.pw_amax = p[17];
+                a.add = bn::I8AddParams{p[18], p[19], p[20], p[21], p[22], p[23], p[24], p[25], p[26], p[27], p[28]};
+                a.has_dw = p[29]; a.transposed = p[30]; a.TH = p[31]; a.TW = p[32]; a.NB = p[33];
+                if (!bn::i8_dwpw_supported(a.Cin, a.Cout) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
+                    return fail(BN_ERR_FORMAT, "operator %zu: unsupported fused INT8 block geometry", oi);
+                bn::launch_i8_dwpw(a, s);
+                break;
+            }
             case BN_OP_I8_MEAN:
                 bn::launch_i8_mean((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], s);
                 break;
@@ -517,7 +541,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 const char* bn_kernel_names(void) {
     return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_mag_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_gap_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";
 }
 

@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 #define BN_BLOB_MAGIC "BNHIPM01"
-#define BN_BLOB_VERSION 2u
+#define BN_BLOB_VERSION 3u
 
 #define BN_SLOT_INPUT (-1)
 #define BN_SLOT_SCORES (-2)
@@ -48,8 +48,8 @@ struct TensorRec {
     uint64_t nbytes;
 };
 
-#define BN_OP_NP 24
-#define BN_OP_NT 8
+#define BN_OP_NP 40
+#define BN_OP_NT 10
 #define BN_OP_NF 8
 
 struct OpRec {
@@ -113,4 +113,9 @@ enum BnOpKind : int32_t {
     BN_OP_I8_FC = 26,
     // [C] int8 -> scores f32 (+ logits f32)  p: C zp_fc zp_out has_lut   f: s_fc s_out   t: lut[256]
     BN_OP_I8_HEAD = 27,
+    // fused [depthwise 3x3 ->] pointwise 1x1 on the int8 matrix cores (has_dw = 0: plain 1x1; transposed = 1: mel mixer)
+    // p: H W Cin sh sw - OH OW pad_top pad_left | dw_zp_in dw_zp_out dw_amin dw_amax | Cout pw_zp_out pw_amin pw_amax
+    //    | has_add z1 m1 s1 m2 s2 mo so zo amin amax | has_dw transposed TH TW NB has_lut
+    // in1: residual slot   t: dw_w dw_b(zp folded) dw_mult dw_shift pw_w(fragment order) pw_b(zp folded) pw_mult pw_shift lut
+    BN_OP_I8_DWPW = 28,
 };

@@ -78,4 +78,27 @@ void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_o
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,
                     float s_out, const int8_t* lut, hipStream_t s);
 
+// Fused INT8 depthwise 3x3 -> pointwise 1x1 block on the int8 matrix cores (bn_i8_fused.hip).
+// has_dw = 0: plain 1x1 convolution; transposed = 1: output [chunk][n][position] with an optional per-channel table
+// (the frontend's mel mixer + PWL).
+struct DwPw8Args {
+    const int8_t* x;
+    const int8_t* res;
+    int8_t* y;
+    const int8_t* dw_w;       // [3][3][Cin]
+    const int32_t* dw_b;      // [Cin], holds bias - zp_in * sum of the nine weights
+    const int32_t* dw_mult;
+    const int32_t* dw_shift;
+    const int8_t* pw_w;       // fragment order [Kp/64][Cout/16][64 lanes][16]
+    const int32_t* pw_b;      // [Cout], zero point folded
+    const int32_t* pw_mult;
+    const int32_t* pw_shift;
+    const int8_t* lut;        // [Cout][256] or null
+    int B, H, W, Cin, Cout, sh, sw, pt, pl, OH, OW, TH, TW, NB, has_dw, transposed;
+    int dw_zp_in, dw_zp_out, dw_amin, dw_amax, pw_zp_out, pw_amin, pw_amax;
+    I8AddParams add;
+};
+bool i8_dwpw_supported(int Cin, int Cout);
+void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s);
+
 }  // namespace bn

@@ -92,7 +92,8 @@ def test_stft_silence_and_ragged_width(torch_mod):
 
 
 # ------------------------------------------------------------------------------------ float32 graph
-def test_f32_graph_per_layer_and_logits(torch_mod, oracle_specs):
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused_mfma", "baseline_kernels"])
+def test_f32_graph_per_layer_and_logits(torch_mod, oracle_specs, fuse):
     from birdnet_stm32.models._keras_loader import load_keras_archive
     from birdnet_stm32.models.runners import load_model_runner
     from oracle import float_graph
@@ -100,7 +101,7 @@ def test_f32_graph_per_layer_and_logits(torch_mod, oracle_specs):
     spec = load_keras_archive(KERAS_PATH)
     x = oracle_specs[..., None]
     ref_scores, ref_logits, acts = float_graph.forward(spec, x, np.float64, return_all=True, return_logits=True)
-    runner = load_model_runner(KERAS_PATH, max_batch=16, keep_all=True)
+    runner = load_model_runner(KERAS_PATH, max_batch=16, keep_all=True, fuse=fuse)
     got = runner.predict(x)
     B = x.shape[0]
     worst = []
@@ -140,7 +141,8 @@ def test_f32_infer_audio_end_to_end(torch_mod, audio24, oracle_specs):
 
 
 # --------------------------------------------------------------------------------------- INT8 graph
-def test_i8_graph_bit_exact_per_tensor(torch_mod, oracle_specs):
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused_mfma", "baseline_kernels"])
+def test_i8_graph_bit_exact_per_tensor(torch_mod, oracle_specs, fuse):
     from birdnet_stm32.models._tflite_reader import load_tflite
     from birdnet_stm32.models.runners import load_model_runner
     from oracle.int8_graph import Int8Interpreter
@@ -148,7 +150,7 @@ def test_i8_graph_bit_exact_per_tensor(torch_mod, oracle_specs):
     model = load_tflite(TFLITE_PATH)
     x = oracle_specs[..., None]
     ref, env = Int8Interpreter(model).invoke(x, return_all=True)
-    runner = load_model_runner(TFLITE_PATH, max_batch=16, keep_all=True)
+    runner = load_model_runner(TFLITE_PATH, max_batch=16, keep_all=True, fuse=fuse)
     got = runner.predict(x)
     B = x.shape[0]
     for oi, op in enumerate(runner.plan.ops):
