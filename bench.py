@@ -61,6 +61,10 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
     e = 4 if dtype == "f32" else 1
     if k == "stft512":
         return batch * (T * 4 + (NFFT // 2 + 1) * W * 4), batch * 3.35e6
+    if k == "f32_stftmel":
+        return batch * (T * 4 + p[2] * p[1] * 4), batch * 3.35e6
+    if k == "f32_melfin":
+        return batch * 2.0 * p[0] * p[1] * 4, batch * 10.0 * p[0] * p[1]
     if k == "f32_mel":
         return batch * (p[0] * p[1] * 4 + p[2] * p[1] * 4), batch * 2.0 * p[0] * p[1] * p[2]
     if k == "i8_quant":
@@ -109,7 +113,7 @@ def roofline_of(rows: list[dict], batch: int, dtype: str) -> tuple[dict, list[di
         roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["traffic"] = None  # PMC-measured HBM bytes live in profiles/ (separate rocprofv3 --pmc passes)
-    roof["kernel"] = dom["kernel"] + "_kernel" if dom["kernel"] != "stft512" else "stft512_mag_kernel"
+    roof["kernel"] = {"stft512": "stft512_mag_kernel", "f32_stftmel": "stft512_mag_kernel"}.get(dom["kernel"], dom["kernel"] + "_kernel")
     roof["layer"] = dom["layer"]
     roof["avg_launch_ms"] = dom["avg_ms"]
     roof["algorithmic_bytes_per_launch"] = dom["bytes"]

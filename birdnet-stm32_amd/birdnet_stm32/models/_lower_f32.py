@@ -162,10 +162,19 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
             t_m = pb.tensor(mag_params(ly), np.float32)
             mag, norm = pk.MAG_CODES[fa.get("mag_scale", "none")], int(bool(fa.get("norm", False)))
             v = pb.value(M * W * 4)
+            both = pk.PATH_BOTH if not fuse else pk.PATH_INPUT
             pb.op(pk.F32_MEL, val[ly.inputs[0]], v, p=[F, W, M, mag, norm], t=[t_w, t_b, t_m],
-                  name=ly.name if not norm else ly.name + ":mel", out_shape=(M, W, 1))
+                  name=ly.name if not norm else ly.name + ":mel", out_shape=(M, W, 1), path=both)
             if norm:
-                pb.op(pk.F32_MAG, v, v, p=[M, W, mag], t=[-1, -1, t_m], name=ly.name, out_shape=(M, W, 1))
+                pb.op(pk.F32_MAG, v, v, p=[M, W, mag], t=[-1, -1, t_m], name=ly.name, out_shape=(M, W, 1), path=both)
+            if fuse and F == 257:
+                # audio entry point: STFT with the mixer fused (no spectrogram in HBM), then normalise + scale
+                wsum = ly.weights["mel"][:F].astype(np.float64).sum(axis=0).astype(np.float32)
+                raw = pb.value(M * W * 4)
+                pb.op(pk.F32_STFTMEL, pk.SLOT_AUDIO, raw, p=[0, W, M], t=[t_w, t_b], name=ly.name + ":melraw", out_shape=(M, W, 1),
+                      path=pk.PATH_AUDIO)
+                pb.op(pk.F32_MELFIN, raw, v, p=[M, W, mag, norm], t=[pb.tensor(wsum, np.float32), -1, t_m], name=ly.name,
+                      out_shape=(M, W, 1), path=pk.PATH_AUDIO)
             val[ly.name], shape[ly.name] = v, (M, W, 1)
         elif k in (ns.CONV, ns.DWCONV):
             src = ly.inputs[0]

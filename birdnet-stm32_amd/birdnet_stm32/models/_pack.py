@@ -21,19 +21,20 @@ BLOB_VERSION = 3
 DTYPE_F32, DTYPE_I8 = 0, 1
 INPUT_SPECTROGRAM, INPUT_WAVEFORM = 0, 1
 
-SLOT_INPUT, SLOT_SCORES, SLOT_LOGITS, SLOT_NONE = -1, -2, -3, -9
+SLOT_INPUT, SLOT_SCORES, SLOT_LOGITS, SLOT_AUDIO, SLOT_NONE = -1, -2, -3, -4, -9
+OP_PATH, PATH_BOTH, PATH_INPUT, PATH_AUDIO = 39, 0, 1, 2
 
 OP_NP, OP_NT, OP_NF = 40, 10, 8
 
 # operator kinds (enum BnOpKind)
 F32_MEL, F32_MAG, F32_RAWFE, F32_STEM, F32_DW, F32_PW = 1, 2, 3, 4, 5, 6
-F32_SEGATE, F32_SCALE, F32_GAP, F32_DENSE, F32_ATTNPOOL, F32_DWPW = 7, 8, 9, 10, 11, 12
+F32_SEGATE, F32_SCALE, F32_GAP, F32_DENSE, F32_ATTNPOOL, F32_DWPW, F32_STFTMEL, F32_MELFIN = 7, 8, 9, 10, 11, 12, 13, 14
 I8_QUANT, I8_MEL, I8_STEM, I8_DW, I8_PW, I8_MEAN, I8_FC, I8_HEAD, I8_DWPW = 20, 21, 22, 23, 24, 25, 26, 27, 28
 
 KIND_NAMES = {
     F32_MEL: "f32_mel", F32_MAG: "f32_mag", F32_RAWFE: "f32_rawfe", F32_STEM: "f32_stem", F32_DW: "f32_dw",
     F32_PW: "f32_pw", F32_SEGATE: "f32_segate", F32_SCALE: "f32_scale", F32_GAP: "f32_gap", F32_DENSE: "f32_dense",
-    F32_ATTNPOOL: "f32_attnpool", F32_DWPW: "f32_dwpw", I8_QUANT: "i8_quant", I8_MEL: "i8_mel", I8_STEM: "i8_stem", I8_DW: "i8_dw",
+    F32_ATTNPOOL: "f32_attnpool", F32_DWPW: "f32_dwpw", F32_STFTMEL: "f32_stftmel", F32_MELFIN: "f32_melfin", I8_QUANT: "i8_quant", I8_MEL: "i8_mel", I8_STEM: "i8_stem", I8_DW: "i8_dw",
     I8_PW: "i8_pw", I8_DWPW: "i8_dwpw", I8_MEAN: "i8_mean", I8_FC: "i8_fc", I8_HEAD: "i8_head",
 }  # fmt: skip
 
@@ -106,8 +107,9 @@ class PlanBuilder:
         return len(self._value_bytes) - 1
 
     def op(self, kind, in0, out, p=(), t=(), f=(), in1=SLOT_NONE, name="", out_shape=(), out_dtype="float32",
-           value_params=()) -> PlanOp:
+           value_params=(), path=PATH_BOTH) -> PlanOp:
         pp = [int(v) for v in p] + [0] * (OP_NP - len(p))
+        pp[OP_PATH] = int(path)
         tt = [int(v) for v in t] + [-1] * (OP_NT - len(t))
         ff = [float(v) for v in f] + [0.0] * (OP_NF - len(f))
         if len(pp) != OP_NP or len(tt) != OP_NT or len(ff) != OP_NF:

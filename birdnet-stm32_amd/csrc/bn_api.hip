@@ -116,9 +116,11 @@ struct ProfScope {
 
 // Executes the plan for a batch slice.
 int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, float* d_scores, float* d_logits,
-             hipStream_t s) {
+             hipStream_t s, const float* d_audio = nullptr, int T = 0, int hop = 0) {
+    const int mode = d_audio ? BN_PATH_AUDIO : BN_PATH_INPUT;
     auto slot_ptr = [&](int id) -> char* {
         if (id == BN_SLOT_INPUT) return (char*)d_input;
+        if (id == BN_SLOT_AUDIO) return (char*)d_audio;
         if (id == BN_SLOT_SCORES) return (char*)d_scores;
         if (id == BN_SLOT_LOGITS) return (char*)d_logits;
         if (id < 0 || id >= (int)m->d_slots.size()) return nullptr;
@@ -127,6 +129,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
+        if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
         ProfScope prof(m, (int)oi, s);
         char* in0 = slot_ptr(o.in0);
         char* in1 = slot_ptr(o.in1);
@@ -140,6 +143,17 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                    (const float*)m->tensor(o.t[2]), p[3], p[4], s);
                 break;
             }
+            case BN_OP_F32_STFTMEL: {
+                bn::launch_minmax_init(m->d_minmax, B, s);
+                if (!bn::launch_stft512_mel(m->ctx->tables, d_audio, B, T, hop, p[1], (float*)out, p[2],
+                                            (const float*)m->tensor(o.t[0]), (const int*)m->tensor(o.t[1]), m->d_minmax, s))
+                    return fail(BN_ERR_UNSUPPORTED, "hop %d too long for the fused STFT+mel kernel", hop);
+                break;
+            }
+            case BN_OP_F32_MELFIN:
+                bn::launch_f32_melfin((const float*)in0, m->d_minmax, (float*)out, B, p[0], p[1], (const float*)m->tensor(o.t[0]),
+                                      (const float*)m->tensor(o.t[2]), p[2], p[3], s);
+                break;
             case BN_OP_F32_MAG:
                 bn::launch_f32_mag((float*)out, m->d_smax, B, p[0], p[1], (const float*)m->tensor(o.t[2]), p[2], s);
                 break;
@@ -487,6 +501,23 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
         return fail(BN_ERR_ARG, "batch %d exceeds the context's max_batch %d", B, m->ctx->max_batch);
     const int F = (int)m->hdr.fft_bins, W = (int)m->hdr.spec_width;
     if (F != kFft / 2 + 1) return fail(BN_ERR_UNSUPPORTED, "model expects %d frequency bins; the STFT kernel gives 257", F);
+    bool audio_plan = false;
+    for (const OpRec& o : m->ops) audio_plan |= o.p[BN_OP_PATH] == BN_PATH_AUDIO;
+    if (audio_plan) {
+        // the plan holds operators that start from the waveform (fused STFT + mel mixer): no spectrogram in HBM
+        if (int rc = check_device(m->ctx)) return rc;
+        if (!d_audio || !d_scores) return fail(BN_ERR_ARG, "null device pointer");
+        if (T <= 0 || hop <= 0 || 1 + T / hop < W) return fail(BN_ERR_ARG, "bad audio geometry T=%d hop=%d W=%d", T, hop, W);
+        if (B == 0) return BN_OK;
+        const size_t C = m->hdr.num_classes;
+        for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
+            const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+            if (int rc = run_plan(m, nullptr, nullptr, nb, d_scores + b0 * C, d_logits ? d_logits + b0 * C : nullptr,
+                                  (hipStream_t)stream, d_audio + (size_t)b0 * T, T, hop))
+                return rc;
+        }
+        return BN_OK;
+    }
     // un-normalised magnitudes + per-chunk min/max; the plan's first operator normalises while loading
     {
         ProfScope prof(m, (int)m->ops.size(), (hipStream_t)stream);
@@ -539,7 +570,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 }
 
 const char* bn_kernel_names(void) {
-    return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_mag_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
+    return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_gap_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";

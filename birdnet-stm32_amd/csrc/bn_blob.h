@@ -18,7 +18,15 @@
 #define BN_SLOT_INPUT (-1)
 #define BN_SLOT_SCORES (-2)
 #define BN_SLOT_LOGITS (-3)
+#define BN_SLOT_AUDIO (-4)   // the caller's waveform tensor (operators of the audio path only)
 #define BN_SLOT_NONE (-9)
+
+// OpRec.p[BN_OP_PATH]: which entry point runs the operator.  bn_forward starts from the runner-boundary input
+// (spectrogram); bn_infer_audio starts from waveforms and may use operators that never materialise the spectrogram.
+#define BN_OP_PATH 39
+#define BN_PATH_BOTH 0
+#define BN_PATH_INPUT 1   // only when starting from BN_SLOT_INPUT
+#define BN_PATH_AUDIO 2   // only when starting from BN_SLOT_AUDIO
 
 struct BlobHeader {
     char magic[8];
@@ -95,6 +103,11 @@ enum BnOpKind : int32_t {
     // p: H W Cin sh sw dw_act OH OW pad_top pad_left | Cout pw_act has_res has_gate gate_slot has_dw TH TW NB
     // in1: residual slot   t: dw_w[3][3][Cin] dw_b[Cin] pw_w(fragment order [Cin/16][Cout/16][64][4]) pw_b[Cout]
     BN_OP_F32_DWPW = 12,
+    // audio [T] -> un-normalised mel energies [M][W] (+ min/max of the magnitudes): STFT with the band-sparse mixer fused
+    // p: T(0 = runtime) W M   t: wvals bands
+    BN_OP_F32_STFTMEL = 13,
+    // un-normalised mel energies -> frontend output [M][W]   p: M W mag norm   t: wsum[M] - magp
+    BN_OP_F32_MELFIN = 14,
 
     // ---- INT8 plan -----------------------------------------------------------------
     // spec f32 [F][W] -> q int8 [W][Kp]   p: F W Kp zp fill   f: scale

@@ -92,6 +92,35 @@ __global__ void f32_mag_kernel(float* x, const float* __restrict__ smax, int M, 
     }
 }
 
+// frontend finalisation for the fused STFT+mel path: un-normalised mel energies [M][W] -> frontend output.
+//   y = relu((mel - mn * wsum[m]) / rng)   (= the mixer applied to the min-max normalised spectrogram)
+//   [y /= max(y) + 1e-6]  then magnitude scaling.  One block per chunk, two passes over the 64 KB tile when norm is on.
+__global__ __launch_bounds__(256) void f32_melfin_kernel(const float* __restrict__ melraw, const float* __restrict__ minmax,
+                                                         float* __restrict__ out, int M, int W, const float* __restrict__ wsum,
+                                                         const float* __restrict__ magp, int mag, int norm) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float mn = minmax[2 * b];
+    const float rng = (float)((double)(minmax[2 * b + 1] - mn) + 1e-10);
+    const float* src = melraw + (size_t)b * M * W;
+    float* dst = out + (size_t)b * M * W;
+    float peak = 0.0f;
+    if (norm) {
+        for (int i = threadIdx.x; i < M * W; i += 256) peak = fmaxf(peak, fmaxf((src[i] - mn * wsum[i / W]) / rng, 0.0f));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) peak = fmaxf(peak, __shfl_xor(peak, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = peak;
+        __syncthreads();
+        peak = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) + 1e-6f;
+    }
+    for (int i = threadIdx.x; i < M * W; i += 256) {
+        const int m = i / W;
+        float y = fmaxf((src[i] - mn * wsum[m]) / rng, 0.0f);
+        if (norm) y = y / peak;
+        dst[i] = mag_scale(y, m, M, magp, mag);
+    }
+}
+
 // stem: [H][W] (one channel) -> [OH][OW][Cout], 3x3.  One thread = 4 output channels of one pixel.
 __global__ void f32_stem_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Cout, int sh,
                                 int sw, int act, int OH, int OW, int pt, int pl, const float* __restrict__ w,
@@ -331,6 +360,11 @@ void launch_f32_mel(const float* spec, const float* minmax, float* out, float* s
 
 void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const float* magp, int mag, hipStream_t s) {
     hipLaunchKernelGGL(f32_mag_kernel, dim3(16, B), dim3(256), 0, s, x, smax, M, W, magp, mag);
+}
+
+void launch_f32_melfin(const float* melraw, const float* minmax, float* out, int B, int M, int W, const float* wsum,
+                       const float* magp, int mag, int norm, hipStream_t s) {
+    hipLaunchKernelGGL(f32_melfin_kernel, dim3(B), dim3(256), 0, s, melraw, minmax, out, M, W, wsum, magp, mag, norm);
 }
 
 void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, int sh, int sw, int act, int OH, int OW,

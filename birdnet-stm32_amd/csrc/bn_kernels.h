@@ -16,11 +16,15 @@ struct StftTables {
 void launch_minmax_init(float* minmax, int B, hipStream_t s);
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec,
                     float* minmax, hipStream_t s);
+bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
+                        const float* wvals, const int* bands, float* minmax, hipStream_t s);
 void launch_spec_normalize(float* spec, const float* minmax, int B, int per_chunk, hipStream_t s);
 
 // ---- float32 plan ------------------------------------------------------------------------
 void launch_f32_mel(const float* spec, const float* minmax, float* out, float* smax, int B, int F, int W, int M,
                     const float* wvals, const int* bands, const float* magp, int mag, int norm, hipStream_t s);
+void launch_f32_melfin(const float* melraw, const float* minmax, float* out, int B, int M, int W, const float* wsum,
+                       const float* magp, int mag, int norm, hipStream_t s);
 void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const float* magp, int mag, hipStream_t s);
 void launch_u32_fill(uint32_t* p, uint32_t v, int n, hipStream_t s);
 void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, int sh, int sw, int act, int OH, int OW,

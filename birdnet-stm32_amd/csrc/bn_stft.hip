@@ -12,6 +12,8 @@
 // k <-> 256-k pairing of the post-pass go through LDS.  A 256-thread workgroup therefore
 // transforms 16 consecutive frames of one chunk; magnitudes are staged in LDS and written as
 // frequency-major rows so that the global stores are 64-byte runs.
+#include <cstdlib>
+
 #include "bn_kernels.h"
 
 namespace bn {
@@ -72,8 +74,20 @@ __global__ void minmax_init_kernel(float* minmax, int B) {
     }
 }
 
+// With MEL_OUT the band-sparse mel mixer is applied while the magnitudes of the tile are still in LDS and the kernel
+// writes [B][M][W] un-normalised mel energies (64 KB/chunk) instead of the [B][257][W] spectrogram (263 KB/chunk).
+// min/max of the magnitudes still go to `minmax`: the reference's min-max normalisation commutes with the linear mixer,
+//   mel((S - mn)/rng)[m] = (mel(S)[m] - mn * sum_f w[f][m]) / rng,   and is applied by the consumer.
+struct MelOut {
+    const float* wvals;  // band-sparse mixer values
+    const int* bands;    // [3][M] start, len, offset
+    float* out;          // [B][M][W]
+    int M;
+};
+
+template <bool MEL_OUT>
 __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop,
-                                                          int W, float* __restrict__ spec, float* minmax) {
+                                                          int W, float* __restrict__ spec, float* minmax, MelOut mel) {
     __shared__ float2 xch[kFT][kFS];
     __shared__ float mag[257][kFT + 1];
     __shared__ float red_min[4], red_max[4];
@@ -91,9 +105,12 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         const int i0 = 2 * (16 * n1 + j);
-        const long g0 = start + i0;
-        const float v0 = (g0 >= 0 && g0 < T) ? x[g0] : 0.0f;
-        const float v1 = (g0 + 1 >= 0 && g0 + 1 < T) ? x[g0 + 1] : 0.0f;
+        // unconditional loads from clamped addresses (all 32 in flight at once), zeroed afterwards when out of range
+        const long g0 = start + i0, g1 = g0 + 1;
+        const long c0 = g0 < 0 ? 0 : (g0 >= T ? T - 1 : g0), c1 = g1 < 0 ? 0 : (g1 >= T ? T - 1 : g1);
+        float v0 = x[c0], v1 = x[c1];
+        v0 = (g0 == c0) ? v0 : 0.0f;
+        v1 = (g1 == c1) ? v1 : 0.0f;
         a[n1] = make_float2(v0 * tb.window[i0], v1 * tb.window[i0 + 1]);
     }
     fft16(a);
@@ -141,11 +158,23 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
     }
     __syncthreads();
 
-    // frequency-major rows, 16 consecutive frames each
-    float* out = spec + (size_t)b * 257 * W;
-    for (int idx = threadIdx.x; idx < 257 * kFT; idx += 256) {
-        const int k = idx / kFT, ff = idx % kFT;
-        if (t0 + ff < W) out[(size_t)k * W + t0 + ff] = mag[k][ff];
+    if (!MEL_OUT) {
+        // frequency-major rows, 16 consecutive frames each
+        float* out = spec + (size_t)b * 257 * W;
+        for (int idx = threadIdx.x; idx < 257 * kFT; idx += 256) {
+            const int k = idx / kFT, ff = idx % kFT;
+            if (t0 + ff < W) out[(size_t)k * W + t0 + ff] = mag[k][ff];
+        }
+    } else {
+        // thread = (frame ff, mel bins m0, m0+16, ...): narrow low bands and wide high bands mix in every thread
+        float* out = mel.out + (size_t)b * mel.M * W;
+        const int ff = threadIdx.x & 15;
+        for (int m = threadIdx.x >> 4; m < mel.M; m += 16) {
+            const int s0 = mel.bands[m], len = mel.bands[mel.M + m], off = mel.bands[2 * mel.M + m];
+            float acc = 0.0f;
+            for (int i = 0; i < len; ++i) acc = fmaf(mag[s0 + i][ff], mel.wvals[off + i], acc);
+            if (t0 + ff < W) out[(size_t)m * W + t0 + ff] = acc;
+        }
     }
 
     // per-chunk min / max (magnitudes are >= 0, so the unsigned bit patterns order like the floats)
@@ -187,8 +216,15 @@ void launch_minmax_init(float* minmax, int B, hipStream_t s) {
 
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, float* minmax,
                     hipStream_t s) {
-    hipLaunchKernelGGL(stft512_mag_kernel, dim3((W + kFT - 1) / kFT, B), dim3(256), 0, s, tb, audio, T, hop, W, spec,
-                       minmax);
+    hipLaunchKernelGGL((stft512_mag_kernel<false>), dim3((W + kFT - 1) / kFT, B), dim3(256), 0, s, tb, audio, T, hop, W, spec,
+                       minmax, MelOut{});
+}
+
+bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
+                        const float* wvals, const int* bands, float* minmax, hipStream_t s) {
+    hipLaunchKernelGGL((stft512_mag_kernel<true>), dim3((W + kFT - 1) / kFT, B), dim3(256), 0, s, tb, audio, T, hop, W, nullptr,
+                       minmax, MelOut{wvals, bands, mel_out, M});
+    return true;
 }
 
 void launch_spec_normalize(float* spec, const float* minmax, int B, int per_chunk, hipStream_t s) {
