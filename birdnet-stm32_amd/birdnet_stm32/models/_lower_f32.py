@@ -219,10 +219,37 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
                     raise NotImplementedError(f"{ly.name}: 3x3 convolutions are only lowered for the 1-channel stem")
                 w, b = fold_bn(ly.weights["kernel"], bn)  # [3,3,1,Cout]
                 Cout = w.shape[-1]
-                v = pb.value(OH * OW * Cout * 4)
-                pb.op(pk.F32_STEM, val[src], v, p=[H, Wd, Cout, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl],
-                      t=[pb.tensor(w[:, :, 0, :], np.float32), pb.tensor(b, np.float32)], name=last, out_shape=(OH, OW, Cout))
-                out_shape = (OH, OW, Cout)
+                # front block: stem -> depthwise stride 2 -> pointwise in one kernel (the stem activation stays in LDS)
+                front = None
+                dw_i = only_consumer(last)
+                if fuse and dw_i is not None and layers[dw_i].kind == ns.DWCONV and (sh, sw) == (1, 2) and Cout == 16:
+                    dwl = layers[dw_i]
+                    bn_d, res_d, act_d, last_d = chain_after(dw_i, dwl.name)
+                    pw_i = only_consumer(last_d)
+                    if (tuple(dwl.attrs["strides"]) == (2, 2) and res_d is None and pw_i is not None and layers[pw_i].kind == ns.CONV
+                            and tuple(layers[pw_i].attrs["kernel"]) == (1, 1) and int(layers[pw_i].attrs["filters"]) == 32):
+                        pwl = layers[pw_i]
+                        bn_p, res_p, act_p, last_p = chain_after(pw_i, pwl.name)
+                        BH, BW = ns.same_pad(OH, 3, 2)[0], ns.same_pad(OW, 3, 2)[0]
+                        if res_p is None and BH % 8 == 0 and BW % 8 == 0 and H == 2 * BH and Wd == 4 * BW:
+                            front = (dwl, bn_d, act_d, pwl, bn_p, act_p, last_p, BH, BW)
+                if front is not None:
+                    dwl, bn_d, act_d, pwl, bn_p, act_p, last_p, BH, BW = front
+                    wd, bd = fold_bn(dwl.weights["kernel"], bn_d)
+                    wp_, bp = fold_bn(pwl.weights["kernel"], bn_p)
+                    N = wp_.shape[-1]
+                    v = pb.value(BH * BW * N * 4)
+                    pb.op(pk.F32_FRONT, val[src], v, p=[H, Wd, Cout, N, BH, BW, pk.ACT_CODES[act], pk.ACT_CODES[act_d], pk.ACT_CODES[act_p]],
+                          t=[pb.tensor(w[:, :, 0, :], np.float32), pb.tensor(b, np.float32), pb.tensor(wd, np.float32), pb.tensor(bd, np.float32),
+                             pb.tensor(pack_pw_fragments(wp_[0, 0]), np.float32), pb.tensor(bp, np.float32)],
+                          name=last_p, out_shape=(BH, BW, N))
+                    out_shape = (BH, BW, N)
+                    last = last_p
+                else:
+                    v = pb.value(OH * OW * Cout * 4)
+                    pb.op(pk.F32_STEM, val[src], v, p=[H, Wd, Cout, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl],
+                          t=[pb.tensor(w[:, :, 0, :], np.float32), pb.tensor(b, np.float32)], name=last, out_shape=(OH, OW, Cout))
+                    out_shape = (OH, OW, Cout)
             elif (kh, kw) == (1, 1) and (sh, sw) == (1, 1):
                 w, b = fold_bn(ly.weights["kernel"], bn)  # [1,1,Cin,Cout]
                 Cout = w.shape[-1]

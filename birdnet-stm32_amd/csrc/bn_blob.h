@@ -108,6 +108,9 @@ enum BnOpKind : int32_t {
     BN_OP_F32_STFTMEL = 13,
     // un-normalised mel energies -> frontend output [M][W]   p: M W mag norm   t: wsum[M] - magp
     BN_OP_F32_MELFIN = 14,
+    // frontend output [H0][W0] -> stem 3x3 s(1,2) -> depthwise 3x3 s2 -> pointwise, one kernel
+    // p: H0 W0 C N OH OW stem_act dw_act pw_act   t: stem_w stem_b dw_w dw_b pw_w(fragment order) pw_b
+    BN_OP_F32_FRONT = 15,
 
     // ---- INT8 plan -----------------------------------------------------------------
     // spec f32 [F][W] -> q int8 [W][Kp]   p: F W Kp zp fill   f: scale

@@ -225,6 +225,147 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Front block: frontend output [64][256] (one channel) -> stem 3x3 (stride 1x2, +BN, ReLU6) -> depthwise 3x3
+// stride 2 (+BN, ReLU6) -> pointwise 1x1 (+BN, ReLU6), in ONE kernel.  The stem activation (512 KB per chunk in
+// float32, the largest tensor of the network) lives only in LDS: a workgroup computes the 17x17x16 stem patch its
+// 8x8 output tile needs from a 19x35 patch of the frontend output.  Same matrix-core tail as f32_dwpw_kernel.
+// Reference: stem_conv/stem_bn/stem_relu + stage1_ds1 of birdnet_stm32/models/dscnn.py:198-202,28-84.
+struct FrontArgs {
+    const float* fe;      // [B][H0][W0]
+    float* y;             // [B][OH][OW][N]
+    const float* stem_w;  // [3][3][C]
+    const float* stem_b;  // [C]
+    const float* dw_w;    // [3][3][C]
+    const float* dw_b;    // [C]
+    const float* pw_w;    // fragment order [C/16][N/16][64][4]
+    const float* pw_b;    // [N]
+    int B, H0, W0, SH, SW, C, N, OH, OW;  // stem map SH x SW, block output OH x OW
+    int stem_act, dw_act, pw_act;
+};
+
+template <int RG, int CT>
+__global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
+    constexpr int TS = 17;            // stem patch edge for an 8x8 tile of a stride-2 depthwise
+    constexpr int FH = 19, FW = 35;   // frontend patch: stem stride (1, 2), 3x3
+    constexpr int C = 16;             // stem channels = contraction width of the pointwise
+    constexpr int NS = RG * CT * 16;
+    __shared__ float fe_t[FH][FW + 1];
+    __shared__ __attribute__((aligned(16))) float stem_t[TS * TS][C];
+    __shared__ __attribute__((aligned(16))) float tile[64 * (NS + 4)];  // activation tile [64][C + 4], later the output tile
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tiles_x = a.OW / 8, tiles_y = a.OH / 8;
+    const int tx0 = (bid % tiles_x) * 8;
+    bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * 8;
+    const int chunk = bid / tiles_y;
+
+    // ---- frontend patch: rows 2*ty0-1 .., cols 4*tx0 .. (zero outside = the stem's SAME padding) ---------------------
+    const int r_base = 2 * ty0 - 1, c_base = 4 * tx0;  // stem pad_top 1, pad_left 0
+    const float* fe = a.fe + (size_t)chunk * a.H0 * a.W0;
+    for (int i = tid; i < FH * FW; i += 256) {
+        const int rr = i / FW, cc = i - rr * FW;
+        const int gr = r_base + rr, gc = c_base + cc;
+        fe_t[rr][cc] = (gr >= 0 && gr < a.H0 && gc >= 0 && gc < a.W0) ? fe[gr * a.W0 + gc] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- stem patch: stem rows 2*ty0 .. +16, cols 2*tx0 .. +16; zero where the stem map ends (depthwise SAME padding) ---
+    {
+        const int cq = tid & 3;
+        float4 w9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[t] = *reinterpret_cast<const float4*>(a.stem_w + t * C + 4 * cq);
+        const float4 b4 = *reinterpret_cast<const float4*>(a.stem_b + 4 * cq);
+        for (int sp = tid >> 2; sp < TS * TS; sp += 64) {
+            const int sr = sp / TS, sc = sp - sr * TS;
+            float4 acc = b4;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float v = fe_t[sr + i][2 * sc + j];
+                    const float4 w = w9[i * 3 + j];
+                    acc.x = fmaf(v, w.x, acc.x);
+                    acc.y = fmaf(v, w.y, acc.y);
+                    acc.z = fmaf(v, w.z, acc.z);
+                    acc.w = fmaf(v, w.w, acc.w);
+                }
+            const bool inside = (2 * ty0 + sr) < a.SH && (2 * tx0 + sc) < a.SW;
+            acc.x = inside ? act_f(acc.x, a.stem_act) : 0.0f;
+            acc.y = inside ? act_f(acc.y, a.stem_act) : 0.0f;
+            acc.z = inside ? act_f(acc.z, a.stem_act) : 0.0f;
+            acc.w = inside ? act_f(acc.w, a.stem_act) : 0.0f;
+            *reinterpret_cast<float4*>(&stem_t[sp][4 * cq]) = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- depthwise 3x3 stride 2 (pad 0 / 1) from the stem patch -> activation tile [64][C] -------------------------------
+    constexpr int S4 = C / 4 + 1;
+    f32x4* lds4 = reinterpret_cast<f32x4*>(tile);
+    {
+        const int cq = tid & 3, p = tid >> 2;  // 64 positions x 4 channel quads = 256 items
+        const int py = p >> 3, px = p & 7;
+        float4 acc = *reinterpret_cast<const float4*>(a.dw_b + 4 * cq);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(&stem_t[(2 * py + i) * TS + 2 * px + j][4 * cq]);
+                const float4 w = *reinterpret_cast<const float4*>(a.dw_w + (i * 3 + j) * C + 4 * cq);
+                acc.x = fmaf(v.x, w.x, acc.x);
+                acc.y = fmaf(v.y, w.y, acc.y);
+                acc.z = fmaf(v.z, w.z, acc.z);
+                acc.w = fmaf(v.w, w.w, acc.w);
+            }
+        lds4[p * S4 + cq] = (f32x4){act_f(acc.x, a.dw_act), act_f(acc.y, a.dw_act), act_f(acc.z, a.dw_act), act_f(acc.w, a.dw_act)};
+    }
+    __syncthreads();
+
+    // ---- pointwise on the matrix cores (one k-step of 16) -----------------------------------------------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    constexpr int WM = 4 / RG;
+    const int wm = wave % WM, wn = wave / WM;
+    const int row0 = wm * RG * 16;
+    const int ct0 = blockIdx.y * (RG * CT) + wn * CT;
+    const int n_ct = a.N >> 4;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.pw_w);
+    f32x4 acc[RG][CT];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            acc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 af = lds4[(row0 + 16 * g + r) * S4 + q];
+            const f32x4 bf = wp[((size_t)0 * n_ct + ct0 + c) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[g][c], 0, 0, 0);
+        }
+    constexpr int SO = NS + 4;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) tile[(row0 + 16 * g + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[g][c][reg];
+    __syncthreads();
+    const int n_base = blockIdx.y * NS;
+    constexpr int Q4 = NS / 4;
+    for (int item = tid; item < 64 * Q4; item += 256) {
+        const int p = item / Q4, c4 = item - p * Q4;
+        const int oh = ty0 + (p >> 3), ow = tx0 + (p & 7);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + p * SO + 4 * c4);
+        const float4 b = *reinterpret_cast<const float4*>(a.pw_b + n_base + 4 * c4);
+        float4 o = make_float4(act_f(v[0] + b.x, a.pw_act), act_f(v[1] + b.y, a.pw_act), act_f(v[2] + b.z, a.pw_act),
+                               act_f(v[3] + b.w, a.pw_act));
+        *reinterpret_cast<float4*>(a.y + (((size_t)chunk * a.OH + oh) * a.OW + ow) * a.N + n_base + 4 * c4) = o;
+    }
+}
+
 template <int RG, int CT>
 void launch_cfg(const DwPwArgs& a, hipStream_t s) {
     const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * ((a.B + a.NB - 1) / a.NB);
@@ -238,6 +379,19 @@ void launch_cfg(const DwPwArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+bool f32_front_supported(int H0, int W0, int C, int N, int OH, int OW) {
+    // stem stride (1,2) pad (1,0); depthwise stride 2 pad (0,0): the shapes of the reference's stem + stage1_ds1
+    return C == 16 && N == 32 && OH % 8 == 0 && OW % 8 == 0 && H0 == 2 * OH && W0 == 4 * OW;
+}
+
+void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, int N, int OH, int OW, int stem_act,
+                      int dw_act, int pw_act, const float* stem_w, const float* stem_b, const float* dw_w, const float* dw_b,
+                      const float* pw_w, const float* pw_b, hipStream_t s) {
+    FrontArgs a{fe, y, stem_w, stem_b, dw_w, dw_b, pw_w, pw_b, B, H0, W0, H0, W0 / 2, C, N, OH, OW, stem_act, dw_act, pw_act};
+    const int tiles = (OH / 8) * (OW / 8) * B;
+    hipLaunchKernelGGL((f32_front_kernel<2, 1>), dim3(tiles, 1), dim3(256), 0, s, a);
+}
 
 bool f32_dwpw_supported(int Cin, int Cout) { return Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 16 && Cin <= 2048; }
 

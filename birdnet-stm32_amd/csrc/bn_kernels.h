@@ -54,6 +54,11 @@ struct DwPwArgs {
     int B, H, W, Cin, Cout, sh, sw, pt, pl, OH, OW, TH, TW, NB, dw_act, pw_act, has_dw;
 };
 bool f32_dwpw_supported(int Cin, int Cout);
+// stem 3x3 (1 -> C channels, stride 1x2) + depthwise 3x3 stride 2 + pointwise C -> N in one kernel (bn_f32_fused.hip)
+bool f32_front_supported(int H0, int W0, int C, int N, int OH, int OW);
+void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, int N, int OH, int OW, int stem_act,
+                      int dw_act, int pw_act, const float* stem_w, const float* stem_b, const float* dw_w, const float* dw_b,
+                      const float* pw_w, const float* pw_b, hipStream_t s);
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s);
 
 // ---- INT8 plan -----------------------------------------------------------------------------
