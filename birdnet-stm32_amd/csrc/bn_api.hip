@@ -44,8 +44,8 @@ struct bn_ctx {
     int device = 0;
     int max_batch = 0;
     float* d_window = nullptr;
-    float2* d_tw256 = nullptr;
-    float2* d_tw512 = nullptr;
+    float4* d_tw256 = nullptr;
+    float4* d_tw512 = nullptr;
     bn::StftTables tables{};
 };
 
@@ -316,17 +316,24 @@ int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
     c->max_batch = max_batch;
     // STFT tables in double, rounded once to float32
     std::vector<float> win(kFft);
-    std::vector<float2> t256(256), t512(257);
+    std::vector<float4> t256(256), t512(257);
     const double two_pi = 6.283185307179586476925286766559;
-    for (int i = 0; i < kFft; ++i) win[i] = (float)(0.5 - 0.5 * cos(two_pi * i / kFft));
-    for (int i = 0; i < 256; ++i) t256[i] = make_float2((float)cos(two_pi * i / 256.0), (float)-sin(two_pi * i / 256.0));
-    for (int i = 0; i < 257; ++i) t512[i] = make_float2((float)cos(two_pi * i / 512.0), (float)-sin(two_pi * i / 512.0));
+    // the 1/2 of the real-FFT split pass is folded into the window (exact: a power of two)
+    for (int i = 0; i < kFft; ++i) win[i] = 0.5f * (float)(0.5 - 0.5 * cos(two_pi * i / kFft));
+    for (int i = 0; i < 256; ++i) {  // w = exp(-2 pi i p / 256), stored with its rotation (-w.y, w.x)
+        const float c = (float)cos(two_pi * i / 256.0), sn = (float)sin(two_pi * i / 256.0);
+        t256[i] = make_float4(c, -sn, sn, c);
+    }
+    for (int i = 0; i < 257; ++i) {  // t = -i exp(-2 pi i k / 512) = (-sin, -cos), rotation (cos, -sin)
+        const float c = (float)cos(two_pi * i / 512.0), sn = (float)sin(two_pi * i / 512.0);
+        t512[i] = make_float4(-sn, -c, c, -sn);
+    }
     HIP_TRY(hipMalloc(&c->d_window, win.size() * sizeof(float)));
-    HIP_TRY(hipMalloc(&c->d_tw256, t256.size() * sizeof(float2)));
-    HIP_TRY(hipMalloc(&c->d_tw512, t512.size() * sizeof(float2)));
+    HIP_TRY(hipMalloc(&c->d_tw256, t256.size() * sizeof(float4)));
+    HIP_TRY(hipMalloc(&c->d_tw512, t512.size() * sizeof(float4)));
     HIP_TRY(hipMemcpy(c->d_window, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_tw256, t256.data(), t256.size() * sizeof(float2), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_tw512, t512.data(), t512.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tw256, t256.data(), t256.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tw512, t512.data(), t512.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->tables = bn::StftTables{c->d_window, c->d_tw256, c->d_tw512};
     *out = c;
     return BN_OK;

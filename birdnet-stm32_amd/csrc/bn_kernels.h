@@ -7,9 +7,9 @@ namespace bn {
 
 // Read-only tables every STFT launch needs (built once per context, in double, stored f32).
 struct StftTables {
-    const float* window;    // [512] periodic Hann
-    const float2* tw256;    // [256] exp(-2 pi i p / 256)
-    const float2* tw512;    // [257] exp(-2 pi i k / 512)
+    const float* window;    // [512] 0.5 * periodic Hann (the 1/2 of the real-FFT split is folded in)
+    const float4* tw256;    // [256] (w, w_rot): w = exp(-2 pi i p / 256), w_rot = (-w.y, w.x)
+    const float4* tw512;    // [257] (t, t_rot): t = -i exp(-2 pi i k / 512)
 };
 
 // ---- STFT ------------------------------------------------------------------------------

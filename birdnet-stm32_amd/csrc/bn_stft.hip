@@ -23,48 +23,53 @@ namespace {
 constexpr int kFT = 16;    // frames per workgroup
 constexpr int kFS = 272;   // complex elements reserved per frame in the exchange buffer
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+// Complex values live in 64-bit register pairs end to end so that the compiler emits packed-f32 instructions
+// (v_pk_add/mul/fma_f32) with the swizzles folded into op_sel: a 16-point FFT is ~100 vector instructions.
+#define BN_SWAP(a) __builtin_shufflevector(a, a, 1, 0)
+#define BN_XX(a) __builtin_shufflevector(a, a, 0, 0)
+#define BN_YY(a) __builtin_shufflevector(a, a, 1, 1)
+
+// a * b for complex b given as (b, b_rot) with b_rot = (-b.y, b.x)
+__device__ __forceinline__ v2f cmulr(v2f a, v2f b, v2f brot) { return __builtin_elementwise_fma(BN_YY(a), brot, BN_XX(a) * b); }
+__device__ __forceinline__ v2f mul_neg_i(v2f a) {  // a * (-i) = (a.y, -a.x)
+    v2f t = BN_SWAP(a);
+    t.y = -t.y;
+    return t;
 }
 
 // forward 4-point DFT, natural order in and out
-__device__ __forceinline__ void fft4(float2& x0, float2& x1, float2& x2, float2& x3) {
-    const float2 s02 = cadd(x0, x2), d02 = csub(x0, x2);
-    const float2 s13 = cadd(x1, x3), d13 = csub(x1, x3);
-    x0 = cadd(s02, s13);
-    x2 = csub(s02, s13);
-    x1 = make_float2(d02.x + d13.y, d02.y - d13.x);  // d02 - i d13
-    x3 = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + i d13
+__device__ __forceinline__ void fft4(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {
+    const v2f s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = x1 - x3;
+    const v2f r = mul_neg_i(d13);
+    x0 = s02 + s13;
+    x2 = s02 - s13;
+    x1 = d02 + r;
+    x3 = d02 - r;
 }
 
-// forward 16-point DFT in registers: n = 4p+q, k = r+4s
-__device__ __forceinline__ void fft16(float2 (&a)[16]) {
+#define BN_TW(c, s) (v2f){c, s}, (v2f){-(s), c}
+// forward 16-point DFT in registers: n = 4p+q, k = r+4s; the result X[r+4s] is left in a[4r+s]
+__device__ __forceinline__ void fft16(v2f (&a)[16]) {
     constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) fft4(a[q], a[4 + q], a[8 + q], a[12 + q]);
     // a[4r+q] *= W16^(q r)
-    a[4 * 1 + 1] = cmul(a[4 * 1 + 1], make_float2(c1, -s1));
-    a[4 * 1 + 2] = cmul(a[4 * 1 + 2], make_float2(h, -h));
-    a[4 * 1 + 3] = cmul(a[4 * 1 + 3], make_float2(s1, -c1));
-    a[4 * 2 + 1] = cmul(a[4 * 2 + 1], make_float2(h, -h));
-    a[4 * 2 + 2] = make_float2(a[4 * 2 + 2].y, -a[4 * 2 + 2].x);  // * (-i)
-    a[4 * 2 + 3] = cmul(a[4 * 2 + 3], make_float2(-h, -h));
-    a[4 * 3 + 1] = cmul(a[4 * 3 + 1], make_float2(s1, -c1));
-    a[4 * 3 + 2] = cmul(a[4 * 3 + 2], make_float2(-h, -h));
-    a[4 * 3 + 3] = cmul(a[4 * 3 + 3], make_float2(-c1, s1));
+    a[5] = cmulr(a[5], BN_TW(c1, -s1));
+    a[6] = cmulr(a[6], BN_TW(h, -h));
+    a[7] = cmulr(a[7], BN_TW(s1, -c1));
+    a[9] = cmulr(a[9], BN_TW(h, -h));
+    a[10] = mul_neg_i(a[10]);
+    a[11] = cmulr(a[11], BN_TW(-h, -h));
+    a[13] = cmulr(a[13], BN_TW(s1, -c1));
+    a[14] = cmulr(a[14], BN_TW(-h, -h));
+    a[15] = cmulr(a[15], BN_TW(-c1, s1));
 #pragma unroll
     for (int r = 0; r < 4; ++r) fft4(a[4 * r], a[4 * r + 1], a[4 * r + 2], a[4 * r + 3]);
-    // X[r+4s] sits in a[4r+s]: transpose the register names
-    float2 b[16];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[r + 4 * s] = a[4 * r + s];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = b[i];
 }
+// index of X[k] in the array fft16 leaves behind
+__device__ __forceinline__ constexpr int fidx(int k) { return 4 * (k & 3) + (k >> 2); }
 
 __global__ void minmax_init_kernel(float* minmax, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,10 +90,19 @@ struct MelOut {
     int M;
 };
 
+// The 16 lanes that own a frame sit in ONE wave, and every LDS exchange of the FFT stays inside that frame's slice of
+// `xch`, so no workgroup barrier is needed between the passes: LDS instructions of a wave execute in issue order, the
+// compiler only has to keep that order.  Waves of a workgroup therefore drift apart and overlap loads with arithmetic.
+__device__ __forceinline__ void frame_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool MEL_OUT>
 __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop,
                                                           int W, float* __restrict__ spec, float* minmax, MelOut mel) {
-    __shared__ float2 xch[kFT][kFS];
+    __shared__ v2f xch[kFT][kFS];
     __shared__ float mag[257][kFT + 1];
     __shared__ float red_min[4], red_max[4];
 
@@ -99,62 +113,65 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
     const int t = t0 + f;
     const float* x = audio + (size_t)b * T;
     const long start = (long)t * hop - 256;
+    const v2f* win2 = reinterpret_cast<const v2f*>(tb.window);  // 0.5 * periodic Hann, as pairs
 
-    // pass 1: lane j owns z[16 n1 + j], n1 = 0..15
-    float2 a[16];
+    // pass 1: lane j owns z[16 n1 + j], n1 = 0..15.  Raw buffer loads through a descriptor that covers exactly this
+    // chunk: samples before the chunk (negative offset = huge unsigned) or after it fail the hardware range check and
+    // read as 0, which is librosa's centre padding — no address clamping, no selects, all 32 loads in flight at once.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
+    const int off0 = (int)(start + 2 * j) * 4;
+    v2f a[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
-        const int i0 = 2 * (16 * n1 + j);
-        // unconditional loads from clamped addresses (all 32 in flight at once), zeroed afterwards when out of range
-        const long g0 = start + i0, g1 = g0 + 1;
-        const long c0 = g0 < 0 ? 0 : (g0 >= T ? T - 1 : g0), c1 = g1 < 0 ? 0 : (g1 >= T ? T - 1 : g1);
-        float v0 = x[c0], v1 = x[c1];
-        v0 = (g0 == c0) ? v0 : 0.0f;
-        v1 = (g1 == c1) ? v1 : 0.0f;
-        a[n1] = make_float2(v0 * tb.window[i0], v1 * tb.window[i0 + 1]);
+        v2f v;
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off0 + 128 * n1, 0, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off0 + 128 * n1 + 4, 0, 0));
+        a[n1] = v * win2[16 * n1 + j];
     }
     fft16(a);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) xch[f][k1 * 17 + j] = cmul(a[k1], tb.tw256[j * k1]);
-    __syncthreads();
+    for (int k1 = 0; k1 < 16; ++k1) {
+        const v4f w = reinterpret_cast<const v4f*>(tb.tw256)[j * k1];  // (w, w_rot)
+        xch[f][k1 * 17 + j] = cmulr(a[fidx(k1)], (v2f){w.x, w.y}, (v2f){w.z, w.w});
+    }
+    frame_sync();
 
     // pass 2: lane j is now k1; gathers over n2
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) a[n2] = xch[f][j * 17 + n2];
-    fft16(a);  // a[k2] = Z[j + 16 k2]
-    __syncthreads();
+    fft16(a);  // a[fidx(k2)] = Z[j + 16 k2] (scaled by 0.5 through the window)
+    frame_sync();
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) xch[f][j + 16 * k2] = a[k2];
-    __syncthreads();
+    for (int k2 = 0; k2 < 16; ++k2) xch[f][j + 16 * k2] = a[fidx(k2)];
+    frame_sync();
 
-    // split post-pass: X[k] = E - i W512^k O, E = (Z[k] + conj Z[256-k])/2, O = (Z[k] - conj Z[256-k])/2
+    // split post-pass: X[k] = E - i W512^k O with E = Z[k] + conj Z[256-k], O = Z[k] - conj Z[256-k] (the 1/2 is in Z)
     float lmin = __uint_as_float(0x7f800000u), lmax = 0.0f;
     const bool live = t < W;
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) {
         const int k = j + 16 * k2;
-        const float2 z = a[k2];
-        const float2 p = xch[f][(256 - k) & 255];
-        const float er = 0.5f * (z.x + p.x), ei = 0.5f * (z.y - p.y);
-        const float orr = 0.5f * (z.x - p.x), oi = 0.5f * (z.y + p.y);
-        const float2 w = tb.tw512[k];  // (cos, -sin)
-        const float c = w.x, sn = -w.y;
-        const float re = er - sn * orr + c * oi;
-        const float im = ei - c * orr - sn * oi;
-        const float m = sqrtf(re * re + im * im);
+        const v2f z = a[fidx(k2)];
+        v2f pc = xch[f][(256 - k) & 255];
+        pc.y = -pc.y;  // conj
+        const v2f e = z + pc, o = z - pc;
+        const v4f w = reinterpret_cast<const v4f*>(tb.tw512)[k];  // (-i W512^k, its rotation)
+        const v2f xr = __builtin_elementwise_fma(BN_YY(o), (v2f){w.z, w.w}, __builtin_elementwise_fma(BN_XX(o), (v2f){w.x, w.y}, e));
+        const v2f sq = xr * xr;
+        const float m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
         mag[k][f] = m;
-        if (live) {
-            lmin = fminf(lmin, m);
-            lmax = fmaxf(lmax, m);
+        lmin = fminf(lmin, m);
+        lmax = fmaxf(lmax, m);
+        if (k == 0) {  // lane 0, k2 = 0: the Nyquist bin is Re Z[0] - Im Z[0]
+            const float ny = fabsf(e.x - o.y);
+            mag[256][f] = ny;
+            lmin = fminf(lmin, ny);
+            lmax = fmaxf(lmax, ny);
         }
     }
-    if (j == 0) {
-        const float m = fabsf(a[0].x - a[0].y);  // Nyquist bin
-        mag[256][f] = m;
-        if (live) {
-            lmin = fminf(lmin, m);
-            lmax = fmaxf(lmax, m);
-        }
+    if (!live) {
+        lmin = __uint_as_float(0x7f800000u);
+        lmax = 0.0f;
     }
     __syncthreads();
 
