@@ -68,6 +68,9 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
     if k == "f32_front":
         macs = 9 * p[0] * (p[1] // 2) * p[2] + p[4] * p[5] * p[2] * (9 + p[3])
         return batch * 4.0 * (p[0] * p[1] + p[4] * p[5] * p[3]), batch * 2.0 * macs
+    if k == "i8_front":
+        macs = 9 * p[0] * (p[1] // 2) * p[2] + p[4] * p[5] * p[2] * (9 + p[3])
+        return batch * 1.0 * (p[0] * p[1] + p[4] * p[5] * p[3]), batch * 2.0 * macs
     if k == "f32_mel":
         return batch * (p[0] * p[1] * 4 + p[2] * p[1] * 4), batch * 2.0 * p[0] * p[1] * p[2]
     if k == "i8_quant":

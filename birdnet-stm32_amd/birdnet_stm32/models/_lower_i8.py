@@ -223,6 +223,31 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             OH, pt, _ = same_pad(H, 3, sh_)
             OW, pl, _ = same_pad(Wd, 3, sw_)
             w = np.transpose(wt_.data[:, :, :, 0], (1, 2, 0))  # [3][3][Cout]
+            # front block: stem -> depthwise stride 2 -> pointwise in one kernel
+            d_op = ops[i + 1] if i + 1 < len(ops) else None
+            p_op = ops[i + 2] if i + 2 < len(ops) else None
+            if (fuse and d_op is not None and p_op is not None and d_op.name == "DEPTHWISE_CONV_2D" and p_op.name == "CONV_2D"
+                    and g.consumers.get(op.outputs[0], []) == [d_op.index] and g.consumers.get(d_op.outputs[0], []) == [p_op.index]
+                    and d_op.inputs[0] == op.outputs[0] and p_op.inputs[0] == d_op.outputs[0]
+                    and d_op.options["stride_h"] == 2 and d_op.options["stride_w"] == 2 and (sh_, sw_) == (1, 2) and Cout == 16
+                    and tuple(t[p_op.inputs[1]].shape[:3]) == (32, 1, 1)
+                    and not (i + 3 < len(ops) and ops[i + 3].name == "ADD" and p_op.outputs[0] in ops[i + 3].inputs)):
+                BH, BW = same_pad(OH, 3, 2)[0], same_pad(OW, 3, 2)[0]
+                if BH % 8 == 0 and BW % 8 == 0 and H == 2 * BH and Wd == 4 * BW:
+                    sd, zd, sdo, zdo, wtd, nd, mud, shd, dlo, dhi, bd = conv_common(d_op)
+                    sp, zp_, spo, zpo, wtp, N, mup, shp, plo, phi, bp = conv_common(p_op)
+                    bd = bd - zd * wtd.data[0].astype(np.int64).sum(axis=(0, 1))
+                    wpw = wtp.data.reshape(N, Cout)
+                    bp = bp - zp_ * wpw.astype(np.int64).sum(axis=1)
+                    v = pb.value(BH * BW * N)
+                    pb.op(pk.I8_FRONT, val[src], v, p=[H, Wd, Cout, N, BH, BW, z_i, z_o, a_lo, a_hi, zdo, dlo, dhi, zpo, plo, phi],
+                          t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
+                             pb.tensor(wtd.data[0], np.int8), pb.tensor(bd, np.int32), pb.tensor(mud, np.int32), pb.tensor(shd, np.int32),
+                             pb.tensor(pack_i8_fragments(wpw), np.int8), pb.tensor(bp, np.int32), pb.tensor(mup, np.int32), pb.tensor(shp, np.int32)],
+                          name=f"t{p_op.outputs[0]}", out_shape=(BH, BW, N), out_dtype="int8")
+                    val[p_op.outputs[0]], shape[p_op.outputs[0]] = v, (BH, BW, N)
+                    i += 3
+                    continue
             v = pb.value(OH * OW * Cout)
             pb.op(pk.I8_STEM, val[src], v, p=[H, Wd, Cout, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi],
                   t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],

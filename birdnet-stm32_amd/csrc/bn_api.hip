@@ -263,6 +263,22 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 bn::launch_i8_dwpw(a, s);
                 break;
             }
+            case BN_OP_I8_FRONT: {
+                bn::I8FrontParams q{};
+                q.stem_w = (const int8_t*)m->tensor(o.t[0]); q.stem_b = (const int32_t*)m->tensor(o.t[1]);
+                q.stem_mult = (const int32_t*)m->tensor(o.t[2]); q.stem_shift = (const int32_t*)m->tensor(o.t[3]);
+                q.dw_w = (const int8_t*)m->tensor(o.t[4]); q.dw_b = (const int32_t*)m->tensor(o.t[5]);
+                q.dw_mult = (const int32_t*)m->tensor(o.t[6]); q.dw_shift = (const int32_t*)m->tensor(o.t[7]);
+                q.pw_w = (const int8_t*)m->tensor(o.t[8]); q.pw_b = (const int32_t*)m->tensor(o.t[9]);
+                q.pw_mult = (const int32_t*)m->tensor(o.t[10]); q.pw_shift = (const int32_t*)m->tensor(o.t[11]);
+                q.H0 = p[0]; q.W0 = p[1]; q.C = p[2]; q.N = p[3]; q.OH = p[4]; q.OW = p[5];
+                q.stem_zp_in = p[6]; q.stem_zp_out = p[7]; q.stem_amin = p[8]; q.stem_amax = p[9];
+                q.dw_zp_out = p[10]; q.dw_amin = p[11]; q.dw_amax = p[12]; q.pw_zp_out = p[13]; q.pw_amin = p[14]; q.pw_amax = p[15];
+                if (!bn::i8_front_supported(q.H0, q.W0, q.C, q.N, q.OH, q.OW))
+                    return fail(BN_ERR_FORMAT, "operator %zu: unsupported INT8 front-block geometry", oi);
+                bn::launch_i8_front(q, (const int8_t*)in0, (int8_t*)out, B, s);
+                break;
+            }
             case BN_OP_I8_MEAN:
                 bn::launch_i8_mean((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], s);
                 break;
@@ -587,7 +603,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 const char* bn_kernel_names(void) {
     return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";
 }
 

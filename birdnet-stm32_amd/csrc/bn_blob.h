@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 #define BN_BLOB_MAGIC "BNHIPM01"
-#define BN_BLOB_VERSION 3u
+#define BN_BLOB_VERSION 4u
 
 #define BN_SLOT_INPUT (-1)
 #define BN_SLOT_SCORES (-2)
@@ -57,7 +57,7 @@ struct TensorRec {
 };
 
 #define BN_OP_NP 40
-#define BN_OP_NT 10
+#define BN_OP_NT 12
 #define BN_OP_NF 8
 
 struct OpRec {
@@ -134,4 +134,8 @@ enum BnOpKind : int32_t {
     //    | has_add z1 m1 s1 m2 s2 mo so zo amin amax | has_dw transposed TH TW NB has_lut
     // in1: residual slot   t: dw_w dw_b(zp folded) dw_mult dw_shift pw_w(fragment order) pw_b(zp folded) pw_mult pw_shift lut
     BN_OP_I8_DWPW = 28,
+    // frontend output [H0][W0] int8 -> stem 3x3 s(1,2) -> depthwise 3x3 s2 -> pointwise, one kernel
+    // p: H0 W0 C N OH OW | stem_zp_in stem_zp_out stem_amin stem_amax | dw_zp_out dw_amin dw_amax | pw_zp_out pw_amin pw_amax
+    // t: stem_w stem_b stem_mult stem_shift dw_w dw_b(zp folded) dw_mult dw_shift pw_w(fragment order) pw_b(zp folded) pw_mult pw_shift
+    BN_OP_I8_FRONT = 29,
 };

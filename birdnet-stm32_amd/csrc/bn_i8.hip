@@ -10,32 +10,14 @@
 // Where a layer has no spatial padding (1x1 convs, mel mixer, FC) the packer folds -zp_x*sum(w)
 // into the bias, which is the same int32 arithmetic re-associated (exact).
 #include "bn_kernels.h"
+#include "bn_requant.h"
 
 namespace bn {
 namespace {
 
-__device__ __forceinline__ int32_t srdhm(int32_t a, int32_t b) {
-    const bool overflow = (a == b) && (a == INT32_MIN);
-    const int64_t ab = (int64_t)a * (int64_t)b;
-    const int64_t nudge = ab >= 0 ? (1ll << 30) : (1ll - (1ll << 30));
-    const int32_t r = (int32_t)((ab + nudge) / (1ll << 31));  // C++ division truncates toward zero
-    return overflow ? INT32_MAX : r;
-}
 
-__device__ __forceinline__ int32_t rounding_divide_by_pot(int32_t x, int exponent) {
-    const int32_t mask = (int32_t)((1u << exponent) - 1u);
-    const int32_t remainder = x & mask;
-    const int32_t threshold = (mask >> 1) + (x < 0 ? 1 : 0);
-    return (x >> exponent) + (remainder > threshold ? 1 : 0);
-}
 
-__device__ __forceinline__ int32_t mbqm(int32_t x, int32_t mult, int shift) {
-    const int left = shift > 0 ? shift : 0;
-    const int right = shift > 0 ? 0 : -shift;
-    return rounding_divide_by_pot(srdhm(x * (1 << left), mult), right);
-}
 
-__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __device__ __forceinline__ int32_t dot4(int32_t a, int32_t b, int32_t c) {
 #if __has_builtin(__builtin_amdgcn_sdot4)

@@ -18,31 +18,13 @@
 //            weights the packer stored in fragment order (1 KiB contiguous per wave-instruction)
 //   epilogue: int32 accumulators -> LDS -> requantise 4 channels per thread -> packed dword stores.
 #include "bn_kernels.h"
+#include "bn_requant.h"
 
 namespace bn {
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ int32_t srdhm(int32_t a, int32_t b) {
-    const bool overflow = (a == b) && (a == INT32_MIN);
-    const int64_t ab = (int64_t)a * (int64_t)b;
-    const int64_t nudge = ab >= 0 ? (1ll << 30) : (1ll - (1ll << 30));
-    const int32_t r = (int32_t)((ab + nudge) / (1ll << 31));
-    return overflow ? INT32_MAX : r;
-}
-__device__ __forceinline__ int32_t rdivpot(int32_t x, int exponent) {
-    const int32_t mask = (int32_t)((1u << exponent) - 1u);
-    const int32_t remainder = x & mask;
-    const int32_t threshold = (mask >> 1) + (x < 0 ? 1 : 0);
-    return (x >> exponent) + (remainder > threshold ? 1 : 0);
-}
-__device__ __forceinline__ int32_t mbqm(int32_t x, int32_t mult, int shift) {
-    const int left = shift > 0 ? shift : 0;
-    const int right = shift > 0 ? 0 : -shift;
-    return rdivpot(srdhm(x * (1 << left), mult), right);
-}
-__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int32_t sx8(int32_t v, int byte) { return (int32_t)(int8_t)(v >> (8 * byte)); }
 
 struct PosInfo8 {
@@ -258,6 +240,145 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// INT8 front block: frontend output [64][256] int8 -> CONV_2D 3x3 stem (stride 1x2, ReLU6) -> DEPTHWISE_CONV_2D 3x3
+// stride 2 (ReLU6) -> CONV_2D 1x1 (ReLU6) in one kernel; the int8 stem activation (128 KB per chunk) stays in LDS.
+// Padding follows TFLite: cells outside the stem's input contribute (zp - zp) = 0, cells outside the stem map hold the
+// stem output zero point for the depthwise stage.  Bit-identical to the three separate kernels.
+struct Front8Args {
+    const int8_t* fe;        // [B][H0][W0]
+    int8_t* y;               // [B][OH][OW][N]
+    const int8_t* stem_w;    // [3][3][C]
+    const int32_t* stem_b;   // [C]
+    const int32_t* stem_mult;
+    const int32_t* stem_shift;
+    const int8_t* dw_w;      // [3][3][C]
+    const int32_t* dw_b;     // [C], zero point folded
+    const int32_t* dw_mult;
+    const int32_t* dw_shift;
+    const int8_t* pw_w;      // fragment order
+    const int32_t* pw_b;     // zero point folded
+    const int32_t* pw_mult;
+    const int32_t* pw_shift;
+    int B, H0, W0, SH, SW, N, OH, OW;
+    int stem_zp_in, stem_zp_out, stem_amin, stem_amax, dw_zp_out, dw_amin, dw_amax, pw_zp_out, pw_amin, pw_amax;
+};
+
+__global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
+    constexpr int TS = 17, FH = 19, FW = 35, C = 16, NS = 32;
+    __shared__ int8_t fe_t[FH][FW + 1];
+    __shared__ __attribute__((aligned(16))) int stem_t[TS * TS][C / 4];       // 4 channels per dword
+    __shared__ __attribute__((aligned(16))) int tile[64 * (NS + 4)];          // A tile [64][64 + 16 bytes], later int32 accumulators
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tiles_x = a.OW / 8, tiles_y = a.OH / 8;
+    const int tx0 = (bid % tiles_x) * 8;
+    bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * 8;
+    const int chunk = bid / tiles_y;
+
+    const int r_base = 2 * ty0 - 1, c_base = 4 * tx0;
+    const int8_t* fe = a.fe + (size_t)chunk * a.H0 * a.W0;
+    for (int i = tid; i < FH * FW; i += 256) {
+        const int rr = i / FW, cc = i - rr * FW;
+        const int gr = r_base + rr, gc = c_base + cc;
+        fe_t[rr][cc] = (gr >= 0 && gr < a.H0 && gc >= 0 && gc < a.W0) ? fe[gr * a.W0 + gc] : (int8_t)a.stem_zp_in;
+    }
+    __syncthreads();
+
+    {   // stem patch: thread = (stem position, channel quad)
+        const int cq = tid & 3;
+        int w9[9], b4[4], m4[4], s4[4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[t] = *reinterpret_cast<const int*>(a.stem_w + t * C + 4 * cq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b4[e] = a.stem_b[4 * cq + e];
+            m4[e] = a.stem_mult[4 * cq + e];
+            s4[e] = a.stem_shift[4 * cq + e];
+        }
+        const int zpo4 = (a.stem_zp_out & 0xff) * 0x01010101;
+        for (int sp = tid >> 2; sp < TS * TS; sp += 64) {
+            const int sr = sp / TS, sc = sp - sr * TS;
+            int acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int v = (int)fe_t[sr + i][2 * sc + j] - a.stem_zp_in;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += v * sx8(w9[i * 3 + j], e);
+                }
+            int packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                packed |= (clampi(mbqm(acc[e], m4[e], s4[e]) + a.stem_zp_out, a.stem_amin, a.stem_amax) & 0xff) << (8 * e);
+            const bool inside = (2 * ty0 + sr) < a.SH && (2 * tx0 + sc) < a.SW;
+            stem_t[sp][cq] = inside ? packed : zpo4;
+        }
+    }
+    __syncthreads();
+
+    {   // depthwise stride 2: 64 positions x 4 channel quads = one item per thread
+        const int cq = tid & 3, p = tid >> 2;
+        const int py = p >> 3, px = p & 7;
+        int acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = a.dw_b[4 * cq + e];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int v = stem_t[(2 * py + i) * TS + 2 * px + j][cq];
+                const int w = *reinterpret_cast<const int*>(a.dw_w + (i * 3 + j) * C + 4 * cq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += sx8(v, e) * sx8(w, e);
+            }
+        int packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            packed |= (clampi(mbqm(acc[e], a.dw_mult[4 * cq + e], a.dw_shift[4 * cq + e]) + a.dw_zp_out, a.dw_amin, a.dw_amax) & 0xff) << (8 * e);
+        tile[p * 20 + cq] = packed;  // row stride 80 bytes = 64 (one MFMA k-step) + 16; columns 16..63 meet zero weights
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;  // 2 x 2 waves: 32 rows x 16 columns each
+    const int row0 = wm * 32;
+    const v4i* lds16 = reinterpret_cast<const v4i*>(tile);
+    const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);
+    v4i acc[2];
+    const v4i bf = wp[(size_t)wn * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        acc[g] = (v4i){0, 0, 0, 0};
+        v4i af = lds16[(row0 + 16 * g + r) * 5 + q];
+        if (q) af = (v4i){0, 0, 0, 0};  // only the first 16 of the 64 contraction bytes are real channels
+        acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[g], 0, 0, 0);
+    }
+    constexpr int SO = NS + 4;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) tile[(row0 + 16 * g + 4 * q + reg) * SO + wn * 16 + r] = acc[g][reg];
+    __syncthreads();
+    for (int item = tid; item < 64 * 8; item += 256) {
+        const int p = item >> 3, c4 = item & 7;
+        const int oh = ty0 + (p >> 3), ow = tx0 + (p & 7);
+        const v4i v = *reinterpret_cast<const v4i*>(tile + p * SO + 4 * c4);
+        const v4i b = *reinterpret_cast<const v4i*>(a.pw_b + 4 * c4);
+        const v4i m = *reinterpret_cast<const v4i*>(a.pw_mult + 4 * c4);
+        const v4i sh = *reinterpret_cast<const v4i*>(a.pw_shift + 4 * c4);
+        int packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            packed |= (clampi(mbqm(v[e] + b[e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax) & 0xff) << (8 * e);
+        *reinterpret_cast<int*>(a.y + (((size_t)chunk * a.OH + oh) * a.OW + ow) * a.N + 4 * c4) = packed;
+    }
+}
+
 template <int RG, int CT>
 void launch_cfg8(const DwPw8Args& a, hipStream_t s) {
     const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * ((a.B + a.NB - 1) / a.NB);
@@ -276,6 +397,17 @@ void launch_cfg8(const DwPw8Args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+bool i8_front_supported(int H0, int W0, int C, int N, int OH, int OW) {
+    return C == 16 && N == 32 && OH % 8 == 0 && OW % 8 == 0 && H0 == 2 * OH && W0 == 4 * OW;
+}
+
+void launch_i8_front(const I8FrontParams& q, const int8_t* fe, int8_t* y, int B, hipStream_t s) {
+    Front8Args a{fe, y, q.stem_w, q.stem_b, q.stem_mult, q.stem_shift, q.dw_w, q.dw_b, q.dw_mult, q.dw_shift, q.pw_w, q.pw_b, q.pw_mult,
+                 q.pw_shift, B, q.H0, q.W0, q.H0, q.W0 / 2, q.N, q.OH, q.OW, q.stem_zp_in, q.stem_zp_out, q.stem_amin, q.stem_amax,
+                 q.dw_zp_out, q.dw_amin, q.dw_amax, q.pw_zp_out, q.pw_amin, q.pw_amax};
+    hipLaunchKernelGGL(i8_front_kernel, dim3((q.OH / 8) * (q.OW / 8) * B), dim3(256), 0, s, a);
+}
 
 bool i8_dwpw_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 16 == 0 && Cin >= 4; }
 

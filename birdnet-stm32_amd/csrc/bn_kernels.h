@@ -108,6 +108,16 @@ struct DwPw8Args {
     I8AddParams add;
 };
 bool i8_dwpw_supported(int Cin, int Cout);
+// INT8 stem 3x3 + depthwise 3x3 stride 2 + pointwise in one kernel (bn_i8_fused.hip)
+struct I8FrontParams {
+    const int8_t* stem_w; const int32_t* stem_b; const int32_t* stem_mult; const int32_t* stem_shift;
+    const int8_t* dw_w; const int32_t* dw_b; const int32_t* dw_mult; const int32_t* dw_shift;
+    const int8_t* pw_w; const int32_t* pw_b; const int32_t* pw_mult; const int32_t* pw_shift;
+    int H0, W0, C, N, OH, OW;
+    int stem_zp_in, stem_zp_out, stem_amin, stem_amax, dw_zp_out, dw_amin, dw_amax, pw_zp_out, pw_amin, pw_amax;
+};
+bool i8_front_supported(int H0, int W0, int C, int N, int OH, int OW);
+void launch_i8_front(const I8FrontParams& q, const int8_t* fe, int8_t* y, int B, hipStream_t s);
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s);
 
 }  // namespace bn

@@ -1,0 +1,57 @@
+// bn_requant.h — gemmlowp/TFLite fixed-point requantisation on the vector ALU, shared by the INT8 kernels.
+//
+//   MultiplyByQuantizedMultiplier(x, M0, shift) = RoundingDivideByPOT(SaturatingRoundingDoublingHighMul(x << left, M0), right)
+//
+// The fast forms below are algebraically identical to the reference definitions for M0 >= 0 and |x| < 2^30 (every
+// accumulator of the supported graphs: |x| <= K * 127 * 255 + |bias|, and (q - zp) << 20 < 2^28 in ADD):
+//   SRDHM: trunc((x*M0 + nudge) / 2^31), nudge = 2^30 for x*M0 >= 0 and 1 - 2^30 otherwise, equals the ARITHMETIC shift
+//          (x*M0 + 2^30) >> 31 for both signs (for negatives trunc(y/2^31) = floor((y + 2^31 - 1)/2^31) and the nudges differ
+//          by exactly 2^31 - 1), i.e. one 32x32 -> 64 multiply, an add with carry and a funnel shift;
+//   RoundingDivideByPOT(v, e): (v >> e) + ((v & mask) > (mask >> 1) + (v < 0)) equals (v + half + (v < 0 ? -1 : 0)) >> e
+//          with half = 2^(e-1) (and v itself for e = 0).
+// Left shifts (shift > 0) and negative multipliers take the literal reference path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bn {
+
+__device__ __forceinline__ int32_t srdhm_ref(int32_t a, int32_t b) {
+    const bool overflow = (a == b) && (a == INT32_MIN);
+    const int64_t ab = (int64_t)a * (int64_t)b;
+    const int64_t nudge = ab >= 0 ? (1ll << 30) : (1ll - (1ll << 30));
+    const int32_t r = (int32_t)((ab + nudge) / (1ll << 31));
+    return overflow ? INT32_MAX : r;
+}
+__device__ __forceinline__ int32_t rdivpot_ref(int32_t x, int exponent) {
+    const int32_t mask = (int32_t)((1u << exponent) - 1u);
+    const int32_t remainder = x & mask;
+    const int32_t threshold = (mask >> 1) + (x < 0 ? 1 : 0);
+    return (x >> exponent) + (remainder > threshold ? 1 : 0);
+}
+__device__ __forceinline__ int32_t mbqm_ref(int32_t x, int32_t mult, int shift) {
+    const int left = shift > 0 ? shift : 0;
+    const int right = shift > 0 ? 0 : -shift;
+    return rdivpot_ref(srdhm_ref(x * (1 << left), mult), right);
+}
+
+__device__ __forceinline__ int32_t srdhm_pos(int32_t x, int32_t m) {  // m >= 0
+    const int32_t hi = __mulhi(x, m);
+    const uint32_t lo = (uint32_t)x * (uint32_t)m;
+    const uint32_t lo2 = lo + 0x40000000u;
+    const int32_t hi2 = hi + (lo2 < lo ? 1 : 0);
+    return (int32_t)(((uint32_t)hi2 << 1) | (lo2 >> 31));
+}
+__device__ __forceinline__ int32_t rdivpot_fast(int32_t v, int e) {  // e >= 0
+    const int32_t half = e ? (1 << (e - 1)) : 0;  // e up to 31 occurs (dead channels with vanishing scales)
+    const int32_t adj = e ? (v >> 31) : 0;
+    return (v + half + adj) >> e;
+}
+__device__ __forceinline__ int32_t mbqm(int32_t x, int32_t mult, int shift) {
+    if (shift <= 0 && mult >= 0) return rdivpot_fast(srdhm_pos(x, mult), -shift);
+    return mbqm_ref(x, mult, shift);
+}
+
+__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+}  // namespace bn
