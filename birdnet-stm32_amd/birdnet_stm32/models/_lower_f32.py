@@ -108,7 +108,8 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
         in_kind, F, W = pk.INPUT_SPECTROGRAM, layers[0].out_shape[0], int(fa["spec_width"])
         in_elems = int(np.prod(layers[0].out_shape))
     elif fa["mode"] == "raw":
-        raise NotImplementedError("raw-waveform frontend is not lowered to HIP yet")
+        in_kind, F, W = pk.INPUT_WAVEFORM, 0, int(fa["spec_width"])
+        in_elems = int(fa["sample_rate"] * fa["chunk_duration"])
     else:
         raise NotImplementedError(f"frontend mode {fa['mode']!r} is not lowered to HIP yet")
 
@@ -155,6 +156,21 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
         if k == ns.INPUT:
             val[ly.name] = pk.SLOT_INPUT
             shape[ly.name] = ly.out_shape
+        elif k == ns.FRONTEND and fa["mode"] == "raw":
+            M, T = int(fa["mel_bins"]), in_elems
+            if M % 4:
+                raise NotImplementedError("raw frontend needs a multiple of 4 filters")
+            stride = -(-T // W)
+            pad_total = max(0, stride * (W - 1) + 16 - T)
+            g_ = ly.weights["fb_gamma"].astype(np.float64) / np.sqrt(ly.weights["fb_var"].astype(np.float64) + float(fa.get("fb_eps", 1e-3)))
+            fb = (ly.weights["fb"].astype(np.float64) * g_).astype(np.float32)  # [16][M], BatchNorm folded
+            fbias = (ly.weights["fb_beta"].astype(np.float64) - ly.weights["fb_mean"].astype(np.float64) * g_).astype(np.float32)
+            mag = pk.MAG_CODES[fa.get("mag_scale", "none")]
+            v = pb.value(M * W * 4)
+            pb.op(pk.F32_RAWFE, val[ly.inputs[0]], v, p=[T, W, M, stride, pad_total // 2, mag],
+                  t=[pb.tensor(fb, np.float32), pb.tensor(fbias, np.float32), pb.tensor(mag_params(ly), np.float32)], name=ly.name,
+                  out_shape=(M, W, 1))
+            val[ly.name], shape[ly.name] = v, (M, W, 1)
         elif k == ns.FRONTEND:
             M = int(fa["mel_bins"])
             wv, bands = mel_bands(ly.weights["mel"], F)

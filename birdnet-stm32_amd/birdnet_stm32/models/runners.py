@@ -66,7 +66,8 @@ class HipRunner:
         torch = self._torch
         x = np.ascontiguousarray(np.asarray(x_batch).astype(np.float32, copy=False))
         if x.ndim < 2 or int(np.prod(x.shape[1:])) != self.input_elems:
-            raise ValueError(f"expected input of shape [B, {self.fft_bins}, {self.spec_width}, 1], got {x.shape}")
+            want = f"[B, {self.fft_bins}, {self.spec_width}, 1]" if self.fft_bins else f"[B, {self.input_elems}, 1]"
+            raise ValueError(f"expected input of shape {want}, got {x.shape}")
         B = x.shape[0]
         out = np.empty((B, self.num_classes), np.float32)
         for b0 in range(0, B, self.max_batch):

@@ -121,6 +121,38 @@ __global__ __launch_bounds__(256) void f32_melfin_kernel(const float* __restrict
     }
 }
 
+// raw-waveform frontend: symmetric zero pad, VALID strided 1x16 convolution (BatchNorm folded), ReLU6, magnitude scaling,
+// output transposed to [M][W] (reference: birdnet_stm32/models/frontend.py:138-164,347-358).  Thread = (frame t, 4 filters).
+__global__ void f32_rawfe_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int W, int M, int stride, int pad_left,
+                                 const float* __restrict__ fb, const float* __restrict__ bias, const float* __restrict__ magp, int mag,
+                                 long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int t = (int)(gid % W);
+    long r = gid / W;
+    const int mq = (int)(r % (M / 4));
+    const long b = r / (M / 4);
+    const float* xin = x + b * T;
+    float4 acc = *reinterpret_cast<const float4*>(bias + 4 * mq);
+    const int s0 = t * stride - pad_left;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int g = s0 + k;
+        const float v = (g >= 0 && g < T) ? xin[g] : 0.0f;
+        const float4 w = *reinterpret_cast<const float4*>(fb + k * M + 4 * mq);
+        acc.x = fmaf(v, w.x, acc.x);
+        acc.y = fmaf(v, w.y, acc.y);
+        acc.z = fmaf(v, w.z, acc.z);
+        acc.w = fmaf(v, w.w, acc.w);
+    }
+    const float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = 4 * mq + e;
+        out[(b * M + m) * W + t] = mag_scale(fminf(fmaxf(o[e], 0.0f), 6.0f), m, M, magp, mag);
+    }
+}
+
 // stem: [H][W] (one channel) -> [OH][OW][Cout], 3x3.  One thread = 4 output channels of one pixel.
 __global__ void f32_stem_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Cout, int sh,
                                 int sw, int act, int OH, int OW, int pt, int pl, const float* __restrict__ w,
@@ -360,6 +392,13 @@ void launch_f32_mel(const float* spec, const float* minmax, float* out, float* s
 
 void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const float* magp, int mag, hipStream_t s) {
     hipLaunchKernelGGL(f32_mag_kernel, dim3(16, B), dim3(256), 0, s, x, smax, M, W, magp, mag);
+}
+
+void launch_f32_rawfe(const float* x, float* out, int B, int T, int W, int M, int stride, int pad_left, const float* fb,
+                      const float* bias, const float* magp, int mag, hipStream_t s) {
+    const long total = (long)B * (M / 4) * W;
+    hipLaunchKernelGGL(f32_rawfe_kernel, grid1d(total, 256), dim3(256), 0, s, x, out, T, W, M, stride, pad_left, fb, bias, magp, mag,
+                       total);
 }
 
 void launch_f32_melfin(const float* melraw, const float* minmax, float* out, int B, int M, int W, const float* wsum,

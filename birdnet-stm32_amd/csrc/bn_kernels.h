@@ -25,6 +25,8 @@ void launch_f32_mel(const float* spec, const float* minmax, float* out, float* s
                     const float* wvals, const int* bands, const float* magp, int mag, int norm, hipStream_t s);
 void launch_f32_melfin(const float* melraw, const float* minmax, float* out, int B, int M, int W, const float* wsum,
                        const float* magp, int mag, int norm, hipStream_t s);
+void launch_f32_rawfe(const float* x, float* out, int B, int T, int W, int M, int stride, int pad_left, const float* fb,
+                      const float* bias, const float* magp, int mag, hipStream_t s);
 void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const float* magp, int mag, hipStream_t s);
 void launch_u32_fill(uint32_t* p, uint32_t v, int n, hipStream_t s);
 void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, int sh, int sw, int act, int OH, int OW,

@@ -11,10 +11,48 @@ import pytest
 from conftest import KERAS_PATH, REPO, TFLITE_PATH
 
 
-def _plans(keep_all=False):
+def _plans(keep_all=False, fuse=False):
     from birdnet_stm32.models.runners import lower_model_file
 
-    return lower_model_file(KERAS_PATH, keep_all=keep_all), lower_model_file(TFLITE_PATH, keep_all=keep_all)
+    return lower_model_file(KERAS_PATH, keep_all=keep_all, fuse=fuse), lower_model_file(TFLITE_PATH, keep_all=keep_all, fuse=fuse)
+
+
+def test_fused_plan_structure():
+    """The production plans: front block + fused depthwise/pointwise blocks on the matrix cores, audio-path operators."""
+    from birdnet_stm32.models import _pack as pk
+
+    f32, i8 = _plans(fuse=True)
+    kinds = [pk.KIND_NAMES[o.kind] for o in f32.ops]
+    assert kinds == ["f32_mel", "f32_stftmel", "f32_melfin", "f32_front"] + ["f32_dwpw"] * 10 + ["f32_gap", "f32_dense"]
+    paths = [o.p[pk.OP_PATH] for o in f32.ops]
+    assert paths[:3] == [pk.PATH_INPUT, pk.PATH_AUDIO, pk.PATH_AUDIO] and set(paths[3:]) == {pk.PATH_BOTH}
+    assert f32.ops[1].in0 == pk.SLOT_AUDIO and f32.ops[0].in0 == pk.SLOT_INPUT
+    assert f32.ops[0].out == f32.ops[2].out  # both entry points feed the same frontend-output slot
+    assert sum(1 for o in f32.ops if o.kind == pk.F32_DWPW and o.p[12]) == 7  # residual blocks
+    kinds = [pk.KIND_NAMES[o.kind] for o in i8.ops]
+    assert kinds == ["i8_quant", "i8_dwpw", "i8_front"] + ["i8_dwpw"] * 10 + ["i8_mean", "i8_fc", "i8_head"]
+    assert i8.ops[1].p[30] == 1 and i8.ops[1].p[34] == 1  # the mel mixer: transposed output + PWL table
+    assert sum(1 for o in i8.ops if o.kind == pk.I8_DWPW and o.p[18]) == 7
+    for plan in (f32, i8):
+        for o in plan.ops:
+            if o.kind in (pk.F32_DWPW, pk.I8_DWPW):
+                th, tw, nb = (o.p[16], o.p[17], o.p[18]) if o.kind == pk.F32_DWPW else (o.p[31], o.p[32], o.p[33])
+                assert th * tw * nb == 64 and o.p[6] % th == 0 and o.p[7] % tw == 0
+    # fragment-ordered pointwise weights: [K/16][N/16][64][4] floats hold exactly the folded [K][N] matrix
+    from birdnet_stm32.models._lower_f32 import pack_pw_fragments
+    from birdnet_stm32.models._lower_i8 import pack_i8_fragments
+
+    w = np.arange(32 * 48, dtype=np.float32).reshape(32, 48)
+    fr = pack_pw_fragments(w)
+    assert fr.shape == (2, 3, 64, 4)
+    for j, ct, lane, e in ((0, 0, 0, 0), (1, 2, 37, 3), (0, 1, 63, 2)):
+        assert fr[j, ct, lane, e] == w[16 * j + 4 * (lane >> 4) + e, 16 * ct + (lane & 15)]
+    w8 = (np.arange(32 * 80) % 251 - 125).astype(np.int8).reshape(32, 80)
+    f8 = pack_i8_fragments(w8)
+    assert f8.shape == (2, 2, 64, 16)
+    assert np.array_equal(f8[1, 0, 5], w8[5, 64:80]) and np.all(f8[1, 1, 17] == 0)  # step 1: lane 5 -> k 64..79; lane 17 -> k 80..95 = padding
+    assert np.array_equal(f8[0, 1, 37], w8[16 + 5, 32:48])  # lane 37: q = 2, c = 5 -> channel 21, k = 32..47
+    assert np.all(f8[1, :, 16:, :] == 0)  # k >= 80 is zero padding (q >= 1 of step 1)
 
 
 def test_plan_structure():
@@ -43,17 +81,13 @@ def test_plan_structure():
 
 def test_slots_never_alias_live_values():
     """Liveness check of the packer: an operator's output slot differs from every slot still to be read."""
-    f32, i8 = _plans()
-    for plan in (f32, i8):
+    for f32, i8 in (_plans(), _plans(fuse=True)):
+      for plan in (f32, i8):
         assert len(plan.slot_bytes) <= 4
         for i, o in enumerate(plan.ops):
             if o.out < 0:
                 continue
-            for later in plan.ops[i + 1 :]:
-                reads = {later.in0, later.in1}
-                if o.out in reads:
-                    break  # consumed; may be recycled afterwards
-            live_inputs = {o.in0, o.in1} - {-9, -1}
+            live_inputs = {o.in0, o.in1} - {-9, -1, -4}
             assert o.out not in live_inputs or o.kind == 2, f"op {i} writes its own input slot"
     keep, _ = _plans(keep_all=True)
     outs = [o.out for o in keep.ops if o.out >= 0]
@@ -63,9 +97,9 @@ def test_slots_never_alias_live_values():
 def test_residual_source_survives_until_the_add():
     from birdnet_stm32.models import _pack as pk
 
-    f32, _ = _plans()
-    for i, o in enumerate(f32.ops):
-        if o.kind == pk.F32_PW and o.p[4]:
+    for f32 in (_plans()[0], _plans(fuse=True)[0]):
+      for i, o in enumerate(f32.ops):
+        if (o.kind == pk.F32_PW and o.p[4]) or (o.kind == pk.F32_DWPW and o.p[12]):
             res = o.in1
             # the producer of `res` is the last writer of that slot before op i
             writers = [j for j in range(i) if f32.ops[j].out == res]
@@ -123,7 +157,9 @@ def test_pwl_table_and_folded_biases_match_the_oracle():
     from oracle import int8_graph as og
 
     model = load_tflite(TFLITE_PATH)
+    _, i8f = _plans(fuse=True)
     _, i8 = _plans()
+    assert np.array_equal(i8f.tensors[i8f.ops[1].t[8]], i8.tensors[i8.ops[1].t[4]])  # same PWL table in both plans
     mel = i8.ops[1]
     lut = i8.tensors[mel.t[4]]  # [64][256]
     interp = og.Int8Interpreter(model)
