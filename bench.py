@@ -128,13 +128,19 @@ def roofline_of(rows: list[dict], batch: int, dtype: str) -> tuple[dict, list[di
     return roof, stages
 
 
-def cpu_baseline(dtype: str, seconds_budget: float = 20.0) -> dict:
-    """Time the numpy oracle (the CPU restatement of the reference path) on a bounded sample."""
+def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
+    """Time the CPU restatement of the reference path (``oracle/``) on this host, on a bounded sample.
+
+    float32: the plain-C + OpenMP port (``oracle/c/oracle_cpu.c``) on all host threads when it has been built, otherwise the
+    numpy oracle on one thread.  INT8: the numpy TFLite-semantics interpreter on one thread (there is no C port of it).
+    """
+    import contextlib
+
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    from oracle import float_graph, stft
+    from oracle import cport, float_graph, stft
     from oracle.int8_graph import Int8Interpreter
 
     from birdnet_stm32.models._keras_loader import load_keras_archive
@@ -144,9 +150,26 @@ def cpu_baseline(dtype: str, seconds_budget: float = 20.0) -> dict:
     rng = np.random.default_rng(42)
     t = np.arange(T) / SR
 
-    def chunk(b):
-        x = 0.3 * rng.standard_normal(T) + np.sin(2 * np.pi * (500 + 37 * (b % 200)) * t)
-        return (x / np.abs(x).max()).astype(np.float32)
+    def chunks(n):
+        x = 0.3 * rng.standard_normal((n, T)) + np.sin(2 * np.pi * (500 + 37 * (np.arange(n) % 200))[:, None] * t[None, :])
+        return (x / np.abs(x).max(axis=1, keepdims=True)).astype(np.float32)
+
+    if dtype == "f32" and os.path.isfile(cport.CPU_LIB):
+        path = cport.CpuFloatPath(load_keras_archive(ckpt + ".keras"))
+        x = chunks(256)
+        path(x[:32])  # warm up the OpenMP pool
+        t0 = time.perf_counter()
+        path(x)
+        per = (time.perf_counter() - t0) / 256
+        n = int(max(256, min(16384, seconds_budget / per // 256 * 256)))
+        reps, done, t0 = n // 256, 0, time.perf_counter()
+        for _ in range(reps):
+            path(x)
+            done += 256
+        dt = time.perf_counter() - t0
+        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": path.threads, "kind": "port",
+                "sample": f"{done} synthetic 3 s @ 24 kHz chunks, plain-C + OpenMP port of the float path (oracle/c/oracle_cpu.c), "
+                          f"{path.threads} threads, {dt:.1f} s"}
 
     if dtype == "f32":
         spec = load_keras_archive(ckpt + ".keras")
@@ -155,19 +178,17 @@ def cpu_baseline(dtype: str, seconds_budget: float = 20.0) -> dict:
         interp = Int8Interpreter(load_tflite(ckpt + ".tflite"))
         run = lambda S: interp.invoke(S)  # noqa: E731
 
-    def work(n):
-        xs = [chunk(b) for b in range(n)]
+    def work(xs):
         t0 = time.perf_counter()
-        S = np.stack([stft.hybrid_spectrogram(a, NFFT, W) for a in xs])[..., None]
-        run(S)
+        for i in range(0, len(xs), 64):
+            S = np.stack([stft.hybrid_spectrogram(a, NFFT, W) for a in xs[i : i + 64]])[..., None]
+            run(S)
         return time.perf_counter() - t0
 
-    import contextlib
-
     with threadpool_limits(limits=1) if threadpool_limits else contextlib.nullcontext():
-        per8 = work(8)  # also warms caches/imports
-        n = int(max(8, min(256, (seconds_budget / max(per8 / 8, 1e-4)) // 8 * 8)))
-        dt = work(n)
+        per = work(chunks(16)) / 16
+        n = int(max(64, min(4096, seconds_budget / per // 64 * 64)))
+        dt = work(chunks(n))
     return {"value": round(n / dt, 2), "unit": "chunks/s", "cores": 1, "kind": "port",
             "sample": f"{n} synthetic 3 s @ 24 kHz chunks, numpy oracle (oracle/stft.py + "
                       f"{'float_graph' if dtype == 'f32' else 'int8_graph'}.py), 1 thread, {dt:.1f} s"}

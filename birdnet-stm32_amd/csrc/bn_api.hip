@@ -338,15 +338,23 @@ int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
     std::vector<float> win(kFft);
     std::vector<float4> t256(256), t512(257);
     const double two_pi = 6.283185307179586476925286766559;
-    // the 1/2 of the real-FFT split pass is folded into the window (exact: a power of two)
-    for (int i = 0; i < kFft; ++i) win[i] = 0.5f * (float)(0.5 - 0.5 * cos(two_pi * i / kFft));
+    // per-lane base angles; the kernel rebuilds window and split-pass twiddles from them (see bn_stft.hip)
+    win.assign(64, 0.0f);
+    for (int j = 0; j < 16; ++j) {
+        const double t0 = two_pi * (2 * j) / 512.0, t1 = two_pi * (2 * j + 1) / 512.0;
+        win[4 * j + 0] = (float)(-0.25 * cos(t0));
+        win[4 * j + 1] = (float)(-0.25 * cos(t1));
+        win[4 * j + 2] = (float)(0.25 * sin(t0));
+        win[4 * j + 3] = (float)(0.25 * sin(t1));
+    }
     for (int i = 0; i < 256; ++i) {  // w = exp(-2 pi i p / 256), stored with its rotation (-w.y, w.x)
         const float c = (float)cos(two_pi * i / 256.0), sn = (float)sin(two_pi * i / 256.0);
         t256[i] = make_float4(c, -sn, sn, c);
     }
-    for (int i = 0; i < 257; ++i) {  // t = -i exp(-2 pi i k / 512) = (-sin, -cos), rotation (cos, -sin)
-        const float c = (float)cos(two_pi * i / 512.0), sn = (float)sin(two_pi * i / 512.0);
-        t512[i] = make_float4(-sn, -c, c, -sn);
+    t512.assign(16, make_float4(0, 0, 0, 0));
+    for (int j = 0; j < 16; ++j) {
+        const float c = (float)cos(two_pi * j / 512.0), sn = (float)sin(two_pi * j / 512.0);
+        t512[j] = make_float4(-sn, -c, -c, sn);
     }
     HIP_TRY(hipMalloc(&c->d_window, win.size() * sizeof(float)));
     HIP_TRY(hipMalloc(&c->d_tw256, t256.size() * sizeof(float4)));

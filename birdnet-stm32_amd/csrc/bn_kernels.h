@@ -7,9 +7,10 @@ namespace bn {
 
 // Read-only tables every STFT launch needs (built once per context, in double, stored f32).
 struct StftTables {
-    const float* window;    // [512] 0.5 * periodic Hann (the 1/2 of the real-FFT split is folded in)
+    const float* window;    // [16][4] per-lane window base: (-0.25 cos th_j0, -0.25 cos th_j1, 0.25 sin th_j0, 0.25 sin th_j1),
+                            //         th_je = 2 pi (2 j + e) / 512; the 1/2 of the real-FFT split is folded into the window
     const float4* tw256;    // [256] (w, w_rot): w = exp(-2 pi i p / 256), w_rot = (-w.y, w.x)
-    const float4* tw512;    // [257] (t, t_rot): t = -i exp(-2 pi i k / 512)
+    const float4* tw512;    // [16] per-lane split-pass base: (-sin a_j, -cos a_j, -cos a_j, sin a_j), a_j = 2 pi j / 512
 };
 
 // ---- STFT ------------------------------------------------------------------------------

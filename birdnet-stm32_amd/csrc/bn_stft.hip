@@ -68,6 +68,12 @@ __device__ __forceinline__ void fft16(v2f (&a)[16]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) fft4(a[4 * r], a[4 * r + 1], a[4 * r + 2], a[4 * r + 3]);
 }
+// cos / sin of n pi/8 (window angle step between a lane's consecutive samples) and of n pi/16 (split-pass twiddle step)
+__device__ constexpr float kCos8[16] = {1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508984f, 6.123233995736766e-17f, -0.38268343236508973f, -0.70710678118654746f, -0.92387953251128674f, -1.0f, -0.92387953251128685f, -0.70710678118654768f, -0.38268343236509034f, -1.8369701987210297e-16f, 0.38268343236509f, 0.70710678118654735f, 0.92387953251128652f};
+__device__ constexpr float kSin8[16] = {0.0f, 0.38268343236508978f, 0.70710678118654746f, 0.92387953251128674f, 1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508989f, 1.2246467991473532e-16f, -0.38268343236508967f, -0.70710678118654746f, -0.92387953251128652f, -1.0f, -0.92387953251128663f, -0.70710678118654768f, -0.38268343236509039f};
+__device__ constexpr float kCos16[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 6.123233995736766e-17f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f, -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
+__device__ constexpr float kSin16[16] = {0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f, 0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
+
 // index of X[k] in the array fft16 leaves behind
 __device__ __forceinline__ constexpr int fidx(int k) { return 4 * (k & 3) + (k >> 2); }
 
@@ -101,96 +107,139 @@ __device__ __forceinline__ void frame_sync() {
 
 template <bool MEL_OUT>
 __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop,
-                                                          int W, float* __restrict__ spec, float* minmax, MelOut mel) {
+                                                          int W, float* __restrict__ spec, float* minmax, MelOut mel,
+                                                          int tiles_per_wg) {
     __shared__ v2f xch[kFT][kFS];
     __shared__ float mag[257][kFT + 1];
     __shared__ float red_min[4], red_max[4];
 
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * kFT;
     const int f = threadIdx.x >> 4;
     const int j = threadIdx.x & 15;
-    const int t = t0 + f;
     const float* x = audio + (size_t)b * T;
-    const long start = (long)t * hop - 256;
-    const v2f* win2 = reinterpret_cast<const v2f*>(tb.window);  // 0.5 * periodic Hann, as pairs
 
-    // pass 1: lane j owns z[16 n1 + j], n1 = 0..15.  Raw buffer loads through a descriptor that covers exactly this
-    // chunk: samples before the chunk (negative offset = huge unsigned) or after it fail the hardware range check and
-    // read as 0, which is librosa's centre padding — no address clamping, no selects, all 32 loads in flight at once.
+    // Window and split-pass twiddles are rebuilt from ONE per-lane base angle each by the angle-addition formulas with
+    // compile-time constants: table gathers through the vector L1 (40 KB per wave and tile) were the bottleneck of this
+    // kernel, the extra ~100 packed multiply-adds are free next to it.
+    //   w[32 n1 + 2 j + e] = 0.25 - 0.25 cos(theta_je + n1 pi/8)        (0.5 * periodic Hann)
+    //   t[j + 16 k2]       = -i exp(-i (alpha_j + k2 pi/16))
+    const v4f wb = reinterpret_cast<const v4f*>(tb.window)[j];  // (-0.25 cos th_j0, -0.25 cos th_j1, 0.25 sin th_j0, 0.25 sin th_j1)
+    const v2f wa = {wb.x, wb.y}, wsn = {wb.z, wb.w};
+    const v4f tbase = reinterpret_cast<const v4f*>(tb.tw512)[j];  // (-sin a_j, -cos a_j, -cos a_j, sin a_j)
+    const v2f tp = {tbase.x, tbase.y}, tq = {tbase.z, tbase.w};
+
+    // Raw buffer loads through a descriptor that covers exactly this chunk: samples before the chunk (negative offset = huge
+    // unsigned) or after it fail the hardware range check and read as 0, which is librosa's centre padding — no address
+    // clamping, no selects, all 32 loads of a tile in flight at once.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
-    const int off0 = (int)(start + 2 * j) * 4;
-    v2f a[16];
+    (void)tiles_per_wg;  // one tile per workgroup (see stft_tiles_per_wg)
+    auto fetch = [&](int tile, v2f (&dst)[16]) {
+        const int off0 = (int)(((long)(tile * kFT + f) * hop - 256 + 2 * j) * 4);
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        v2f v;
-        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off0 + 128 * n1, 0, 0));
-        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off0 + 128 * n1 + 4, 0, 0));
-        a[n1] = v * win2[16 * n1 + j];
-    }
-    fft16(a);
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-        const v4f w = reinterpret_cast<const v4f*>(tb.tw256)[j * k1];  // (w, w_rot)
-        xch[f][k1 * 17 + j] = cmulr(a[fidx(k1)], (v2f){w.x, w.y}, (v2f){w.z, w.w});
-    }
-    frame_sync();
-
-    // pass 2: lane j is now k1; gathers over n2
-#pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) a[n2] = xch[f][j * 17 + n2];
-    fft16(a);  // a[fidx(k2)] = Z[j + 16 k2] (scaled by 0.5 through the window)
-    frame_sync();
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) xch[f][j + 16 * k2] = a[fidx(k2)];
-    frame_sync();
-
-    // split post-pass: X[k] = E - i W512^k O with E = Z[k] + conj Z[256-k], O = Z[k] - conj Z[256-k] (the 1/2 is in Z)
+        for (int n1 = 0; n1 < 16; ++n1) {
+            dst[n1].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off0 + 128 * n1, 0, 0));
+            dst[n1].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off0 + 128 * n1 + 4, 0, 0));
+        }
+    };
     float lmin = __uint_as_float(0x7f800000u), lmax = 0.0f;
-    const bool live = t < W;
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {
-        const int k = j + 16 * k2;
-        const v2f z = a[fidx(k2)];
-        v2f pc = xch[f][(256 - k) & 255];
-        pc.y = -pc.y;  // conj
-        const v2f e = z + pc, o = z - pc;
-        const v4f w = reinterpret_cast<const v4f*>(tb.tw512)[k];  // (-i W512^k, its rotation)
-        const v2f xr = __builtin_elementwise_fma(BN_YY(o), (v2f){w.z, w.w}, __builtin_elementwise_fma(BN_XX(o), (v2f){w.x, w.y}, e));
-        const v2f sq = xr * xr;
-        const float m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
-        mag[k][f] = m;
-        lmin = fminf(lmin, m);
-        lmax = fmaxf(lmax, m);
-        if (k == 0) {  // lane 0, k2 = 0: the Nyquist bin is Re Z[0] - Im Z[0]
-            const float ny = fabsf(e.x - o.y);
-            mag[256][f] = ny;
-            lmin = fminf(lmin, ny);
-            lmax = fmaxf(lmax, ny);
-        }
-    }
-    if (!live) {
-        lmin = __uint_as_float(0x7f800000u);
-        lmax = 0.0f;
-    }
-    __syncthreads();
 
-    if (!MEL_OUT) {
-        // frequency-major rows, 16 consecutive frames each
-        float* out = spec + (size_t)b * 257 * W;
-        for (int idx = threadIdx.x; idx < 257 * kFT; idx += 256) {
-            const int k = idx / kFT, ff = idx % kFT;
-            if (t0 + ff < W) out[(size_t)k * W + t0 + ff] = mag[k][ff];
+    {
+        const int tile = blockIdx.x;
+        const int t0 = tile * kFT;
+        const int t = t0 + f;
+        // pass 1: lane j owns z[16 n1 + j], n1 = 0..15
+        v2f a[16];
+        fetch(tile, a);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const v2f wn = __builtin_elementwise_fma(wsn, (v2f){kSin8[n1], kSin8[n1]},
+                                                     __builtin_elementwise_fma(wa, (v2f){kCos8[n1], kCos8[n1]}, (v2f){0.25f, 0.25f}));
+            a[n1] = a[n1] * wn;
         }
-    } else {
-        // thread = (frame ff, mel bins m0, m0+16, ...): narrow low bands and wide high bands mix in every thread
-        float* out = mel.out + (size_t)b * mel.M * W;
-        const int ff = threadIdx.x & 15;
-        for (int m = threadIdx.x >> 4; m < mel.M; m += 16) {
-            const int s0 = mel.bands[m], len = mel.bands[mel.M + m], off = mel.bands[2 * mel.M + m];
-            float acc = 0.0f;
-            for (int i = 0; i < len; ++i) acc = fmaf(mag[s0 + i][ff], mel.wvals[off + i], acc);
-            if (t0 + ff < W) out[(size_t)m * W + t0 + ff] = acc;
+        fft16(a);
+        {
+            // inter-pass twiddles W256^(j k1), k1 = 0..15: powers of w = W256^j built from one table entry per lane by
+            // square-and-multiply (at most four roundings deep) instead of sixteen strided gathers
+            const v4f wl = reinterpret_cast<const v4f*>(tb.tw256)[j];
+            v2f p[16];
+            p[1] = (v2f){wl.x, wl.y};
+#define BN_ROT(z) ((v2f){-(z).y, (z).x})
+#define BN_CM(u, v) cmulr(u, v, BN_ROT(v))
+            p[2] = BN_CM(p[1], p[1]);
+            p[3] = BN_CM(p[2], p[1]);
+            p[4] = BN_CM(p[2], p[2]);
+            p[5] = BN_CM(p[4], p[1]);
+            p[6] = BN_CM(p[4], p[2]);
+            p[7] = BN_CM(p[4], p[3]);
+            p[8] = BN_CM(p[4], p[4]);
+#pragma unroll
+            for (int k1 = 9; k1 < 16; ++k1) p[k1] = BN_CM(p[8], p[k1 - 8]);
+            xch[f][j] = a[fidx(0)];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) xch[f][k1 * 17 + j] = BN_CM(a[fidx(k1)], p[k1]);
+#undef BN_CM
+#undef BN_ROT
+        }
+        frame_sync();
+
+        // pass 2: lane j is now k1; gathers over n2
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) a[n2] = xch[f][j * 17 + n2];
+        fft16(a);  // a[fidx(k2)] = Z[j + 16 k2] (scaled by 0.5 through the window)
+        frame_sync();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) xch[f][j + 16 * k2] = a[fidx(k2)];
+        frame_sync();
+
+        // split post-pass: X[k] = E - i W512^k O with E = Z[k] + conj Z[256-k], O = Z[k] - conj Z[256-k] (the 1/2 is in Z)
+        const bool live = t < W;
+        float tmin = __uint_as_float(0x7f800000u), tmax = 0.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = j + 16 * k2;
+            const v2f z = a[fidx(k2)];
+            v2f pc = xch[f][(256 - k) & 255];
+            pc.y = -pc.y;  // conj
+            const v2f e = z + pc, o = z - pc;
+            const v2f tk = __builtin_elementwise_fma(tq, (v2f){kSin16[k2], kSin16[k2]}, tp * (v2f){kCos16[k2], kCos16[k2]});  // -i W512^k
+            v2f tkr = BN_SWAP(tk);
+            tkr.x = -tkr.x;  // its rotation (-t.y, t.x)
+            const v2f xr = __builtin_elementwise_fma(BN_YY(o), tkr, __builtin_elementwise_fma(BN_XX(o), tk, e));
+            const v2f sq = xr * xr;
+            const float m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+            mag[k][f] = m;
+            tmin = fminf(tmin, m);
+            tmax = fmaxf(tmax, m);
+            if (k == 0) {  // lane 0, k2 = 0: the Nyquist bin is Re Z[0] - Im Z[0]
+                const float ny = fabsf(e.x - o.y);
+                mag[256][f] = ny;
+                tmin = fminf(tmin, ny);
+                tmax = fmaxf(tmax, ny);
+            }
+        }
+        if (live) {
+            lmin = fminf(lmin, tmin);
+            lmax = fmaxf(lmax, tmax);
+        }
+        __syncthreads();
+
+        if (!MEL_OUT) {
+            // frequency-major rows, 16 consecutive frames each
+            float* out = spec + (size_t)b * 257 * W;
+            for (int idx = threadIdx.x; idx < 257 * kFT; idx += 256) {
+                const int k = idx / kFT, ff = idx % kFT;
+                if (t0 + ff < W) out[(size_t)k * W + t0 + ff] = mag[k][ff];
+            }
+        } else {
+            // thread = (frame ff, mel bins m0, m0+16, ...): narrow low bands and wide high bands mix in every thread
+            float* out = mel.out + (size_t)b * mel.M * W;
+            const int ff = threadIdx.x & 15;
+            for (int m = threadIdx.x >> 4; m < mel.M; m += 16) {
+                const int s0 = mel.bands[m], len = mel.bands[mel.M + m], off = mel.bands[2 * mel.M + m];
+                float acc = 0.0f;
+                for (int i = 0; i < len; ++i) acc = fmaf(mag[s0 + i][ff], mel.wvals[off + i], acc);
+                if (t0 + ff < W) out[(size_t)m * W + t0 + ff] = acc;
+            }
         }
     }
 
@@ -231,16 +280,29 @@ void launch_minmax_init(float* minmax, int B, hipStream_t s) {
     hipLaunchKernelGGL(minmax_init_kernel, dim3((B + 255) / 256), dim3(256), 0, s, minmax, B);
 }
 
+// tiles a workgroup walks; one is fastest on MI355X (a loop that prefetches the next tile's samples needs > 170 VGPRs and
+// drops the kernel to 2 waves per SIMD; measured 0.27 ms against 0.20 ms per 1024 chunks)
+static int stft_tiles_per_wg(int B, int n_tiles) {
+    static const int forced = getenv("BN_STFT_TPW") ? atoi(getenv("BN_STFT_TPW")) : 0;
+    (void)B;
+    (void)n_tiles;
+    return forced > 0 ? forced : 1;
+}
+
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, float* minmax,
                     hipStream_t s) {
-    hipLaunchKernelGGL((stft512_mag_kernel<false>), dim3((W + kFT - 1) / kFT, B), dim3(256), 0, s, tb, audio, T, hop, W, spec,
-                       minmax, MelOut{});
+    const int n_tiles = (W + kFT - 1) / kFT;
+    const int tpw = stft_tiles_per_wg(B, n_tiles);
+    hipLaunchKernelGGL((stft512_mag_kernel<false>), dim3((n_tiles + tpw - 1) / tpw, B), dim3(256), 0, s, tb, audio, T, hop, W, spec,
+                       minmax, MelOut{}, tpw);
 }
 
 bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
                         const float* wvals, const int* bands, float* minmax, hipStream_t s) {
-    hipLaunchKernelGGL((stft512_mag_kernel<true>), dim3((W + kFT - 1) / kFT, B), dim3(256), 0, s, tb, audio, T, hop, W, nullptr,
-                       minmax, MelOut{wvals, bands, mel_out, M});
+    const int n_tiles = (W + kFT - 1) / kFT;
+    const int tpw = stft_tiles_per_wg(B, n_tiles);
+    hipLaunchKernelGGL((stft512_mag_kernel<true>), dim3((n_tiles + tpw - 1) / tpw, B), dim3(256), 0, s, tb, audio, T, hop, W, nullptr,
+                       minmax, MelOut{wvals, bands, mel_out, M}, tpw);
     return true;
 }
 
