@@ -95,6 +95,8 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
         return batch * (p[0] * p[1] + p[0] * p[2] * (2 if p[6] else 1)), batch * 2.0 * p[0] * p[1] * p[2]
     if k in ("f32_gap", "i8_mean"):
         return batch * (p[0] * p[1] * e + p[1] * e), batch * 1.0 * p[0] * p[1]
+    if k == "f32_gapdense":
+        return batch * (p[0] * p[1] * 4 + p[2] * 4), batch * (1.0 * p[0] * p[1] + 2.0 * p[1] * p[2])
     if k in ("f32_dense", "i8_fc"):
         return batch * (p[0] * e + p[1] * 4), batch * 2.0 * p[0] * p[1]
     return 0.0, 0.0

@@ -92,6 +92,21 @@ def pack_pw_fragments(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(t.transpose(0, 3, 1, 4, 2)).reshape(cin // 16, cout // 16, 64, 4).astype(np.float32)
 
 
+def _gap_dense_tail(layers, i, only_consumer):
+    """Index of the classifier Dense if layer i (a GAP) is followed only by identities and that Dense, else None."""
+    cur = i
+    while True:
+        nxt = only_consumer(layers[cur].name)
+        if nxt is None:
+            return None
+        if layers[nxt].kind == ns.IDENTITY:
+            cur = nxt
+            continue
+        if layers[nxt].kind == ns.DENSE and nxt == len(layers) - 1:
+            return nxt
+        return None
+
+
 def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     """Build the float32 plan for ``spec``.  ``keep_all`` disables slot reuse (debug/tests); ``fuse=False`` keeps
     depthwise and pointwise convolutions as separate baseline kernels instead of the fused matrix-core block."""
@@ -118,6 +133,7 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
     val: dict[str, int] = {}  # layer name -> value id holding its output
     shape: dict[str, tuple] = {}
     gate_of: dict[str, tuple[int, int]] = {}  # multiply output name -> (value of x, value of gate)
+    audio_raw: dict[str, dict] = {}  # frontend name -> un-normalised mel value + finalisation tensors (audio path, norm off)
     done: set[int] = set()
 
     def only_consumer(name: str):
@@ -189,8 +205,14 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
                 raw = pb.value(M * W * 4)
                 pb.op(pk.F32_STFTMEL, pk.SLOT_AUDIO, raw, p=[0, W, M], t=[t_w, t_b], name=ly.name + ":melraw", out_shape=(M, W, 1),
                       path=pk.PATH_AUDIO)
-                pb.op(pk.F32_MELFIN, raw, v, p=[M, W, mag, norm], t=[pb.tensor(wsum, np.float32), -1, t_m], name=ly.name,
-                      out_shape=(M, W, 1), path=pk.PATH_AUDIO)
+                t_ws = pb.tensor(wsum, np.float32)
+                nxt_i = only_consumer(ly.name)
+                front_next = (not norm and nxt_i is not None and layers[nxt_i].kind == ns.CONV and tuple(layers[nxt_i].attrs["kernel"]) == (3, 3)
+                              and tuple(layers[nxt_i].attrs["strides"]) == (1, 2) and int(layers[nxt_i].attrs["filters"]) == 16)
+                if front_next:
+                    audio_raw[ly.name] = {"value": raw, "wsum": t_ws, "magp": t_m, "mag": mag}  # the front block finalises while loading
+                else:
+                    pb.op(pk.F32_MELFIN, raw, v, p=[M, W, mag, norm], t=[t_ws, -1, t_m], name=ly.name, out_shape=(M, W, 1), path=pk.PATH_AUDIO)
             val[ly.name], shape[ly.name] = v, (M, W, 1)
         elif k in (ns.CONV, ns.DWCONV):
             src = ly.inputs[0]
@@ -255,13 +277,25 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
                     wp_, bp = fold_bn(pwl.weights["kernel"], bn_p)
                     N = wp_.shape[-1]
                     v = pb.value(BH * BW * N * 4)
-                    pb.op(pk.F32_FRONT, val[src], v, p=[H, Wd, Cout, N, BH, BW, pk.ACT_CODES[act], pk.ACT_CODES[act_d], pk.ACT_CODES[act_p]],
-                          t=[pb.tensor(w[:, :, 0, :], np.float32), pb.tensor(b, np.float32), pb.tensor(wd, np.float32), pb.tensor(bd, np.float32),
-                             pb.tensor(pack_pw_fragments(wp_[0, 0]), np.float32), pb.tensor(bp, np.float32)],
-                          name=last_p, out_shape=(BH, BW, N))
+                    tens = [pb.tensor(w[:, :, 0, :], np.float32), pb.tensor(b, np.float32), pb.tensor(wd, np.float32), pb.tensor(bd, np.float32),
+                            pb.tensor(pack_pw_fragments(wp_[0, 0]), np.float32), pb.tensor(bp, np.float32)]
+                    base_p = [H, Wd, Cout, N, BH, BW, pk.ACT_CODES[act], pk.ACT_CODES[act_d], pk.ACT_CODES[act_p]]
+                    raw = audio_raw.get(src)
+                    if raw is not None:
+                        # audio entry point: read the un-normalised mel energies and finalise them while loading the patch
+                        pb.op(pk.F32_FRONT, val[src], v, p=base_p + [0, 0], t=tens, name=last_p, out_shape=(BH, BW, N), path=pk.PATH_INPUT)
+                        pb.op(pk.F32_FRONT, raw["value"], v, p=base_p + [1, raw["mag"]], t=tens + [raw["wsum"], raw["magp"]], name=last_p,
+                              out_shape=(BH, BW, N), path=pk.PATH_AUDIO)
+                    else:
+                        pb.op(pk.F32_FRONT, val[src], v, p=base_p + [0, 0], t=tens, name=last_p, out_shape=(BH, BW, N))
                     out_shape = (BH, BW, N)
                     last = last_p
                 else:
+                    raw = audio_raw.pop(src, None)
+                    if raw is not None:  # no front block after all: finalise the mel energies in their own pass
+                        Ms, Ws, _ = shape[src]
+                        pb.op(pk.F32_MELFIN, raw["value"], val[src], p=[Ms, Ws, raw["mag"], 0], t=[raw["wsum"], -1, raw["magp"]], name=src,
+                              out_shape=(Ms, Ws, 1), path=pk.PATH_AUDIO)
                     v = pb.value(OH * OW * Cout * 4)
                     pb.op(pk.F32_STEM, val[src], v, p=[H, Wd, Cout, sh, sw, pk.ACT_CODES[act], OH, OW, pt, pl],
                           t=[pb.tensor(w[:, :, 0, :], np.float32), pb.tensor(b, np.float32)], name=last, out_shape=(OH, OW, Cout))
@@ -327,6 +361,16 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
                 v = pb.value(H * Wd * C * 4)
                 pb.op(pk.F32_SCALE, val[x], v, p=[H * Wd, C], in1=g, name=mul.name, out_shape=(H, Wd, C))
                 val[mul.name], shape[mul.name] = v, shape[x]
+        elif k == ns.GAP and fuse and _gap_dense_tail(layers, i, only_consumer) is not None:
+            head_i = _gap_dense_tail(layers, i, only_consumer)
+            head = layers[head_i]
+            H, Wd, C = shape[ly.inputs[0]]
+            cout = int(head.attrs["units"])
+            act = {"linear": 0, "sigmoid": 1, "softmax": 2}[head.attrs.get("activation", "linear")]
+            bias = head.weights.get("bias", np.zeros(cout, np.float32))
+            pb.op(pk.F32_GAPDENSE, val[ly.inputs[0]], pk.SLOT_SCORES, p=[H * Wd, C, cout, act],
+                  t=[pb.tensor(head.weights["kernel"], np.float32), pb.tensor(bias, np.float32)], name=head.name, out_shape=(cout,))
+            done.update(range(i + 1, head_i + 1))
         elif k == ns.GAP:
             H, Wd, C = shape[ly.inputs[0]]
             v = pb.value(C * 4)

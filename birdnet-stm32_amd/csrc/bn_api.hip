@@ -198,7 +198,12 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 bn::launch_f32_front((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8],
                                      (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]),
                                      (const float*)m->tensor(o.t[2]), (const float*)m->tensor(o.t[3]),
-                                     (const float*)m->tensor(o.t[4]), (const float*)m->tensor(o.t[5]), s);
+                                     (const float*)m->tensor(o.t[4]), (const float*)m->tensor(o.t[5]), p[9] ? m->d_minmax : nullptr,
+                                     (const float*)m->tensor(o.t[6]), (const float*)m->tensor(o.t[7]), p[10], s);
+                break;
+            case BN_OP_F32_GAPDENSE:
+                bn::launch_f32_gap_dense((const float*)in0, (float*)out, d_logits, B, p[0], p[1], p[2], p[3],
+                                         (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
                 break;
             case BN_OP_F32_SEGATE:
                 bn::launch_f32_segate((const float*)in0, (float*)out, B, p[0], p[1], p[2],
@@ -614,7 +619,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 
 const char* bn_kernel_names(void) {
     return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
-           "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
+           "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";
 }

@@ -109,8 +109,12 @@ enum BnOpKind : int32_t {
     // un-normalised mel energies -> frontend output [M][W]   p: M W mag norm   t: wsum[M] - magp
     BN_OP_F32_MELFIN = 14,
     // frontend output [H0][W0] -> stem 3x3 s(1,2) -> depthwise 3x3 s2 -> pointwise, one kernel
-    // p: H0 W0 C N OH OW stem_act dw_act pw_act   t: stem_w stem_b dw_w dw_b pw_w(fragment order) pw_b
+    // p: H0 W0 C N OH OW stem_act dw_act pw_act raw_mel mag   t: stem_w stem_b dw_w dw_b pw_w(fragment order) pw_b wsum magp
+    // raw_mel = 1 (audio path): in0 holds un-normalised mel energies, finalised while the patch is loaded
     BN_OP_F32_FRONT = 15,
+    // global average pool + Dense + sigmoid/softmax in one kernel: [P][Cin] -> scores [Cout] (+ logits)
+    // p: P Cin Cout act   t: w[Cin][Cout] bias
+    BN_OP_F32_GAPDENSE = 16,
 
     // ---- INT8 plan -----------------------------------------------------------------
     // spec f32 [F][W] -> q int8 [W][Kp]   p: F W Kp zp fill   f: scale

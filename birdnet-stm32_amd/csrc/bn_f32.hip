@@ -376,6 +376,50 @@ __global__ void f32_dense_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
+// global average pool + Dense (+ sigmoid / softmax): one 256-thread block per chunk.  Threads first average their channel
+// over the P positions, then 4 groups of 64 lanes each take a quarter of the contraction for up to 64 x 4 outputs and the
+// partial sums meet in LDS (reference: birdnet_stm32/models/dscnn.py:256-261).
+__global__ __launch_bounds__(256) void f32_gap_dense_kernel(const float* __restrict__ x, float* __restrict__ scores,
+                                                            float* __restrict__ logits, int P, int Cin, int Cout, int act,
+                                                            const float* __restrict__ w, const float* __restrict__ bias) {
+    extern __shared__ float sm[];  // [Cin] pooled, [4][Cout] partial sums, [Cout] logits
+    float* pooled = sm;
+    float* part = sm + Cin;
+    float* z = part + 4 * Cout;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < Cin; c += 256) {
+        const float* p = x + (size_t)b * P * Cin + c;
+        float s = 0.0f;
+        for (int i = 0; i < P; ++i) s += p[(size_t)i * Cin];
+        pooled[c] = s / (float)P;
+    }
+    __syncthreads();
+    const int g = tid >> 6, lane = tid & 63;
+    const int k0 = g * ((Cin + 3) / 4), k1 = min(Cin, k0 + (Cin + 3) / 4);
+    for (int n = lane; n < Cout; n += 64) {
+        float s = 0.0f;
+        for (int k = k0; k < k1; ++k) s = fmaf(pooled[k], w[(size_t)k * Cout + n], s);
+        part[g * Cout + n] = s;
+    }
+    __syncthreads();
+    for (int n = tid; n < Cout; n += 256) {
+        // summed in contraction order, bias first, like the separate Dense kernel
+        const float v = (((((bias ? bias[n] : 0.0f) + part[n]) + part[Cout + n]) + part[2 * Cout + n]) + part[3 * Cout + n]);
+        z[n] = v;
+        if (logits) logits[(size_t)b * Cout + n] = v;
+    }
+    __syncthreads();
+    if (act == 2) {
+        float mx = -3.4e38f;
+        for (int n = 0; n < Cout; ++n) mx = fmaxf(mx, z[n]);
+        float den = 0.0f;
+        for (int n = 0; n < Cout; ++n) den += expf(z[n] - mx);
+        for (int n = tid; n < Cout; n += 256) scores[(size_t)b * Cout + n] = expf(z[n] - mx) / den;
+    } else {
+        for (int n = tid; n < Cout; n += 256) scores[(size_t)b * Cout + n] = act == 1 ? 1.0f / (1.0f + expf(-z[n])) : z[n];
+    }
+}
+
 inline dim3 grid1d(long total, int block) { return dim3((unsigned)((total + block - 1) / block)); }
 
 }  // namespace
@@ -444,6 +488,12 @@ void launch_f32_gap(const float* x, float* y, int B, int P, int C, hipStream_t s
 void launch_f32_dense(const float* x, float* scores, float* logits, int B, int Cin, int Cout, int act, const float* w,
                       const float* bias, hipStream_t s) {
     hipLaunchKernelGGL(f32_dense_kernel, dim3(B), dim3(128), (Cin + Cout) * sizeof(float), s, x, scores, logits, Cin,
+                       Cout, act, w, bias);
+}
+
+void launch_f32_gap_dense(const float* x, float* scores, float* logits, int B, int P, int Cin, int Cout, int act, const float* w,
+                          const float* bias, hipStream_t s) {
+    hipLaunchKernelGGL(f32_gap_dense_kernel, dim3(B), dim3(256), (Cin + 5 * Cout) * sizeof(float), s, x, scores, logits, P, Cin,
                        Cout, act, w, bias);
 }
 

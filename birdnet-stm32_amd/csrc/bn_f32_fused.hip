@@ -242,6 +242,12 @@ struct FrontArgs {
     const float* pw_b;    // [N]
     int B, H0, W0, SH, SW, C, N, OH, OW;  // stem map SH x SW, block output OH x OW
     int stem_act, dw_act, pw_act;
+    // audio path: `fe` holds UN-normalised mel energies; the patch load applies relu((x - mn * wsum[row]) / rng) and the
+    // magnitude scaling (the frontend without per-sample max normalisation), saving a separate pass over the tensor
+    const float* minmax;  // [B][2] or null
+    const float* wsum;    // [H0]
+    const float* magp;    // [NP][H0]
+    int mag;
 };
 
 template <int RG, int CT>
@@ -264,10 +270,48 @@ __global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
     // ---- frontend patch: rows 2*ty0-1 .., cols 4*tx0 .. (zero outside = the stem's SAME padding) ---------------------
     const int r_base = 2 * ty0 - 1, c_base = 4 * tx0;  // stem pad_top 1, pad_left 0
     const float* fe = a.fe + (size_t)chunk * a.H0 * a.W0;
+    float mn = 0.0f, inv_rng = 1.0f;
+    if (a.minmax) {
+        mn = a.minmax[2 * chunk];
+        inv_rng = 1.0f / (float)((double)(a.minmax[2 * chunk + 1] - mn) + 1e-10);  // one division per workgroup, not per element
+    }
+    // per-row constants of the finalisation (mel bin = patch row): wsum and the magnitude-scaling rows, staged in LDS once —
+    // fetching them per element through the vector L1 would cost ten loads for every patch element
+    __shared__ float rowc[FH][12];
+    if (a.minmax) {
+        for (int i = tid; i < FH * 12; i += 256) {
+            const int rr = i / 12, c = i - rr * 12;
+            const int gr = r_base + rr;
+            float v = 0.0f;
+            if (gr >= 0 && gr < a.H0) v = c == 0 ? a.wsum[gr] : (c <= 10 ? a.magp[(c - 1) * a.H0 + gr] : 0.0f);
+            rowc[rr][c] = v;
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < FH * FW; i += 256) {
         const int rr = i / FW, cc = i - rr * FW;
         const int gr = r_base + rr, gc = c_base + cc;
-        fe_t[rr][cc] = (gr >= 0 && gr < a.H0 && gc >= 0 && gc < a.W0) ? fe[gr * a.W0 + gc] : 0.0f;
+        float v = 0.0f;
+        if (gr >= 0 && gr < a.H0 && gc >= 0 && gc < a.W0) {
+            v = fe[gr * a.W0 + gc];
+            if (a.minmax) {
+                const float* rc = rowc[rr];
+                const float y = fmaxf((v - mn * rc[0]) * inv_rng, 0.0f);
+                if (a.mag == 1) {  // pwl: rows k0, k1..3, w1..3, b1..3
+                    v = y * rc[1];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) v += rc[2 + q] * fmaxf(rc[5 + q] * y + rc[8 + q], 0.0f);
+                } else if (a.mag == 2) {  // pcen-like: rows agc, k1, sw, sb, k2
+                    const float y0 = fmaxf(y - rc[1] * y, 0.0f);
+                    v = fmaxf(rc[2] * y0 + rc[5] * fmaxf(rc[3] * y0 + rc[4], 0.0f), 0.0f);
+                } else if (a.mag == 3) {
+                    v = 10.0f * logf(fmaxf(y, 1e-6f)) / logf(10.0f);
+                } else {
+                    v = y;
+                }
+            }
+        }
+        fe_t[rr][cc] = v;
     }
     __syncthreads();
 
@@ -387,8 +431,10 @@ bool f32_front_supported(int H0, int W0, int C, int N, int OH, int OW) {
 
 void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, int N, int OH, int OW, int stem_act,
                       int dw_act, int pw_act, const float* stem_w, const float* stem_b, const float* dw_w, const float* dw_b,
-                      const float* pw_w, const float* pw_b, hipStream_t s) {
-    FrontArgs a{fe, y, stem_w, stem_b, dw_w, dw_b, pw_w, pw_b, B, H0, W0, H0, W0 / 2, C, N, OH, OW, stem_act, dw_act, pw_act};
+                      const float* pw_w, const float* pw_b, const float* minmax, const float* wsum, const float* magp, int mag,
+                      hipStream_t s) {
+    FrontArgs a{fe, y, stem_w, stem_b, dw_w, dw_b, pw_w, pw_b, B, H0, W0, H0, W0 / 2, C, N, OH, OW, stem_act, dw_act, pw_act,
+                minmax, wsum, magp, mag};
     const int tiles = (OH / 8) * (OW / 8) * B;
     hipLaunchKernelGGL((f32_front_kernel<2, 1>), dim3(tiles, 1), dim3(256), 0, s, a);
 }

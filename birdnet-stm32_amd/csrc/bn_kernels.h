@@ -61,7 +61,10 @@ bool f32_dwpw_supported(int Cin, int Cout);
 bool f32_front_supported(int H0, int W0, int C, int N, int OH, int OW);
 void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, int N, int OH, int OW, int stem_act,
                       int dw_act, int pw_act, const float* stem_w, const float* stem_b, const float* dw_w, const float* dw_b,
-                      const float* pw_w, const float* pw_b, hipStream_t s);
+                      const float* pw_w, const float* pw_b, const float* minmax, const float* wsum, const float* magp, int mag,
+                      hipStream_t s);
+void launch_f32_gap_dense(const float* x, float* scores, float* logits, int B, int P, int Cin, int Cout, int act, const float* w,
+                          const float* bias, hipStream_t s);
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s);
 
 // ---- INT8 plan -----------------------------------------------------------------------------

@@ -23,11 +23,13 @@ def test_fused_plan_structure():
 
     f32, i8 = _plans(fuse=True)
     kinds = [pk.KIND_NAMES[o.kind] for o in f32.ops]
-    assert kinds == ["f32_mel", "f32_stftmel", "f32_melfin", "f32_front"] + ["f32_dwpw"] * 10 + ["f32_gap", "f32_dense"]
+    assert kinds == ["f32_mel", "f32_stftmel", "f32_front", "f32_front"] + ["f32_dwpw"] * 10 + ["f32_gapdense"]
     paths = [o.p[pk.OP_PATH] for o in f32.ops]
-    assert paths[:3] == [pk.PATH_INPUT, pk.PATH_AUDIO, pk.PATH_AUDIO] and set(paths[3:]) == {pk.PATH_BOTH}
+    assert paths[:4] == [pk.PATH_INPUT, pk.PATH_AUDIO, pk.PATH_INPUT, pk.PATH_AUDIO] and set(paths[4:]) == {pk.PATH_BOTH}
     assert f32.ops[1].in0 == pk.SLOT_AUDIO and f32.ops[0].in0 == pk.SLOT_INPUT
-    assert f32.ops[0].out == f32.ops[2].out  # both entry points feed the same frontend-output slot
+    # runner boundary: mel -> front block; audio: STFT+mel -> front block that finalises the raw mel energies while loading
+    assert f32.ops[2].in0 == f32.ops[0].out and f32.ops[3].in0 == f32.ops[1].out and f32.ops[2].out == f32.ops[3].out
+    assert (f32.ops[2].p[9], f32.ops[3].p[9]) == (0, 1)
     assert sum(1 for o in f32.ops if o.kind == pk.F32_DWPW and o.p[12]) == 7  # residual blocks
     kinds = [pk.KIND_NAMES[o.kind] for o in i8.ops]
     assert kinds == ["i8_quant", "i8_dwpw", "i8_front"] + ["i8_dwpw"] * 10 + ["i8_mean", "i8_fc", "i8_head"]
