@@ -96,6 +96,23 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
         for (int c = 0; c < CT; ++c) acc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.pw_w);  // [K/16][N/16][64 lanes] float4
 
+    // The residual rows this thread will add in the epilogue are requested now, so that their HBM/L2 latency hides behind
+    // the depthwise and matrix phases (narrow slices only: the prefetch costs NS/16 float4 registers).
+    constexpr int NS = RG * CT * 16;  // columns of this workgroup's slice
+    constexpr int Q4 = NS / 4;        // float4 per output row
+    constexpr int EP = (64 * Q4) / 256;  // epilogue items per thread
+    constexpr bool PREFETCH_RES = NS <= 32;  // at 64 columns the extra registers cost more occupancy than the latency they hide (measured)
+    float4 res_pf[PREFETCH_RES ? EP : 1];
+    if (PREFETCH_RES && a.res) {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) {
+            const int item = tid + 256 * i;
+            const int p = item / Q4, c4 = item - p * Q4;
+            const int ob = pos[p].out_base;
+            res_pf[i] = ob >= 0 ? *reinterpret_cast<const float4*>(a.res + (long)ob + blockIdx.y * NS + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
     for (int k0 = 0; k0 < K; k0 += kKC) {
         const int kc = (K - k0) < kKC ? (K - k0) : kKC;
         const int kq = kc >> 2;   // float4 groups per position
@@ -190,7 +207,6 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
     }
 
     // ---- epilogue: accumulators -> LDS [64][NS + 4] -> bias, residual, activation -> whole-row stores --------
-    constexpr int NS = RG * CT * 16;  // columns of this workgroup's slice
     constexpr int SO = NS + 4;
     __syncthreads();                  // everyone is done reading the activation tile
 #pragma unroll
@@ -201,8 +217,9 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
             for (int reg = 0; reg < 4; ++reg) lds_raw[(row0 + 16 * g + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[g][c][reg];
     __syncthreads();
     const int n_base = blockIdx.y * NS;
-    constexpr int Q4 = NS / 4;  // float4 per row
-    for (int item = tid; item < 64 * Q4; item += 256) {
+#pragma unroll
+    for (int i = 0; i < EP; ++i) {
+        const int item = tid + 256 * i;
         const int p = item / Q4, c4 = item - p * Q4;
         const int ob = pos[p].out_base;
         if (ob < 0) continue;
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
         float4 o = make_float4(v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w);
         const long off = (long)ob + n_base + 4 * c4;
         if (a.res) {
-            const float4 rv = *reinterpret_cast<const float4*>(a.res + off);
+            const float4 rv = PREFETCH_RES ? res_pf[PREFETCH_RES ? i : 0] : *reinterpret_cast<const float4*>(a.res + off);
             o.x += rv.x;
             o.y += rv.y;
             o.z += rv.z;
