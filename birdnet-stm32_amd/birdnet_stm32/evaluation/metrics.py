@@ -11,10 +11,11 @@ Two execution modes:
 
 * any object with ``predict(x_batch)`` (the reference's duck-typed runner, e.g. the tests' ``FakeRunner``):
   the reference loop, one file at a time, batches never crossing files (reference :117-141);
-* a :class:`HipRunner` on a hybrid-frontend model: the *device pipeline* — chunks of many files are
-  packed into batches of ``batch_size`` (the reference never batches across files, SURVEY.md finding 10),
-  uploaded once as waveforms and turned into scores by ``bn_infer_audio`` (STFT + frontend + network on the
-  GPU); scores are then pooled per file exactly as above.
+* a :class:`HipRunner` on a hybrid-frontend model: the *device pipeline* — the PCM of a group of files is
+  uploaded as it lies in the files; decode, mono mix, resampling, peak normalisation and chunking
+  (``bn_ingest_resample`` / ``bn_ingest_chunks``), STFT + frontend + network (``bn_infer_audio``, batches of
+  ``batch_size`` chunks crossing file boundaries — the reference never batches across files, SURVEY.md
+  finding 10) and file-level pooling (``bn_pool_scores``) all run on the GPU; one pooled row per file returns.
 """
 
 from __future__ import annotations
@@ -68,7 +69,7 @@ def _label_of(path: str) -> str:
 
 
 def _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scale, n_fft, overlap, batch_size, measure_latency,
-                           spectrogram_fn):
+                           spectrogram_fn, pooling, beta):
     """The reference loop: per file, batches of at most ``batch_size`` chunks, never across files."""
     lat: list[float] = []
     for path in files:
@@ -84,60 +85,43 @@ def _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scal
             preds.append(model_runner.predict(batch))
             if measure_latency:
                 lat.extend([(time.perf_counter() - t0) * 1000.0 / batch.shape[0]] * batch.shape[0])
-        yield path, np.concatenate(preds, axis=0), lat
+        chunk_scores = np.concatenate(preds, axis=0)
+        yield path, chunk_scores.shape[0], pool_scores(chunk_scores, method=pooling, beta=beta), lat
 
 
-def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measure_latency):
-    """Device pipeline: waveform chunks of many files per batch, ``bn_infer_audio`` per batch."""
+def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, beta, files_per_group=64):
+    """Device pipeline: ingest, inference and pooling of ``files_per_group`` files at a time on the GPU.
+
+    Per group: the PCM payloads are uploaded as they lie in the files, ``bn_ingest_resample`` + ``bn_ingest_chunks``
+    produce the chunk matrix, ``bn_infer_audio`` scores it in batches of ``batch_size`` chunks (batches cross file
+    boundaries), ``bn_pool_scores`` reduces it to one row per file; only that row travels back to the host.
+    """
     import torch
 
+    from birdnet_stm32.audio.ingest import load_audio_files_device, pool_scores_device
+
     sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
-    pending: list[tuple[str, int]] = []  # (path, n_chunks) in arrival order
-    stash: list[np.ndarray] = []
-    scores_ready: list[np.ndarray] = []
+    todo = [p for p in files if _label_of(p) in classes]
     lat: list[float] = []
-
-    def flush(n):
-        nonlocal stash
-        block = np.concatenate(stash, axis=0)
-        take, rest = block[:n], block[n:]
-        stash = [rest] if len(rest) else []
-        t0 = time.perf_counter()
-        d = torch.from_numpy(np.ascontiguousarray(take)).to(runner.device)
-        s = runner.infer_audio_device(d).cpu().numpy()
-        if measure_latency:
-            lat.extend([(time.perf_counter() - t0) * 1000.0 / n] * n)
-        scores_ready.append(s)
-
-    def drain():
-        have = np.concatenate(scores_ready, axis=0) if scores_ready else np.zeros((0, runner.num_classes), np.float32)
-        done = []
-        while pending and pending[0][1] <= len(have):
-            path, n = pending.pop(0)
-            done.append((path, have[:n]))
-            have = have[n:]
-        scores_ready.clear()
-        if len(have):
-            scores_ready.append(have)
-        return done
-
-    for path in files:
-        if _label_of(path) not in classes:
+    for g0 in range(0, len(todo), files_per_group):
+        group = todo[g0 : g0 + files_per_group]
+        chunks, counts = load_audio_files_device(runner.ctx, group, sample_rate=sr, max_duration=60, chunk_duration=cd,
+                                                 chunk_overlap=overlap)
+        n = chunks.shape[0]
+        if n == 0:
             continue
-        chunks = load_audio_file(path, sample_rate=sr, max_duration=60, chunk_duration=cd, random_offset=False, chunk_overlap=overlap)
-        if len(chunks) == 0:
-            continue
-        pending.append((path, len(chunks)))
-        stash.append(np.asarray(chunks, np.float32))
-        while sum(len(s) for s in stash) >= batch_size:
-            flush(batch_size)
-        for item in drain():
-            yield (*item, lat)
-    left = sum(len(s) for s in stash)
-    if left:
-        flush(left)
-    for item in drain():
-        yield (*item, lat)
+        scores = torch.empty((n, runner.num_classes), dtype=torch.float32, device=chunks.device)
+        for b0 in range(0, n, batch_size):
+            nb = min(batch_size, n - b0)
+            t0 = time.perf_counter()
+            scores[b0 : b0 + nb] = runner.infer_audio_device(chunks[b0 : b0 + nb])
+            if measure_latency:
+                torch.cuda.synchronize(chunks.device)
+                lat.extend([(time.perf_counter() - t0) * 1000.0 / nb] * nb)
+        pooled = pool_scores_device(runner.ctx, scores, counts, pooling, beta).cpu().numpy()
+        for path, c, row in zip(group, counts, pooled):
+            if c:
+                yield path, c, row, lat
 
 
 def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pooling: str = "average", batch_size: int = 64,
@@ -158,19 +142,20 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
     if device_pipeline is None:
         device_pipeline = frontend == "hybrid" and hasattr(model_runner, "infer_audio_device") and spectrogram_fn is None
     if device_pipeline:
-        stream = _score_files_device(model_runner, files, classes, cfg, overlap, batch_size, measure_latency)
+        if pooling.lower() not in ("avg", "mean", "average", "max", "lme", "log_mean_exp", "log_mean_exponential"):
+            raise ValueError(f"Unsupported pooling method: {pooling}")
+        stream = _score_files_device(model_runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, mep_beta)
     else:
         stream = _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scale, n_fft, overlap, batch_size,
-                                        measure_latency, spectrogram_fn)
+                                        measure_latency, spectrogram_fn, pooling, mep_beta)
 
     y_true, y_scores, per_file, lat = [], [], [], []
     total_chunks = 0
-    for path, chunk_scores, lat in stream:
+    for path, n_chunks, pooled, lat in stream:
         label = _label_of(path)
         target = np.zeros(n_cls, np.float32)
         target[classes.index(label)] = 1.0
-        pooled = pool_scores(chunk_scores, method=pooling, beta=mep_beta)
-        total_chunks += chunk_scores.shape[0]
+        total_chunks += n_chunks
         y_true.append(target)
         y_scores.append(pooled)
         per_file.append({"file": path, "label": label, "scores": pooled.tolist()})

@@ -47,6 +47,8 @@ struct bn_ctx {
     float4* d_tw256 = nullptr;
     float4* d_tw512 = nullptr;
     bn::StftTables tables{};
+    float* d_block_peaks = nullptr;  // bn_ingest_resample: per-workgroup maxima, grown on demand
+    size_t block_peaks_elems = 0;
 };
 
 struct bn_model {
@@ -378,6 +380,7 @@ void bn_ctx_destroy(bn_ctx* c) {
     (void)hipFree(c->d_window);
     (void)hipFree(c->d_tw256);
     (void)hipFree(c->d_tw512);
+    (void)hipFree(c->d_block_peaks);
     delete c;
 }
 
@@ -575,6 +578,73 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     return bn_forward(m, m->d_spec, m->d_minmax, B, d_scores, d_logits, stream);
 }
 
+int bn_ingest_resample(bn_ctx* ctx, const void* d_pcm, int sample_format, int channels, const int64_t* d_in_off,
+                       const int64_t* d_out_off, int n_windows, int64_t max_in_len, int64_t max_out_len, const float* d_taps,
+                       int up, int down, int taps_per_phase, int n_pre_remove, float* d_mono, float* d_peak, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (!d_pcm || !d_in_off || !d_out_off || !d_mono || !d_peak) return fail(BN_ERR_ARG, "null device pointer");
+    if (sample_format < BN_PCM_S16 || sample_format > BN_PCM_F32) return fail(BN_ERR_ARG, "unknown sample format %d", sample_format);
+    if (channels < 1 || channels > 8)
+        return fail(BN_ERR_UNSUPPORTED, "%d channels: the channel mean is implemented for 1..8 channels", channels);
+    if (n_windows < 0 || max_in_len < 0 || max_out_len < 0 || up < 1 || down < 1 || taps_per_phase < 0 || n_pre_remove < 0)
+        return fail(BN_ERR_ARG, "bad ingest geometry");
+    if (taps_per_phase > 0 && !d_taps) return fail(BN_ERR_ARG, "null filter");
+    if (taps_per_phase == 0 && up != down) return fail(BN_ERR_ARG, "up=%d down=%d needs a filter", up, down);
+    if (n_windows == 0 || max_out_len == 0) return BN_OK;
+    if (n_windows > 65535) return fail(BN_ERR_ARG, "at most 65535 windows per call");
+    if ((double)(max_out_len + n_pre_remove + 4096) * down >= 4294967296.0 || (double)max_in_len * up >= 4294967296.0)
+        return fail(BN_ERR_UNSUPPORTED, "window too long for the 32-bit polyphase index (%lld samples, up=%d, down=%d)",
+                    (long long)max_in_len, up, down);
+    const size_t lds = bn::ingest_resample_lds_bytes(up, down, taps_per_phase, bn::ingest_resample_block(up, down, taps_per_phase));
+    if (lds > 64 * 1024)
+        return fail(BN_ERR_UNSUPPORTED, "resampling ratio %d/%d needs %zu bytes of LDS per workgroup (limit 65536)", up, down, lds);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = bn::ingest_partial_elems(n_windows, (long)max_out_len, up, down, taps_per_phase);
+    if (need > ctx->block_peaks_elems) {  // growing frees the old buffer, which waits for launches still using it
+        if (ctx->d_block_peaks) HIP_TRY(hipFree(ctx->d_block_peaks));
+        ctx->d_block_peaks = nullptr;
+        ctx->block_peaks_elems = 0;
+        HIP_TRY(hipMalloc(&ctx->d_block_peaks, need * sizeof(float)));
+        ctx->block_peaks_elems = need;
+    }
+    bn::launch_ingest_resample(d_pcm, sample_format, channels, (const long*)d_in_off, (const long*)d_out_off, n_windows,
+                               (long)max_out_len, d_taps, up, down, taps_per_phase, n_pre_remove, d_mono, ctx->d_block_peaks,
+                               d_peak, s);
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
+int bn_ingest_chunks(bn_ctx* ctx, const float* d_mono, const float* d_peak, const int64_t* d_chunk_src,
+                     const int32_t* d_chunk_valid, const int32_t* d_chunk_window, int n_chunks, int chunk_len,
+                     float* d_chunks, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (n_chunks < 0 || chunk_len <= 0) return fail(BN_ERR_ARG, "bad chunk geometry n=%d T=%d", n_chunks, chunk_len);
+    if (n_chunks == 0) return BN_OK;
+    if (!d_mono || !d_peak || !d_chunk_src || !d_chunk_valid || !d_chunk_window || !d_chunks)
+        return fail(BN_ERR_ARG, "null device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    for (int c0 = 0; c0 < n_chunks; c0 += kMaxGridBatch) {
+        const int nc = n_chunks - c0 < kMaxGridBatch ? n_chunks - c0 : kMaxGridBatch;
+        bn::launch_ingest_chunks(d_mono, d_peak, (const long*)d_chunk_src + c0, d_chunk_valid + c0, d_chunk_window + c0, nc,
+                                 chunk_len, d_chunks + (size_t)c0 * chunk_len, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
+int bn_pool_scores(bn_ctx* ctx, const float* d_scores, const int64_t* d_file_off, int n_files, int n_classes, int method,
+                   float beta, float* d_pooled, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (n_files < 0 || n_classes <= 0) return fail(BN_ERR_ARG, "bad pooling geometry files=%d classes=%d", n_files, n_classes);
+    if (method < BN_POOL_AVG || method > BN_POOL_LME) return fail(BN_ERR_ARG, "Unsupported pooling method: %d", method);
+    if (n_files == 0) return BN_OK;
+    if (!d_scores || !d_file_off || !d_pooled) return fail(BN_ERR_ARG, "null device pointer");
+    if ((int64_t)n_files * n_classes > 0x7fffffffLL) return fail(BN_ERR_ARG, "files x classes exceeds 2^31");
+    bn::launch_pool_scores(d_scores, (const long*)d_file_off, n_files, n_classes, method, beta, d_pooled, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
 int bn_debug_op_output(bn_model* m, int op_index, int B, void* d_dst, size_t dst_bytes, size_t* bytes_per_chunk,
                        void* stream) {
     if (!m) return fail(BN_ERR_ARG, "null model");
@@ -618,7 +688,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 }
 
 const char* bn_kernel_names(void) {
-    return "stft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
+    return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";

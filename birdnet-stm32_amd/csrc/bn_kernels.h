@@ -21,6 +21,18 @@ bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, 
                         const float* wvals, const int* bands, float* minmax, hipStream_t s);
 void launch_spec_normalize(float* spec, const float* minmax, int B, int per_chunk, hipStream_t s);
 
+// ---- ingest and pooling (bn_ingest.hip) ---------------------------------------------------
+size_t ingest_resample_lds_bytes(int up, int down, int hpp, int blk);
+int ingest_resample_block(int up, int down, int hpp);
+size_t ingest_partial_elems(int n_files, long max_out, int up, int down, int hpp);
+void launch_ingest_resample(const void* pcm, int fmt, int ch, const long* in_off, const long* out_off, int n_files,
+                            long max_out, const float* taps, int up, int down, int hpp, int n_pre_remove, float* mono,
+                            float* partial, float* peak, hipStream_t s);
+void launch_ingest_chunks(const float* mono, const float* peak, const long* src, const int* valid, const int* file,
+                          int n_chunks, int T, float* out, hipStream_t s);
+void launch_pool_scores(const float* scores, const long* seg, int F, int C, int method, float beta, float* out,
+                        hipStream_t s);
+
 // ---- float32 plan ------------------------------------------------------------------------
 void launch_f32_mel(const float* spec, const float* minmax, float* out, float* smax, int B, int F, int W, int M,
                     const float* wvals, const int* bands, const float* magp, int mag, int norm, hipStream_t s);

@@ -125,6 +125,58 @@ BN_API int bn_forward(bn_model* model, const float* d_input, const float* d_minm
 BN_API int bn_infer_audio(bn_model* model, const float* d_audio, int B, int T, int hop,
                    float* d_scores, float* d_logits, void* stream);
 
+/* ---- the steps either side of the path ------------------------- */
+
+/* sample formats of bn_ingest_resample's interleaved PCM (libsndfile's float scaling: /2^15, /2^23, /2^31) */
+#define BN_PCM_S16 0
+#define BN_PCM_S24 1 /* packed 3-byte little endian */
+#define BN_PCM_S32 2
+#define BN_PCM_F32 3
+
+/* Decode + mono mix + polyphase resampling + absolute peak of a batch of audio windows that share one
+ * (format, channel count, rate pair) — the device form of load_audio_window's arithmetic
+ * (reference: birdnet_stm32/audio/io.py:112-124: y.mean(axis=1), fast_resample -> scipy.signal.resample_poly,
+ * np.max(np.abs(y))).  Operation order is numpy's / scipy's, so the result is bit-identical to theirs.
+ *   d_pcm       interleaved frames of all windows back to back
+ *   d_in_off    [n_windows+1] frame offsets of the windows in d_pcm
+ *   d_out_off   [n_windows+1] sample offsets of the resampled windows in d_mono;
+ *               d_out_off[i+1]-d_out_off[i] = ceil(n_in * up / down)
+ *   d_taps      [up][taps_per_phase] polyphase filter, phase-major, the coefficient for the OLDEST input sample
+ *               first (scipy upfirdn's transposed, flipped layout of the zero-padded resample_poly filter);
+ *               taps_per_phase = 0 with up == down: no resampling (same rate)
+ *   n_pre_remove  leading filter-delay outputs resample_poly drops
+ *   d_mono      resampled mono float32, NOT yet peak-normalised
+ *   d_peak      [n_windows] max |y| per window
+ * Channels 1..8.  Window length * up and output length * down must stay below 2^32. */
+BN_API int bn_ingest_resample(bn_ctx* ctx, const void* d_pcm, int sample_format, int channels,
+                       const int64_t* d_in_off, const int64_t* d_out_off, int n_windows, int64_t max_in_len,
+                       int64_t max_out_len, const float* d_taps, int up, int down, int taps_per_phase,
+                       int n_pre_remove, float* d_mono, float* d_peak, void* stream);
+
+/* Fixed-length chunks of peak-normalised audio (reference: audio/io.py:122-124 `y / peak` when peak > 0, then
+ * split_audio_into_chunks :133-174; the host computes the start positions, which depend only on lengths).
+ *   d_chunk_src    [n_chunks] absolute sample offset of the chunk's first sample in d_mono
+ *   d_chunk_valid  [n_chunks] samples to copy (< chunk_len only for a window shorter than one chunk: right zero pad)
+ *   d_chunk_window [n_chunks] index into d_peak
+ *   d_chunks       [n_chunks, chunk_len] float32 — the [B, T] input of bn_infer_audio / bn_stft_mag */
+BN_API int bn_ingest_chunks(bn_ctx* ctx, const float* d_mono, const float* d_peak, const int64_t* d_chunk_src,
+                     const int32_t* d_chunk_valid, const int32_t* d_chunk_window, int n_chunks, int chunk_len,
+                     float* d_chunks, void* stream);
+
+/* pooling methods of bn_pool_scores (reference names: 'avg'|'mean'|'average', 'max', 'lme'|'log_mean_exp'|...) */
+#define BN_POOL_AVG 0
+#define BN_POOL_MAX 1
+#define BN_POOL_LME 2
+
+/* File-level pooling of chunk scores (reference: birdnet_stm32/evaluation/pooling.py:6-47 pool_scores /
+ * lme_pooling, called once per file by evaluation/metrics.py:143-146), for all files of a batch at once.
+ *   d_scores   [n_rows, n_classes] float32, the rows of one file contiguous
+ *   d_file_off [n_files+1] row offsets; an empty file pools to zeros
+ *   d_pooled   [n_files, n_classes]
+ * mean and max are bit-identical to numpy's float32 result; lme = (m + log(mean(exp(beta s - m)) + 1e-12)) / beta. */
+BN_API int bn_pool_scores(bn_ctx* ctx, const float* d_scores, const int64_t* d_file_off, int n_files, int n_classes,
+                   int method, float beta, float* d_pooled, void* stream);
+
 /* Test hook: number of plan operators' outputs and a copy of one of them.
  * `op_index` in [0, n_ops); the element type/shape is what the packer recorded.
  * Valid until the next forward call. */

@@ -1,0 +1,191 @@
+"""GPU parity of the steps either side of the path: audio ingest and score pooling.
+
+Integer/bit-level bar: the device chunks must equal, bit for bit, what numpy + scipy produce for the same
+PCM (``oracle.ingest`` restates their operation order and is itself pinned to them in
+tests/test_oracle_pinning.py); mean and max pooling bit-exact, log-mean-exp within 2e-6 absolute
+(``exp``/``log`` differ in the last bits between libm and the device).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import fixture_signals
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a ROCm device; there is no CPU fallback to fall back to")
+    from birdnet_stm32 import _hip
+
+    c = _hip.Context(0, 64)
+    yield c
+    c.close()
+
+
+def _pcm16(rng, n, ch):
+    t = np.arange(n) / 48000.0
+    x = 0.4 * np.sin(2 * np.pi * 1500.0 * t)[:, None] + 0.2 * rng.standard_normal((n, ch))
+    return np.clip(np.rint(x * 20000.0), -32768, 32767).astype(np.int16)
+
+
+def _oracle_chunks(frames_f32, sr_in, sr_out, cd, overlap):
+    from oracle import ingest as oi
+
+    y = oi.ingest_window(frames_f32, sr_in, sr_out)
+    return oi.split_chunks(y, sr_out, cd, overlap), y
+
+
+@pytest.mark.parametrize("sr_in", [48000, 44100, 22050, 32000, 16000, 24000])
+def test_ingest_pcm16_bit_exact_against_scipy_order(ctx, sr_in):
+    from birdnet_stm32.audio import ingest
+
+    rng = np.random.default_rng(sr_in)
+    lengths = [int(sr_in * 7.3) + 11, int(sr_in * 1.2), int(sr_in * 3.0), 777]  # long, shorter than a chunk, exact, tiny
+    for ch in (1, 2):
+        pcm = [_pcm16(rng, n, ch) for n in lengths]
+        wins = [ingest.window_from_int16(p, sr_in) for p in pcm]
+        chunks, counts, mono, off, peak = ingest.ingest_windows_device(ctx, wins, 24000, 3.0, 0.5, return_windows=True)
+        chunks = chunks.cpu().numpy()
+        mono = mono.cpu().numpy()
+        at = 0
+        for i, p in enumerate(pcm):
+            want, y = _oracle_chunks(p.astype(np.float32) / 32768.0, sr_in, 24000, 3.0, 0.5)
+            assert counts[i] == want.shape[0]
+            got = chunks[at : at + counts[i]]
+            at += counts[i]
+            assert got.shape == want.shape
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sr_in, ch, i, np.abs(got - want).max())
+        assert at == chunks.shape[0]
+
+
+def test_ingest_matches_host_functions_that_call_scipy(ctx, tmp_path):
+    """End to end from WAV files, against birdnet_stm32.audio.io (numpy mean + scipy.signal.resample_poly itself)."""
+    from birdnet_stm32.audio import ingest, io
+
+    rng = np.random.default_rng(5)
+    paths = []
+    for k, (sr, secs, ch) in enumerate([(44100, 7.0, 2), (48000, 2.0, 1), (24000, 6.5, 2), (22050, 31.0, 1)]):
+        n = int(sr * secs)
+        x = _pcm16(rng, n, ch)
+        p = str(tmp_path / f"f{k}.wav")
+        import struct
+
+        payload = x.tobytes()
+        hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(payload), b"WAVE", b"fmt ", 16, 1, ch, sr, sr * 2 * ch, 2 * ch, 16,
+                          b"data", len(payload))
+        with open(p, "wb") as fh:
+            fh.write(hdr + payload)
+        paths.append(p)
+    paths.append(str(tmp_path / "missing.wav"))
+    chunks, counts = ingest.load_audio_files_device(ctx, paths, 24000, 30, 3.0, 0.0)
+    chunks = chunks.cpu().numpy()
+    at = 0
+    for p, c in zip(paths, counts):
+        want = io.load_audio_file(p, 24000, 30, 3.0, 0.0)
+        assert c == len(want)
+        if c:
+            assert np.array_equal(chunks[at : at + c].view(np.uint32), np.asarray(want, np.float32).view(np.uint32)), p
+        at += c
+    assert counts[-1] == 0 and at == chunks.shape[0]
+
+
+@pytest.mark.parametrize("fmt", ["s24", "s32", "f32"])
+def test_ingest_other_sample_formats_and_channel_counts(ctx, fmt):
+    from birdnet_stm32.audio import ingest
+    from oracle import ingest as oi
+
+    rng = np.random.default_rng(11)
+    for ch in (1, 2, 3, 6, 8):
+        n = 48000 + 333
+        x = np.clip(0.5 * rng.standard_normal((n, ch)), -0.999, 0.999)
+        if fmt == "s24":
+            v = np.rint(x * 8388607).astype(np.int32)
+            b = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=-1).astype(np.uint8)
+            win = ingest.PcmWindow(b.reshape(-1), ingest.PCM_S24, ch, 32000)
+            f = (v.astype(np.float32) / np.float32(8388608.0)).astype(np.float32)
+        elif fmt == "s32":
+            v = np.rint(x * 2147483000).astype(np.int64).astype(np.int32)
+            win = ingest.PcmWindow(v.reshape(-1).view(np.uint8), ingest.PCM_S32, ch, 32000)
+            f = (v.astype(np.float64) / 2147483648.0).astype(np.float32)
+        else:
+            f = x.astype(np.float32)
+            win = ingest.window_from_frames(f, 32000)
+        chunks, counts, mono, off, peak = ingest.ingest_windows_device(ctx, [win], 24000, 1.0, 0.0, return_windows=True)
+        y = oi.mono_mean(f)
+        y = oi.resample_poly_f32(y, 3, 4)
+        assert np.array_equal(mono.cpu().numpy().view(np.uint32), y.view(np.uint32)), (fmt, ch)
+        assert float(peak.cpu().numpy()[0]) == float(np.abs(y).max())
+        want = oi.split_chunks((y / np.float32(np.abs(y).max())).astype(np.float32), 24000, 1.0, 0.0)
+        assert np.array_equal(chunks.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_ingest_edge_cases(ctx):
+    from birdnet_stm32.audio import ingest
+
+    # silence: peak 0 -> no division; a one-sample window; no windows at all
+    wins = [ingest.window_from_int16(np.zeros((5000, 2), np.int16), 44100), ingest.window_from_int16(np.array([[1234]], np.int16), 48000)]
+    chunks, counts = ingest.ingest_windows_device(ctx, wins, 24000, 3.0, 0.0)
+    assert counts == [1, 1] and chunks.shape == (2, 72000)
+    c = chunks.cpu().numpy()
+    assert not c[0].any()
+    assert c[1, 0] == 1.0 and not c[1, 1:].any()  # the single resampled sample is its own peak
+    chunks, counts = ingest.ingest_windows_device(ctx, [], 24000, 3.0, 0.0)
+    assert chunks.shape == (0, 72000) and counts == []
+    with pytest.raises(Exception, match="channels"):
+        ingest.ingest_windows_device(ctx, [ingest.window_from_frames(np.zeros((100, 9), np.float32), 48000)], 24000)
+
+
+def test_ingest_then_infer_equals_host_ingest_then_infer(ctx, tmp_path):
+    """The widened path end to end: device ingest -> bn_infer_audio gives the scores of host ingest -> bn_infer_audio."""
+    import torch
+
+    from birdnet_stm32.audio import ingest, io
+    from birdnet_stm32.models.runners import load_model_runner
+    from conftest import KERAS_PATH
+
+    sig = fixture_signals(44100, 5.0)
+    wins, host = [], []
+    for name in ("sine", "chirp", "noise"):
+        pcm = np.clip(np.rint(sig[name] * 32768.0), -32768, 32767).astype(np.int16)
+        wins.append(ingest.window_from_int16(pcm, 44100))
+        p = str(tmp_path / f"{name}.wav")
+        io.save_wav(sig[name], p, 44100)
+        host.append(np.asarray(io.load_audio_file(p, 24000, 30, 3.0, 0.0), np.float32))
+    runner = load_model_runner(KERAS_PATH, max_batch=64)
+    chunks, counts = ingest.ingest_windows_device(runner.ctx, wins, 24000, 3.0, 0.0)
+    a = runner.infer_audio_device(chunks).cpu().numpy()
+    b = runner.infer_audio_device(torch.from_numpy(np.concatenate(host)).cuda()).cpu().numpy()
+    assert counts == [len(h) for h in host]
+    assert np.array_equal(a, b)
+    runner.close()
+
+
+# ------------------------------------------------------------------------------------- pooling
+def test_pool_scores_device_matches_numpy(ctx):
+    import torch
+
+    from birdnet_stm32.audio.ingest import pool_scores_device
+    from birdnet_stm32.evaluation.pooling import pool_scores
+
+    rng = np.random.default_rng(3)
+    counts = [1, 20, 0, 7, 3, 41]
+    scores = rng.random((sum(counts), 100)).astype(np.float32) ** 4
+    d = torch.from_numpy(scores).cuda()
+    off = np.concatenate([[0], np.cumsum(counts)])
+    for method in ("avg", "max", "lme"):
+        got = pool_scores_device(ctx, d, counts, method, beta=10.0).cpu().numpy()
+        for i, n in enumerate(counts):
+            want = pool_scores(scores[off[i] : off[i + 1]], method, beta=10.0)
+            if method == "lme":
+                np.testing.assert_allclose(got[i], want, rtol=0, atol=2e-6)
+            else:
+                assert np.array_equal(got[i].view(np.uint32), np.asarray(want, np.float32).view(np.uint32)), (method, i)
+    with pytest.raises(ValueError, match="Unsupported pooling method"):
+        pool_scores_device(ctx, d, counts, "median")
+    with pytest.raises(ValueError, match="N_chunks"):
+        pool_scores_device(ctx, d[0], counts, "avg")

@@ -290,3 +290,42 @@ def test_hot_path_fails_loudly_without_gpu():
         get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=-1)
     with pytest.raises(NotImplementedError):
         get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=64)
+
+
+# ------------------------------------------------------------- device-ingest host side (no GPU needed)
+def test_polyphase_filter_layout_and_chunk_table(tmp_path):
+    from birdnet_stm32.audio import ingest, io
+    from oracle import ingest as oi
+
+    for up, down in [(1, 2), (80, 147), (160, 147), (3, 4), (3, 1)]:
+        taps, per_phase, pre = ingest.polyphase_filter(up, down)
+        h, pre_o = oi.design_filter(up, down)
+        assert pre == pre_o and taps.shape == (up, per_phase) and taps.dtype == np.float32
+        full = np.zeros(per_phase * up, np.float32)
+        full[: h.shape[0]] = h
+        for phase in (0, up // 2, up - 1):
+            assert np.array_equal(taps[phase], full[phase::up][::-1])  # oldest input sample first
+    # chunk table == split_audio_into_chunks start positions (reference: audio/io.py:155-174)
+    for n, overlap in [(72000 * 3 + 5, 0.0), (72000, 0.0), (100, 0.0), (72000 * 2, 1.5), (72001, 2.95), (0, 0.0)]:
+        starts, valid, owner, counts, size = ingest.chunk_table([n], 24000, 3.0, overlap)
+        y = np.arange(n, dtype=np.float32)
+        want = io.split_audio_into_chunks(y, 24000, 3.0, overlap)
+        assert counts == [want.shape[0]] and size == 72000
+        assert counts[0] == io.estimate_num_chunks(n, 24000, 3.0, overlap)
+        for s, v, row in zip(starts, valid, want):
+            assert np.array_equal(row[:v], y[s : s + v]) and not row[v:].any()
+    # header-only window reader: PCM16 payload passes through untouched, window limited by max_duration
+    pcm = (np.arange(48000 * 2 * 2) % 2000 - 1000).astype(np.int16).reshape(-1, 2)
+    p = str(tmp_path / "a.wav")
+    import struct
+
+    payload = pcm.tobytes()
+    with open(p, "wb") as fh:
+        fh.write(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(payload), b"WAVE", b"fmt ", 16, 1, 2, 48000, 48000 * 4, 4, 16,
+                             b"data", len(payload)) + payload)
+    w = ingest.read_pcm_window(p, max_duration=1.5)
+    assert (w.fmt, w.channels, w.sample_rate, w.frames) == (ingest.PCM_S16, 2, 48000, 72000)
+    assert np.array_equal(w.payload.view(np.int16).reshape(-1, 2), pcm[:72000])
+    assert ingest.read_pcm_window(str(tmp_path / "nope.wav")) is None
+    io.save_wav(np.zeros(10, np.float32), p, 24000, subtype="FLOAT")
+    assert ingest.read_pcm_window(p).fmt == ingest.PCM_F32

@@ -259,3 +259,52 @@ def test_c_port_matches_numpy_oracle(netspec):
     p, l = float_graph.forward(netspec, Sref[..., None], np.float64, return_logits=True)
     assert np.abs(scores - p).max() < 1e-5
     assert min(cosine(logits[b], l[b]) for b in range(4)) > 1 - 1e-6
+
+
+# ------------------------------------------------------------- audio ingest
+@pytest.mark.parametrize("sr_in", [48000, 44100, 22050, 32000, 16000, 8000, 96000, 11025])
+def test_ingest_resampler_is_scipy_bit_for_bit(sr_in):
+    """oracle.ingest restates scipy.signal.resample_poly (the call the reference makes, audio/io.py:30): same bits."""
+    from scipy.signal import resample_poly
+
+    from oracle import ingest
+
+    up, down = ingest.rates_to_ratio(sr_in, 24000)
+    sig = fixture_signals(sr_in, 1.0)
+    rng = np.random.default_rng(sr_in)
+    for x in (sig["sine"], sig["chirp"], sig["noise"], rng.standard_normal(sr_in // 3 + 17).astype(np.float32), np.ones(5, np.float32)):
+        want = resample_poly(x, up, down)
+        got = ingest.resample_poly_f32(x, up, down)
+        assert want.dtype == np.float32 and got.shape == want.shape
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_ingest_channel_mean_is_numpy_bit_for_bit():
+    from oracle import ingest
+
+    rng = np.random.default_rng(8)
+    for ch in (1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 23):
+        f = (rng.standard_normal((4000, ch)) * rng.choice([1e-3, 1.0, 1e3], size=(4000, ch))).astype(np.float32)
+        assert np.array_equal(ingest.mono_mean(f).view(np.uint32), f.mean(axis=1).astype(np.float32).view(np.uint32)), ch
+
+
+def test_ingest_window_and_chunks_equal_host_io(tmp_path):
+    """Whole ingest restatement vs birdnet_stm32.audio.io (numpy + scipy calls in the reference's order) from WAV files."""
+    from birdnet_stm32.audio import io
+    from oracle import ingest
+
+    rng = np.random.default_rng(21)
+    for sr, secs, ch, overlap in [(44100, 7.4, 2, 0.0), (48000, 2.0, 1, 0.0), (24000, 6.5, 2, 1.0), (22050, 9.1, 1, 2.95)]:
+        n = int(sr * secs)
+        pcm = np.clip(np.rint(rng.standard_normal((n, ch)) * 6000), -32768, 32767).astype(np.int16)
+        p = str(tmp_path / "x.wav")
+        payload = pcm.tobytes()
+        import struct
+
+        with open(p, "wb") as fh:
+            fh.write(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(payload), b"WAVE", b"fmt ", 16, 1, ch, sr, sr * 2 * ch,
+                                 2 * ch, 16, b"data", len(payload)) + payload)
+        want = np.asarray(io.load_audio_file(p, 24000, 30, 3.0, overlap), np.float32)
+        y = ingest.ingest_window(pcm.astype(np.float32) / 32768.0, sr, 24000)
+        got = ingest.split_chunks(y, 24000, 3.0, overlap)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
