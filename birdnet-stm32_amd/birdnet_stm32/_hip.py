@@ -27,7 +27,7 @@ EXPORTS = (
     "bn_version", "bn_last_error", "bn_device_count", "bn_ctx_create", "bn_ctx_destroy", "bn_model_load",
     "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
     "bn_kernel_names", "bn_profile_enable", "bn_profile_collect", "bn_ingest_resample", "bn_ingest_chunks",
-    "bn_pool_scores",
+    "bn_pool_scores", "bn_mel_spectrogram",
 )  # fmt: skip
 
 
@@ -85,6 +85,8 @@ def load_library(path: str | None = None):
     lib.bn_ingest_chunks.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                      c_void_p]
     lib.bn_pool_scores.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
+    lib.bn_mel_spectrogram.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       ctypes.c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     if lib.bn_version() != ABI_VERSION:
         raise RuntimeError(f"libbirdnet_hip ABI {lib.bn_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

@@ -59,9 +59,12 @@ def make_chunks_for_file(path: str, cfg: dict, frontend: str, mag_scale: str, n_
             x[: min(size, ch.shape[0])] = ch[:size]
             out.append((x / (np.max(np.abs(x)) + 1e-6))[:, None].astype(np.float32))
         return out
-    if frontend in ("librosa", "mfcc", "log_mel"):
-        raise NotImplementedError(f"precomputed frontend '{frontend}' has no MI355X path in this build (SURVEY.md §8f)")
-    raise ValueError(f"Invalid audio_frontend: {frontend}")
+    if frontend == "librosa":
+        from birdnet_stm32.audio.spectrogram import mel_spectrograms_from_chunks
+
+        specs = mel_spectrograms_from_chunks(np.asarray(chunks, np.float32), sr, n_fft, int(cfg["num_mels"]), width, mag_scale, "mel")
+        return [s[:, :, None] for s in specs]
+    raise ValueError(f"Invalid audio_frontend: {frontend}")  # the reference's evaluator knows librosa | hybrid | raw only (:72)
 
 
 def _label_of(path: str) -> str:
@@ -140,7 +143,10 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
     rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss if profile_memory else 0
 
     if device_pipeline is None:
-        device_pipeline = frontend == "hybrid" and hasattr(model_runner, "infer_audio_device") and spectrogram_fn is None
+        device_pipeline = (frontend in ("hybrid", "librosa", "log_mel", "mfcc") and hasattr(model_runner, "infer_audio_device")
+                           and spectrogram_fn is None)
+    if device_pipeline and frontend != "hybrid":
+        model_runner.configure_precomputed(frontend, int(cfg["sample_rate"]), mag_scale, n_fft, int(cfg["num_mels"]), int(cfg.get("n_mfcc", 20)))
     if device_pipeline:
         if pooling.lower() not in ("avg", "mean", "average", "max", "lme", "log_mean_exp", "log_mean_exponential"):
             raise ValueError(f"Unsupported pooling method: {pooling}")

@@ -125,10 +125,19 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
     elif fa["mode"] == "raw":
         in_kind, F, W = pk.INPUT_WAVEFORM, 0, int(fa["spec_width"])
         in_elems = int(fa["sample_rate"] * fa["chunk_duration"])
+    elif fa["mode"] == "precomputed":
+        # the graph passes a host-side (here: bn_mel_spectrogram) mel / log-mel / MFCC map through, cut to spec_width
+        # (reference: models/frontend.py:296-297); the plan starts at the stem
+        in_kind, F, W = pk.INPUT_MEL, 0, int(fa["spec_width"])
+        if tuple(layers[0].out_shape[:2]) != (int(fa["mel_bins"]), W):
+            raise NotImplementedError(f"precomputed input {layers[0].out_shape} wider than spec_width {W}")
+        in_elems = int(np.prod(layers[0].out_shape))
     else:
         raise NotImplementedError(f"frontend mode {fa['mode']!r} is not lowered to HIP yet")
 
-    plan = pk.Plan(pk.DTYPE_F32, in_kind, in_elems, F, W, spec.num_classes, meta={"source": spec.meta.get("source", "")})
+    plan = pk.Plan(pk.DTYPE_F32, in_kind, in_elems, F, W, spec.num_classes,
+                   meta={"source": spec.meta.get("source", ""),
+                         "frontend": {k: fa.get(k) for k in ("mode", "mel_bins", "spec_width", "sample_rate", "fft_length", "mag_scale")}})
     pb = pk.PlanBuilder(plan)
     val: dict[str, int] = {}  # layer name -> value id holding its output
     shape: dict[str, tuple] = {}
@@ -172,6 +181,8 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
         if k == ns.INPUT:
             val[ly.name] = pk.SLOT_INPUT
             shape[ly.name] = ly.out_shape
+        elif k == ns.FRONTEND and fa["mode"] == "precomputed":
+            val[ly.name], shape[ly.name] = val[ly.inputs[0]], (int(fa["mel_bins"]), W, 1)
         elif k == ns.FRONTEND and fa["mode"] == "raw":
             M, T = int(fa["mel_bins"]), in_elems
             if M % 4:

@@ -19,7 +19,7 @@ BLOB_MAGIC = b"BNHIPM01"
 BLOB_VERSION = 4
 
 DTYPE_F32, DTYPE_I8 = 0, 1
-INPUT_SPECTROGRAM, INPUT_WAVEFORM = 0, 1
+INPUT_SPECTROGRAM, INPUT_WAVEFORM, INPUT_MEL = 0, 1, 2
 
 SLOT_INPUT, SLOT_SCORES, SLOT_LOGITS, SLOT_AUDIO, SLOT_NONE = -1, -2, -3, -4, -9
 OP_PATH, PATH_BOTH, PATH_INPUT, PATH_AUDIO = 39, 0, 1, 2

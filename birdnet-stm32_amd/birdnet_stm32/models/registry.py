@@ -59,11 +59,11 @@ def is_n6_compatible(name: str) -> bool:
 
 for _row in (
     # name       mode           precomputed  n6    hip    description
-    ("librosa", "precomputed", True, True, False, "Host-side mel spectrogram; the model passes it through."),
+    ("librosa", "precomputed", True, True, True, "Host-side mel spectrogram; the model passes it through."),
     ("hybrid", "hybrid", False, True, True, "Linear STFT magnitude outside the model, 1x1 mel mixer + magnitude scaling inside."),
-    ("raw", "raw", False, True, False, "Waveform in, learned strided filterbank inside the model (T < 65536 on the STM32N6)."),
-    ("mfcc", "precomputed", True, True, False, "Host-side MFCC (mel -> dB -> DCT -> truncate); passed through."),
-    ("log_mel", "precomputed", True, True, False, "Host-side log1p mel spectrogram; passed through."),
+    ("raw", "raw", False, True, True, "Waveform in, learned strided filterbank inside the model (T < 65536 on the STM32N6)."),
+    ("mfcc", "precomputed", True, True, True, "Host-side MFCC (mel -> dB -> DCT -> truncate); passed through."),
+    ("log_mel", "precomputed", True, True, True, "Host-side log1p mel spectrogram; passed through."),
 ):
     register_frontend(FrontendInfo(*_row[:4], description=_row[5], hip_path=_row[4]))
 del _row

@@ -48,6 +48,8 @@ class HipRunner:
         self.input_elems = int(info.input_elems)
         self.fft_bins, self.spec_width = int(info.fft_bins), int(info.spec_width)
         self.dtype = "i8" if info.dtype == pk.DTYPE_I8 else "f32"
+        self.input_kind = int(info.input_kind)
+        self._precomputed: dict | None = None  # spectrogram settings of a precomputed-frontend model (configure_precomputed)
 
     # -- helpers ----------------------------------------------------------------------------
     def _stream(self) -> ctypes.c_void_p:
@@ -103,10 +105,42 @@ class HipRunner:
                 )
         return (scores, logits) if return_logits else scores
 
+    def configure_precomputed(self, audio_frontend: str, sample_rate: int, mag_scale: str = "none", n_fft: int = 512,
+                              num_mels: int | None = None, n_mfcc: int = 20) -> None:
+        """Tell a precomputed-frontend runner ('librosa' | 'log_mel' | 'mfcc') how its input spectrograms are made, so that
+        ``infer_audio_device`` can start from waveforms.  The graph itself only passes the map through (reference:
+        models/frontend.py:296-297); which host transform feeds it is a property of the training config
+        (``audio_frontend``, ``mag_scale``, ``num_mels``, ``n_mfcc``: reference evaluation/metrics.py:49-54, data/generator)."""
+        from birdnet_stm32.models.frontend import normalize_frontend_name
+
+        name = normalize_frontend_name(audio_frontend)
+        if name not in ("librosa", "log_mel", "mfcc"):
+            raise ValueError(f"'{audio_frontend}' is not a precomputed frontend")
+        if self.input_kind != pk.INPUT_MEL:
+            raise ValueError("this model does not take precomputed spectrograms")
+        rows = self.input_elems // self.spec_width
+        mels = int(num_mels) if num_mels is not None else rows
+        if (n_mfcc if name == "mfcc" else mels) != rows:
+            raise ValueError(f"model input has {rows} rows; frontend '{name}' with num_mels={mels}, n_mfcc={n_mfcc} does not produce that")
+        self._precomputed = {"mode": {"librosa": "mel", "log_mel": "log_mel", "mfcc": "mfcc"}[name], "sample_rate": int(sample_rate),
+                             "mag_scale": mag_scale if name == "librosa" else "none", "n_fft": int(n_fft), "mel_bins": mels, "n_mfcc": int(n_mfcc)}
+
     def infer_audio_device(self, audio, hop: int | None = None, return_logits: bool = False, out=None):
         """``audio``: CUDA float32 ``[B, T]`` chunks -> scores ``[B, C]`` (STFT + frontend + network on the GPU)."""
         torch = self._torch
         self._check_dev(audio, "audio")
+        if self.input_kind == pk.INPUT_MEL:
+            if self._precomputed is None:
+                raise ValueError("precomputed-frontend model: call configure_precomputed(audio_frontend, sample_rate, mag_scale, ...) first")
+            from birdnet_stm32.audio.spectrogram import mel_spectrograms_device
+
+            c = self._precomputed
+            spec = mel_spectrograms_device(self.ctx, audio, c["sample_rate"], c["n_fft"], c["mel_bins"], self.spec_width, c["mag_scale"],
+                                           c["mode"], c["n_mfcc"])
+            res = self.predict_device(spec.view(spec.shape[0], -1), return_logits=return_logits)
+            if out is not None:
+                out.copy_(res[0] if return_logits else res)
+            return res
         B, T = audio.shape
         hop = int(hop) if hop is not None else T // self.spec_width
         scores = out if out is not None else torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)

@@ -524,6 +524,42 @@ int bn_stft_mag(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int 
     return BN_OK;
 }
 
+int bn_mel_spectrogram(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, const float* d_mel_w,
+                       const int32_t* d_mel_bands, int n_mels, int mode, int mag_scale, double pcen_b, const float* d_dct,
+                       int n_mfcc, float* d_work, float* d_out, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (!d_audio || !d_mel_w || !d_mel_bands || !d_work || !d_out) return fail(BN_ERR_ARG, "null device pointer");
+    if (n_fft != kFft) return fail(BN_ERR_UNSUPPORTED, "n_fft=%d: only 512 is implemented", n_fft);
+    if (B < 0 || T <= 0 || W <= 0 || hop <= 0 || n_mels <= 0) return fail(BN_ERR_ARG, "bad shape B=%d T=%d hop=%d W=%d mels=%d", B, T, hop, W, n_mels);
+    if (1 + T / hop < W)
+        return fail(BN_ERR_ARG, "T=%d hop=%d gives %d frames, fewer than spec_width=%d", T, hop, 1 + T / hop, W);
+    if (mode < BN_SPEC_MEL || mode > BN_SPEC_MFCC) return fail(BN_ERR_ARG, "unknown spectrogram mode %d", mode);
+    if (mag_scale < BN_MAG_NONE || mag_scale > BN_MAG_DB) return fail(BN_ERR_ARG, "unknown mag_scale %d", mag_scale);
+    if (mode != BN_SPEC_MEL) mag_scale = BN_MAG_NONE;  // the reference applies mag_scale only in 'mel' / 'linear' mode
+    if (mode == BN_SPEC_MFCC && (!d_dct || n_mfcc <= 0 || n_mfcc > n_mels)) return fail(BN_ERR_ARG, "mfcc needs 0 < n_mfcc <= n_mels and a DCT matrix");
+    // mfcc: the reference takes the dB reference and floor over ALL 1 + T / hop frames and cuts to W after the DCT
+    const int Wall = mode == BN_SPEC_MFCC ? 1 + T / hop : W;
+    if ((n_mels * Wall) % 4) return fail(BN_ERR_UNSUPPORTED, "n_mels * frames must be a multiple of 4");
+    if (bn::melspec_finish_lds_bytes(n_mels, Wall, W, mode, mag_scale, n_mfcc) + 64 > 160 * 1024)
+        return fail(BN_ERR_UNSUPPORTED, "a %d x %d mel map (mode %d) does not fit one workgroup's LDS", n_mels, Wall, mode);
+    if (B == 0) return BN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per = (size_t)n_mels * Wall;
+    const size_t per_out = mode == BN_SPEC_MFCC ? (size_t)n_mfcc * W : per;
+    for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
+        const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+        float* mel = d_work + (size_t)b0 * per;
+        float* minmax = d_work + (size_t)B * per + 2 * (size_t)b0;
+        bn::launch_minmax_init(minmax, nb, s);
+        bn::launch_stft512_mel(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, Wall, mel, n_mels, d_mel_w, d_mel_bands, minmax, s,
+                               mode == BN_SPEC_MFCC);
+        if (!bn::launch_melspec_finish(mel, d_out + (size_t)b0 * per_out, d_dct, nb, n_mels, Wall, W, mode, mag_scale, n_mfcc, pcen_b, s))
+            return fail(BN_ERR_DEVICE, "could not raise the LDS limit of the spectrogram finishing kernel");
+    }
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
 int bn_forward(bn_model* m, const float* d_input, const float* d_minmax, int B, float* d_scores, float* d_logits,
                void* stream) {
     if (!m) return fail(BN_ERR_ARG, "null model");
@@ -688,7 +724,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 }
 
 const char* bn_kernel_names(void) {
-    return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
+    return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";

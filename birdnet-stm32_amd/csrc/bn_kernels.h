@@ -18,7 +18,11 @@ void launch_minmax_init(float* minmax, int B, hipStream_t s);
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec,
                     float* minmax, hipStream_t s);
 bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
-                        const float* wvals, const int* bands, float* minmax, hipStream_t s);
+                        const float* wvals, const int* bands, float* minmax, hipStream_t s, int square = 0);
+// per-chunk finishing pass of the precomputed-frontend spectrogram modes (bn_melspec.hip)
+size_t melspec_finish_lds_bytes(int M, int W, int Wout, int mode, int mag, int n_mfcc);
+bool launch_melspec_finish(const float* mel, float* out, const float* dct, int B, int M, int W, int Wout, int mode, int mag,
+                           int n_mfcc, double pcen_b, hipStream_t s);
 void launch_spec_normalize(float* spec, const float* minmax, int B, int per_chunk, hipStream_t s);
 
 // ---- ingest and pooling (bn_ingest.hip) ---------------------------------------------------

@@ -94,6 +94,7 @@ struct MelOut {
     const int* bands;    // [3][M] start, len, offset
     float* out;          // [B][M][W]
     int M;
+    int square;          // mix |S|^2 instead of |S| (power mel spectrogram of the MFCC mode)
 };
 
 // The 16 lanes that own a frame sit in ONE wave, and every LDS exchange of the FFT stays inside that frame's slice of
@@ -237,7 +238,14 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
             for (int m = threadIdx.x >> 4; m < mel.M; m += 16) {
                 const int s0 = mel.bands[m], len = mel.bands[mel.M + m], off = mel.bands[2 * mel.M + m];
                 float acc = 0.0f;
-                for (int i = 0; i < len; ++i) acc = fmaf(mag[s0 + i][ff], mel.wvals[off + i], acc);
+                if (mel.square) {
+                    for (int i = 0; i < len; ++i) {
+                        const float v = mag[s0 + i][ff];
+                        acc = fmaf(v * v, mel.wvals[off + i], acc);
+                    }
+                } else {
+                    for (int i = 0; i < len; ++i) acc = fmaf(mag[s0 + i][ff], mel.wvals[off + i], acc);
+                }
                 if (t0 + ff < W) out[(size_t)m * W + t0 + ff] = acc;
             }
         }
@@ -298,11 +306,11 @@ void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int 
 }
 
 bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
-                        const float* wvals, const int* bands, float* minmax, hipStream_t s) {
+                        const float* wvals, const int* bands, float* minmax, hipStream_t s, int square) {
     const int n_tiles = (W + kFT - 1) / kFT;
     const int tpw = stft_tiles_per_wg(B, n_tiles);
     hipLaunchKernelGGL((stft512_mag_kernel<true>), dim3((n_tiles + tpw - 1) / tpw, B), dim3(256), 0, s, tb, audio, T, hop, W, nullptr,
-                       minmax, MelOut{wvals, bands, mel_out, M}, tpw);
+                       minmax, MelOut{wvals, bands, mel_out, M, square}, tpw);
     return true;
 }
 

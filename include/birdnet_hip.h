@@ -68,6 +68,7 @@ typedef struct bn_model bn_model;
 /* what bn_forward's d_input holds */
 #define BN_INPUT_SPECTROGRAM 0 /* [B, F, W] float32 linear STFT magnitude (hybrid frontend) */
 #define BN_INPUT_WAVEFORM 1    /* [B, T] float32 (raw frontend) */
+#define BN_INPUT_MEL 2         /* [B, M, W] float32 precomputed (mel / log-mel / MFCC) spectrogram, passed through */
 
 typedef struct bn_model_info {
     int32_t dtype;          /* BN_DTYPE_* */
@@ -176,6 +177,35 @@ BN_API int bn_ingest_chunks(bn_ctx* ctx, const float* d_mono, const float* d_pea
  * mean and max are bit-identical to numpy's float32 result; lme = (m + log(mean(exp(beta s - m)) + 1e-12)) / beta. */
 BN_API int bn_pool_scores(bn_ctx* ctx, const float* d_scores, const int64_t* d_file_off, int n_files, int n_classes,
                    int method, float beta, float* d_pooled, void* stream);
+
+/* ---- precomputed frontends ---------------------------------------------- */
+
+/* spectrogram modes / magnitude scalings of get_spectrogram_from_audio (reference: audio/spectrogram.py:24-33) */
+#define BN_SPEC_MEL 0    /* mode='mel': magnitude mel spectrogram, then mag_scale, then min-max normalise */
+#define BN_SPEC_LOGMEL 1 /* mode='log_mel': log1p(magnitude mel), normalise */
+#define BN_SPEC_MFCC 2   /* mode='mfcc': power mel -> dB (ref=max, 80 dB floor) -> orthonormal DCT-II, first n_mfcc rows, normalise */
+#define BN_MAG_NONE 0
+#define BN_MAG_PWL 1
+#define BN_MAG_PCEN 2
+#define BN_MAG_DB 3
+
+/* Batched get_spectrogram_from_audio(audio, sample_rate, n_fft=512, mel_bins > 0, spec_width, mag_scale, mode, n_mfcc)
+ * (reference: birdnet_stm32/audio/spectrogram.py:61-149, as called per chunk by evaluation/metrics.py:49-54 for the
+ * 'librosa' frontend and by the data generator for 'log_mel' / 'mfcc'): hop-framed STFT magnitude (same kernel as
+ * bn_stft_mag) mixed by the Slaney mel basis while still in LDS, then one finishing pass per chunk.
+ *   d_audio     [B, T] float32
+ *   d_mel_w / d_mel_bands   band-sparse mel basis (librosa.filters.mel(sr, 512, n_mels, fmin=150, fmax=sr//2)):
+ *               d_mel_bands = int32 [3, n_mels] (first bin, band length, offset into d_mel_w), d_mel_w the
+ *               non-zero runs back to back — what birdnet_stm32.models._lower_f32.mel_bands() produces
+ *   pcen_b      smoothing coefficient of librosa.pcen for (sample_rate, hop): (sqrt(1+4T^2)-1)/(2T^2), T = 0.4 sr / hop
+ *               (only read for mag_scale = BN_MAG_PCEN)
+ *   d_dct       [n_mfcc, n_mels] orthonormal DCT-II rows (only for mode = BN_SPEC_MFCC), else NULL
+ *   d_work      scratch, B * (n_mels * (1 + T / hop) + 2) floats (mfcc takes its dB reference over all frames, like the
+ *               reference, and cuts to W afterwards; the other modes use only the first W frames)
+ *   d_out       [B, n_mels, W] (mel, log_mel) or [B, n_mfcc, W] (mfcc), values in [0, 1] */
+BN_API int bn_mel_spectrogram(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W,
+                       const float* d_mel_w, const int32_t* d_mel_bands, int n_mels, int mode, int mag_scale,
+                       double pcen_b, const float* d_dct, int n_mfcc, float* d_work, float* d_out, void* stream);
 
 /* Test hook: number of plan operators' outputs and a copy of one of them.
  * `op_index` in [0, n_ops); the element type/shape is what the packer recorded.

@@ -189,3 +189,140 @@ def test_pool_scores_device_matches_numpy(ctx):
         pool_scores_device(ctx, d, counts, "median")
     with pytest.raises(ValueError, match="N_chunks"):
         pool_scores_device(ctx, d[0], counts, "avg")
+
+
+# ------------------------------------------------------------------- precomputed-frontend spectrograms (§8f rank 3)
+@pytest.mark.parametrize("mode,mag", [("mel", "none"), ("mel", "pwl"), ("mel", "db"), ("mel", "pcen"), ("log_mel", "none"), ("mfcc", "none")])
+@pytest.mark.parametrize("sr", [24000, 22050])
+def test_mel_spectrogram_modes_match_oracle(ctx, mode, mag, sr):
+    """get_spectrogram_from_audio(mel_bins=64) for every mode / mag_scale against the librosa restatement (float tolerance).
+
+    Outputs are min-max normalised to [0, 1]; bars are absolute.  The float32 GPU STFT differs from the float64 one by
+    ~1e-6 of the peak, which the logarithmic modes amplify for near-silent bins.
+    """
+    import torch
+
+    from birdnet_stm32.audio.spectrogram import mel_spectrograms_device
+    from conftest import synth_chunks
+    from oracle import melspec
+    from oracle import stft as stft_oracle
+
+    sig = fixture_signals(sr, 3.0)
+    x = np.stack([sig["sine"], sig["chirp"], sig["noise"], synth_chunks(1, sr=sr)[0]]).astype(np.float32)
+    got, energies = mel_spectrograms_device(ctx, torch.from_numpy(x).cuda(), sr, 512, 64, 256, mag, mode, 20, return_energies=True)
+    got, energies = got.cpu().numpy(), energies.cpu().numpy()
+    bar = {"none": 2e-5, "pwl": 2e-5, "db": 2e-4, "pcen": 2e-3}[mag] if mode == "mel" else (2e-5 if mode == "log_mel" else 5e-4)
+    for b in range(x.shape[0]):
+        want, hop = melspec.get_spectrogram(x[b], sr, 512, 64, 256, mag, mode, 20)
+        assert got[b].shape == want.shape == ((20, 256) if mode == "mfcc" else (64, 256))
+        assert got[b].min() >= 0.0 and got[b].max() <= 1.0
+        # un-normalised mel energies (magnitude or power) against the float64-STFT restatement, relative to the chunk's peak
+        ref_mel, _ = melspec.mel_spectrogram(x[b], sr, 512, 64, 256, 2.0 if mode == "mfcc" else 1.0)
+        ref_mel = ref_mel[:, : energies.shape[2]]
+        assert np.abs(energies[b] - ref_mel).max() <= 3e-6 * ref_mel.max()
+        if mag == "pcen":
+            # PCEN divides every bin by its own smoothed level, so bins that hold nothing but round-off (pure tones) come
+            # out O(1) different between a float32 and a float64 STFT: check the finishing pass on the GPU's own energies,
+            # and end to end only on the signals with a noise floor
+            fin = stft_oracle.minmax_normalize(melspec.pcen(energies[b].astype(np.float32) * (2.0**31), sr, hop))
+            assert np.abs(got[b] - fin).max() <= 2e-5, (sr, b)
+            if b < 2:
+                continue
+        err = np.abs(got[b] - want).max()
+        assert err <= bar, (mode, mag, sr, b, err)
+
+
+def test_get_spectrogram_from_audio_signature_and_edge_cases(ctx):
+    """The reference entry point itself: every mode's shape/range (reference tests/test_spectrogram.py), silence, mag_scale ignored off 'mel'."""
+    from birdnet_stm32.audio.spectrogram import get_spectrogram_from_audio, mel_spectrograms_from_chunks
+
+    sig = fixture_signals(24000, 3.0)
+    for kw, shape in [(dict(mel_bins=64), (64, 256)), (dict(mel_bins=64, mag_scale="pwl"), (64, 256)), (dict(mel_bins=64, mode="log_mel"), (64, 256)),
+                      (dict(mel_bins=64, mode="mfcc", n_mfcc=20), (20, 256)), (dict(mel_bins=-1), (257, 256)), (dict(mel_bins=32, spec_width=128), (32, 128))]:
+        S = get_spectrogram_from_audio(sig["chirp"], sample_rate=24000, n_fft=512, **kw)
+        assert S.shape == shape and S.dtype == np.float32 and np.isfinite(S).all()
+        assert S.min() >= 0.0 and S.max() <= 1.0 and S.max() > 0.99
+    for mode, mag in [("mel", "none"), ("mel", "db"), ("mel", "pcen"), ("log_mel", "none"), ("mfcc", "none")]:
+        S = mel_spectrograms_from_chunks(sig["silence"][None], 24000, 512, 64, 256, mag, mode)[0]
+        assert np.isfinite(S).all() and not S.any()  # constant map: (S - min) / (0 + 1e-10) = 0
+    a = mel_spectrograms_from_chunks(sig["chirp"][None], 24000, 512, 64, 256, "pcen", "log_mel")
+    b = mel_spectrograms_from_chunks(sig["chirp"][None], 24000, 512, 64, 256, "none", "log_mel")
+    assert np.array_equal(a, b)
+    with pytest.raises(ValueError, match="mode"):
+        mel_spectrograms_from_chunks(sig["chirp"][None], mode="cqt")
+    assert mel_spectrograms_from_chunks(np.zeros((0, 72000), np.float32)).shape == (0, 64, 256)
+
+
+@pytest.mark.parametrize("frontend,mag", [("librosa", "pwl"), ("librosa", "db"), ("log_mel", "none"), ("mfcc", "none")])
+def test_precomputed_frontend_models_from_audio(ctx, frontend, mag):
+    """Models built for the precomputed frontends (reference models/dscnn.py:154-168): the graph passes the host-side map
+    through, so audio -> bn_mel_spectrogram -> bn_forward must equal oracle spectrogram -> oracle float graph (per layer, 1e-3 bar)."""
+    import torch
+
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from conftest import cosine, synth_chunks
+    from oracle import float_graph, melspec
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=12,
+                       audio_frontend=frontend, mag_scale=mag, n_mfcc=20, use_se=False, use_inverted_residual=False, randomize_bn=True, seed=11)
+    audio = np.concatenate([synth_chunks(3), fixture_signals(24000)["chirp"][None]]).astype(np.float32)
+    mode = {"librosa": "mel", "log_mel": "log_mel", "mfcc": "mfcc"}[frontend]
+    maps = np.stack([melspec.get_spectrogram(a, 24000, 512, 64, 256, mag, mode, 20)[0] for a in audio])[..., None].astype(np.float32)
+    ref_scores, ref_logits, acts = float_graph.forward(spec, maps, np.float64, return_all=True, return_logits=True)
+
+    runner = HipRunner(lower_f32(spec, keep_all=True), max_batch=4)
+    assert runner.input_kind == 2 and runner.input_elems == maps[0].size
+    with pytest.raises(ValueError, match="configure_precomputed"):
+        runner.infer_audio_device(torch.from_numpy(audio).cuda())
+    runner.configure_precomputed(frontend, 24000, mag, 512, 64, 20)
+    got_maps = runner.predict(maps)  # runner boundary: the reference's Runner.predict on precomputed maps
+    for oi, op in enumerate(runner.plan.ops):
+        if op.out < 0 or op.name not in acts:
+            continue
+        a = runner.op_output(oi, 4)
+        r = acts[op.name].reshape(a.shape)
+        assert np.abs(a - r).max() / (np.abs(r).max() + 1e-12) < 5e-4, op.name
+    got_audio = runner.infer_audio_device(torch.from_numpy(audio).cuda()).cpu().numpy()
+    for b in range(4):
+        assert 1.0 - cosine(got_maps[b], ref_scores[b]) < 1e-5
+        assert 1.0 - cosine(got_audio[b], ref_scores[b]) < 1e-3  # north-star bar for float frontends
+    assert np.abs(got_audio - ref_scores).max() < (2e-2 if frontend == "mfcc" else 2e-3)
+    with pytest.raises(ValueError, match="rows"):
+        runner.configure_precomputed("mfcc" if frontend != "mfcc" else "librosa", 24000, "none", 512, 64, 20)
+    runner.close()
+
+
+def test_evaluate_librosa_frontend_device_pipeline_matches_reference_loop(tmp_path):
+    """evaluate() with audio_frontend='librosa': device pipeline (ingest -> mel spectrogram -> net -> pooling on the GPU) against the
+    reference-style per-file loop (make_chunks_for_file -> Runner.predict -> host pooling)."""
+    from birdnet_stm32.audio.io import save_wav
+    from birdnet_stm32.evaluation.metrics import evaluate
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from conftest import synth_chunks
+
+    classes = [f"sp{i}" for i in range(6)]
+    cfg = dict(sample_rate=24000, chunk_duration=3, num_mels=64, spec_width=256, fft_length=512, audio_frontend="precomputed", mag_scale="pwl")
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=6,
+                       audio_frontend="librosa", mag_scale="pwl", use_se=False, use_inverted_residual=False, class_activation="sigmoid", seed=3)
+    x = synth_chunks(8)
+    files = []
+    for i in range(8):
+        d = tmp_path / classes[i % 6]
+        d.mkdir(exist_ok=True)
+        wav = np.concatenate([x[i], x[(i + 3) % 8]])[: 72000 + (40000 if i % 2 else 0)]
+        save_wav(wav, str(d / f"f{i}.wav"), 24000)
+        files.append(str(d / f"f{i}.wav"))
+    runner = HipRunner(lower_f32(spec), max_batch=8)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)  # 'precomputed' is the deprecated alias of 'librosa'
+        m_dev, pf_dev, _, ys_dev = evaluate(runner, files, classes, cfg, pooling="max", batch_size=8)
+        m_ref, pf_ref, _, ys_ref = evaluate(runner, files, classes, cfg, pooling="max", batch_size=8, device_pipeline=False)
+    assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
+    assert np.array_equal(ys_dev, ys_ref)  # same kernels either way; only the orchestration differs
+    runner.close()

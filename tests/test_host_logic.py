@@ -232,8 +232,10 @@ def test_evaluate_with_fake_runner_cpu_plumbing(tiny_dataset):
     assert "latency_mean_ms" not in m2 and "total_chunks" not in m2 and "peak_rss_mb" in m2
     with pytest.raises(RuntimeError, match="No valid test samples"):
         evaluate(runner, [files[17]], classes, cfg, spectrogram_fn=_oracle_specs)
-    with pytest.raises(NotImplementedError):
-        make_chunks_for_file(files[0], cfg, "librosa", "none", 512, 0.0)
+    with pytest.raises(Exception, match="(?i)no HIP device|no CPU fallback|not found"):  # the mel modes run on the GPU only
+        make_chunks_for_file(files[0], dict(cfg, num_mels=64), "librosa", "none", 512, 0.0)
+    with pytest.raises(ValueError, match="Invalid audio_frontend"):  # the reference's evaluator knows librosa | hybrid | raw
+        make_chunks_for_file(files[0], dict(cfg, num_mels=64), "mfcc", "none", 512, 0.0)
 
 
 def test_cli_surface(tiny_dataset, tmp_path, capsys):
@@ -288,8 +290,10 @@ def test_hot_path_fails_loudly_without_gpu():
         load_model_runner(TFLITE_PATH)
     with pytest.raises(Exception, match="(?i)no HIP device|no CPU fallback|not found"):
         get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=-1)
-    with pytest.raises(NotImplementedError):
-        get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=64)
+    with pytest.raises(Exception, match="(?i)no HIP device|no CPU fallback|not found"):
+        get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=64, mode="mfcc")
+    with pytest.raises(NotImplementedError):  # mag_scale on a linear spectrogram: no frontend's path uses it
+        get_spectrogram_from_audio(np.zeros(72000, np.float32), mel_bins=-1, mag_scale="db")
 
 
 # ------------------------------------------------------------- device-ingest host side (no GPU needed)

@@ -200,8 +200,15 @@ def test_unsupported_graphs_are_rejected():
     with pytest.raises(ValueError, match="HDF5"):
         H5File(b"\x00" * 128)
     kw = dict(num_mels=64, spec_width=256, sample_rate=22050, chunk_duration=3, embeddings_size=256, num_classes=10)
+    # precomputed frontends lower to a plan that starts at the stem (the graph passes the host-side map through)
+    plan = lower_f32(build_model("dscnn", audio_frontend="librosa", use_se=False, use_inverted_residual=False, **kw))
+    assert plan.input_kind == 2 and plan.input_elems == 64 * 256 and plan.ops[0].in0 == -1
+    plan = lower_f32(build_model("dscnn", audio_frontend="mfcc", n_mfcc=20, **kw))
+    assert plan.input_kind == 2 and plan.input_elems == 20 * 256
+    spec = build_model("dscnn", audio_frontend="librosa", **kw)
+    spec.frontend.attrs["mode"] = "cqt"
     with pytest.raises(NotImplementedError):
-        lower_f32(build_model("dscnn", audio_frontend="librosa", **kw))
+        lower_f32(spec)
 
 
 # ------------------------------------------------------------------------------------------ C ABI
