@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--spec_batch", type=int, default=1024)
     args = ap.parse_args()
 
     import torch
@@ -113,6 +114,29 @@ def main():
                        "up": up, "down": down, "taps_per_phase": per_phase},
         }))
     print(json.dumps({"metric": "ingested audio chunks/s (resample + chunk gather)", "value": round(N / total_ms * 1e3, 1), "ms_per_step": round(total_ms, 4)}))
+
+    # precomputed-frontend spectrograms: [B, 72000] float32 -> [B, 64 | 20, 256]
+    from birdnet_stm32.audio.spectrogram import mel_spectrograms_device
+
+    B = args.spec_batch
+    audio = chunks[:B].contiguous() if N >= B else torch.rand((B, T), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
+    for mode, mag in (("mel", "none"), ("mel", "pwl"), ("mel", "db"), ("mel", "pcen"), ("log_mel", "none"), ("mfcc", "none")):
+        for _ in range(args.warmup):
+            mel_spectrograms_device(ctx, audio, args.sr_out, 512, 64, 256, mag, mode, 20)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in ev:
+            a.record()
+            mel_spectrograms_device(ctx, audio, args.sr_out, 512, 64, 256, mag, mode, 20)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.min([a.elapsed_time(b) for a, b in ev]))  # host-side allocation jitter is not the kernels' time
+        rows = 20 if mode == "mfcc" else 64
+        nbytes = B * (T * 4 + rows * 256 * 4)
+        gbs = nbytes / ms / 1e6
+        print(json.dumps({"kernel": f"stft512_mag_kernel<mel> + melspec_finish_kernel [{mode}/{mag}]", "ms": round(ms, 4), "chunks": B,
+                          "chunks_per_s": round(B / ms * 1e3, 1),
+                          "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                          "algorithmic_bytes_per_chunk": nbytes // B}))
 
 
 if __name__ == "__main__":
