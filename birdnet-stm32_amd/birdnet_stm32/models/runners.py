@@ -179,6 +179,10 @@ class HipRunner:
     def profile(self, enable: bool) -> None:
         _hip.check(self.lib.bn_profile_enable(self.model.handle, int(bool(enable))))
 
+    def profile_only(self, op_index: int) -> None:
+        """Bracket only operator ``op_index`` with events (-1: all operators again)."""
+        _hip.check(self.lib.bn_profile_only(self.model.handle, int(op_index)))
+
     def profile_collect(self) -> list[dict]:
         """Elapsed time per plan operator since the last collect; the extra last entry is the STFT stage."""
         n = len(self.plan.ops) + 1

@@ -67,6 +67,7 @@ struct bn_model {
     size_t workspace_bytes = 0;
     // per-operator HIP-event timing (bn_profile_*): one (start, stop) pair per launch group
     bool profiling = false;
+    int prof_only = -1;                  // >= 0: bracket only this operator (index n_ops = the STFT stage)
     struct EvRec {
         int op;
         hipEvent_t start, stop;
@@ -105,7 +106,7 @@ struct ProfScope {
     hipStream_t s;
     hipEvent_t stop = nullptr;
     ProfScope(bn_model* m_, int op, hipStream_t s_) : m(m_), s(s_) {
-        if (!m->profiling) return;
+        if (!m->profiling || (m->prof_only >= 0 && m->prof_only != op)) return;
         hipEvent_t start = m->take_event();
         stop = m->take_event();
         (void)hipEventRecord(start, s);
@@ -699,6 +700,13 @@ int bn_debug_op_output(bn_model* m, int op_index, int B, void* d_dst, size_t dst
 int bn_profile_enable(bn_model* m, int enable) {
     if (!m) return fail(BN_ERR_ARG, "null model");
     m->profiling = enable != 0;
+    return BN_OK;
+}
+
+int bn_profile_only(bn_model* m, int op_index) {
+    if (!m) return fail(BN_ERR_ARG, "null model");
+    if (op_index < -1 || op_index > (int)m->ops.size()) return fail(BN_ERR_ARG, "op_index %d out of range", op_index);
+    m->prof_only = op_index;
     return BN_OK;
 }
 

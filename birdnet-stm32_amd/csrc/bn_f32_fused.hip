@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
     // ---- which 64 positions -------------------------------------------------------------------------
     if (tid < 64) {
         const int tiles_x = a.OW / a.TW, tiles_y = a.OH / a.TH;
-        int bid = blockIdx.x;
+        int bid = xcd_tile(blockIdx.x, gridDim.x);
         const int tx0 = (bid % tiles_x) * a.TW;
         bid /= tiles_x;
         const int ty0 = (bid % tiles_y) * a.TH;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
     __shared__ __attribute__((aligned(16))) float stem_t[TS * TS][C];
     __shared__ __attribute__((aligned(16))) float tile[64 * (NS + 4)];  // activation tile [64][C + 4], later the output tile
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int tiles_x = a.OW / 8, tiles_y = a.OH / 8;
     const int tx0 = (bid % tiles_x) * 8;
     bid /= tiles_x;

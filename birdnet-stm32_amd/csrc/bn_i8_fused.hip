@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
 
     if (tid < 64) {
         const int tiles_x = a.OW / a.TW, tiles_y = a.OH / a.TH;
-        int bid = blockIdx.x;
+        int bid = xcd_tile(blockIdx.x, gridDim.x);
         const int tx0 = (bid % tiles_x) * a.TW;
         bid /= tiles_x;
         const int ty0 = (bid % tiles_y) * a.TH;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
     __shared__ __attribute__((aligned(16))) int stem_t[TS * TS][C / 4];       // 4 channels per dword
     __shared__ __attribute__((aligned(16))) int tile[64 * (NS + 4)];          // A tile [64][64 + 16 bytes], later int32 accumulators
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int tiles_x = a.OW / 8, tiles_y = a.OH / 8;
     const int tx0 = (bid % tiles_x) * 8;
     bid /= tiles_x;

@@ -5,6 +5,14 @@
 
 namespace bn {
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Tiles that share input rows
+// (3x3 halos, the residual of the same positions) should meet in ONE L2, so the linear tile index is permuted: XCD k walks
+// the k-th eighth of the tile range.  A bijection on [0, nb); the tail nb % 8 maps to itself.
+__device__ __forceinline__ int xcd_tile(int b, int nb) {
+    const int nb8 = nb & ~7;
+    return b < nb8 ? (b & 7) * (nb8 >> 3) + (b >> 3) : b;
+}
+
 // Read-only tables every STFT launch needs (built once per context, in double, stored f32).
 struct StftTables {
     const float* window;    // [16][4] per-lane window base: (-0.25 cos th_j0, -0.25 cos th_j1, 0.25 sin th_j0, 0.25 sin th_j1),

@@ -219,6 +219,9 @@ BN_API int bn_debug_op_output(bn_model* model, int op_index, int B, void* d_dst,
  * milliseconds and launch counts per operator into total_ms[n] / launches[n] (n >= n_ops + 1)
  * and forgets them. */
 BN_API int bn_profile_enable(bn_model* model, int enable);
+/* Restrict the event pairs to ONE operator (op_index in [0, n_ops]; -1 = every operator again).  A pair per operator costs
+ * ~6 % of a 1.5 ms step; bracketing only the kernel under study keeps the timed region undisturbed. */
+BN_API int bn_profile_only(bn_model* model, int op_index);
 BN_API int bn_profile_collect(bn_model* model, double* total_ms, int64_t* launches, int n);
 
 /* Names of the HIP kernels a forward pass launches, '\n'-separated (for profiling tools). */

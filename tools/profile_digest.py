@@ -51,6 +51,16 @@ def main():
         hit = 100 * mean(h) / max(mean(h) + mean(ms), 1)
         lines.append(f"| {key[0]} | {key[1]} | {2*mean(f)/1024:.1f} | {mean(w)/1024:.1f} | {hit:.0f} | {mean(s.get('SQ_INSTS_VALU',[0]))/waves:.0f} | "
                      f"{mean(s.get('SQ_INSTS_MFMA',[0]))/waves:.1f} | {mean(s.get('SQ_LDS_BANK_CONFLICT',[0]))/waves:.0f} |")
+    # machine-readable HBM traffic per launch (bytes), read back by bench.py for roofline.traffic
+    import json
+
+    traffic = []
+    for key in sorted(set(fe) | set(wr)):
+        f = fe.get(key, {}).get("FETCH_SIZE", [0.0])
+        w = wr.get(key, {}).get("WRITE_SIZE", [0.0])
+        mean = lambda v: sum(v) / max(len(v), 1)  # noqa: E731
+        traffic.append({"kernel": key[0], "grid_threads": int(key[1]), "read_bytes": int(2 * mean(f) * 1024), "write_bytes": int(mean(w) * 1024)})
+    open(re.sub(r"_digest\.md$|\.md$", "", out) + "_traffic.json", "w").write(json.dumps(traffic, indent=1) + "\n")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
