@@ -265,6 +265,7 @@ struct FrontArgs {
     const float* wsum;    // [H0]
     const float* magp;    // [NP][H0]
     int mag;
+    int tpw;              // horizontally adjacent tiles one workgroup walks (divides OW / 8)
 };
 
 template <int RG, int CT>
@@ -273,19 +274,21 @@ __global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
     constexpr int FH = 19, FW = 35;   // frontend patch: stem stride (1, 2), 3x3
     constexpr int C = 16;             // stem channels = contraction width of the pointwise
     constexpr int NS = RG * CT * 16;
+    constexpr int PF = (FH * FW + 255) / 256;  // patch elements per thread
     __shared__ float fe_t[FH][FW + 1];
     __shared__ __attribute__((aligned(16))) float stem_t[TS * TS][C];
     __shared__ __attribute__((aligned(16))) float tile[64 * (NS + 4)];  // activation tile [64][C + 4], later the output tile
     const int tid = threadIdx.x;
-    int bid = xcd_tile(blockIdx.x, gridDim.x);
+    // A workgroup walks `tpw` horizontally adjacent 8x8 tiles of one chunk.  The next tile's frontend patch (three floats per
+    // thread) is fetched into registers while the current tile is computed, so only the first patch's HBM latency is exposed.
     const int tiles_x = a.OW / 8, tiles_y = a.OH / 8;
-    const int tx0 = (bid % tiles_x) * 8;
+    int bid = xcd_tile(blockIdx.x, gridDim.x) * a.tpw;
+    const int tx_first = (bid % tiles_x) * 8;
     bid /= tiles_x;
     const int ty0 = (bid % tiles_y) * 8;
     const int chunk = bid / tiles_y;
 
-    // ---- frontend patch: rows 2*ty0-1 .., cols 4*tx0 .. (zero outside = the stem's SAME padding) ---------------------
-    const int r_base = 2 * ty0 - 1, c_base = 4 * tx0;  // stem pad_top 1, pad_left 0
+    const int r_base = 2 * ty0 - 1;  // stem pad_top 1
     const float* fe = a.fe + (size_t)chunk * a.H0 * a.W0;
     float mn = 0.0f, inv_rng = 1.0f;
     if (a.minmax) {
@@ -303,21 +306,65 @@ __global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
             if (gr >= 0 && gr < a.H0) v = c == 0 ? a.wsum[gr] : (c <= 10 ? a.magp[(c - 1) * a.H0 + gr] : 0.0f);
             rowc[rr][c] = v;
         }
-        __syncthreads();
     }
-    for (int i = tid; i < FH * FW; i += 256) {
-        const int rr = i / FW, cc = i - rr * FW;
-        const int gr = r_base + rr, gc = c_base + cc;
-        float v = 0.0f;
-        if (gr >= 0 && gr < a.H0 && gc >= 0 && gc < a.W0) {
-            v = fe[gr * a.W0 + gc];
-            if (a.minmax) {
+    // Stem and depthwise weights + biases go to LDS once per workgroup; pointwise fragment and bias stay in registers.  Fetching
+    // them from global inside every phase of every tile exposed an L2 round trip per phase (waves were stalled ~85 % of their life).
+    __shared__ __attribute__((aligned(16))) float wts[2][10][C];  // [stem | depthwise][9 taps + bias][C]
+    if (tid < 2 * 10 * (C / 4)) {
+        const int which = tid / (10 * (C / 4)), rem = tid - which * 10 * (C / 4);
+        const int k = rem / (C / 4), c4 = rem - k * (C / 4);
+        const float* src = which ? (k < 9 ? a.dw_w + k * C : a.dw_b) : (k < 9 ? a.stem_w + k * C : a.stem_b);
+        *reinterpret_cast<float4*>(&wts[which][k][4 * c4]) = *reinterpret_cast<const float4*>(src + 4 * c4);
+    }
+    // rows 2*ty0-1 .., cols 4*tx0 .. of the frontend map (zero outside = the stem's SAME padding, pad_left 0)
+    float pf[PF];
+    auto fetch_patch = [&](int tx0) {
+        const int c_base = 4 * tx0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = tid + 256 * u;
+            const int rr = i / FW, cc = i - rr * FW;
+            const int gr = r_base + rr, gc = c_base + cc;
+            pf[u] = (i < FH * FW && gr >= 0 && gr < a.H0 && gc >= 0 && gc < a.W0) ? fe[gr * a.W0 + gc] : __uint_as_float(0x7fc00000u);
+        }
+    };
+    fetch_patch(tx_first);
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    constexpr int WM = 4 / RG;
+    const int wm = wave % WM, wn = wave / WM;
+    const int row0 = wm * RG * 16;
+    const int ct0 = blockIdx.y * (RG * CT) + wn * CT;
+    const int n_ct = a.N >> 4;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.pw_w);
+    const int n_base = blockIdx.y * NS;
+    f32x4 bfrag[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bfrag[c] = wp[((size_t)0 * n_ct + ct0 + c) * 64 + lane];
+    constexpr int Q4 = NS / 4;
+    static_assert(256 % Q4 == 0, "each thread keeps one bias quad");
+    const float4 pwb = *reinterpret_cast<const float4*>(a.pw_b + n_base + 4 * (tid % Q4));
+
+    for (int t = 0; t < a.tpw; ++t) {
+        const int tx0 = tx_first + 8 * t;
+        __syncthreads();  // rowc ready (first pass) / previous tile's epilogue done with `tile`, stem phase done with fe_t
+        // ---- frontend patch registers -> LDS, finalised on the way (NaN marks "outside the map": stays an exact zero) ------
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = tid + 256 * u;
+            if (i >= FH * FW) continue;
+            const int rr = i / FW, cc = i - rr * FW;
+            float v = pf[u];
+            if (v != v) {
+                v = 0.0f;
+            } else if (a.minmax) {
                 const float* rc = rowc[rr];
                 const float y = fmaxf((v - mn * rc[0]) * inv_rng, 0.0f);
                 if (a.mag == 1) {  // pwl: rows k0, k1..3, w1..3, b1..3
                     v = y * rc[1];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) v += rc[2 + q] * fmaxf(rc[5 + q] * y + rc[8 + q], 0.0f);
+                    for (int qq = 0; qq < 3; ++qq) v += rc[2 + qq] * fmaxf(rc[5 + qq] * y + rc[8 + qq], 0.0f);
                 } else if (a.mag == 2) {  // pcen-like: rows agc, k1, sw, sb, k2
                     const float y0 = fmaxf(y - rc[1] * y, 0.0f);
                     v = fmaxf(rc[2] * y0 + rc[5] * fmaxf(rc[3] * y0 + rc[4], 0.0f), 0.0f);
@@ -327,103 +374,94 @@ __global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
                     v = y;
                 }
             }
+            fe_t[rr][cc] = v;
         }
-        fe_t[rr][cc] = v;
-    }
-    __syncthreads();
+        __syncthreads();
+        if (t + 1 < a.tpw) fetch_patch(tx0 + 8);  // in flight during the stem / depthwise / pointwise phases below
 
-    // ---- stem patch: stem rows 2*ty0 .. +16, cols 2*tx0 .. +16; zero where the stem map ends (depthwise SAME padding) ---
-    {
-        const int cq = tid & 3;
-        float4 w9[9];
+        // ---- stem patch: stem rows 2*ty0 .. +16, cols 2*tx0 .. +16; zero where the stem map ends (depthwise SAME padding) ---
+        {
+            const int cq = tid & 3;
+            float4 w9[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w9[t] = *reinterpret_cast<const float4*>(a.stem_w + t * C + 4 * cq);
-        const float4 b4 = *reinterpret_cast<const float4*>(a.stem_b + 4 * cq);
-        for (int sp = tid >> 2; sp < TS * TS; sp += 64) {
-            const int sr = sp / TS, sc = sp - sr * TS;
-            float4 acc = b4;
+            for (int k = 0; k < 9; ++k) w9[k] = *reinterpret_cast<const float4*>(&wts[0][k][4 * cq]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&wts[0][9][4 * cq]);
+            for (int sp = tid >> 2; sp < TS * TS; sp += 64) {
+                const int sr = sp / TS, sc = sp - sr * TS;
+                float4 acc = b4;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float v = fe_t[sr + i][2 * sc + j];
+                        const float4 w = w9[i * 3 + j];
+                        acc.x = fmaf(v, w.x, acc.x);
+                        acc.y = fmaf(v, w.y, acc.y);
+                        acc.z = fmaf(v, w.z, acc.z);
+                        acc.w = fmaf(v, w.w, acc.w);
+                    }
+                const bool inside = (2 * ty0 + sr) < a.SH && (2 * tx0 + sc) < a.SW;
+                acc.x = inside ? act_f(acc.x, a.stem_act) : 0.0f;
+                acc.y = inside ? act_f(acc.y, a.stem_act) : 0.0f;
+                acc.z = inside ? act_f(acc.z, a.stem_act) : 0.0f;
+                acc.w = inside ? act_f(acc.w, a.stem_act) : 0.0f;
+                *reinterpret_cast<float4*>(&stem_t[sp][4 * cq]) = acc;
+            }
+        }
+        __syncthreads();
+
+        // ---- depthwise 3x3 stride 2 (pad 0 / 1) from the stem patch -> activation tile [64][C] ----------------------------
+        constexpr int S4 = C / 4 + 1;
+        f32x4* lds4 = reinterpret_cast<f32x4*>(tile);
+        {
+            const int cq = tid & 3, p = tid >> 2;  // 64 positions x 4 channel quads = 256 items
+            const int py = p >> 3, px = p & 7;
+            float4 acc = *reinterpret_cast<const float4*>(&wts[1][9][4 * cq]);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const float v = fe_t[sr + i][2 * sc + j];
-                    const float4 w = w9[i * 3 + j];
-                    acc.x = fmaf(v, w.x, acc.x);
-                    acc.y = fmaf(v, w.y, acc.y);
-                    acc.z = fmaf(v, w.z, acc.z);
-                    acc.w = fmaf(v, w.w, acc.w);
+                    const float4 v = *reinterpret_cast<const float4*>(&stem_t[(2 * py + i) * TS + 2 * px + j][4 * cq]);
+                    const float4 w = *reinterpret_cast<const float4*>(&wts[1][i * 3 + j][4 * cq]);
+                    acc.x = fmaf(v.x, w.x, acc.x);
+                    acc.y = fmaf(v.y, w.y, acc.y);
+                    acc.z = fmaf(v.z, w.z, acc.z);
+                    acc.w = fmaf(v.w, w.w, acc.w);
                 }
-            const bool inside = (2 * ty0 + sr) < a.SH && (2 * tx0 + sc) < a.SW;
-            acc.x = inside ? act_f(acc.x, a.stem_act) : 0.0f;
-            acc.y = inside ? act_f(acc.y, a.stem_act) : 0.0f;
-            acc.z = inside ? act_f(acc.z, a.stem_act) : 0.0f;
-            acc.w = inside ? act_f(acc.w, a.stem_act) : 0.0f;
-            *reinterpret_cast<float4*>(&stem_t[sp][4 * cq]) = acc;
+            lds4[p * S4 + cq] = (f32x4){act_f(acc.x, a.dw_act), act_f(acc.y, a.dw_act), act_f(acc.z, a.dw_act), act_f(acc.w, a.dw_act)};
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- depthwise 3x3 stride 2 (pad 0 / 1) from the stem patch -> activation tile [64][C] -------------------------------
-    constexpr int S4 = C / 4 + 1;
-    f32x4* lds4 = reinterpret_cast<f32x4*>(tile);
-    {
-        const int cq = tid & 3, p = tid >> 2;  // 64 positions x 4 channel quads = 256 items
-        const int py = p >> 3, px = p & 7;
-        float4 acc = *reinterpret_cast<const float4*>(a.dw_b + 4 * cq);
+        // ---- pointwise on the matrix cores (one k-step of 16) --------------------------------------------------------------
+        f32x4 acc[RG][CT];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int g = 0; g < RG; ++g)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(&stem_t[(2 * py + i) * TS + 2 * px + j][4 * cq]);
-                const float4 w = *reinterpret_cast<const float4*>(a.dw_w + (i * 3 + j) * C + 4 * cq);
-                acc.x = fmaf(v.x, w.x, acc.x);
-                acc.y = fmaf(v.y, w.y, acc.y);
-                acc.z = fmaf(v.z, w.z, acc.z);
-                acc.w = fmaf(v.w, w.w, acc.w);
+            for (int c = 0; c < CT; ++c) {
+                acc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 af = lds4[(row0 + 16 * g + r) * S4 + q];
+                const f32x4 bf = bfrag[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[g][c], 0, 0, 0);
             }
-        lds4[p * S4 + cq] = (f32x4){act_f(acc.x, a.dw_act), act_f(acc.y, a.dw_act), act_f(acc.z, a.dw_act), act_f(acc.w, a.dw_act)};
-    }
-    __syncthreads();
-
-    // ---- pointwise on the matrix cores (one k-step of 16) -----------------------------------------------------------------
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    constexpr int WM = 4 / RG;
-    const int wm = wave % WM, wn = wave / WM;
-    const int row0 = wm * RG * 16;
-    const int ct0 = blockIdx.y * (RG * CT) + wn * CT;
-    const int n_ct = a.N >> 4;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.pw_w);
-    f32x4 acc[RG][CT];
+        constexpr int SO = NS + 4;
+        __syncthreads();
 #pragma unroll
-    for (int g = 0; g < RG; ++g)
+        for (int g = 0; g < RG; ++g)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            acc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const f32x4 af = lds4[(row0 + 16 * g + r) * S4 + q];
-            const f32x4 bf = wp[((size_t)0 * n_ct + ct0 + c) * 64 + lane];
+            for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[g][c], 0, 0, 0);
+                for (int reg = 0; reg < 4; ++reg) tile[(row0 + 16 * g + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[g][c][reg];
+        __syncthreads();
+        for (int item = tid; item < 64 * Q4; item += 256) {
+            const int p = item / Q4, c4 = item - p * Q4;
+            const int oh = ty0 + (p >> 3), ow = tx0 + (p & 7);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + p * SO + 4 * c4);
+            const float4 b = pwb;
+            float4 o = make_float4(act_f(v[0] + b.x, a.pw_act), act_f(v[1] + b.y, a.pw_act), act_f(v[2] + b.z, a.pw_act),
+                                   act_f(v[3] + b.w, a.pw_act));
+            *reinterpret_cast<float4*>(a.y + (((size_t)chunk * a.OH + oh) * a.OW + ow) * a.N + n_base + 4 * c4) = o;
         }
-    constexpr int SO = NS + 4;
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < RG; ++g)
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) tile[(row0 + 16 * g + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[g][c][reg];
-    __syncthreads();
-    const int n_base = blockIdx.y * NS;
-    constexpr int Q4 = NS / 4;
-    for (int item = tid; item < 64 * Q4; item += 256) {
-        const int p = item / Q4, c4 = item - p * Q4;
-        const int oh = ty0 + (p >> 3), ow = tx0 + (p & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + p * SO + 4 * c4);
-        const float4 b = *reinterpret_cast<const float4*>(a.pw_b + n_base + 4 * c4);
-        float4 o = make_float4(act_f(v[0] + b.x, a.pw_act), act_f(v[1] + b.y, a.pw_act), act_f(v[2] + b.z, a.pw_act),
-                               act_f(v[3] + b.w, a.pw_act));
-        *reinterpret_cast<float4*>(a.y + (((size_t)chunk * a.OH + oh) * a.OW + ow) * a.N + n_base + 4 * c4) = o;
     }
 }
 
@@ -451,9 +489,14 @@ void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, i
                       const float* pw_w, const float* pw_b, const float* minmax, const float* wsum, const float* magp, int mag,
                       hipStream_t s) {
     FrontArgs a{fe, y, stem_w, stem_b, dw_w, dw_b, pw_w, pw_b, B, H0, W0, H0, W0 / 2, C, N, OH, OW, stem_act, dw_act, pw_act,
-                minmax, wsum, magp, mag};
-    const int tiles = (OH / 8) * (OW / 8) * B;
-    hipLaunchKernelGGL((f32_front_kernel<2, 1>), dim3(tiles, 1), dim3(256), 0, s, a);
+                minmax, wsum, magp, mag, 1};
+    static const int forced = getenv("BN_FRONT_TPW") ? atoi(getenv("BN_FRONT_TPW")) : 0;
+    const int tiles_x = OW / 8;
+    int tpw = forced > 0 ? forced : 4;
+    while (tiles_x % tpw) --tpw;
+    a.tpw = tpw;
+    const int tiles = (OH / 8) * tiles_x * B;
+    hipLaunchKernelGGL((f32_front_kernel<2, 1>), dim3(tiles / tpw, 1), dim3(256), 0, s, a);
 }
 
 bool f32_dwpw_supported(int Cin, int Cout) { return Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 16 && Cin <= 2048; }
