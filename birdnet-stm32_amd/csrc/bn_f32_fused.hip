@@ -243,6 +243,147 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Wave-autonomous variant for the narrow early layers (Cin, Cout <= 64: stage 1 and 2 of the shipped net).
+// Each of the four waves owns 16 of the workgroup's 64 positions from the depthwise inputs to the stores: its depthwise
+// outputs, its 16-row A fragments, all Cout columns, its epilogue rows.  Nothing is exchanged between waves, so there is
+// no workgroup barrier: the waves drift apart and one wave's HBM round trip overlaps the others' arithmetic (with
+// barriers every wave waited for the slowest four times per tile).  Each wave reads the whole (small) weight matrix.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTA>
+__global__ __launch_bounds__(256) void f32_dwpw_wave_kernel(DwPwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    constexpr int N = 16 * CTA;
+    constexpr int Q4 = N / 4;             // float4 per output row
+    constexpr int EP = (16 * Q4) / 64;    // epilogue items per lane
+    const int K = a.Cin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int SA = (K > N ? K : N) + 4;   // row stride of the wave's tile in floats
+    const int S4 = SA >> 2;
+    float* at = lds_raw + wave * 16 * SA;
+    f32x4* at4 = reinterpret_cast<f32x4*>(at);
+    __shared__ PosInfo pos_all[64];
+    PosInfo* pos = pos_all + 16 * wave;
+
+    // ---- this wave's 16 positions: rows of the tile --------------------------------------------------------------
+    if (lane < 16) {
+        const int tiles_x = a.OW / a.TW, tiles_y = a.OH / a.TH;
+        int bid = xcd_tile(blockIdx.x, gridDim.x);
+        const int tx0 = (bid % tiles_x) * a.TW;
+        bid /= tiles_x;
+        const int ty0 = (bid % tiles_y) * a.TH;
+        const int chunk = bid / tiles_y;  // NB == 1
+        const int rr = 16 * wave + lane;
+        const int oh = ty0 + rr / a.TW, ow = tx0 + rr % a.TW;
+        PosInfo pi;
+        pi.pad = 0;
+        pi.out_base = ((chunk * a.OH + oh) * a.OW + ow) * N;
+        const int ih0 = oh * a.sh - a.pt, iw0 = ow * a.sw - a.pl;
+        pi.in_base = ((chunk * a.H + ih0) * a.W + iw0) * K;
+        int mask = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (ih0 + i >= 0 && ih0 + i < a.H && iw0 + j >= 0 && iw0 + j < a.W) mask |= 1 << (i * 3 + j);
+        pi.mask = mask;
+        pos[lane] = pi;
+    }
+    wave_sync();
+
+    // residual rows and bias of the epilogue: requested now, used at the very end
+    float4 res_pf[EP];
+    float4 pwb[EP];
+#pragma unroll
+    for (int i = 0; i < EP; ++i) {
+        const int item = lane + 64 * i;
+        const int p = item / Q4, c4 = item - p * Q4;
+        pwb[i] = *reinterpret_cast<const float4*>(a.pw_b + 4 * c4);
+        res_pf[i] = a.res ? *reinterpret_cast<const float4*>(a.res + (long)pos[p].out_base + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // ---- depthwise 3x3 of the 16 positions -> the wave's tile [16][K] -------------------------------------------------
+    const int kq = K >> 2;             // 64 % kq == 0 (launcher): a lane keeps one channel quad
+    const int cq = lane % kq;
+    const int ppp = 64 / kq;           // positions per pass
+    const int p_first = lane / kq;
+    float4 wgt[9];
+    const float4 bias = *reinterpret_cast<const float4*>(a.dw_b + 4 * cq);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wgt[t] = *reinterpret_cast<const float4*>(a.dw_w + t * K + 4 * cq);
+    for (int p = p_first; p < 16; p += ppp) {
+        const PosInfo pi = pos[p];
+        const float* xin = a.x + (long)pi.in_base + 4 * cq;
+        float4 v9[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = i * 3 + j;
+                v9[t] = (pi.mask >> t) & 1 ? *reinterpret_cast<const float4*>(xin + (i * a.W + j) * K) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        float4 accv = bias;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            accv.x = fmaf(v9[t].x, wgt[t].x, accv.x);
+            accv.y = fmaf(v9[t].y, wgt[t].y, accv.y);
+            accv.z = fmaf(v9[t].z, wgt[t].z, accv.z);
+            accv.w = fmaf(v9[t].w, wgt[t].w, accv.w);
+        }
+        at4[p * S4 + cq] = (f32x4){act_f(accv.x, a.dw_act), act_f(accv.y, a.dw_act), act_f(accv.z, a.dw_act), act_f(accv.w, a.dw_act)};
+    }
+    wave_sync();
+
+    // ---- [16 x K] x [K x N] on the matrix cores ---------------------------------------------------------------------------
+    f32x4 acc[CTA];
+#pragma unroll
+    for (int c = 0; c < CTA; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.pw_w);  // [K/16][N/16][64 lanes] float4
+    const int ksteps = K >> 4;
+    for (int j = 0; j < ksteps; ++j) {
+        const f32x4 af = at4[r * S4 + 4 * j + q];
+        f32x4 bf[CTA];
+#pragma unroll
+        for (int c = 0; c < CTA; ++c) bf[c] = wp[((size_t)j * CTA + c) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < CTA; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[c][e], acc[c], 0, 0, 0);
+    }
+    wave_sync();  // every lane has read its A fragments: the tile can take the outputs
+#pragma unroll
+    for (int c = 0; c < CTA; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) at[(4 * q + reg) * SA + 16 * c + r] = acc[c][reg];
+    wave_sync();
+
+    // ---- bias, residual, activation, whole-row stores -----------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < EP; ++i) {
+        const int item = lane + 64 * i;
+        const int p = item / Q4, c4 = item - p * Q4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(at + p * SA + 4 * c4);
+        float4 o = make_float4(v[0] + pwb[i].x, v[1] + pwb[i].y, v[2] + pwb[i].z, v[3] + pwb[i].w);
+        if (a.res) {
+            o.x += res_pf[i].x;
+            o.y += res_pf[i].y;
+            o.z += res_pf[i].z;
+            o.w += res_pf[i].w;
+        }
+        o.x = act_f(o.x, a.pw_act);
+        o.y = act_f(o.y, a.pw_act);
+        o.z = act_f(o.z, a.pw_act);
+        o.w = act_f(o.w, a.pw_act);
+        *reinterpret_cast<float4*>(a.y + (long)pos[p].out_base + 4 * c4) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Front block: frontend output [64][256] (one channel) -> stem 3x3 (stride 1x2, +BN, ReLU6) -> depthwise 3x3
 // stride 2 (+BN, ReLU6) -> pointwise 1x1 (+BN, ReLU6), in ONE kernel.  The stem activation (512 KB per chunk in
 // float32, the largest tensor of the network) lives only in LDS: a workgroup computes the 17x17x16 stem patch its
@@ -503,8 +644,24 @@ bool f32_dwpw_supported(int Cin, int Cout) { return Cin % 16 == 0 && Cout % 16 =
 
 // Each workgroup covers RG*CT column tiles of 16 (4 waves = (4/RG) along the 64 rows x RG along the columns);
 // wider layers are cut into column slices (grid.y), each recomputing the cheap depthwise stage.
+template <int CTA>
+static void launch_wave(const DwPwArgs& a, hipStream_t s) {
+    const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * a.B;
+    const int sa = (a.Cin > a.Cout ? a.Cin : a.Cout) + 4;
+    hipLaunchKernelGGL((f32_dwpw_wave_kernel<CTA>), dim3(tiles), dim3(256), (size_t)64 * sa * sizeof(float), s, a);
+}
+
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s) {
     const int ct_total = a.Cout / 16;
+    static const int wave_variant = getenv("BN_WAVE_DWPW") ? atoi(getenv("BN_WAVE_DWPW")) : 1;
+    if (wave_variant && a.has_dw && a.NB == 1 && a.Cin <= 64 && a.Cout <= 64 && 64 % (a.Cin / 4) == 0 && !a.gate) {
+        switch (ct_total) {
+            case 1: launch_wave<1>(a, s); return;
+            case 2: launch_wave<2>(a, s); return;
+            case 3: launch_wave<3>(a, s); return;
+            case 4: launch_wave<4>(a, s); return;
+        }
+    }
     static const int kSlices[] = {24, 16, 12, 8, 6, 4, 3, 2, 1};
     int slice = 1;
     for (int v : kSlices)
