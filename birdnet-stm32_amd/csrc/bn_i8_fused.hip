@@ -27,6 +27,50 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int32_t sx8(int32_t v, int byte) { return (int32_t)(int8_t)(v >> (8 * byte)); }
 
+// One multiply-accumulate of channel e of a packed 4-channel dword without unpacking: v_dot4_i32_i8 against a weight dword
+// whose other three bytes are zero (the reduction over the four bytes then has a single non-zero term).  Exact int32.
+__device__ __forceinline__ int32_t lane_byte(int32_t w, int e) { return w & (0xff << (8 * e)); }
+__device__ __forceinline__ int32_t dot4(int32_t a, int32_t b, int32_t c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+// 4 x 4 byte transpose: rows r0..r3 hold four channels of one tap each; c[e] gets channel e of the four taps.
+// v_perm_b32 picks bytes out of the 8-byte value {s0 (bytes 4-7), s1 (bytes 0-3)}.
+__device__ __forceinline__ void transpose4x4(int r0, int r1, int r2, int r3, int c[4]) {
+    const uint32_t a_lo = __builtin_amdgcn_perm((uint32_t)r1, (uint32_t)r0, 0x05010400u);  // r0.0 r1.0 r0.1 r1.1
+    const uint32_t a_hi = __builtin_amdgcn_perm((uint32_t)r1, (uint32_t)r0, 0x07030602u);  // r0.2 r1.2 r0.3 r1.3
+    const uint32_t b_lo = __builtin_amdgcn_perm((uint32_t)r3, (uint32_t)r2, 0x05010400u);
+    const uint32_t b_hi = __builtin_amdgcn_perm((uint32_t)r3, (uint32_t)r2, 0x07030602u);
+    c[0] = (int)__builtin_amdgcn_perm(b_lo, a_lo, 0x05040100u);  // a_lo.01 b_lo.01 = r0.0 r1.0 r2.0 r3.0
+    c[1] = (int)__builtin_amdgcn_perm(b_lo, a_lo, 0x07060302u);
+    c[2] = (int)__builtin_amdgcn_perm(b_hi, a_hi, 0x05040100u);
+    c[3] = (int)__builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
+}
+
+// Depthwise 3x3 weights of one channel quad, transposed once per thread: per channel the bytes of taps 0-3 and 4-7, and
+// tap 8 left in its own lane of a dword.  dw9() then needs 16 byte-permutes + 12 dot4 for 36 multiply-accumulates.
+struct DwTaps {
+    int w03[4], w47[4], w8[4];
+};
+__device__ __forceinline__ DwTaps load_dw_taps(const int8_t* w, int stride) {  // tap t at w + t * stride (4 bytes = 4 channels)
+    int r[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) r[t] = *reinterpret_cast<const int*>(w + t * stride);
+    DwTaps d;
+    transpose4x4(r[0], r[1], r[2], r[3], d.w03);
+    transpose4x4(r[4], r[5], r[6], r[7], d.w47);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d.w8[e] = lane_byte(r[8], e);
+    return d;
+}
+__device__ __forceinline__ void dw9(const int v9[9], const DwTaps& d, int acc[4]) {
+    int c[4];
+    transpose4x4(v9[0], v9[1], v9[2], v9[3], c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = dot4(c[e], d.w03[e], acc[e]);
+    transpose4x4(v9[4], v9[5], v9[6], v9[7], c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = dot4(c[e], d.w47[e], dot4(v9[8], d.w8[e], acc[e]));
+}
+
 struct PosInfo8 {
     int in_base;   // byte offset of tap (0,0) in x
     int out_base;  // byte offset of channel 0 in y / res (transposed output: offset of (chunk, n = 0, t)), -1 = skip
@@ -106,11 +150,10 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
         // ---- phase 1 -------------------------------------------------------------------------------------
         const bool fixed_cq = (256 % kq) == 0;
         const int cq_fixed = tid % kq;
-        int wq[9];
+        DwTaps taps;
         int bias4[4], mult4[4], shift4[4];
         auto load_consts = [&](int cq) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const int*>(a.dw_w + t * K + k0 + 4 * cq);
+            taps = load_dw_taps(a.dw_w + k0 + 4 * cq, K);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 bias4[e] = a.dw_b[k0 + 4 * cq + e];
@@ -136,12 +179,11 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
                         const int t = i * 3 + j;
                         v9[t] = (pi.mask >> t) & 1 ? *reinterpret_cast<const int*>(xin + (i * a.W + j) * K) : zp4;
                     }
+                int s4[4] = {bias4[0], bias4[1], bias4[2], bias4[3]};  // bias already holds -zp_in * sum of the nine weights
+                dw9(v9, taps, s4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int s = bias4[e];  // bias already holds -zp_in * sum of the nine weights
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) s += sx8(v9[t], e) * sx8(wq[t], e);
-                    const int qv = clampi(mbqm(s, mult4[e], shift4[e]) + a.dw_zp_out, a.dw_amin, a.dw_amax);
+                    const int qv = clampi(mbqm(s4[e], mult4[e], shift4[e]) + a.dw_zp_out, a.dw_amin, a.dw_amax);
                     packed |= (qv & 0xff) << (8 * e);
                 }
             } else if (pi.mask) {
@@ -288,27 +330,40 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
 
     {   // stem patch: thread = (stem position, channel quad)
         const int cq = tid & 3;
-        int w9[9], b4[4], m4[4], s4[4];
+        int b4[4], m4[4], s4[4];
+        int wt[4][3];  // per channel: taps 0-3, 4-7 and 8 as bytes of three dwords (the window is a 9-byte vector of ONE input channel)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w9[t] = *reinterpret_cast<const int*>(a.stem_w + t * C + 4 * cq);
+        for (int e = 0; e < 4; ++e) wt[e][0] = wt[e][1] = wt[e][2] = 0;
+        int wsum[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int w = *reinterpret_cast<const int*>(a.stem_w + t * C + 4 * cq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wt[e][t >> 2] |= ((w >> (8 * e)) & 0xff) << (8 * (t & 3));
+                wsum[e] += sx8(w, e);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            b4[e] = a.stem_b[4 * cq + e];
+            b4[e] = a.stem_b[4 * cq + e] - a.stem_zp_in * wsum[e];  // sum (x - zp) w = sum x w - zp sum w
             m4[e] = a.stem_mult[4 * cq + e];
             s4[e] = a.stem_shift[4 * cq + e];
         }
         const int zpo4 = (a.stem_zp_out & 0xff) * 0x01010101;
         for (int sp = tid >> 2; sp < TS * TS; sp += 64) {
             const int sr = sp / TS, sc = sp - sr * TS;
-            int acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+            int tb[9];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int v = (int)fe_t[sr + i][2 * sc + j] - a.stem_zp_in;
+                for (int j = 0; j < 3; ++j) tb[i * 3 + j] = (uint8_t)fe_t[sr + i][2 * sc + j];
+            const int x0 = tb[0] | (tb[1] << 8) | (tb[2] << 16) | (tb[3] << 24);
+            const int x1 = tb[4] | (tb[5] << 8) | (tb[6] << 16) | (tb[7] << 24);
+            const int x2 = tb[8];
+            int acc[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += v * sx8(w9[i * 3 + j], e);
-                }
+            for (int e = 0; e < 4; ++e) acc[e] = dot4(x2, wt[e][2], dot4(x1, wt[e][1], dot4(x0, wt[e][0], b4[e])));
             int packed = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -325,15 +380,13 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
         int acc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = a.dw_b[4 * cq + e];
+        const DwTaps taps = load_dw_taps(a.dw_w + 4 * cq, C);
+        int v9[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int v = stem_t[(2 * py + i) * TS + 2 * px + j][cq];
-                const int w = *reinterpret_cast<const int*>(a.dw_w + (i * 3 + j) * C + 4 * cq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += sx8(v, e) * sx8(w, e);
-            }
+            for (int j = 0; j < 3; ++j) v9[i * 3 + j] = stem_t[(2 * py + i) * TS + 2 * px + j][cq];
+        dw9(v9, taps, acc);
         int packed = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
