@@ -60,6 +60,7 @@ struct bn_model {
     char* d_consts = nullptr;            // one allocation, tensors at their blob offsets
     size_t consts_base = 0;              // blob offset of the first payload byte
     size_t consts_bytes = 0;
+    std::vector<uint8_t> rq_right;       // per operator: all requantisation multipliers >= 0 and shifts < 0
     std::vector<char*> d_slots;          // max_batch * bytes_per_chunk each
     float* d_spec = nullptr;             // [max_batch][F][W] for bn_infer_audio
     float* d_minmax = nullptr;           // [max_batch][2]
@@ -270,6 +271,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 a.Cout = p[14]; a.pw_zp_out = p[15]; a.pw_amin = p[16]; a.pw_amax = p[17];
                 a.add = bn::I8AddParams{p[18], p[19], p[20], p[21], p[22], p[23], p[24], p[25], p[26], p[27], p[28]};
                 a.has_dw = p[29]; a.transposed = p[30]; a.TH = p[31]; a.TW = p[32]; a.NB = p[33];
+                a.rq_right = m->rq_right[oi];
                 if (!bn::i8_dwpw_supported(a.Cin, a.Cout) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported fused INT8 block geometry", oi);
                 bn::launch_i8_dwpw(a, s);
@@ -286,6 +288,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 q.H0 = p[0]; q.W0 = p[1]; q.C = p[2]; q.N = p[3]; q.OH = p[4]; q.OW = p[5];
                 q.stem_zp_in = p[6]; q.stem_zp_out = p[7]; q.stem_amin = p[8]; q.stem_amax = p[9];
                 q.dw_zp_out = p[10]; q.dw_amin = p[11]; q.dw_amax = p[12]; q.pw_zp_out = p[13]; q.pw_amin = p[14]; q.pw_amax = p[15];
+                q.rq_right = m->rq_right[oi];
                 if (!bn::i8_front_supported(q.H0, q.W0, q.C, q.N, q.OH, q.OW))
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported INT8 front-block geometry", oi);
                 bn::launch_i8_front(q, (const int8_t*)in0, (int8_t*)out, B, s);
@@ -435,6 +438,31 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
                 delete m;
                 return fail(BN_ERR_FORMAT, "operator references slot %d of %u", id, h.n_slots);
             }
+    }
+    // INT8 blocks: can every requantisation of the operator take the branch-free right-shift form?
+    m->rq_right.assign(h.n_ops, 0);
+    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+        const OpRec& o = m->ops[oi];
+        auto all_right = [&](int t_mult, int t_shift) {
+            if (t_mult < 0 || t_shift < 0) return false;
+            const TensorRec& tm = m->tensors[t_mult];
+            const TensorRec& ts = m->tensors[t_shift];
+            const int32_t* pm = (const int32_t*)(base + tm.offset);
+            const int32_t* ps = (const int32_t*)(base + ts.offset);
+            for (size_t i = 0; i < tm.nbytes / 4; ++i)
+                if (pm[i] < 0) return false;
+            for (size_t i = 0; i < ts.nbytes / 4; ++i)
+                if (ps[i] >= 0) return false;
+            return true;
+        };
+        if (o.kind == BN_OP_I8_DWPW) {
+            const int* p = o.p;
+            bool ok = all_right(o.t[6], o.t[7]) && (!p[29] || all_right(o.t[2], o.t[3]));
+            if (p[18]) ok = ok && p[20] >= 0 && p[21] < 0 && p[22] >= 0 && p[23] < 0 && p[24] >= 0 && p[25] < 0;  // ADD: m1 s1 m2 s2 mo so
+            m->rq_right[oi] = ok;
+        } else if (o.kind == BN_OP_I8_FRONT) {
+            m->rq_right[oi] = all_right(o.t[2], o.t[3]) && all_right(o.t[6], o.t[7]) && all_right(o.t[10], o.t[11]);
+        }
     }
     auto cleanup_fail = [&](int code) {
         bn_model_free(m);

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
     v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);  // activation tile [64][kcp/16 + 1] x 16 bytes
     const int K = a.Cin, N = a.Cout;
     const int tid = threadIdx.x;
+    const bool rq = a.rq_right != 0;  // uniform: every requantisation of this operator is a pure right shift
 
     if (tid < 64) {
         const int tiles_x = a.OW / a.TW, tiles_y = a.OH / a.TH;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
                 dw9(v9, taps, s4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int qv = clampi(mbqm(s4[e], mult4[e], shift4[e]) + a.dw_zp_out, a.dw_amin, a.dw_amax);
+                    const int qv = clampi(mbqm_u(s4[e], mult4[e], shift4[e], rq) + a.dw_zp_out, a.dw_amin, a.dw_amax);
                     packed |= (qv & 0xff) << (8 * e);
                 }
             } else if (pi.mask) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
             int packed = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int qv = clampi(mbqm(v[e] + b[e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                int qv = clampi(mbqm_u(v[e] + b[e], m[e], sh[e], rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
                 if (a.add.enabled) {
                     const int sa = mbqm((sx8(rv, e) - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);
                     const int sb = mbqm((qv - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
             int packed = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int qv = clampi(mbqm(v[e] + b, m, sh) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                int qv = clampi(mbqm_u(v[e] + b, m, sh, rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
                 if (a.lut) qv = a.lut[nn * 256 + qv + 128];
                 packed |= (qv & 0xff) << (8 * e);
             }
@@ -304,6 +305,7 @@ struct Front8Args {
     const int32_t* pw_shift;
     int B, H0, W0, SH, SW, N, OH, OW;
     int stem_zp_in, stem_zp_out, stem_amin, stem_amax, dw_zp_out, dw_amin, dw_amax, pw_zp_out, pw_amin, pw_amax;
+    int rq_right;
 };
 
 __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
     __shared__ __attribute__((aligned(16))) int stem_t[TS * TS][C / 4];       // 4 channels per dword
     __shared__ __attribute__((aligned(16))) int tile[64 * (NS + 4)];          // A tile [64][64 + 16 bytes], later int32 accumulators
     const int tid = threadIdx.x;
+    const bool rq = a.rq_right != 0;
     int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int tiles_x = a.OW / 8, tiles_y = a.OH / 8;
     const int tx0 = (bid % tiles_x) * 8;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
             int packed = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                packed |= (clampi(mbqm(acc[e], m4[e], s4[e]) + a.stem_zp_out, a.stem_amin, a.stem_amax) & 0xff) << (8 * e);
+                packed |= (clampi(mbqm_u(acc[e], m4[e], s4[e], rq) + a.stem_zp_out, a.stem_amin, a.stem_amax) & 0xff) << (8 * e);
             const bool inside = (2 * ty0 + sr) < a.SH && (2 * tx0 + sc) < a.SW;
             stem_t[sp][cq] = inside ? packed : zpo4;
         }
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
         int packed = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            packed |= (clampi(mbqm(acc[e], a.dw_mult[4 * cq + e], a.dw_shift[4 * cq + e]) + a.dw_zp_out, a.dw_amin, a.dw_amax) & 0xff) << (8 * e);
+            packed |= (clampi(mbqm_u(acc[e], a.dw_mult[4 * cq + e], a.dw_shift[4 * cq + e], rq) + a.dw_zp_out, a.dw_amin, a.dw_amax) & 0xff) << (8 * e);
         tile[p * 20 + cq] = packed;  // row stride 80 bytes = 64 (one MFMA k-step) + 16; columns 16..63 meet zero weights
     }
     __syncthreads();
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
         int packed = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            packed |= (clampi(mbqm(v[e] + b[e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax) & 0xff) << (8 * e);
+            packed |= (clampi(mbqm_u(v[e] + b[e], m[e], sh[e], rq) + a.pw_zp_out, a.pw_amin, a.pw_amax) & 0xff) << (8 * e);
         *reinterpret_cast<int*>(a.y + (((size_t)chunk * a.OH + oh) * a.OW + ow) * a.N + 4 * c4) = packed;
     }
 }
@@ -458,7 +461,7 @@ bool i8_front_supported(int H0, int W0, int C, int N, int OH, int OW) {
 void launch_i8_front(const I8FrontParams& q, const int8_t* fe, int8_t* y, int B, hipStream_t s) {
     Front8Args a{fe, y, q.stem_w, q.stem_b, q.stem_mult, q.stem_shift, q.dw_w, q.dw_b, q.dw_mult, q.dw_shift, q.pw_w, q.pw_b, q.pw_mult,
                  q.pw_shift, B, q.H0, q.W0, q.H0, q.W0 / 2, q.N, q.OH, q.OW, q.stem_zp_in, q.stem_zp_out, q.stem_amin, q.stem_amax,
-                 q.dw_zp_out, q.dw_amin, q.dw_amax, q.pw_zp_out, q.pw_amin, q.pw_amax};
+                 q.dw_zp_out, q.dw_amin, q.dw_amax, q.pw_zp_out, q.pw_amin, q.pw_amax, q.rq_right};
     hipLaunchKernelGGL(i8_front_kernel, dim3((q.OH / 8) * (q.OW / 8) * B), dim3(256), 0, s, a);
 }
 

@@ -136,6 +136,7 @@ struct DwPw8Args {
     int B, H, W, Cin, Cout, sh, sw, pt, pl, OH, OW, TH, TW, NB, has_dw, transposed;
     int dw_zp_in, dw_zp_out, dw_amin, dw_amax, pw_zp_out, pw_amin, pw_amax;
     I8AddParams add;
+    int rq_right;  // every multiplier >= 0 and every shift < 0 in this operator (set at load): branch-free requantisation
 };
 bool i8_dwpw_supported(int Cin, int Cout);
 // INT8 stem 3x3 + depthwise 3x3 stride 2 + pointwise in one kernel (bn_i8_fused.hip)
@@ -145,6 +146,7 @@ struct I8FrontParams {
     const int8_t* pw_w; const int32_t* pw_b; const int32_t* pw_mult; const int32_t* pw_shift;
     int H0, W0, C, N, OH, OW;
     int stem_zp_in, stem_zp_out, stem_amin, stem_amax, dw_zp_out, dw_amin, dw_amax, pw_zp_out, pw_amin, pw_amax;
+    int rq_right;
 };
 bool i8_front_supported(int H0, int W0, int C, int N, int OH, int OW);
 void launch_i8_front(const I8FrontParams& q, const int8_t* fe, int8_t* y, int B, hipStream_t s);

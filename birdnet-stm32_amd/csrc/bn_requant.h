@@ -52,6 +52,17 @@ __device__ __forceinline__ int32_t mbqm(int32_t x, int32_t mult, int shift) {
     return mbqm_ref(x, mult, shift);
 }
 
+// Every multiplier >= 0 and every shift < 0 (checked on the host over all channels of an operator at load time): the
+// workgroup-uniform flag `all_right` selects the branch-free form, with no per-element sign/zero tests on the exponent.
+__device__ __forceinline__ int32_t mbqm_right(int32_t x, int32_t mult, int shift) {
+    const int e = -shift;  // >= 1
+    const int32_t v = srdhm_pos(x, mult);
+    return (v + (1 << (e - 1)) + (v >> 31)) >> e;
+}
+__device__ __forceinline__ int32_t mbqm_u(int32_t x, int32_t mult, int shift, bool all_right) {
+    return all_right ? mbqm_right(x, mult, shift) : mbqm(x, mult, shift);
+}
+
 __device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 }  // namespace bn
