@@ -376,47 +376,70 @@ __global__ void f32_dense_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
-// global average pool + Dense (+ sigmoid / softmax): one 256-thread block per chunk.  Threads first average their channel
-// over the P positions, then 4 groups of 64 lanes each take a quarter of the contraction for up to 64 x 4 outputs and the
-// partial sums meet in LDS (reference: birdnet_stm32/models/dscnn.py:256-261).
+// global average pool + Dense (+ sigmoid / softmax): one 256-thread block per kGdChunks chunks, so that the dense weight
+// matrix (100 KB for 256 x 100: three times the activations it multiplies) is fetched from L2 once per four chunks.
+// Threads first average their channel over the P positions, then 4 groups of 64 lanes each take a quarter of the
+// contraction for up to 64 x 4 outputs and the partial sums meet in LDS (reference: birdnet_stm32/models/dscnn.py:256-261).
+// Per chunk the operations and their order are those of the separate GAP and Dense kernels.
+constexpr int kGdChunks = 4;
 __global__ __launch_bounds__(256) void f32_gap_dense_kernel(const float* __restrict__ x, float* __restrict__ scores,
-                                                            float* __restrict__ logits, int P, int Cin, int Cout, int act,
+                                                            float* __restrict__ logits, int B, int P, int Cin, int Cout, int act,
                                                             const float* __restrict__ w, const float* __restrict__ bias) {
-    extern __shared__ float sm[];  // [Cin] pooled, [4][Cout] partial sums, [Cout] logits
+    extern __shared__ float sm[];  // [NC][Cin] pooled, [NC][4][Cout] partial sums, [NC][Cout] logits
     float* pooled = sm;
-    float* part = sm + Cin;
-    float* z = part + 4 * Cout;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < Cin; c += 256) {
-        const float* p = x + (size_t)b * P * Cin + c;
+    float* part = sm + kGdChunks * Cin;
+    float* z = part + kGdChunks * 4 * Cout;
+    const int b0 = blockIdx.x * kGdChunks, tid = threadIdx.x;
+    const int nc = B - b0 < kGdChunks ? B - b0 : kGdChunks;
+    for (int item = tid; item < nc * Cin; item += 256) {
+        const int cb = item / Cin, c = item - cb * Cin;
+        const float* p = x + (size_t)(b0 + cb) * P * Cin + c;
         float s = 0.0f;
-        for (int i = 0; i < P; ++i) s += p[(size_t)i * Cin];
-        pooled[c] = s / (float)P;
+#pragma unroll 16
+        for (int i = 0; i < P; ++i) s += p[(size_t)i * Cin];  // summed in position order; sixteen loads in flight
+        pooled[cb * Cin + c] = s / (float)P;
     }
+    for (int item = nc * Cin + tid; item < kGdChunks * Cin; item += 256) pooled[item] = 0.0f;  // chunks past the batch end
     __syncthreads();
     const int g = tid >> 6, lane = tid & 63;
     const int k0 = g * ((Cin + 3) / 4), k1 = min(Cin, k0 + (Cin + 3) / 4);
     for (int n = lane; n < Cout; n += 64) {
-        float s = 0.0f;
-        for (int k = k0; k < k1; ++k) s = fmaf(pooled[k], w[(size_t)k * Cout + n], s);
-        part[g * Cout + n] = s;
+        float s[kGdChunks];
+#pragma unroll
+        for (int cb = 0; cb < kGdChunks; ++cb) s[cb] = 0.0f;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            const float wk = w[(size_t)k * Cout + n];
+#pragma unroll
+            for (int cb = 0; cb < kGdChunks; ++cb) s[cb] = fmaf(pooled[cb * Cin + k], wk, s[cb]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < kGdChunks; ++cb) part[(cb * 4 + g) * Cout + n] = s[cb];
     }
     __syncthreads();
-    for (int n = tid; n < Cout; n += 256) {
+    for (int item = tid; item < nc * Cout; item += 256) {
+        const int cb = item / Cout, n = item - cb * Cout;
+        const float* pp = part + cb * 4 * Cout;
         // summed in contraction order, bias first, like the separate Dense kernel
-        const float v = (((((bias ? bias[n] : 0.0f) + part[n]) + part[Cout + n]) + part[2 * Cout + n]) + part[3 * Cout + n]);
-        z[n] = v;
-        if (logits) logits[(size_t)b * Cout + n] = v;
+        const float v = (((((bias ? bias[n] : 0.0f) + pp[n]) + pp[Cout + n]) + pp[2 * Cout + n]) + pp[3 * Cout + n]);
+        z[cb * Cout + n] = v;
+        if (logits) logits[(size_t)(b0 + cb) * Cout + n] = v;
     }
     __syncthreads();
-    if (act == 2) {
-        float mx = -3.4e38f;
-        for (int n = 0; n < Cout; ++n) mx = fmaxf(mx, z[n]);
-        float den = 0.0f;
-        for (int n = 0; n < Cout; ++n) den += expf(z[n] - mx);
-        for (int n = tid; n < Cout; n += 256) scores[(size_t)b * Cout + n] = expf(z[n] - mx) / den;
-    } else {
-        for (int n = tid; n < Cout; n += 256) scores[(size_t)b * Cout + n] = act == 1 ? 1.0f / (1.0f + expf(-z[n])) : z[n];
+    for (int item = tid; item < nc * Cout; item += 256) {
+        const int cb = item / Cout, n = item - cb * Cout;
+        const float* zz = z + cb * Cout;
+        float out;
+        if (act == 2) {
+            float mx = -3.4e38f;
+            for (int j = 0; j < Cout; ++j) mx = fmaxf(mx, zz[j]);
+            float den = 0.0f;
+            for (int j = 0; j < Cout; ++j) den += expf(zz[j] - mx);
+            out = expf(zz[n] - mx) / den;
+        } else {
+            out = act == 1 ? 1.0f / (1.0f + expf(-zz[n])) : zz[n];
+        }
+        scores[(size_t)(b0 + cb) * Cout + n] = out;
     }
 }
 
@@ -493,8 +516,8 @@ void launch_f32_dense(const float* x, float* scores, float* logits, int B, int C
 
 void launch_f32_gap_dense(const float* x, float* scores, float* logits, int B, int P, int Cin, int Cout, int act, const float* w,
                           const float* bias, hipStream_t s) {
-    hipLaunchKernelGGL(f32_gap_dense_kernel, dim3(B), dim3(256), (Cin + 5 * Cout) * sizeof(float), s, x, scores, logits, P, Cin,
-                       Cout, act, w, bias);
+    hipLaunchKernelGGL(f32_gap_dense_kernel, dim3((B + kGdChunks - 1) / kGdChunks), dim3(256),
+                       kGdChunks * (Cin + 5 * Cout) * sizeof(float), s, x, scores, logits, B, P, Cin, Cout, act, w, bias);
 }
 
 void launch_f32_attnpool(const float* x, float* y, int B, int P, int C, const float* score, hipStream_t s) {
