@@ -1,7 +1,7 @@
 """``python -m birdnet_stm32 <command>`` dispatcher (reference: birdnet_stm32/__main__.py:12-47).
 
-Only ``evaluate`` exists in this build; the reference's train / convert / deploy / board-test commands are
-outside the accelerated path and answer with a pointer to the reference package.
+``evaluate`` and ``convert`` (own post-training quantisation, no TensorFlow) exist in this build; the reference's train /
+deploy / board-test commands are outside the accelerated path and answer with a pointer to the reference package.
 """
 
 import sys
@@ -19,7 +19,11 @@ def main():
         from birdnet_stm32.cli.evaluate import main as run
 
         run()
-    elif command in ("train", "convert", "deploy", "board-test"):
+    elif command == "convert":
+        from birdnet_stm32.cli.convert import main as run
+
+        run()
+    elif command in ("train", "deploy", "board-test"):
         print(f"'{command}' is not part of the MI355X hot-path build; use the reference package for it.")
         sys.exit(2)
     else:

@@ -317,3 +317,61 @@ def load_tflite(path: str) -> TfliteModel:
     """Read and decode a `.tflite` file."""
     with open(path, "rb") as fh:
         return parse_tflite(fh.read())
+
+
+def patch_tflite(template_raw: bytes, new: TfliteModel) -> bytes:
+    """Write ``new`` as a `.tflite` file by overwriting the constant payloads and quantisation vectors of ``template_raw``.
+
+    ``new`` must have the template's structure (same tensors, shapes, dtypes, operators, per-tensor number of scales) —
+    what :func:`birdnet_stm32.conversion.quantize.requantize_like` produces.  Every changed value has a fixed-size slot in
+    the FlatBuffer (buffer bytes, ``scale`` float32 vector, ``zero_point`` int64 vector, ``quantized_dimension``), so no
+    general FlatBuffer writer is needed and everything else (operator codes, options, names, metadata) stays byte-identical.
+    """
+    if len(template_raw) < 8 or template_raw[4:8] != b"TFL3":
+        raise ValueError("not a TFLite flatbuffer (missing 'TFL3' identifier)")
+    out = bytearray(template_raw)
+    buf = _Buf(template_raw)
+    root = _Table(buf, buf.u32(0))
+    buffers = root.tables(4)
+    sg = root.tables(2)[0]
+    ttabs = sg.tables(0)
+    if len(ttabs) != len(new.tensors):
+        raise ValueError(f"template has {len(ttabs)} tensors, the model {len(new.tensors)}")
+
+    def put_vector(table: _Table, idx: int, arr: np.ndarray, what: str):
+        p = table._indirect(idx)
+        n = buf.u32(p) if p else 0
+        if n != arr.size:
+            raise ValueError(f"{what}: template holds {n} values, the model {arr.size}")
+        if n:
+            out[p + 4 : p + 4 + arr.nbytes] = arr.tobytes()
+
+    for tt, t in zip(ttabs, new.tensors):
+        shape = tuple(int(v) for v in tt.vector(0, np.int32))
+        if shape != tuple(t.shape) or _TENSOR_DTYPES.get(tt.scalar(1, "b", 0)) != t.dtype.type:
+            raise ValueError(f"tensor {t.index}: shape/dtype differ from the template")
+        q = tt.table(4)
+        if q is not None:
+            put_vector(q, 2, np.ascontiguousarray(t.scale, "<f4"), f"tensor {t.index} scale")
+            put_vector(q, 3, np.ascontiguousarray(t.zero_point, "<i8"), f"tensor {t.index} zero_point")
+            p = q.slot(6)
+            if p:
+                struct.pack_into("<i", out, p, int(t.quantized_dimension))
+            elif t.quantized_dimension != 0 and t.scale.size > 1:
+                raise ValueError(f"tensor {t.index}: template stores no quantized_dimension (default 0), the model needs {t.quantized_dimension}")
+        elif t.scale.size:
+            raise ValueError(f"tensor {t.index}: quantised in the model, not in the template")
+        bi = tt.scalar(2, "I", 0)
+        if t.data is None or bi <= 0 or bi >= len(buffers):
+            continue
+        payload = np.ascontiguousarray(t.data.astype(t.dtype.newbyteorder("<"), copy=False)).tobytes()
+        bt = buffers[bi]
+        p = bt._indirect(0)
+        if p:
+            n, at = buf.u32(p), p + 4
+        else:
+            at, n = bt.scalar(1, "Q", 0), bt.scalar(2, "Q", 0)
+        if n != len(payload):
+            raise ValueError(f"tensor {t.index}: buffer holds {n} bytes, the model {len(payload)}")
+        out[at : at + n] = payload
+    return bytes(out)
