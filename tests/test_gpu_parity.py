@@ -359,3 +359,40 @@ def test_f32_raw_frontend_config5_topology(torch_mod):
     with pytest.raises(ValueError, match="expected input of shape"):
         runner.predict(np.zeros((1, 72000, 1), np.float32))
     runner.close()
+
+
+@pytest.mark.parametrize(
+    "kw",
+    [
+        dict(num_mels=32, spec_width=128, sample_rate=16000, chunk_duration=2),
+        dict(num_mels=48, spec_width=192, sample_rate=22050, chunk_duration=3, alpha=0.75),
+        dict(num_mels=128, spec_width=256, sample_rate=24000, chunk_duration=3, use_se=False, use_inverted_residual=False),
+        dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, use_se=False, use_inverted_residual=False, depth_multiplier=2, alpha=1.25),
+    ],
+    ids=["32mel_w128_16k2s", "48mel_w192_alpha.75", "128mel_legacy", "legacy_deep_alpha1.25"],
+)
+def test_f32_other_geometries(torch_mod, kw):
+    """Mel counts, spectrogram widths, chunk lengths and widths other than the shipped 64 x 256 @ 3 s: maps whose tiles, strips and
+    K-slices differ (ragged tiles, the unfused stem, other K / N splits), fused and baseline plans, from spectrograms and from audio."""
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle import float_graph, stft
+
+    args = dict(embeddings_size=256, num_classes=10, randomize_bn=True, seed=5)
+    args.update(kw)
+    spec = build_model("dscnn", **args)
+    T = int(args["sample_rate"] * args["chunk_duration"])
+    rng = np.random.default_rng(0)
+    audio = (rng.standard_normal((3, T)) * 0.2 + np.sin(2 * np.pi * 900 * np.arange(T) / args["sample_rate"])).astype(np.float32)
+    audio /= np.abs(audio).max(axis=1, keepdims=True)
+    S = np.stack([stft.hybrid_spectrogram(a, 512, args["spec_width"]) for a in audio])[..., None]
+    ref = float_graph.forward(spec, S, np.float64)
+    for fuse in (True, False):
+        r = HipRunner(lower_f32(spec, fuse=fuse), max_batch=4)
+        got = r.predict(S)
+        from_audio = r.infer_audio_device(torch_mod.from_numpy(audio).cuda()).cpu().numpy()
+        r.close()
+        assert np.abs(got - ref).max() < 1e-5 and np.abs(from_audio - ref).max() < 1e-4
+        for b in range(3):
+            assert 1.0 - cosine(got[b], ref[b]) < 1e-6
