@@ -287,6 +287,51 @@ __global__ __launch_bounds__(256) void ingest_decimate_kernel(ResampleArgs a, co
     store_block_peak(a.partial + (size_t)f * gridDim.x + blockIdx.x, vmax, tid);
 }
 
+// Rational ratios with up <= 256 and one of the filter lengths scipy designs for the common rate pairs (HPP taps per phase).
+// Outputs j and j + up share their filter phase, so a thread that walks outputs at stride `up` (its input pointer advancing
+// by `down`) keeps its HPP coefficients in registers: the tap loop reads only the input tile from LDS — half the LDS traffic
+// of the generic kernel, which is what bounds it.  Lanes of a wave still cover consecutive outputs (coalesced stores).
+template <int FMT, int HPP>
+__global__ __launch_bounds__(256) void ingest_resample_phase_kernel(ResampleArgs a, const float* __restrict__ taps, float* __restrict__ mono) {
+    extern __shared__ float lds[];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const long in0 = a.in_off[f], n_in = a.in_off[f + 1] - in0;
+    const long out0 = a.out_off[f], n_out = a.out_off[f + 1] - out0;
+    const long n0 = (long)blockIdx.x * a.blk;
+    if (n0 >= n_out) return;
+    const int cnt = n_out - n0 < a.blk ? (int)(n_out - n0) : a.blk;
+    const int up = a.up, down = a.down;
+    const unsigned t_first = (unsigned)(n0 + a.n_pre_remove) * (unsigned)down;
+    const unsigned t_last = (unsigned)(n0 + cnt - 1 + a.n_pre_remove) * (unsigned)down;
+    const long k_lo = (long)(t_first / (unsigned)up) - (HPP - 1);
+    const int tile = (int)((long)(t_last / (unsigned)up) - k_lo) + 1;
+    fill_tile<FMT>(a.pcm, in0, k_lo, tile, n_in, a.ch, lds, tid);
+    const int streams = 256 / up;           // output streams per phase slot that fit the workgroup
+    const int slot = tid % up, stream = tid / up;
+    const bool active = stream < streams;
+    const int j0 = slot + stream * up;
+    const unsigned t0 = t_first + (unsigned)j0 * (unsigned)down;
+    const unsigned kmax0 = t0 / (unsigned)up;
+    const unsigned phase = t0 - kmax0 * (unsigned)up;
+    float h[HPP];
+#pragma unroll
+    for (int q = 0; q < HPP; ++q) h[q] = taps[phase * HPP + q];
+    __syncthreads();
+    float vmax = 0.0f;
+    if (active) {
+        const float* xp = lds + ((long)kmax0 - (HPP - 1) - k_lo);
+        const int xstep = streams * down, jstep = streams * up;
+        for (int j = j0; j < cnt; j += jstep, xp += xstep) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < HPP; ++q) acc = f_add(acc, f_mul(xp[q], h[q]));
+            mono[out0 + n0 + j] = acc;
+            vmax = fmaxf(vmax, fabsf(acc));
+        }
+    }
+    store_block_peak(a.partial + (size_t)f * gridDim.x + blockIdx.x, vmax, tid);
+}
+
 __global__ __launch_bounds__(256) void ingest_peak_kernel(const float* __restrict__ partial, const long* __restrict__ out_off,
                                                           int stride, int blk, float* __restrict__ peak) {
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -397,6 +442,20 @@ static void launch_resample_kernels(const ResampleArgs& a, int fmt, int n_files,
             default: BN_DECIMATE(3); break;
         }
 #undef BN_DECIMATE
+        return;
+    }
+    if (up > 1 && up <= 256 && (hpp == 21 || hpp == 29 || hpp == 39) && !getenv("BN_INGEST_GENERIC")) {
+#define BN_PHASE(F)                                                                                                   \
+    if (hpp == 21) hipLaunchKernelGGL((ingest_resample_phase_kernel<F, 21>), grid, dim3(256), smem, s, a, taps, mono);     \
+    else if (hpp == 29) hipLaunchKernelGGL((ingest_resample_phase_kernel<F, 29>), grid, dim3(256), smem, s, a, taps, mono); \
+    else hipLaunchKernelGGL((ingest_resample_phase_kernel<F, 39>), grid, dim3(256), smem, s, a, taps, mono)
+        switch (fmt) {
+            case 0: BN_PHASE(0); break;
+            case 1: BN_PHASE(1); break;
+            case 2: BN_PHASE(2); break;
+            default: BN_PHASE(3); break;
+        }
+#undef BN_PHASE
         return;
     }
     switch (fmt) {
