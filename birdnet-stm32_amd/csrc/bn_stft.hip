@@ -110,8 +110,12 @@ template <bool MEL_OUT>
 __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop,
                                                           int W, float* __restrict__ spec, float* minmax, MelOut mel,
                                                           int tiles_per_wg) {
+    // The magnitude tile [257][kFT + 1] (17.5 KB) re-uses the exchange buffer (34.8 KB): every lane takes its sixteen conjugate
+    // partners into registers, one workgroup barrier later the buffer is free.  35 KB instead of 52 KB of LDS = four
+    // workgroups per CU instead of three.
     __shared__ v2f xch[kFT][kFS];
-    __shared__ float mag[257][kFT + 1];
+    float (*mag)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(&xch[0][0]);
+    static_assert(sizeof(float) * 257 * (kFT + 1) <= sizeof(v2f) * kFT * kFS, "magnitude tile must fit the exchange buffer");
     __shared__ float red_min[4], red_max[4];
 
     const int b = blockIdx.y;
@@ -195,11 +199,15 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
         // split post-pass: X[k] = E - i W512^k O with E = Z[k] + conj Z[256-k], O = Z[k] - conj Z[256-k] (the 1/2 is in Z)
         const bool live = t < W;
         float tmin = __uint_as_float(0x7f800000u), tmax = 0.0f;
+        v2f partner[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) partner[k2] = xch[f][(256 - (j + 16 * k2)) & 255];
+        __syncthreads();  // all frames have their partners: the buffer becomes the magnitude tile
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             const int k = j + 16 * k2;
             const v2f z = a[fidx(k2)];
-            v2f pc = xch[f][(256 - k) & 255];
+            v2f pc = partner[k2];
             pc.y = -pc.y;  // conj
             const v2f e = z + pc, o = z - pc;
             const v2f tk = __builtin_elementwise_fma(tq, (v2f){kSin16[k2], kSin16[k2]}, tp * (v2f){kCos16[k2], kCos16[k2]});  // -i W512^k
