@@ -410,7 +410,7 @@ struct FrontArgs {
 };
 
 template <int RG, int CT>
-__global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
+__global__ __launch_bounds__(256, 4) void f32_front_kernel(FrontArgs a) {  // 4 waves per SIMD: without the bound the allocator takes 121 registers (3 waves)
     constexpr int TS = 17;            // stem patch edge for an 8x8 tile of a stride-2 depthwise
     constexpr int FH = 19, FW = 35;   // frontend patch: stem stride (1, 2), 3x3
     constexpr int C = 16;             // stem channels = contraction width of the pointwise
@@ -418,7 +418,9 @@ __global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
     constexpr int PF = (FH * FW + 255) / 256;  // patch elements per thread
     __shared__ float fe_t[FH][FW + 1];
     __shared__ __attribute__((aligned(16))) float stem_t[TS * TS][C];
-    __shared__ __attribute__((aligned(16))) float tile[64 * (NS + 4)];  // activation tile [64][C + 4], later the output tile
+    __shared__ __attribute__((aligned(16))) float tile[64 * (C + 4)];  // activation tile [64][C + 4]
+    float* otile = &stem_t[0][0];  // output tile [64][NS + 4]: the stem patch is dead once the depthwise stage has run (28.5 KB -> 5 workgroups per CU)
+    static_assert(64 * (NS + 4) <= TS * TS * C, "output tile must fit the stem patch");
     const int tid = threadIdx.x;
     // A workgroup walks `tpw` horizontally adjacent 8x8 tiles of one chunk.  The next tile's frontend patch (three floats per
     // thread) is fetched into registers while the current tile is computed, so only the first patch's HBM latency is exposed.
@@ -586,18 +588,17 @@ __global__ __launch_bounds__(256) void f32_front_kernel(FrontArgs a) {
                 for (int e = 0; e < 4; ++e) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[g][c], 0, 0, 0);
             }
         constexpr int SO = NS + 4;
-        __syncthreads();
 #pragma unroll
         for (int g = 0; g < RG; ++g)
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) tile[(row0 + 16 * g + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[g][c][reg];
+                for (int reg = 0; reg < 4; ++reg) otile[(row0 + 16 * g + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[g][c][reg];
         __syncthreads();
         for (int item = tid; item < 64 * Q4; item += 256) {
             const int p = item / Q4, c4 = item - p * Q4;
             const int oh = ty0 + (p >> 3), ow = tx0 + (p & 7);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + p * SO + 4 * c4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(otile + p * SO + 4 * c4);
             const float4 b = pwb;
             float4 o = make_float4(act_f(v[0] + b.x, a.pw_act), act_f(v[1] + b.y, a.pw_act), act_f(v[2] + b.z, a.pw_act),
                                    act_f(v[3] + b.w, a.pw_act));
@@ -633,7 +634,7 @@ void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, i
                 minmax, wsum, magp, mag, 1};
     static const int forced = getenv("BN_FRONT_TPW") ? atoi(getenv("BN_FRONT_TPW")) : 0;
     const int tiles_x = OW / 8;
-    int tpw = forced > 0 ? forced : 4;
+    int tpw = forced > 0 ? forced : 8;
     while (tiles_x % tpw) --tpw;
     a.tpw = tpw;
     const int tiles = (OH / 8) * tiles_x * B;
