@@ -41,12 +41,18 @@ __device__ __forceinline__ int32_t add_q(int32_t a, int32_t b, const AddQ& q) {
     return clampi(mbqm(sa + sb, q.mo, q.so) + q.zo, q.amin, q.amax);
 }
 
-// QUANTIZE + TRANSPOSE + zero-pad: spec f32 [F][W] -> int8 [W][Kp].  64x64 tile through LDS so that
-// both the float loads (along t) and the byte stores (along f) are contiguous.
+// QUANTIZE + TRANSPOSE + zero-pad: spec f32 [F][W] -> int8 [W][Kp].  64x64 tile through LDS so that both sides move whole
+// dwords: float4 loads along t (four frequency rows per wave-instruction), dword stores along f (four frames per
+// wave-instruction) — byte-wide global stores were the bottleneck of the first version.
+__device__ __forceinline__ int quant_one(float v, bool renorm, float mn, float rng, float scale, int zp) {
+    if (renorm) v = (v - mn) / rng;
+    return clampi((int32_t)roundf(v / scale) + zp, -128, 127);  // roundf: halves away from zero
+}
+
 __global__ __launch_bounds__(256) void i8_quant_kernel(const float* __restrict__ spec, const float* __restrict__ minmax,
                                                        int8_t* __restrict__ out, int F, int W, int Kp, int zp,
                                                        int fill, float scale) {
-    __shared__ int8_t tile[64][68];
+    __shared__ __attribute__((aligned(4))) int8_t tile[64][68];  // [t][f], row stride 17 dwords
     const int b = blockIdx.z;
     const int f0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
     const float* S = spec + (size_t)b * F * W;
@@ -56,21 +62,40 @@ __global__ __launch_bounds__(256) void i8_quant_kernel(const float* __restrict__
         mn = minmax[2 * b];
         rng = (float)((double)(minmax[2 * b + 1] - mn) + 1e-10);
     }
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {
-        const int f = f0 + r, t = t0 + tx;
-        int q = fill;  // padded frequency columns: the graph's FILL constant (the zero point = real 0.0)
-        if (f < F && t < W) {
-            float v = S[(size_t)f * W + t];
-            if (renorm) v = (v - mn) / rng;
-            q = clampi((int32_t)roundf(v / scale) + zp, -128, 127);  // roundf: halves away from zero
+    const int c4 = threadIdx.x & 15, r4 = threadIdx.x >> 4;
+    const bool vec = (W & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r4 + 16 * i, f = f0 + r, t = t0 + 4 * c4;
+        int q[4] = {fill, fill, fill, fill};  // padded frequency columns: the graph's FILL constant (the zero point = real 0.0)
+        if (f < F) {
+            if (vec && t + 3 < W) {
+                const float4 v = *reinterpret_cast<const float4*>(S + (size_t)f * W + t);
+                q[0] = quant_one(v.x, renorm, mn, rng, scale, zp);
+                q[1] = quant_one(v.y, renorm, mn, rng, scale, zp);
+                q[2] = quant_one(v.z, renorm, mn, rng, scale, zp);
+                q[3] = quant_one(v.w, renorm, mn, rng, scale, zp);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + e < W) q[e] = quant_one(S[(size_t)f * W + t + e], renorm, mn, rng, scale, zp);
+            }
         }
-        tile[tx][r] = (int8_t)q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[4 * c4 + e][r] = (int8_t)q[e];
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int t = t0 + r, f = f0 + tx;
-        if (t < W && f < Kp) out[((size_t)b * W + t) * Kp + f] = tile[r][tx];
+    const bool dword_rows = (Kp & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r4 + 16 * i, t = t0 + r, f = f0 + 4 * c4;
+        if (t >= W || f >= Kp) continue;
+        int8_t* dst = out + ((size_t)b * W + t) * Kp + f;
+        if (dword_rows && f + 3 < Kp) {
+            *reinterpret_cast<int*>(dst) = *reinterpret_cast<const int*>(&tile[r][4 * c4]);
+        } else {
+            for (int e = 0; e < 4 && f + e < Kp; ++e) dst[e] = tile[r][4 * c4 + e];
+        }
     }
 }
 
