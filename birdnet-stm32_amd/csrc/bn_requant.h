@@ -6,7 +6,7 @@
 // accumulator of the supported graphs: |x| <= K * 127 * 255 + |bias|, and (q - zp) << 20 < 2^28 in ADD):
 //   SRDHM: trunc((x*M0 + nudge) / 2^31), nudge = 2^30 for x*M0 >= 0 and 1 - 2^30 otherwise, equals the ARITHMETIC shift
 //          (x*M0 + 2^30) >> 31 for both signs (for negatives trunc(y/2^31) = floor((y + 2^31 - 1)/2^31) and the nudges differ
-//          by exactly 2^31 - 1), i.e. one 32x32 -> 64 multiply, an add with carry and a funnel shift;
+//          by exactly 2^31 - 1), i.e. one 32x32+64 -> 64 multiply-add (v_mad_i64_i32) and a funnel shift;
 //   RoundingDivideByPOT(v, e): (v >> e) + ((v & mask) > (mask >> 1) + (v < 0)) equals (v + half + (v < 0 ? -1 : 0)) >> e
 //          with half = 2^(e-1) (and v itself for e = 0).
 // Left shifts (shift > 0) and negative multipliers take the literal reference path.
@@ -36,11 +36,8 @@ __device__ __forceinline__ int32_t mbqm_ref(int32_t x, int32_t mult, int shift) 
 }
 
 __device__ __forceinline__ int32_t srdhm_pos(int32_t x, int32_t m) {  // m >= 0
-    const int32_t hi = __mulhi(x, m);
-    const uint32_t lo = (uint32_t)x * (uint32_t)m;
-    const uint32_t lo2 = lo + 0x40000000u;
-    const int32_t hi2 = hi + (lo2 < lo ? 1 : 0);
-    return (int32_t)(((uint32_t)hi2 << 1) | (lo2 >> 31));
+    // (x*m + 2^30) >> 31 on the 64-bit product: one v_mad_i64_i32 and one v_alignbit_b32
+    return (int32_t)(((int64_t)x * (int64_t)m + (1ll << 30)) >> 31);
 }
 __device__ __forceinline__ int32_t rdivpot_fast(int32_t v, int e) {  // e >= 0
     const int32_t half = e ? (1 << (e - 1)) : 0;  // e up to 31 occurs (dead channels with vanishing scales)
