@@ -124,6 +124,28 @@ def test_ingest_other_sample_formats_and_channel_counts(ctx, fmt):
         assert np.array_equal(chunks.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+def test_ingest_interleaved_groups_share_one_output_buffer(ctx):
+    """Windows of different (format, channels, rate) interleaved in one call: each group launches over its own runs of the
+    shared mono / peak buffers, and the chunk gather sees them in the caller's order."""
+    from birdnet_stm32.audio import ingest
+    from oracle import ingest as oi
+
+    rng = np.random.default_rng(17)
+    spec = [(44100, 2, 3.3), (48000, 1, 4.1), (44100, 2, 0.7), (24000, 2, 6.2), (48000, 1, 3.0), (44100, 2, 9.9), (44100, 1, 2.2)]
+    pcm = [_pcm16(rng, int(sr * secs), ch) for sr, ch, secs in spec]
+    wins = [ingest.window_from_int16(p, sr) for p, (sr, ch, secs) in zip(pcm, spec)]
+    wins.insert(3, ingest.window_from_frames(np.zeros((0, 1), np.float32), 32000))  # an empty window in the middle
+    chunks, counts = ingest.ingest_windows_device(ctx, wins, 24000, 3.0, 1.0)
+    chunks = chunks.cpu().numpy()
+    assert counts[3] == 0
+    at = 0
+    for p, (sr, ch, secs), c in zip(pcm, spec, counts[:3] + counts[4:]):
+        want = oi.split_chunks(oi.ingest_window(p.astype(np.float32) / 32768.0, sr, 24000), 24000, 3.0, 1.0)
+        assert c == want.shape[0] and np.array_equal(chunks[at : at + c].view(np.uint32), want.view(np.uint32)), (sr, ch, secs)
+        at += c
+    assert at == chunks.shape[0]
+
+
 def test_ingest_edge_cases(ctx):
     from birdnet_stm32.audio import ingest
 
