@@ -27,7 +27,7 @@ EXPORTS = (
     "bn_version", "bn_last_error", "bn_device_count", "bn_ctx_create", "bn_ctx_destroy", "bn_model_load",
     "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
     "bn_kernel_names", "bn_profile_enable", "bn_profile_collect", "bn_ingest_resample", "bn_ingest_chunks",
-    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only",
+    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize",
 )  # fmt: skip
 
 
@@ -80,6 +80,7 @@ def load_library(path: str | None = None):
     lib.bn_kernel_names.restype = c_char_p
     lib.bn_profile_enable.argtypes = [c_void_p, c_int]
     lib.bn_profile_only.argtypes = [c_void_p, c_int]
+    lib.bn_chunk_peak_normalize.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]
     lib.bn_profile_collect.argtypes = [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int]
     lib.bn_ingest_resample.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                        c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]

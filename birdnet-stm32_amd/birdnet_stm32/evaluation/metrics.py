@@ -143,9 +143,9 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
     rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss if profile_memory else 0
 
     if device_pipeline is None:
-        device_pipeline = (frontend in ("hybrid", "librosa", "log_mel", "mfcc") and hasattr(model_runner, "infer_audio_device")
+        device_pipeline = (frontend in ("hybrid", "raw", "librosa", "log_mel", "mfcc") and hasattr(model_runner, "infer_audio_device")
                            and spectrogram_fn is None)
-    if device_pipeline and frontend != "hybrid":
+    if device_pipeline and frontend not in ("hybrid", "raw"):
         model_runner.configure_precomputed(frontend, int(cfg["sample_rate"]), mag_scale, n_fft, int(cfg["num_mels"]), int(cfg.get("n_mfcc", 20)))
     if device_pipeline:
         if pooling.lower() not in ("avg", "mean", "average", "max", "lme", "log_mean_exp", "log_mean_exponential"):

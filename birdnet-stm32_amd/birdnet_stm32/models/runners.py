@@ -141,6 +141,18 @@ class HipRunner:
             if out is not None:
                 out.copy_(res[0] if return_logits else res)
             return res
+        if self.input_kind == pk.INPUT_WAVEFORM:
+            # raw frontend: the model input is the chunk divided by (its peak + 1e-6) (reference: evaluation/metrics.py:62-69)
+            if audio.shape[1] != self.input_elems:
+                raise ValueError(f"raw-frontend model expects {self.input_elems} samples per chunk, got {audio.shape[1]}")
+            x = torch.empty_like(audio)
+            with torch.cuda.device(self.device):
+                _hip.check(self.lib.bn_chunk_peak_normalize(self.ctx.handle, audio.data_ptr(), audio.shape[0], audio.shape[1], 1e-6,
+                                                            x.data_ptr(), self._stream()))
+            res = self.predict_device(x, return_logits=return_logits)
+            if out is not None:
+                out.copy_(res[0] if return_logits else res)
+            return res
         B, T = audio.shape
         hop = int(hop) if hop is not None else T // self.spec_width
         scores = out if out is not None else torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)

@@ -697,6 +697,20 @@ int bn_ingest_chunks(bn_ctx* ctx, const float* d_mono, const float* d_peak, cons
     return BN_OK;
 }
 
+int bn_chunk_peak_normalize(bn_ctx* ctx, const float* d_x, int B, int T, float eps, float* d_y, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (B < 0 || T <= 0) return fail(BN_ERR_ARG, "bad shape B=%d T=%d", B, T);
+    if (B == 0) return BN_OK;
+    if (!d_x || !d_y) return fail(BN_ERR_ARG, "null device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
+        const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+        bn::launch_chunk_peaknorm(d_x + (size_t)b0 * T, d_y + (size_t)b0 * T, nb, T, eps, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
 int bn_pool_scores(bn_ctx* ctx, const float* d_scores, const int64_t* d_file_off, int n_files, int n_classes, int method,
                    float beta, float* d_pooled, void* stream) {
     if (int rc = check_device(ctx)) return rc;
@@ -760,7 +774,7 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
 }
 
 const char* bn_kernel_names(void) {
-    return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
+    return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";

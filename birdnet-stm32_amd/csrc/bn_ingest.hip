@@ -373,6 +373,23 @@ __global__ __launch_bounds__(256) void ingest_chunks_kernel(const float* __restr
     }
 }
 
+// Per-chunk peak normalisation of the raw frontend's input: x / (max|x| + eps) in float32 (reference:
+// evaluation/metrics.py:62-69, conversion/quantize.py:96-98).  One workgroup per chunk, two passes over 288 KB (the second
+// one hits L2).
+__global__ __launch_bounds__(256) void chunk_peaknorm_kernel(const float* x, float* y, int T, float eps) {  // x and y may be the same buffer
+    const float* src = x + (size_t)blockIdx.x * T;
+    float* dst = y + (size_t)blockIdx.x * T;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < T; i += 256) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float denom = f_add(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])), eps);
+    for (int i = threadIdx.x; i < T; i += 256) dst[i] = f_div(src[i], denom);
+}
+
 // One thread per (file, class): rows of one file are read in order, so the float32 sums match numpy's axis-0 reduction.
 __global__ __launch_bounds__(256) void pool_scores_kernel(const float* __restrict__ scores, const long* __restrict__ seg,
                                                           int F, int C, int method, float beta, float* __restrict__ out) {
@@ -484,6 +501,10 @@ void launch_ingest_chunks(const float* mono, const float* peak, const long* src,
                           int n_chunks, int T, float* out, hipStream_t s) {
     const dim3 grid((unsigned)((T + 1023) / 1024), (unsigned)n_chunks);
     hipLaunchKernelGGL(ingest_chunks_kernel, grid, dim3(256), 0, s, mono, peak, src, valid, file, T, out);
+}
+
+void launch_chunk_peaknorm(const float* x, float* y, int B, int T, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(chunk_peaknorm_kernel, dim3(B), dim3(256), 0, s, x, y, T, eps);
 }
 
 void launch_pool_scores(const float* scores, const long* seg, int F, int C, int method, float beta, float* out,

@@ -42,6 +42,7 @@ void launch_ingest_resample(const void* pcm, int fmt, int ch, const long* in_off
                             float* partial, float* peak, hipStream_t s);
 void launch_ingest_chunks(const float* mono, const float* peak, const long* src, const int* valid, const int* file,
                           int n_chunks, int T, float* out, hipStream_t s);
+void launch_chunk_peaknorm(const float* x, float* y, int B, int T, float eps, hipStream_t s);
 void launch_pool_scores(const float* scores, const long* seg, int F, int C, int method, float beta, float* out,
                         hipStream_t s);
 

@@ -164,6 +164,10 @@ BN_API int bn_ingest_chunks(bn_ctx* ctx, const float* d_mono, const float* d_pea
                      const int32_t* d_chunk_valid, const int32_t* d_chunk_window, int n_chunks, int chunk_len,
                      float* d_chunks, void* stream);
 
+/* Per-chunk peak normalisation y = x / (max|x| + eps) of the raw frontend's model input (reference:
+ * birdnet_stm32/evaluation/metrics.py:62-69, with eps = 1e-6): d_x, d_y [B, T] float32 (may alias). */
+BN_API int bn_chunk_peak_normalize(bn_ctx* ctx, const float* d_x, int B, int T, float eps, float* d_y, void* stream);
+
 /* pooling methods of bn_pool_scores (reference names: 'avg'|'mean'|'average', 'max', 'lme'|'log_mean_exp'|...) */
 #define BN_POOL_AVG 0
 #define BN_POOL_MAX 1

@@ -348,3 +348,39 @@ def test_evaluate_librosa_frontend_device_pipeline_matches_reference_loop(tmp_pa
     assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
     assert np.array_equal(ys_dev, ys_ref)  # same kernels either way; only the orchestration differs
     runner.close()
+
+
+def test_evaluate_raw_frontend_device_pipeline(tmp_path):
+    """evaluate() for a raw-frontend model (BASELINE configs[4] topology, 24 kHz x 2 s): device ingest -> per-chunk peak
+    normalisation (bn_chunk_peak_normalize) -> network -> pooling on the GPU == the reference-style per-file loop, bit for bit."""
+    import torch
+
+    from birdnet_stm32.audio.io import save_wav
+    from birdnet_stm32.evaluation.metrics import evaluate
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from conftest import synth_chunks
+
+    classes = [f"sp{i}" for i in range(5)]
+    cfg = dict(sample_rate=24000, chunk_duration=2, num_mels=64, spec_width=256, fft_length=512, audio_frontend="raw", mag_scale="pcen")
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=5,
+                       audio_frontend="raw", mag_scale="pcen", alpha=0.5, class_activation="sigmoid", randomize_bn=True, seed=4)
+    x = synth_chunks(6, seed=2)
+    files = []
+    for i in range(6):
+        d = tmp_path / classes[i % 5]
+        d.mkdir(exist_ok=True)
+        save_wav(np.concatenate([x[i], x[(i + 1) % 6]])[: 48000 * (1 + i % 3) + 1234], str(d / f"f{i}.wav"), 24000)
+        files.append(str(d / f"f{i}.wav"))
+    runner = HipRunner(lower_f32(spec), max_batch=8)
+    # the kernel itself: y = x / (max|x| + 1e-6) in float32, exactly numpy's result
+    a = torch.from_numpy(x[:, :48000].copy()).cuda()
+    got = runner.infer_audio_device(a).cpu().numpy()
+    xn = (x[:, :48000] / (np.abs(x[:, :48000]).max(axis=1, keepdims=True) + 1e-6)).astype(np.float32)
+    assert np.array_equal(got, runner.predict(xn[..., None]))
+    _, pf_dev, _, ys_dev = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=8)
+    _, pf_ref, _, ys_ref = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=8, device_pipeline=False)
+    assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
+    assert np.array_equal(ys_dev, ys_ref)
+    runner.close()
