@@ -88,6 +88,9 @@ def pack_pw_fragments(w: np.ndarray) -> np.ndarray:
     """``[Cin][Cout]`` -> ``[Cin/16][Cout/16][64 lanes][4]``: lane (q = l >> 4, c = l & 15) of k-step j holds
     ``W[16 j + 4 q + e][16 ct + c]`` for e = 0..3 — the B operands of four consecutive ``mfma_f32_16x16x4``."""
     cin, cout = w.shape
+    if cin % 16:  # zero rows up to a whole number of k-steps (the kernel zero-fills the matching tile columns)
+        w = np.concatenate([w, np.zeros((-cin % 16, cout), w.dtype)], axis=0)
+        cin = w.shape[0]
     t = w.reshape(cin // 16, 4, 4, cout // 16, 16)  # [j][q][e][ct][c]
     return np.ascontiguousarray(t.transpose(0, 3, 1, 4, 2)).reshape(cin // 16, cout // 16, 64, 4).astype(np.float32)
 
@@ -321,7 +324,7 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
                     x_val, gate_val = val[src], None
                 v = pb.value(P * Cout * 4)
                 tile = pick_tile(H, Wd)
-                if fuse and tile is not None and Cin % 16 == 0 and Cout % 16 == 0:
+                if fuse and tile is not None and Cin % 4 == 0 and Cout % 16 == 0:
                     p = [H, Wd, Cin, 1, 1, 0, H, Wd, 0, 0, Cout, pk.ACT_CODES[act], int(res is not None), int(gate_val is not None),
                          gate_val if gate_val is not None else 0, 0, *tile]
                     zero = pb.tensor(np.zeros(4, np.float32), np.float32)

@@ -191,7 +191,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 a.B = B; a.H = p[0]; a.W = p[1]; a.Cin = p[2]; a.sh = p[3]; a.sw = p[4]; a.dw_act = p[5];
                 a.OH = p[6]; a.OW = p[7]; a.pt = p[8]; a.pl = p[9]; a.Cout = p[10]; a.pw_act = p[11];
                 a.has_dw = p[15]; a.TH = p[16]; a.TW = p[17]; a.NB = p[18];
-                if (!bn::f32_dwpw_supported(a.Cin, a.Cout) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
+                if (!bn::f32_dwpw_supported(a.Cin, a.Cout) || (a.has_dw && a.Cin % 16) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported fused block geometry", oi);
                 bn::launch_f32_dwpw(a, s);
                 break;

@@ -286,27 +286,56 @@ __global__ void f32_gap_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
-// squeeze-excite gate: mean over positions -> Dense(Cr, relu) -> Dense(C, sigmoid); one block per chunk
-__global__ void f32_segate_kernel(const float* __restrict__ x, float* __restrict__ gate, int P, int C, int Cr,
-                                  const float* __restrict__ w1, const float* __restrict__ w2) {
-    extern __shared__ float sm[];  // [C] means, [Cr] hidden
+// squeeze-excite gate: mean over positions -> Dense(Cr, relu) -> Dense(C, sigmoid); one 256-thread block per chunk.
+// The pooling is the whole cost (the block reads its chunk's [P][C] activation once): all 256 threads take part — thread
+// (g, cq) adds the float4 channel quad cq of positions g, g + G, ... (G = 256 / (C/4) position groups, eight loads in
+// flight), the G partial sums are then added in group order.  (The first version used one thread per channel: 48 of 256.)
+__global__ __launch_bounds__(256) void f32_segate_kernel(const float* __restrict__ x, float* __restrict__ gate, int P, int C, int Cr,
+                                                         const float* __restrict__ w1, const float* __restrict__ w2) {
+    extern __shared__ float sm[];  // [C] means, [Cr] hidden, [G][C] partial sums
     float* mean = sm;
     float* hid = sm + C;
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float* p = x + (size_t)b * P * C + c;
-        float s = 0.0f;
-        for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
-        mean[c] = s / (float)P;
+    float* part = hid + Cr;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Cq = C >> 2;
+    if ((C & 3) == 0 && Cq <= 256) {
+        const int G = 256 / Cq;
+        const int g = tid / Cq, cq = tid - g * Cq;
+        if (g < G) {
+            const float4* p = reinterpret_cast<const float4*>(x + (size_t)b * P * C) + cq;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int i = g; i < P; i += G) {
+                const float4 v = p[(size_t)i * Cq];
+                s.x += v.x;
+                s.y += v.y;
+                s.z += v.z;
+                s.w += v.w;
+            }
+            *reinterpret_cast<float4*>(part + g * C + 4 * cq) = s;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.0f;
+            for (int k = 0; k < G; ++k) s += part[k * C + c];
+            mean[c] = s / (float)P;
+        }
+    } else {
+        for (int c = tid; c < C; c += 256) {
+            const float* p = x + (size_t)b * P * C + c;
+            float s = 0.0f;
+            for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
+            mean[c] = s / (float)P;
+        }
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < Cr; r += blockDim.x) {
+    for (int r = tid; r < Cr; r += 256) {
         float s = 0.0f;
         for (int c = 0; c < C; ++c) s = fmaf(mean[c], w1[c * Cr + r], s);
         hid[r] = fmaxf(s, 0.0f);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c = tid; c < C; c += 256) {
         float s = 0.0f;
         for (int r = 0; r < Cr; ++r) s = fmaf(hid[r], w2[r * C + c], s);
         gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
@@ -496,7 +525,8 @@ void launch_f32_pw(const float* x, const float* res, const float* gate, float* y
 
 void launch_f32_segate(const float* x, float* gate, int B, int P, int C, int Cr, const float* w1, const float* w2,
                        hipStream_t s) {
-    hipLaunchKernelGGL(f32_segate_kernel, dim3(B), dim3(256), (C + Cr) * sizeof(float), s, x, gate, P, C, Cr, w1, w2);
+    const int groups = (C & 3) == 0 && C / 4 <= 256 ? 256 / (C / 4) : 0;
+    hipLaunchKernelGGL(f32_segate_kernel, dim3(B), dim3(256), (C + Cr + (size_t)groups * C) * sizeof(float), s, x, gate, P, C, Cr, w1, w2);
 }
 
 void launch_f32_scale(const float* x, const float* gate, float* y, int B, int P, int C, hipStream_t s) {

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
     for (int k0 = 0; k0 < K; k0 += kKC) {
         const int kc = (K - k0) < kKC ? (K - k0) : kKC;
         const int kq = kc >> 2;   // float4 groups per position
-        const int S4 = kq + 1;    // row stride of the tile in float4 units (one float4 of padding)
+        const int kcp = (kc + 15) & ~15;  // whole matrix-core k-steps; columns kc..kcp-1 are zero and meet zero weight rows (1x1 convs with Cin % 16 != 0)
+        const int S4 = (kcp >> 2) + 1;    // row stride of the tile in float4 units (one float4 of padding)
         if (k0) __syncthreads();  // the previous slice's fragments have been read
 
         // ---- phase 1: fill the LDS tile [64][kc] ---------------------------------------------------------
@@ -179,10 +180,14 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
             }
             lds4[p * S4 + cq] = (f32x4){accv.x, accv.y, accv.z, accv.w};
         }
+        if (kcp != kc) {
+            const int padq = (kcp - kc) >> 2;
+            for (int item = tid; item < 64 * padq; item += 256) lds4[(item / padq) * S4 + kq + item % padq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();
 
         // ---- phase 2: [64 x kc] x [kc x N] on the matrix cores, B fragments one k-step ahead -------------
-        const int ksteps = kc >> 4, j0 = k0 >> 4;
+        const int ksteps = kcp >> 4, j0 = k0 >> 4;
         f32x4 bf[CT], bnext[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) bf[c] = wp[((size_t)j0 * n_ct + ct0 + c) * 64 + lane];
@@ -611,7 +616,7 @@ template <int RG, int CT>
 void launch_cfg(const DwPwArgs& a, hipStream_t s) {
     const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * ((a.B + a.NB - 1) / a.NB);
     const int slices = (a.Cout / 16) / (RG * CT);
-    const int kc = a.Cin < kKC ? a.Cin : kKC, ns = RG * CT * 16;
+    const int kc = ((a.Cin < kKC ? a.Cin : kKC) + 15) & ~15, ns = RG * CT * 16;
     const size_t smem = (size_t)64 * ((kc > ns ? kc : ns) + 4) * sizeof(float);
     if (a.has_dw)
         hipLaunchKernelGGL((f32_dwpw_kernel<RG, CT, true>), dim3(tiles, slices), dim3(256), smem, s, a);
@@ -641,7 +646,7 @@ void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, i
     hipLaunchKernelGGL((f32_front_kernel<2, 1>), dim3(tiles / tpw, 1), dim3(256), 0, s, a);
 }
 
-bool f32_dwpw_supported(int Cin, int Cout) { return Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 16 && Cin <= 2048; }
+bool f32_dwpw_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 16 == 0 && Cin >= 4 && Cin <= 2048; }  // Cin % 16 != 0 only without the depthwise stage
 
 // Each workgroup covers RG*CT column tiles of 16 (4 waves = (4/RG) along the 64 rows x RG along the columns);
 // wider layers are cut into column slices (grid.y), each recomputing the cheap depthwise stage.
