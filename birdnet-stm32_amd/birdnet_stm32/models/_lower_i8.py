@@ -99,6 +99,80 @@ def pack_i8_fragments(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(t.transpose(2, 0, 3, 1, 4)).reshape(kp // 64, cout // 16, 64, 16)
 
 
+STRIP_MAX_SHIFT = 22  # c1 = 2^(e-1) + (zp << e) and the rounded product must stay inside int32
+
+
+def _strip_requant(mult, shift, zp: int, acc_lo, acc_hi) -> tuple[np.ndarray, np.ndarray, np.ndarray] | None:
+    """Per-channel (multiplier, c1, e) of the strip kernel's requantisation ``((v + c1 + (v >> 31)) >> e)`` with
+    ``v = (x * multiplier + 2^30) >> 31`` — ``RoundingDivideByPOT(SRDHM(x, M0), e) + zp`` with the rounding offset and the
+    zero point in one addend.  ``[acc_lo[c], acc_hi[c]]`` contains every accumulator the channel can see.  Channels whose
+    shift exceeds ``STRIP_MAX_SHIFT`` are dead (vanishing weight scale, the bias is all that is left): requantisation is
+    monotone in x, so when both ends of the range give the same value the channel is constant and is rewritten as
+    (multiplier 0, e = 1, c1 = 1 + 2 (value + zp)), which produces exactly that.  ``None`` = not expressible (left shifts,
+    negative multipliers, a dead channel that is not constant)."""
+    m = np.asarray(mult, np.int64).copy()
+    sh = np.asarray(shift, np.int64)
+    e = -sh
+    lo, hi = np.asarray(acc_lo, np.int64), np.asarray(acc_hi, np.int64)
+    if (m < 0).any() or (e < 1).any():
+        return None
+    c1 = (np.int64(1) << (e - 1)) + (np.int64(zp) << e)
+    for c in np.nonzero(e > STRIP_MAX_SHIFT)[0]:
+        q_lo, q_hi = (int(qz.requantize(np.array([v]), m[c], sh[c])[0]) for v in (lo[c], hi[c]))
+        if q_lo != q_hi:
+            return None
+        m[c], e[c], c1[c] = 0, 1, 1 + 2 * (q_lo + zp)
+    if (np.maximum(np.abs(lo), np.abs(hi))[m != 0] >= 2**30).any():  # |v| <= |x| and |c1| < 2^30 must add inside int32
+        return None
+    return m.astype(np.int32), c1.astype(np.int32), e.astype(np.int32)
+
+
+def strip_constants(wd, bdw, mu, sh, z_dw_out, w2, b2, mu2, sh2, z_pw_out, add: bool) -> np.ndarray | None:
+    """Constant block of ``i8_strip_kernel`` (csrc/bn_i8_strip.hip) for one DW 3x3 -> PW 1x1 [-> ADD] block, int32 words:
+
+    lane (n, kq) of a wave holds the CL = Cin/4 channels ``CL kq ..`` of column n (QL = CL/4 quads) and ends up with the
+    COL = Cout/4 output channels ``COL kq ..``.  Sections: depthwise weights ``[kq][ql][row][e]`` as bytes (tap0, tap1,
+    tap2, 0) of channel ``CL kq + 4 ql + e``; folded depthwise bias ``[kq][ql][e]``; depthwise (multiplier, c1, e)
+    ``[kq][ql][3][e]``; pointwise A fragments ``[t][lane][QL]`` = ``W[COL (m >> 2) + 4 t + (m & 3)][CL kq : CL kq + CL]``
+    for lane (m, kq); folded pointwise bias ``[q][t][reg]`` for channel ``COL q + 4 t + reg``; pointwise (multiplier, c1, e)
+    ``[q][t][3][reg]``.  With the ADD the block's own value is produced + 128 (it indexes a table).  ``None`` if the block's
+    requantisation cannot take the kernel's form."""
+    wd = np.asarray(wd, np.int8)  # [3][3][C]
+    C, (N, K) = wd.shape[2], w2.shape
+    if K != C or C not in (32, 64) or N not in (32, 64):
+        return None
+    CL, COL = C // 4, N // 4
+    QL, NT = CL // 4, N // 16
+    # accumulator ranges over every int8 input (the folded biases already hold -zp * sum(w); padded taps read zp)
+    wd64, w264 = wd.astype(np.int64), np.asarray(w2, np.int64)
+    lo_dw = np.minimum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(bdw, np.int64)
+    hi_dw = np.maximum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(bdw, np.int64)
+    lo_pw = np.minimum(-128 * w264, 127 * w264).sum(axis=1) + np.asarray(b2, np.int64)
+    hi_pw = np.maximum(-128 * w264, 127 * w264).sum(axis=1) + np.asarray(b2, np.int64)
+    rq_dw = _strip_requant(mu, sh, z_dw_out, lo_dw, hi_dw)
+    rq_pw = _strip_requant(mu2, sh2, z_pw_out + (128 if add else 0), lo_pw, hi_pw)
+    if rq_dw is None or rq_pw is None:
+        return None
+    ch_in = (CL * np.arange(4)[:, None, None] + 4 * np.arange(QL)[None, :, None] + np.arange(4)[None, None, :])  # [kq][ql][e]
+    dww = np.zeros((4, QL, 3, 4, 4), np.uint8)  # [...][row][e][byte]
+    for i in range(3):
+        for j in range(3):
+            dww[:, :, i, :, j] = wd[i, j][ch_in].view(np.uint8)
+    sec = [dww.view(np.int32).reshape(-1), np.asarray(bdw, np.int32)[ch_in].reshape(-1),
+           np.stack([r[ch_in] for r in rq_dw], axis=2).reshape(-1)]  # [kq][ql][3][e]
+    lane = np.arange(64)
+    m_, kq_ = lane & 15, lane >> 4
+    pwa = np.zeros((NT, 64, CL), np.int8)
+    for t in range(NT):
+        ch = COL * (m_ >> 2) + 4 * t + (m_ & 3)
+        for k in range(CL):
+            pwa[t, :, k] = w2[ch, CL * kq_ + k]
+    ch_out = (COL * np.arange(4)[:, None, None] + 4 * np.arange(NT)[None, :, None] + np.arange(4)[None, None, :])  # [q][t][reg]
+    sec += [pwa.view(np.int32).reshape(-1), np.asarray(b2, np.int32)[ch_out].reshape(-1),
+            np.stack([r[ch_out] for r in rq_pw], axis=2).reshape(-1)]
+    return np.concatenate(sec).astype(np.int32)
+
+
 def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse; ``fuse=False`` keeps the
     baseline one-kernel-per-operator plan instead of the fused matrix-core blocks."""
@@ -293,10 +367,19 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                     out_t = nn.outputs[0]
                     i += 1
                 v = pb.value(OH * OW * Cout)
-                p = [H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi, Cout, zo2, lo2, hi2, *add_p, 1, 0, *tile, 0]
+                # wide early layers: constant block of the wave-autonomous strip kernel (the residual must be the block input,
+                # every per-channel requantisation and the ADD's output one a right shift; tap column 1 never in the padding)
+                cst = None
+                ow_ = np.arange(OW)
+                if (OW % 16 == 0 and sh_ == sw_ and sh_ in (1, 2) and (not add_p[0] or (res_val == val[src] and sh_ == 1 and Cout == C
+                        and add_p[6] >= 0 and -STRIP_MAX_SHIFT <= add_p[7] < 0))
+                        and ((ow_ * sw_ - pl + 1 >= 0) & (ow_ * sw_ - pl + 1 < Wd)).all()):
+                    cst = strip_constants(wt_.data[0], bdw, mu, sh, z_o, w2, b2, mu2, sh2, zo2, bool(add_p[0]))
+                p = [H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi, Cout, zo2, lo2, hi2, *add_p, 1, 0, *tile, 0, int(cst is not None)]
                 pb.op(pk.I8_DWPW, val[src], v, p=p, in1=res_val,
                       t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(bdw, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
-                         pb.tensor(pack_i8_fragments(w2), np.int8), pb.tensor(b2, np.int32), pb.tensor(mu2, np.int32), pb.tensor(sh2, np.int32)],
+                         pb.tensor(pack_i8_fragments(w2), np.int8), pb.tensor(b2, np.int32), pb.tensor(mu2, np.int32), pb.tensor(sh2, np.int32),
+                         -1, pb.tensor(cst, np.int32) if cst is not None else -1],
                       name=f"t{out_t}", out_shape=(OH, OW, Cout), out_dtype="int8")
                 val[out_t], shape[out_t] = v, (OH, OW, Cout)
                 i += 2

@@ -61,6 +61,7 @@ struct bn_model {
     size_t consts_base = 0;              // blob offset of the first payload byte
     size_t consts_bytes = 0;
     std::vector<uint8_t> rq_right;       // per operator: all requantisation multipliers >= 0 and shifts < 0
+    bool use_strip = true;               // BN_I8_STRIP=0 keeps the generic fused INT8 block everywhere (A/B runs, tests)
     std::vector<char*> d_slots;          // max_batch * bytes_per_chunk each
     float* d_spec = nullptr;             // [max_batch][F][W] for bn_infer_audio
     float* d_minmax = nullptr;           // [max_batch][2]
@@ -272,6 +273,15 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 a.add = bn::I8AddParams{p[18], p[19], p[20], p[21], p[22], p[23], p[24], p[25], p[26], p[27], p[28]};
                 a.has_dw = p[29]; a.transposed = p[30]; a.TH = p[31]; a.TW = p[32]; a.NB = p[33];
                 a.rq_right = m->rq_right[oi];
+                // wide early layers: wave-autonomous strip kernel when the packer prepared its constant block
+                if (p[35] && o.t[9] >= 0 && m->use_strip && a.has_dw && !a.transposed && a.sh == a.sw &&
+                    bn::i8_strip_supported(a.Cin, a.Cout, a.sh, a.OW, a.add.enabled != 0) && (!a.add.enabled || a.res == a.x)) {
+                    const int off = a.add.enabled ? 128 : 0;
+                    bn::Strip8Args q{a.x, a.y, (const int32_t*)m->tensor(o.t[9]), B, a.H, a.W, a.OH, a.OW, 0, a.pt, a.pl,
+                                     a.dw_zp_in, a.dw_amin, a.dw_amax, a.pw_amin + off, a.pw_amax + off, a.pw_zp_out, a.add, 0};
+                    bn::launch_i8_strip(q, a.Cin, a.Cout, a.sh, s);
+                    break;
+                }
                 if (!bn::i8_dwpw_supported(a.Cin, a.Cout) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported fused INT8 block geometry", oi);
                 bn::launch_i8_dwpw(a, s);
@@ -441,6 +451,7 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
     }
     // INT8 blocks: can every requantisation of the operator take the branch-free right-shift form?
     m->rq_right.assign(h.n_ops, 0);
+    if (const char* e = getenv("BN_I8_STRIP")) m->use_strip = e[0] != '0';
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         auto all_right = [&](int t_mult, int t_shift) {

@@ -1,0 +1,315 @@
+// bn_i8_strip.hip — wave-autonomous INT8 depthwise-separable block for the wide early stages (Cin, Cout in {32, 64}):
+//
+//   DEPTHWISE_CONV_2D 3x3 (ReLU6 clamp) -> CONV_2D 1x1 on the int8 matrix cores [-> TFLite ADD with the block input]
+//
+// Same integer semantics as bn_i8_fused.hip / bn_i8.hip (bit-identical results); what changes is who does what.
+// The generic fused kernel spends ~950 vector instructions per wave and 64-position tile, most of them on index
+// arithmetic, per-tap bounds tests and 64-bit addresses; these layers are bound by the vector ALU, so this kernel is
+// organised around issuing as few vector instructions as the arithmetic allows:
+//
+//   * one WAVE owns a strip of 16 output columns and walks TH output rows downwards; the four waves of a workgroup
+//     share nothing but read-only tables, so there is no barrier after the prologue;
+//   * lane (n, kq) = (column n of the strip, channel group kq) holds CL = Cin/4 consecutive channels.  Its depthwise
+//     outputs ARE its B fragment of v_mfma_i32_16x16x32_i8 (Cin = 32) / 16x16x64 (Cin = 64): no LDS staging;
+//   * the pointwise weights are the A operand with their rows permuted by the packer so that the 4 accumulator
+//     registers of tile t in lane (n, q) are output channels (Cout/4) q + 4 t + 0..3: a lane ends up with Cout/4
+//     CONSECUTIVE output channels of its own column — one 8/16-byte store, no LDS transpose — which for Cin = Cout is
+//     exactly the channel group it read, so the residual of the ADD is the centre tap it already holds;
+//   * input rows stream through a 3-row register window in byte-transposed form (per channel the three taps of a row in
+//     one dword): a new row costs 3 buffer loads (scalar row offset, no address arithmetic) and 6 byte-permutes per
+//     channel quad, and serves three output rows; 12 v_dot4_i32_i8 per quad and output row do the 36 MACs;
+//   * vertical padding is a wave-uniform branch, horizontal padding two selects per quad and row (lanes 0 / 15 of the
+//     outer strips); rows are prefetched two steps ahead;
+//   * requantisation constants come prepared by the packer (rounding offset and zero point folded into one addend:
+//     ((v + c1 + (v >> 31)) >> e with c1 = 2^(e-1) + (zp << e)), the per-channel ones from LDS as 128-bit reads.
+//
+// The packer (models/_lower_i8.py: strip_constants) only emits the constant block when every multiplier is >= 0, every
+// shift is a right shift of 1..22 bits (dead channels with larger shifts are canonicalised to multiplier 0 when their
+// accumulator bound proves the result is the zero point) — bn_api.hip falls back to the generic kernel otherwise.
+#include <stdlib.h>
+
+#include "bn_kernels.h"
+#include "bn_requant.h"
+
+namespace bn {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int perm(int s0, int s1, uint32_t sel) { return (int)__builtin_amdgcn_perm((uint32_t)s0, (uint32_t)s1, sel); }
+__device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+// clamp as ONE instruction; lo <= hi.  (The compiler cannot prove lo <= hi for run-time bounds and emits compare + select + min.)
+__device__ __forceinline__ int med3(int v, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+// first link of a dot4 chain in the three-address form (no move of the bias into the accumulator)
+__device__ __forceinline__ int dot4_first(int a, int b, int c) {
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// q = ((srdhm(x, m) + c1 + sign) >> e), c1 = 2^(e-1) + (zp << e): RoundingDivideByPOT(SRDHM(x, m), e) + zp (bn_requant.h)
+__device__ __forceinline__ int rq(int x, int m, int c1, int e) {
+    const int v = srdhm_pos(x, m);
+    return (v + c1 + (v >> 31)) >> e;
+}
+
+template <int QL> struct RawRow { int t[3][QL]; };   // three taps (columns j = 0..2) of one input row, QL dwords each
+template <int QL> struct TRow { int c[QL][4]; };     // per channel: bytes (tap0, tap1, tap2, 0)
+
+template <int QL>
+__device__ __forceinline__ RawRow<QL> load_row(__amdgpu_buffer_rsrc_t rsrc, const int voff[3], int soff) {
+    RawRow<QL> r;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if constexpr (QL == 2) {
+            const v2i v = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[j], soff, 0));
+            r.t[j][0] = v.x; r.t[j][1] = v.y;
+        } else {
+            const v4i v = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], soff, 0));
+            r.t[j][0] = v.x; r.t[j][1] = v.y; r.t[j][2] = v.z; r.t[j][3] = v.w;
+        }
+    }
+    return r;
+}
+
+template <int CIN, int COUT, int S, bool ADD>
+__global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
+    constexpr int CL = CIN / 4, QL = CL / 4, NT = COUT / 16, COL = COUT / 4;
+    static_assert(!ADD || (CIN == COUT && S == 1), "the residual is the block input");
+    // constant block (int32 words), see strip_constants() in models/_lower_i8.py
+    constexpr int kDWW = 0;                          // [kq][ql][row 3][e 4]
+    constexpr int kDWB = kDWW + 4 * QL * 12;         // [kq][ql][e]
+    constexpr int kDWC = kDWB + 4 * QL * 4;          // [kq][ql][kind 3][e]: multiplier, c1, shift
+    constexpr int kPWA = kDWC + 4 * QL * 12;         // [t][lane][CL / 4]
+    constexpr int kPWB = kPWA + NT * 64 * QL;        // [q][t][reg]
+    constexpr int kPWC = kPWB + 4 * NT * 4;          // [q][t][kind 3][reg]
+    __shared__ v4i c_dw[4 * QL * 3];
+    __shared__ v4i c_pw[4 * NT * 3];
+    __shared__ int add_lut[2][256];
+    const int tid = threadIdx.x;
+    {
+        const v4i* src = reinterpret_cast<const v4i*>(a.cst);
+        if (tid < 4 * QL * 3) c_dw[tid] = src[kDWC / 4 + tid];
+        if (tid >= 64 && tid < 64 + 4 * NT * 3) c_pw[tid - 64] = src[kPWC / 4 + tid - 64];
+        if (ADD) {
+            add_lut[0][tid] = mbqm(((int)(int8_t)tid - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);  // index: residual byte pattern
+            add_lut[1][tid] = mbqm((tid - 128 - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);         // index: own value + 128
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int strips_x = a.OW >> 4;
+    const int rblocks = (a.OH + a.TH - 1) / a.TH;
+    int wid = xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wid >= a.B * strips_x * rblocks) return;
+    const int sx = wid % strips_x;
+    wid /= strips_x;
+    const int ry = wid % rblocks;
+    const int chunk = wid / rblocks;
+    const int oh0 = ry * a.TH;
+    const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
+    const int ow = sx * 16 + n;
+
+    // per-lane constants in registers
+    int dww[QL][3][4], dwb[QL][4];
+    {
+        const v4i* p = reinterpret_cast<const v4i*>(a.cst + kDWW) + kq * QL * 3;
+#pragma unroll
+        for (int ql = 0; ql < QL; ++ql)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const v4i v = p[ql * 3 + i];
+                dww[ql][i][0] = v.x; dww[ql][i][1] = v.y; dww[ql][i][2] = v.z; dww[ql][i][3] = v.w;
+            }
+        const v4i* pb = reinterpret_cast<const v4i*>(a.cst + kDWB) + kq * QL;
+#pragma unroll
+        for (int ql = 0; ql < QL; ++ql) {
+            const v4i v = pb[ql];
+            dwb[ql][0] = v.x; dwb[ql][1] = v.y; dwb[ql][2] = v.z; dwb[ql][3] = v.w;
+        }
+    }
+    int pwa[NT][QL];
+    v4i pwb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int ql = 0; ql < QL; ++ql) pwa[t][ql] = a.cst[kPWA + (t * 64 + lane) * QL + ql];
+        pwb[t] = reinterpret_cast<const v4i*>(a.cst + kPWB)[kq * NT + t];
+    }
+
+    const int zp4 = (a.zp_in & 0xff) * 0x01010101;
+    const int zprow = (a.zp_in & 0xff) * 0x00010101;
+    const int iw0 = ow * S - a.pl;
+    const bool left_pad = iw0 < 0, right_pad = iw0 + 2 >= a.W;  // tap j = 1 is always inside (checked by the packer)
+    const int in_chunk_bytes = a.H * a.W * CIN;
+    const int row_bytes = a.W * CIN;
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x) + (size_t)chunk * in_chunk_bytes, 0, in_chunk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)chunk * a.OH * a.OW * COUT, 0, a.OH * a.OW * COUT, 0x00020000);
+    // padding columns load a valid neighbour instead (their value is replaced by the zero point below)
+    const int voff_in[3] = {(left_pad ? 0 : iw0) * CIN + CL * kq, (iw0 + 1) * CIN + CL * kq, (right_pad ? a.W - 1 : iw0 + 2) * CIN + CL * kq};
+    const int voff_out = ow * COUT + COL * kq;
+    const int ir0 = oh0 * S - a.pt;           // first input row of the strip
+    const int rows_needed = S * (nrows - 1) + 3;
+
+    RawRow<QL> raw[2];
+    TRow<QL> T[3];
+    int cen[3][QL];
+
+    auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
+    auto issue = [&](int slot, int rr) {
+        if (row_ok(rr)) raw[slot] = load_row<QL>(rs_in, voff_in, (ir0 + rr) * row_bytes);
+    };
+    auto consume = [&](int slot, int rr, int ti) {
+        if (row_ok(rr)) {
+#pragma unroll
+            for (int ql = 0; ql < QL; ++ql) {
+                const int r0 = left_pad ? zp4 : raw[slot].t[0][ql];
+                const int r1 = raw[slot].t[1][ql];
+                const int r2 = right_pad ? zp4 : raw[slot].t[2][ql];
+                const int lo = perm(r1, r0, 0x05010400u);  // r0.0 r1.0 r0.1 r1.1
+                const int hi = perm(r1, r0, 0x07030602u);  // r0.2 r1.2 r0.3 r1.3
+                T[ti].c[ql][0] = perm(r2, lo, 0x0c040100u);
+                T[ti].c[ql][1] = perm(r2, lo, 0x0c050302u);
+                T[ti].c[ql][2] = perm(r2, hi, 0x0c060100u);
+                T[ti].c[ql][3] = perm(r2, hi, 0x0c070302u);
+                cen[ti][ql] = r1;
+            }
+        } else {
+#pragma unroll
+            for (int ql = 0; ql < QL; ++ql) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[ti].c[ql][e] = zprow;
+                cen[ti][ql] = zp4;
+            }
+        }
+    };
+
+    // one output row from window rows (i0, i1, i2)
+    auto emit = [&](int i0, int i1, int i2, int oh) {
+        int bfrag[QL];
+#pragma unroll
+        for (int ql = 0; ql < QL; ++ql) {
+            const v4i m = c_dw[(kq * QL + ql) * 3 + 0], c1 = c_dw[(kq * QL + ql) * 3 + 1], sh = c_dw[(kq * QL + ql) * 3 + 2];
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int acc = dot4_first(T[i0].c[ql][e], dww[ql][0][e], dwb[ql][e]);
+                acc = dot4(T[i1].c[ql][e], dww[ql][1][e], acc);
+                acc = dot4(T[i2].c[ql][e], dww[ql][2][e], acc);
+                qv[e] = med3(rq(acc, m[e], c1[e], sh[e]), a.dw_lo, a.dw_hi);
+            }
+            bfrag[ql] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+        }
+        int outw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            v4i acc;
+            if constexpr (QL == 2) {
+                const long af = ((long)(uint32_t)pwa[t][1] << 32) | (uint32_t)pwa[t][0];
+                const long bf = ((long)(uint32_t)bfrag[1] << 32) | (uint32_t)bfrag[0];
+                acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bf, pwb[t], 0, 0, 0);
+            } else {
+                const v4i af = {pwa[t][0], pwa[t][1], pwa[t][2], pwa[t][3]};
+                const v4i bf = {bfrag[0], bfrag[1], bfrag[2], bfrag[3]};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, pwb[t], 0, 0, 0);
+            }
+            const v4i m = c_pw[(kq * NT + t) * 3 + 0], c1 = c_pw[(kq * NT + t) * 3 + 1], sh = c_pw[(kq * NT + t) * 3 + 2];
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int v = med3(rq(acc[e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);  // ADD: value + 128 (table index), else the int8 value
+                if constexpr (ADD) {
+                    const int sa = add_lut[0][(cen[i1][t] >> (8 * e)) & 0xff];
+                    const int sb = add_lut[1][v];
+                    v = med3(rq(sa + sb, a.add.mo, a.add_c1, -a.add.so), a.add.amin, a.add.amax);
+                }
+                qv[e] = v;
+            }
+            outw[t] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+        }
+        const int soff = oh * a.OW * COUT;
+        if constexpr (NT == 2) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, soff, 0);
+        } else {
+            static_assert(NT == 4, "Cout is 32 or 64");
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(int)))) int, (v4i){outw[0], outw[1], outw[2], outw[3]}), rs_out, voff_out, soff, 0);
+        }
+    };
+
+    // rows consumed before the first output row: 3 - S; afterwards S per step.  Relative row rr lives in raw slot rr & 1 and in
+    // window slot rr % 3; a slot is reloaded with row rr + 2 as soon as it has been transposed.
+    constexpr int P = 3 - S;
+    issue(0, 0);
+    issue(1, 1);
+#pragma unroll
+    for (int rr = 0; rr < P; ++rr) {
+        consume(rr & 1, rr, rr % 3);
+        issue(rr & 1, rr + 2);
+    }
+    constexpr int U = 6 / S;  // unroll period: window slots (3) x raw slots (2)
+    for (int k = 0; k < nrows; k += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k + u >= nrows) break;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int rs = P + S * u + s;  // static part of the relative row index (k is a multiple of 6 rows)
+                consume(rs & 1, S * k + rs, rs % 3);
+                issue(rs & 1, S * k + rs + 2);
+            }
+            emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
+        }
+    }
+}
+
+template <int CIN, int COUT, int S, bool ADD>
+void launch_strip(const Strip8Args& a, hipStream_t s) {
+    const long waves = (long)a.B * (a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
+    hipLaunchKernelGGL((i8_strip_kernel<CIN, COUT, S, ADD>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+bool i8_strip_supported(int Cin, int Cout, int stride, int OW, bool add) {
+    if (OW % 16) return false;
+    if (add) return stride == 1 && Cin == Cout && (Cin == 32 || Cin == 64);
+    return (stride == 1 || stride == 2) && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64);
+}
+
+void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s) {
+    // rows per wave: as tall as possible while the launch still fills the chip a few times over
+    int th = a.OH;
+    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 16384) th = (th + 1) / 2;
+    if (const char* e = getenv("BN_I8_STRIP_TH")) {  // tests: force the rows per wave (any value >= 1)
+        const int v = atoi(e);
+        if (v >= 1) th = v < a.OH ? v : a.OH;
+    }
+    a.TH = th;
+    const bool add = a.add.enabled != 0;
+    if (add) a.add_c1 = (1 << (-a.add.so - 1)) + (a.add.zo << -a.add.so);
+#define BN_STRIP(CI, CO, ST, AD) \
+    if (Cin == CI && Cout == CO && stride == ST && add == AD) return launch_strip<CI, CO, ST, AD>(a, s);
+    BN_STRIP(32, 32, 1, true)
+    BN_STRIP(64, 64, 1, true)
+    BN_STRIP(32, 32, 1, false)
+    BN_STRIP(64, 64, 1, false)
+    BN_STRIP(32, 64, 1, false)
+    BN_STRIP(64, 32, 1, false)
+    BN_STRIP(32, 32, 2, false)
+    BN_STRIP(32, 64, 2, false)
+    BN_STRIP(64, 32, 2, false)
+    BN_STRIP(64, 64, 2, false)
+#undef BN_STRIP
+}
+
+}  // namespace bn

@@ -140,6 +140,20 @@ struct DwPw8Args {
     int rq_right;  // every multiplier >= 0 and every shift < 0 in this operator (set at load): branch-free requantisation
 };
 bool i8_dwpw_supported(int Cin, int Cout);
+// Wave-autonomous strip kernel for the same block at Cin, Cout in {32, 64} (bn_i8_strip.hip); `cst` is the constant block
+// the packer prepares (models/_lower_i8.py: strip_constants).  With the ADD the residual must be the block input x.
+struct Strip8Args {
+    const int8_t* x;
+    int8_t* y;
+    const int32_t* cst;
+    int B, H, W, OH, OW, TH, pt, pl;
+    int zp_in, dw_lo, dw_hi;
+    int pw_lo, pw_hi, pw_zp_out;  // with the ADD: clamp bounds + 128 (the block's own value is kept as a table index)
+    I8AddParams add;
+    int add_c1;
+};
+bool i8_strip_supported(int Cin, int Cout, int stride, int OW, bool add);
+void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s);
 // INT8 stem 3x3 + depthwise 3x3 stride 2 + pointwise in one kernel (bn_i8_fused.hip)
 struct I8FrontParams {
     const int8_t* stem_w; const int32_t* stem_b; const int32_t* stem_mult; const int32_t* stem_shift;

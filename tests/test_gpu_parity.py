@@ -169,6 +169,37 @@ def test_i8_graph_bit_exact_per_tensor(torch_mod, oracle_specs, fuse):
     runner.close()
 
 
+def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypatch):
+    """The wave-autonomous strip kernel (stage 1-2 blocks) against the generic fused block: every tensor bit for bit, for
+    rows-per-wave values that put the strip borders everywhere (1, 3, 5, 7 rows, whole map), and a batch large enough for
+    the launcher's own choice."""
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models.runners import load_model_runner
+
+    x = np.tile(oracle_specs[..., None], (17, 1, 1, 1))[:260]
+    x = np.ascontiguousarray(x[np.random.default_rng(3).permutation(x.shape[0])])
+    B = x.shape[0]
+    monkeypatch.setenv("BN_I8_STRIP", "0")
+    runner = load_model_runner(TFLITE_PATH, max_batch=B, keep_all=True)
+    want_scores = runner.predict(x)
+    strip_ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.I8_DWPW and op.p[35]]
+    assert len(strip_ops) == 4
+    want = {oi: runner.op_output(oi, B) for oi in strip_ops}
+    runner.close()
+    monkeypatch.setenv("BN_I8_STRIP", "1")
+    runner = load_model_runner(TFLITE_PATH, max_batch=B, keep_all=True)
+    for th in ("", "1", "3", "5", "7", "64"):
+        if th:
+            monkeypatch.setenv("BN_I8_STRIP_TH", th)
+        got_scores = runner.predict(x)
+        for oi in strip_ops:
+            a = runner.op_output(oi, B)
+            bad = int((a != want[oi]).sum())
+            assert bad == 0, f"rows per wave {th or 'auto'}: tensor {runner.plan.ops[oi].name}: {bad} of {a.size} values differ, first at {np.argwhere(a != want[oi])[:3].tolist()}"
+        assert np.array_equal(got_scores, want_scores)
+    runner.close()
+
+
 def test_i8_from_audio_top1_and_cosine(torch_mod, audio24, oracle_specs):
     torch = torch_mod
     from birdnet_stm32.models._tflite_reader import load_tflite
