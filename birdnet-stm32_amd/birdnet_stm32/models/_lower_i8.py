@@ -127,22 +127,42 @@ def _strip_requant(mult, shift, zp: int, acc_lo, acc_hi) -> tuple[np.ndarray, np
     return m.astype(np.int32), c1.astype(np.int32), e.astype(np.int32)
 
 
-def strip_constants(wd, bdw, mu, sh, z_dw_out, w2, b2, mu2, sh2, z_pw_out, add: bool) -> np.ndarray | None:
-    """Constant block of ``i8_strip_kernel`` (csrc/bn_i8_strip.hip) for one DW 3x3 -> PW 1x1 [-> ADD] block, int32 words:
+def strip_waves(cin: int, cout: int, stride: int, ow: int, add: bool) -> int:
+    """Waves sharing one strip (channel split) — mirrors ``i8_strip_waves`` in csrc/bn_i8_strip.hip; 0 = no strip kernel."""
+    if ow % 16 or stride not in (1, 2) or (add and (stride != 1 or cin != cout)):
+        return 0
+    if cin in (32, 64) and cout in (32, 64):
+        return 1
+    if add:
+        return 4 if cin == 128 else 0
+    if (cin, cout) == (64, 128):
+        return 2
+    if (cin, cout) == (128, 128):
+        return 4
+    return 0
 
-    lane (n, kq) of a wave holds the CL = Cin/4 channels ``CL kq ..`` of column n (QL = CL/4 quads) and ends up with the
-    COL = Cout/4 output channels ``COL kq ..``.  Sections: depthwise weights ``[kq][ql][row][e]`` as bytes (tap0, tap1,
-    tap2, 0) of channel ``CL kq + 4 ql + e``; folded depthwise bias ``[kq][ql][e]``; depthwise (multiplier, c1, e)
-    ``[kq][ql][3][e]``; pointwise A fragments ``[t][lane][QL]`` = ``W[COL (m >> 2) + 4 t + (m & 3)][CL kq : CL kq + CL]``
-    for lane (m, kq); folded pointwise bias ``[q][t][reg]`` for channel ``COL q + 4 t + reg``; pointwise (multiplier, c1, e)
-    ``[q][t][3][reg]``.  With the ADD the block's own value is produced + 128 (it indexes a table).  ``None`` if the block's
-    requantisation cannot take the kernel's form."""
+
+def strip_constants(wd, bdw, mu, sh, z_dw_out, w2, b2, mu2, sh2, z_pw_out, add: bool, nw: int = 1) -> np.ndarray | None:
+    """Constant block of ``i8_strip_kernel`` (csrc/bn_i8_strip.hip) for one DW 3x3 -> PW 1x1 [-> ADD] block, int32 words.
+
+    ``nw`` waves share a strip: wave w runs the depthwise stage for the CW = Cin/nw input channels ``CW w ..`` and produces
+    the CWO = Cout/nw output channels ``CWO w ..``.  Lane (n, kq) of wave w holds the CL = CW/4 channels ``CW w + CL kq ..``
+    of column n (QL = CL/4 quads) and ends up with the COL = CWO/4 output channels ``CWO w + COL kq ..``.  Sections, each
+    with the wave index first: depthwise weights ``[w][kq][ql][row][e]`` as bytes (tap0, tap1, tap2, 0) of channel
+    ``CW w + CL kq + 4 ql + e``; folded depthwise bias ``[w][kq][ql][e]``; depthwise (multiplier, c1, e) ``[w][kq][ql][3][e]``;
+    pointwise A fragments ``[w][t][ks][lane][QL]`` = ``W[CWO w + COL (m >> 2) + 4 t + (m & 3)][CW ks + CL kq : + CL]`` for lane
+    (m, kq) and channel slice ks; folded pointwise bias ``[w][q][t][reg]`` for channel ``CWO w + COL q + 4 t + reg``;
+    pointwise (multiplier, c1, e) ``[w][q][t][3][reg]``.  With the ADD the block's own value is produced + 128 (it indexes a
+    table).  ``None`` if the block's requantisation cannot take the kernel's form."""
     wd = np.asarray(wd, np.int8)  # [3][3][C]
     C, (N, K) = wd.shape[2], w2.shape
-    if K != C or C not in (32, 64) or N not in (32, 64):
+    if K != C or nw < 1 or C % (16 * nw) or N % (16 * nw):
         return None
-    CL, COL = C // 4, N // 4
-    QL, NT = CL // 4, N // 16
+    CW, CWO = C // nw, N // nw
+    CL, COL = CW // 4, CWO // 4
+    QL, NT = CL // 4, CWO // 16
+    if (CW, QL) not in ((32, 2), (64, 4)) or NT not in (2, 4) or (nw > 1 and CW != 32):
+        return None
     # accumulator ranges over every int8 input (the folded biases already hold -zp * sum(w); padded taps read zp)
     wd64, w264 = wd.astype(np.int64), np.asarray(w2, np.int64)
     lo_dw = np.minimum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(bdw, np.int64)
@@ -153,23 +173,26 @@ def strip_constants(wd, bdw, mu, sh, z_dw_out, w2, b2, mu2, sh2, z_pw_out, add: 
     rq_pw = _strip_requant(mu2, sh2, z_pw_out + (128 if add else 0), lo_pw, hi_pw)
     if rq_dw is None or rq_pw is None:
         return None
-    ch_in = (CL * np.arange(4)[:, None, None] + 4 * np.arange(QL)[None, :, None] + np.arange(4)[None, None, :])  # [kq][ql][e]
-    dww = np.zeros((4, QL, 3, 4, 4), np.uint8)  # [...][row][e][byte]
+    ax = np.arange
+    ch_in = (CW * ax(nw)[:, None, None, None] + CL * ax(4)[None, :, None, None] + 4 * ax(QL)[None, None, :, None] + ax(4)[None, None, None, :])  # [w][kq][ql][e]
+    dww = np.zeros((nw, 4, QL, 3, 4, 4), np.uint8)  # [...][row][e][byte]
     for i in range(3):
         for j in range(3):
-            dww[:, :, i, :, j] = wd[i, j][ch_in].view(np.uint8)
+            dww[..., i, :, j] = wd[i, j][ch_in].view(np.uint8)
     sec = [dww.view(np.int32).reshape(-1), np.asarray(bdw, np.int32)[ch_in].reshape(-1),
-           np.stack([r[ch_in] for r in rq_dw], axis=2).reshape(-1)]  # [kq][ql][3][e]
-    lane = np.arange(64)
+           np.stack([r[ch_in] for r in rq_dw], axis=3).reshape(-1)]  # [w][kq][ql][3][e]
+    lane = ax(64)
     m_, kq_ = lane & 15, lane >> 4
-    pwa = np.zeros((NT, 64, CL), np.int8)
-    for t in range(NT):
-        ch = COL * (m_ >> 2) + 4 * t + (m_ & 3)
-        for k in range(CL):
-            pwa[t, :, k] = w2[ch, CL * kq_ + k]
-    ch_out = (COL * np.arange(4)[:, None, None] + 4 * np.arange(NT)[None, :, None] + np.arange(4)[None, None, :])  # [q][t][reg]
+    pwa = np.zeros((nw, NT, nw, 64, CL), np.int8)
+    for w in range(nw):
+        for t in range(NT):
+            ch = CWO * w + COL * (m_ >> 2) + 4 * t + (m_ & 3)
+            for ks in range(nw):
+                for k in range(CL):
+                    pwa[w, t, ks, :, k] = w2[ch, CW * ks + CL * kq_ + k]
+    ch_out = (CWO * ax(nw)[:, None, None, None] + COL * ax(4)[None, :, None, None] + 4 * ax(NT)[None, None, :, None] + ax(4)[None, None, None, :])  # [w][q][t][reg]
     sec += [pwa.view(np.int32).reshape(-1), np.asarray(b2, np.int32)[ch_out].reshape(-1),
-            np.stack([r[ch_out] for r in rq_pw], axis=2).reshape(-1)]
+            np.stack([r[ch_out] for r in rq_pw], axis=3).reshape(-1)]
     return np.concatenate(sec).astype(np.int32)
 
 
@@ -371,10 +394,10 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                 # every per-channel requantisation and the ADD's output one a right shift; tap column 1 never in the padding)
                 cst = None
                 ow_ = np.arange(OW)
-                if (OW % 16 == 0 and sh_ == sw_ and sh_ in (1, 2) and (not add_p[0] or (res_val == val[src] and sh_ == 1 and Cout == C
-                        and add_p[6] >= 0 and -STRIP_MAX_SHIFT <= add_p[7] < 0))
+                nw = strip_waves(C, Cout, sh_, OW, bool(add_p[0])) if sh_ == sw_ else 0
+                if (nw and (not add_p[0] or (res_val == val[src] and add_p[6] >= 0 and -STRIP_MAX_SHIFT <= add_p[7] < 0))
                         and ((ow_ * sw_ - pl + 1 >= 0) & (ow_ * sw_ - pl + 1 < Wd)).all()):
-                    cst = strip_constants(wt_.data[0], bdw, mu, sh, z_o, w2, b2, mu2, sh2, zo2, bool(add_p[0]))
+                    cst = strip_constants(wt_.data[0], bdw, mu, sh, z_o, w2, b2, mu2, sh2, zo2, bool(add_p[0]), nw)
                 p = [H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi, Cout, zo2, lo2, hi2, *add_p, 1, 0, *tile, 0, int(cst is not None)]
                 pb.op(pk.I8_DWPW, val[src], v, p=p, in1=res_val,
                       t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(bdw, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),

@@ -23,6 +23,11 @@
 //   * requantisation constants come prepared by the packer (rounding offset and zero point folded into one addend:
 //     ((v + c1 + (v >> 31)) >> e with c1 = 2^(e-1) + (zp << e)), the per-channel ones from LDS as 128-bit reads.
 //
+// Blocks wider than 64 channels (or with more than 64 outputs) split the CHANNELS over the NW waves of a workgroup: wave w
+// runs the depthwise stage for input channels 32 w .. 32 w + 31 of the same strip, the waves swap their 8-byte B fragments
+// through LDS (one barrier per output row, double-buffered), and each wave multiplies all NW fragments into ITS Cout/NW
+// output channels — per-lane registers stay those of the 32-channel kernel whatever the width.
+//
 // The packer (models/_lower_i8.py: strip_constants) only emits the constant block when every multiplier is >= 0, every
 // shift is a right shift of 1..22 bits (dead channels with larger shifts are canonicalised to multiplier 0 when their
 // accumulator bound proves the result is the zero point) — bn_api.hip falls back to the generic kernel otherwise.
@@ -77,39 +82,49 @@ __device__ __forceinline__ RawRow<QL> load_row(__amdgpu_buffer_rsrc_t rsrc, cons
     return r;
 }
 
-template <int CIN, int COUT, int S, bool ADD>
-__global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
-    constexpr int CL = CIN / 4, QL = CL / 4, NT = COUT / 16, COL = COUT / 4;
+// CW = input channels per wave (32 or 64; 32 when NW > 1), NW = waves sharing a strip (channel split), COUT = all output channels
+template <int CW, int NW, int COUT, int S, bool ADD>
+__global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip8Args a) {
+    constexpr int CIN = CW * NW, CL = CW / 4, QL = CL / 4;
+    constexpr int CWO = COUT / NW, NT = CWO / 16, COL = CWO / 4;  // output channels per wave / tiles per wave / per lane
+    constexpr int NTHREADS = NW == 1 ? 256 : 64 * NW;
+    static_assert(NW == 1 || CW == 32, "the channel split works on 32-channel slices");
     static_assert(!ADD || (CIN == COUT && S == 1), "the residual is the block input");
-    // constant block (int32 words), see strip_constants() in models/_lower_i8.py
-    constexpr int kDWW = 0;                          // [kq][ql][row 3][e 4]
-    constexpr int kDWB = kDWW + 4 * QL * 12;         // [kq][ql][e]
-    constexpr int kDWC = kDWB + 4 * QL * 4;          // [kq][ql][kind 3][e]: multiplier, c1, shift
-    constexpr int kPWA = kDWC + 4 * QL * 12;         // [t][lane][CL / 4]
-    constexpr int kPWB = kPWA + NT * 64 * QL;        // [q][t][reg]
-    constexpr int kPWC = kPWB + 4 * NT * 4;          // [q][t][kind 3][reg]
-    __shared__ v4i c_dw[4 * QL * 3];
-    __shared__ v4i c_pw[4 * NT * 3];
+    static_assert(NT == 2 || NT == 4, "8 or 16 output channels per lane");
+    // constant block (int32 words), see strip_constants() in models/_lower_i8.py; every section starts with the wave index
+    constexpr int nDWW = 4 * QL * 12, nDWB = 4 * QL * 4, nDWC = 4 * QL * 12, nPWA = NT * NW * 64 * QL, nPWB = 4 * NT * 4, nPWC = 4 * NT * 12;
+    constexpr int kDWW = 0;                   // [w][kq][ql][row 3][e 4]
+    constexpr int kDWB = kDWW + NW * nDWW;    // [w][kq][ql][e]
+    constexpr int kDWC = kDWB + NW * nDWB;    // [w][kq][ql][kind 3][e]: multiplier, c1, shift
+    constexpr int kPWA = kDWC + NW * nDWC;    // [w][t][ks][lane][QL]
+    constexpr int kPWB = kPWA + NW * nPWA;    // [w][q][t][reg]
+    constexpr int kPWC = kPWB + NW * nPWB;    // [w][q][t][kind 3][reg]
+    __shared__ v4i c_dw[NW * nDWC / 4];
+    __shared__ v4i c_pw[NW * nPWC / 4];
     __shared__ int add_lut[2][256];
+    __shared__ v2i xchg[NW > 1 ? 2 * NW * 64 : 1];  // [buffer][wave][lane]: B fragments of the current output row
     const int tid = threadIdx.x;
     {
         const v4i* src = reinterpret_cast<const v4i*>(a.cst);
-        if (tid < 4 * QL * 3) c_dw[tid] = src[kDWC / 4 + tid];
-        if (tid >= 64 && tid < 64 + 4 * NT * 3) c_pw[tid - 64] = src[kPWC / 4 + tid - 64];
+        for (int i = tid; i < NW * nDWC / 4; i += NTHREADS) c_dw[i] = src[kDWC / 4 + i];
+        for (int i = tid; i < NW * nPWC / 4; i += NTHREADS) c_pw[i] = src[kPWC / 4 + i];
         if (ADD) {
-            add_lut[0][tid] = mbqm(((int)(int8_t)tid - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);  // index: residual byte pattern
-            add_lut[1][tid] = mbqm((tid - 128 - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);         // index: own value + 128
+            for (int i = tid; i < 256; i += NTHREADS) {
+                add_lut[0][i] = mbqm(((int)(int8_t)i - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);  // index: residual byte pattern
+                add_lut[1][i] = mbqm((i - 128 - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);         // index: own value + 128
+            }
         }
     }
     __syncthreads();
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = NW == 1 ? 0 : wave;  // channel slice of this wave
     const int n = lane & 15, kq = lane >> 4;
     const int strips_x = a.OW >> 4;
     const int rblocks = (a.OH + a.TH - 1) / a.TH;
-    int wid = xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
-    if (wid >= a.B * strips_x * rblocks) return;
+    int wid = NW == 1 ? xcd_tile(blockIdx.x, gridDim.x) * 4 + wave : xcd_tile(blockIdx.x, gridDim.x);
+    if (wid >= a.B * strips_x * rblocks) return;  // uniform per workgroup when the waves share a strip
     const int sx = wid % strips_x;
     wid /= strips_x;
     const int ry = wid % rblocks;
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
     // per-lane constants in registers
     int dww[QL][3][4], dwb[QL][4];
     {
-        const v4i* p = reinterpret_cast<const v4i*>(a.cst + kDWW) + kq * QL * 3;
+        const v4i* p = reinterpret_cast<const v4i*>(a.cst + kDWW + w * nDWW) + kq * QL * 3;
 #pragma unroll
         for (int ql = 0; ql < QL; ++ql)
 #pragma unroll
@@ -129,21 +144,25 @@ __global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
                 const v4i v = p[ql * 3 + i];
                 dww[ql][i][0] = v.x; dww[ql][i][1] = v.y; dww[ql][i][2] = v.z; dww[ql][i][3] = v.w;
             }
-        const v4i* pb = reinterpret_cast<const v4i*>(a.cst + kDWB) + kq * QL;
+        const v4i* pb = reinterpret_cast<const v4i*>(a.cst + kDWB + w * nDWB) + kq * QL;
 #pragma unroll
         for (int ql = 0; ql < QL; ++ql) {
             const v4i v = pb[ql];
             dwb[ql][0] = v.x; dwb[ql][1] = v.y; dwb[ql][2] = v.z; dwb[ql][3] = v.w;
         }
     }
-    int pwa[NT][QL];
+    int pwa[NT][NW][QL];
     v4i pwb[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int ql = 0; ql < QL; ++ql) pwa[t][ql] = a.cst[kPWA + (t * 64 + lane) * QL + ql];
-        pwb[t] = reinterpret_cast<const v4i*>(a.cst + kPWB)[kq * NT + t];
+        for (int ks = 0; ks < NW; ++ks)
+#pragma unroll
+            for (int ql = 0; ql < QL; ++ql) pwa[t][ks][ql] = a.cst[kPWA + w * nPWA + ((t * NW + ks) * 64 + lane) * QL + ql];
+        pwb[t] = reinterpret_cast<const v4i*>(a.cst + kPWB + w * nPWB)[kq * NT + t];
     }
+    const v4i* my_dw = c_dw + w * (nDWC / 4);
+    const v4i* my_pw = c_pw + w * (nPWC / 4);
 
     const int zp4 = (a.zp_in & 0xff) * 0x01010101;
     const int zprow = (a.zp_in & 0xff) * 0x00010101;
@@ -156,8 +175,9 @@ __global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)chunk * a.OH * a.OW * COUT, 0, a.OH * a.OW * COUT, 0x00020000);
     // padding columns load a valid neighbour instead (their value is replaced by the zero point below)
-    const int voff_in[3] = {(left_pad ? 0 : iw0) * CIN + CL * kq, (iw0 + 1) * CIN + CL * kq, (right_pad ? a.W - 1 : iw0 + 2) * CIN + CL * kq};
-    const int voff_out = ow * COUT + COL * kq;
+    const int coff = CW * w + CL * kq;
+    const int voff_in[3] = {(left_pad ? 0 : iw0) * CIN + coff, (iw0 + 1) * CIN + coff, (right_pad ? a.W - 1 : iw0 + 2) * CIN + coff};
+    const int voff_out = ow * COUT + CWO * w + COL * kq;
     const int ir0 = oh0 * S - a.pt;           // first input row of the strip
     const int rows_needed = S * (nrows - 1) + 3;
 
@@ -194,12 +214,12 @@ __global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
         }
     };
 
-    // one output row from window rows (i0, i1, i2)
-    auto emit = [&](int i0, int i1, int i2, int oh) {
+    // one output row from window rows (i0, i1, i2); `step` counts output rows of this strip (exchange buffer parity)
+    auto emit = [&](int i0, int i1, int i2, int oh, int step) {
         int bfrag[QL];
 #pragma unroll
         for (int ql = 0; ql < QL; ++ql) {
-            const v4i m = c_dw[(kq * QL + ql) * 3 + 0], c1 = c_dw[(kq * QL + ql) * 3 + 1], sh = c_dw[(kq * QL + ql) * 3 + 2];
+            const v4i m = my_dw[(kq * QL + ql) * 3 + 0], c1 = my_dw[(kq * QL + ql) * 3 + 1], sh = my_dw[(kq * QL + ql) * 3 + 2];
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -210,20 +230,35 @@ __global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
             }
             bfrag[ql] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         }
+        long bfs[NW];  // B fragments of every channel slice (QL == 2 whenever NW > 1)
+        if constexpr (NW > 1) {
+            v2i* buf = xchg + (step & 1) * (NW * 64);
+            buf[w * 64 + lane] = (v2i){bfrag[0], bfrag[1]};
+            // LDS only: the prefetched global loads stay in flight across the barrier (a __syncthreads would drain them)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < NW; ++ks) bfs[ks] = __builtin_bit_cast(long, buf[ks * 64 + lane]);
+        }
         int outw[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            v4i acc;
-            if constexpr (QL == 2) {
-                const long af = ((long)(uint32_t)pwa[t][1] << 32) | (uint32_t)pwa[t][0];
+            v4i acc = pwb[t];
+            if constexpr (NW > 1) {
+#pragma unroll
+                for (int ks = 0; ks < NW; ++ks) {
+                    const long af = ((long)(uint32_t)pwa[t][ks][1] << 32) | (uint32_t)pwa[t][ks][0];
+                    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bfs[ks], acc, 0, 0, 0);
+                }
+            } else if constexpr (QL == 2) {
+                const long af = ((long)(uint32_t)pwa[t][0][1] << 32) | (uint32_t)pwa[t][0][0];
                 const long bf = ((long)(uint32_t)bfrag[1] << 32) | (uint32_t)bfrag[0];
-                acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bf, pwb[t], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bf, acc, 0, 0, 0);
             } else {
-                const v4i af = {pwa[t][0], pwa[t][1], pwa[t][2], pwa[t][3]};
+                const v4i af = {pwa[t][0][0], pwa[t][0][1], pwa[t][0][2], pwa[t][0][3]};
                 const v4i bf = {bfrag[0], bfrag[1], bfrag[2], bfrag[3]};
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, pwb[t], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc, 0, 0, 0);
             }
-            const v4i m = c_pw[(kq * NT + t) * 3 + 0], c1 = c_pw[(kq * NT + t) * 3 + 1], sh = c_pw[(kq * NT + t) * 3 + 2];
+            const v4i m = my_pw[(kq * NT + t) * 3 + 0], c1 = my_pw[(kq * NT + t) * 3 + 1], sh = my_pw[(kq * NT + t) * 3 + 2];
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -241,7 +276,6 @@ __global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
         if constexpr (NT == 2) {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, soff, 0);
         } else {
-            static_assert(NT == 4, "Cout is 32 or 64");
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(int)))) int, (v4i){outw[0], outw[1], outw[2], outw[3]}), rs_out, voff_out, soff, 0);
         }
     };
@@ -267,48 +301,64 @@ __global__ __launch_bounds__(256) void i8_strip_kernel(Strip8Args a) {
                 consume(rs & 1, S * k + rs, rs % 3);
                 issue(rs & 1, S * k + rs + 2);
             }
-            emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
+            emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u, k + u);
         }
     }
 }
 
-template <int CIN, int COUT, int S, bool ADD>
+template <int CW, int NW, int COUT, int S, bool ADD>
 void launch_strip(const Strip8Args& a, hipStream_t s) {
-    const long waves = (long)a.B * (a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
-    hipLaunchKernelGGL((i8_strip_kernel<CIN, COUT, S, ADD>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    const long strips = (long)a.B * (a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
+    if (NW == 1)
+        hipLaunchKernelGGL((i8_strip_kernel<CW, NW, COUT, S, ADD>), dim3((unsigned)((strips + 3) / 4)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((i8_strip_kernel<CW, NW, COUT, S, ADD>), dim3((unsigned)strips), dim3(64 * NW), 0, s, a);
 }
 
 }  // namespace
 
-bool i8_strip_supported(int Cin, int Cout, int stride, int OW, bool add) {
-    if (OW % 16) return false;
-    if (add) return stride == 1 && Cin == Cout && (Cin == 32 || Cin == 64);
-    return (stride == 1 || stride == 2) && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64);
+// channel split of a block: waves per strip (1 = a wave holds all input channels); 0 = no strip kernel for this shape
+int i8_strip_waves(int Cin, int Cout, int stride, int OW, bool add) {
+    if (OW % 16 || (stride != 1 && stride != 2)) return 0;
+    if (add && (stride != 1 || Cin != Cout)) return 0;
+    if ((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) return 1;
+    if (add) return Cin == 128 ? 4 : 0;
+    if (Cin == 64 && Cout == 128) return 2;
+    if (Cin == 128 && Cout == 128) return 4;
+    return 0;
 }
 
+bool i8_strip_supported(int Cin, int Cout, int stride, int OW, bool add) { return i8_strip_waves(Cin, Cout, stride, OW, add) != 0; }
+
 void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s) {
+    const bool add = a.add.enabled != 0;
+    const int nw = i8_strip_waves(Cin, Cout, stride, a.OW, add);
     // rows per wave: as tall as possible while the launch still fills the chip a few times over
     int th = a.OH;
-    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 16384) th = (th + 1) / 2;
+    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 16384) th = (th + 1) / 2;
     if (const char* e = getenv("BN_I8_STRIP_TH")) {  // tests: force the rows per wave (any value >= 1)
         const int v = atoi(e);
         if (v >= 1) th = v < a.OH ? v : a.OH;
     }
     a.TH = th;
-    const bool add = a.add.enabled != 0;
     if (add) a.add_c1 = (1 << (-a.add.so - 1)) + (a.add.zo << -a.add.so);
-#define BN_STRIP(CI, CO, ST, AD) \
-    if (Cin == CI && Cout == CO && stride == ST && add == AD) return launch_strip<CI, CO, ST, AD>(a, s);
-    BN_STRIP(32, 32, 1, true)
-    BN_STRIP(64, 64, 1, true)
-    BN_STRIP(32, 32, 1, false)
-    BN_STRIP(64, 64, 1, false)
-    BN_STRIP(32, 64, 1, false)
-    BN_STRIP(64, 32, 1, false)
-    BN_STRIP(32, 32, 2, false)
-    BN_STRIP(32, 64, 2, false)
-    BN_STRIP(64, 32, 2, false)
-    BN_STRIP(64, 64, 2, false)
+#define BN_STRIP(CW, NW, CO, ST, AD) \
+    if (Cin == CW * NW && nw == NW && Cout == CO && stride == ST && add == AD) return launch_strip<CW, NW, CO, ST, AD>(a, s);
+    BN_STRIP(32, 1, 32, 1, true)
+    BN_STRIP(64, 1, 64, 1, true)
+    BN_STRIP(32, 4, 128, 1, true)
+    BN_STRIP(32, 1, 32, 1, false)
+    BN_STRIP(64, 1, 64, 1, false)
+    BN_STRIP(32, 1, 64, 1, false)
+    BN_STRIP(64, 1, 32, 1, false)
+    BN_STRIP(32, 4, 128, 1, false)
+    BN_STRIP(32, 2, 128, 1, false)
+    BN_STRIP(32, 1, 32, 2, false)
+    BN_STRIP(32, 1, 64, 2, false)
+    BN_STRIP(64, 1, 32, 2, false)
+    BN_STRIP(64, 1, 64, 2, false)
+    BN_STRIP(32, 4, 128, 2, false)
+    BN_STRIP(32, 2, 128, 2, false)
 #undef BN_STRIP
 }
 

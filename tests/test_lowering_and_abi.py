@@ -249,27 +249,26 @@ def test_context_creation_fails_loudly_without_device():
 
 
 # ------------------------------------------------------------------ strip-kernel constant block (bn_i8_strip.hip)
-def _emulate_strip(cst, x, p):
+def _emulate_strip(cst, x, p, nw):
     """numpy restatement of ``i8_strip_kernel``'s lane arithmetic (csrc/bn_i8_strip.hip) from the packer's constant block:
-    lane (n, kq) owns channels CL kq .. of column n, row-transposed depthwise weights, folded requantisation addends, A
-    fragments with permuted rows, own value + 128 as the table index of the ADD.  x: int8 [B][H][W][C]."""
+    wave w / lane (n, kq) owns channels CW w + CL kq .. of column n, row-transposed depthwise weights, folded requantisation
+    addends, A fragments with permuted rows per channel slice, own value + 128 as the table index of the ADD.
+    x: int8 [B][H][W][C]."""
     H, W, C, S, OH, OW, pt, pl = p[0], p[1], p[2], p[3], p[6], p[7], p[8], p[9]
     z_in, dw_lo, dw_hi, N, pw_zp, pw_lo, pw_hi = p[10], p[12], p[13], p[14], p[15], p[16], p[17]
     add = p[18:29]
-    CL, COL = C // 4, N // 4
-    QL, NT = CL // 4, N // 16
-    o_dww, o_dwb = 0, 4 * QL * 12
-    o_dwc = o_dwb + 4 * QL * 4
-    o_pwa = o_dwc + 4 * QL * 12
-    o_pwb = o_pwa + NT * 64 * QL
-    o_pwc = o_pwb + 4 * NT * 4
-    assert cst.size == o_pwc + 4 * NT * 12
-    dww = cst[o_dww:o_dwb].view(np.int8).reshape(4, QL, 3, 4, 4).astype(np.int64)  # [kq][ql][row][e][tap byte]
-    dwb = cst[o_dwb:o_dwc].reshape(4, QL, 4).astype(np.int64)
-    dwc = cst[o_dwc:o_pwa].reshape(4, QL, 3, 4).astype(np.int64)
-    pwa = cst[o_pwa:o_pwb].view(np.int8).reshape(NT, 64, CL).astype(np.int64)
-    pwb = cst[o_pwb:o_pwc].reshape(4, NT, 4).astype(np.int64)
-    pwc = cst[o_pwc:].reshape(4, NT, 3, 4).astype(np.int64)
+    CW, CWO = C // nw, N // nw
+    CL, COL = CW // 4, CWO // 4
+    QL, NT = CL // 4, CWO // 16
+    sizes = [nw * 4 * QL * 12, nw * 4 * QL * 4, nw * 4 * QL * 12, nw * NT * nw * 64 * QL, nw * 4 * NT * 4, nw * 4 * NT * 12]
+    assert cst.size == sum(sizes)
+    o = np.concatenate([[0], np.cumsum(sizes)])
+    dww = cst[o[0]:o[1]].view(np.int8).reshape(nw, 4, QL, 3, 4, 4).astype(np.int64)  # [w][kq][ql][row][e][tap byte]
+    dwb = cst[o[1]:o[2]].reshape(nw, 4, QL, 4).astype(np.int64)
+    dwc = cst[o[2]:o[3]].reshape(nw, 4, QL, 3, 4).astype(np.int64)
+    pwa = cst[o[3]:o[4]].view(np.int8).reshape(nw, NT, nw, 64, CL).astype(np.int64)
+    pwb = cst[o[4]:o[5]].reshape(nw, 4, NT, 4).astype(np.int64)
+    pwc = cst[o[5]:o[6]].reshape(nw, 4, NT, 3, 4).astype(np.int64)
     assert np.all(dww[..., 3] == 0)
 
     def rq(v, m, c1, e):
@@ -281,17 +280,18 @@ def _emulate_strip(cst, x, p):
     B = x.shape[0]
     xp = np.full((B, H + 2 + S, W + 2 + S, C), z_in, np.int64)
     xp[:, pt:pt + H, pl:pl + W] = x
-    bfrag = np.zeros((B, OH, OW, 4, CL), np.int64)  # [.. position][kq][k byte of the lane]
-    for kq in range(4):
-        for ql in range(QL):
-            for e in range(4):
-                c = CL * kq + 4 * ql + e
-                acc = np.full((B, OH, OW), dwb[kq, ql, e])
-                for i in range(3):
-                    for j in range(3):
-                        acc = acc + xp[:, i:i + S * OH:S, j:j + S * OW:S, c] * dww[kq, ql, i, e, j]
-                m, c1, sh = dwc[kq, ql, :, e]
-                bfrag[..., kq, 4 * ql + e] = np.clip(rq(acc, m, c1, sh), dw_lo, dw_hi)
+    bfrag = np.zeros((B, OH, OW, nw, 4, CL), np.int64)  # [.. position][wave][kq][k byte of the lane]
+    for w in range(nw):
+        for kq in range(4):
+            for ql in range(QL):
+                for e in range(4):
+                    c = CW * w + CL * kq + 4 * ql + e
+                    acc = np.full((B, OH, OW), dwb[w, kq, ql, e])
+                    for i in range(3):
+                        for j in range(3):
+                            acc = acc + xp[:, i:i + S * OH:S, j:j + S * OW:S, c] * dww[w, kq, ql, i, e, j]
+                    m, c1, sh = dwc[w, kq, ql, :, e]
+                    bfrag[..., w, kq, 4 * ql + e] = np.clip(rq(acc, m, c1, sh), dw_lo, dw_hi)
     y = np.zeros((B, OH, OW, N), np.int64)
     off = 128 if add[0] else 0
     if add[0]:
@@ -301,19 +301,21 @@ def _emulate_strip(cst, x, p):
         lut0 = qz.requantize((np.arange(256).astype(np.int8).astype(np.int64) - z1) << 20, m1, s1)  # index: residual byte pattern
         lut1 = qz.requantize((np.arange(256, dtype=np.int64) - 128 - pw_zp) << 20, m2, s2)            # index: own value + 128
         c1o = (1 << (-so - 1)) + (zo << -so)
-    for t in range(NT):
-        for mrow in range(16):
-            q, reg = mrow >> 2, mrow & 3
-            acc = np.full((B, OH, OW), pwb[q, t, reg])
-            for kq in range(4):
-                acc = acc + (bfrag[..., kq, :] * pwa[t, 16 * kq + mrow]).sum(axis=-1)
-            m, c1, sh = pwc[q, t, :, reg]
-            v = np.clip(rq(acc, m, c1, sh), pw_lo + off, pw_hi + off)
-            ch = COL * q + 4 * t + reg
-            if add[0]:
-                res = x[..., ch].view(np.uint8).astype(np.int64)  # centre tap of the lane's own channel group
-                v = np.clip(rq(lut0[res] + lut1[v], mo, c1o, -so), alo, ahi)
-            y[..., ch] = v
+    for w in range(nw):
+        for t in range(NT):
+            for mrow in range(16):
+                q, reg = mrow >> 2, mrow & 3
+                acc = np.full((B, OH, OW), pwb[w, q, t, reg])
+                for ks in range(nw):
+                    for kq in range(4):
+                        acc = acc + (bfrag[..., ks, kq, :] * pwa[w, t, ks, 16 * kq + mrow]).sum(axis=-1)
+                m, c1, sh = pwc[w, q, t, :, reg]
+                v = np.clip(rq(acc, m, c1, sh), pw_lo + off, pw_hi + off)
+                ch = CWO * w + COL * q + 4 * t + reg
+                if add[0]:
+                    res = x[..., ch].view(np.uint8).astype(np.int64)  # centre tap of the lane's own channel group
+                    v = np.clip(rq(lut0[res] + lut1[v], mo, c1o, -so), alo, ahi)
+                y[..., ch] = v
     return y.astype(np.int8)
 
 
@@ -331,7 +333,7 @@ def test_strip_constant_block_reproduces_the_oracle():
 
     plan = lower_model_file(TFLITE_PATH, keep_all=True, fuse=True)
     strip_ops = [o for o in plan.ops if o.kind == pk.I8_DWPW and o.p[35]]
-    assert [o.name for o in strip_ops] == ["t102", "t104", "t107", "t110"]
+    assert [o.name for o in strip_ops] == ["t102", "t104", "t107", "t110", "t112", "t115", "t118", "t121"]
     S = np.stack([stft.hybrid_spectrogram(a) for a in synth_chunks(2)])[..., None]
     _, env = Int8Interpreter(load_tflite(TFLITE_PATH)).invoke(S, return_all=True)
     by_val = {o.out: o for o in plan.ops}
@@ -341,5 +343,9 @@ def test_strip_constant_block_reproduces_the_oracle():
         want = env[int(o.name[1:])].reshape(2, o.p[6], o.p[7], o.p[14])
         if o.p[18]:
             assert o.in1 == o.in0  # the residual is the block input
-        got = _emulate_strip(np.asarray(plan.tensors[o.t[9]], np.int32), x, o.p)
+        from birdnet_stm32.models._lower_i8 import strip_waves
+
+        nw = strip_waves(o.p[2], o.p[14], o.p[3], o.p[7], bool(o.p[18]))
+        assert nw == {32: 1, 64: 1 if o.p[14] <= 64 else 2, 128: 4}[o.p[2]]
+        got = _emulate_strip(np.asarray(plan.tensors[o.t[9]], np.int32), x, o.p, nw)
         assert np.array_equal(got, want), f"{o.name}: {(got != want).sum()} of {got.size} values differ"
