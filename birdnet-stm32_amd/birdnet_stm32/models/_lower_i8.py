@@ -196,6 +196,50 @@ def strip_constants(wd, bdw, mu, sh, z_dw_out, w2, b2, mu2, sh2, z_pw_out, add: 
     return np.concatenate(sec).astype(np.int32)
 
 
+def front_strip_constants(ws, bs, mus, shs, z_fe, z_st, wd, bdw, mud, shd, z_dw, w2, b2, mu2, sh2, z_pw) -> np.ndarray | None:
+    """Constant block of ``i8_front_strip_kernel`` (csrc/bn_i8_strip.hip), int32 words.  ``ws`` [3][3][16] stem weights,
+    ``bs`` stem bias (unfolded), ``wd`` [3][3][16] depthwise weights with folded bias ``bdw``, ``w2`` [32][16] pointwise
+    weights with folded bias ``b2``.  Lane (n, kq) holds channel quad kq.  Sections: stem A fragments ``[lane]`` = bytes
+    (w[kq][0][m], w[kq][1][m], w[kq][2][m], 0) for lane (m, kq), 0 for kq = 3 (contraction index 8 * window row + column);
+    stem bias with ``-zp_fe * sum(w)`` folded ``[q][reg]``; stem (multiplier, c1, e) ``[q][3][reg]``; depthwise weights
+    ``[kq][row][e]`` as bytes (tap0, tap1, tap2, 0); depthwise bias ``[kq][e]``, (multiplier, c1, e) ``[kq][3][e]``; pointwise A
+    fragments ``[t][lane]`` = ``W[8 (m >> 2) + 4 t + (m & 3)][4 kq : 4 kq + 4]``; pointwise bias ``[q][t][reg]`` and
+    (multiplier, c1, e) ``[q][t][3][reg]`` for channel ``8 q + 4 t + reg``."""
+    ws, wd, w2 = np.asarray(ws, np.int8), np.asarray(wd, np.int8), np.asarray(w2, np.int8)
+    if ws.shape != (3, 3, 16) or wd.shape != (3, 3, 16) or w2.shape != (32, 16):
+        return None
+    ws64, wd64, w264 = ws.astype(np.int64), wd.astype(np.int64), w2.astype(np.int64)
+    bsf = np.asarray(bs, np.int64) - z_fe * ws64.sum(axis=(0, 1))
+    rng = lambda w, b, ax: (np.minimum(-128 * w, 127 * w).sum(axis=ax) + b, np.maximum(-128 * w, 127 * w).sum(axis=ax) + b)  # noqa: E731
+    rq_st = _strip_requant(mus, shs, z_st, *rng(ws64, bsf, (0, 1)))
+    rq_dw = _strip_requant(mud, shd, z_dw, *rng(wd64, np.asarray(bdw, np.int64), (0, 1)))
+    rq_pw = _strip_requant(mu2, sh2, z_pw, *rng(w264, np.asarray(b2, np.int64), 1))
+    if rq_st is None or rq_dw is None or rq_pw is None or np.abs(bsf).max() >= 2**31:
+        return None
+    lane = np.arange(64)
+    m_, kq_ = lane & 15, lane >> 4
+    sta = np.zeros((64, 4), np.int8)
+    for j in range(3):
+        sta[:, j] = np.where(kq_ < 3, ws[np.minimum(kq_, 2), j, m_], 0)
+    quad = 4 * np.arange(4)[:, None] + np.arange(4)[None, :]  # [q][reg] -> channel
+    dww = np.zeros((4, 3, 4, 4), np.uint8)
+    for i in range(3):
+        for j in range(3):
+            dww[:, i, :, j] = wd[i, j][quad].view(np.uint8)
+    pwa = np.zeros((2, 64, 4), np.int8)
+    for t in range(2):
+        ch = 8 * (m_ >> 2) + 4 * t + (m_ & 3)
+        for k in range(4):
+            pwa[t, :, k] = w2[ch, 4 * kq_ + k]
+    ch_out = 8 * np.arange(4)[:, None, None] + 4 * np.arange(2)[None, :, None] + np.arange(4)[None, None, :]  # [q][t][reg]
+    sec = [sta.view(np.int32).reshape(-1), bsf.astype(np.int32)[quad].reshape(-1), np.stack([r[quad] for r in rq_st], axis=1).reshape(-1),
+           dww.view(np.int32).reshape(-1), np.asarray(bdw, np.int32)[quad].reshape(-1), np.stack([r[quad] for r in rq_dw], axis=1).reshape(-1),
+           pwa.view(np.int32).reshape(-1), np.asarray(b2, np.int32)[ch_out].reshape(-1), np.stack([r[ch_out] for r in rq_pw], axis=2).reshape(-1)]
+    out = np.concatenate(sec).astype(np.int32)
+    assert out.size == 496
+    return out
+
+
 def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse; ``fuse=False`` keeps the
     baseline one-kernel-per-operator plan instead of the fused matrix-core blocks."""
@@ -337,10 +381,12 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                     wpw = wtp.data.reshape(N, Cout)
                     bp = bp - zp_ * wpw.astype(np.int64).sum(axis=1)
                     v = pb.value(BH * BW * N)
-                    pb.op(pk.I8_FRONT, val[src], v, p=[H, Wd, Cout, N, BH, BW, z_i, z_o, a_lo, a_hi, zdo, dlo, dhi, zpo, plo, phi],
+                    cst = front_strip_constants(w, b, mu, sh, z_i, z_o, wtd.data[0], bd, mud, shd, zdo, wpw, bp, mup, shp, zpo) if BW % 16 == 0 else None
+                    pb.op(pk.I8_FRONT, val[src], v, p=[H, Wd, Cout, N, BH, BW, z_i, z_o, a_lo, a_hi, zdo, dlo, dhi, zpo, plo, phi, int(cst is not None)],
                           t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
                              pb.tensor(wtd.data[0], np.int8), pb.tensor(bd, np.int32), pb.tensor(mud, np.int32), pb.tensor(shd, np.int32),
-                             pb.tensor(pack_i8_fragments(wpw), np.int8), pb.tensor(bp, np.int32), pb.tensor(mup, np.int32), pb.tensor(shp, np.int32)],
+                             pb.tensor(pack_i8_fragments(wpw), np.int8), pb.tensor(bp, np.int32), pb.tensor(mup, np.int32), pb.tensor(shp, np.int32),
+                             pb.tensor(cst, np.int32) if cst is not None else -1],
                           name=f"t{p_op.outputs[0]}", out_shape=(BH, BW, N), out_dtype="int8")
                     val[p_op.outputs[0]], shape[p_op.outputs[0]] = v, (BH, BW, N)
                     i += 3

@@ -16,7 +16,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 BLOB_MAGIC = b"BNHIPM01"
-BLOB_VERSION = 4
+BLOB_VERSION = 5
 
 DTYPE_F32, DTYPE_I8 = 0, 1
 INPUT_SPECTROGRAM, INPUT_WAVEFORM, INPUT_MEL = 0, 1, 2
@@ -24,7 +24,7 @@ INPUT_SPECTROGRAM, INPUT_WAVEFORM, INPUT_MEL = 0, 1, 2
 SLOT_INPUT, SLOT_SCORES, SLOT_LOGITS, SLOT_AUDIO, SLOT_NONE = -1, -2, -3, -4, -9
 OP_PATH, PATH_BOTH, PATH_INPUT, PATH_AUDIO = 39, 0, 1, 2
 
-OP_NP, OP_NT, OP_NF = 40, 12, 8
+OP_NP, OP_NT, OP_NF = 40, 16, 8
 
 # operator kinds (enum BnOpKind)
 F32_MEL, F32_MAG, F32_RAWFE, F32_STEM, F32_DW, F32_PW = 1, 2, 3, 4, 5, 6

@@ -299,6 +299,12 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 q.stem_zp_in = p[6]; q.stem_zp_out = p[7]; q.stem_amin = p[8]; q.stem_amax = p[9];
                 q.dw_zp_out = p[10]; q.dw_amin = p[11]; q.dw_amax = p[12]; q.pw_zp_out = p[13]; q.pw_amin = p[14]; q.pw_amax = p[15];
                 q.rq_right = m->rq_right[oi];
+                if (p[16] && o.t[12] >= 0 && m->use_strip && bn::i8_front_strip_supported(q.H0, q.W0, q.C, q.N, q.OH, q.OW)) {
+                    bn::FrontStrip8Args fa{(const int8_t*)in0, (int8_t*)out, (const int32_t*)m->tensor(o.t[12]), B, q.H0, q.W0, q.OH, q.OW, 0,
+                                           q.stem_zp_in, q.stem_amin, q.stem_amax, q.stem_zp_out, q.dw_amin, q.dw_amax, q.pw_amin, q.pw_amax};
+                    bn::launch_i8_front_strip(fa, s);
+                    break;
+                }
                 if (!bn::i8_front_supported(q.H0, q.W0, q.C, q.N, q.OH, q.OW))
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported INT8 front-block geometry", oi);
                 bn::launch_i8_front(q, (const int8_t*)in0, (int8_t*)out, B, s);

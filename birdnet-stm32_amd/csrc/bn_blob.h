@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 #define BN_BLOB_MAGIC "BNHIPM01"
-#define BN_BLOB_VERSION 4u
+#define BN_BLOB_VERSION 5u
 
 #define BN_SLOT_INPUT (-1)
 #define BN_SLOT_SCORES (-2)
@@ -57,7 +57,7 @@ struct TensorRec {
 };
 
 #define BN_OP_NP 40
-#define BN_OP_NT 12
+#define BN_OP_NT 16
 #define BN_OP_NF 8
 
 struct OpRec {

@@ -315,6 +315,154 @@ void launch_strip(const Strip8Args& a, hipStream_t s) {
         hipLaunchKernelGGL((i8_strip_kernel<CW, NW, COUT, S, ADD>), dim3((unsigned)strips), dim3(64 * NW), 0, s, a);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Front block in the same style: frontend output [H0][W0] int8 -> CONV_2D 3x3 stem (stride 1x2, 16 channels, ReLU6) ->
+// DEPTHWISE_CONV_2D 3x3 stride 2 (ReLU6) -> CONV_2D 1x1 to 32 channels (ReLU6); bit-identical to i8_front_kernel.
+//
+// A wave owns 16 output columns and walks down the output rows; lane (n, kq) = (output column, channel quad).  The stem
+// runs on the matrix cores as well: with the contraction index K = 8 * (window row) + (window column), lane (n, kq) of the
+// B operand holds the three bytes fe[sr - 1 + kq][2 sc .. 2 sc + 2] of its OWN input row — every lane streams input row
+// (stem row - 1 + kq), so a B fragment is one AND / byte-permute of the two dwords it loaded, and the result lands as the
+// four channels 4 q .. 4 q + 3 of stem column sc in lane (n, q): exactly the quad the depthwise stage of that lane needs.
+// Three MFMAs per stem row give stem columns 2 ow, 2 ow + 1, 2 ow + 2 (the three taps of the stride-2 depthwise window);
+// what remains on the vector ALU is the requantisation of each value and the byte shuffles.
+constexpr int kF_STA = 0, kF_STB = 64, kF_STC = 80, kF_DWW = 128, kF_DWB = 176, kF_DWC = 192, kF_PWA = 240, kF_PWB = 368, kF_PWC = 400;
+
+__global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int strips_x = a.OW >> 4;
+    const int rblocks = (a.OH + a.TH - 1) / a.TH;
+    int wid = xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wid >= a.B * strips_x * rblocks) return;
+    const int sx = wid % strips_x;
+    wid /= strips_x;
+    const int ry = wid % rblocks;
+    const int chunk = wid / rblocks;
+    const int oh0 = ry * a.TH;
+    const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
+    const int ow = sx * 16 + n;
+
+    const v4i* c4 = reinterpret_cast<const v4i*>(a.cst);
+    const long sta = (long)(uint32_t)a.cst[kF_STA + lane];
+    const v4i stb = c4[kF_STB / 4 + kq];
+    const v4i stm = c4[kF_STC / 4 + kq * 3 + 0], stc1 = c4[kF_STC / 4 + kq * 3 + 1], ste = c4[kF_STC / 4 + kq * 3 + 2];
+    int dww[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const v4i v = c4[kF_DWW / 4 + kq * 3 + i];
+        dww[i][0] = v.x; dww[i][1] = v.y; dww[i][2] = v.z; dww[i][3] = v.w;
+    }
+    const v4i dwb = c4[kF_DWB / 4 + kq];
+    const v4i dwm = c4[kF_DWC / 4 + kq * 3 + 0], dwc1 = c4[kF_DWC / 4 + kq * 3 + 1], dwe = c4[kF_DWC / 4 + kq * 3 + 2];
+    long pwa[2];
+    v4i pwb[2], pwm[2], pwc1[2], pwe[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        pwa[t] = (long)(uint32_t)a.cst[kF_PWA + t * 64 + lane];
+        pwb[t] = c4[kF_PWB / 4 + kq * 2 + t];
+        pwm[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 0];
+        pwc1[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 1];
+        pwe[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 2];
+    }
+
+    const int zfe4 = (a.zp_fe & 0xff) * 0x01010101;
+    const int zst4 = (a.zp_st & 0xff) * 0x01010101;
+    const int zstrow = (a.zp_st & 0xff) * 0x00010101;
+    const int fe_bytes = a.H0 * a.W0;
+    const __amdgpu_buffer_rsrc_t rs_fe =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.fe) + (size_t)chunk * fe_bytes, 0, fe_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)chunk * a.OH * a.OW * 32, 0, a.OH * a.OW * 32, 0x00020000);
+    const bool right_fe = 4 * ow + 4 >= a.W0;       // second dword of the row lies beyond the input: stem padding column
+    const bool right_st = 2 * ow + 2 >= a.W0 / 2;   // third stem column lies beyond the stem map: depthwise padding column
+    const int voff_out = ow * 32 + 8 * kq;
+    const int sr0 = 2 * oh0;                        // first stem row of the strip (depthwise: stride 2, no top padding)
+    const int rows_needed = 2 * (nrows - 1) + 3;
+
+    v2i raw[2];
+    TRow<1> T[3];
+
+    // stem row sr0 + srel: lane (n, kq) reads input row sr - 1 + kq (the stem's top padding is row -1)
+    auto fe_row = [&](int srel) { return sr0 + srel - 1 + kq; };
+    auto issue = [&](int slot, int srel) {
+        if (srel < rows_needed) {
+            int fr = fe_row(srel);
+            fr = fr < 0 ? 0 : (fr >= a.H0 ? a.H0 - 1 : fr);  // padding rows load a valid row, replaced below
+            raw[slot] = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rs_fe, fr * a.W0 + 4 * ow, 0, 0));
+        }
+    };
+    auto stem_row = [&](int slot, int srel, int ti) {
+        if (srel < rows_needed && sr0 + srel < a.H0) {
+            const int fr = fe_row(srel);
+            const bool ok = fr >= 0 && fr < a.H0;
+            const int A = ok ? raw[slot].x : zfe4;
+            const int Bd = (ok && !right_fe) ? raw[slot].y : zfe4;
+            const int x[3] = {A & 0x00ffffff, perm(Bd, A, 0x0c040302u), Bd & 0x00ffffff};
+            int pk[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(sta, (long)(uint32_t)x[j], stb, 0, 0, 0);
+                int qv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qv[e] = med3(rq(acc[e], stm[e], stc1[e], ste[e]), a.st_lo, a.st_hi);
+                pk[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+            }
+            if (right_st) pk[2] = zst4;
+            const int lo = perm(pk[1], pk[0], 0x05010400u);
+            const int hi = perm(pk[1], pk[0], 0x07030602u);
+            T[ti].c[0][0] = perm(pk[2], lo, 0x0c040100u);
+            T[ti].c[0][1] = perm(pk[2], lo, 0x0c050302u);
+            T[ti].c[0][2] = perm(pk[2], hi, 0x0c060100u);
+            T[ti].c[0][3] = perm(pk[2], hi, 0x0c070302u);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[ti].c[0][e] = zstrow;
+        }
+    };
+    auto emit = [&](int i0, int i1, int i2, int oh) {
+        int qv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int acc = dot4_first(T[i0].c[0][e], dww[0][e], dwb[e]);
+            acc = dot4(T[i1].c[0][e], dww[1][e], acc);
+            acc = dot4(T[i2].c[0][e], dww[2][e], acc);
+            qv[e] = med3(rq(acc, dwm[e], dwc1[e], dwe[e]), a.dw_lo, a.dw_hi);
+        }
+        const long bf = (long)(uint32_t)perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+        int outw[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(pwa[t], bf, pwb[t], 0, 0, 0);
+            int ov[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = med3(rq(acc[e], pwm[t][e], pwc1[t][e], pwe[t][e]), a.pw_lo, a.pw_hi);
+            outw[t] = perm(perm(ov[3], ov[2], 0x0c0c0400u), perm(ov[1], ov[0], 0x0c0c0400u), 0x05040100u);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, oh * a.OW * 32, 0);
+    };
+
+    issue(0, 0);
+    issue(1, 1);
+    stem_row(0, 0, 0);
+    issue(0, 2);
+    for (int k = 0; k < nrows; k += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (k + u >= nrows) break;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int rs = 1 + 2 * u + s;  // static part of the relative stem row (k is a multiple of 3 output rows)
+                stem_row(rs & 1, 2 * k + rs, rs % 3);
+                issue(rs & 1, 2 * k + rs + 2);
+            }
+            emit((2 * u) % 3, (2 * u + 1) % 3, (2 * u + 2) % 3, oh0 + k + u);
+        }
+    }
+}
+
 }  // namespace
 
 // channel split of a block: waves per strip (1 = a wave holds all input channels); 0 = no strip kernel for this shape
@@ -360,6 +508,22 @@ void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s)
     BN_STRIP(32, 4, 128, 2, false)
     BN_STRIP(32, 2, 128, 2, false)
 #undef BN_STRIP
+}
+
+bool i8_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW) {
+    return C == 16 && N == 32 && OW % 16 == 0 && H0 == 2 * OH && W0 == 4 * OW && W0 % 4 == 0;
+}
+
+void launch_i8_front_strip(FrontStrip8Args a, hipStream_t s) {
+    int th = a.OH;
+    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 16384) th = (th + 1) / 2;
+    if (const char* e = getenv("BN_I8_STRIP_TH")) {
+        const int v = atoi(e);
+        if (v >= 1) th = v < a.OH ? v : a.OH;
+    }
+    a.TH = th;
+    const long waves = (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th);
+    hipLaunchKernelGGL(i8_front_strip_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
 }
 
 }  // namespace bn

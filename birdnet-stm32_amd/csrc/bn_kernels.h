@@ -152,6 +152,15 @@ struct Strip8Args {
     I8AddParams add;
     int add_c1;
 };
+struct FrontStrip8Args {
+    const int8_t* fe;   // [B][H0][W0]
+    int8_t* y;          // [B][OH][OW][32]
+    const int32_t* cst; // models/_lower_i8.py: front_strip_constants
+    int B, H0, W0, OH, OW, TH;
+    int zp_fe, st_lo, st_hi, zp_st, dw_lo, dw_hi, pw_lo, pw_hi;
+};
+bool i8_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW);
+void launch_i8_front_strip(FrontStrip8Args a, hipStream_t s);
 bool i8_strip_supported(int Cin, int Cout, int stride, int OW, bool add);
 void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s);
 // INT8 stem 3x3 + depthwise 3x3 stride 2 + pointwise in one kernel (bn_i8_fused.hip)

@@ -170,7 +170,7 @@ def test_i8_graph_bit_exact_per_tensor(torch_mod, oracle_specs, fuse):
 
 
 def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypatch):
-    """The wave-autonomous strip kernel (stage 1-2 blocks) against the generic fused block: every tensor bit for bit, for
+    """The wave-autonomous strip kernels (front block, stage 1-3 blocks) against the generic fused kernels: every tensor bit for bit, for
     rows-per-wave values that put the strip borders everywhere (1, 3, 5, 7 rows, whole map), and a batch large enough for
     the launcher's own choice."""
     from birdnet_stm32.models import _pack as pk
@@ -182,8 +182,8 @@ def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypa
     monkeypatch.setenv("BN_I8_STRIP", "0")
     runner = load_model_runner(TFLITE_PATH, max_batch=B, keep_all=True)
     want_scores = runner.predict(x)
-    strip_ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.I8_DWPW and op.p[35]]
-    assert len(strip_ops) == 8
+    strip_ops = [oi for oi, op in enumerate(runner.plan.ops) if (op.kind == pk.I8_DWPW and op.p[35]) or (op.kind == pk.I8_FRONT and op.p[16])]
+    assert len(strip_ops) == 9
     want = {oi: runner.op_output(oi, B) for oi in strip_ops}
     runner.close()
     monkeypatch.setenv("BN_I8_STRIP", "1")

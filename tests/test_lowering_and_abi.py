@@ -349,3 +349,80 @@ def test_strip_constant_block_reproduces_the_oracle():
         assert nw == {32: 1, 64: 1 if o.p[14] <= 64 else 2, 128: 4}[o.p[2]]
         got = _emulate_strip(np.asarray(plan.tensors[o.t[9]], np.int32), x, o.p, nw)
         assert np.array_equal(got, want), f"{o.name}: {(got != want).sum()} of {got.size} values differ"
+
+
+def _emulate_front_strip(cst, fe, p):
+    """numpy restatement of ``i8_front_strip_kernel`` from its constant block: the stem as a matrix product with contraction
+    index 8 * (window row) + column, lane (n, kq) reading input row (stem row - 1 + kq).  fe: int8 [B][H0][W0]."""
+    H0, W0, OH, OW = p[0], p[1], p[4], p[5]
+    z_fe, z_st, st_lo, st_hi, dw_lo, dw_hi, pw_lo, pw_hi = p[6], p[7], p[8], p[9], p[11], p[12], p[14], p[15]
+    sta = cst[0:64].view(np.int8).reshape(64, 4).astype(np.int64)
+    stb = cst[64:80].reshape(4, 4).astype(np.int64)
+    stc = cst[80:128].reshape(4, 3, 4).astype(np.int64)
+    dww = cst[128:176].view(np.int8).reshape(4, 3, 4, 4).astype(np.int64)
+    dwb = cst[176:192].reshape(4, 4).astype(np.int64)
+    dwc = cst[192:240].reshape(4, 3, 4).astype(np.int64)
+    pwa = cst[240:368].view(np.int8).reshape(2, 64, 4).astype(np.int64)
+    pwb = cst[368:400].reshape(4, 2, 4).astype(np.int64)
+    pwc = cst[400:496].reshape(4, 2, 3, 4).astype(np.int64)
+    assert np.all(sta[48:] == 0) and np.all(sta[:, 3] == 0)
+
+    def rq(v, m, c1, e):
+        t = (v * m + (1 << 30)) >> 31
+        r = t + c1 + (t >> 63)
+        assert np.abs(r).max() < 2**31 and np.abs(t).max() < 2**31
+        return r >> e
+
+    B = fe.shape[0]
+    fp = np.full((B, H0 + 2, W0 + 2), z_fe, np.int64)
+    fp[:, 1:H0 + 1, :W0] = fe
+    SH, SW = H0, W0 // 2
+    stem = np.full((B, SH + 1, SW + 1, 16), z_st, np.int64)
+    for q in range(4):
+        for reg in range(4):
+            c = 4 * q + reg
+            acc = np.full((B, SH, SW), stb[q, reg])
+            for kq in range(3):
+                for j in range(3):
+                    acc = acc + fp[:, kq:kq + SH, j:j + 2 * SW:2] * sta[16 * kq + c, j]
+            stem[:, :SH, :SW, c] = np.clip(rq(acc, *stc[q, :, reg]), st_lo, st_hi)
+    dwq = np.zeros((B, OH, OW, 16), np.int64)
+    for kq in range(4):
+        for e in range(4):
+            acc = np.full((B, OH, OW), dwb[kq, e])
+            for i in range(3):
+                for j in range(3):
+                    acc = acc + stem[:, i:i + 2 * OH:2, j:j + 2 * OW:2, 4 * kq + e] * dww[kq, i, e, j]
+            dwq[..., 4 * kq + e] = np.clip(rq(acc, *dwc[kq, :, e]), dw_lo, dw_hi)
+    y = np.zeros((B, OH, OW, 32), np.int64)
+    for q in range(4):
+        for t in range(2):
+            for reg in range(4):
+                acc = np.full((B, OH, OW), pwb[q, t, reg])
+                for kq in range(4):
+                    acc = acc + (dwq[..., 4 * kq:4 * kq + 4] * pwa[t, 16 * kq + 4 * q + reg]).sum(axis=-1)
+                y[..., 8 * q + 4 * t + reg] = np.clip(rq(acc, *pwc[q, t, :, reg]), pw_lo, pw_hi)
+    return y.astype(np.int8)
+
+
+def test_front_strip_constant_block_reproduces_the_oracle():
+    """The INT8 front block (stem on the matrix cores + depthwise + pointwise) restated from the strip kernel's constant
+    block: bit-identical to the oracle's tensor after the first pointwise convolution."""
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models._tflite_reader import load_tflite
+    from birdnet_stm32.models.runners import lower_model_file
+    from oracle import stft
+    from oracle.int8_graph import Int8Interpreter
+
+    from conftest import synth_chunks
+
+    plan = lower_model_file(TFLITE_PATH, keep_all=True, fuse=True)
+    (o,) = [o for o in plan.ops if o.kind == pk.I8_FRONT]
+    assert o.p[16] == 1 and o.t[12] >= 0
+    S = np.stack([stft.hybrid_spectrogram(a) for a in synth_chunks(2)])[..., None]
+    _, env = Int8Interpreter(load_tflite(TFLITE_PATH)).invoke(S, return_all=True)
+    src = {q.out: q for q in plan.ops}[o.in0]
+    fe = env[int(src.name[1:])].reshape(2, o.p[0], o.p[1])
+    want = env[int(o.name[1:])].reshape(2, o.p[4], o.p[5], o.p[3])
+    got = _emulate_front_strip(np.asarray(plan.tensors[o.t[12]], np.int32), fe, o.p)
+    assert np.array_equal(got, want), f"{(got != want).sum()} of {got.size} values differ"
