@@ -131,6 +131,8 @@ def strip_waves(cin: int, cout: int, stride: int, ow: int, add: bool) -> int:
     """Waves sharing one strip (channel split) — mirrors ``i8_strip_waves`` in csrc/bn_i8_strip.hip; 0 = no strip kernel."""
     if ow % 16 or stride not in (1, 2) or (add and (stride != 1 or cin != cout)):
         return 0
+    if (cin, cout) == (64, 64):
+        return 2
     if cin in (32, 64) and cout in (32, 64):
         return 1
     if add:
@@ -140,6 +142,18 @@ def strip_waves(cin: int, cout: int, stride: int, ow: int, add: bool) -> int:
     if (cin, cout) == (128, 128):
         return 4
     return 0
+
+
+def add_table(add_p, z_own: int) -> np.ndarray:
+    """The whole TFLite int8 ADD as a function of two bytes: int8 ``[256][256]``, row = byte pattern of the residual, column =
+    the block's own value + 128.  ``add_p`` = [1, z_res, m_res, s_res, m_own, s_own, m_out, s_out, z_out, amin, amax]."""
+    _, z1, m1, s1, m2, s2, mo, so, zo, amin, amax = add_p
+    res = np.arange(256).astype(np.uint8).view(np.int8).astype(np.int64)
+    own = np.arange(256, dtype=np.int64) - 128
+    sa = qz.requantize((res - z1) << 20, m1, s1)
+    sb = qz.requantize((own - z_own) << 20, m2, s2)
+    out = np.clip(qz.requantize(sa[:, None] + sb[None, :], mo, so) + zo, amin, amax)
+    return out.astype(np.int8)
 
 
 def strip_constants(wd, bdw, mu, sh, z_dw_out, w2, b2, mu2, sh2, z_pw_out, add: bool, nw: int = 1) -> np.ndarray | None:
@@ -441,14 +455,15 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                 cst = None
                 ow_ = np.arange(OW)
                 nw = strip_waves(C, Cout, sh_, OW, bool(add_p[0])) if sh_ == sw_ else 0
-                if (nw and (not add_p[0] or (res_val == val[src] and add_p[6] >= 0 and -STRIP_MAX_SHIFT <= add_p[7] < 0))
+                if (nw and (not add_p[0] or res_val == val[src])
                         and ((ow_ * sw_ - pl + 1 >= 0) & (ow_ * sw_ - pl + 1 < Wd)).all()):
                     cst = strip_constants(wt_.data[0], bdw, mu, sh, z_o, w2, b2, mu2, sh2, zo2, bool(add_p[0]), nw)
                 p = [H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi, Cout, zo2, lo2, hi2, *add_p, 1, 0, *tile, 0, int(cst is not None)]
                 pb.op(pk.I8_DWPW, val[src], v, p=p, in1=res_val,
                       t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(bdw, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
                          pb.tensor(pack_i8_fragments(w2), np.int8), pb.tensor(b2, np.int32), pb.tensor(mu2, np.int32), pb.tensor(sh2, np.int32),
-                         -1, pb.tensor(cst, np.int32) if cst is not None else -1],
+                         -1, pb.tensor(cst, np.int32) if cst is not None else -1,
+                         pb.tensor(add_table(add_p, zo2), np.int8) if cst is not None and add_p[0] else -1],
                       name=f"t{out_t}", out_shape=(OH, OW, Cout), out_dtype="int8")
                 val[out_t], shape[out_t] = v, (OH, OW, Cout)
                 i += 2

@@ -275,10 +275,12 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 a.rq_right = m->rq_right[oi];
                 // wide early layers: wave-autonomous strip kernel when the packer prepared its constant block
                 if (p[35] && o.t[9] >= 0 && m->use_strip && a.has_dw && !a.transposed && a.sh == a.sw &&
-                    bn::i8_strip_supported(a.Cin, a.Cout, a.sh, a.OW, a.add.enabled != 0) && (!a.add.enabled || a.res == a.x)) {
+                    bn::i8_strip_supported(a.Cin, a.Cout, a.sh, a.OW, a.add.enabled != 0) &&
+                    (!a.add.enabled || (a.res == a.x && o.t[10] >= 0))) {
                     const int off = a.add.enabled ? 128 : 0;
                     bn::Strip8Args q{a.x, a.y, (const int32_t*)m->tensor(o.t[9]), B, a.H, a.W, a.OH, a.OW, 0, a.pt, a.pl,
-                                     a.dw_zp_in, a.dw_amin, a.dw_amax, a.pw_amin + off, a.pw_amax + off, a.pw_zp_out, a.add, 0};
+                                     a.dw_zp_in, a.dw_amin, a.dw_amax, a.pw_amin + off, a.pw_amax + off, a.pw_zp_out, a.add,
+                                     a.add.enabled ? (const int8_t*)m->tensor(o.t[10]) : nullptr};
                     bn::launch_i8_strip(q, a.Cin, a.Cout, a.sh, s);
                     break;
                 }

@@ -82,12 +82,16 @@ __device__ __forceinline__ RawRow<QL> load_row(__amdgpu_buffer_rsrc_t rsrc, cons
     return r;
 }
 
-// CW = input channels per wave (32 or 64; 32 when NW > 1), NW = waves sharing a strip (channel split), COUT = all output channels
+// CW = input channels per wave (32 or 64; 32 when NW > 1), NW = waves sharing a strip (channel split), COUT = all output channels.
+// Strips per workgroup: 4 single-wave strips, or one NW-wave strip; with the ADD 8 / 2, so that the 64 KB table is shared by 512
+// threads and two workgroups (16 waves) fit a CU.
 template <int CW, int NW, int COUT, int S, bool ADD>
-__global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip8Args a) {
+__global__ __launch_bounds__(64 * NW * (ADD ? 8 / NW : (NW == 1 ? 4 : 1))) __attribute__((amdgpu_waves_per_eu(CW == 32 ? 4 : 2)))
+void i8_strip_kernel(Strip8Args a) {
     constexpr int CIN = CW * NW, CL = CW / 4, QL = CL / 4;
     constexpr int CWO = COUT / NW, NT = CWO / 16, COL = CWO / 4;  // output channels per wave / tiles per wave / per lane
-    constexpr int NTHREADS = NW == 1 ? 256 : 64 * NW;
+    constexpr int SPB = ADD ? 8 / NW : (NW == 1 ? 4 : 1);
+    constexpr int NTHREADS = 64 * NW * SPB;
     static_assert(NW == 1 || CW == 32, "the channel split works on 32-channel slices");
     static_assert(!ADD || (CIN == COUT && S == 1), "the residual is the block input");
     static_assert(NT == 2 || NT == 4, "8 or 16 output channels per lane");
@@ -99,36 +103,50 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip
     constexpr int kPWA = kDWC + NW * nDWC;    // [w][t][ks][lane][QL]
     constexpr int kPWB = kPWA + NW * nPWA;    // [w][q][t][reg]
     constexpr int kPWC = kPWB + NW * nPWB;    // [w][q][t][kind 3][reg]
-    __shared__ v4i c_dw[NW * nDWC / 4];
-    __shared__ v4i c_pw[NW * nPWC / 4];
-    __shared__ int add_lut[2][256];
-    __shared__ v2i xchg[NW > 1 ? 2 * NW * 64 : 1];  // [buffer][wave][lane]: B fragments of the current output row
+    // LDS (dynamic: the ADD table alone is 64 KB): [ADD table 65536 B] [c_dw] [c_pw] [xchg]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    const unsigned char* add_tab = lds_all;   // [residual byte pattern][own value + 128] -> output byte (packer: add_table)
+    v4i* c_dw = reinterpret_cast<v4i*>(lds_all + (ADD ? 65536 : 0));
+    v4i* c_pw = c_dw + NW * nDWC / 4;
+    v4i* c_dww = c_pw + NW * nPWC / 4;                          // depthwise weights (only when the waves split the channels)
+    constexpr bool DWW_LDS = NW > 1;                            // 24 long-lived registers less per lane; LDS reads are free here
+    v2i* xchg = reinterpret_cast<v2i*>(c_dww + (DWW_LDS ? NW * nDWW / 4 : 0));  // [buffer][wave of the workgroup][lane]: B fragments
     const int tid = threadIdx.x;
     {
         const v4i* src = reinterpret_cast<const v4i*>(a.cst);
         for (int i = tid; i < NW * nDWC / 4; i += NTHREADS) c_dw[i] = src[kDWC / 4 + i];
         for (int i = tid; i < NW * nPWC / 4; i += NTHREADS) c_pw[i] = src[kPWC / 4 + i];
-        if (ADD) {
-            for (int i = tid; i < 256; i += NTHREADS) {
-                add_lut[0][i] = mbqm(((int)(int8_t)i - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);  // index: residual byte pattern
-                add_lut[1][i] = mbqm((i - 128 - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);         // index: own value + 128
-            }
+        if constexpr (DWW_LDS)
+            for (int i = tid; i < NW * nDWW / 4; i += NTHREADS) c_dww[i] = src[kDWW / 4 + i];
+        if constexpr (ADD) {
+            const v4i* tsrc = reinterpret_cast<const v4i*>(a.add_tab);
+            v4i* tdst = reinterpret_cast<v4i*>(lds_all);
+            for (int i = tid; i < 4096; i += NTHREADS) tdst[i] = tsrc[i];
         }
     }
     __syncthreads();
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = NW == 1 ? 0 : wave;  // channel slice of this wave
+    const int w = NW == 1 ? 0 : wave % NW;  // channel slice of this wave
     const int n = lane & 15, kq = lane >> 4;
     const int strips_x = a.OW >> 4;
     const int rblocks = (a.OH + a.TH - 1) / a.TH;
-    int wid = NW == 1 ? xcd_tile(blockIdx.x, gridDim.x) * 4 + wave : xcd_tile(blockIdx.x, gridDim.x);
-    if (wid >= a.B * strips_x * rblocks) return;  // uniform per workgroup when the waves share a strip
+    int wid, chunk;
+    if constexpr (NW == 1) {
+        wid = xcd_tile(blockIdx.x, gridDim.x) * SPB + wave;
+        if (wid >= a.B * strips_x * rblocks) return;  // no barrier after this point
+    } else {
+        wid = xcd_tile(blockIdx.x, gridDim.x);         // (strip column, row block, group of SPB chunks): the strips of a workgroup
+    }                                                  // share the row block, hence the number of barriers
     const int sx = wid % strips_x;
     wid /= strips_x;
     const int ry = wid % rblocks;
-    const int chunk = wid / rblocks;
+    chunk = wid / rblocks;
+    if constexpr (NW > 1 && SPB > 1) {
+        chunk = chunk * SPB + wave / NW;
+        if (chunk >= a.B) chunk = a.B - 1;             // odd batch: the spare strip repeats the last chunk (same bytes written twice)
+    }
     const int oh0 = ry * a.TH;
     const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
     const int ow = sx * 16 + n;
@@ -137,13 +155,15 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip
     int dww[QL][3][4], dwb[QL][4];
     {
         const v4i* p = reinterpret_cast<const v4i*>(a.cst + kDWW + w * nDWW) + kq * QL * 3;
+        if constexpr (!DWW_LDS) {
 #pragma unroll
-        for (int ql = 0; ql < QL; ++ql)
+            for (int ql = 0; ql < QL; ++ql)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const v4i v = p[ql * 3 + i];
-                dww[ql][i][0] = v.x; dww[ql][i][1] = v.y; dww[ql][i][2] = v.z; dww[ql][i][3] = v.w;
-            }
+                for (int i = 0; i < 3; ++i) {
+                    const v4i v = p[ql * 3 + i];
+                    dww[ql][i][0] = v.x; dww[ql][i][1] = v.y; dww[ql][i][2] = v.z; dww[ql][i][3] = v.w;
+                }
+        }
         const v4i* pb = reinterpret_cast<const v4i*>(a.cst + kDWB + w * nDWB) + kq * QL;
 #pragma unroll
         for (int ql = 0; ql < QL; ++ql) {
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip
             for (int ql = 0; ql < QL; ++ql) pwa[t][ks][ql] = a.cst[kPWA + w * nPWA + ((t * NW + ks) * 64 + lane) * QL + ql];
         pwb[t] = reinterpret_cast<const v4i*>(a.cst + kPWB + w * nPWB)[kq * NT + t];
     }
+    const v4i* my_dww = c_dww + w * (nDWW / 4) + kq * QL * 3;
     const v4i* my_dw = c_dw + w * (nDWC / 4);
     const v4i* my_pw = c_pw + w * (nPWC / 4);
 
@@ -216,23 +237,33 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip
 
     // one output row from window rows (i0, i1, i2); `step` counts output rows of this strip (exchange buffer parity)
     auto emit = [&](int i0, int i1, int i2, int oh, int step) {
+        asm volatile("" ::: "memory");  // the per-channel requantisation constants are re-read from LDS every row instead of pinning
+                                        // ~48 registers (the kernel is bound by vector-ALU issue, LDS reads are free)
         int bfrag[QL];
 #pragma unroll
         for (int ql = 0; ql < QL; ++ql) {
             const v4i m = my_dw[(kq * QL + ql) * 3 + 0], c1 = my_dw[(kq * QL + ql) * 3 + 1], sh = my_dw[(kq * QL + ql) * 3 + 2];
             int qv[4];
+            v4i w0, w1, w2;
+            if constexpr (DWW_LDS) {
+                w0 = my_dww[ql * 3 + 0]; w1 = my_dww[ql * 3 + 1]; w2 = my_dww[ql * 3 + 2];
+            } else {
+                w0 = (v4i){dww[ql][0][0], dww[ql][0][1], dww[ql][0][2], dww[ql][0][3]};
+                w1 = (v4i){dww[ql][1][0], dww[ql][1][1], dww[ql][1][2], dww[ql][1][3]};
+                w2 = (v4i){dww[ql][2][0], dww[ql][2][1], dww[ql][2][2], dww[ql][2][3]};
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int acc = dot4_first(T[i0].c[ql][e], dww[ql][0][e], dwb[ql][e]);
-                acc = dot4(T[i1].c[ql][e], dww[ql][1][e], acc);
-                acc = dot4(T[i2].c[ql][e], dww[ql][2][e], acc);
+                int acc = dot4_first(T[i0].c[ql][e], w0[e], dwb[ql][e]);
+                acc = dot4(T[i1].c[ql][e], w1[e], acc);
+                acc = dot4(T[i2].c[ql][e], w2[e], acc);
                 qv[e] = med3(rq(acc, m[e], c1[e], sh[e]), a.dw_lo, a.dw_hi);
             }
             bfrag[ql] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         }
         long bfs[NW];  // B fragments of every channel slice (QL == 2 whenever NW > 1)
         if constexpr (NW > 1) {
-            v2i* buf = xchg + (step & 1) * (NW * 64);
+            v2i* buf = xchg + ((step & 1) * SPB + wave / NW) * (NW * 64);
             buf[w * 64 + lane] = (v2i){bfrag[0], bfrag[1]};
             // LDS only: the prefetched global loads stay in flight across the barrier (a __syncthreads would drain them)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -263,11 +294,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int v = med3(rq(acc[e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);  // ADD: value + 128 (table index), else the int8 value
-                if constexpr (ADD) {
-                    const int sa = add_lut[0][(cen[i1][t] >> (8 * e)) & 0xff];
-                    const int sb = add_lut[1][v];
-                    v = med3(rq(sa + sb, a.add.mo, a.add_c1, -a.add.so), a.add.amin, a.add.amax);
-                }
+                if constexpr (ADD)  // the whole TFLite ADD (two input rescales, sum, output rescale, clamp) is a function of two bytes
+                    v = add_tab[(uint32_t)perm(cen[i1][t], v, 0x0c0c0400u + (e << 8))];
                 qv[e] = v;
             }
             outw[t] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
@@ -308,11 +336,20 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void i8_strip_kernel(Strip
 
 template <int CW, int NW, int COUT, int S, bool ADD>
 void launch_strip(const Strip8Args& a, hipStream_t s) {
-    const long strips = (long)a.B * (a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
-    if (NW == 1)
-        hipLaunchKernelGGL((i8_strip_kernel<CW, NW, COUT, S, ADD>), dim3((unsigned)((strips + 3) / 4)), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((i8_strip_kernel<CW, NW, COUT, S, ADD>), dim3((unsigned)strips), dim3(64 * NW), 0, s, a);
+    constexpr int SPB = ADD ? 8 / NW : (NW == 1 ? 4 : 1);
+    constexpr int QL = CW / 16, NT = COUT / NW / 16;
+    constexpr size_t smem = (ADD ? 65536 : 0) + (size_t)NW * (4 * QL * 12 + 4 * NT * 12) * 4 + (NW > 1 ? NW * 4 * QL * 12 * 4 + 2 * SPB * NW * 64 * 8 : 0);
+    const long per_chunk = (long)(a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
+    const long blocks = NW == 1 ? (a.B * per_chunk + SPB - 1) / SPB : ((a.B + SPB - 1) / SPB) * per_chunk;
+    auto kern = i8_strip_kernel<CW, NW, COUT, S, ADD>;
+    if (smem > 65536) {
+        static bool raised = false;  // one attribute call per instantiation
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW * SPB), smem, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -469,6 +506,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
 int i8_strip_waves(int Cin, int Cout, int stride, int OW, bool add) {
     if (OW % 16 || (stride != 1 && stride != 2)) return 0;
     if (add && (stride != 1 || Cin != Cout)) return 0;
+    if (Cin == 64 && Cout == 64) return 2;  // measured: two waves x 32 channels (136 VGPRs) beat one wave x 64 (230) by 5 %
     if ((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) return 1;
     if (add) return Cin == 128 ? 4 : 0;
     if (Cin == 64 && Cout == 128) return 2;
@@ -489,14 +527,14 @@ void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s)
         if (v >= 1) th = v < a.OH ? v : a.OH;
     }
     a.TH = th;
-    if (add) a.add_c1 = (1 << (-a.add.so - 1)) + (a.add.zo << -a.add.so);
 #define BN_STRIP(CW, NW, CO, ST, AD) \
     if (Cin == CW * NW && nw == NW && Cout == CO && stride == ST && add == AD) return launch_strip<CW, NW, CO, ST, AD>(a, s);
     BN_STRIP(32, 1, 32, 1, true)
-    BN_STRIP(64, 1, 64, 1, true)
     BN_STRIP(32, 4, 128, 1, true)
+    BN_STRIP(32, 2, 64, 1, true)
+    BN_STRIP(32, 2, 64, 1, false)
+    BN_STRIP(32, 2, 64, 2, false)
     BN_STRIP(32, 1, 32, 1, false)
-    BN_STRIP(64, 1, 64, 1, false)
     BN_STRIP(32, 1, 64, 1, false)
     BN_STRIP(64, 1, 32, 1, false)
     BN_STRIP(32, 4, 128, 1, false)
@@ -504,7 +542,6 @@ void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s)
     BN_STRIP(32, 1, 32, 2, false)
     BN_STRIP(32, 1, 64, 2, false)
     BN_STRIP(64, 1, 32, 2, false)
-    BN_STRIP(64, 1, 64, 2, false)
     BN_STRIP(32, 4, 128, 2, false)
     BN_STRIP(32, 2, 128, 2, false)
 #undef BN_STRIP

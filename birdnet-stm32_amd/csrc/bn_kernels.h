@@ -150,7 +150,7 @@ struct Strip8Args {
     int zp_in, dw_lo, dw_hi;
     int pw_lo, pw_hi, pw_zp_out;  // with the ADD: clamp bounds + 128 (the block's own value is kept as a table index)
     I8AddParams add;
-    int add_c1;
+    const int8_t* add_tab;  // [256][256]: (residual byte pattern, own value + 128) -> output of the TFLite ADD (packer: add_table)
 };
 struct FrontStrip8Args {
     const int8_t* fe;   // [B][H0][W0]

@@ -249,7 +249,7 @@ def test_context_creation_fails_loudly_without_device():
 
 
 # ------------------------------------------------------------------ strip-kernel constant block (bn_i8_strip.hip)
-def _emulate_strip(cst, x, p, nw):
+def _emulate_strip(cst, x, p, nw, tab=None):
     """numpy restatement of ``i8_strip_kernel``'s lane arithmetic (csrc/bn_i8_strip.hip) from the packer's constant block:
     wave w / lane (n, kq) owns channels CW w + CL kq .. of column n, row-transposed depthwise weights, folded requantisation
     addends, A fragments with permuted rows per channel slice, own value + 128 as the table index of the ADD.
@@ -294,13 +294,6 @@ def _emulate_strip(cst, x, p, nw):
                     bfrag[..., w, kq, 4 * ql + e] = np.clip(rq(acc, m, c1, sh), dw_lo, dw_hi)
     y = np.zeros((B, OH, OW, N), np.int64)
     off = 128 if add[0] else 0
-    if add[0]:
-        from birdnet_stm32.models import _quant as qz
-
-        _, z1, m1, s1, m2, s2, mo, so, zo, alo, ahi = add
-        lut0 = qz.requantize((np.arange(256).astype(np.int8).astype(np.int64) - z1) << 20, m1, s1)  # index: residual byte pattern
-        lut1 = qz.requantize((np.arange(256, dtype=np.int64) - 128 - pw_zp) << 20, m2, s2)            # index: own value + 128
-        c1o = (1 << (-so - 1)) + (zo << -so)
     for w in range(nw):
         for t in range(NT):
             for mrow in range(16):
@@ -314,7 +307,7 @@ def _emulate_strip(cst, x, p, nw):
                 ch = CWO * w + COL * q + 4 * t + reg
                 if add[0]:
                     res = x[..., ch].view(np.uint8).astype(np.int64)  # centre tap of the lane's own channel group
-                    v = np.clip(rq(lut0[res] + lut1[v], mo, c1o, -so), alo, ahi)
+                    v = tab[res, v]  # the ADD as a two-byte table
                 y[..., ch] = v
     return y.astype(np.int8)
 
@@ -346,8 +339,9 @@ def test_strip_constant_block_reproduces_the_oracle():
         from birdnet_stm32.models._lower_i8 import strip_waves
 
         nw = strip_waves(o.p[2], o.p[14], o.p[3], o.p[7], bool(o.p[18]))
-        assert nw == {32: 1, 64: 1 if o.p[14] <= 64 else 2, 128: 4}[o.p[2]]
-        got = _emulate_strip(np.asarray(plan.tensors[o.t[9]], np.int32), x, o.p, nw)
+        assert nw == {32: 1, 64: 2, 128: 4}[o.p[2]]
+        tab = np.asarray(plan.tensors[o.t[10]], np.int8).reshape(256, 256) if o.p[18] else None
+        got = _emulate_strip(np.asarray(plan.tensors[o.t[9]], np.int32), x, o.p, nw, tab)
         assert np.array_equal(got, want), f"{o.name}: {(got != want).sum()} of {got.size} values differ"
 
 

@@ -12,7 +12,7 @@ rows = defaultdict(lambda: defaultdict(list))
 for pat in sys.argv[1:]:
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0].replace("bn::(anonymous namespace)::", "")
+            name = r["Kernel_Name"].replace("bn::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             if name.startswith("void at::") or "at::native" in name:
                 continue
             key = (name[:60], r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
