@@ -660,6 +660,9 @@ static void launch_wave(const DwPwArgs& a, hipStream_t s) {
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s) {
     const int ct_total = a.Cout / 16;
     static const int wave_variant = getenv("BN_WAVE_DWPW") ? atoi(getenv("BN_WAVE_DWPW")) : 1;
+    const char* strip_env = getenv("BN_F32_STRIP");  // read per launch: the tests switch it inside one process
+    const int strip_variant = strip_env ? atoi(strip_env) : 1;
+    if (strip_variant && f32_strip_supported(a)) return launch_f32_strip(a, s);
     if (wave_variant && a.has_dw && a.NB == 1 && a.Cin <= 64 && a.Cout <= 64 && 64 % (a.Cin / 4) == 0 && !a.gate) {
         switch (ct_total) {
             case 1: launch_wave<1>(a, s); return;

@@ -91,6 +91,9 @@ void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, i
 void launch_f32_gap_dense(const float* x, float* scores, float* logits, int B, int P, int Cin, int Cout, int act, const float* w,
                           const float* bias, hipStream_t s);
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s);
+// row-streaming strip kernel for the wide early blocks (bn_f32_strip.hip); launch_f32_dwpw picks it when supported
+bool f32_strip_supported(const DwPwArgs& a);
+void launch_f32_strip(DwPwArgs a, hipStream_t s);
 
 // ---- INT8 plan -----------------------------------------------------------------------------
 void launch_i8_quant(const float* spec, const float* minmax, int8_t* out, int B, int F, int W, int Kp, int zp,

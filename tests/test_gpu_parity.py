@@ -140,6 +140,33 @@ def test_f32_infer_audio_end_to_end(torch_mod, audio24, oracle_specs):
     runner.close()
 
 
+def test_f32_strip_kernel_matches_tile_kernels(torch_mod, oracle_specs, monkeypatch):
+    """The row-streaming float32 strip kernel (stage 1-2 blocks) against the tile kernels it replaces: per layer within
+    float32 round-off of each other (the FMA order differs), for strip heights that move the strip borders around."""
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models.runners import load_model_runner
+
+    x = np.tile(oracle_specs[..., None], (9, 1, 1, 1))[:130]
+    B = x.shape[0]
+    runner = load_model_runner(KERAS_PATH, max_batch=B, keep_all=True)
+    ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.F32_DWPW and op.p[2] <= 64 and op.p[10] <= 64 and op.p[7] % 16 == 0]
+    assert len(ops) == 4
+    monkeypatch.setenv("BN_F32_STRIP", "0")
+    want_scores = runner.predict(x)
+    want = {oi: runner.op_output(oi, B) for oi in ops}
+    monkeypatch.setenv("BN_F32_STRIP", "1")
+    for th in ("", "1", "3", "5", "7", "64"):
+        if th:
+            monkeypatch.setenv("BN_F32_STRIP_TH", th)
+        got_scores = runner.predict(x)
+        for oi in ops:
+            a = runner.op_output(oi, B)
+            err = np.abs(a - want[oi]).max() / np.abs(want[oi]).max()
+            assert err < 2e-6, f"rows per strip {th or 'auto'}: layer {runner.plan.ops[oi].name}: relative-to-peak difference {err:.3e}"
+        assert np.abs(got_scores - want_scores).max() < 1e-6
+    runner.close()
+
+
 # --------------------------------------------------------------------------------------- INT8 graph
 @pytest.mark.parametrize("fuse", [True, False], ids=["fused_mfma", "baseline_kernels"])
 def test_i8_graph_bit_exact_per_tensor(torch_mod, oracle_specs, fuse):
