@@ -30,21 +30,25 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float act1(float v, int act) {
-    if (act == 1) return fmaxf(v, 0.0f);
-    if (act == 2) return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f);
-    return v;
+// every activation code (none / ReLU / ReLU6) is one v_med3_f32 with run-time bounds: no per-code copies of the row loop
+struct ActBounds { float lo, hi; };
+__device__ __forceinline__ ActBounds act_bounds(int act) {
+    return {act == 0 ? -__builtin_inff() : 0.0f, act == 2 ? 6.0f : __builtin_inff()};
 }
-__device__ __forceinline__ v4f act4(v4f v, int act) { return (v4f){act1(v.x, act), act1(v.y, act), act1(v.z, act), act1(v.w, act)}; }
+__device__ __forceinline__ v4f act4(v4f v, ActBounds b) {
+    return (v4f){__builtin_amdgcn_fmed3f(v.x, b.lo, b.hi), __builtin_amdgcn_fmed3f(v.y, b.lo, b.hi), __builtin_amdgcn_fmed3f(v.z, b.lo, b.hi),
+                 __builtin_amdgcn_fmed3f(v.w, b.lo, b.hi)};
+}
 
 struct Row4 { v4f t[3]; };  // the three taps (columns j = 0..2) of one input row, one channel quad
 
 template <int NW, int COUT, int S, bool RES>
-__global__ __launch_bounds__(64 * NW) void f32_strip_kernel(DwPwArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void f32_strip_kernel(DwPwArgs a) {
     constexpr int CIN = 16 * NW, CWO = COUT / NW, NT = CWO / 16;
     static_assert(NT == 1 || NT == 2, "16 or 32 output channels per wave");
     static_assert(!RES || (CIN == COUT && S == 1), "the residual is the block input");
     __shared__ v4f xchg[2][NW][64];
+    __shared__ v4f dw_lds[9][CIN / 4];  // depthwise taps: re-read every row (9 x 16 B per lane) instead of pinning 36 registers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -61,12 +65,11 @@ __global__ __launch_bounds__(64 * NW) void f32_strip_kernel(DwPwArgs a) {
     const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
     const int ow = sx * 16 + n;
     const int c0 = 16 * w + 4 * kq;  // first input channel of the lane
+    const ActBounds dw_bounds = act_bounds(a.dw_act), pw_bounds = act_bounds(a.pw_act);
 
-    v4f dw[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dw[i][j] = *reinterpret_cast<const v4f*>(a.dw_w + (i * 3 + j) * CIN + c0);
+    for (int i = tid; i < 9 * (CIN / 4); i += 64 * NW) (&dw_lds[0][0])[i] = reinterpret_cast<const v4f*>(a.dw_w)[i];
+    __syncthreads();
+    const v4f* dw = &dw_lds[0][c0 >> 2];  // tap t of this lane's quad at dw[t * (CIN / 4)]
     const v4f dwb = *reinterpret_cast<const v4f*>(a.dw_b + c0);
     // A operands: pa[t][ks] = W[16 ks + 4 kq + g][ch], g = 0..3, ch = CWO w + 4 NT (m >> 2) + 4 t + (m & 3) for lane (m, kq);
     // the packer's fragment order [K/16][N/16][64][4] holds W[16 j + 4 (l >> 4) + e][16 ct + (l & 15)] at [j][ct][l][e].
@@ -113,14 +116,15 @@ __global__ __launch_bounds__(64 * NW) void f32_strip_kernel(DwPwArgs a) {
         }
     };
     auto emit = [&](int i0, int i1, int i2, int oh, int step) {
+        asm volatile("" ::: "memory");  // keeps the tap reads inside the row loop
         v4f acc = dwb;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            acc = __builtin_elementwise_fma(T[i0].t[j], dw[0][j], acc);
-            acc = __builtin_elementwise_fma(T[i1].t[j], dw[1][j], acc);
-            acc = __builtin_elementwise_fma(T[i2].t[j], dw[2][j], acc);
+            acc = __builtin_elementwise_fma(T[i0].t[j], dw[(0 + j) * (CIN / 4)], acc);
+            acc = __builtin_elementwise_fma(T[i1].t[j], dw[(3 + j) * (CIN / 4)], acc);
+            acc = __builtin_elementwise_fma(T[i2].t[j], dw[(6 + j) * (CIN / 4)], acc);
         }
-        acc = act4(acc, a.dw_act);
+        acc = act4(acc, dw_bounds);
         v4f (*buf)[64] = xchg[step & 1];
         buf[w][lane] = acc;
         // LDS only: the prefetched global loads stay in flight across the barrier
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void f32_strip_kernel(DwPwArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t][ks][g], f[ks][g], o, 0, 0, 0);
             if constexpr (RES) o += T[i1].t[1];  // centre tap = the block input at this position, channels 16 w + 4 q + 0..3
-            o = act4(o, a.pw_act);
+            o = act4(o, pw_bounds);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), rs_out,
                                                    voff_out + 16 * t, oh * a.OW * COUT * 4, 0);
         }
@@ -177,7 +181,8 @@ void launch_strip(const DwPwArgs& a, hipStream_t s) {
 bool f32_strip_supported(const DwPwArgs& a) {
     if (!a.has_dw || a.gate || a.OW % 16 || a.sh != a.sw || (a.sh != 1 && a.sh != 2)) return false;
     if (a.res && (a.res != a.x || a.sh != 1 || a.Cin != a.Cout)) return false;
-    const bool shape = (a.Cin == 32 && (a.Cout == 32 || a.Cout == 64)) || (a.Cin == 64 && a.Cout == 64);
+    // 128 -> 128 (eight waves per strip, 8 x 16 maps) was measured and is no faster than the tile kernel: left out
+    const bool shape = (a.Cin == 32 && (a.Cout == 32 || a.Cout == 64)) || (a.Cin == 64 && (a.Cout == 64 || a.Cout == 128));
     return shape && (long)a.H * a.W * a.Cin * 4 < 0x7fff0000L;
 }
 
@@ -201,6 +206,8 @@ void launch_f32_strip(DwPwArgs a, hipStream_t s) {
     BN_FSTRIP(2, 32, 2, false)
     BN_FSTRIP(2, 64, 2, false)
     BN_FSTRIP(4, 64, 2, false)
+    BN_FSTRIP(4, 128, 1, false)
+    BN_FSTRIP(4, 128, 2, false)
 #undef BN_FSTRIP
 }
 
