@@ -587,10 +587,14 @@ __global__ __launch_bounds__(256, 4) void f32_front_kernel(FrontArgs a) {  // 4 
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 acc[g][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const f32x4 af = lds4[(row0 + 16 * g + r) * S4 + q];
+                f32x4 af = lds4[(row0 + 16 * g + r) * S4 + q];
                 const f32x4 bf = bfrag[c];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[g][c], 0, 0, 0);
+                // the A operand stays an in/out operand past the chain: the allocator otherwise re-uses it as the destination of the last
+                // MFMA, and a multi-pass MFMA on MI355X reads operands while it already writes results (bn_f32_strip.hip,
+                // tools/mfma_overlap_check.py)
+                asm volatile("" : "+v"(af));
             }
         constexpr int SO = NS + 4;
 #pragma unroll

@@ -43,9 +43,10 @@ __device__ __forceinline__ v4f act4(v4f v, ActBounds b) {
 struct Row4 { v4f t[3]; };  // the three taps (columns j = 0..2) of one input row, one channel quad
 
 template <int NW, int COUT, int S, bool RES>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void f32_strip_kernel(DwPwArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 2 && COUT == 32) ? 4 : 3))) void f32_strip_kernel(DwPwArgs a) {
     constexpr int CIN = 16 * NW, CWO = COUT / NW, NT = CWO / 16;
     static_assert(NT == 1 || NT == 2, "16 or 32 output channels per wave");
+    static_assert(NW == 2 || NW == 4, "two or four waves per strip");
     static_assert(!RES || (CIN == COUT && S == 1), "the residual is the block input");
     __shared__ v4f xchg[2][NW][64];
     __shared__ v4f dw_lds[9][CIN / 4];  // depthwise taps: re-read every row (9 x 16 B per lane) instead of pinning 36 registers
@@ -132,16 +133,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
         v4f f[NW];
 #pragma unroll
         for (int ks = 0; ks < NW; ++ks) f[ks] = buf[ks][lane];
+        v4f o[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            v4f o = pb[t];
+            o[t] = pb[t];
 #pragma unroll
             for (int ks = 0; ks < NW; ++ks)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t][ks][g], f[ks][g], o, 0, 0, 0);
-            if constexpr (RES) o += T[i1].t[1];  // centre tap = the block input at this position, channels 16 w + 4 q + 0..3
-            o = act4(o, pw_bounds);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), rs_out,
+                for (int g = 0; g < 4; ++g) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t][ks][g], f[ks][g], o[t], 0, 0, 0);
+        }
+        // The B operands must stay untouched until the MFMAs have READ them, and on MI355X v_mfma_f32_16x16x4_f32 (8 passes) reads B
+        // pass by pass: output columns 12-15 use the values B holds ~30 cycles after issue.  The compiler assumes operands are
+        // consumed at issue — it re-used a dying B register as the destination of a chain's last MFMA (`v_mfma_f32_16x16x4_f32
+        // v[46:49], v33, v49, v[58:61]`: columns 12-15 wrong in every run) and scheduled `v_mov_b32 v6, s33` right behind an MFMA
+        // reading v6 (wrong in 1 run of 100).  Here every B register is an in/out operand of a 32-cycle wait placed after the last
+        // MFMA, so nothing can write one before that; tools/mfma_overlap_check.py scans the assembly for the first pattern.
+        if constexpr (NW == 2)
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(f[0]), "+v"(f[1]));
+        else
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            v4f r = o[t];
+            if constexpr (RES) r += T[i1].t[1];  // centre tap = the block input at this position, channels 16 w + 4 q + 0..3
+            r = act4(r, pw_bounds);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, r), rs_out,
                                                    voff_out + 16 * t, oh * a.OW * COUT * 4, 0);
         }
     };
@@ -181,15 +197,18 @@ void launch_strip(const DwPwArgs& a, hipStream_t s) {
 bool f32_strip_supported(const DwPwArgs& a) {
     if (!a.has_dw || a.gate || a.OW % 16 || a.sh != a.sw || (a.sh != 1 && a.sh != 2)) return false;
     if (a.res && (a.res != a.x || a.sh != 1 || a.Cin != a.Cout)) return false;
-    // 128 -> 128 (eight waves per strip, 8 x 16 maps) was measured and is no faster than the tile kernel: left out
+    // 128 -> 128 (eight waves per strip) needs ~145 registers per lane: one workgroup per CU, no faster than the tile kernel
     const bool shape = (a.Cin == 32 && (a.Cout == 32 || a.Cout == 64)) || (a.Cin == 64 && (a.Cout == 64 || a.Cout == 128));
     return shape && (long)a.H * a.W * a.Cin * 4 < 0x7fff0000L;
 }
 
 void launch_f32_strip(DwPwArgs a, hipStream_t s) {
     const int nw = a.Cin / 16;
+    // rows per strip (measured at B = 1024): 16 on the 32-row maps (32: fewer, longer strips leave CUs idle at the end; 8: the
+    // two-row prologue weighs 25 %), the whole map below that; shorter only while the launch would not fill the chip once
     int th = a.OH;
-    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 16384) th = (th + 1) / 2;
+    while (th > 16) th = (th + 1) / 2;
+    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 4096) th = (th + 1) / 2;
     if (const char* e = getenv("BN_F32_STRIP_TH")) {  // tests: force the rows per strip
         const int v = atoi(e);
         if (v >= 1) th = v < a.OH ? v : a.OH;
