@@ -1,14 +1,26 @@
 #!/usr/bin/env python3
-"""Scan gfx950 assembly for MFMAs whose destination registers overlap their A or B operand.
+"""Scan gfx950 assembly for code that touches the A/B operand registers of an MFMA while it may still be reading them.
 
     hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only -o k.s kernel.hip && python tools/mfma_overlap_check.py k.s
 
-On MI355X a multi-pass MFMA writes its result while later passes still read B: `v_mfma_f32_16x16x4_f32 v[46:49], v33, v49,
-v[58:61]` (the register allocator re-used the B operand's register for the result) gave wrong columns 12-15.  The compiler
-does not forbid the overlap for every variant, so kernels keep the B operands alive past the MFMA chain and this script
-checks the generated code."""
+Measured on MI355X: a multi-pass MFMA (v_mfma_f32_16x16x4_f32, 8 passes) reads its B operand pass by pass while it already
+writes results, so the values B holds ~30 cycles after issue decide output columns 12-15.  The compiler assumes operands are
+consumed at issue.  Two patterns gave wrong results in bn_f32_strip.hip:
+
+  1. destination overlapping an operand:   v_mfma_f32_16x16x4_f32 v[46:49], v33, v49, v[58:61]        (every run)
+  2. vector-ALU write right behind the MFMA: v_mfma_f32_16x16x4_f32 ..., v30, v6, ... ; v_mov_b32 v6, s33  (1 run in 100)
+
+Pattern 1 is an error for every MFMA and either operand; pattern 2 for the B operand of the f32 MFMAs within a window of ~32
+cycles (one vector-ALU instruction = 4 cycles, an MFMA = its passes x 4, s_nop n = n + 1).  Exit status 1 on either: the Makefile
+gates the build on it.  The A operand is consumed at issue (the tile kernels of bn_f32_fused.hip overwrite A registers right
+behind the last MFMA of a chain and have always matched the oracle); the int8 MFMAs (16x16x32 / 16x16x64) showed neither
+problem in 100-launch stress runs.  --strict reports those cases too, as notes.
+Memory loads into an operand register are ignored: their data arrives hundreds of cycles later."""
 import re
 import sys
+
+WINDOW = 32
+PASSES = {"v_mfma_f32_16x16x4_f32": 8, "v_mfma_i32_16x16x32_i8": 4, "v_mfma_i32_16x16x64_i8": 8}
 
 
 def rng(op):
@@ -21,20 +33,47 @@ def rng(op):
     return None
 
 
-bad = 0
-for path in sys.argv[1:]:
+def hit(a, b):
+    return a and b and a[0] == b[0] and not (a[2] < b[1] or b[2] < a[1])
+
+
+strict = "--strict" in sys.argv
+errors = warnings = 0
+for path in [p for p in sys.argv[1:] if not p.startswith("--")]:
     kernel = "?"
+    recent = []  # (cycles since issue, opcode, srcA, srcB, line number)
     for ln, line in enumerate(open(path), 1):
         if line.startswith("_Z") and line.rstrip().endswith(":"):
-            kernel = line.strip()[:-1]
-        m = re.match(r"\s+(v_mfma\S+)\s+(.*)", line)
-        if not m:
+            kernel, recent = line.strip()[:-1], []
+        m = re.match(r"\s+([a-z_0-9]+)\s*(.*)", line)
+        if not m or line.lstrip().startswith((";", ".")):
             continue
-        ops = [o.strip() for o in m.group(2).split(",")]
-        d, a, b = rng(ops[0]), rng(ops[1]), rng(ops[2])
-        for name, s in (("A", a), ("B", b)):
-            if d and s and d[0] == s[0] and not (d[2] < s[1] or s[2] < d[1]):
-                bad += 1
-                print(f"{path}:{ln}: {kernel[:70]}: dst {ops[0]} overlaps src{name} {ops[1] if name == 'A' else ops[2]}: {line.strip()}")
-print(f"{bad} overlapping MFMA(s)")
-sys.exit(1 if bad else 0)
+        opc, ops = m.group(1), [o.strip() for o in m.group(2).split(";")[0].split(",")]
+        if opc.startswith("s_cbranch") or opc in ("s_branch", "s_barrier", "s_endpgm"):
+            recent = []  # other paths / long waits: not followed
+            continue
+        cost = 4
+        if opc.startswith("v_mfma"):
+            d, a, b = rng(ops[0]), rng(ops[1]), rng(ops[2])
+            for name, s in (("A", a), ("B", b)):
+                if hit(d, s):
+                    errors += 1
+                    print(f"{path}:{ln}: {kernel[:60]}: destination overlaps src{name}: {line.strip()}")
+            cost = 4 * PASSES.get(opc, 8)
+            recent = [(c + cost, o, x, y, l) for c, o, x, y, l in recent]
+            recent.append((0, opc, a, b, ln))
+            recent = [r for r in recent if r[0] < WINDOW]
+            continue
+        if opc == "s_nop":
+            cost = int(ops[0]) + 1 if ops and ops[0].isdigit() else 1
+        elif opc.startswith("v_") and not opc.startswith("v_cmp") and ops:
+            w = rng(ops[0])
+            for c, o, a, b, l in recent:
+                if (strict or "f32" in o) and hit(w, b):
+                    warnings += 1
+                    print(f"{path}:{ln}: {kernel[:60]}: writes the B operand of the {o} at line {l}, {c} cycles after its issue: {line.strip()}")
+                elif strict and hit(w, a):
+                    print(f"{path}:{ln}: note: writes the A operand of the {o} at line {l}, {c} cycles after its issue: {line.strip()}")
+        recent = [(c + cost, o, x, y, l) for c, o, x, y, l in recent if c + cost < WINDOW]
+print(f"{errors} MFMA(s) with a destination overlapping an operand, {warnings} early write(s) to an operand")
+sys.exit(1 if errors or warnings else 0)
