@@ -119,6 +119,23 @@ def output_bytes(kind: str, p: list, batch: int, dtype: str):
     return None
 
 
+def kernel_symbol(kind: str, p: list) -> str:
+    """The device kernel an operator launches (the launchers' choices: strip kernels for the wide early blocks)."""
+    if kind in ("stft512", "f32_stftmel"):
+        return "stft512_mag_kernel"
+    if kind == "i8_dwpw" and p[35]:
+        return "i8_strip_kernel"
+    if kind == "i8_front" and p[16]:
+        return "i8_front_strip_kernel"
+    if kind == "f32_dwpw" and p[15]:
+        cin, cout, ow, stride = p[2], p[10], p[7], p[3]
+        if ow % 16 == 0 and stride in (1, 2) and ((cin == 32 and cout in (32, 64)) or (cin == 64 and cout in (64, 128))):
+            return "f32_strip_kernel"
+        if cin <= 64 and cout <= 64:
+            return "f32_dwpw_wave_kernel"
+    return kind + "_kernel"
+
+
 def pmc_traffic(dom: dict, batch: int, dtype: str):
     """HBM bytes per launch of the dominant kernel from the committed PMC digest of this workload (rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
@@ -128,11 +145,11 @@ def pmc_traffic(dom: dict, batch: int, dtype: str):
     want = output_bytes(dom["kernel"], dom["p"], batch, dtype)
     if want is None or not os.path.isfile(path):
         return None
-    base = {"stft512": "stft512_mag_kernel", "f32_stftmel": "stft512_mag_kernel"}.get(dom["kernel"], dom["kernel"] + "_kernel")
+    base = kernel_symbol(dom["kernel"], dom["p"])
     best = None
     for row in json.load(open(path)):
-        name = row["kernel"].split("<")[0]  # the narrow layers run the wave-autonomous variant of the same operator
-        if name in (base, base.replace("_kernel", "_wave_kernel")) and abs(row["write_bytes"] - want) <= 0.05 * want:
+        name = row["kernel"].split("<")[0]
+        if name == base and abs(row["write_bytes"] - want) <= 0.05 * want:
             if best is None or abs(row["write_bytes"] - want) < abs(best["write_bytes"] - want):
                 best = row
     return None if best is None else int(best["read_bytes"] + best["write_bytes"])
@@ -158,9 +175,7 @@ def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> t
         roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["traffic"] = pmc_traffic(dom, batch, dtype)
-    roof["kernel"] = {"stft512": "stft512_mag_kernel", "f32_stftmel": "stft512_mag_kernel"}.get(dom["kernel"], dom["kernel"] + "_kernel")
-    if dom["kernel"] == "f32_dwpw" and dom["p"][2] <= 64 and dom["p"][10] <= 64 and dom["p"][15]:
-        roof["kernel"] = "f32_dwpw_wave_kernel"  # launch_f32_dwpw's choice for Cin, Cout <= 64 with a depthwise stage
+    roof["kernel"] = kernel_symbol(dom["kernel"], dom["p"])
     roof["layer"] = dom["layer"]
     roof["avg_launch_ms"] = dom["avg_ms"]
     roof["algorithmic_bytes_per_launch"] = dom["bytes"]
@@ -233,6 +248,30 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
     return {"value": round(n / dt, 2), "unit": "chunks/s", "cores": 1, "kind": "port",
             "sample": f"{n} synthetic 3 s @ 24 kHz chunks, numpy oracle (oracle/stft.py + "
                       f"{'float_graph' if dtype == 'f32' else 'int8_graph'}.py), 1 thread, {dt:.1f} s"}
+
+
+def quick_rate(torch, dtype: str, batch: int, device, local_rank: int, steps: int = 10) -> dict:
+    """Whole-path throughput of another BASELINE configuration on this GPU (same synthetic audio, resident in HBM), reported
+    beside the main measurement: two warm-up steps, then `steps` timed steps between device synchronisations."""
+    from birdnet_stm32.models.runners import load_model_runner
+
+    ckpt = os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100" + (".keras" if dtype == "f32" else ".tflite"))
+    runner = load_model_runner(ckpt, device=local_rank, max_batch=batch)
+    audio = synth_audio_device(torch, batch, 0, device)
+    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
+    for _ in range(2):
+        runner.infer_audio_device(audio, hop=HOP, out=scores)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.infer_audio_device(audio, hop=HOP, out=scores)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    runner.close()
+    del audio, scores
+    return {"workload": ("birdnet_stm32n6_100 float32 DS-CNN" if dtype == "f32" else "birdnet_stm32n6_100 INT8 DS-CNN") + ", hybrid+pwl frontend",
+            "dtype": dtype, "batch_per_gpu": batch, "value": round(batch * steps / dt, 1), "unit": "chunks/s", "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 4)}
 
 
 def main() -> None:
@@ -337,12 +376,18 @@ def main() -> None:
             "roofline": roof,
             "stages": stages,
         }
+        if world == 1 and not args.batch:  # the other single-GPU BASELINE configuration, for reference (not the reported value)
+            runner.close()
+            runner = None
+            other = "i8" if args.dtype == "f32" else "f32"
+            out["also_measured"] = quick_rate(torch, other, 4096 if other == "i8" else 1024, device, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.dtype)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-    runner.close()
+    if runner is not None:
+        runner.close()
 
 
 if __name__ == "__main__":
