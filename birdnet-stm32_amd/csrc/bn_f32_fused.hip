@@ -199,13 +199,26 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
             f32x4 af[RG];
 #pragma unroll
             for (int g = 0; g < RG; ++g) af[g] = lds4[(row0 + 16 * g + r) * S4 + 4 * j + q];
+            // Dependent MFMAs either follow each other directly or sit at least four MFMAs apart: two or three interleaved chains
+            // lose a term now and then on MI355X (bn_f32_strip.hip, tools/mfma_overlap_check.py pattern 3).
+            if constexpr (RG * CT >= 4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < RG; ++g)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bf[c][e], acc[g][c], 0, 0, 0);
+            } else {
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
 #pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bf[c][e], acc[g][c], 0, 0, 0);
+                    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bf[c][e], acc[g][c], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
 #pragma unroll
             for (int c = 0; c < CT; ++c) bf[c] = bnext[c];
         }
@@ -355,10 +368,19 @@ __global__ __launch_bounds__(256) void f32_dwpw_wave_kernel(DwPwArgs a) {
         f32x4 bf[CTA];
 #pragma unroll
         for (int c = 0; c < CTA; ++c) bf[c] = wp[((size_t)j * CTA + c) * 64 + lane];
+        if constexpr (CTA >= 4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < CTA; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[c][e], acc[c], 0, 0, 0);
+                for (int c = 0; c < CTA; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[c][e], acc[c], 0, 0, 0);
+        } else {  // fewer than four chains: one after the other (see f32_dwpw_kernel)
+#pragma unroll
+            for (int c = 0; c < CTA; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[c][e], acc[c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
     wave_sync();  // every lane has read its A fragments: the tile can take the outputs
 #pragma unroll

@@ -141,6 +141,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
             for (int ks = 0; ks < NW; ++ks)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t][ks][g], f[ks][g], o[t], 0, 0, 0);
+            // One chain after the other: the scheduler otherwise interleaves the two tiles' chains (t0, t1, t0, t1, ...), and with ONE
+            // independent MFMA between dependent ones an accumulator register of the first chain came out short of a term in output
+            // columns 12-15 (1 launch in ~50 on MI355X; the single-chain variants never failed in hundreds of launches).
+            __builtin_amdgcn_sched_barrier(0);
         }
         // The B operands must stay untouched until the MFMAs have READ them, and on MI355X v_mfma_f32_16x16x4_f32 (8 passes) reads B
         // pass by pass: output columns 12-15 use the values B holds ~30 cycles after issue.  The compiler assumes operands are

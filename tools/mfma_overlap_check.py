@@ -10,6 +10,11 @@ consumed at issue.  Two patterns gave wrong results in bn_f32_strip.hip:
   1. destination overlapping an operand:   v_mfma_f32_16x16x4_f32 v[46:49], v33, v49, v[58:61]        (every run)
   2. vector-ALU write right behind the MFMA: v_mfma_f32_16x16x4_f32 ..., v30, v6, ... ; v_mov_b32 v6, s33  (1 run in 100)
 
+  3. two interleaved dependent chains:     v_mfma D0, .., .., D0 ; v_mfma D1, .., .., D1 ; v_mfma D0, .., .., D0       (1 launch in 50:
+     an accumulator register of the first chain short of one term in columns 12-15; back-to-back dependent MFMAs and chains
+     interleaved four or more deep have never failed)
+
+Pattern 3 is an error for the f32 MFMAs when exactly one or two other MFMAs and nothing else separate the dependent pair.
 Pattern 1 is an error for every MFMA and either operand; pattern 2 for the B operand of the f32 MFMAs within a window of ~32
 cycles (one vector-ALU instruction = 4 cycles, an MFMA = its passes x 4, s_nop n = n + 1).  Exit status 1 on either: the Makefile
 gates the build on it.  The A operand is consumed at issue (the tile kernels of bn_f32_fused.hip overwrite A registers right
@@ -42,9 +47,10 @@ errors = warnings = 0
 for path in [p for p in sys.argv[1:] if not p.startswith("--")]:
     kernel = "?"
     recent = []  # (cycles since issue, opcode, srcA, srcB, line number)
+    chain = []   # (destination, opcode, line number) of the MFMAs seen so far
     for ln, line in enumerate(open(path), 1):
-        if line.startswith("_Z") and line.rstrip().endswith(":"):
-            kernel, recent = line.strip()[:-1], []
+        if line.startswith("_Z") and ":" in line:
+            kernel, recent, chain = line.split(":")[0], [], []
         m = re.match(r"\s+([a-z_0-9]+)\s*(.*)", line)
         if not m or line.lstrip().startswith((";", ".")):
             continue
@@ -59,6 +65,13 @@ for path in [p for p in sys.argv[1:] if not p.startswith("--")]:
                 if hit(d, s):
                     errors += 1
                     print(f"{path}:{ln}: {kernel[:60]}: destination overlaps src{name}: {line.strip()}")
+            c_src = rng(ops[3]) if len(ops) > 3 else None
+            if "f32" in opc:
+                for back in (2, 3):  # dependent on the MFMA issued `back` MFMAs ago with only MFMAs in between
+                    if len(chain) >= back and chain[-back][2] == ln - back and hit(c_src, chain[-back][0]) and not any(hit(c_src, chain[-k][0]) for k in range(1, back)):
+                        errors += 1
+                        print(f"{path}:{ln}: {kernel[:60]}: depends on the MFMA {back} instructions back with only MFMAs between (interleaved chains): {line.strip()}")
+            chain.append((d, opc, ln))
             cost = 4 * PASSES.get(opc, 8)
             recent = [(c + cost, o, x, y, l) for c, o, x, y, l in recent]
             recent.append((0, opc, a, b, ln))
@@ -75,5 +88,5 @@ for path in [p for p in sys.argv[1:] if not p.startswith("--")]:
                 elif strict and hit(w, a):
                     print(f"{path}:{ln}: note: writes the A operand of the {o} at line {l}, {c} cycles after its issue: {line.strip()}")
         recent = [(c + cost, o, x, y, l) for c, o, x, y, l in recent if c + cost < WINDOW]
-print(f"{errors} MFMA(s) with a destination overlapping an operand, {warnings} early write(s) to an operand")
+print(f"{errors} MFMA operand-overlap or interleaved-chain error(s), {warnings} early write(s) to a B operand")
 sys.exit(1 if errors or warnings else 0)
