@@ -40,6 +40,19 @@ __device__ __forceinline__ v4f act4(v4f v, ActBounds b) {
                  __builtin_amdgcn_fmed3f(v.w, b.lo, b.hi)};
 }
 
+__device__ __forceinline__ void mfma_acc(v4f& acc, float a, float b) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0); }
+
+// A 16-byte store must not see its data registers rewritten right behind it.  Measured on MI355X: `buffer_store_dwordx4 v[4:7], ..,
+// s6 offen` followed at once by `v_med3_f32 v4, ..` (the next tile's result re-using the registers) stored the NEW v4 for lanes
+// 12-15 of every 16 — wrong output columns 12-15 in 1 launch of 50 up to every launch, depending on how busy the memory pipeline
+// was.  The compiler knows this hazard only for stores without an SGPR offset.  Keeping the data an in/out operand of a
+// two-wait-state no-op placed after the store makes the allocator pick other registers for what follows;
+// tools/store_hazard_check.py scans the generated assembly of every kernel file and the Makefile fails the build on a hit.
+__device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t rs, v4f r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, r), rs, voff, soff, 0);
+    asm volatile("s_nop 1" : "+v"(r));
+}
+
 struct Row4 { v4f t[3]; };  // the three taps (columns j = 0..2) of one input row, one channel quad
 
 template <int NW, int COUT, int S, bool RES>
@@ -140,29 +153,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
 #pragma unroll
             for (int ks = 0; ks < NW; ++ks)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t][ks][g], f[ks][g], o[t], 0, 0, 0);
-            // One chain after the other: the scheduler otherwise interleaves the two tiles' chains (t0, t1, t0, t1, ...), and with ONE
-            // independent MFMA between dependent ones an accumulator register of the first chain came out short of a term in output
-            // columns 12-15 (1 launch in ~50 on MI355X; the single-chain variants never failed in hundreds of launches).
-            __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < 4; ++g) mfma_acc(o[t], pa[t][ks][g], f[ks][g]);
         }
-        // The B operands must stay untouched until the MFMAs have READ them, and on MI355X v_mfma_f32_16x16x4_f32 (8 passes) reads B
-        // pass by pass: output columns 12-15 use the values B holds ~30 cycles after issue.  The compiler assumes operands are
-        // consumed at issue — it re-used a dying B register as the destination of a chain's last MFMA (`v_mfma_f32_16x16x4_f32
-        // v[46:49], v33, v49, v[58:61]`: columns 12-15 wrong in every run) and scheduled `v_mov_b32 v6, s33` right behind an MFMA
-        // reading v6 (wrong in 1 run of 100).  Here every B register is an in/out operand of a 32-cycle wait placed after the last
-        // MFMA, so nothing can write one before that; tools/mfma_overlap_check.py scans the assembly for the first pattern.
-        if constexpr (NW == 2)
-            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(f[0]), "+v"(f[1]));
-        else
-            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             v4f r = o[t];
             if constexpr (RES) r += T[i1].t[1];  // centre tap = the block input at this position, channels 16 w + 4 q + 0..3
             r = act4(r, pw_bounds);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, r), rs_out,
-                                                   voff_out + 16 * t, oh * a.OW * COUT * 4, 0);
+            store16(rs_out, r, voff_out + 16 * t, oh * a.OW * COUT * 4);
         }
     };
 
@@ -190,6 +188,171 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Front block as strips: frontend map [H0][W0] (finalised, or raw mel energies finalised while loading like f32_front_kernel)
+// -> 3x3 stem (stride 1x2, 16 channels) -> depthwise 3x3 stride 2 -> pointwise 16 -> 32; same arithmetic as f32_front_kernel up to
+// the FMA order.  One wave per strip of 16 output columns, no barrier in the row loop.  The stem runs on the f32 matrix cores:
+// the contraction index of MFMA j is the window ROW (lane group kq; kq = 3 carries zero weights), lane (n, kq) streams input
+// row (stem row - 1 + kq) and feeds the element fe[row][2 sc + j] of ITS row as the B operand, so three MFMAs (j = 0..2) give
+// stem column sc for the four channels 4 q .. 4 q + 3 in lane (n, q) — the quad its depthwise stage needs.  Nine MFMAs per stem
+// row cover stem columns 2 ow, 2 ow + 1, 2 ow + 2 (the taps of the stride-2 depthwise window).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f32_front_strip_kernel(F32FrontStripArgs a) {
+    __shared__ float rowc[64][12];          // per input row: wsum, then the ten magnitude-scaling rows (finalising mode)
+    __shared__ v4f dw_lds[9][4];            // depthwise taps [tap][quad]
+    const int tid = threadIdx.x;
+    const bool fin = a.minmax != nullptr;
+    if (fin)
+        for (int i = tid; i < a.H0 * 12; i += 256) {
+            const int rr = i / 12, c = i - rr * 12;
+            rowc[rr][c] = c == 0 ? a.wsum[rr] : (c <= 10 ? a.magp[(c - 1) * a.H0 + rr] : 0.0f);
+        }
+    if (tid < 36) (&dw_lds[0][0])[tid] = reinterpret_cast<const v4f*>(a.dw_w)[tid];
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int strips_x = a.OW >> 4;
+    const int rblocks = (a.OH + a.TH - 1) / a.TH;
+    int wid = xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wid >= a.B * strips_x * rblocks) return;
+    const int sx = wid % strips_x;
+    wid /= strips_x;
+    const int ry = wid % rblocks;
+    const int chunk = wid / rblocks;
+    const int oh0 = ry * a.TH;
+    const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
+    const int ow = sx * 16 + n;
+    const ActBounds st_bounds = act_bounds(a.stem_act), dw_bounds = act_bounds(a.dw_act), pw_bounds = act_bounds(a.pw_act);
+
+    // stem A operands: lane (m, kq) holds w[kq][j][m] for j = 0..2 (0 for kq = 3); bias of channels 4 q .. 4 q + 3 as C operand
+    float sa[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sa[j] = kq < 3 ? a.stem_w[(kq * 3 + j) * 16 + n] : 0.0f;
+    const v4f stb = *reinterpret_cast<const v4f*>(a.stem_b + 4 * kq);
+    const v4f dwb = *reinterpret_cast<const v4f*>(a.dw_b + 4 * kq);
+    v4f pa[2], pb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = 8 * (n >> 2) + 4 * t + (n & 3);
+        pa[t] = reinterpret_cast<const v4f*>(a.pw_w)[(ch >> 4) * 64 + kq * 16 + (ch & 15)];
+        pb[t] = *reinterpret_cast<const v4f*>(a.pw_b + 8 * kq + 4 * t);
+    }
+    float mn = 0.0f, inv_rng = 1.0f;
+    if (fin) {
+        mn = a.minmax[2 * chunk];
+        inv_rng = 1.0f / (float)((double)(a.minmax[2 * chunk + 1] - mn) + 1e-10);
+    }
+
+    const int fe_bytes = a.H0 * a.W0 * 4;
+    const __amdgpu_buffer_rsrc_t rs_fe =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fe) + (size_t)chunk * a.H0 * a.W0, 0, fe_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)chunk * a.OH * a.OW * 32, 0, a.OH * a.OW * 32 * 4, 0x00020000);
+    const int voff_out = (ow * 32 + 8 * kq) * 4;
+    const bool right_st = 2 * ow + 2 >= a.W0 / 2;  // third stem column lies beyond the stem map: depthwise padding (0)
+    const int sr0 = 2 * oh0;
+    const int rows_needed = 2 * (nrows - 1) + 3;
+
+    v4f raw[2][2];
+    Row4 T[3];
+    auto fe_row = [&](int srel) { return sr0 + srel - 1 + kq; };
+    auto issue = [&](int slot, int srel) {
+        if (srel < rows_needed) {
+            const int fr = fe_row(srel);
+            const int base = (fr >= 0 && fr < a.H0) ? (fr * a.W0 + 4 * ow) * 4 : 0x7fff0000;  // padding rows read as 0
+            raw[slot][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_fe, base, 0, 0));
+            raw[slot][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_fe, base + 16, 0, 0));  // beyond the row end only for ow = OW - 1
+        }
+    };
+    auto stem_row = [&](int slot, int srel, int ti) {
+        if (srel < rows_needed && sr0 + srel < a.H0) {
+            const int fr = fe_row(srel);
+            const bool ok = fr >= 0 && fr < a.H0;
+            const bool has_hi = 4 * ow + 4 < a.W0;
+            float x[7] = {raw[slot][0].x, raw[slot][0].y, raw[slot][0].z, raw[slot][0].w, raw[slot][1].x, raw[slot][1].y, raw[slot][1].z};
+            if (fin) {
+                const int rr = ok ? fr : 0;
+                const v4f c0 = *reinterpret_cast<const v4f*>(&rowc[rr][0]), c1 = *reinterpret_cast<const v4f*>(&rowc[rr][4]),
+                          c2 = *reinterpret_cast<const v4f*>(&rowc[rr][8]);
+                const float off = mn * c0.x;
+#pragma unroll
+                for (int e = 0; e < 7; ++e) {
+                    const float y = fmaxf((x[e] - off) * inv_rng, 0.0f);
+                    float v = y;
+                    if (a.mag == 1) {  // pwl: rows k0, k1..3, w1..3, b1..3
+                        v = y * c0.y;
+                        v += c0.z * fmaxf(c1.y * y + c2.x, 0.0f);
+                        v += c0.w * fmaxf(c1.z * y + c2.y, 0.0f);
+                        v += c1.x * fmaxf(c1.w * y + c2.z, 0.0f);
+                    } else if (a.mag == 2) {  // pcen-like: rows agc, k1, sw, sb, k2
+                        const float y0 = fmaxf(y - c0.y * y, 0.0f);
+                        v = fmaxf(c0.z * y0 + c1.y * fmaxf(c0.w * y0 + c1.x, 0.0f), 0.0f);
+                    } else if (a.mag == 3) {
+                        v = 10.0f * logf(fmaxf(y, 1e-6f)) / logf(10.0f);
+                    }
+                    x[e] = ok ? v : 0.0f;  // padding rows stay an exact zero
+                }
+            }
+            if (!has_hi) x[4] = x[5] = x[6] = 0.0f;  // columns beyond the map (the second load wrapped into the next row)
+            v4f st[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                st[c] = stb;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) mfma_acc(st[c], sa[j], x[2 * c + j]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) T[ti].t[c] = act4(st[c], st_bounds);
+            if (right_st) T[ti].t[2] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) T[ti].t[c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto emit = [&](int i0, int i1, int i2, int oh) {
+        asm volatile("" ::: "memory");
+        const v4f* dw = &dw_lds[0][kq];
+        v4f d = dwb;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            d = __builtin_elementwise_fma(T[i0].t[j], dw[(0 + j) * 4], d);
+            d = __builtin_elementwise_fma(T[i1].t[j], dw[(3 + j) * 4], d);
+            d = __builtin_elementwise_fma(T[i2].t[j], dw[(6 + j) * 4], d);
+        }
+        d = act4(d, dw_bounds);
+        v4f o[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            o[t] = pb[t];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_acc(o[t], pa[t][g], d[g]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            store16(rs_out, act4(o[t], pw_bounds), voff_out + 16 * t, oh * a.OW * 32 * 4);
+        }
+    };
+
+    issue(0, 0);
+    issue(1, 1);
+    stem_row(0, 0, 0);
+    issue(0, 2);
+    for (int k = 0; k < nrows; k += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (k + u >= nrows) break;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int rs = 1 + 2 * u + s;
+                stem_row(rs & 1, 2 * k + rs, rs % 3);
+                issue(rs & 1, 2 * k + rs + 2);
+            }
+            emit((2 * u) % 3, (2 * u + 1) % 3, (2 * u + 2) % 3, oh0 + k + u);
+        }
+    }
+}
+
 template <int NW, int COUT, int S, bool RES>
 void launch_strip(const DwPwArgs& a, hipStream_t s) {
     const long strips = (long)a.B * (a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
@@ -204,6 +367,23 @@ bool f32_strip_supported(const DwPwArgs& a) {
     // 128 -> 128 (eight waves per strip) needs ~145 registers per lane: one workgroup per CU, no faster than the tile kernel
     const bool shape = (a.Cin == 32 && (a.Cout == 32 || a.Cout == 64)) || (a.Cin == 64 && (a.Cout == 64 || a.Cout == 128));
     return shape && (long)a.H * a.W * a.Cin * 4 < 0x7fff0000L;
+}
+
+bool f32_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW) {
+    return C == 16 && N == 32 && OW % 16 == 0 && H0 == 2 * OH && W0 == 4 * OW && H0 <= 64 && (long)H0 * W0 * 4 < 0x7fff0000L;
+}
+
+void launch_f32_front_strip(F32FrontStripArgs a, hipStream_t s) {
+    int th = a.OH;
+    while (th > 16) th = (th + 1) / 2;
+    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 4096) th = (th + 1) / 2;
+    if (const char* e = getenv("BN_F32_STRIP_TH")) {
+        const int v = atoi(e);
+        if (v >= 1) th = v < a.OH ? v : a.OH;
+    }
+    a.TH = th;
+    const long waves = (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th);
+    hipLaunchKernelGGL(f32_front_strip_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
 }
 
 void launch_f32_strip(DwPwArgs a, hipStream_t s) {

@@ -300,19 +300,13 @@ void i8_strip_kernel(Strip8Args a) {
             }
             outw[t] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         }
-        // B operands stay live past the last MFMA: no destination may re-use their registers (see bn_f32_strip.hip)
-        if constexpr (NW > 1) {
-#pragma unroll
-            for (int ks = 0; ks < NW; ++ks) asm volatile("" ::"v"(bfs[ks]));
-        } else {
-#pragma unroll
-            for (int ql = 0; ql < QL; ++ql) asm volatile("" ::"v"(bfrag[ql]));
-        }
         const int soff = oh * a.OW * COUT;
         if constexpr (NT == 2) {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, soff, 0);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(int)))) int, (v4i){outw[0], outw[1], outw[2], outw[3]}), rs_out, voff_out, soff, 0);
+            v4i ov = {outw[0], outw[1], outw[2], outw[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(int)))) int, ov), rs_out, voff_out, soff, 0);
+            asm volatile("s_nop 1" : "+v"(ov));  // the data registers of a 16-byte store are not rewritten right behind it (bn_f32_strip.hip: store16)
         }
     };
 
@@ -455,7 +449,6 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
                 for (int e = 0; e < 4; ++e) qv[e] = med3(rq(acc[e], stm[e], stc1[e], ste[e]), a.st_lo, a.st_hi);
                 pk[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
             }
-            asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]));  // B operands live past the MFMAs (no destination re-uses them)
             if (right_st) pk[2] = zst4;
             const int lo = perm(pk[1], pk[0], 0x05010400u);
             const int hi = perm(pk[1], pk[0], 0x07030602u);
@@ -487,7 +480,6 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
             for (int e = 0; e < 4; ++e) ov[e] = med3(rq(acc[e], pwm[t][e], pwc1[t][e], pwe[t][e]), a.pw_lo, a.pw_hi);
             outw[t] = perm(perm(ov[3], ov[2], 0x0c0c0400u), perm(ov[1], ov[0], 0x0c0c0400u), 0x05040100u);
         }
-        asm volatile("" ::"v"(bf));
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, oh * a.OW * 32, 0);
     };
 

@@ -92,6 +92,17 @@ void launch_f32_gap_dense(const float* x, float* scores, float* logits, int B, i
                           const float* bias, hipStream_t s);
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s);
 // row-streaming strip kernel for the wide early blocks (bn_f32_strip.hip); launch_f32_dwpw picks it when supported
+struct F32FrontStripArgs {
+    const float* fe;      // [B][H0][W0]: frontend map, or raw mel energies when minmax != null
+    float* y;             // [B][OH][OW][32]
+    const float* stem_w; const float* stem_b;  // [3][3][16], [16]
+    const float* dw_w; const float* dw_b;      // [3][3][16], [16]
+    const float* pw_w; const float* pw_b;      // fragment order [1][2][64][4], [32]
+    const float* minmax; const float* wsum; const float* magp;  // finalising mode (see f32_front_kernel)
+    int B, H0, W0, OH, OW, TH, stem_act, dw_act, pw_act, mag;
+};
+bool f32_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW);
+void launch_f32_front_strip(F32FrontStripArgs a, hipStream_t s);
 bool f32_strip_supported(const DwPwArgs& a);
 void launch_f32_strip(DwPwArgs a, hipStream_t s);
 
