@@ -129,7 +129,7 @@ def kernel_symbol(kind: str, p: list) -> str:
         return "i8_front_strip_kernel"
     if kind == "f32_dwpw" and p[15]:
         cin, cout, ow, stride = p[2], p[10], p[7], p[3]
-        if ow % 16 == 0 and stride in (1, 2) and ((cin == 32 and cout in (32, 64)) or (cin == 64 and cout in (64, 128))):
+        if ow % 16 == 0 and stride in (1, 2) and ((cin == 32 and cout in (32, 64)) or (cin == 64 and cout in (64, 128)) or (cin, cout) == (128, 128)):
             return "f32_strip_kernel"
         if cin <= 64 and cout <= 64:
             return "f32_dwpw_wave_kernel"

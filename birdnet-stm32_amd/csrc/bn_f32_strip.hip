@@ -59,7 +59,6 @@ template <int NW, int COUT, int S, bool RES>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 2 && COUT == 32) ? 4 : 3))) void f32_strip_kernel(DwPwArgs a) {
     constexpr int CIN = 16 * NW, CWO = COUT / NW, NT = CWO / 16;
     static_assert(NT == 1 || NT == 2, "16 or 32 output channels per wave");
-    static_assert(NW == 2 || NW == 4, "two or four waves per strip");
     static_assert(!RES || (CIN == COUT && S == 1), "the residual is the block input");
     __shared__ v4f xchg[2][NW][64];
     __shared__ v4f dw_lds[9][CIN / 4];  // depthwise taps: re-read every row (9 x 16 B per lane) instead of pinning 36 registers
@@ -364,8 +363,8 @@ void launch_strip(const DwPwArgs& a, hipStream_t s) {
 bool f32_strip_supported(const DwPwArgs& a) {
     if (!a.has_dw || a.gate || a.OW % 16 || a.sh != a.sw || (a.sh != 1 && a.sh != 2)) return false;
     if (a.res && (a.res != a.x || a.sh != 1 || a.Cin != a.Cout)) return false;
-    // 128 -> 128 (eight waves per strip) needs ~145 registers per lane: one workgroup per CU, no faster than the tile kernel
-    const bool shape = (a.Cin == 32 && (a.Cout == 32 || a.Cout == 64)) || (a.Cin == 64 && (a.Cout == 64 || a.Cout == 128));
+    const bool shape = (a.Cin == 32 && (a.Cout == 32 || a.Cout == 64)) || (a.Cin == 64 && (a.Cout == 64 || a.Cout == 128)) ||
+                       (a.Cin == 128 && a.Cout == 128);  // eight waves per strip: ~145 registers, one workgroup per CU, still 0.07 vs 0.09 ms
     return shape && (long)a.H * a.W * a.Cin * 4 < 0x7fff0000L;
 }
 
@@ -410,6 +409,8 @@ void launch_f32_strip(DwPwArgs a, hipStream_t s) {
     BN_FSTRIP(2, 64, 2, false)
     BN_FSTRIP(4, 64, 2, false)
     BN_FSTRIP(4, 128, 1, false)
+    BN_FSTRIP(8, 128, 1, true)
+    BN_FSTRIP(8, 128, 1, false)
     BN_FSTRIP(4, 128, 2, false)
 #undef BN_FSTRIP
 }

@@ -149,9 +149,9 @@ def test_f32_strip_kernel_matches_tile_kernels(torch_mod, oracle_specs, monkeypa
     x = np.tile(oracle_specs[..., None], (9, 1, 1, 1))[:130]
     B = x.shape[0]
     runner = load_model_runner(KERAS_PATH, max_batch=B, keep_all=True)
-    ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.F32_DWPW and op.p[2] <= 64 and op.p[10] <= 128 and op.p[7] % 16 == 0]
+    ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.F32_DWPW and op.p[2] <= 128 and op.p[10] <= 128 and op.p[7] % 16 == 0]
     ops += [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.F32_FRONT and op.p[pk.OP_PATH] == pk.PATH_INPUT]  # front block
-    assert len(ops) == 6
+    assert len(ops) == 9
     monkeypatch.setenv("BN_F32_STRIP", "0")
     want_scores = runner.predict(x)
     want = {oi: runner.op_output(oi, B) for oi in ops}
@@ -167,7 +167,7 @@ def test_f32_strip_kernel_matches_tile_kernels(torch_mod, oracle_specs, monkeypa
             a = runner.op_output(oi, B)
             err = np.abs(a - want[oi]).max() / np.abs(want[oi]).max()
             assert err < 1e-5, f"rows per strip {th or 'auto'}: layer {runner.plan.ops[oi].name}: relative-to-peak difference {err:.3e}"
-        assert np.abs(got_scores - want_scores).max() < 1e-6
+        assert np.abs(got_scores - want_scores).max() < 5e-6
     # the audio path: the front block finalises the raw mel energies while loading (its own operator variant)
     import torch
 
@@ -180,7 +180,7 @@ def test_f32_strip_kernel_matches_tile_kernels(torch_mod, oracle_specs, monkeypa
             monkeypatch.setenv("BN_F32_STRIP_TH", th)
         else:
             monkeypatch.delenv("BN_F32_STRIP_TH", raising=False)
-        assert np.abs(runner.infer_audio_device(audio).cpu().numpy() - want_audio).max() < 1e-6
+        assert np.abs(runner.infer_audio_device(audio).cpu().numpy() - want_audio).max() < 5e-6
     runner.close()
 
 
