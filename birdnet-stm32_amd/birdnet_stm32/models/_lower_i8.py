@@ -129,7 +129,13 @@ def _strip_requant(mult, shift, zp: int, acc_lo, acc_hi) -> tuple[np.ndarray, np
 
 def strip_waves(cin: int, cout: int, stride: int, ow: int, add: bool) -> int:
     """Waves sharing one strip (channel split) — mirrors ``i8_strip_waves`` in csrc/bn_i8_strip.hip; 0 = no strip kernel."""
-    if ow % 16 or stride not in (1, 2) or (add and (stride != 1 or cin != cout)):
+    if stride not in (1, 2) or (add and (stride != 1 or cin != cout)):
+        return 0
+    if ow == 8:  # stage 4: two row blocks x 8 columns per wave (needs an even map height, checked by the caller)
+        if add:
+            return 8 if cin == 256 else 0
+        return 4 if (cin, cout, stride) == (128, 256, 2) else 0
+    if ow % 16:
         return 0
     if (cin, cout) == (64, 64):
         return 2
@@ -454,7 +460,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                 # every per-channel requantisation and the ADD's output one a right shift; tap column 1 never in the padding)
                 cst = None
                 ow_ = np.arange(OW)
-                nw = strip_waves(C, Cout, sh_, OW, bool(add_p[0])) if sh_ == sw_ else 0
+                nw = strip_waves(C, Cout, sh_, OW, bool(add_p[0])) if sh_ == sw_ and (OW != 8 or OH % 2 == 0) else 0
                 if (nw and (not add_p[0] or res_val == val[src])
                         and ((ow_ * sw_ - pl + 1 >= 0) & (ow_ * sw_ - pl + 1 < Wd)).all()):
                     cst = strip_constants(wt_.data[0], bdw, mu, sh, z_o, w2, b2, mu2, sh2, zo2, bool(add_p[0]), nw)

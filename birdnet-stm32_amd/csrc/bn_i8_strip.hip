@@ -85,7 +85,9 @@ __device__ __forceinline__ RawRow<QL> load_row(__amdgpu_buffer_rsrc_t rsrc, cons
 // CW = input channels per wave (32 or 64; 32 when NW > 1), NW = waves sharing a strip (channel split), COUT = all output channels.
 // Strips per workgroup: 4 single-wave strips, or one NW-wave strip; with the ADD 8 / 2, so that the 64 KB table is shared by 512
 // threads and two workgroups (16 waves) fit a CU.
-template <int CW, int NW, int COUT, int S, bool ADD>
+// W8: maps 8 columns wide (stage 4).  The 16 positions of a wave are 2 row blocks x 8 columns: lanes n < 8 walk the upper half of
+// the rows, lanes n >= 8 the lower half, each half streaming its own input rows (row offsets and row padding become per-lane).
+template <int CW, int NW, int COUT, int S, bool ADD, bool W8 = false>
 __global__ __launch_bounds__(64 * NW * (ADD ? 8 / NW : (NW == 1 ? 4 : 1))) __attribute__((amdgpu_waves_per_eu(CW == 32 ? 4 : 2)))
 void i8_strip_kernel(Strip8Args a) {
     constexpr int CIN = CW * NW, CL = CW / 4, QL = CL / 4;
@@ -130,7 +132,7 @@ void i8_strip_kernel(Strip8Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = NW == 1 ? 0 : wave % NW;  // channel slice of this wave
     const int n = lane & 15, kq = lane >> 4;
-    const int strips_x = a.OW >> 4;
+    const int strips_x = W8 ? 1 : a.OW >> 4;
     const int rblocks = (a.OH + a.TH - 1) / a.TH;
     int wid, chunk;
     if constexpr (NW == 1) {
@@ -149,7 +151,9 @@ void i8_strip_kernel(Strip8Args a) {
     }
     const int oh0 = ry * a.TH;
     const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
-    const int ow = sx * 16 + n;
+    const int steps = W8 ? nrows >> 1 : nrows;           // W8: two row blocks of nrows / 2 rows side by side (nrows even, see launcher)
+    const int rofs = W8 ? (n >> 3) * steps : 0;          // first output row of this lane's block, relative to oh0
+    const int ow = W8 ? (n & 7) : sx * 16 + n;
 
     // per-lane constants in registers
     int dww[QL][3][4], dwb[QL][4];
@@ -198,25 +202,36 @@ void i8_strip_kernel(Strip8Args a) {
     // padding columns load a valid neighbour instead (their value is replaced by the zero point below)
     const int coff = CW * w + CL * kq;
     const int voff_in[3] = {(left_pad ? 0 : iw0) * CIN + coff, (iw0 + 1) * CIN + coff, (right_pad ? a.W - 1 : iw0 + 2) * CIN + coff};
-    const int voff_out = ow * COUT + CWO * w + COL * kq;
-    const int ir0 = oh0 * S - a.pt;           // first input row of the strip
-    const int rows_needed = S * (nrows - 1) + 3;
+    const int voff_out = (rofs * a.OW + ow) * COUT + CWO * w + COL * kq;
+    const int ir0 = (oh0 + rofs) * S - a.pt;  // first input row of the strip (W8: of this lane's row block)
+    const int rows_needed = S * (steps - 1) + 3;
 
     RawRow<QL> raw[2];
     TRow<QL> T[3];
     int cen[3][QL];
 
+    // row_ok is wave-uniform except in W8 mode, where the two lane halves stream different rows
     auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
     auto issue = [&](int slot, int rr) {
-        if (row_ok(rr)) raw[slot] = load_row<QL>(rs_in, voff_in, (ir0 + rr) * row_bytes);
+        if constexpr (W8) {
+            if (rr < rows_needed) {
+                int ir = ir0 + rr;
+                ir = ir < 0 ? 0 : (ir >= a.H ? a.H - 1 : ir);  // padding rows load a valid row, replaced in consume()
+                const int vo[3] = {voff_in[0] + ir * row_bytes, voff_in[1] + ir * row_bytes, voff_in[2] + ir * row_bytes};
+                raw[slot] = load_row<QL>(rs_in, vo, 0);
+            }
+        } else {
+            if (row_ok(rr)) raw[slot] = load_row<QL>(rs_in, voff_in, (ir0 + rr) * row_bytes);
+        }
     };
     auto consume = [&](int slot, int rr, int ti) {
-        if (row_ok(rr)) {
+        const bool ok = row_ok(rr);
+        if (W8 ? rr < rows_needed : ok) {
 #pragma unroll
             for (int ql = 0; ql < QL; ++ql) {
-                const int r0 = left_pad ? zp4 : raw[slot].t[0][ql];
-                const int r1 = raw[slot].t[1][ql];
-                const int r2 = right_pad ? zp4 : raw[slot].t[2][ql];
+                const int r0 = (left_pad || (W8 && !ok)) ? zp4 : raw[slot].t[0][ql];
+                const int r1 = (W8 && !ok) ? zp4 : raw[slot].t[1][ql];
+                const int r2 = (right_pad || (W8 && !ok)) ? zp4 : raw[slot].t[2][ql];
                 const int lo = perm(r1, r0, 0x05010400u);  // r0.0 r1.0 r0.1 r1.1
                 const int hi = perm(r1, r0, 0x07030602u);  // r0.2 r1.2 r0.3 r1.3
                 T[ti].c[ql][0] = perm(r2, lo, 0x0c040100u);
@@ -321,10 +336,10 @@ void i8_strip_kernel(Strip8Args a) {
         issue(rr & 1, rr + 2);
     }
     constexpr int U = 6 / S;  // unroll period: window slots (3) x raw slots (2)
-    for (int k = 0; k < nrows; k += U) {
+    for (int k = 0; k < steps; k += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (k + u >= nrows) break;
+            if (k + u >= steps) break;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int rs = P + S * u + s;  // static part of the relative row index (k is a multiple of 6 rows)
@@ -336,14 +351,14 @@ void i8_strip_kernel(Strip8Args a) {
     }
 }
 
-template <int CW, int NW, int COUT, int S, bool ADD>
+template <int CW, int NW, int COUT, int S, bool ADD, bool W8 = false>
 void launch_strip(const Strip8Args& a, hipStream_t s) {
     constexpr int SPB = ADD ? 8 / NW : (NW == 1 ? 4 : 1);
     constexpr int QL = CW / 16, NT = COUT / NW / 16;
     constexpr size_t smem = (ADD ? 65536 : 0) + (size_t)NW * (4 * QL * 12 + 4 * NT * 12) * 4 + (NW > 1 ? NW * 4 * QL * 12 * 4 + 2 * SPB * NW * 64 * 8 : 0);
-    const long per_chunk = (long)(a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
+    const long per_chunk = (long)(W8 ? 1 : a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
     const long blocks = NW == 1 ? (a.B * per_chunk + SPB - 1) / SPB : ((a.B + SPB - 1) / SPB) * per_chunk;
-    auto kern = i8_strip_kernel<CW, NW, COUT, S, ADD>;
+    auto kern = i8_strip_kernel<CW, NW, COUT, S, ADD, W8>;
     if (smem > 65536) {
         static bool raised = false;  // one attribute call per instantiation
         if (!raised) {
@@ -506,7 +521,12 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
 
 // channel split of a block: waves per strip (1 = a wave holds all input channels); 0 = no strip kernel for this shape
 int i8_strip_waves(int Cin, int Cout, int stride, int OW, bool add) {
-    if (OW % 16 || (stride != 1 && stride != 2)) return 0;
+    if (stride != 1 && stride != 2) return 0;
+    if (OW == 8) {  // stage 4: two row blocks x 8 columns per wave
+        if (add) return (stride == 1 && Cin == 256 && Cout == 256) ? 8 : 0;
+        return (stride == 2 && Cin == 128 && Cout == 256) ? 4 : 0;
+    }
+    if (OW % 16) return 0;
     if (add && (stride != 1 || Cin != Cout)) return 0;
     if (Cin == 64 && Cout == 64) return 2;  // measured: two waves x 32 channels (136 VGPRs) beat one wave x 64 (230) by 5 %
     if ((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) return 1;
@@ -517,17 +537,20 @@ int i8_strip_waves(int Cin, int Cout, int stride, int OW, bool add) {
 }
 
 bool i8_strip_supported(int Cin, int Cout, int stride, int OW, bool add) { return i8_strip_waves(Cin, Cout, stride, OW, add) != 0; }
+// (8-wide maps additionally need an even height: checked by the packer, which only then emits the constant block)
 
 void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s) {
     const bool add = a.add.enabled != 0;
     const int nw = i8_strip_waves(Cin, Cout, stride, a.OW, add);
     // rows per wave: as tall as possible while the launch still fills the chip a few times over
     int th = a.OH;
-    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 16384) th = (th + 1) / 2;
-    if (const char* e = getenv("BN_I8_STRIP_TH")) {  // tests: force the rows per wave (any value >= 1)
-        const int v = atoi(e);
-        if (v >= 1) th = v < a.OH ? v : a.OH;
-    }
+    if (a.OW != 8) {
+        while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 16384) th = (th + 1) / 2;
+        if (const char* e = getenv("BN_I8_STRIP_TH")) {  // tests: force the rows per wave (any value >= 1)
+            const int v = atoi(e);
+            if (v >= 1) th = v < a.OH ? v : a.OH;
+        }
+    }  // 8-wide maps: the whole (even) height, half per lane group
     a.TH = th;
 #define BN_STRIP(CW, NW, CO, ST, AD) \
     if (Cin == CW * NW && nw == NW && Cout == CO && stride == ST && add == AD) return launch_strip<CW, NW, CO, ST, AD>(a, s);
@@ -547,6 +570,10 @@ void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s)
     BN_STRIP(32, 4, 128, 2, false)
     BN_STRIP(32, 2, 128, 2, false)
 #undef BN_STRIP
+    if (a.OW == 8 && (a.OH & 1) == 0) {
+        if (Cin == 128 && Cout == 256 && stride == 2 && !add) return launch_strip<32, 4, 256, 2, false, true>(a, s);
+        if (Cin == 256 && Cout == 256 && stride == 1 && add) return launch_strip<32, 8, 256, 1, true, true>(a, s);
+    }
 }
 
 bool i8_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW) {

@@ -227,7 +227,7 @@ def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypa
     runner = load_model_runner(TFLITE_PATH, max_batch=B, keep_all=True)
     want_scores = runner.predict(x)
     strip_ops = [oi for oi, op in enumerate(runner.plan.ops) if (op.kind == pk.I8_DWPW and op.p[35]) or (op.kind == pk.I8_FRONT and op.p[16])]
-    assert len(strip_ops) == 9
+    assert len(strip_ops) == 11
     want = {oi: runner.op_output(oi, B) for oi in strip_ops}
     runner.close()
     monkeypatch.setenv("BN_I8_STRIP", "1")

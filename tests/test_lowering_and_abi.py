@@ -326,7 +326,7 @@ def test_strip_constant_block_reproduces_the_oracle():
 
     plan = lower_model_file(TFLITE_PATH, keep_all=True, fuse=True)
     strip_ops = [o for o in plan.ops if o.kind == pk.I8_DWPW and o.p[35]]
-    assert [o.name for o in strip_ops] == ["t102", "t104", "t107", "t110", "t112", "t115", "t118", "t121"]
+    assert [o.name for o in strip_ops] == ["t102", "t104", "t107", "t110", "t112", "t115", "t118", "t121", "t123", "t126"]
     S = np.stack([stft.hybrid_spectrogram(a) for a in synth_chunks(2)])[..., None]
     _, env = Int8Interpreter(load_tflite(TFLITE_PATH)).invoke(S, return_all=True)
     by_val = {o.out: o for o in plan.ops}
@@ -339,7 +339,7 @@ def test_strip_constant_block_reproduces_the_oracle():
         from birdnet_stm32.models._lower_i8 import strip_waves
 
         nw = strip_waves(o.p[2], o.p[14], o.p[3], o.p[7], bool(o.p[18]))
-        assert nw == {32: 1, 64: 2, 128: 4}[o.p[2]]
+        assert nw == {32: 1, 64: 2, 128: 4, 256: 8}[o.p[2]]
         tab = np.asarray(plan.tensors[o.t[10]], np.int8).reshape(256, 256) if o.p[18] else None
         got = _emulate_strip(np.asarray(plan.tensors[o.t[9]], np.int32), x, o.p, nw, tab)
         assert np.array_equal(got, want), f"{o.name}: {(got != want).sum()} of {got.size} values differ"
