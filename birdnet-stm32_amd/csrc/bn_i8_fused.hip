@@ -17,6 +17,8 @@
 //   phase 2: A fragments = 16 consecutive channel bytes per lane (one ds_read_b128), B fragments from the
 //            weights the packer stored in fragment order (1 KiB contiguous per wave-instruction)
 //   epilogue: int32 accumulators -> LDS -> requantise 4 channels per thread -> packed dword stores.
+#include <stdlib.h>
+
 #include "bn_kernels.h"
 #include "bn_requant.h"
 
@@ -444,6 +446,67 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The frontend's mel mixer as its own kernel: CONV_2D 1x1 over the padded frequency axis (K = Kp, a multiple of 64) to 64 mel
+// bins + ReLU clamp + per-channel PWL table, output transposed to [M][W].  Same results as i8_dwpw_kernel<.., TRANSPOSED>; the
+// generic kernel spends its time on position tables and item loops, here the 64 x Kp activation tile of a workgroup is ONE
+// contiguous 20 KB run of the [W][Kp] input (plain 16-byte copies into LDS), each wave owns 16 mel bins, and a lane requantises
+// four consecutive frames of one bin (one dword store into the transposed output).
+__global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
+    extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+    v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);
+    const int Kp = a.Cin, W = a.W, M = a.Cout;
+    const int S16 = (Kp >> 4) + 1;  // row stride in 16-byte units (one unit of padding: conflict-free 16-byte reads along rows)
+    const int tid = threadIdx.x;
+    const int tiles_x = W >> 6;
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int chunk = bid / tiles_x, t0 = (bid - chunk * tiles_x) << 6;
+    const v4i* src = reinterpret_cast<const v4i*>(a.x + ((size_t)chunk * W + t0) * Kp);
+    const int per_row = Kp >> 4;
+    for (int i = tid; i < 64 * per_row; i += 256) {
+        const int row = i / per_row, c = i - row * per_row;
+        lds16[row * S16 + c] = src[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;  // wave wv: mel bins 16 wv .. 16 wv + 15
+    const int r = lane & 15, q = lane >> 4;
+    const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);  // [Kp/64][M/16][64 lanes] x 16 bytes
+    const int n_ct = M >> 4;
+    v4i acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (v4i){0, 0, 0, 0};
+    const int ksteps = Kp >> 6;
+    v4i bf = wp[((size_t)0 * n_ct + wv) * 64 + lane];
+    for (int s = 0; s < ksteps; ++s) {
+        v4i bnext = bf;
+        if (s + 1 < ksteps) bnext = wp[((size_t)(s + 1) * n_ct + wv) * 64 + lane];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16[(16 * g + r) * S16 + 4 * s + q], bf, acc[g], 0, 0, 0);
+        bf = bnext;
+    }
+    // lane (n = r, q): accumulator register reg of row group g = frame t0 + 16 g + 4 q + reg of mel bin 16 wv + r
+    const int mel = 16 * wv + r;
+    const int b = a.pw_b[mel], m = a.pw_mult[mel], sh = a.pw_shift[mel];
+    const bool rq = a.rq_right != 0;
+    int8_t* yrow = a.y + ((size_t)chunk * M + mel) * W + t0 + 4 * q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int qv = clampi(mbqm_u(acc[g][e] + b, m, sh, rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+            if (a.lut) qv = a.lut[mel * 256 + qv + 128];
+            packed |= (qv & 0xff) << (8 * e);
+        }
+        *reinterpret_cast<int*>(yrow + 16 * g) = packed;
+    }
+}
+
+bool i8_mel_mfma_supported(const DwPw8Args& a) {
+    return a.transposed && !a.has_dw && !a.add.enabled && a.Cout == 64 && a.Cin % 64 == 0 && a.W % 64 == 0 && a.H == 1 && a.OH == 1 && a.OW == a.W &&
+           (size_t)64 * (a.Cin + 16) <= 65536;
+}
+
 template <int RG, int CT>
 void launch_cfg8(const DwPw8Args& a, hipStream_t s) {
     const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * ((a.B + a.NB - 1) / a.NB);
@@ -477,6 +540,11 @@ void launch_i8_front(const I8FrontParams& q, const int8_t* fe, int8_t* y, int B,
 bool i8_dwpw_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 16 == 0 && Cin >= 4; }
 
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
+    static const bool mel_kernel = !(getenv("BN_I8_MEL_GENERIC") && atoi(getenv("BN_I8_MEL_GENERIC")));
+    if (mel_kernel && i8_mel_mfma_supported(a)) {
+        hipLaunchKernelGGL(i8_mel_mfma_kernel, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);
+        return;
+    }
     const int ct_total = a.Cout / 16;
     static const int kSlices[] = {16, 12, 8, 6, 4, 3, 2, 1};
     int slice = 1;
