@@ -188,7 +188,8 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
     """Time the CPU restatement of the reference path (``oracle/``) on this host, on a bounded sample.
 
     float32: the plain-C + OpenMP port (``oracle/c/oracle_cpu.c``) on all host threads when it has been built, otherwise the
-    numpy oracle on one thread.  INT8: the numpy TFLite-semantics interpreter on one thread (there is no C port of it).
+    numpy oracle on one thread.  INT8: the C + OpenMP port of the TFLite int8 reference kernels (``oracle/c/oracle_i8.c``) when
+    built, otherwise the numpy interpreter on one thread.
     """
     import contextlib
 
@@ -226,6 +227,23 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
         return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": path.threads, "kind": "port",
                 "sample": f"{done} synthetic 3 s @ 24 kHz chunks, plain-C + OpenMP port of the float path (oracle/c/oracle_cpu.c), "
                           f"{path.threads} threads, {dt:.1f} s"}
+
+    if dtype == "i8" and os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB):
+        path = cport.CpuInt8Path(load_tflite(ckpt + ".tflite"))
+        x = chunks(256)
+        path.invoke(path.spectrogram(x[:32], HOP, W))  # warm up the OpenMP pool
+        t0 = time.perf_counter()
+        path.invoke(path.spectrogram(x, HOP, W))
+        per = (time.perf_counter() - t0) / 256
+        n = int(max(256, min(16384, seconds_budget / per // 256 * 256)))
+        reps, done, t0 = n // 256, 0, time.perf_counter()
+        for _ in range(reps):
+            path.invoke(path.spectrogram(x, HOP, W))
+            done += 256
+        dt = time.perf_counter() - t0
+        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": path.threads, "kind": "port",
+                "sample": f"{done} synthetic 3 s @ 24 kHz chunks, plain-C + OpenMP port of the TFLite int8 reference kernels "
+                          f"(oracle/c/oracle_i8.c under the numpy interpreter's graph walk) + C STFT, {path.threads} threads, {dt:.1f} s"}
 
     if dtype == "f32":
         spec = load_keras_archive(ckpt + ".keras")

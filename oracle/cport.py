@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CPU_LIB = os.path.join(_HERE, "_build", "liboracle_cpu.so")
+I8_LIB = os.path.join(_HERE, "_build", "liboracle_i8.so")
 FW_LIB = os.path.join(_HERE, "_ref", "libfw_ref.so")
 
 _f = ctypes.POINTER(ctypes.c_float)
@@ -122,6 +123,139 @@ class CpuFloatPath:
         bd = np.ascontiguousarray(head.weights["bias"], np.float32)
         lib.oc_gap_dense(_p(feat), B, H * Wd, C, N, _p(wd), _p(bd), act, _p(logits), _p(scores))
         return scores, logits, S
+
+
+def _i8(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int8))
+
+
+def _i32(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if a is not None else None
+
+
+class CpuInt8Path:
+    """The numpy TFLite-semantics interpreter (oracle/int8_graph.py) with its heavy operators in plain C + OpenMP
+    (oracle/c/oracle_i8.c): CONV_2D, DEPTHWISE_CONV_2D, ADD, MEAN, FULLY_CONNECTED.  Quantisation parameters, multipliers
+    and activation ranges come from the numpy interpreter's own preparation code, so both paths share one definition;
+    tests check that their tensors are identical.  ``spectrogram()`` is the C STFT of the float port."""
+
+    def __init__(self, model):
+        from oracle import int8_graph as ig
+
+        self.ig = ig
+        self.lib = ctypes.CDLL(I8_LIB)
+        self.lib.oi_max_threads.restype = ctypes.c_int
+        self.threads = int(self.lib.oi_max_threads())
+        outer = self
+
+        class _Interp(ig.Int8Interpreter):
+            def _conv(self, op, env, depthwise):
+                x = np.ascontiguousarray(self._value(env, op.inputs[0]), np.int8)
+                wt = self.model.tensors[op.inputs[1]]
+                w = np.ascontiguousarray(wt.data, np.int8)
+                bias = (np.ascontiguousarray(self.model.tensors[op.inputs[2]].data, np.int32)
+                        if len(op.inputs) > 2 and op.inputs[2] >= 0 else None)
+                s_in, zp_in = self._q(op.inputs[0])
+                s_out, zp_out = self._q(op.outputs[0])
+                o = op.options
+                if o["padding"] != "SAME" or o.get("dilation_w", 1) != 1 or o.get("dilation_h", 1) != 1:
+                    raise ValueError("only SAME, undilated convolutions occur in the reference graphs")
+                sh, sw = o["stride_h"], o["stride_w"]
+                B, H, W, Cin = x.shape
+                if depthwise:
+                    _, kh, kw, cout = w.shape
+                else:
+                    cout, kh, kw, _ = w.shape
+                if op.index not in self._prep:
+                    mult, shift = ig._per_channel_multipliers(s_in, wt.scale, s_out, cout)
+                    self._prep[op.index] = {"mult": np.ascontiguousarray(mult, np.int32), "shift": np.ascontiguousarray(shift, np.int32),
+                                            "act": ig.activation_range(o["activation"], s_out, zp_out)}
+                p = self._prep[op.index]
+                oh, pt, _ = ig._same(H, kh, sh)
+                ow, pl, _ = ig._same(W, kw, sw)
+                y = np.empty((B, oh, ow, cout), np.int8)
+                lo, hi = (int(v) for v in p["act"])
+                if depthwise:
+                    outer.lib.oi_dwconv(_i8(x), _i8(y), B, H, W, Cin, kh, kw, sh, sw, oh, ow, pt, pl, _i8(w), _i32(bias), zp_in, zp_out,
+                                        _i32(p["mult"]), _i32(p["shift"]), lo, hi)
+                else:
+                    outer.lib.oi_conv(_i8(x), _i8(y), B, H, W, Cin, kh, kw, cout, sh, sw, oh, ow, pt, pl, _i8(w), _i32(bias), zp_in, zp_out,
+                                      _i32(p["mult"]), _i32(p["shift"]), lo, hi)
+                return y
+
+            def _add(self, op, env):
+                a = np.ascontiguousarray(self._value(env, op.inputs[0]), np.int8)
+                b = np.ascontiguousarray(self._value(env, op.inputs[1]), np.int8)
+                if b.shape != a.shape:  # broadcast operand: only a trailing-axes match maps onto the C kernel's period
+                    if a.size < b.size or b.size == 0 or a.size % b.size or tuple(a.shape[a.ndim - b.ndim:]) != tuple(b.shape):
+                        return super()._add(op, env)
+                s1, z1 = self._q(op.inputs[0])
+                s2, z2 = self._q(op.inputs[1])
+                so, zo = self._q(op.outputs[0])
+                if op.index not in self._prep:
+                    twice_max = 2.0 * max(float(np.float32(s1)), float(np.float32(s2)))
+                    self._prep[op.index] = {"m1": ig.quantize_multiplier(float(np.float32(s1)) / twice_max),
+                                            "m2": ig.quantize_multiplier(float(np.float32(s2)) / twice_max),
+                                            "mo": ig.quantize_multiplier(twice_max / ((1 << 20) * float(np.float32(so)))),
+                                            "act": ig.activation_range(op.options["activation"], so, zo)}
+                p = self._prep[op.index]
+                y = np.empty(a.shape, np.int8)
+                lo, hi = (int(v) for v in p["act"])
+                outer.lib.oi_add(_i8(a), _i8(b), _i8(y), ctypes.c_long(a.size), ctypes.c_long(b.size), z1, int(p["m1"][0]), int(p["m1"][1]), z2,
+                                 int(p["m2"][0]), int(p["m2"][1]), int(p["mo"][0]), int(p["mo"][1]), zo, lo, hi)
+                return y
+
+            def _mean(self, op, env):
+                x = self._value(env, op.inputs[0])
+                axes = sorted(int(a) % x.ndim for a in np.atleast_1d(self._value(env, op.inputs[1])))
+                if x.ndim != 4 or axes != [1, 2]:
+                    return super()._mean(op, env)
+                x = np.ascontiguousarray(x, np.int8)
+                B, H, W, C = x.shape
+                s_in, zp_in = self._q(op.inputs[0])
+                s_out, zp_out = self._q(op.outputs[0])
+                n = H * W
+                mult, shift = ig.quantize_multiplier(float(np.float32(s_in)) / float(np.float32(s_out)))
+                fold = min(n.bit_length() - 1, 32, 31 + shift)
+                mult = int((mult << fold) // n)
+                shift -= fold
+                y = np.empty((B, C), np.int8)
+                outer.lib.oi_mean(_i8(x), _i8(y), B, n, C, zp_in, mult, shift, zp_out)
+                return y.reshape((B, 1, 1, C)) if op.options.get("keep_dims") else y
+
+            def _fully_connected(self, op, env):
+                x = np.ascontiguousarray(self._value(env, op.inputs[0]), np.int8)
+                wt = self.model.tensors[op.inputs[1]]
+                w = np.ascontiguousarray(wt.data, np.int8)
+                bias = (np.ascontiguousarray(self.model.tensors[op.inputs[2]].data, np.int32)
+                        if len(op.inputs) > 2 and op.inputs[2] >= 0 else None)
+                s_in, zp_in = self._q(op.inputs[0])
+                s_out, zp_out = self._q(op.outputs[0])
+                if op.index not in self._prep:
+                    mult, shift = ig._per_channel_multipliers(s_in, wt.scale, s_out, w.shape[0])
+                    self._prep[op.index] = {"mult": np.ascontiguousarray(mult, np.int32), "shift": np.ascontiguousarray(shift, np.int32),
+                                            "act": ig.activation_range(op.options["activation"], s_out, zp_out)}
+                p = self._prep[op.index]
+                x2 = x.reshape(-1, w.shape[1])
+                y = np.empty((x2.shape[0], w.shape[0]), np.int8)
+                lo, hi = (int(v) for v in p["act"])
+                outer.lib.oi_fc(_i8(x2), _i8(y), x2.shape[0], w.shape[1], w.shape[0], _i8(w), _i32(bias), zp_in, zp_out, _i32(p["mult"]),
+                                _i32(p["shift"]), lo, hi)
+                return y
+
+        self.interp = _Interp(model)
+
+    def invoke(self, x, return_all: bool = False):
+        return self.interp.invoke(x, return_all=return_all)
+
+    @staticmethod
+    def spectrogram(audio: np.ndarray, hop: int, width: int) -> np.ndarray:
+        """Normalised |STFT| [B, 257, width, 1] through the float port's C STFT (OpenMP over chunks)."""
+        lib = ctypes.CDLL(CPU_LIB)
+        x = np.ascontiguousarray(audio, np.float32)
+        S = np.empty((x.shape[0], 257, width), np.float32)
+        lib.oc_stft_norm(_p(x), x.shape[0], x.shape[1], hop, width, _p(S))
+        return S[..., None]
 
 
 class FirmwareRef:

@@ -308,3 +308,25 @@ def test_ingest_window_and_chunks_equal_host_io(tmp_path):
         y = ingest.ingest_window(pcm.astype(np.float32) / 32768.0, sr, 24000)
         got = ingest.split_chunks(y, 24000, 3.0, overlap)
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_c_int8_port_is_identical_to_the_numpy_interpreter():
+    """oracle/c/oracle_i8.c (the INT8 CPU baseline) against oracle/int8_graph.py: every tensor of the shipped graph, bit for bit."""
+    from birdnet_stm32.models._tflite_reader import load_tflite
+    from oracle import cport, stft
+    from oracle.int8_graph import Int8Interpreter
+
+    from conftest import TFLITE_PATH, synth_chunks
+
+    if not (os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB)):
+        pytest.skip("oracle C libraries not built (python -c 'import __graft_entry__ as g; g.build()')")
+    model = load_tflite(TFLITE_PATH)
+    x = synth_chunks(3)
+    S = np.stack([stft.hybrid_spectrogram(a) for a in x])[..., None]
+    ref, env = Int8Interpreter(model).invoke(S, return_all=True)
+    port = cport.CpuInt8Path(model)
+    got, env_c = port.invoke(S, return_all=True)
+    assert np.array_equal(got, ref)
+    for k, v in env.items():
+        assert np.array_equal(np.asarray(v), np.asarray(env_c[k])), f"tensor {k} differs"
+    assert np.abs(port.spectrogram(x, 281, 256) - S).max() < 1e-6  # the C STFT of the float port
