@@ -86,6 +86,8 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
         n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[10]
         macs = p[6] * p[7] * p[2] * (p[10] + (9 if p[15] else 0))
         return batch * 4.0 * (n_in + n_out * (2 if p[12] else 1)), batch * 2.0 * macs
+    if k == "i8_dwpw" and p[36]:  # mel mixer with QUANTIZE fused into its load: float32 spectrogram in, int8 [M][W] out
+        return batch * (p[5] * p[1] * 4.0 + p[14] * p[1]), batch * 2.0 * p[1] * p[2] * p[14]
     if k == "i8_dwpw":
         n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[14]
         macs = p[6] * p[7] * p[2] * (p[14] + (9 if p[29] else 0))
@@ -125,6 +127,8 @@ def kernel_symbol(kind: str, p: list) -> str:
         return "stft512_mag_kernel"
     if kind == "i8_dwpw" and p[35]:
         return "i8_strip_kernel"
+    if kind == "i8_dwpw" and p[30] and p[14] == 64:
+        return "i8_mel_mfma_kernel"
     if kind == "i8_front" and p[16]:
         return "i8_front_strip_kernel"
     if kind == "f32_dwpw" and p[15]:

@@ -340,21 +340,28 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
 
     plan = pk.Plan(pk.DTYPE_I8, pk.INPUT_SPECTROGRAM, F * W, F, W, int(t[model.outputs[0]].shape[-1]), meta={"tflite_ops": len(ops)})
     pb = pk.PlanBuilder(plan)
-    v_q = pb.value(W * Kp)
-    pb.op(pk.I8_QUANT, pk.SLOT_INPUT, v_q, p=[F, W, Kp, q_zp, fill_value], f=[q_scale], name=f"t{mel.inputs[0]}",
-          out_shape=(W, Kp), out_dtype="int8")
-    v = pb.value(M * W)
     tens = [pb.tensor(w_mel, np.int8), pb.tensor(bias, np.int32), pb.tensor(mult, np.int32), pb.tensor(shift, np.int32)]
     if lut is not None:
         tens.append(pb.tensor(lut, np.int8))
     mel_tile = pick_tile(1, W)
-    if fuse and mel_tile is not None and M % 16 == 0:
+    mfma_mel = fuse and mel_tile is not None and M % 16 == 0
+    # production plans quantise inside the mel mixer's load (i8_mel_mfma_kernel<QIN>: one pass over the float32 spectrogram, no int8
+    # copy of it in HBM); keep_all plans keep QUANTIZE as its own operator so that its tensor can be compared
+    quant_in_mel = mfma_mel and not keep_all and M == 64 and Kp % 64 == 0 and W % 64 == 0
+    v_q = pk.SLOT_INPUT
+    if not quant_in_mel:
+        v_q = pb.value(W * Kp)
+        pb.op(pk.I8_QUANT, pk.SLOT_INPUT, v_q, p=[F, W, Kp, q_zp, fill_value], f=[q_scale], name=f"t{mel.inputs[0]}",
+              out_shape=(W, Kp), out_dtype="int8")
+    v = pb.value(M * W)
+    if mfma_mel:
         zero = pb.tensor(np.zeros(4, np.int32), np.int32)
-        p = [1, W, Kp, 1, 1, 0, 1, W, 0, 0, 0, 0, 0, 0, M, z_mel, lo, hi, *([0] * 11), 0, 1, *mel_tile, int(lut is not None)]
+        p = [1, W, Kp, 1, 1, F if quant_in_mel else 0, 1, W, 0, 0, 0, 0, 0, 0, M, z_mel, lo, hi, *([0] * 11), 0, 1, *mel_tile, int(lut is not None),
+             0, int(quant_in_mel), q_zp, fill_value]
         tt = [zero, zero, zero, zero, pb.tensor(pack_i8_fragments(w_mel), np.int8), tens[1], tens[2], tens[3]]
         if lut is not None:
             tt.append(tens[4])
-        pb.op(pk.I8_DWPW, v_q, v, p=p, t=tt, name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
+        pb.op(pk.I8_DWPW, v_q, v, p=p, t=tt, f=[q_scale], name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
     else:
         pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
               out_shape=(M, W, 1), out_dtype="int8")

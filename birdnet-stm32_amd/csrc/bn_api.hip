@@ -273,6 +273,16 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 a.add = bn::I8AddParams{p[18], p[19], p[20], p[21], p[22], p[23], p[24], p[25], p[26], p[27], p[28]};
                 a.has_dw = p[29]; a.transposed = p[30]; a.TH = p[31]; a.TW = p[32]; a.NB = p[33];
                 a.rq_right = m->rq_right[oi];
+                if (a.transposed && p[36]) {  // QUANTIZE fused into the mel mixer: the input slot holds the float32 spectrogram
+                    a.qx = (const float*)in0;
+                    a.qminmax = mm;
+                    a.qscale = o.f[0];
+                    a.qzp = p[37];
+                    a.qfill = p[38];
+                    a.qF = p[5];
+                    a.x = nullptr;
+                    if (!bn::i8_mel_mfma_supported(a)) return fail(BN_ERR_FORMAT, "operator %zu: fused QUANTIZE needs the mel-mixer kernel's geometry", oi);
+                }
                 // wide early layers: wave-autonomous strip kernel when the packer prepared its constant block
                 if (p[35] && o.t[9] >= 0 && m->use_strip && a.has_dw && !a.transposed && a.sh == a.sw &&
                     bn::i8_strip_supported(a.Cin, a.Cout, a.sh, a.OW, a.add.enabled != 0) &&

@@ -452,6 +452,19 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
 // generic kernel spends its time on position tables and item loops, here the 64 x Kp activation tile of a workgroup is ONE
 // contiguous 20 KB run of the [W][Kp] input (plain 16-byte copies into LDS), each wave owns 16 mel bins, and a lane requantises
 // four consecutive frames of one bin (one dword store into the transposed output).
+// Exact float32 division by a constant whose correctly rounded reciprocal y = RN(1 / b) is known: q0 = RN(a y),
+// r = fma(-b, q0, a) (exact residual), q = fma(r, y, q0) is RN(a / b) (Markstein's correction step; no underflow or overflow
+// occurs for the operands here: a / b lies in [0, 256]).  Three instructions instead of the ~10 of the IEEE division sequence;
+// tests compare it with true division on 10^8 operand pairs and the fused kernel with the separate QUANTIZE bit for bit.
+__device__ __forceinline__ float div_by_const(float a, float b, float y) {
+    const float q0 = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+}
+
+// QIN: QUANTIZE fused into the load — the input is the float32 spectrogram [B][qF][W] (frequency-major like the reference's
+// array); a 64 x 64 block is read as float4 along the frames, normalised with the chunk's min / max (audio path), quantised
+// with the same roundf(v / scale) + zp as i8_quant_kernel and written into the activation tile transposed.
+template <bool QIN>
 __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
     v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);
@@ -461,11 +474,45 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
     const int tiles_x = W >> 6;
     const int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int chunk = bid / tiles_x, t0 = (bid - chunk * tiles_x) << 6;
-    const v4i* src = reinterpret_cast<const v4i*>(a.x + ((size_t)chunk * W + t0) * Kp);
-    const int per_row = Kp >> 4;
-    for (int i = tid; i < 64 * per_row; i += 256) {
-        const int row = i / per_row, c = i - row * per_row;
-        lds16[row * S16 + c] = src[i];
+    if constexpr (!QIN) {
+        const v4i* src = reinterpret_cast<const v4i*>(a.x + ((size_t)chunk * W + t0) * Kp);
+        const int per_row = Kp >> 4;
+        for (int i = tid; i < 64 * per_row; i += 256) {
+            const int row = i / per_row, c = i - row * per_row;
+            lds16[row * S16 + c] = src[i];
+        }
+    } else {
+        int8_t* tile = reinterpret_cast<int8_t*>(lds_raw);
+        const int stride = S16 * 16;
+        const float* S = a.qx + (size_t)chunk * a.qF * W + t0;
+        float mn = 0.0f, rng = 1.0f, y_rng = 1.0f;
+        const bool renorm = a.qminmax != nullptr;
+        if (renorm) {
+            mn = a.qminmax[2 * chunk];
+            rng = (float)((double)(a.qminmax[2 * chunk + 1] - mn) + 1e-10);
+            y_rng = (float)(1.0 / (double)rng);
+        }
+        const float scale = a.qscale, y_scale = (float)(1.0 / (double)a.qscale);
+        const int c4 = tid & 15, r4 = tid >> 4;
+        for (int f0 = 0; f0 < Kp; f0 += 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = f0 + r4 + 16 * i;
+                int q[4] = {a.qfill, a.qfill, a.qfill, a.qfill};  // padded frequency columns: the graph's FILL constant
+                if (f < a.qF) {
+                    const float4 v = *reinterpret_cast<const float4*>(S + (size_t)f * W + 4 * c4);
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float x = e[k];
+                        if (renorm) x = div_by_const(x - mn, rng, y_rng);
+                        q[k] = clampi((int32_t)roundf(div_by_const(x, scale, y_scale)) + a.qzp, -128, 127);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tile[(4 * c4 + k) * stride + f] = (int8_t)q[k];
+            }
+        }
     }
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;  // wave wv: mel bins 16 wv .. 16 wv + 15
@@ -502,11 +549,6 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
     }
 }
 
-bool i8_mel_mfma_supported(const DwPw8Args& a) {
-    return a.transposed && !a.has_dw && !a.add.enabled && a.Cout == 64 && a.Cin % 64 == 0 && a.W % 64 == 0 && a.H == 1 && a.OH == 1 && a.OW == a.W &&
-           (size_t)64 * (a.Cin + 16) <= 65536;
-}
-
 template <int RG, int CT>
 void launch_cfg8(const DwPw8Args& a, hipStream_t s) {
     const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * ((a.B + a.NB - 1) / a.NB);
@@ -537,12 +579,20 @@ void launch_i8_front(const I8FrontParams& q, const int8_t* fe, int8_t* y, int B,
     hipLaunchKernelGGL(i8_front_kernel, dim3((q.OH / 8) * (q.OW / 8) * B), dim3(256), 0, s, a);
 }
 
+bool i8_mel_mfma_supported(const DwPw8Args& a) {
+    return a.transposed && !a.has_dw && !a.add.enabled && a.Cout == 64 && a.Cin % 64 == 0 && a.W % 64 == 0 && a.H == 1 && a.OH == 1 && a.OW == a.W &&
+           (size_t)64 * (a.Cin + 16) <= 65536;
+}
+
 bool i8_dwpw_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 16 == 0 && Cin >= 4; }
 
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
     static const bool mel_kernel = !(getenv("BN_I8_MEL_GENERIC") && atoi(getenv("BN_I8_MEL_GENERIC")));
-    if (mel_kernel && i8_mel_mfma_supported(a)) {
-        hipLaunchKernelGGL(i8_mel_mfma_kernel, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);
+    if (a.qx || (mel_kernel && i8_mel_mfma_supported(a))) {  // (the packer only fuses QUANTIZE for shapes this kernel takes)
+        if (a.qx)
+            hipLaunchKernelGGL(i8_mel_mfma_kernel<true>, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);
+        else
+            hipLaunchKernelGGL(i8_mel_mfma_kernel<false>, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);
         return;
     }
     const int ct_total = a.Cout / 16;

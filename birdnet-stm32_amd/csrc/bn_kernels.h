@@ -152,8 +152,14 @@ struct DwPw8Args {
     int dw_zp_in, dw_zp_out, dw_amin, dw_amax, pw_zp_out, pw_amin, pw_amax;
     I8AddParams add;
     int rq_right;  // every multiplier >= 0 and every shift < 0 in this operator (set at load): branch-free requantisation
+    // mel mixer only: QUANTIZE fused into the load — x is unused, the input is the float32 spectrogram [B][qF][W]
+    const float* qx;       // null = int8 input in x
+    const float* qminmax;  // [B][2] per-chunk min / max for the (S - min) / (max - min + 1e-10) normalisation, or null
+    float qscale;
+    int qzp, qfill, qF;
 };
 bool i8_dwpw_supported(int Cin, int Cout);
+bool i8_mel_mfma_supported(const DwPw8Args& a);
 // Wave-autonomous strip kernel for the same block at Cin, Cout in {32, 64} (bn_i8_strip.hip); `cst` is the constant block
 // the packer prepares (models/_lower_i8.py: strip_constants).  With the ADD the residual must be the block input x.
 struct Strip8Args {

@@ -244,6 +244,20 @@ def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypa
             assert bad == 0, f"rows per wave {th or 'auto'}: tensor {runner.plan.ops[oi].name}: {bad} of {a.size} values differ, first at {np.argwhere(a != want[oi])[:3].tolist()}"
         assert np.array_equal(got_scores, want_scores)
     runner.close()
+    # the production plan (slots recycled, QUANTIZE fused into the mel mixer's load with the three-instruction exact division) gives
+    # the same scores bit for bit, on the test spectrograms and on random ones that exercise the rounding of the quantiser
+    monkeypatch.delenv("BN_I8_STRIP_TH", raising=False)
+    prod = load_model_runner(TFLITE_PATH, max_batch=B)
+    assert prod.plan.ops[0].kind == pk.I8_DWPW and prod.plan.ops[0].p[36] == 1
+    assert np.array_equal(prod.predict(x), want_scores)
+    dbg = load_model_runner(TFLITE_PATH, max_batch=B, keep_all=True)
+    xr = np.random.default_rng(11).random((64, 257, 256, 1), dtype=np.float32)
+    xr[:8] *= np.float32(1.0 / 255.0) * np.arange(0, 256, 32, dtype=np.float32)[:, None, None, None]  # values near the quantiser's steps
+    assert np.array_equal(prod.predict(xr), dbg.predict(xr))
+    mel_dbg = dbg.op_output(1, 64)
+    prod.close()
+    dbg.close()
+    assert mel_dbg.shape[1:] == (64, 256, 1) or mel_dbg.shape[1:] == (64, 256)
 
 
 def test_i8_from_audio_top1_and_cosine(torch_mod, audio24, oracle_specs):

@@ -32,8 +32,11 @@ def test_fused_plan_structure():
     assert (f32.ops[2].p[9], f32.ops[3].p[9]) == (0, 1)
     assert sum(1 for o in f32.ops if o.kind == pk.F32_DWPW and o.p[12]) == 7  # residual blocks
     kinds = [pk.KIND_NAMES[o.kind] for o in i8.ops]
-    assert kinds == ["i8_quant", "i8_dwpw", "i8_front"] + ["i8_dwpw"] * 10 + ["i8_mean", "i8_fc", "i8_head"]
-    assert i8.ops[1].p[30] == 1 and i8.ops[1].p[34] == 1  # the mel mixer: transposed output + PWL table
+    assert kinds == ["i8_dwpw", "i8_front"] + ["i8_dwpw"] * 10 + ["i8_mean", "i8_fc", "i8_head"]
+    mel = i8.ops[0]  # the mel mixer: QUANTIZE fused into its load (float32 spectrogram in), transposed output + PWL table
+    assert mel.in0 == pk.SLOT_INPUT and mel.p[36] == 1 and mel.p[5] == 257 and mel.p[30] == 1 and mel.p[34] == 1 and mel.f[0] > 0
+    _, i8_dbg = _plans(keep_all=True, fuse=True)  # debug plans keep QUANTIZE as its own operator (its tensor can be compared)
+    assert [pk.KIND_NAMES[o.kind] for o in i8_dbg.ops][:2] == ["i8_quant", "i8_dwpw"] and i8_dbg.ops[1].p[36] == 0
     assert sum(1 for o in i8.ops if o.kind == pk.I8_DWPW and o.p[18]) == 7
     for plan in (f32, i8):
         for o in plan.ops:
@@ -161,7 +164,7 @@ def test_pwl_table_and_folded_biases_match_the_oracle():
     model = load_tflite(TFLITE_PATH)
     _, i8f = _plans(fuse=True)
     _, i8 = _plans()
-    assert np.array_equal(i8f.tensors[i8f.ops[1].t[8]], i8.tensors[i8.ops[1].t[4]])  # same PWL table in both plans
+    assert np.array_equal(i8f.tensors[i8f.ops[0].t[8]], i8.tensors[i8.ops[1].t[4]])  # same PWL table in both plans (fused: mel mixer first)
     mel = i8.ops[1]
     lut = i8.tensors[mel.t[4]]  # [64][256]
     interp = og.Int8Interpreter(model)
