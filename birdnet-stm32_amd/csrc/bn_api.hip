@@ -62,6 +62,9 @@ struct bn_model {
     size_t consts_bytes = 0;
     std::vector<uint8_t> rq_right;       // per operator: all requantisation multipliers >= 0 and shifts < 0
     bool use_strip = true;               // BN_I8_STRIP=0 keeps the generic fused INT8 block everywhere (A/B runs, tests)
+    bool spec_tiled_ok = false;          // the plan's first operator reads the spectrogram through i8_mel_mfma_kernel<QIN>: bn_infer_audio
+                                         // may hand it the tile-major layout the STFT writes fastest
+    bool spec_tiled_now = false;         // set by bn_infer_audio around its bn_forward call
     std::vector<char*> d_slots;          // max_batch * bytes_per_chunk each
     float* d_spec = nullptr;             // [max_batch][F][W] for bn_infer_audio
     float* d_minmax = nullptr;           // [max_batch][2]
@@ -280,6 +283,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     a.qzp = p[37];
                     a.qfill = p[38];
                     a.qF = p[5];
+                    a.qtiled = (m->spec_tiled_now && o.in0 == BN_SLOT_INPUT) ? 1 : 0;
                     a.x = nullptr;
                     if (!bn::i8_mel_mfma_supported(a)) return fail(BN_ERR_FORMAT, "operator %zu: fused QUANTIZE needs the mel-mixer kernel's geometry", oi);
                 }
@@ -470,6 +474,9 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
     // INT8 blocks: can every requantisation of the operator take the branch-free right-shift form?
     m->rq_right.assign(h.n_ops, 0);
     if (const char* e = getenv("BN_I8_STRIP")) m->use_strip = e[0] != '0';
+    for (const OpRec& o : m->ops)
+        if (o.in0 == BN_SLOT_INPUT) m->spec_tiled_ok = o.kind == BN_OP_I8_DWPW && o.p[36] && o.p[30] && o.p[1] % 64 == 0;
+    if (getenv("BN_STFT_ROWMAJOR")) m->spec_tiled_ok = false;  // A/B: keep the reference layout inside bn_infer_audio
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         auto all_right = [&](int t_mult, int t_shift) {
@@ -559,8 +566,17 @@ int bn_model_get_info(const bn_model* m, bn_model_info* out) {
     return BN_OK;
 }
 
+static int stft_mag_impl(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize, float* d_spec,
+                         float* d_minmax, void* stream, bool tile_major);
+
 int bn_stft_mag(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize,
                 float* d_spec, float* d_minmax, void* stream) {
+    return stft_mag_impl(ctx, d_audio, B, T, n_fft, hop, W, normalize, d_spec, d_minmax, stream, false);
+}
+
+// tile_major: spectrogram as [W/16][257][16] per chunk (private to bn_infer_audio; the public entry point keeps [257][W])
+static int stft_mag_impl(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize, float* d_spec,
+                         float* d_minmax, void* stream, bool tile_major) {
     if (int rc = check_device(ctx)) return rc;
     if (!d_audio || !d_spec || !d_minmax) return fail(BN_ERR_ARG, "null device pointer");
     if (n_fft != kFft) return fail(BN_ERR_UNSUPPORTED, "n_fft=%d: only 512 is implemented", n_fft);
@@ -574,7 +590,7 @@ int bn_stft_mag(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int 
         const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
         bn::launch_minmax_init(d_minmax + 2 * (size_t)b0, nb, s);
         bn::launch_stft512(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, d_spec + b0 * per_chunk,
-                           d_minmax + 2 * (size_t)b0, s);
+                           d_minmax + 2 * (size_t)b0, s, tile_major);
         if (normalize)
             bn::launch_spec_normalize(d_spec + b0 * per_chunk, d_minmax + 2 * (size_t)b0, nb, (int)per_chunk, s);
     }
@@ -666,10 +682,13 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     // un-normalised magnitudes + per-chunk min/max; the plan's first operator normalises while loading
     {
         ProfScope prof(m, (int)m->ops.size(), (hipStream_t)stream);
-        if (int rc = bn_stft_mag(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream))
+        if (int rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, m->spec_tiled_ok))
             return rc;
     }
-    return bn_forward(m, m->d_spec, m->d_minmax, B, d_scores, d_logits, stream);
+    m->spec_tiled_now = m->spec_tiled_ok;
+    const int rc = bn_forward(m, m->d_spec, m->d_minmax, B, d_scores, d_logits, stream);
+    m->spec_tiled_now = false;
+    return rc;
 }
 
 int bn_ingest_resample(bn_ctx* ctx, const void* d_pcm, int sample_format, int channels, const int64_t* d_in_off,

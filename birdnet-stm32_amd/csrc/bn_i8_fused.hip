@@ -493,6 +493,29 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
             y_rng = (float)(1.0 / (double)rng);
         }
         const float scale = a.qscale, y_scale = (float)(1.0 / (double)a.qscale);
+        if (a.qtiled) {
+            // tile-major spectrogram [W/16][qF][16]: wave wv reads ITS 16-frame block as 1 KB runs (16 frequency rows x 64 bytes);
+            // lane = (row fr within the group of 16, frame quad ft)
+            const int lane = tid & 63, wv = tid >> 6;
+            const int ft = lane & 3, fr = lane >> 2;
+            const float* Sb = a.qx + (size_t)chunk * a.qF * W + (size_t)(t0 / 16 + wv) * a.qF * 16 + 4 * ft;
+            for (int f0 = 0; f0 < Kp; f0 += 16) {
+                const int f = f0 + fr;
+                int q[4] = {a.qfill, a.qfill, a.qfill, a.qfill};
+                if (f < a.qF) {
+                    const float4 v = *reinterpret_cast<const float4*>(Sb + (size_t)f * 16);
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float x = e[k];
+                        if (renorm) x = div_by_const(x - mn, rng, y_rng);
+                        q[k] = clampi((int32_t)roundf(div_by_const(x, scale, y_scale)) + a.qzp, -128, 127);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tile[(16 * wv + 4 * ft + k) * stride + f] = (int8_t)q[k];
+            }
+        } else {
         const int c4 = tid & 15, r4 = tid >> 4;
         for (int f0 = 0; f0 < Kp; f0 += 64) {
 #pragma unroll
@@ -512,6 +535,7 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) tile[(4 * c4 + k) * stride + f] = (int8_t)q[k];
             }
+        }
         }
     }
     __syncthreads();

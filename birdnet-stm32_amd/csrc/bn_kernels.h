@@ -23,8 +23,9 @@ struct StftTables {
 
 // ---- STFT ------------------------------------------------------------------------------
 void launch_minmax_init(float* minmax, int B, hipStream_t s);
+// tile_major: spectrogram written as [W/16][257][16] instead of [257][W] (needs W % 16 == 0; private layout of bn_infer_audio)
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec,
-                    float* minmax, hipStream_t s);
+                    float* minmax, hipStream_t s, bool tile_major = false);
 bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
                         const float* wvals, const int* bands, float* minmax, hipStream_t s, int square = 0);
 // per-chunk finishing pass of the precomputed-frontend spectrogram modes (bn_melspec.hip)
@@ -157,6 +158,7 @@ struct DwPw8Args {
     const float* qminmax;  // [B][2] per-chunk min / max for the (S - min) / (max - min + 1e-10) normalisation, or null
     float qscale;
     int qzp, qfill, qF;
+    int qtiled;            // the spectrogram is tile-major [W/16][qF][16] (written by launch_stft512(..., tile_major))
 };
 bool i8_dwpw_supported(int Cin, int Cout);
 bool i8_mel_mfma_supported(const DwPw8Args& a);
