@@ -155,7 +155,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 bn::launch_minmax_init(m->d_minmax, B, s);
                 if (!bn::launch_stft512_mel(m->ctx->tables, d_audio, B, T, hop, p[1], (float*)out, p[2],
                                             (const float*)m->tensor(o.t[0]), (const int*)m->tensor(o.t[1]), m->d_minmax, s))
-                    return fail(BN_ERR_UNSUPPORTED, "hop %d too long for the fused STFT+mel kernel", hop);
+                    return fail(BN_ERR_UNSUPPORTED, "the fused STFT+mel kernel takes at most 128 mel bins (got %d)", p[2]);
                 break;
             }
             case BN_OP_F32_MELFIN:
@@ -625,8 +625,9 @@ int bn_mel_spectrogram(bn_ctx* ctx, const float* d_audio, int B, int T, int n_ff
         float* mel = d_work + (size_t)b0 * per;
         float* minmax = d_work + (size_t)B * per + 2 * (size_t)b0;
         bn::launch_minmax_init(minmax, nb, s);
-        bn::launch_stft512_mel(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, Wall, mel, n_mels, d_mel_w, d_mel_bands, minmax, s,
-                               mode == BN_SPEC_MFCC);
+        if (!bn::launch_stft512_mel(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, Wall, mel, n_mels, d_mel_w, d_mel_bands, minmax, s,
+                                    mode == BN_SPEC_MFCC))
+            return fail(BN_ERR_UNSUPPORTED, "n_mels=%d: the fused STFT+mel kernel takes at most 128 mel bins", n_mels);
         if (!bn::launch_melspec_finish(mel, d_out + (size_t)b0 * per_out, d_dct, nb, n_mels, Wall, W, mode, mag_scale, n_mfcc, pcen_b, s))
             return fail(BN_ERR_DEVICE, "could not raise the LDS limit of the spectrogram finishing kernel");
     }
