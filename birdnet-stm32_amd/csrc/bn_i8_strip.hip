@@ -250,11 +250,15 @@ void i8_strip_kernel(Strip8Args a) {
         }
     };
 
-    // one output row from window rows (i0, i1, i2); `step` counts output rows of this strip (exchange buffer parity)
-    auto emit = [&](int i0, int i1, int i2, int oh, int step) {
+    // One output row from window rows (i0, i1, i2) in three parts: depthwise (vector ALU) -> B fragment; matrix cores -> int32
+    // accumulators; epilogue (vector ALU: requantisation, ADD table, store).  Single-wave strips run them back to back.  When the
+    // waves split the channels (NW > 1) the row loop is software-pipelined: a wave writes its B fragment of row k, then does the
+    // EPILOGUE OF ROW k - 1, and only then meets the others at the barrier — the LDS write and the other waves' arrival are
+    // hidden behind ~80 vector instructions, and the MFMAs of row k are hidden behind the depthwise stage of row k + 1.
+    constexpr bool PIPE = NW > 1 && NT == 2 && !W8;  // (16 accumulator registers of the four-tile variants spill when carried over)
+    auto dw_part = [&](int i0, int i1, int i2, int (&bfrag)[QL]) {
         asm volatile("" ::: "memory");  // the per-channel requantisation constants are re-read from LDS every row instead of pinning
                                         // ~48 registers (the kernel is bound by vector-ALU issue, LDS reads are free)
-        int bfrag[QL];
 #pragma unroll
         for (int ql = 0; ql < QL; ++ql) {
             const v4i m = my_dw[(kq * QL + ql) * 3 + 0], c1 = my_dw[(kq * QL + ql) * 3 + 1], sh = my_dw[(kq * QL + ql) * 3 + 2];
@@ -276,41 +280,44 @@ void i8_strip_kernel(Strip8Args a) {
             }
             bfrag[ql] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         }
+    };
+    auto mma_part = [&](const int (&bfrag)[QL], const v2i* buf, v4i (&acc)[NT]) {
         long bfs[NW];  // B fragments of every channel slice (QL == 2 whenever NW > 1)
         if constexpr (NW > 1) {
-            v2i* buf = xchg + ((step & 1) * SPB + wave / NW) * (NW * 64);
-            buf[w * 64 + lane] = (v2i){bfrag[0], bfrag[1]};
-            // LDS only: the prefetched global loads stay in flight across the barrier (a __syncthreads would drain them)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
             for (int ks = 0; ks < NW; ++ks) bfs[ks] = __builtin_bit_cast(long, buf[ks * 64 + lane]);
         }
-        int outw[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            v4i acc = pwb[t];
+            acc[t] = pwb[t];
             if constexpr (NW > 1) {
 #pragma unroll
                 for (int ks = 0; ks < NW; ++ks) {
                     const long af = ((long)(uint32_t)pwa[t][ks][1] << 32) | (uint32_t)pwa[t][ks][0];
-                    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bfs[ks], acc, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bfs[ks], acc[t], 0, 0, 0);
                 }
             } else if constexpr (QL == 2) {
                 const long af = ((long)(uint32_t)pwa[t][0][1] << 32) | (uint32_t)pwa[t][0][0];
                 const long bf = ((long)(uint32_t)bfrag[1] << 32) | (uint32_t)bfrag[0];
-                acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bf, acc, 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(af, bf, acc[t], 0, 0, 0);
             } else {
                 const v4i af = {pwa[t][0][0], pwa[t][0][1], pwa[t][0][2], pwa[t][0][3]};
                 const v4i bf = {bfrag[0], bfrag[1], bfrag[2], bfrag[3]};
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc, 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[t], 0, 0, 0);
             }
+        }
+    };
+    auto epi_part = [&](const v4i (&acc)[NT], const int (&cenv)[QL], int oh) {
+        int outw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
             const v4i m = my_pw[(kq * NT + t) * 3 + 0], c1 = my_pw[(kq * NT + t) * 3 + 1], sh = my_pw[(kq * NT + t) * 3 + 2];
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int v = med3(rq(acc[e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);  // ADD: value + 128 (table index), else the int8 value
+                int v = med3(rq(acc[t][e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);  // ADD: value + 128 (table index), else the int8 value
                 if constexpr (ADD)  // the whole TFLite ADD (two input rescales, sum, output rescale, clamp) is a function of two bytes
-                    v = add_tab[(uint32_t)perm(cen[i1][t], v, 0x0c0c0400u + (e << 8))];
+                    v = add_tab[(uint32_t)perm(cenv[t % QL], v, 0x0c0c0400u + (e << 8))];
                 qv[e] = v;
             }
             outw[t] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
@@ -322,6 +329,35 @@ void i8_strip_kernel(Strip8Args a) {
             v4i ov = {outw[0], outw[1], outw[2], outw[3]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(int)))) int, ov), rs_out, voff_out, soff, 0);
             asm volatile("s_nop 1" : "+v"(ov));  // the data registers of a 16-byte store are not rewritten right behind it (bn_f32_strip.hip: store16)
+        }
+    };
+    v4i pacc[NT];     // pipelined form: accumulators, centre taps and row of the previous step
+    int pcen[QL] = {};
+    int poh = 0;
+    auto emit = [&](int i0, int i1, int i2, int oh, int step) {
+        int bfrag[QL];
+        dw_part(i0, i1, i2, bfrag);
+        if constexpr (NW > 1 && !PIPE) {
+            v2i* buf = xchg + ((step & 1) * SPB + wave / NW) * (NW * 64);
+            buf[w * 64 + lane] = (v2i){bfrag[0], bfrag[1]};
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            v4i acc[NT];
+            mma_part(bfrag, buf, acc);
+            epi_part(acc, cen[i1], oh);
+        } else if constexpr (PIPE) {
+            v2i* buf = xchg + ((step & 1) * SPB + wave / NW) * (NW * 64);
+            buf[w * 64 + lane] = (v2i){bfrag[0], bfrag[1]};
+            if (step > 0) epi_part(pacc, pcen, poh);
+            // LDS only: the prefetched global loads stay in flight across the barrier (a __syncthreads would drain them)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            mma_part(bfrag, buf, pacc);
+#pragma unroll
+            for (int ql = 0; ql < QL; ++ql) pcen[ql] = cen[i1][ql];
+            poh = oh;
+        } else {
+            v4i acc[NT];
+            mma_part(bfrag, nullptr, acc);
+            epi_part(acc, cen[i1], oh);
         }
     };
 
@@ -348,6 +384,9 @@ void i8_strip_kernel(Strip8Args a) {
             }
             emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u, k + u);
         }
+    }
+    if constexpr (PIPE) {
+        if (steps > 0) epi_part(pacc, pcen, poh);  // the last row's epilogue
     }
 }
 
