@@ -1,5 +1,5 @@
-// bn_f32_strip.hip — float32 depthwise-separable block of the wide early stages (Cin, Cout in {32, 64}) as row-streaming
-// strips, the float32 sibling of bn_i8_strip.hip:
+// bn_f32_strip.hip — float32 depthwise-separable blocks of stages 1-3 (Cin 32 / 64 / 128, maps at least 16 columns wide) and the
+// front block as row-streaming strips, the float32 sibling of bn_i8_strip.hip:
 //
 //   DW 3x3 (+bias, activation) -> PW 1x1 on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 FMA chain)
 //   [+ residual = the block input] -> activation
