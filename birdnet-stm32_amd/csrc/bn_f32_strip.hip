@@ -195,13 +195,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
 // row (stem row - 1 + kq) and feeds the element fe[row][2 sc + j] of ITS row as the B operand, so three MFMAs (j = 0..2) give
 // stem column sc for the four channels 4 q .. 4 q + 3 in lane (n, q) — the quad its depthwise stage needs.  Nine MFMAs per stem
 // row cover stem columns 2 ow, 2 ow + 1, 2 ow + 2 (the taps of the stride-2 depthwise window).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f32_front_strip_kernel(F32FrontStripArgs a) {
+// STAGED: the workgroup = the OW / 16 strips of one row block.  It copies the 2 TH + 4 input rows it needs into LDS once —
+// whole rows, finalised ONCE per element on the way — and the row loop reads its B operands from LDS.  The per-wave variant
+// (each lane streaming its own rows from memory one step ahead) was bound by memory latency, 3150 cycles per wave and row, and
+// finalised every element three times.
+template <bool STAGED>
+__global__ __launch_bounds__(STAGED ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4))) void f32_front_strip_kernel(F32FrontStripArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fe_tile[];  // STAGED: [2 TH + 4][W0 + 8], rows sr0 - 1 .., zero outside the map
     __shared__ float rowc[64][12];          // per input row: wsum, then the ten magnitude-scaling rows (finalising mode)
     __shared__ v4f dw_lds[9][4];            // depthwise taps [tap][quad]
     const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
     const bool fin = a.minmax != nullptr;
     if (fin)
-        for (int i = tid; i < a.H0 * 12; i += 256) {
+        for (int i = tid; i < a.H0 * 12; i += nthreads) {
             const int rr = i / 12, c = i - rr * 12;
             rowc[rr][c] = c == 0 ? a.wsum[rr] : (c <= 10 ? a.magp[(c - 1) * a.H0 + rr] : 0.0f);
         }
@@ -213,8 +220,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     const int n = lane & 15, kq = lane >> 4;
     const int strips_x = a.OW >> 4;
     const int rblocks = (a.OH + a.TH - 1) / a.TH;
-    int wid = xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
-    if (wid >= a.B * strips_x * rblocks) return;
+    int wid = STAGED ? xcd_tile(blockIdx.x, gridDim.x) * strips_x + wave : xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    if (!STAGED && wid >= a.B * strips_x * rblocks) return;
     const int sx = wid % strips_x;
     wid /= strips_x;
     const int ry = wid % rblocks;
@@ -253,11 +260,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     const int sr0 = 2 * oh0;
     const int rows_needed = 2 * (nrows - 1) + 3;
 
+    const int tile_w = a.W0 + 8;
+    if constexpr (STAGED) {
+        const int quads = a.W0 >> 2, nr = 2 * a.TH + 4;
+        for (int i = tid; i < nr * (quads + 2); i += nthreads) {
+            const int row = i / (quads + 2), c = i - row * (quads + 2);
+            const int fr = sr0 - 1 + row;
+            v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (c < quads && fr >= 0 && fr < a.H0) {
+                v = *reinterpret_cast<const v4f*>(a.fe + ((size_t)chunk * a.H0 + fr) * a.W0 + 4 * c);
+                if (fin) {
+                    const v4f c0 = *reinterpret_cast<const v4f*>(&rowc[fr][0]), c1 = *reinterpret_cast<const v4f*>(&rowc[fr][4]),
+                              c2 = *reinterpret_cast<const v4f*>(&rowc[fr][8]);
+                    const float off = mn * c0.x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = fmaxf((v[e] - off) * inv_rng, 0.0f);
+                        float r = y;
+                        if (a.mag == 1) {
+                            r = y * c0.y;
+                            r += c0.z * fmaxf(c1.y * y + c2.x, 0.0f);
+                            r += c0.w * fmaxf(c1.z * y + c2.y, 0.0f);
+                            r += c1.x * fmaxf(c1.w * y + c2.z, 0.0f);
+                        } else if (a.mag == 2) {
+                            const float y0 = fmaxf(y - c0.y * y, 0.0f);
+                            r = fmaxf(c0.z * y0 + c1.y * fmaxf(c0.w * y0 + c1.x, 0.0f), 0.0f);
+                        } else if (a.mag == 3) {
+                            r = 10.0f * logf(fmaxf(y, 1e-6f)) / logf(10.0f);
+                        }
+                        v[e] = r;
+                    }
+                }
+            }
+            *reinterpret_cast<v4f*>(fe_tile + row * tile_w + 4 * c) = v;
+        }
+        __syncthreads();
+    }
     v4f raw[2][2];
     Row4 T[3];
     auto fe_row = [&](int srel) { return sr0 + srel - 1 + kq; };
     auto issue = [&](int slot, int srel) {
-        if (srel < rows_needed) {
+        if (!STAGED && srel < rows_needed) {
             const int fr = fe_row(srel);
             const int base = (fr >= 0 && fr < a.H0) ? (fr * a.W0 + 4 * ow) * 4 : 0x7fff0000;  // padding rows read as 0
             raw[slot][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_fe, base, 0, 0));
@@ -269,8 +312,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             const int fr = fe_row(srel);
             const bool ok = fr >= 0 && fr < a.H0;
             const bool has_hi = 4 * ow + 4 < a.W0;
-            float x[7] = {raw[slot][0].x, raw[slot][0].y, raw[slot][0].z, raw[slot][0].w, raw[slot][1].x, raw[slot][1].y, raw[slot][1].z};
-            if (fin) {
+            float x[7];
+            if constexpr (STAGED) {
+                const float* trow = fe_tile + (srel + kq) * tile_w + 4 * ow;  // input row sr - 1 + kq, already finalised / zero-padded
+                const v4f lo = *reinterpret_cast<const v4f*>(trow), hi = *reinterpret_cast<const v4f*>(trow + 4);
+                x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z;
+            } else {
+                x[0] = raw[slot][0].x; x[1] = raw[slot][0].y; x[2] = raw[slot][0].z; x[3] = raw[slot][0].w;
+                x[4] = raw[slot][1].x; x[5] = raw[slot][1].y; x[6] = raw[slot][1].z;
+            }
+            if (!STAGED && fin) {
                 const int rr = ok ? fr : 0;
                 const v4f c0 = *reinterpret_cast<const v4f*>(&rowc[rr][0]), c1 = *reinterpret_cast<const v4f*>(&rowc[rr][4]),
                           c2 = *reinterpret_cast<const v4f*>(&rowc[rr][8]);
@@ -293,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                     x[e] = ok ? v : 0.0f;  // padding rows stay an exact zero
                 }
             }
-            if (!has_hi) x[4] = x[5] = x[6] = 0.0f;  // columns beyond the map (the second load wrapped into the next row)
+            if (!STAGED && !has_hi) x[4] = x[5] = x[6] = 0.0f;  // columns beyond the map (the second load wrapped into the next row)
             v4f st[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -380,9 +431,20 @@ void launch_f32_front_strip(F32FrontStripArgs a, hipStream_t s) {
         const int v = atoi(e);
         if (v >= 1) th = v < a.OH ? v : a.OH;
     }
+    const char* st = getenv("BN_F32_FRONT_STAGED");
+    const bool staged = !(st && !atoi(st)) && a.OW / 16 <= 16 && a.W0 % 4 == 0;
+    if (staged && !getenv("BN_F32_STRIP_TH")) th = a.OH < 8 ? a.OH : 8;  // 19 input rows per block (+19 % halo), 21 KB of LDS
     a.TH = th;
-    const long waves = (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th);
-    hipLaunchKernelGGL(f32_front_strip_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    const long blocks = (long)a.B * ((a.OH + th - 1) / th);
+    if (staged) {
+        const size_t smem = (size_t)(2 * th + 4) * (a.W0 + 8) * sizeof(float);
+        if (smem <= 60000) {
+            hipLaunchKernelGGL(f32_front_strip_kernel<true>, dim3((unsigned)blocks), dim3(64 * (a.OW / 16)), smem, s, a);
+            return;
+        }
+    }
+    const long waves = blocks * (a.OW / 16);
+    hipLaunchKernelGGL(f32_front_strip_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
 }
 
 void launch_f32_strip(DwPwArgs a, hipStream_t s) {
