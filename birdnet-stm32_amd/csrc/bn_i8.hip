@@ -247,16 +247,35 @@ __global__ void i8_mean_kernel(const int8_t* __restrict__ x, int8_t* __restrict_
     }
 }
 
-__global__ void i8_fc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int Cin, int Cout, int zp_out,
-                             int amin, int amax, const int8_t* __restrict__ w, const int32_t* __restrict__ bias,
-                             const int32_t* __restrict__ mult, const int32_t* __restrict__ shift) {
-    const int b = blockIdx.x;
-    const int32_t* xr = reinterpret_cast<const int32_t*>(x + (size_t)b * Cin);
+// FULLY_CONNECTED: a workgroup takes kFcChunks chunks, so a weight row is fetched once per kFcChunks chunks (the 25.6 KB matrix
+// was read from L2 once per chunk: 0.048 -> 0.02 ms per 4096 chunks); the activations of the chunks sit in LDS.
+constexpr int kFcChunks = 8;
+__global__ __launch_bounds__(128) void i8_fc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int B, int Cin, int Cout,
+                                                    int zp_out, int amin, int amax, const int8_t* __restrict__ w,
+                                                    const int32_t* __restrict__ bias, const int32_t* __restrict__ mult,
+                                                    const int32_t* __restrict__ shift) {
+    extern __shared__ int32_t fc_x[];  // [kFcChunks][Cin / 4]
+    const int b0 = blockIdx.x * kFcChunks;
+    const int nb = B - b0 < kFcChunks ? B - b0 : kFcChunks;
+    const int kq = Cin / 4;
+    const int32_t* xr = reinterpret_cast<const int32_t*>(x + (size_t)b0 * Cin);
+    for (int i = threadIdx.x; i < nb * kq; i += blockDim.x) fc_x[i] = xr[i];
+    for (int i = nb * kq + threadIdx.x; i < kFcChunks * kq; i += blockDim.x) fc_x[i] = 0;
+    __syncthreads();
     for (int n = threadIdx.x; n < Cout; n += blockDim.x) {
         const int32_t* wr = reinterpret_cast<const int32_t*>(w + (size_t)n * Cin);
-        int32_t acc = bias[n];
-        for (int k = 0; k < Cin / 4; ++k) acc = dot4(xr[k], wr[k], acc);
-        y[(size_t)b * Cout + n] = (int8_t)clampi(mbqm(acc, mult[n], shift[n]) + zp_out, amin, amax);
+        int32_t acc[kFcChunks];
+#pragma unroll
+        for (int c = 0; c < kFcChunks; ++c) acc[c] = bias[n];
+        for (int k = 0; k < kq; ++k) {
+            const int32_t wk = wr[k];
+#pragma unroll
+            for (int c = 0; c < kFcChunks; ++c) acc[c] = dot4(fc_x[c * kq + k], wk, acc[c]);
+        }
+        const int32_t m = mult[n], sh = shift[n];
+#pragma unroll
+        for (int c = 0; c < kFcChunks; ++c)
+            if (c < nb) y[(size_t)(b0 + c) * Cout + n] = (int8_t)clampi(mbqm(acc[c], m, sh) + zp_out, amin, amax);
     }
 }
 
@@ -320,8 +339,8 @@ void launch_i8_mean(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, 
 
 void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_out, int amin, int amax, const int8_t* w,
                   const int32_t* bias, const int32_t* mult, const int32_t* shift, hipStream_t s) {
-    hipLaunchKernelGGL(i8_fc_kernel, dim3(B), dim3(128), 0, s, x, y, Cin, Cout, zp_out, amin, amax, w, bias, mult,
-                       shift);
+    hipLaunchKernelGGL(i8_fc_kernel, dim3((B + kFcChunks - 1) / kFcChunks), dim3(128), (size_t)kFcChunks * Cin, s, x, y, B, Cin, Cout, zp_out,
+                       amin, amax, w, bias, mult, shift);
 }
 
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,
