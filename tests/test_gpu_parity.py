@@ -243,6 +243,10 @@ def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypa
             bad = int((a != want[oi]).sum())
             assert bad == 0, f"rows per wave {th or 'auto'}: tensor {runner.plan.ops[oi].name}: {bad} of {a.size} values differ, first at {np.argwhere(a != want[oi])[:3].tolist()}"
         assert np.array_equal(got_scores, want_scores)
+    # odd batch sizes: workgroups of the ADD kernels take 8 / NW strips, the spare ones repeat the last chunk
+    monkeypatch.delenv("BN_I8_STRIP_TH", raising=False)
+    for nb in (1, 3, 37):
+        assert np.array_equal(runner.predict(x[:nb]), want_scores[:nb])
     runner.close()
     # the production plan (slots recycled, QUANTIZE fused into the mel mixer's load with the three-instruction exact division) gives
     # the same scores bit for bit, on the test spectrograms and on random ones that exercise the rounding of the quantiser
