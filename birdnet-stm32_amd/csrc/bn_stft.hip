@@ -21,7 +21,7 @@ namespace bn {
 namespace {
 
 constexpr int kFT = 16;    // frames per workgroup
-constexpr int kFS = 272;   // complex elements reserved per frame in the exchange buffer
+constexpr int kFS = 274;   // floats reserved per frame in the exchange buffer (one component at a time, see the kernel)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
     // The magnitude tile [257][kFT + 1] (17.5 KB) re-uses the exchange buffer (34.8 KB): every lane takes its sixteen conjugate
     // partners into registers, one workgroup barrier later the buffer is free.  35 KB instead of 52 KB of LDS = four
     // workgroups per CU instead of three.
-    __shared__ v2f xch[kFT][kFS];
+    // The exchange buffer holds ONE float per complex element: real and imaginary parts take turns (write re, read re, write im,
+    // read im — the syncs are wave-level).  17.5 KB instead of 35 KB of LDS lets five workgroups instead of four share a CU (the
+    // kernel is latency-bound: 87 registers, ~3.5 k cycles of arithmetic in a 20 k-cycle workgroup lifetime).
+    __shared__ float xch[kFT][kFS];
     float (*mag)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(&xch[0][0]);
-    static_assert(sizeof(float) * 257 * (kFT + 1) <= sizeof(v2f) * kFT * kFS, "magnitude tile must fit the exchange buffer");
+    static_assert(sizeof(float) * 257 * (kFT + 1) <= sizeof(float) * kFT * kFS, "magnitude tile must fit the exchange buffer");
     __shared__ float red_min[4], red_max[4];
     // mel mixer tables (MEL_OUT): up to 1024 band-sparse values and 3 x 128 band entries (the launcher refuses more mel bins)
     constexpr int kMelW = MEL_OUT ? 1024 : 1, kMelT = MEL_OUT ? 384 : 1;
@@ -191,21 +194,30 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
             p[8] = BN_CM(p[4], p[4]);
 #pragma unroll
             for (int k1 = 9; k1 < 16; ++k1) p[k1] = BN_CM(p[8], p[k1 - 8]);
-            xch[f][j] = a[fidx(0)];
 #pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) xch[f][k1 * 17 + j] = BN_CM(a[fidx(k1)], p[k1]);
+            for (int k1 = 1; k1 < 16; ++k1) a[fidx(k1)] = BN_CM(a[fidx(k1)], p[k1]);
 #undef BN_CM
 #undef BN_ROT
         }
+        // 16 x 16 transpose through LDS, real parts first: a[n].x may be overwritten as soon as every x of the frame has been written
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) xch[f][k1 * 17 + j] = a[fidx(k1)].x;
+        frame_sync();
+        float re_in[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) re_in[n2] = xch[f][j * 17 + n2];
+        frame_sync();
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) xch[f][k1 * 17 + j] = a[fidx(k1)].y;
         frame_sync();
 
         // pass 2: lane j is now k1; gathers over n2
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) a[n2] = xch[f][j * 17 + n2];
+        for (int n2 = 0; n2 < 16; ++n2) a[n2] = (v2f){re_in[n2], xch[f][j * 17 + n2]};
         fft16(a);  // a[fidx(k2)] = Z[j + 16 k2] (scaled by 0.5 through the window)
         frame_sync();
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) xch[f][j + 16 * k2] = a[fidx(k2)];
+        for (int k2 = 0; k2 < 16; ++k2) xch[f][j + 16 * k2] = a[fidx(k2)].x;
         frame_sync();
 
         // split post-pass: X[k] = E - i W512^k O with E = Z[k] + conj Z[256-k], O = Z[k] - conj Z[256-k] (the 1/2 is in Z)
@@ -213,7 +225,13 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
         float tmin = __uint_as_float(0x7f800000u), tmax = 0.0f;
         v2f partner[16];
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) partner[k2] = xch[f][(256 - (j + 16 * k2)) & 255];
+        for (int k2 = 0; k2 < 16; ++k2) partner[k2].x = xch[f][(256 - (j + 16 * k2)) & 255];
+        frame_sync();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) xch[f][j + 16 * k2] = a[fidx(k2)].y;
+        frame_sync();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) partner[k2].y = xch[f][(256 - (j + 16 * k2)) & 255];
         __syncthreads();  // all frames have their partners: the buffer becomes the magnitude tile
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
