@@ -511,6 +511,7 @@ void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, in
 
 void launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW,
                    int pt, int pl, const float* w, const float* bias, hipStream_t s) {
+    if (launch_f32_dw_stream(x, y, B, H, W, C, sh, sw, act, OH, OW, pt, pl, w, bias, s)) return;
     const long total = (long)B * OH * OW * (C / 4);
     hipLaunchKernelGGL(f32_dw_kernel, grid1d(total, 256), dim3(256), 0, s, x, y, H, W, C, sh, sw, act, OH, OW, pt, pl,
                        w, bias, total);

@@ -403,6 +403,117 @@ __global__ __launch_bounds__(STAGED ? 1024 : 256) __attribute__((amdgpu_waves_pe
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stand-alone depthwise 3x3 (the inverted-residual blocks: expand 1x1 -> DEPTHWISE -> squeeze-excite -> project 1x1) as a
+// row-streaming kernel.  The one-thread-per-output-quad kernel (bn_f32.hip) loads nine taps per output: 2.4 TB/s.  Here a wave
+// owns NCOL = 64 / CQ columns x CQ channel quads (CQ = the largest of 16, 8, 4, 2, 1 dividing C / 4, so that a tap load of the
+// wave covers NCOL runs of 16 CQ bytes) and walks down the rows with the 3x3 window of its quad in registers: three 16-byte loads
+// per output instead of nine, rows requested two steps ahead, SAME padding = the buffer descriptor's range check.
+struct DwStreamArgs {
+    const float* x;
+    float* y;
+    const float* w;     // [3][3][C]
+    const float* bias;  // [C]
+    int B, H, W, C, OH, OW, TH, pt, pl, act, CQ;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f32_dw_stream_kernel(DwStreamArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int CQ = a.CQ, NCOL = 64 / CQ;
+    const int cq = lane % CQ, n = lane / CQ;
+    const int groups = a.C / (4 * CQ);
+    const int strips_x = (a.OW + NCOL - 1) / NCOL;
+    const int rblocks = (a.OH + a.TH - 1) / a.TH;
+    long wid = (long)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wid >= (long)a.B * groups * strips_x * rblocks) return;
+    const int g = (int)(wid % groups);
+    wid /= groups;
+    const int sx = (int)(wid % strips_x);
+    wid /= strips_x;
+    const int ry = (int)(wid % rblocks);
+    const int chunk = (int)(wid / rblocks);
+    const int oh0 = ry * a.TH;
+    const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
+    const int ow = sx * NCOL + n;
+    const bool live = ow < a.OW;
+    const int c0 = 4 * (g * CQ + cq);
+    const ActBounds bounds = act_bounds(a.act);
+
+    v4f wt[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wt[i][j] = *reinterpret_cast<const v4f*>(a.w + (i * 3 + j) * a.C + c0);
+    const v4f b4 = *reinterpret_cast<const v4f*>(a.bias + c0);
+
+    const int in_chunk_bytes = a.H * a.W * a.C * 4;
+    const int row_bytes = a.W * a.C * 4;
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)chunk * a.H * a.W * a.C, 0, in_chunk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)chunk * a.OH * a.OW * a.C, 0, a.OH * a.OW * a.C * 4, 0x00020000);
+    const int iw0 = ow * S - a.pl;
+    int voff_in[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) voff_in[j] = (live && iw0 + j >= 0 && iw0 + j < a.W) ? ((iw0 + j) * a.C + c0) * 4 : 0x7fff0000;
+    const int voff_out = live ? (ow * a.C + c0) * 4 : 0x7fff0000;  // beyond the descriptor's range: the store is dropped
+    const int ir0 = oh0 * S - a.pt;
+    const int rows_needed = S * (nrows - 1) + 3;
+
+    Row4 raw[2], T[3];
+    auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
+    auto issue = [&](int slot, int rr) {
+        if (row_ok(rr)) {
+            const int soff = (ir0 + rr) * row_bytes;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) raw[slot].t[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff_in[j], soff, 0));
+        }
+    };
+    auto consume = [&](int slot, int rr, int ti) {
+        if (row_ok(rr)) {
+            T[ti] = raw[slot];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) T[ti].t[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto emit = [&](int i0, int i1, int i2, int oh) {
+        v4f acc = b4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            acc = __builtin_elementwise_fma(T[i0].t[j], wt[0][j], acc);
+            acc = __builtin_elementwise_fma(T[i1].t[j], wt[1][j], acc);
+            acc = __builtin_elementwise_fma(T[i2].t[j], wt[2][j], acc);
+        }
+        store16(rs_out, act4(acc, bounds), voff_out, oh * a.OW * a.C * 4);
+    };
+    constexpr int P = 3 - S;
+    issue(0, 0);
+    issue(1, 1);
+#pragma unroll
+    for (int rr = 0; rr < P; ++rr) {
+        consume(rr & 1, rr, rr % 3);
+        issue(rr & 1, rr + 2);
+    }
+    constexpr int U = 6 / S;
+    for (int k = 0; k < nrows; k += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k + u >= nrows) break;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int rs = P + S * u + s;
+                consume(rs & 1, S * k + rs, rs % 3);
+                issue(rs & 1, S * k + rs + 2);
+            }
+            emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
+        }
+    }
+}
+
 template <int NW, int COUT, int S, bool RES>
 void launch_strip(const DwPwArgs& a, hipStream_t s) {
     const long strips = (long)a.B * (a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
@@ -417,6 +528,32 @@ bool f32_strip_supported(const DwPwArgs& a) {
     const bool shape = (a.Cin == 32 && (a.Cout == 32 || a.Cout == 64)) || (a.Cin == 64 && (a.Cout == 64 || a.Cout == 128)) ||
                        (a.Cin == 128 && a.Cout == 128);  // eight waves per strip: ~145 registers, one workgroup per CU, still 0.07 vs 0.09 ms
     return shape && (long)a.H * a.W * a.Cin * 4 < 0x7fff0000L;
+}
+
+bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW, int pt, int pl,
+                          const float* w, const float* bias, hipStream_t s) {
+    if (sh != sw || (sh != 1 && sh != 2) || C % 4 || (long)H * W * C * 4 >= 0x7fff0000L || (long)OH * OW * C * 4 >= 0x7fff0000L) return false;
+    if (const char* e = getenv("BN_F32_STRIP"))
+        if (!atoi(e)) return false;
+    int cq = 16;
+    while ((C / 4) % cq) cq >>= 1;
+    DwStreamArgs a{x, y, w, bias, B, H, W, C, OH, OW, 0, pt, pl, act, cq};
+    const int ncol = 64 / cq;
+    const long per_row_block = (long)B * (C / (4 * cq)) * ((OW + ncol - 1) / ncol);
+    int th = OH;
+    while (th > 16) th = (th + 1) / 2;
+    while (th > 4 && per_row_block * ((OH + th - 1) / th) < 8192) th = (th + 1) / 2;
+    if (const char* e = getenv("BN_F32_STRIP_TH")) {
+        const int v = atoi(e);
+        if (v >= 1) th = v < OH ? v : OH;
+    }
+    a.TH = th;
+    const long waves = per_row_block * ((OH + th - 1) / th);
+    if (sh == 1)
+        hipLaunchKernelGGL(f32_dw_stream_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(f32_dw_stream_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    return true;
 }
 
 bool f32_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW) {

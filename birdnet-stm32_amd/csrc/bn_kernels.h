@@ -104,6 +104,9 @@ struct F32FrontStripArgs {
 };
 bool f32_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW);
 void launch_f32_front_strip(F32FrontStripArgs a, hipStream_t s);
+// stand-alone depthwise 3x3 as a row-streaming kernel (bn_f32_strip.hip); false = shape not taken, use launch_f32_dw's own kernel
+bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW, int pt, int pl,
+                          const float* w, const float* bias, hipStream_t s);
 bool f32_strip_supported(const DwPwArgs& a);
 void launch_f32_strip(DwPwArgs a, hipStream_t s);
 
