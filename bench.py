@@ -4,25 +4,35 @@
 One *step* = one pass of the whole path over one batch of synthetic 3 s @ 24 kHz chunks that are
 already resident in HBM:  windowed STFT magnitude -> hybrid mel mixer -> PWL -> DS-CNN -> scores.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|i8] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype i8|f32] [--batch B]
 
-* N = 1 (default): BASELINE.json configs[1] — the shipped birdnet_stm32n6_100 float32 DS-CNN with the
-  hybrid+pwl frontend at batch 1024 (``--dtype i8 --batch 4096`` gives configs[2]).
-* N > 1: launched by ``python -m torch.distributed.run --nproc-per-node N``; every rank runs the same
-  per-GPU batch on its own shard of the chunk stream (weak scaling, no data-path collective) and the
-  job ends with the single RCCL all-gather of the scores named by the north star, inside the timed region.
+* N = 1 (default): BASELINE.json configs[2] — the shipped birdnet_stm32n6_100 INT8 DS-CNN (int8 MFMA 1x1 convolutions)
+  with the hybrid+pwl frontend at batch 4096, the largest single-GPU configuration (``--dtype f32`` gives configs[1],
+  float32 at batch 1024; the default run reports it under ``also_measured``).
+* N > 1: BASELINE.json configs[3] — the INT8 chunk stream sharded over N GPUs, one process per GPU.  Started bare
+  (``python bench.py --gpus N`` with WORLD_SIZE unset) the parent launches ``python -m torch.distributed.run
+  --nproc-per-node N`` on itself BEFORE anything touches a GPU and relays the workers' output; started by the driver's
+  torchrun line it reads RANK / LOCAL_RANK / WORLD_SIZE.  The global stream has N x K x 4096 chunks (K = 8 on 8 GPUs is
+  the 262 144 chunks of configs[3]); rank r scores its contiguous block of K x 4096 chunks in K batches of 4096 into a
+  ``[K * 4096, 100]`` buffer (``evaluation/sharding.py: run_sharded`` — the same function ``evaluate`` shards with) and
+  the job ends with ONE RCCL all-gather of those scores (12.8 MB per rank at K = 8), inside the timed region.
 
-Rank 0 prints ONE JSON line: the throughput contract fields plus ``roofline`` (dominant kernel — named by the
-fully profiled warm-up steps, then timed with HIP events on the launch stream during the timed region, where it is the
-only bracketed operator; ``stages`` are the warm-up measurements of the other operators) and ``cpu_baseline`` (the numpy oracle of
-``oracle/`` timed on this host on a bounded sample — a reported baseline, not a target).
+Every rank keeps ``min(K, 8)`` distinct synthetic batches in HBM (9.4 GB) and walks them round-robin, so no step re-reads a
+cache-warm input.  Rank 0 prints ONE JSON line: the throughput contract fields plus ``roofline`` (dominant kernel — named by
+the fully profiled warm-up steps, then timed with HIP events on the launch stream during the timed region, where it is the
+only bracketed operator; ``stages`` are the warm-up measurements of the other operators) and ``cpu_baseline`` (the C/OpenMP
+restatement of the reference path under ``oracle/`` timed on this host on a bounded sample — a reported baseline, not a
+target).
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -41,14 +51,17 @@ HOP = T // W
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 / 16x16x4 = vector FP32 rate
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 = 2x bf16
+MOP_PER_CHUNK = 53.08  # 26 539 008 MAC per chunk (mel mixer + backbone), 2 ops per MAC
+STFT_MFLOP_PER_CHUNK = 3.35
+MAX_DISTINCT_BATCHES = 8
 
 
-def synth_audio_device(torch, batch: int, rank: int, device):
-    """peaknorm(0.3 N(0,1) + sin(2 pi f_b t)), f_b = 500 + 37 (g mod 200), g = global chunk index."""
+def synth_audio_device(torch, batch: int, first_chunk: int, device, seed: int):
+    """peaknorm(0.3 N(0,1) + sin(2 pi f_g t)), f_g = 500 + 37 (g mod 200), g = global chunk index."""
     gen = torch.Generator(device=device)
-    gen.manual_seed(42 + rank)
+    gen.manual_seed(seed)
     t = torch.arange(T, device=device, dtype=torch.float64) / SR
-    g = torch.arange(batch, device=device, dtype=torch.float64) + rank * batch
+    g = torch.arange(batch, device=device, dtype=torch.float64) + first_chunk
     f = 500.0 + 37.0 * torch.remainder(g, 200.0)
     tone = torch.sin(2.0 * np.pi * f[:, None] * t[None, :]).to(torch.float32)
     x = 0.3 * torch.randn((batch, T), generator=gen, device=device, dtype=torch.float32) + tone
@@ -56,53 +69,82 @@ def synth_audio_device(torch, batch: int, rank: int, device):
     return x.contiguous()
 
 
-def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float]:
-    """(bytes, ops) one launch of plan operator ``row`` must move / execute for ``batch`` chunks."""
+def kernel_symbol(kind: str, p: list) -> str:
+    """The device kernel an operator launches (the launchers' choices: strip kernels for the wide early blocks)."""
+    if kind in ("stft512", "f32_stftmel"):
+        return "stft512_mag_kernel"
+    if kind == "i8_tail":
+        return "i8_tail_kernel"
+    if kind == "i8_dwpw" and p[35]:
+        return "i8_strip_kernel"
+    if kind == "i8_dwpw" and p[30] and p[14] == 64:
+        return "i8_mel_mfma_kernel"
+    if kind == "i8_front" and p[16]:
+        return "i8_front_strip_kernel"
+    if kind == "f32_dwpw" and p[15]:
+        cin, cout, ow, stride = p[2], p[10], p[7], p[3]
+        if ow % 16 == 0 and stride in (1, 2) and ((cin == 32 and cout in (32, 64)) or (cin == 64 and cout in (64, 128)) or (cin, cout) == (128, 128)):
+            return "f32_strip_kernel"
+        if cin <= 64 and cout <= 64:
+            return "f32_dwpw_wave_kernel"
+    return kind + "_kernel"
+
+
+def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float, float]:
+    """(bytes, ops, matrix-core ops) one launch of plan operator ``row`` must move / execute for ``batch`` chunks.
+
+    Bytes are what the kernel that runs the operator has to move once: a residual that the strip kernels take from the centre
+    tap they already hold is NOT counted (only the generic tile kernels read it again).  Matrix-core ops are the 1x1
+    convolutions' (and the mel mixer's) multiply-accumulates x 2 — the numerator of ``mfma_frac``.
+    """
     k, p = row["kind"], row["p"]
     e = 4 if dtype == "f32" else 1
+    sym = kernel_symbol(k, p)
     if k == "stft512":
-        return batch * (T * 4 + (NFFT // 2 + 1) * W * 4), batch * 3.35e6
+        return batch * (T * 4 + (NFFT // 2 + 1) * W * 4), batch * 3.35e6, 0.0
     if k == "f32_stftmel":
-        return batch * (T * 4 + p[2] * p[1] * 4), batch * 3.35e6
+        return batch * (T * 4 + p[2] * p[1] * 4), batch * 3.35e6, 0.0
     if k == "f32_melfin":
-        return batch * 2.0 * p[0] * p[1] * 4, batch * 10.0 * p[0] * p[1]
-    if k == "f32_front":
+        return batch * 2.0 * p[0] * p[1] * 4, batch * 10.0 * p[0] * p[1], 0.0
+    if k in ("f32_front", "i8_front"):
         macs = 9 * p[0] * (p[1] // 2) * p[2] + p[4] * p[5] * p[2] * (9 + p[3])
-        return batch * 4.0 * (p[0] * p[1] + p[4] * p[5] * p[3]), batch * 2.0 * macs
-    if k == "i8_front":
-        macs = 9 * p[0] * (p[1] // 2) * p[2] + p[4] * p[5] * p[2] * (9 + p[3])
-        return batch * 1.0 * (p[0] * p[1] + p[4] * p[5] * p[3]), batch * 2.0 * macs
+        mm = 2.0 * (9 * p[0] * (p[1] // 2) * p[2] + p[4] * p[5] * p[2] * p[3]) if "strip" in sym else 2.0 * p[4] * p[5] * p[2] * p[3]
+        return batch * float(e) * (p[0] * p[1] + p[4] * p[5] * p[3]), batch * 2.0 * macs, batch * mm
     if k == "f32_mel":
-        return batch * (p[0] * p[1] * 4 + p[2] * p[1] * 4), batch * 2.0 * p[0] * p[1] * p[2]
+        return batch * (p[0] * p[1] * 4 + p[2] * p[1] * 4), batch * 2.0 * p[0] * p[1] * p[2], 0.0
     if k == "i8_quant":
-        return batch * (p[0] * p[1] * 4 + p[1] * p[2]), batch * 2.0 * p[0] * p[1]
+        return batch * (p[0] * p[1] * 4 + p[1] * p[2]), batch * 2.0 * p[0] * p[1], 0.0
     if k == "i8_mel":
-        return batch * (p[0] * p[1] + p[2] * p[0]), batch * 2.0 * p[0] * p[1] * p[2]
+        return batch * (p[0] * p[1] + p[2] * p[0]), batch * 2.0 * p[0] * p[1] * p[2], 0.0
     if k in ("f32_stem", "i8_stem"):
-        return batch * (p[0] * p[1] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2]
+        return batch * (p[0] * p[1] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2], 0.0
     if k in ("f32_dw", "i8_dw"):
-        return batch * (p[0] * p[1] * p[2] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2]
+        return batch * (p[0] * p[1] * p[2] * e + p[6] * p[7] * p[2] * e), batch * 2.0 * 9 * p[6] * p[7] * p[2], 0.0
     if k == "f32_dwpw":
         n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[10]
         macs = p[6] * p[7] * p[2] * (p[10] + (9 if p[15] else 0))
-        return batch * 4.0 * (n_in + n_out * (2 if p[12] else 1)), batch * 2.0 * macs
+        res = 1 if (p[12] and sym != "f32_strip_kernel") else 0
+        return batch * 4.0 * (n_in + n_out * (1 + res)), batch * 2.0 * macs, batch * 2.0 * p[6] * p[7] * p[2] * p[10]
     if k == "i8_dwpw" and p[36]:  # mel mixer with QUANTIZE fused into its load: float32 spectrogram in, int8 [M][W] out
-        return batch * (p[5] * p[1] * 4.0 + p[14] * p[1]), batch * 2.0 * p[1] * p[2] * p[14]
+        return batch * (p[5] * p[1] * 4.0 + p[14] * p[1]), batch * 2.0 * p[1] * p[2] * p[14], batch * 2.0 * p[1] * p[2] * p[14]
     if k == "i8_dwpw":
         n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[14]
         macs = p[6] * p[7] * p[2] * (p[14] + (9 if p[29] else 0))
-        return batch * 1.0 * (n_in + n_out * (2 if p[18] else 1)), batch * 2.0 * macs
+        res = 1 if (p[18] and sym != "i8_strip_kernel") else 0
+        return batch * 1.0 * (n_in + n_out * (1 + res)), batch * 2.0 * macs, batch * 2.0 * p[6] * p[7] * p[2] * p[14]
+    if k == "i8_tail":  # p: in_bytes pw_macs dw_macs other_macs n_classes
+        return batch * (p[0] + 4.0 * p[4]), batch * 2.0 * (p[1] + p[2] + p[3]), batch * 2.0 * p[1]
     if k == "f32_pw":
-        return batch * (p[0] * p[1] * 4 + p[0] * p[2] * 4 * (2 if p[4] else 1)), batch * 2.0 * p[0] * p[1] * p[2]
+        return batch * (p[0] * p[1] * 4 + p[0] * p[2] * 4 * (2 if p[4] else 1)), batch * 2.0 * p[0] * p[1] * p[2], batch * 2.0 * p[0] * p[1] * p[2]
     if k == "i8_pw":
-        return batch * (p[0] * p[1] + p[0] * p[2] * (2 if p[6] else 1)), batch * 2.0 * p[0] * p[1] * p[2]
+        return batch * (p[0] * p[1] + p[0] * p[2] * (2 if p[6] else 1)), batch * 2.0 * p[0] * p[1] * p[2], 0.0
     if k in ("f32_gap", "i8_mean"):
-        return batch * (p[0] * p[1] * e + p[1] * e), batch * 1.0 * p[0] * p[1]
+        return batch * (p[0] * p[1] * e + p[1] * e), batch * 1.0 * p[0] * p[1], 0.0
     if k == "f32_gapdense":
-        return batch * (p[0] * p[1] * 4 + p[2] * 4), batch * (1.0 * p[0] * p[1] + 2.0 * p[1] * p[2])
+        return batch * (p[0] * p[1] * 4 + p[2] * 4), batch * (1.0 * p[0] * p[1] + 2.0 * p[1] * p[2]), 0.0
     if k in ("f32_dense", "i8_fc"):
-        return batch * (p[0] * e + p[1] * 4), batch * 2.0 * p[0] * p[1]
-    return 0.0, 0.0
+        return batch * (p[0] * e + p[1] * 4), batch * 2.0 * p[0] * p[1], 0.0
+    return 0.0, 0.0, 0.0
 
 
 def output_bytes(kind: str, p: list, batch: int, dtype: str):
@@ -121,68 +163,57 @@ def output_bytes(kind: str, p: list, batch: int, dtype: str):
     return None
 
 
-def kernel_symbol(kind: str, p: list) -> str:
-    """The device kernel an operator launches (the launchers' choices: strip kernels for the wide early blocks)."""
-    if kind in ("stft512", "f32_stftmel"):
-        return "stft512_mag_kernel"
-    if kind == "i8_dwpw" and p[35]:
-        return "i8_strip_kernel"
-    if kind == "i8_dwpw" and p[30] and p[14] == 64:
-        return "i8_mel_mfma_kernel"
-    if kind == "i8_front" and p[16]:
-        return "i8_front_strip_kernel"
-    if kind == "f32_dwpw" and p[15]:
-        cin, cout, ow, stride = p[2], p[10], p[7], p[3]
-        if ow % 16 == 0 and stride in (1, 2) and ((cin == 32 and cout in (32, 64)) or (cin == 64 and cout in (64, 128)) or (cin, cout) == (128, 128)):
-            return "f32_strip_kernel"
-        if cin <= 64 and cout <= 64:
-            return "f32_dwpw_wave_kernel"
-    return kind + "_kernel"
-
-
 def pmc_traffic(dom: dict, batch: int, dtype: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC digest of this workload (rocprofv3 --pmc
-    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
-    produced by tools/profile_digest.py).  Counters cannot be read from inside the benchmark, so this is null when no
-    digest of the same workload (dtype, batch, kernel, output size) is on disk."""
-    path = os.path.join(REPO, "profiles", f"r01_{dtype}_b{batch}_traffic.json")
+    """(HBM bytes per launch of the dominant kernel, source file) from the newest committed PMC digest of this workload
+    (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950; produced by tools/profile_digest.py).  Counters cannot be read from inside the benchmark, so this is a REPLAY of
+    the committed profile — ``traffic_source`` names the file — and null when no digest of the same workload (dtype, batch,
+    kernel, output size) is on disk."""
     want = output_bytes(dom["kernel"], dom["p"], batch, dtype)
-    if want is None or not os.path.isfile(path):
-        return None
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{dtype}_b{batch}_traffic.json")),
+                   key=lambda q: int(re.search(r"r(\d+)_", os.path.basename(q)).group(1)), reverse=True)
+    if want is None:
+        return None, None
     base = kernel_symbol(dom["kernel"], dom["p"])
-    best = None
-    for row in json.load(open(path)):
-        name = row["kernel"].split("<")[0]
-        if name == base and abs(row["write_bytes"] - want) <= 0.05 * want:
-            if best is None or abs(row["write_bytes"] - want) < abs(best["write_bytes"] - want):
-                best = row
-    return None if best is None else int(best["read_bytes"] + best["write_bytes"])
+    for path in paths:
+        best = None
+        for row in json.load(open(path)):
+            name = row["kernel"].split("<")[0]
+            if name == base and abs(row["write_bytes"] - want) <= 0.05 * want:
+                if best is None or abs(row["write_bytes"] - want) < abs(best["write_bytes"] - want):
+                    best = row
+        if best is not None:
+            return int(best["read_bytes"] + best["write_bytes"]), "profiles/" + os.path.basename(path) + " (committed rocprofv3 --pmc run of this workload, replayed)"
+    return None, None
 
 
 def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> tuple[dict, list[dict]]:
     stages = []
+    peak_compute = F32_MFMA_PEAK_TFLOPS if dtype == "f32" else I8_MFMA_PEAK_TOPS
     for r in rows:
         if not r["launches"]:
             continue
         avg_ms = r["ms"] / r["launches"]
-        nbytes, nops = algorithmic_work(r, batch, dtype)
-        stages.append({"kernel": r["kind"], "layer": r["name"], "avg_ms": round(avg_ms, 4), "GBps": round(nbytes / avg_ms / 1e6, 1),
-                       "Tops": round(nops / avg_ms / 1e9, 2), "bytes": nbytes, "ops": nops, "p": r["p"], "op": r["op"]})
+        nbytes, nops, mops = algorithmic_work(r, batch, dtype)
+        stages.append({"kernel": r["kind"], "symbol": kernel_symbol(r["kind"], r["p"]), "layer": r["name"], "avg_ms": round(avg_ms, 4),
+                       "GBps": round(nbytes / avg_ms / 1e6, 1), "hbm_frac": round(nbytes / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
+                       "Tops": round(nops / avg_ms / 1e9, 2), "mfma_frac": round(mops / avg_ms / 1e9 / peak_compute, 4),
+                       "bytes": nbytes, "ops": nops, "p": r["p"], "op": r["op"]})
     picked = [s for s in stages if s["op"] == dom_op]
     dom = picked[0] if picked else max(stages, key=lambda s: s["avg_ms"])
-    peak_compute = F32_MFMA_PEAK_TFLOPS if dtype == "f32" else I8_MFMA_PEAK_TOPS
     ridge = peak_compute * 1e12 / (HBM_PEAK_GBS * 1e9)
     intensity = dom["ops"] / max(dom["bytes"], 1.0)
-    if intensity > ridge and dom["kernel"].endswith("pw"):
+    if intensity > ridge and (dom["kernel"].endswith("pw") or dom["kernel"] == "i8_tail"):
         roof = {"bound": "mfma", "achieved": dom["Tops"], "peak": peak_compute, "unit": "TFLOP/s" if dtype == "f32" else "TOP/s"}
     else:
         roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    roof["traffic"] = pmc_traffic(dom, batch, dtype)
-    roof["kernel"] = kernel_symbol(dom["kernel"], dom["p"])
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(dom, batch, dtype)
+    roof["kernel"] = dom["symbol"]
     roof["layer"] = dom["layer"]
     roof["avg_launch_ms"] = dom["avg_ms"]
     roof["algorithmic_bytes_per_launch"] = dom["bytes"]
+    roof["timing"] = "HIP events on the launch stream around this kernel only, averaged over the timed region"
     for s in stages:
         s.pop("bytes"), s.pop("ops"), s.pop("p"), s.pop("op")
     return roof, stages
@@ -193,7 +224,9 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
 
     float32: the plain-C + OpenMP port (``oracle/c/oracle_cpu.c``) on all host threads when it has been built, otherwise the
     numpy oracle on one thread.  INT8: the C + OpenMP port of the TFLite int8 reference kernels (``oracle/c/oracle_i8.c``) when
-    built, otherwise the numpy interpreter on one thread.
+    built, otherwise the numpy interpreter on one thread.  ``gops`` is the arithmetic rate that throughput amounts to
+    (53.08 MOP + 3.35 MFLOP of STFT per chunk) — a plain port, not a tuned CPU library: the ratio to the GPU
+    number says nothing about either.
     """
     import contextlib
 
@@ -210,44 +243,34 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
     ckpt = os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100")
     rng = np.random.default_rng(42)
     t = np.arange(T) / SR
+    gops = lambda rate: round(rate * (MOP_PER_CHUNK + STFT_MFLOP_PER_CHUNK) / 1e3, 2)  # noqa: E731
 
     def chunks(n):
         x = 0.3 * rng.standard_normal((n, T)) + np.sin(2 * np.pi * (500 + 37 * (np.arange(n) % 200))[:, None] * t[None, :])
         return (x / np.abs(x).max(axis=1, keepdims=True)).astype(np.float32)
 
+    def timed(fn, threads, what):
+        x = chunks(256)
+        fn(x[:32])  # warm up the OpenMP pool
+        t0 = time.perf_counter()
+        fn(x)
+        per = (time.perf_counter() - t0) / 256
+        n = int(max(256, min(16384, seconds_budget / per // 256 * 256)))
+        reps, done, t0 = n // 256, 0, time.perf_counter()
+        for _ in range(reps):
+            fn(x)
+            done += 256
+        dt = time.perf_counter() - t0
+        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": threads, "kind": "port", "gops": gops(done / dt),
+                "sample": f"{done} synthetic 3 s @ 24 kHz chunks, {what}, {threads} threads, {dt:.1f} s"}
+
     if dtype == "f32" and os.path.isfile(cport.CPU_LIB):
         path = cport.CpuFloatPath(load_keras_archive(ckpt + ".keras"))
-        x = chunks(256)
-        path(x[:32])  # warm up the OpenMP pool
-        t0 = time.perf_counter()
-        path(x)
-        per = (time.perf_counter() - t0) / 256
-        n = int(max(256, min(16384, seconds_budget / per // 256 * 256)))
-        reps, done, t0 = n // 256, 0, time.perf_counter()
-        for _ in range(reps):
-            path(x)
-            done += 256
-        dt = time.perf_counter() - t0
-        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": path.threads, "kind": "port",
-                "sample": f"{done} synthetic 3 s @ 24 kHz chunks, plain-C + OpenMP port of the float path (oracle/c/oracle_cpu.c), "
-                          f"{path.threads} threads, {dt:.1f} s"}
-
+        return timed(path, path.threads, "plain-C + OpenMP port of the float path (oracle/c/oracle_cpu.c)")
     if dtype == "i8" and os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB):
         path = cport.CpuInt8Path(load_tflite(ckpt + ".tflite"))
-        x = chunks(256)
-        path.invoke(path.spectrogram(x[:32], HOP, W))  # warm up the OpenMP pool
-        t0 = time.perf_counter()
-        path.invoke(path.spectrogram(x, HOP, W))
-        per = (time.perf_counter() - t0) / 256
-        n = int(max(256, min(16384, seconds_budget / per // 256 * 256)))
-        reps, done, t0 = n // 256, 0, time.perf_counter()
-        for _ in range(reps):
-            path.invoke(path.spectrogram(x, HOP, W))
-            done += 256
-        dt = time.perf_counter() - t0
-        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": path.threads, "kind": "port",
-                "sample": f"{done} synthetic 3 s @ 24 kHz chunks, plain-C + OpenMP port of the TFLite int8 reference kernels "
-                          f"(oracle/c/oracle_i8.c under the numpy interpreter's graph walk) + C STFT, {path.threads} threads, {dt:.1f} s"}
+        return timed(lambda x: path.invoke(path.spectrogram(x, HOP, W)), path.threads,
+                     "plain-C + OpenMP port of the TFLite int8 reference kernels (oracle/c/oracle_i8.c under the numpy interpreter's graph walk) + C STFT")
 
     if dtype == "f32":
         spec = load_keras_archive(ckpt + ".keras")
@@ -267,7 +290,7 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
         per = work(chunks(16)) / 16
         n = int(max(64, min(4096, seconds_budget / per // 64 * 64)))
         dt = work(chunks(n))
-    return {"value": round(n / dt, 2), "unit": "chunks/s", "cores": 1, "kind": "port",
+    return {"value": round(n / dt, 2), "unit": "chunks/s", "cores": 1, "kind": "port", "gops": gops(n / dt),
             "sample": f"{n} synthetic 3 s @ 24 kHz chunks, numpy oracle (oracle/stft.py + "
                       f"{'float_graph' if dtype == 'f32' else 'int8_graph'}.py), 1 thread, {dt:.1f} s"}
 
@@ -279,7 +302,7 @@ def quick_rate(torch, dtype: str, batch: int, device, local_rank: int, steps: in
 
     ckpt = os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100" + (".keras" if dtype == "f32" else ".tflite"))
     runner = load_model_runner(ckpt, device=local_rank, max_batch=batch)
-    audio = synth_audio_device(torch, batch, 0, device)
+    audio = synth_audio_device(torch, batch, 0, device, 42)
     scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
     for _ in range(2):
         runner.infer_audio_device(audio, hop=HOP, out=scores)
@@ -296,15 +319,66 @@ def quick_rate(torch, dtype: str, batch: int, device, local_rank: int, steps: in
             "ms_per_step": round(dt / steps * 1e3, 4)}
 
 
+def timed_job(score_batch, steps: int, batch: int, n_classes: int, device, barrier, sync):
+    """The timed region: this rank's ``steps`` batches through ``evaluation/sharding.py: run_sharded`` (one process: all of
+    them) and the ONE all-gather of the scores; bracketed by barrier + device synchronisation on both sides.
+
+    ``score_batch(k, out_rows)`` scores the rank's k-th batch into ``out_rows`` ([batch, n_classes]).  Returns
+    ``(seconds on this rank, gathered scores [world * steps * batch, n_classes])``.
+    """
+    import torch
+
+    from birdnet_stm32.evaluation.sharding import run_sharded, shard_bounds, world_info
+
+    rank, world = world_info()
+    n_items = world * steps * batch
+    lo, _hi = shard_bounds(n_items, rank, world)
+    local = torch.empty((steps * batch, n_classes), dtype=torch.float32, device=device)
+
+    def score(start, stop, out_rows):
+        score_batch((start - lo) // batch, out_rows)
+
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    gathered = run_sharded(score, n_items, batch, into=local)
+    sync()
+    barrier()
+    return time.perf_counter() - t0, gathered
+
+
+def self_launch(args, argv: list[str]) -> int:
+    """``python bench.py --gpus N`` with WORLD_SIZE unset: start N workers (one per GPU) with torch.distributed.run as a CHILD
+    process before this process has touched a GPU, relay their output, return their exit code."""
+    import socket
+
+    import torch  # device_count() does not initialise the GPU on this image
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 20 on one GPU, 8 = BASELINE configs[3] on several)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", choices=["f32", "i8"], default="f32")
-    ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (default 1024 f32, 4096 i8)")
+    ap.add_argument("--dtype", choices=["f32", "i8"], default="i8")
+    ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (default 4096 i8, 1024 f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    steps = args.steps or (20 if args.gpus == 1 else 8)
 
     import torch
     import torch.distributed as dist
@@ -312,7 +386,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -327,9 +401,10 @@ def main() -> None:
     batch = args.batch or (1024 if args.dtype == "f32" else 4096)
     ckpt = os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100" + (".keras" if args.dtype == "f32" else ".tflite"))
     runner = load_model_runner(ckpt, device=local_rank, max_batch=batch)
-    audio = synth_audio_device(torch, batch, rank, device)
-    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
-    gathered = torch.empty((world * batch, runner.num_classes), dtype=torch.float32, device=device) if world > 1 else None
+    n_distinct = min(steps, MAX_DISTINCT_BATCHES)
+    # this rank's block of the global chunk stream starts at chunk rank * steps * batch; batch k of it is pool[k % n_distinct]
+    pool = [synth_audio_device(torch, batch, (rank * steps + k) * batch, device, 42 + rank * 1000 + k) for k in range(n_distinct)]
+    scratch = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
 
     def barrier():
         if world > 1:
@@ -342,23 +417,19 @@ def main() -> None:
         if w == args.warmup - 1 and w > 0:  # first launches carry module loading: the table comes from the last warm-up step
             torch.cuda.synchronize(device)
             runner.profile_collect()
-        runner.infer_audio_device(audio, hop=HOP, out=scores)
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, scores)  # warm the RCCL communicator outside the timed region
+        runner.infer_audio_device(pool[w % n_distinct], hop=HOP, out=scratch)
+    if world > 1:  # warm the RCCL communicator (and its buffers for this message size) outside the timed region
+        warm = torch.empty((world * steps * batch, runner.num_classes), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(warm, warm[rank * steps * batch : (rank + 1) * steps * batch].clone())
+        del warm
     torch.cuda.synchronize(device)
     warm_rows = runner.profile_collect()
     dom_op = max((r for r in warm_rows if r["launches"]), key=lambda r: r["ms"] / r["launches"])["op"] if args.warmup else -1
     runner.profile_only(dom_op)
-    barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.infer_audio_device(audio, hop=HOP, out=scores)
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, scores)  # the one collective of the path: scores of all shards
-    torch.cuda.synchronize(device)
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    elapsed, gathered = timed_job(lambda k, out: runner.infer_audio_device(pool[k % n_distinct], hop=HOP, out=out), steps, batch,
+                                  runner.num_classes, device, barrier, lambda: torch.cuda.synchronize(device))
+    assert gathered.shape == (world * steps * batch, runner.num_classes)
     runner.profile(False)
     rows = runner.profile_collect()
     runner.profile_only(-1)
@@ -370,37 +441,50 @@ def main() -> None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    finite = bool(torch.isfinite(gathered).all().item())
+    del gathered
 
     if rank == 0:
         roof, stages = roofline_of(rows, batch, args.dtype, dom_op)
-        total_chunks = world * batch * args.steps
+        total_chunks = world * batch * steps
+        name = "birdnet_stm32n6_100 " + ("float32" if args.dtype == "f32" else "INT8") + " DS-CNN, hybrid+pwl frontend"
+        if world > 1:
+            name += f": {total_chunks} synthetic chunks sharded over {world} GPUs (BASELINE configs[3] is 262144 over 8), one RCCL all-gather of the scores"
         out = {
             "metric": "audio chunks/sec (3 s @ 24 kHz)",
             "value": round(total_chunks / elapsed, 1),
             "unit": "chunks/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (peak-normalised tone + gaussian noise, generated on device); shipped birdnet_stm32n6_100 weights",
             "config": {
-                "workload": ("birdnet_stm32n6_100 float32 DS-CNN, hybrid+pwl frontend" if args.dtype == "f32"
-                             else "birdnet_stm32n6_100 INT8 DS-CNN, hybrid+pwl frontend"),
+                "workload": name,
                 "batch_per_gpu": batch,
                 "global_batch": world * batch,
+                "chunks_total": total_chunks,
                 "chunk": "3 s @ 24 kHz (72000 samples), n_fft 512, hop 281, 257x256 spectrogram",
-                "path": "audio in HBM -> STFT -> mel+PWL -> DS-CNN -> scores in HBM" + (" -> RCCL all-gather" if world > 1 else ""),
+                "path": "audio in HBM -> STFT -> mel+PWL -> DS-CNN -> scores in HBM" + (
+                    f" -> ONE RCCL all-gather of [{steps * batch}, {runner.num_classes}] f32 per rank "
+                    f"({steps * batch * runner.num_classes * 4 / 1e6:.1f} MB), inside the timed region" if world > 1 else ""),
+                "distinct_input_batches_per_gpu": n_distinct,
             },
+            "scores_finite": finite,
+            "whole_path_mfma_frac": round(total_chunks / world * MOP_PER_CHUNK * 1e6 / elapsed / 1e12 /
+                                          (I8_MFMA_PEAK_TOPS if args.dtype == "i8" else F32_MFMA_PEAK_TFLOPS), 4),
             "roofline": roof,
             "stages": stages,
         }
         if world == 1 and not args.batch:  # the other single-GPU BASELINE configuration, for reference (not the reported value)
             runner.close()
             runner = None
+            del pool
+            torch.cuda.empty_cache()
             other = "i8" if args.dtype == "f32" else "f32"
             out["also_measured"] = quick_rate(torch, other, 4096 if other == "i8" else 1024, device, local_rank)
         if not args.no_cpu_baseline and world == 1:

@@ -52,6 +52,15 @@ def _step(sample_rate: int, chunk_duration: float, chunk_overlap: float) -> int:
     return max(1, int(sample_rate * (chunk_duration - overlap)))
 
 
+def have_soundfile() -> bool:
+    """Is libsndfile's Python binding importable (needed for containers other than RIFF/WAVE)?"""
+    try:
+        import soundfile  # noqa: F401
+    except Exception:
+        return False
+    return True
+
+
 # ------------------------------------------------------------------------------------------ WAV
 def _wav_layout(raw: bytes):
     """Return (format_tag, channels, sample_rate, bits, data_offset, data_bytes) of a RIFF/WAVE file."""
@@ -189,7 +198,8 @@ def save_wav(audio: np.ndarray, path: str, sample_rate: int = 24000, subtype: st
         code, bits, payload = 3, 32, x.astype("<f4").tobytes()
     else:
         code, bits = 1, 16
-        payload = np.clip(np.rint(x * 32768.0), -32768, 32767).astype("<i2").tobytes()  # libsndfile: lrint(x * 0x8000), clipped
+        # libsndfile's float -> int16 write path scales by 0x7FFF and rounds to nearest (lrintf); samples inside [-1, 1] never clip
+        payload = np.clip(np.rint(x * 32767.0), -32768, 32767).astype("<i2").tobytes()
     hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(payload), b"WAVE", b"fmt ", 16, code, 1, sample_rate,
                       sample_rate * bits // 8, bits // 8, bits, b"data", len(payload))
     with open(path, "wb") as fh:

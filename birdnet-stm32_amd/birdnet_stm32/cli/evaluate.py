@@ -4,9 +4,14 @@ Flow (reference :81-207): resolve ``<model>_model_config.json`` next to the mode
 given, read ``class_names`` from it, collect the test files under ``--data_path_test/<class>/``, load the runner,
 run ``evaluate`` and print the metric summary.  ``--benchmark`` writes the reference's JSON report shape
 (``model_path``, ``num_classes``, ``num_files`` (= total chunks, as in the reference), ``metrics``, ``config``)
-and ``--save_csv`` the per-file scores.  The presentation-only reports of the reference (confusion matrix,
-DET curve, species bootstrap CI, threshold optimisation, HTML) are outside the accelerated path: their flags
-are accepted and answered with a one-line notice.
+and ``--save_csv`` the per-file scores.  ``--confusion_matrix``, ``--det_curve`` (text forms), ``--species_report`` /
+``--n_bootstrap`` (bootstrap AP intervals) and ``--optimize_thresholds`` work as in the reference.  The plot / HTML
+renderings (``--save_cm_plot``, ``--save_det_plot``, ``--report_html``: matplotlib) are outside the accelerated path:
+the command refuses them with a non-zero exit before doing any work, so a script written for the reference fails
+loudly instead of missing an output file.
+
+Under ``python -m torch.distributed.run --nproc-per-node N`` (``WORLD_SIZE`` > 1) the test files are sharded over the
+N GPUs with one RCCL all-gather of the chunk scores (``evaluation/sharding.py``); rank 0 reports.
 
 Extra flags of this build: ``--device`` (GPU index) and ``--max_batch`` (workspace size in chunks).
 """
@@ -57,10 +62,13 @@ def resolve_config_path(model_path: str, model_config: str = "") -> str:
     return path
 
 
-def save_benchmark_json(metrics: dict, classes: list[str], model_path: str, out_path: str, config: dict | None = None) -> None:
+def save_benchmark_json(metrics: dict, classes: list[str], model_path: str, out_path: str, config: dict | None = None,
+                        species_data: list[dict] | None = None) -> None:
     """Reference report shape (reference: birdnet_stm32/evaluation/reporting.py:192-236)."""
     core = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in metrics.items() if k != "ap_per_class"}
     report = {"model_path": model_path, "num_classes": len(classes), "num_files": metrics.get("total_chunks", 0), "metrics": core}
+    if species_data:
+        report["species"] = species_data
     if config:
         report["config"] = config
     os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
@@ -77,32 +85,115 @@ def save_predictions_csv(per_file: list[dict], classes: list[str], out_path: str
             fh.write(f"{row['file']},{row['label']}," + ",".join(f"{s:.6f}" for s in row["scores"]) + "\n")
 
 
+PLOT_FLAGS = ("save_cm_plot", "save_det_plot", "report_html")  # matplotlib / HTML renderings: not part of this build
+
+
+def _init_distributed(device_arg: int):
+    """One process per GPU under ``torch.distributed.run``: join the RCCL group, pick this rank's GPU.  Returns
+    ``(rank, world, device index)``; (0, 1, device_arg) when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, device_arg
+    import torch
+    import torch.distributed as dist
+
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def print_confusion_matrix(y_true, y_scores, classes, threshold: float = 0.5) -> None:
+    """Top-1 confusion matrix as text, predictions below ``threshold`` counted as no prediction (reference:
+    birdnet_stm32/evaluation/reporting.py:81-114)."""
+    import numpy as np
+
+    truth = np.argmax(y_true, axis=1)
+    pred = np.argmax(y_scores, axis=1)
+    pred[np.max(y_scores, axis=1) < threshold] = -1
+    n = len(classes)
+    cm = np.zeros((n, n), np.int64)
+    keep = pred >= 0
+    np.add.at(cm, (truth[keep], pred[keep]), 1)
+    w = min(12, max(len(c) for c in classes)) if classes else 6
+    names = [c[:w] for c in classes]
+    print("\nConfusion Matrix (rows=true, cols=predicted):\n" + " " * (w + 1) + " ".join(f"{x:>{w}}" for x in names))
+    for i, row in enumerate(cm):
+        print(f"{names[i]:>{w}} " + " ".join(f"{v:>{w}}" for v in row))
+    total = int(cm.sum())
+    print(f"\nAccuracy: {int(np.trace(cm))}/{total} ({100 * int(np.trace(cm)) / max(total, 1):.1f}%)")
+
+
+def save_species_report_csv(species_data: list[dict], out_path: str) -> None:
+    """Per-species AP with bootstrap interval, best first (reference: birdnet_stm32/evaluation/reporting.py:173-189)."""
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    with open(out_path, "w") as fh:
+        fh.write("class,ap,ci_lower,ci_upper,n_positive,n_total\n")
+        for r in sorted(species_data, key=lambda r: r["ap"], reverse=True):
+            fh.write(f"{r['class']},{r['ap']:.6f},{r['ci_lower']:.6f},{r['ci_upper']:.6f},{r['n_positive']},{r['n_total']}\n")
+    print(f"Species AP report saved to {out_path}")
+
+
+def print_det_curve(far, frr, bins: int = 10, width: int = 40) -> None:
+    """Text DET curve: lowest FAR reached inside each FRR bin (reference: birdnet_stm32/evaluation/reporting.py:239-256)."""
+    import numpy as np
+
+    print("\nASCII DET Curve (FRR down, FAR right):")
+    edges = np.linspace(0.0, 1.0, bins + 1)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        inside = (frr >= lo) & (frr < hi)
+        best = float(far[inside].min()) if inside.any() else 1.0
+        print(f"FRR {lo:4.2f}-{hi:4.2f} | {'#' * int(width * best)} (FAR={best:4.3f})")
+
+
 def main(argv=None, runner=None):
-    """Evaluate a model on a class-structured test set.  ``runner`` lets tests inject a predict()-object."""
+    """Evaluate a model on a class-structured test set.  ``runner`` lets tests inject a predict()-object.
+
+    Launched under ``python -m torch.distributed.run --nproc-per-node N`` the files are sharded over the N GPUs
+    (``evaluation/sharding.py``); every rank computes the same metrics, rank 0 prints and writes the reports.
+    """
     from birdnet_stm32.data.dataset import SUPPORTED_AUDIO_EXTS, load_file_paths_from_directory
-    from birdnet_stm32.evaluation.metrics import evaluate
+    from birdnet_stm32.evaluation.metrics import bootstrap_ap_ci, compute_det_curve, evaluate, optimize_thresholds
     from birdnet_stm32.training.config import ModelConfig
 
     args = get_args(argv)
+    unsupported = [f for f in PLOT_FLAGS if getattr(args, f)]
+    if unsupported:  # refuse before any work instead of silently producing nothing
+        raise SystemExit("error: " + ", ".join("--" + f for f in unsupported) + " render plots / HTML, which this MI355X hot-path build "
+                         "does not include; use --save_csv / --benchmark / --species_report and the reference's reporting module")
     cfg = ModelConfig.load(resolve_config_path(args.model_path, args.model_config)).to_dict()
     classes = cfg.get("class_names", [])
     if not classes:
         raise ValueError("class_names missing in model config.")
+    rank, world, device = (0, 1, args.device) if runner is not None else _init_distributed(args.device)
+    if world > 1:  # every rank must walk the same shuffled file list
+        import numpy as np
+
+        np.random.seed(0)
     files, _ = load_file_paths_from_directory(args.data_path_test, classes=classes, exts=SUPPORTED_AUDIO_EXTS, max_samples=args.max_files)
     if not files:
         raise RuntimeError(f"No test audio found in {args.data_path_test}")
     if runner is None:
         from birdnet_stm32.models.runners import load_model_runner
 
-        runner = load_model_runner(args.model_path, device=args.device, max_batch=args.max_batch)
+        runner = load_model_runner(args.model_path, device=device, max_batch=args.max_batch)
 
     metrics, per_file, y_true, y_scores = evaluate(
         model_runner=runner, files=files, classes=classes, cfg=cfg, pooling=args.pooling, batch_size=args.batch_size,
         overlap=max(0.0, min(cfg["chunk_duration"] - 0.1, args.overlap)), measure_latency=args.benchmark_latency,
         profile_memory=args.profile_memory,
     )  # fmt: skip
+    if world > 1:
+        import torch.distributed as dist
 
-    print(f"\nEvaluated {len(per_file)} files across {len(classes)} classes.")
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return metrics
+
+    print(f"\nEvaluated {len(per_file)} files across {len(classes)} classes." + (f" ({world} GPUs)" if world > 1 else ""))
     for key, value in metrics.items():
         if key == "ap_per_class":
             continue
@@ -113,14 +204,32 @@ def main(argv=None, runner=None):
         print("\nTop 10 classes by AP:")
         for name, ap in ranked[:10]:
             print(f"  {name}: {ap:.4f}")
-    for flag in ("confusion_matrix", "save_cm_plot", "optimize_thresholds", "species_report", "det_curve", "save_det_plot", "report_html"):
-        if getattr(args, flag):
-            print(f"[notice] --{flag}: presentation report not included in the MI355X hot-path build")
+        print("\nBottom 10 classes by AP:")
+        for name, ap in ranked[-10:]:
+            print(f"  {name}: {ap:.4f}")
+    if args.det_curve:
+        far, frr, _ = compute_det_curve(y_true, y_scores)
+        print_det_curve(far, frr)
+    species = None
+    if args.species_report or args.benchmark:
+        species = bootstrap_ap_ci(y_true, y_scores, classes, n_bootstrap=args.n_bootstrap)
+        if args.species_report:
+            save_species_report_csv(species, args.species_report)
     if args.save_csv:
         save_predictions_csv(per_file, classes, args.save_csv)
         print(f"Predictions saved to {args.save_csv}")
+    if args.confusion_matrix:
+        print_confusion_matrix(y_true, y_scores, classes)
+    if args.optimize_thresholds:
+        print("\nOptimal per-class thresholds (max F1):")
+        for name, thr in sorted(optimize_thresholds(y_true, y_scores, classes).items(), key=lambda t: t[1], reverse=True):
+            print(f"  {name}: {thr:.4f}")
     if args.benchmark:
-        save_benchmark_json(metrics, classes, args.model_path, args.benchmark, config=cfg)
+        save_benchmark_json(metrics, classes, args.model_path, args.benchmark, config=cfg, species_data=species)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
     return metrics
 
 

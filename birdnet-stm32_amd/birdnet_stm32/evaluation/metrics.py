@@ -98,21 +98,25 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
     Per group: the PCM payloads are uploaded as they lie in the files, ``bn_ingest_resample`` + ``bn_ingest_chunks``
     produce the chunk matrix, ``bn_infer_audio`` scores it in batches of ``batch_size`` chunks (batches cross file
     boundaries), ``bn_pool_scores`` reduces it to one row per file; only that row travels back to the host.
+
+    Under ``torch.distributed`` (one process per GPU, ``WORLD_SIZE`` > 1) the files are dealt to the ranks in contiguous
+    blocks (``evaluation/sharding.py: score_files_sharded``): every rank scores the chunks of its files, the chunk scores
+    meet in ONE all-gather (RCCL over xGMI) and every rank pools all files from the gathered tensor, so ``evaluate``
+    returns the same metrics on every rank.  The latency list then covers this rank's batches only.
     """
     import torch
 
     from birdnet_stm32.audio.ingest import load_audio_files_device, pool_scores_device
+    from birdnet_stm32.evaluation.sharding import score_files_sharded, world_info
 
     sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
     todo = [p for p in files if _label_of(p) in classes]
     lat: list[float] = []
-    for g0 in range(0, len(todo), files_per_group):
-        group = todo[g0 : g0 + files_per_group]
+
+    def score_group(group):
         chunks, counts = load_audio_files_device(runner.ctx, group, sample_rate=sr, max_duration=60, chunk_duration=cd,
                                                  chunk_overlap=overlap)
         n = chunks.shape[0]
-        if n == 0:
-            continue
         scores = torch.empty((n, runner.num_classes), dtype=torch.float32, device=chunks.device)
         for b0 in range(0, n, batch_size):
             nb = min(batch_size, n - b0)
@@ -121,6 +125,31 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
             if measure_latency:
                 torch.cuda.synchronize(chunks.device)
                 lat.extend([(time.perf_counter() - t0) * 1000.0 / nb] * nb)
+        return scores, counts
+
+    if world_info()[1] > 1:
+        def score_block(lo, hi):
+            parts, counts = [], []
+            for g0 in range(lo, hi, files_per_group):
+                s, c = score_group(todo[g0 : min(g0 + files_per_group, hi)])
+                parts.append(s)
+                counts += c
+            return (torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]), counts
+
+        scores, counts = score_files_sharded(len(todo), score_block, runner.num_classes, device=runner.device)
+        if scores.shape[0] == 0:
+            return
+        pooled = pool_scores_device(runner.ctx, scores.contiguous(), counts, pooling, beta).cpu().numpy()
+        for path, c, row in zip(todo, counts, pooled):
+            if c:
+                yield path, c, row, lat
+        return
+
+    for g0 in range(0, len(todo), files_per_group):
+        group = todo[g0 : g0 + files_per_group]
+        scores, counts = score_group(group)
+        if scores.shape[0] == 0:
+            continue
         pooled = pool_scores_device(runner.ctx, scores, counts, pooling, beta).cpu().numpy()
         for path, c, row in zip(group, counts, pooled):
             if c:
@@ -165,6 +194,24 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
         y_true.append(target)
         y_scores.append(pooled)
         per_file.append({"file": path, "label": label, "scores": pooled.tolist()})
+    known = [p for p in files if _label_of(p) in classes]
+    if len(per_file) < len(known):  # the reference skips such files silently (:112-116); say which kind they were
+        import warnings
+
+        done = {r["file"] for r in per_file}
+        by_ext: dict[str, int] = {}
+        for p in known:
+            if p not in done:
+                ext = os.path.splitext(p)[1].lower()
+                by_ext[ext] = by_ext.get(ext, 0) + 1
+        hint = ""
+        if any(e != ".wav" for e in by_ext):
+            from birdnet_stm32.audio.io import have_soundfile
+
+            if not have_soundfile():
+                hint = " (only RIFF/WAVE and FLAC are decoded natively; other containers need the `soundfile` package, which is not installed)"
+        warnings.warn(f"evaluate: {len(known) - len(per_file)} of {len(known)} files were empty or could not be decoded and were skipped: "
+                      + ", ".join(f"{n} x {e or '<no extension>'}" for e, n in sorted(by_ext.items())) + hint, RuntimeWarning, stacklevel=2)
     if not y_true:
         raise RuntimeError("No valid test samples found for the provided class set.")
 
@@ -205,3 +252,79 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
         metrics["peak_rss_mb"] = round(rss1 / 1024, 1)
         metrics["rss_delta_mb"] = round((rss1 - rss0) / 1024, 1)
     return metrics, per_file, yt, ys
+
+
+def optimize_thresholds(y_true: np.ndarray, y_scores: np.ndarray, classes: list[str]) -> dict[str, float]:
+    """Per-class score threshold with the largest F1 on the precision-recall curve (reference :209-236); a class
+    without positives keeps 0.5."""
+    from sklearn.metrics import precision_recall_curve
+
+    best: dict[str, float] = {}
+    for c, name in enumerate(classes):
+        truth = y_true[:, c]
+        if truth.sum() == 0:
+            best[name] = 0.5
+            continue
+        prec, rec, thr = precision_recall_curve(truth, y_scores[:, c])
+        p, r = prec[:-1], rec[:-1]  # the curve carries one more point than thresholds
+        best[name] = float(thr[int(np.argmax(2 * p * r / (p + r + 1e-12)))])
+    return best
+
+
+def bootstrap_ap_ci(y_true: np.ndarray, y_scores: np.ndarray, classes: list[str], n_bootstrap: int = 1000, confidence: float = 0.95,
+                    seed: int = 42) -> list[dict]:
+    """Per-class average precision with a percentile bootstrap interval (reference :239-318).
+
+    One generator seeded with ``seed`` is consumed class by class, ``n_bootstrap`` draws of ``n`` indices each for every
+    class that has both positives and negatives (the reference's draw order, so the intervals agree for equal inputs);
+    resamples without both kinds of label are dropped.
+    """
+    from sklearn.metrics import average_precision_score
+
+    rng = np.random.default_rng(seed)
+    n = y_true.shape[0]
+    tail = (1.0 - confidence) / 2.0
+    rows = []
+    for c, name in enumerate(classes):
+        truth, score = y_true[:, c], y_scores[:, c]
+        pos = int(truth.sum())
+        try:
+            ap = float(average_precision_score(truth, score))
+        except Exception:
+            ap = float("nan")
+        lo = hi = ap
+        if 0 < pos < n:
+            draws = []
+            for _ in range(n_bootstrap):
+                pick = rng.integers(0, n, size=n)
+                t = truth[pick]
+                k = t.sum()
+                if k == 0 or k == len(t):
+                    continue
+                try:
+                    draws.append(float(average_precision_score(t, score[pick])))
+                except Exception:
+                    continue
+            if draws:
+                lo, hi = float(np.percentile(draws, 100 * tail)), float(np.percentile(draws, 100 * (1 - tail)))
+        rows.append({"class": name, "ap": ap, "ci_lower": lo, "ci_upper": hi, "n_positive": pos, "n_total": n})
+    return rows
+
+
+def compute_det_curve(y_true: np.ndarray, y_scores: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Detection-error-tradeoff points ``(far, frr, thresholds)`` over the distinct scores, highest threshold first
+    (reference :321-372): at threshold t, FAR = negatives scored >= t / negatives, FRR = positives scored < t / positives.
+    Degenerate label sets give the single point (0, 0, 0.5)."""
+    t = np.asarray(y_true).ravel()
+    s = np.asarray(y_scores).ravel()
+    n_pos = t.sum()
+    n_neg = len(t) - n_pos
+    if n_pos == 0 or n_neg == 0:
+        return np.array([0.0]), np.array([0.0]), np.array([0.5])
+    order = np.argsort(-s, kind="stable")
+    s_sorted, t_sorted = s[order], t[order]
+    thr, first = np.unique(-s_sorted, return_index=True)  # ascending in -score = descending in score
+    last = np.append(first[1:], len(s_sorted)) - 1        # last index whose score is >= the threshold
+    tp = np.cumsum(t_sorted)[last]
+    fp = (last + 1) - tp
+    return fp / n_neg, (n_pos - tp) / n_pos, -thr

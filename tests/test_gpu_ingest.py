@@ -173,7 +173,7 @@ def test_ingest_then_infer_equals_host_ingest_then_infer(ctx, tmp_path):
     sig = fixture_signals(44100, 5.0)
     wins, host = [], []
     for name in ("sine", "chirp", "noise"):
-        pcm = np.clip(np.rint(sig[name] * 32768.0), -32768, 32767).astype(np.int16)
+        pcm = np.clip(np.rint(sig[name] * 32767.0), -32768, 32767).astype(np.int16)  # save_wav's (libsndfile's) write scaling
         wins.append(ingest.window_from_int16(pcm, 44100))
         p = str(tmp_path / f"{name}.wav")
         io.save_wav(sig[name], p, 44100)

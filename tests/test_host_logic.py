@@ -110,10 +110,10 @@ def test_wav_decode_mix_resample_normalise(tmp_path):
     assert chunks.shape == (1, 3 * sr)
     np.testing.assert_allclose(chunks[0, :sr], x / np.abs(x).max(), rtol=1e-6, atol=1e-6)
     assert np.all(chunks[0, sr:] == 0)
-    # PCM16: libsndfile scaling x/32768; peak-normalised afterwards
+    # PCM16: libsndfile writes lrint(x * 0x7FFF) and reads int16 / 32768; peak-normalised afterwards
     save_wav(x, str(tmp_path / "b.wav"), sr)
     y = load_audio_window(str(tmp_path / "b.wav"), sample_rate=sr)
-    q = np.clip(np.rint(x * 32768), -32768, 32767) / 32768.0
+    q = np.clip(np.rint(x * 32767), -32768, 32767) / 32768.0
     np.testing.assert_allclose(y, (q / np.abs(q).max()).astype(np.float32), atol=1e-7)
     # stereo PCM16 -> channel mean; 24-bit PCM; resampling on load
     l, r = (np.sin(np.arange(8000) * 0.01) * 12000).astype("<i2"), (np.cos(np.arange(8000) * 0.02) * 9000).astype("<i2")
@@ -268,12 +268,62 @@ def test_cli_surface(tiny_dataset, tmp_path, capsys):
     cfgp.write_text(json.dumps(rawcfg))
     out_json, out_csv = tmp_path / "bench.json", tmp_path / "pred.csv"
     main(["--model_path", str(tmp_path / "m.keras"), "--data_path_test", str(root), "--benchmark_latency", "--benchmark", str(out_json),
-          "--save_csv", str(out_csv), "--confusion_matrix"], runner=Const())
+          "--save_csv", str(out_csv), "--confusion_matrix", "--optimize_thresholds", "--det_curve", "--n_bootstrap", "5",
+          "--species_report", str(tmp_path / "species.csv")], runner=Const())
     rep = json.loads(out_json.read_text())
-    assert set(rep) == {"model_path", "num_classes", "num_files", "metrics", "config"} and rep["num_classes"] == 100
+    # reference report shape (evaluation/reporting.py:192-236): species rows ride along whenever --benchmark is given
+    assert set(rep) == {"model_path", "num_classes", "num_files", "metrics", "config", "species"} and rep["num_classes"] == 100
     assert rep["num_files"] == rep["metrics"]["total_chunks"] == 19
+    assert len(rep["species"]) == 100 and set(rep["species"][0]) == {"class", "ap", "ci_lower", "ci_upper", "n_positive", "n_total"}
     assert out_csv.read_text().count("\n") == 18
-    assert "presentation report not included" in capsys.readouterr().out
+    assert (tmp_path / "species.csv").read_text().splitlines()[0] == "class,ap,ci_lower,ci_upper,n_positive,n_total"
+    out = capsys.readouterr().out
+    assert "Confusion Matrix (rows=true, cols=predicted)" in out and "Optimal per-class thresholds (max F1)" in out and "ASCII DET Curve" in out
+    # the plot / HTML renderings are not in this build: the command refuses them before doing any work
+    for flag in ("--save_cm_plot", "--save_det_plot", "--report_html"):
+        with pytest.raises(SystemExit, match="render plots"):
+            main(["--model_path", str(tmp_path / "m.keras"), "--data_path_test", str(root), flag, str(tmp_path / "x")], runner=Const())
+
+
+def test_metric_helpers_match_their_definitions():
+    """optimize_thresholds / bootstrap_ap_ci / compute_det_curve (reference evaluation/metrics.py:209-372) against
+    direct restatements of their definitions."""
+    from sklearn.metrics import average_precision_score, precision_recall_curve
+
+    from birdnet_stm32.evaluation.metrics import bootstrap_ap_ci, compute_det_curve, optimize_thresholds
+
+    rng = np.random.default_rng(3)
+    yt = (rng.random((60, 5)) < 0.3).astype(np.float32)
+    yt[:, 4] = 0  # a class without positives
+    ys = np.round(rng.random((60, 5)), 2).astype(np.float32)  # ties on purpose
+    names = list("abcde")
+    # DET: one point per distinct score, highest first
+    far, frr, thr = compute_det_curve(yt, ys)
+    t, s = yt.ravel(), ys.ravel()
+    want = [((s >= u)[t == 0].sum() / (t == 0).sum(), 1 - (s >= u)[t == 1].sum() / (t == 1).sum(), u) for u in np.unique(s)[::-1]]
+    np.testing.assert_allclose(np.stack([far, frr, thr], 1), np.asarray(want, np.float64), atol=1e-12)
+    assert [a.tolist() for a in compute_det_curve(np.zeros(4), np.ones(4))] == [[0.0], [0.0], [0.5]]
+    # thresholds: argmax F1 over the PR curve, 0.5 without positives
+    got = optimize_thresholds(yt, ys, names)
+    assert got["e"] == 0.5
+    for c in range(4):
+        p, r, th = precision_recall_curve(yt[:, c], ys[:, c])
+        assert got[names[c]] == float(th[np.argmax(2 * p[:-1] * r[:-1] / (p[:-1] + r[:-1] + 1e-12))])
+    # bootstrap: one generator(seed) consumed class by class, n draws per resample, degenerate resamples dropped
+    rows = bootstrap_ap_ci(yt, ys, names, n_bootstrap=25, seed=7)
+    g = np.random.default_rng(7)
+    for c in range(5):
+        pos = int(yt[:, c].sum())
+        assert rows[c]["n_positive"] == pos and rows[c]["n_total"] == 60 and rows[c]["class"] == names[c]
+        if pos == 0:
+            assert rows[c]["ci_lower"] == rows[c]["ci_upper"] or np.isnan(rows[c]["ap"])
+            continue
+        aps = []
+        for _ in range(25):
+            idx = g.integers(0, 60, size=60)
+            if 0 < yt[idx, c].sum() < 60:
+                aps.append(average_precision_score(yt[idx, c], ys[idx, c]))
+        assert rows[c]["ci_lower"] == pytest.approx(np.percentile(aps, 2.5), abs=1e-12) and rows[c]["ci_upper"] == pytest.approx(np.percentile(aps, 97.5), abs=1e-12)
 
 
 def test_hot_path_fails_loudly_without_gpu():

@@ -36,6 +36,62 @@ print("rank", rank, "ok", lo, hi)
 """
 
 
+WORKER2 = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from birdnet_stm32.evaluation.sharding import all_gather_ragged, run_sharded, score_files_sharded, shard_bounds
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+C = 7
+# 1) bench.py's timed region with a fake scorer: K batches per rank into one buffer, ONE all-gather, equal shards
+K, B = 3, 4
+seen = []
+def score_batch(k, out_rows):   # row j of the rank's batch k is global chunk (rank*K + k)*B + j
+    seen.append(k)
+    g = torch.arange(B, dtype=torch.float32) + (rank * K + k) * B
+    out_rows.copy_(g[:, None] * torch.arange(1, C + 1, dtype=torch.float32)[None, :])
+calls = {"barrier": 0, "sync": 0}
+def barrier():
+    calls["barrier"] += 1
+    dist.barrier()
+def sync():
+    calls["sync"] += 1
+dt, gathered = bench.timed_job(score_batch, K, B, C, torch.device("cpu"), barrier, sync)
+assert seen == [0, 1, 2] and calls == {"barrier": 2, "sync": 2} and dt > 0
+expect = torch.arange(world * K * B, dtype=torch.float32)[:, None] * torch.arange(1, C + 1, dtype=torch.float32)[None, :]
+assert torch.equal(gathered, expect)
+# 2) fewer items than ranks: every rank raises before any work (no rank is left in the collective)
+try:
+    run_sharded(lambda a, b: torch.zeros((b - a, C)), 1, 4)
+    raise SystemExit("expected ValueError")
+except ValueError as e:
+    assert "cannot be sharded" in str(e)
+# 3) ragged all-gather
+local = torch.full((3 + 2 * rank, C), float(rank))
+allrows, counts = all_gather_ragged(local)
+assert counts == [3, 5] and allrows.shape == (8, C) and torch.equal(allrows[:3], torch.zeros(3, C)) and torch.equal(allrows[3:], torch.ones(5, C))
+# 4) evaluate's file-level sharding: 5 files with 1..5 chunks; file f's chunk rows carry f
+per = [1, 2, 3, 4, 5]
+def score_files(lo, hi):
+    rows = [torch.full((per[f], C), float(f)) for f in range(lo, hi)]
+    return torch.cat(rows), per[lo:hi]
+scores, counts = score_files_sharded(5, score_files, C)
+assert counts == per and scores.shape == (15, C)
+assert torch.equal(scores[:, 0], torch.repeat_interleave(torch.arange(5, dtype=torch.float32), torch.tensor(per)))
+# fewer files than ranks: the rank without files still joins both collectives
+scores, counts = score_files_sharded(1, lambda lo, hi: (torch.ones(2, C), [2]), C)
+assert counts == [2] and scores.shape == (2, C)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -72,3 +128,48 @@ def test_shard_bounds_cover_the_range():
     assert shard_bounds(262144, 3, 8) == (98304, 131072)  # BASELINE configs[3]: 32768 chunks per rank
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+def test_bench_job_ragged_gather_and_file_sharding(tmp_path):
+    """bench.py's timed region (run_sharded + one all-gather) with a fake scorer, the all-ranks refusal of an unshardable job,
+    the ragged all-gather and evaluate's file-level sharding — world size 2 on gloo."""
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2 % (PKG, REPO))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts torch.distributed.run as a child (never an exec of a process
+    that touched the GPU) and refuses when fewer GPUs are visible."""
+    import argparse
+
+    import bench
+
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    import torch
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    assert bench.self_launch(argparse.Namespace(gpus=4), ["--gpus", "4", "--steps", "8"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "8"]
+    assert cmd[cmd.index("--master-port") + 2] == os.path.join(REPO, "bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert bench.self_launch(argparse.Namespace(gpus=8), ["--gpus", "8"]) == 2
