@@ -27,8 +27,13 @@ EXPORTS = (
     "bn_version", "bn_last_error", "bn_device_count", "bn_ctx_create", "bn_ctx_destroy", "bn_model_load",
     "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
     "bn_kernel_names", "bn_profile_enable", "bn_profile_collect", "bn_ingest_resample", "bn_ingest_chunks",
-    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize",
+    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize", "bn_set_option", "bn_get_option",
+    "bn_blob_check", "bn_debug_requant",
 )  # fmt: skip
+
+# launcher switches of bn_set_option (include/birdnet_hip.h); the production defaults are what a fresh process has
+OPTION_NAMES = ("f32_strip", "f32_strip_th", "f32_front_staged", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th", "i8_tail",
+                "i8_mel_generic", "stft_rowmajor", "stft_tpw", "ingest_blk", "ingest_generic")
 
 
 class BnModelInfo(ctypes.Structure):
@@ -89,6 +94,10 @@ def load_library(path: str | None = None):
     lib.bn_pool_scores.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
     lib.bn_mel_spectrogram.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                        ctypes.c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+    lib.bn_blob_check.argtypes = [c_char_p, c_size_t]
+    lib.bn_debug_requant.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.bn_set_option.argtypes = [c_char_p, c_int]
+    lib.bn_get_option.argtypes = [c_char_p, POINTER(c_int)]
     if lib.bn_version() != ABI_VERSION:
         raise RuntimeError(f"libbirdnet_hip ABI {lib.bn_version()} != binding ABI {ABI_VERSION}")
     _lib = lib
@@ -99,6 +108,40 @@ def check(rc: int) -> None:
     if rc != 0:
         msg = load_library().bn_last_error()
         raise HipError(f"libbirdnet_hip error {rc}: {msg.decode('utf-8', 'replace') if msg else ''}")
+
+
+def blob_check(blob: bytes) -> None:
+    """``bn_blob_check``: raise :class:`HipError` unless ``blob`` is a well-formed plan (host only, no device needed)."""
+    check(load_library().bn_blob_check(blob, len(blob)))
+
+
+def set_option(name: str, value: int) -> None:
+    """``bn_set_option``: process-wide launcher switch (A/B runs, tests)."""
+    check(load_library().bn_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = c_int()
+    check(load_library().bn_get_option(name.encode(), byref(v)))
+    return int(v.value)
+
+
+class options:
+    """``with options(i8_strip=0, i8_strip_th=3): ...`` — set launcher switches, restore the previous values on exit."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def loaded_hip_runtimes() -> list[str]:
@@ -161,4 +204,5 @@ class Model:
             pass
 
 
-__all__ = ["load_library", "check", "Context", "Model", "HipError", "BnModelInfo", "EXPORTS", "LIB_PATH", "c_float"]
+__all__ = ["load_library", "check", "Context", "Model", "HipError", "BnModelInfo", "EXPORTS", "LIB_PATH", "c_float", "set_option", "get_option",
+           "options", "OPTION_NAMES"]

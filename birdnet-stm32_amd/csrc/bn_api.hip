@@ -3,9 +3,11 @@
 // bn_forward()/bn_infer_audio() call into a sequence of kernel launches on the caller's stream.
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,7 +40,36 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kFft = 512;
 constexpr int kMaxGridBatch = 32768;  // chunks per launch group (gridDim.y/z limit is 65535)
 
+struct OptName {
+    const char* name;
+    int bn::Options::*field;
+};
+const OptName kOptions[] = {
+    {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"front_tpw", &bn::Options::front_tpw},
+    {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
+    {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
+    {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
+    {"stft_tpw", &bn::Options::stft_tpw},         {"ingest_blk", &bn::Options::ingest_blk},
+    {"ingest_generic", &bn::Options::ingest_generic},
+};
+
+// BN_<NAME> environment variables seed the options once, when the library is loaded (A/B runs of bench.py from a shell)
+bn::Options options_from_env() {
+    bn::Options o;
+    for (const OptName& e : kOptions) {
+        std::string var = "BN_";
+        for (const char* c = e.name; *c; ++c) var += (char)toupper((unsigned char)*c);
+        if (const char* v = getenv(var.c_str())) o.*(e.field) = atoi(v);
+    }
+    return o;
+}
+
 }  // namespace
+
+namespace bn {
+Options g_opt = options_from_env();
+}
 
 struct bn_ctx {
     int device = 0;
@@ -61,7 +92,6 @@ struct bn_model {
     size_t consts_base = 0;              // blob offset of the first payload byte
     size_t consts_bytes = 0;
     std::vector<uint8_t> rq_right;       // per operator: all requantisation multipliers >= 0 and shifts < 0
-    bool use_strip = true;               // BN_I8_STRIP=0 keeps the generic fused INT8 block everywhere (A/B runs, tests)
     bool spec_tiled_ok = false;          // the plan's first operator reads the spectrogram through i8_mel_mfma_kernel<QIN>: bn_infer_audio
                                          // may hand it the tile-major layout the STFT writes fastest
     bool spec_tiled_now = false;         // set by bn_infer_audio around its bn_forward call
@@ -288,7 +318,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     if (!bn::i8_mel_mfma_supported(a)) return fail(BN_ERR_FORMAT, "operator %zu: fused QUANTIZE needs the mel-mixer kernel's geometry", oi);
                 }
                 // wide early layers: wave-autonomous strip kernel when the packer prepared its constant block
-                if (p[35] && o.t[9] >= 0 && m->use_strip && a.has_dw && !a.transposed && a.sh == a.sw &&
+                if (p[35] && o.t[9] >= 0 && bn::g_opt.i8_strip && a.has_dw && !a.transposed && a.sh == a.sw &&
                     bn::i8_strip_supported(a.Cin, a.Cout, a.sh, a.OW, a.add.enabled != 0) &&
                     (!a.add.enabled || (a.res == a.x && o.t[10] >= 0))) {
                     const int off = a.add.enabled ? 128 : 0;
@@ -315,7 +345,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 q.stem_zp_in = p[6]; q.stem_zp_out = p[7]; q.stem_amin = p[8]; q.stem_amax = p[9];
                 q.dw_zp_out = p[10]; q.dw_amin = p[11]; q.dw_amax = p[12]; q.pw_zp_out = p[13]; q.pw_amin = p[14]; q.pw_amax = p[15];
                 q.rq_right = m->rq_right[oi];
-                if (p[16] && o.t[12] >= 0 && m->use_strip && bn::i8_front_strip_supported(q.H0, q.W0, q.C, q.N, q.OH, q.OW)) {
+                if (p[16] && o.t[12] >= 0 && bn::g_opt.i8_strip && bn::i8_front_strip_supported(q.H0, q.W0, q.C, q.N, q.OH, q.OW)) {
                     bn::FrontStrip8Args fa{(const int8_t*)in0, (int8_t*)out, (const int32_t*)m->tensor(o.t[12]), B, q.H0, q.W0, q.OH, q.OW, 0,
                                            q.stem_zp_in, q.stem_amin, q.stem_amax, q.stem_zp_out, q.dw_amin, q.dw_amax, q.pw_amin, q.pw_amax};
                     bn::launch_i8_front_strip(fa, s);
@@ -375,6 +405,12 @@ int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
         return fail(BN_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
 
     bn_ctx* c = new bn_ctx();
+    struct Guard {  // a failing HIP call below returns early: release what has been allocated so far
+        bn_ctx* c;
+        ~Guard() {
+            if (c) bn_ctx_destroy(c);
+        }
+    } guard{c};
     c->device = device;
     c->max_batch = max_batch;
     // STFT tables in double, rounded once to float32
@@ -406,6 +442,12 @@ int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
     HIP_TRY(hipMemcpy(c->d_tw256, t256.data(), t256.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_tw512, t512.data(), t512.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->tables = bn::StftTables{c->d_window, c->d_tw256, c->d_tw512};
+    // bn_ingest_resample's per-workgroup peak scratch (one float per >= 1024 resampled samples): sized here for windows that
+    // yield max_batch 3 s chunks at 24 kHz (72 blocks per chunk) with headroom, so that the ingest call itself does not allocate
+    // (no hidden device sync on that path); a call that needs more still grows it, once.
+    c->block_peaks_elems = (size_t)max_batch * 128 + 65536;
+    HIP_TRY(hipMalloc(&c->d_block_peaks, c->block_peaks_elems * sizeof(float)));
+    guard.c = nullptr;
     *out = c;
     return BN_OK;
 }
@@ -420,13 +462,12 @@ void bn_ctx_destroy(bn_ctx* c) {
     delete c;
 }
 
-int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) {
-    if (!out) return fail(BN_ERR_ARG, "out is null");
-    *out = nullptr;
-    if (int rc = check_device(ctx)) return rc;
+// Parse and validate a packed blob (host only): tables inside the blob, payloads aligned and in range, operator references in
+// range, every operator's geometry against the slot and tensor sizes (bn_plan_check.hip).
+static int parse_blob(const void* blob, size_t nbytes, BlobHeader& h, std::vector<SlotRec>& slots, std::vector<TensorRec>& tensors,
+                      std::vector<OpRec>& ops) {
     if (!blob || nbytes < sizeof(BlobHeader)) return fail(BN_ERR_FORMAT, "blob too small (%zu bytes)", nbytes);
     const char* base = (const char*)blob;
-    BlobHeader h;
     memcpy(&h, base, sizeof h);
     if (memcmp(h.magic, BN_BLOB_MAGIC, 8) != 0) return fail(BN_ERR_FORMAT, "bad blob magic");
     if (h.version != BN_BLOB_VERSION)
@@ -436,47 +477,59 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
         !in_range(h.tensors_off, (uint64_t)h.n_tensors * sizeof(TensorRec)) ||
         !in_range(h.ops_off, (uint64_t)h.n_ops * sizeof(OpRec)))
         return fail(BN_ERR_FORMAT, "blob tables exceed the blob size");
+    slots.resize(h.n_slots);
+    tensors.resize(h.n_tensors);
+    ops.resize(h.n_ops);
+    if (h.n_slots) memcpy(slots.data(), base + h.slots_off, h.n_slots * sizeof(SlotRec));
+    if (h.n_tensors) memcpy(tensors.data(), base + h.tensors_off, h.n_tensors * sizeof(TensorRec));
+    if (h.n_ops) memcpy(ops.data(), base + h.ops_off, h.n_ops * sizeof(OpRec));
+    for (const TensorRec& t : tensors)
+        if (!in_range(t.offset, t.nbytes) || (t.offset & 255)) return fail(BN_ERR_FORMAT, "tensor payload out of range or misaligned");
+    for (const SlotRec& sl : slots)
+        if (sl.bytes_per_chunk > (1ull << 32)) return fail(BN_ERR_FORMAT, "slot of %llu bytes per chunk", (unsigned long long)sl.bytes_per_chunk);
+    for (const OpRec& o : ops) {
+        for (int k = 0; k < BN_OP_NT; ++k)
+            if (o.t[k] >= (int)h.n_tensors) return fail(BN_ERR_FORMAT, "operator references tensor %d of %u", o.t[k], h.n_tensors);
+        const int ids[3] = {o.in0, o.in1, o.out};
+        for (int id : ids)
+            if (id >= (int)h.n_slots || (id < 0 && id != BN_SLOT_INPUT && id != BN_SLOT_SCORES && id != BN_SLOT_LOGITS && id != BN_SLOT_AUDIO && id != BN_SLOT_NONE))
+                return fail(BN_ERR_FORMAT, "operator references slot %d of %u", id, h.n_slots);
+    }
+    std::string why;
+    if (!bn::check_plan(h, slots, tensors, ops, why)) return fail(BN_ERR_FORMAT, "%s", why.c_str());
+    return BN_OK;
+}
 
+int bn_blob_check(const void* blob, size_t nbytes) {
+    BlobHeader h;
+    std::vector<SlotRec> slots;
+    std::vector<TensorRec> tensors;
+    std::vector<OpRec> ops;
+    return parse_blob(blob, nbytes, h, slots, tensors, ops);
+}
+
+int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) {
+    if (!out) return fail(BN_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (int rc = check_device(ctx)) return rc;
     bn_model* m = new bn_model();
     m->ctx = ctx;
-    m->hdr = h;
-    m->slots.resize(h.n_slots);
-    m->tensors.resize(h.n_tensors);
-    m->ops.resize(h.n_ops);
-    if (h.n_slots) memcpy(m->slots.data(), base + h.slots_off, h.n_slots * sizeof(SlotRec));
-    if (h.n_tensors) memcpy(m->tensors.data(), base + h.tensors_off, h.n_tensors * sizeof(TensorRec));
-    if (h.n_ops) memcpy(m->ops.data(), base + h.ops_off, h.n_ops * sizeof(OpRec));
-
+    if (int rc = parse_blob(blob, nbytes, m->hdr, m->slots, m->tensors, m->ops)) {
+        delete m;
+        return rc;
+    }
+    const BlobHeader& h = m->hdr;
+    const char* base = (const char*)blob;
     size_t lo = nbytes, hi = 0;
-    for (const TensorRec& t : m->tensors) {
-        if (!in_range(t.offset, t.nbytes) || (t.offset & 255)) {
-            delete m;
-            return fail(BN_ERR_FORMAT, "tensor payload out of range or misaligned");
-        }
+    for (const TensorRec& t : m->tensors)
         if (t.nbytes) {
             lo = t.offset < lo ? (size_t)t.offset : lo;
             hi = t.offset + t.nbytes > hi ? (size_t)(t.offset + t.nbytes) : hi;
         }
-    }
-    for (const OpRec& o : m->ops) {
-        for (int k = 0; k < BN_OP_NT; ++k)
-            if (o.t[k] >= (int)h.n_tensors) {
-                delete m;
-                return fail(BN_ERR_FORMAT, "operator references tensor %d of %u", o.t[k], h.n_tensors);
-            }
-        const int ids[3] = {o.in0, o.in1, o.out};
-        for (int id : ids)
-            if (id >= (int)h.n_slots) {
-                delete m;
-                return fail(BN_ERR_FORMAT, "operator references slot %d of %u", id, h.n_slots);
-            }
-    }
     // INT8 blocks: can every requantisation of the operator take the branch-free right-shift form?
     m->rq_right.assign(h.n_ops, 0);
-    if (const char* e = getenv("BN_I8_STRIP")) m->use_strip = e[0] != '0';
     for (const OpRec& o : m->ops)
         if (o.in0 == BN_SLOT_INPUT) m->spec_tiled_ok = o.kind == BN_OP_I8_DWPW && o.p[36] && o.p[30] && o.p[1] % 64 == 0;
-    if (getenv("BN_STFT_ROWMAJOR")) m->spec_tiled_ok = false;  // A/B: keep the reference layout inside bn_infer_audio
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         auto all_right = [&](int t_mult, int t_shift) {
@@ -485,6 +538,7 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             const TensorRec& ts = m->tensors[t_shift];
             const int32_t* pm = (const int32_t*)(base + tm.offset);
             const int32_t* ps = (const int32_t*)(base + ts.offset);
+            if ((tm.nbytes | ts.nbytes) & 3) return false;
             for (size_t i = 0; i < tm.nbytes / 4; ++i)
                 if (pm[i] < 0) return false;
             for (size_t i = 0; i < ts.nbytes / 4; ++i)
@@ -681,12 +735,14 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
         return BN_OK;
     }
     // un-normalised magnitudes + per-chunk min/max; the plan's first operator normalises while loading
+    bool tiled = false;
     {
         ProfScope prof(m, (int)m->ops.size(), (hipStream_t)stream);
-        if (int rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, m->spec_tiled_ok))
+        tiled = m->spec_tiled_ok && !bn::g_opt.stft_rowmajor;  // option stft_rowmajor: keep the reference layout (A/B)
+        if (int rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, tiled))
             return rc;
     }
-    m->spec_tiled_now = m->spec_tiled_ok;
+    m->spec_tiled_now = tiled;
     const int rc = bn_forward(m, m->d_spec, m->d_minmax, B, d_scores, d_logits, stream);
     m->spec_tiled_now = false;
     return rc;
@@ -788,6 +844,17 @@ int bn_debug_op_output(bn_model* m, int op_index, int B, void* d_dst, size_t dst
     return BN_OK;
 }
 
+int bn_debug_requant(bn_ctx* ctx, const int32_t* d_x, const int32_t* d_mult, const int32_t* d_shift, int n, int mode, int zero_point,
+                     int32_t* d_out, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (n < 0 || mode < 0 || mode > 3) return fail(BN_ERR_ARG, "bad n / mode");
+    if (n == 0) return BN_OK;
+    if (!d_x || !d_mult || !d_shift || !d_out) return fail(BN_ERR_ARG, "null device pointer");
+    bn::launch_debug_requant(d_x, d_mult, d_shift, n, mode, zero_point, d_out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
 int bn_profile_enable(bn_model* m, int enable) {
     if (!m) return fail(BN_ERR_ARG, "null model");
     m->profiling = enable != 0;
@@ -820,6 +887,26 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
     }
     m->ev_used.clear();
     return BN_OK;
+}
+
+int bn_set_option(const char* name, int value) {
+    if (!name) return fail(BN_ERR_ARG, "null option name");
+    for (const OptName& e : kOptions)
+        if (strcmp(name, e.name) == 0) {
+            bn::g_opt.*(e.field) = value;
+            return BN_OK;
+        }
+    return fail(BN_ERR_ARG, "unknown option '%s'", name);
+}
+
+int bn_get_option(const char* name, int* value) {
+    if (!name || !value) return fail(BN_ERR_ARG, "null argument");
+    for (const OptName& e : kOptions)
+        if (strcmp(name, e.name) == 0) {
+            *value = bn::g_opt.*(e.field);
+            return BN_OK;
+        }
+    return fail(BN_ERR_ARG, "unknown option '%s'", name);
 }
 
 const char* bn_kernel_names(void) {

@@ -635,15 +635,14 @@ void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, i
                       int dw_act, int pw_act, const float* stem_w, const float* stem_b, const float* dw_w, const float* dw_b,
                       const float* pw_w, const float* pw_b, const float* minmax, const float* wsum, const float* magp, int mag,
                       hipStream_t s) {
-    const char* strip_env = getenv("BN_F32_STRIP");
-    if ((!strip_env || atoi(strip_env)) && f32_front_strip_supported(H0, W0, C, N, OH, OW)) {
+    if (g_opt.f32_strip && f32_front_strip_supported(H0, W0, C, N, OH, OW)) {
         launch_f32_front_strip(F32FrontStripArgs{fe, y, stem_w, stem_b, dw_w, dw_b, pw_w, pw_b, minmax, wsum, magp, B, H0, W0, OH, OW, 0,
                                                  stem_act, dw_act, pw_act, mag}, s);
         return;
     }
     FrontArgs a{fe, y, stem_w, stem_b, dw_w, dw_b, pw_w, pw_b, B, H0, W0, H0, W0 / 2, C, N, OH, OW, stem_act, dw_act, pw_act,
                 minmax, wsum, magp, mag, 1};
-    static const int forced = getenv("BN_FRONT_TPW") ? atoi(getenv("BN_FRONT_TPW")) : 0;
+    const int forced = g_opt.front_tpw;
     const int tiles_x = OW / 8;
     int tpw = forced > 0 ? forced : 8;
     while (tiles_x % tpw) --tpw;
@@ -665,9 +664,8 @@ static void launch_wave(const DwPwArgs& a, hipStream_t s) {
 
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s) {
     const int ct_total = a.Cout / 16;
-    static const int wave_variant = getenv("BN_WAVE_DWPW") ? atoi(getenv("BN_WAVE_DWPW")) : 1;
-    const char* strip_env = getenv("BN_F32_STRIP");  // read per launch: the tests switch it inside one process
-    const int strip_variant = strip_env ? atoi(strip_env) : 1;
+    const int wave_variant = g_opt.wave_dwpw;
+    const int strip_variant = g_opt.f32_strip;  // (tests switch it inside one process through bn_set_option)
     if (strip_variant && f32_strip_supported(a)) return launch_f32_strip(a, s);
     if (wave_variant && a.has_dw && a.NB == 1 && a.Cin <= 64 && a.Cout <= 64 && 64 % (a.Cin / 4) == 0 && !a.gate) {
         switch (ct_total) {

@@ -533,8 +533,7 @@ bool f32_strip_supported(const DwPwArgs& a) {
 bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW, int pt, int pl,
                           const float* w, const float* bias, hipStream_t s) {
     if (sh != sw || (sh != 1 && sh != 2) || C % 4 || (long)H * W * C * 4 >= 0x7fff0000L || (long)OH * OW * C * 4 >= 0x7fff0000L) return false;
-    if (const char* e = getenv("BN_F32_STRIP"))
-        if (!atoi(e)) return false;
+    if (!g_opt.f32_strip) return false;
     int cq = 16;
     while ((C / 4) % cq) cq >>= 1;
     DwStreamArgs a{x, y, w, bias, B, H, W, C, OH, OW, 0, pt, pl, act, cq};
@@ -543,10 +542,7 @@ bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, 
     int th = OH;
     while (th > 16) th = (th + 1) / 2;
     while (th > 4 && per_row_block * ((OH + th - 1) / th) < 8192) th = (th + 1) / 2;
-    if (const char* e = getenv("BN_F32_STRIP_TH")) {
-        const int v = atoi(e);
-        if (v >= 1) th = v < OH ? v : OH;
-    }
+    if (const int v = g_opt.f32_strip_th; v >= 1) th = v < OH ? v : OH;
     a.TH = th;
     const long waves = per_row_block * ((OH + th - 1) / th);
     if (sh == 1)
@@ -564,13 +560,9 @@ void launch_f32_front_strip(F32FrontStripArgs a, hipStream_t s) {
     int th = a.OH;
     while (th > 16) th = (th + 1) / 2;
     while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 4096) th = (th + 1) / 2;
-    if (const char* e = getenv("BN_F32_STRIP_TH")) {
-        const int v = atoi(e);
-        if (v >= 1) th = v < a.OH ? v : a.OH;
-    }
-    const char* st = getenv("BN_F32_FRONT_STAGED");
-    const bool staged = !(st && !atoi(st)) && a.OW / 16 <= 16 && a.W0 % 4 == 0;
-    if (staged && !getenv("BN_F32_STRIP_TH")) th = a.OH < 8 ? a.OH : 8;  // 19 input rows per block (+19 % halo), 21 KB of LDS
+    if (const int v = g_opt.f32_strip_th; v >= 1) th = v < a.OH ? v : a.OH;
+    const bool staged = g_opt.f32_front_staged && a.OW / 16 <= 16 && a.W0 % 4 == 0;
+    if (staged && g_opt.f32_strip_th < 1) th = a.OH < 8 ? a.OH : 8;  // 19 input rows per block (+19 % halo), 21 KB of LDS
     a.TH = th;
     const long blocks = (long)a.B * ((a.OH + th - 1) / th);
     if (staged) {
@@ -591,10 +583,7 @@ void launch_f32_strip(DwPwArgs a, hipStream_t s) {
     int th = a.OH;
     while (th > 16) th = (th + 1) / 2;
     while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 4096) th = (th + 1) / 2;
-    if (const char* e = getenv("BN_F32_STRIP_TH")) {  // tests: force the rows per strip
-        const int v = atoi(e);
-        if (v >= 1) th = v < a.OH ? v : a.OH;
-    }
+    if (const int v = g_opt.f32_strip_th; v >= 1) th = v < a.OH ? v : a.OH;  // tests: force the rows per strip
     a.TH = th;
     const bool res = a.res != nullptr;
 #define BN_FSTRIP(NW, CO, ST, RS) \

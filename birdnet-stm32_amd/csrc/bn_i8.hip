@@ -350,4 +350,29 @@ void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C,
                        s_out, lut, total);
 }
 
+// Test hook (bn_debug_requant): the requantisation forms of bn_requant.h and of the strip kernels, one element per thread.
+// mode 0: mbqm (what the generic kernels call), 1: mbqm_ref (literal gemmlowp definitions), 2: mbqm_right (branch-free right-shift form),
+// 3: the strip kernels' folded form ((v + c1 + (v >> 31)) >> e, c1 = 2^(e-1) + (zp << e)) minus zp
+__global__ void debug_requant_kernel(const int32_t* x, const int32_t* mult, const int32_t* shift, int n, int mode, int zp, int32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = x[i], m = mult[i];
+    const int sh = shift[i];
+    int32_t r;
+    if (mode == 0) r = mbqm(v, m, sh);
+    else if (mode == 1) r = mbqm_ref(v, m, sh);
+    else if (mode == 2) r = mbqm_right(v, m, sh);
+    else {
+        const int e = -sh;
+        const int32_t c1 = (1 << (e - 1)) + (zp << e);
+        const int32_t hv = srdhm_pos(v, m);
+        r = ((hv + c1 + (hv >> 31)) >> e) - zp;
+    }
+    out[i] = r;
+}
+
+void launch_debug_requant(const int32_t* x, const int32_t* mult, const int32_t* shift, int n, int mode, int zp, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(debug_requant_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, mult, shift, n, mode, zp, out);
+}
+
 }  // namespace bn

@@ -611,7 +611,7 @@ bool i8_mel_mfma_supported(const DwPw8Args& a) {
 bool i8_dwpw_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 16 == 0 && Cin >= 4; }
 
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
-    static const bool mel_kernel = !(getenv("BN_I8_MEL_GENERIC") && atoi(getenv("BN_I8_MEL_GENERIC")));
+    const bool mel_kernel = !g_opt.i8_mel_generic;
     if (a.qx || (mel_kernel && i8_mel_mfma_supported(a))) {  // (the packer only fuses QUANTIZE for shapes this kernel takes)
         if (a.qx)
             hipLaunchKernelGGL(i8_mel_mfma_kernel<true>, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);

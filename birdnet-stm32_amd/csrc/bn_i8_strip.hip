@@ -585,10 +585,7 @@ void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s)
     int th = a.OH;
     if (a.OW != 8) {
         while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 16384) th = (th + 1) / 2;
-        if (const char* e = getenv("BN_I8_STRIP_TH")) {  // tests: force the rows per wave (any value >= 1)
-            const int v = atoi(e);
-            if (v >= 1) th = v < a.OH ? v : a.OH;
-        }
+        if (const int v = g_opt.i8_strip_th; v >= 1) th = v < a.OH ? v : a.OH;  // tests: force the rows per wave
     }  // 8-wide maps: the whole (even) height, half per lane group
     a.TH = th;
 #define BN_STRIP(CW, NW, CO, ST, AD) \
@@ -622,10 +619,7 @@ bool i8_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW) {
 void launch_i8_front_strip(FrontStrip8Args a, hipStream_t s) {
     int th = a.OH;
     while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 16384) th = (th + 1) / 2;
-    if (const char* e = getenv("BN_I8_STRIP_TH")) {
-        const int v = atoi(e);
-        if (v >= 1) th = v < a.OH ? v : a.OH;
-    }
+    if (const int v = g_opt.i8_strip_th; v >= 1) th = v < a.OH ? v : a.OH;
     a.TH = th;
     const long waves = (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th);
     hipLaunchKernelGGL(i8_front_strip_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);

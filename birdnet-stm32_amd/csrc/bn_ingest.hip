@@ -437,7 +437,7 @@ static bool decimate_case(int up, int down, int hpp) { return up == 1 && (down =
 // outputs per workgroup: as many as keep the input tile + filter within ~40 KB of LDS (4 workgroups per CU)
 int ingest_resample_block(int up, int down, int hpp) {
     if (hpp == 0) return 1024;  // same rate: one quad per thread, parallelism comes from the grid
-    if (const char* e = getenv("BN_INGEST_BLK")) return atoi(e);
+    if (g_opt.ingest_blk > 0) return g_opt.ingest_blk;
     for (int blk = 4096; blk > 1024; blk >>= 1)
         if (ingest_resample_lds_bytes(up, down, hpp, blk) <= 40 * 1024) return blk;
     return 1024;
@@ -461,7 +461,7 @@ static void launch_resample_kernels(const ResampleArgs& a, int fmt, int n_files,
 #undef BN_DECIMATE
         return;
     }
-    if (up > 1 && up <= 256 && (hpp == 21 || hpp == 29 || hpp == 39) && !getenv("BN_INGEST_GENERIC")) {
+    if (up > 1 && up <= 256 && (hpp == 21 || hpp == 29 || hpp == 39) && !g_opt.ingest_generic) {
 #define BN_PHASE(F)                                                                                                   \
     if (hpp == 21) hipLaunchKernelGGL((ingest_resample_phase_kernel<F, 21>), grid, dim3(256), smem, s, a, taps, mono);     \
     else if (hpp == 29) hipLaunchKernelGGL((ingest_resample_phase_kernel<F, 29>), grid, dim3(256), smem, s, a, taps, mono); \

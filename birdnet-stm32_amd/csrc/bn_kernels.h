@@ -3,7 +3,35 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+#include <vector>
+
+#include "bn_blob.h"
+
 namespace bn {
+
+// Run-time switches of the launchers (A/B runs, tests).  Process-wide, set through the C ABI (bn_set_option); the BN_* environment
+// variables of the same names seed them ONCE when the library is loaded — nothing on a launch path reads the environment.
+struct Options {
+    int f32_strip = 1;         // float32 row-streaming strip kernels (0: tile kernels everywhere)
+    int f32_strip_th = 0;      // force the rows per strip (0: the launcher's choice)
+    int f32_front_staged = 1;  // LDS-staged form of the float32 front strip kernel
+    int front_tpw = 0;         // tiles per workgroup of the float32 front tile kernel (0: auto)
+    int wave_dwpw = 1;         // wave-autonomous variant of the small float32 fused block
+    int i8_strip = 1;          // INT8 strip kernels (0: generic fused block everywhere)
+    int i8_strip_th = 0;       // force the rows per wave of the INT8 strip kernels (0: auto)
+    int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
+    int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
+    int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
+    int stft_tpw = 0;          // STFT tiles per workgroup (0: auto)
+    int ingest_blk = 0;        // outputs per workgroup of the resampler (0: auto)
+    int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
+};
+extern Options g_opt;
+
+// Load-time validation of a packed plan (bn_plan_check.hip): every operator's geometry against the slot and tensor sizes.
+bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const std::vector<TensorRec>& tensors,
+                const std::vector<OpRec>& ops, std::string& err);
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Tiles that share input rows
 // (3x3 halos, the residual of the same positions) should meet in ONE L2, so the linear tile index is permuted: XCD k walks
@@ -135,6 +163,8 @@ void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_o
                   const int32_t* bias, const int32_t* mult, const int32_t* shift, hipStream_t s);
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,
                     float s_out, const int8_t* lut, hipStream_t s);
+
+void launch_debug_requant(const int32_t* x, const int32_t* mult, const int32_t* shift, int n, int mode, int zp, int32_t* out, hipStream_t s);
 
 // Fused INT8 depthwise 3x3 -> pointwise 1x1 block on the int8 matrix cores (bn_i8_fused.hip).
 // has_dw = 0: plain 1x1 convolution; transposed = 1: output [chunk][n][position] with an optional per-channel table

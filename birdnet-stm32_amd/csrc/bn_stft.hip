@@ -349,7 +349,7 @@ void launch_minmax_init(float* minmax, int B, hipStream_t s) {
 // tiles a workgroup walks; one is fastest on MI355X (a loop that prefetches the next tile's samples needs > 170 VGPRs and
 // drops the kernel to 2 waves per SIMD; measured 0.27 ms against 0.20 ms per 1024 chunks)
 static int stft_tiles_per_wg(int B, int n_tiles) {
-    static const int forced = getenv("BN_STFT_TPW") ? atoi(getenv("BN_STFT_TPW")) : 0;
+    const int forced = g_opt.stft_tpw;
     (void)B;
     (void)n_tiles;
     return forced > 0 ? forced : 1;

@@ -98,6 +98,11 @@ BN_API void bn_ctx_destroy(bn_ctx* ctx);
  * .tflite file), copy its constants to HBM and allocate the activation workspace.
  * The blob may be freed by the caller after the call returns. */
 BN_API int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out);
+/* Validate a packed blob without loading it (host only, needs no device): the checks bn_model_load runs before it allocates —
+ * tables and payloads inside the blob, operator references in range, every operator's geometry against the slot and tensor
+ * sizes it addresses.  BN_ERR_FORMAT + bn_last_error() on the first violation.  (Reference counterpart: the flatbuffer
+ * verification inside tf.lite.Interpreter(model_path=...), birdnet_stm32/models/runners.py:57.) */
+BN_API int bn_blob_check(const void* blob, size_t nbytes);
 BN_API void bn_model_free(bn_model* model);
 BN_API int bn_model_get_info(const bn_model* model, bn_model_info* out);
 
@@ -217,6 +222,15 @@ BN_API int bn_mel_spectrogram(bn_ctx* ctx, const float* d_audio, int B, int T, i
 BN_API int bn_debug_op_output(bn_model* model, int op_index, int B, void* d_dst, size_t dst_bytes,
                        size_t* bytes_per_chunk, void* stream);
 
+/* Test hook: the device's fixed-point requantisation, element-wise on n (accumulator, multiplier, shift) triples — TFLite's
+ * MultiplyByQuantizedMultiplier as every INT8 kernel here computes it (csrc/bn_requant.h).  mode 0: the form the generic kernels
+ * call; 1: the literal gemmlowp definitions (SaturatingRoundingDoublingHighMul + RoundingDivideByPOT); 2: the branch-free
+ * right-shift form (needs multiplier >= 0, shift < 0); 3: the strip kernels' form with rounding offset and zero_point folded into
+ * one addend (same preconditions, shift >= -22), zero point subtracted again.  (Reference: the int8 kernels inside
+ * tf.lite.Interpreter.invoke, birdnet_stm32/models/runners.py:93.) */
+BN_API int bn_debug_requant(bn_ctx* ctx, const int32_t* d_x, const int32_t* d_mult, const int32_t* d_shift, int n, int mode,
+                     int zero_point, int32_t* d_out, void* stream);
+
 /* Per-operator timing with HIP events recorded on the launch stream.  While enabled, every plan
  * operator of bn_forward / bn_infer_audio is bracketed by an event pair (index n_ops = the STFT
  * stage of bn_infer_audio).  bn_profile_collect waits for the recorded events, adds the elapsed
@@ -227,6 +241,15 @@ BN_API int bn_profile_enable(bn_model* model, int enable);
  * ~6 % of a 1.5 ms step; bracketing only the kernel under study keeps the timed region undisturbed. */
 BN_API int bn_profile_only(bn_model* model, int op_index);
 BN_API int bn_profile_collect(bn_model* model, double* total_ms, int64_t* launches, int n);
+
+/* Run-time switches of the kernel launchers, for A/B measurements and tests (process-wide; the defaults are the production
+ * choices).  Names: "f32_strip", "f32_strip_th", "f32_front_staged", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th",
+ * "i8_tail", "i8_mel_generic", "stft_rowmajor", "stft_tpw", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
+ * what each selects).  An environment variable BN_<NAME IN CAPITALS> seeds the value once when the library is loaded; no
+ * launch reads the environment.  The reference has no counterpart (tf.lite.Interpreter's delegates / num_threads arguments,
+ * birdnet_stm32/models/runners.py:57, are the closest thing).  Unknown name: BN_ERR_ARG. */
+BN_API int bn_set_option(const char* name, int value);
+BN_API int bn_get_option(const char* name, int* value);
 
 /* Names of the HIP kernels a forward pass launches, '\n'-separated (for profiling tools). */
 BN_API const char* bn_kernel_names(void);

@@ -140,7 +140,7 @@ def test_f32_infer_audio_end_to_end(torch_mod, audio24, oracle_specs):
     runner.close()
 
 
-def test_f32_strip_kernel_matches_tile_kernels(torch_mod, oracle_specs, monkeypatch):
+def test_f32_strip_kernel_matches_tile_kernels(torch_mod, oracle_specs):
     """The row-streaming float32 strip kernel (stage 1-3 blocks) against the tile kernels it replaces: per layer within
     float32 round-off of each other (the FMA order differs), for strip heights that move the strip borders around."""
     from birdnet_stm32.models import _pack as pk
@@ -152,35 +152,29 @@ def test_f32_strip_kernel_matches_tile_kernels(torch_mod, oracle_specs, monkeypa
     ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.F32_DWPW and op.p[2] <= 128 and op.p[10] <= 128 and op.p[7] % 16 == 0]
     ops += [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.F32_FRONT and op.p[pk.OP_PATH] == pk.PATH_INPUT]  # front block
     assert len(ops) == 9
-    monkeypatch.setenv("BN_F32_STRIP", "0")
-    want_scores = runner.predict(x)
-    want = {oi: runner.op_output(oi, B) for oi in ops}
-    monkeypatch.setenv("BN_F32_STRIP", "1")
+    from birdnet_stm32 import _hip
+
+    with _hip.options(f32_strip=0):
+        want_scores = runner.predict(x)
+        want = {oi: runner.op_output(oi, B) for oi in ops}
     # repeated: the store-data hazard these kernels guard against (bn_f32_strip.hip: store16) showed up in 1 launch of 50-100
-    for th in ("", "1", "3", "5", "7", "64") * 12:
-        if th:
-            monkeypatch.setenv("BN_F32_STRIP_TH", th)
-        else:
-            monkeypatch.delenv("BN_F32_STRIP_TH", raising=False)
-        got_scores = runner.predict(x)
-        for oi in ops:
-            a = runner.op_output(oi, B)
-            err = np.abs(a - want[oi]).max() / np.abs(want[oi]).max()
-            assert err < 1e-5, f"rows per strip {th or 'auto'}: layer {runner.plan.ops[oi].name}: relative-to-peak difference {err:.3e}"
-        assert np.abs(got_scores - want_scores).max() < 5e-6
+    for th in (0, 1, 3, 5, 7, 64) * 12:
+        with _hip.options(f32_strip=1, f32_strip_th=th):
+            got_scores = runner.predict(x)
+            for oi in ops:
+                a = runner.op_output(oi, B)
+                err = np.abs(a - want[oi]).max() / np.abs(want[oi]).max()
+                assert err < 1e-5, f"rows per strip {th or 'auto'}: layer {runner.plan.ops[oi].name}: relative-to-peak difference {err:.3e}"
+            assert np.abs(got_scores - want_scores).max() < 5e-6
     # the audio path: the front block finalises the raw mel energies while loading (its own operator variant)
     import torch
 
     audio = torch.from_numpy(np.tile(synth_chunks(8), (5, 1))).cuda()
-    monkeypatch.setenv("BN_F32_STRIP", "0")
-    want_audio = runner.infer_audio_device(audio).cpu().numpy()
-    monkeypatch.setenv("BN_F32_STRIP", "1")
-    for th in ("", "1", "5", "64") * 3:
-        if th:
-            monkeypatch.setenv("BN_F32_STRIP_TH", th)
-        else:
-            monkeypatch.delenv("BN_F32_STRIP_TH", raising=False)
-        assert np.abs(runner.infer_audio_device(audio).cpu().numpy() - want_audio).max() < 5e-6
+    with _hip.options(f32_strip=0):
+        want_audio = runner.infer_audio_device(audio).cpu().numpy()
+    for th in (0, 1, 5, 64) * 3:
+        with _hip.options(f32_strip=1, f32_strip_th=th):
+            assert np.abs(runner.infer_audio_device(audio).cpu().numpy() - want_audio).max() < 5e-6
     runner.close()
 
 
@@ -213,7 +207,7 @@ def test_i8_graph_bit_exact_per_tensor(torch_mod, oracle_specs, fuse):
     runner.close()
 
 
-def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypatch):
+def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs):
     """The wave-autonomous strip kernels (front block, stage 1-3 blocks) against the generic fused kernels: every tensor bit for bit, for
     rows-per-wave values that put the strip borders everywhere (1, 3, 5, 7 rows, whole map), and a batch large enough for
     the launcher's own choice."""
@@ -223,34 +217,28 @@ def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypa
     x = np.tile(oracle_specs[..., None], (17, 1, 1, 1))[:260]
     x = np.ascontiguousarray(x[np.random.default_rng(3).permutation(x.shape[0])])
     B = x.shape[0]
-    monkeypatch.setenv("BN_I8_STRIP", "0")
+    from birdnet_stm32 import _hip
+
     runner = load_model_runner(TFLITE_PATH, max_batch=B, keep_all=True)
-    want_scores = runner.predict(x)
     strip_ops = [oi for oi, op in enumerate(runner.plan.ops) if (op.kind == pk.I8_DWPW and op.p[35]) or (op.kind == pk.I8_FRONT and op.p[16])]
     assert len(strip_ops) == 11
-    want = {oi: runner.op_output(oi, B) for oi in strip_ops}
-    runner.close()
-    monkeypatch.setenv("BN_I8_STRIP", "1")
-    runner = load_model_runner(TFLITE_PATH, max_batch=B, keep_all=True)
-    for th in ("", "1", "3", "5", "7", "64") * 4:
-        if th:
-            monkeypatch.setenv("BN_I8_STRIP_TH", th)
-        else:
-            monkeypatch.delenv("BN_I8_STRIP_TH", raising=False)
-        got_scores = runner.predict(x)
-        for oi in strip_ops:
-            a = runner.op_output(oi, B)
-            bad = int((a != want[oi]).sum())
-            assert bad == 0, f"rows per wave {th or 'auto'}: tensor {runner.plan.ops[oi].name}: {bad} of {a.size} values differ, first at {np.argwhere(a != want[oi])[:3].tolist()}"
-        assert np.array_equal(got_scores, want_scores)
+    with _hip.options(i8_strip=0):
+        want_scores = runner.predict(x)
+        want = {oi: runner.op_output(oi, B) for oi in strip_ops}
+    for th in (0, 1, 3, 5, 7, 64) * 4:
+        with _hip.options(i8_strip=1, i8_strip_th=th):
+            got_scores = runner.predict(x)
+            for oi in strip_ops:
+                a = runner.op_output(oi, B)
+                bad = int((a != want[oi]).sum())
+                assert bad == 0, f"rows per wave {th or 'auto'}: tensor {runner.plan.ops[oi].name}: {bad} of {a.size} values differ, first at {np.argwhere(a != want[oi])[:3].tolist()}"
+            assert np.array_equal(got_scores, want_scores)
     # odd batch sizes: workgroups of the ADD kernels take 8 / NW strips, the spare ones repeat the last chunk
-    monkeypatch.delenv("BN_I8_STRIP_TH", raising=False)
     for nb in (1, 3, 37):
         assert np.array_equal(runner.predict(x[:nb]), want_scores[:nb])
     runner.close()
     # the production plan (slots recycled, QUANTIZE fused into the mel mixer's load with the three-instruction exact division) gives
     # the same scores bit for bit, on the test spectrograms and on random ones that exercise the rounding of the quantiser
-    monkeypatch.delenv("BN_I8_STRIP_TH", raising=False)
     prod = load_model_runner(TFLITE_PATH, max_batch=B)
     assert prod.plan.ops[0].kind == pk.I8_DWPW and prod.plan.ops[0].p[36] == 1
     assert np.array_equal(prod.predict(x), want_scores)
@@ -261,17 +249,15 @@ def test_i8_strip_kernel_matches_generic_block(torch_mod, oracle_specs, monkeypa
     prod.close()
     dbg.close()
     # from audio, the spectrogram between the STFT and the fused QUANTIZE is tile-major ([W/16][257][16], the layout the STFT writes
-    # fastest); BN_STFT_ROWMAJOR keeps the reference layout: identical scores
+    # fastest); option stft_rowmajor keeps the reference layout: identical scores
     import torch
 
     audio = torch.from_numpy(np.tile(synth_chunks(8), (9, 1))[:70]).cuda()
     tiled = load_model_runner(TFLITE_PATH, max_batch=70)
     s_tiled = tiled.infer_audio_device(audio).cpu().numpy()
+    with _hip.options(stft_rowmajor=1):
+        s_row = tiled.infer_audio_device(audio).cpu().numpy()
     tiled.close()
-    monkeypatch.setenv("BN_STFT_ROWMAJOR", "1")
-    rowmajor = load_model_runner(TFLITE_PATH, max_batch=70)
-    s_row = rowmajor.infer_audio_device(audio).cpu().numpy()
-    rowmajor.close()
     assert np.array_equal(s_tiled, s_row)
 
 
@@ -403,7 +389,10 @@ def test_evaluate_device_pipeline_matches_reference_loop(torch_mod, tmp_path):
     assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
     assert m_dev["total_chunks"] == m_ref["total_chunks"] == 12 + 4 * 3
     np.testing.assert_allclose(ys_dev, ys_ref, atol=1.5 / 256)  # host-normalised float spectrograms vs normalise-at-load: <= 1 LSB of the int8 sigmoid
-    assert (ys_dev.argmax(axis=1) == ys_ref.argmax(axis=1)).mean() >= 0.9
+    # top-1 per file: identical wherever the reference loop's best pooled score leads by more than the 1-LSB tolerance on both sides
+    top = np.sort(ys_ref, axis=1)
+    clear = (top[:, -1] - top[:, -2]) > 3.0 / 256
+    assert (ys_dev.argmax(axis=1) == ys_ref.argmax(axis=1))[clear].all()
     for k in ("latency_mean_ms", "latency_p99_ms"):
         assert m_dev[k] > 0 and m_ref[k] > 0
     runner.close()

@@ -1,0 +1,303 @@
+"""GPU parity sweeps at BASELINE sizes and the fixed-point primitives pinned on the device.
+
+* INT8 at the runner boundary: 4096 spectrograms (BASELINE configs[2]'s batch) through the production plan, bit for bit against the C
+  port of the TFLite reference kernels (``oracle/c/oracle_i8.c``, itself identical per tensor to ``oracle/int8_graph.py``).
+* INT8 from audio: 2048 chunks; top-1 of the pre-sigmoid outputs against the oracle fed with the float64 oracle STFT, the number of
+  quantised input bytes the float32 GPU STFT flips, and the bound on what those flips do to the outputs.
+* ``bn_requant.h`` (every requantisation form the kernels use) against the literal gemmlowp definitions on edge cases.
+* float32 row-streaming depthwise kernel (``f32_dw_stream_kernel``) against the baseline depthwise kernel at production batch sizes.
+* BASELINE configs[4] (raw + PCEN + alpha 1.5 IR/SE) at its full batch through size-independent properties.
+
+All comparisons go through the C ABI (ctypes -> libbirdnet_hip.so).
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import KERAS_PATH, TFLITE_PATH, cosine, synth_chunks
+
+pytestmark = pytest.mark.gpu
+
+I32_MIN, I32_MAX = -(1 << 31), (1 << 31) - 1
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch
+
+
+# ----------------------------------------------------------------------------- gemmlowp definitions, literally (Python integers)
+def srdhm_def(a: int, b: int) -> int:
+    """SaturatingRoundingDoublingHighMul (gemmlowp fixedpoint.h): saturate only for INT32_MIN x INT32_MIN, nudge by +-2^30, divide by
+    2^31 truncating toward zero."""
+    if a == b == I32_MIN:
+        return I32_MAX
+    ab = a * b
+    nudge = (1 << 30) if ab >= 0 else 1 - (1 << 30)
+    v = ab + nudge
+    return v // (1 << 31) if v >= 0 else -((-v) // (1 << 31))
+
+
+def rdivpot_def(x: int, e: int) -> int:
+    """RoundingDivideByPOT: arithmetic shift, ties away from zero."""
+    mask = (1 << e) - 1
+    rem = x & mask
+    thr = (mask >> 1) + (1 if x < 0 else 0)
+    return (x >> e) + (1 if rem > thr else 0)
+
+
+def wrap32(v: int) -> int:
+    return ((v + (1 << 31)) % (1 << 32)) - (1 << 31)
+
+
+def mbqm_def(x: int, m: int, shift: int) -> int:
+    left, right = max(shift, 0), max(-shift, 0)
+    return rdivpot_def(srdhm_def(wrap32(x * (1 << left)), m), right)
+
+
+def _requant_cases():
+    rng = np.random.default_rng(5)
+    xs = [0, 1, -1, 2, -2, 3, -3, (1 << 30) - 1, -(1 << 30) + 1, 1 << 29, -(1 << 29), 12345677, -12345677, 255 * 127 * 256, -255 * 127 * 256]
+    ms = [1 << 30, (1 << 31) - 1, (1 << 30) + 1, 1518500250, 1073741825, 2000000000, 0]
+    shs = [-1, -2, -3, -7, -8, -12, -20, -22]
+    cases = [(x, m, s) for x in xs for m in ms for s in shs]
+    # negative-half ties of the rounding shift: srdhm result = -(2k + 1) * 2^(e-1)
+    for e in (1, 2, 5, 9):
+        for k in (0, 1, 7):
+            v = -(2 * k + 1) * (1 << (e - 1))
+            cases.append((2 * v, 1 << 30, -e))  # srdhm(2v, 2^30) = v exactly
+            cases.append((-2 * v, 1 << 30, -e))
+    x = rng.integers(-(1 << 30) + 1, 1 << 30, size=20000)
+    m = rng.integers(1 << 30, 1 << 31, size=20000)
+    s = -rng.integers(1, 23, size=20000)
+    cases += list(zip(x.tolist(), m.tolist(), s.tolist()))
+    return cases
+
+
+def test_requant_forms_match_gemmlowp_definitions(torch_mod):
+    """bn_requant.h on the device (through bn_debug_requant) against SaturatingRoundingDoublingHighMul + RoundingDivideByPOT written
+    out with Python integers: the general form (incl. left shifts, negative multipliers, INT32_MIN x INT32_MIN saturation, shift 0 and
+    shifts up to 31), the branch-free right-shift form and the strip kernels' folded-addend form (with zero points at both ends)."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+
+    ctx = _hip.Context(0, 4)
+
+    def run(cases, mode, zp=0):
+        x, m, s = (torch.tensor([c[i] for c in cases], dtype=torch.int32, device="cuda") for i in range(3))
+        out = torch.empty_like(x)
+        _hip.check(ctx.lib.bn_debug_requant(ctx.handle, x.data_ptr(), m.data_ptr(), s.data_ptr(), len(cases), mode, zp, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        return out.cpu().numpy().astype(np.int64)
+
+    right = _requant_cases()
+    want = np.array([mbqm_def(*c) for c in right], np.int64)
+    for mode in (0, 1, 2):
+        got = run(right, mode)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"mode {mode}: {bad.size} mismatches, first {right[bad[0]]}: got {got[bad[0]]}, want {want[bad[0]]}"
+    for zp in (-128, -34, 0, 73, 127, 255):  # + 128 of the ADD blocks included
+        got = run(right, 3, zp)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"strip form, zp {zp}: first mismatch {right[bad[0]]}: got {got[bad[0]]}, want {want[bad[0]]}"
+    # the general forms outside the fast path's domain
+    wide = [(I32_MIN, I32_MIN, 0), (I32_MIN, I32_MIN, -1), (I32_MIN, I32_MAX, 0), (I32_MAX, I32_MAX, 0), (I32_MAX, I32_MIN + 1, -3),
+            (I32_MIN, 1 << 30, -31), (I32_MAX, (1 << 31) - 1, -31), (-1, 1 << 30, -31), (5, 1 << 30, 0), (-5, 1 << 30, 0),
+            (1000, 1 << 30, 3), (-1000, 1 << 30, 3), (1 << 26, 1518500250, 4), (-(1 << 26), 1518500250, 4), (77, -(1 << 30), -2), (-77, -(1 << 30), -2),
+            (123456, -1518500250, -5), (-123456, -1518500250, 2), (0, 0, 0), (99, 0, -4)]
+    want = np.array([mbqm_def(*c) for c in wide], np.int64)
+    for mode in (0, 1):
+        got = run(wide, mode)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"mode {mode}: first mismatch {wide[bad[0]]}: got {got[bad[0]]}, want {want[bad[0]]}"
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------- INT8 sweeps
+def _c_int8_path():
+    from birdnet_stm32.models._tflite_reader import load_tflite
+    from oracle import cport
+
+    import os
+
+    if not (os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB)):
+        pytest.skip("oracle/_build is missing: run __graft_entry__.build()")
+    return cport.CpuInt8Path(load_tflite(TFLITE_PATH))
+
+
+def test_i8_runner_boundary_4096_spectrograms_bit_exact(torch_mod):
+    """BASELINE configs[2]'s batch at the runner boundary: 3584 spectrograms of the synthetic chunks + 512 random ones (uniform noise,
+    values on the quantiser's steps, silence, a single spike) through the PRODUCTION plan == the C port of the TFLite reference kernels,
+    score for score (the dequantised int8 sigmoid and the pre-sigmoid outputs)."""
+    torch = torch_mod
+    from birdnet_stm32.models.runners import load_model_runner
+
+    path = _c_int8_path()
+    S = np.empty((4096, 257, 256, 1), np.float32)
+    S[:3584] = path.spectrogram(synth_chunks(3584, seed=1234), 281, 256)
+    rng = np.random.default_rng(99)
+    S[3584:] = rng.random((512, 257, 256, 1), dtype=np.float32)
+    S[3584:3592] *= np.float32(1.0 / 255.0) * np.arange(0, 256, 32, dtype=np.float32)[:, None, None, None]
+    S[3592:3600] = (np.round(S[3592:3600] * 255.0) / 255.0).astype(np.float32)  # exactly on the quantiser's steps
+    S[3600] = 0.0
+    S[3601] = 0.0
+    S[3601, 40, 100, 0] = 1.0
+    S[3602] = 1.0
+    want = np.concatenate([path.invoke(S[i : i + 512]) for i in range(0, 4096, 512)])
+    runner = load_model_runner(TFLITE_PATH, max_batch=4096)
+    x = torch.from_numpy(S.reshape(4096, -1)).cuda()
+    scores, logits = runner.predict_device(x, return_logits=True)
+    got = scores.cpu().numpy()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of 4096 chunks differ from the oracle, first {bad[:5].tolist()}"
+    # pre-sigmoid outputs: dequantised FC output of the oracle
+    from birdnet_stm32.models._tflite_reader import load_tflite
+
+    model = load_tflite(TFLITE_PATH)
+    fc = model.ops[53].outputs[0]
+    s, z = float(model.tensors[fc].scale[0]), int(model.tensors[fc].zero_point[0])
+    _, env = path.invoke(S[:512], return_all=True)
+    assert np.array_equal(logits[:512].cpu().numpy(), (env[fc].astype(np.float32) - z) * np.float32(s))
+    runner.close()
+
+
+def test_i8_from_audio_2048_chunks_top1_and_flipped_bytes(torch_mod):
+    """From audio the GPU computes the STFT in float32, the oracle in float64 (librosa's arithmetic), so a few quantised input bytes differ
+    by one step; everything behind the quantiser is exact.  Measured and asserted here on 2048 chunks: the share of flipped input bytes
+    (<= 2e-3, each by exactly one LSB), exact top-1 of the pre-sigmoid outputs wherever the oracle's top-1 leads by more than one
+    output LSB, logit cosine >= 0.999 for every chunk, and scores within one LSB of the int8 sigmoid."""
+    torch = torch_mod
+    from birdnet_stm32.models._tflite_reader import load_tflite
+    from birdnet_stm32.models.runners import load_model_runner
+    from oracle import stft
+
+    path = _c_int8_path()
+    N = 2048
+    audio = synth_chunks(N, seed=77)
+    audio[:4] = 0.0  # silence
+    audio[4:8] *= 1e-3  # quiet chunks (the normalisation is scale-free)
+    S_ref = np.stack([stft.hybrid_spectrogram(a, 512, 256) for a in audio])[..., None].astype(np.float32)
+    model = load_tflite(TFLITE_PATH)
+    fc = model.ops[53].outputs[0]
+    s_fc, z_fc = float(model.tensors[fc].scale[0]), int(model.tensors[fc].zero_point[0])
+    qin = model.ops[0].outputs[0]
+    s_in, z_in = np.float32(model.tensors[qin].scale[0]), int(model.tensors[qin].zero_point[0])
+    ref_scores, ref_q, ref_fc = [], [], []
+    for i in range(0, N, 512):
+        sc, env = path.invoke(S_ref[i : i + 512], return_all=True)
+        ref_scores.append(sc)
+        ref_q.append(env[qin].reshape(len(sc), -1))
+        ref_fc.append(env[fc].reshape(len(sc), -1).astype(np.int32))
+    ref_scores, ref_q, ref_fc = np.concatenate(ref_scores), np.concatenate(ref_q), np.concatenate(ref_fc)
+
+    runner = load_model_runner(TFLITE_PATH, max_batch=N)
+    d_audio = torch.from_numpy(audio).cuda()
+    scores, logits = runner.infer_audio_device(d_audio, return_logits=True)
+    scores, logits = scores.cpu().numpy(), logits.cpu().numpy()
+    got_fc = np.rint(logits / np.float32(s_fc)).astype(np.int32) + z_fc
+    # quantised input bytes of the GPU's own spectrogram (the oracle's QUANTIZE formula on the GPU's normalised float32 STFT)
+    S_gpu = runner.stft_device(d_audio).cpu().numpy()
+    r = (S_gpu / s_in).astype(np.float32)
+    t = np.trunc(r)
+    q_gpu = np.clip(np.where(np.abs(r - t) >= 0.5, t + np.sign(r), t).astype(np.int64) + z_in, -128, 127).astype(np.int8).reshape(N, -1)
+    dq = q_gpu.astype(np.int32) - ref_q.astype(np.int32)
+    flipped = float((dq != 0).mean())
+    assert np.abs(dq).max() <= 1 and flipped <= 2e-3, f"flipped input bytes: {flipped:.2e}, largest step {np.abs(dq).max()}"
+    # top-1 of the pre-sigmoid outputs
+    order = np.sort(ref_fc, axis=1)
+    clear = (order[:, -1] - order[:, -2]) > 1
+    same = got_fc.argmax(axis=1) == ref_fc.argmax(axis=1)
+    assert same[clear].all(), f"{int((~same[clear]).sum())} chunks with a clear oracle top-1 disagree"
+    agree = float(same.mean())
+    lsb = np.abs(got_fc - ref_fc).max()
+    worst_cos = min(cosine((got_fc[b] - z_fc).astype(np.float64), (ref_fc[b] - z_fc).astype(np.float64)) for b in range(N))
+    print(f"INT8 from audio, {N} chunks: flipped input bytes {flipped:.2e}, top-1 agreement {agree:.4f} ({int(clear.sum())} chunks with a clear "
+          f"top-1: all agree), largest pre-sigmoid difference {lsb} LSB, worst logit cosine {worst_cos:.6f}")
+    assert agree >= 0.99 and lsb <= 2 and worst_cos >= 0.999
+    assert np.abs(scores - ref_scores).max() <= 1.0 / 256 + 1e-7
+    runner.close()
+
+
+# ----------------------------------------------------------------------- float32 row-streaming depthwise kernel
+def test_f32_dw_stream_matches_baseline_kernel(torch_mod):
+    """Every stand-alone depthwise 3x3 of an inverted-residual + squeeze-excite model (stride 1 and the stride-2 stage openers):
+    ``f32_dw_stream_kernel`` (option f32_strip = 1) against the baseline ``f32_dw_kernel`` (f32_strip = 0), within 1e-6 of the map's
+    peak (float32 round-off of a nine-term sum), for rows-per-wave values that move the row-block borders everywhere, at an
+    odd batch (130) and a production-size one (1024: the launcher's own choice of 16 rows per wave), 50 launches each — the store-data
+    hazard class of these row-streaming kernels showed up once in 50-100 launches."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=10,
+                       randomize_bn=True, seed=7)
+    rng = np.random.default_rng(17)
+    for B, ths in ((130, (0, 1, 3, 5, 7, 64) * 8), (1024, (0, 3, 64))):
+        runner = HipRunner(lower_f32(spec, keep_all=True), max_batch=B)
+        dw_ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.F32_DW]
+        assert len(dw_ops) >= 8 and {runner.plan.ops[oi].p[3] for oi in dw_ops} == {1, 2}
+        x = torch.from_numpy(rng.random((B, 257 * 256), dtype=np.float32)).cuda()
+        with _hip.options(f32_strip=0):
+            want_scores = runner.predict_device(x).clone()
+            want = {oi: torch.from_numpy(runner.op_output(oi, B)) for oi in dw_ops}
+        launches = 0
+        for th in ths:
+            with _hip.options(f32_strip=1, f32_strip_th=th):
+                got_scores = runner.predict_device(x)
+                launches += 1
+                for oi in dw_ops:
+                    a = torch.from_numpy(runner.op_output(oi, B))
+                    err = float((a - want[oi]).abs().max() / want[oi].abs().max())
+                    if err > 1e-6:
+                        raise AssertionError(f"B={B}, rows per wave {th or 'auto'}: depthwise {runner.plan.ops[oi].name} differs (relative to peak {err:.3e})")
+                assert float((got_scores - want_scores).abs().max()) < 5e-6
+        # the remaining launches of the 50: scores only (every depthwise feeds them)
+        with _hip.options(f32_strip=1):
+            for _ in range(50 - launches):
+                assert float((runner.predict_device(x) - want_scores).abs().max()) < 5e-6
+        runner.close()
+
+
+# -------------------------------------------------------------------------------- configs[4] at its full batch
+def test_config5_full_batch_properties(torch_mod):
+    """BASELINE configs[4] (raw learned-filterbank frontend + PCEN + alpha 1.5 DS-CNN with SE / inverted residuals, seeded weights,
+    24 kHz x 2 s) at B = 1024: a chunk's scores do not depend on its batch neighbours, position or batch slicing (== the same chunks
+    through a 96-chunk workspace, where the per-layer parity test against the oracle runs), repeated runs are bit-identical, softmax rows
+    sum to one; and the first chunks agree with the float64 oracle."""
+    torch = torch_mod
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle import float_graph
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+    base = torch.from_numpy(synth_chunks(64)[:, :48000].copy()).cuda()
+    B = 1024
+    idx = torch.randint(0, 64, (B,), generator=torch.Generator().manual_seed(3)).cuda()
+    audio = base[idx].contiguous()
+    big = HipRunner(lower_f32(spec), max_batch=B)
+    s1 = big.infer_audio_device(audio).clone()
+    s2 = big.infer_audio_device(audio)
+    assert torch.equal(s1, s2), "run-to-run determinism"
+    small = HipRunner(lower_f32(spec), max_batch=96)
+    ref64 = small.infer_audio_device(base)
+    assert torch.equal(s1, ref64[idx]), "a chunk's scores depend on its batch position / neighbours"
+    assert torch.isfinite(s1).all() and float((s1.sum(dim=1) - 1).abs().max()) < 1e-5
+    x = base[:4].cpu().numpy()
+    x = (x / (np.abs(x).max(axis=1, keepdims=True) + 1e-6)).astype(np.float32)[..., None]
+    ref = float_graph.forward(spec, x, np.float64)
+    got = ref64[:4].cpu().numpy()
+    for b in range(4):
+        assert 1.0 - cosine(got[b], ref[b]) < 1e-5
+    big.close()
+    small.close()

@@ -8,7 +8,7 @@ import struct
 import numpy as np
 import pytest
 
-from conftest import KERAS_PATH, REPO, TFLITE_PATH
+from conftest import KERAS_PATH, PKG, REPO, TFLITE_PATH
 
 
 def _plans(keep_all=False, fuse=False):
@@ -234,6 +234,110 @@ def test_library_exports_every_declared_symbol():
     lib.bn_kernel_names.restype = ctypes.c_char_p
     names = lib.bn_kernel_names().decode().split("\n")
     assert "stft512_mag_kernel" in names and "i8_pw_kernel" in names
+
+
+def test_launcher_options_round_trip_without_a_device():
+    """bn_set_option / bn_get_option are plain host state (no compute): every documented name exists with its production
+    default, values round-trip, unknown names are refused, and no launcher reads the environment any more."""
+    from birdnet_stm32 import _hip
+
+    defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_th": 0,
+                "i8_tail": 1, "i8_mel_generic": 0, "stft_rowmajor": 0, "stft_tpw": 0, "ingest_blk": 0, "ingest_generic": 0}
+    assert sorted(defaults) == sorted(_hip.OPTION_NAMES)
+    hdr = open(os.path.join(REPO, "include", "birdnet_hip.h")).read()
+    for name, want in defaults.items():
+        assert f'"{name}"' in hdr, name
+        if not os.environ.get("BN_" + name.upper()):
+            assert _hip.get_option(name) == want, name
+        with _hip.options(**{name: 7}):
+            assert _hip.get_option(name) == 7
+        assert _hip.get_option(name) == (want if not os.environ.get("BN_" + name.upper()) else int(os.environ["BN_" + name.upper()]))
+    with pytest.raises(_hip.HipError, match="unknown option"):
+        _hip.set_option("no_such_switch", 1)
+    csrc = os.path.join(PKG, "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith(".hip") and fn != "bn_api.hip":
+            assert "getenv" not in open(os.path.join(csrc, fn)).read(), f"{fn} reads the environment on a launch path"
+    assert open(os.path.join(csrc, "bn_api.hip")).read().count("getenv(") == 1  # options_from_env, once at load
+
+
+def _all_plans():
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import lower_model_file
+
+    for path in (KERAS_PATH, TFLITE_PATH):
+        for keep_all in (False, True):
+            for fuse in (True, False):
+                yield f"{os.path.basename(path)} keep_all={keep_all} fuse={fuse}", lower_model_file(path, keep_all=keep_all, fuse=fuse)
+    base = dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=10, randomize_bn=True, seed=7)
+    for kw in (dict(), dict(use_inverted_residual=False, use_se=True, embeddings_size=128, use_attention_pooling=True, class_activation="sigmoid"),
+               dict(alpha=1.5, mag_scale="pcen", num_classes=37), dict(use_se=False, depth_multiplier=2, alpha=0.5, mag_scale="none"),
+               dict(num_mels=32, spec_width=128, sample_rate=16000, chunk_duration=2), dict(num_mels=48, spec_width=192, sample_rate=22050, alpha=0.75),
+               dict(chunk_duration=2, audio_frontend="raw", mag_scale="pcen", alpha=1.5), dict(audio_frontend="librosa"), dict(audio_frontend="mfcc", num_mels=20)):
+        spec = build_model("dscnn", **{**base, **kw})
+        for fuse in (True, False):
+            yield f"dscnn {kw} fuse={fuse}", lower_f32(spec, fuse=fuse)
+
+
+def test_blob_check_accepts_every_lowered_plan_and_refuses_damaged_ones():
+    """bn_blob_check (host only): the validation bn_model_load runs before it touches the device.  Every plan the lowering passes
+    produce passes; a slot made too small for an operator's output, a gate / residual slot id outside the plan, a slot without storage,
+    a truncated constant tensor, an impossible geometry and a truncated blob are all refused with BN_ERR_FORMAT."""
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+
+    plans = dict(_all_plans())
+    assert len(plans) >= 20
+    for name, plan in plans.items():
+        try:
+            _hip.blob_check(plan.to_blob())
+        except _hip.HipError as e:  # pragma: no cover
+            raise AssertionError(f"{name}: {e}") from e
+
+    import copy
+
+    def refused(plan, why):
+        with pytest.raises(_hip.HipError, match=why):
+            _hip.blob_check(plan.to_blob())
+
+    i8 = plans[f"{os.path.basename(TFLITE_PATH)} keep_all=True fuse=True"]
+    f32 = next(p for n, p in plans.items() if n.startswith("dscnn {} fuse=True"))
+    # 1) an output slot smaller than what the operator writes
+    bad = copy.deepcopy(i8)
+    oi = next(i for i, o in enumerate(bad.ops) if o.kind == pk.I8_DWPW and o.p[29])
+    bad.slot_bytes[bad.ops[oi].out] = 256
+    refused(bad, "needs .* bytes per chunk")
+    # 2) a gate slot id stored in p[] that is not a slot of the plan (squeeze-excite)
+    bad = copy.deepcopy(f32)
+    gated = [i for i, o in enumerate(bad.ops) if (o.kind == pk.F32_DWPW and o.p[13]) or (o.kind == pk.F32_PW and o.p[5])]
+    assert gated
+    o = bad.ops[gated[0]]
+    o.p[14 if o.kind == pk.F32_DWPW else 6] = 10_000
+    refused(bad, "slot id 10000 is not a slot")
+    # 3) a referenced slot without storage
+    bad = copy.deepcopy(i8)
+    bad.slot_bytes[bad.ops[2].in0] = 0
+    refused(bad, "has no storage")
+    # 4) a constant tensor shorter than the operator reads
+    bad = copy.deepcopy(i8)
+    o = bad.ops[oi]
+    bad.tensors[o.t[4]] = bad.tensors[o.t[4]].reshape(-1)[:64].copy()
+    refused(bad, "holds 64 bytes, the operator reads")
+    # 5) geometry that does not follow from the input size
+    bad = copy.deepcopy(i8)
+    bad.ops[oi].p[6] -= 1
+    refused(bad, "does not follow from input")
+    # 6) residual slot missing
+    bad = copy.deepcopy(i8)
+    oj = next(i for i, o in enumerate(bad.ops) if o.kind == pk.I8_DWPW and o.p[18])
+    bad.ops[oj].in1 = pk.SLOT_NONE
+    refused(bad, "residual")
+    # 7) truncated blob, bad magic
+    blob = i8.to_blob()
+    for cut in (10, 63, 200, len(blob) // 2):
+        assert _hip.load_library().bn_blob_check(blob[:cut], cut) == -3
+    assert _hip.load_library().bn_blob_check(b"XXXXXXXX" + blob[8:], len(blob)) == -3
 
 
 def test_context_creation_fails_loudly_without_device():
