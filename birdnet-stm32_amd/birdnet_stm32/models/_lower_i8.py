@@ -56,6 +56,24 @@ def _expect(cond: bool, what: str) -> None:
         raise NotImplementedError(f"unsupported INT8 graph: {what}")
 
 
+def _expect_acc_range(w, folded_bias, axes, what: str, mult=None, shift=None) -> None:
+    """Domain proof of the device's fast requantisation forms (csrc/bn_requant.h: ``(x*m + 2^30) >> 31`` on a 64-bit product, then
+    ``(v + 2^(e-1) + sign) >> e`` in 32 bits): every int32 accumulator ``x = sum(q * w) + folded_bias`` over int8 inputs ``q`` must fit
+    int32, and per channel ``|x| * m / 2^31 + 2^(e-1) + 1`` must stay below 2^31 (the folded bias already holds ``-zp * sum(w)``).
+    Channels with a negative multiplier or a left shift take the literal reference path on the device, which only needs int32 inputs."""
+    w64 = np.asarray(w, np.int64)
+    b = np.asarray(folded_bias, np.int64)
+    lo = np.minimum(-128 * w64, 127 * w64).sum(axis=axes) + b
+    hi = np.maximum(-128 * w64, 127 * w64).sum(axis=axes) + b
+    top = np.maximum(np.abs(lo), np.abs(hi))
+    _expect(int(top.max()) < 2**31, f"{what}: accumulators overflow int32")
+    if mult is not None:
+        m, e = np.asarray(mult, np.int64), -np.asarray(shift, np.int64)
+        fast = (m >= 0) & (e >= 0)
+        half = np.where(e > 0, np.int64(1) << np.maximum(e - 1, 0), 0)
+        _expect(bool((((top * m) >> 31) + half + 1 < 2**31)[fast].all()), f"{what}: the rounding shift of the requantisation can overflow int32")
+
+
 def _pwl_table(g: _Graph, ops: list, src: int, dst: int, channels: int) -> np.ndarray:
     """Evaluate the element-wise sub-graph ``ops`` for every int8 value of ``src``: int8 [C][256]."""
     env = {src: np.repeat(np.arange(-128, 128, dtype=np.int64)[:, None], channels, axis=1)}  # [256, C]
@@ -260,6 +278,118 @@ def front_strip_constants(ws, bs, mus, shs, z_fe, z_st, wd, bdw, mud, shd, z_dw,
     return out
 
 
+
+TAIL_G = 4          # chunks a workgroup of i8_tail_kernel holds in LDS at a time (csrc/bn_i8_tail.hip)
+TAIL_LAYER_WORDS = 24
+TAIL_HEAD_WORDS = 16
+
+
+def _tail_quad_base(cin: int) -> list[int]:
+    """First channel quad of lane group kq in i8_tail_kernel's depthwise stage (mirrors pq_base() in csrc/bn_i8_tail.hip): lane
+    (n, kq) takes the quads ``base[kq] + 4 ks + j`` (k-step ks, j = 0..3).  With a map pitch of Cin + 4 bytes the groups kq and
+    kq ^ 1 are 16 quads apart, so the 32 lanes of one LDS access cycle hit 32 different banks."""
+    return {64: [0, 4, 8, 12], 128: [0, 16, 8, 24], 256: [0, 16, 32, 48]}[cin]
+
+
+def tail_layer_sections(wd, bdw, rq_dw, w2, b2, rq_pw, add_luts):
+    """Constant sections of one block of the fused tail, int32 words: pointwise A fragments ``[nt][ks][lane][16 bytes]`` = bytes
+    ``W[16 nt + m][4 pq(kq, ks, b >> 2) + (b & 3)]`` for lane (m, kq); depthwise constants ``[quad][7][4]`` (three tap rows as bytes
+    (tap0, tap1, tap2, 0) per channel, folded bias, multiplier, c1, shift); pointwise constants ``[nt][q][4][4]`` (folded bias,
+    multiplier, c1, shift of channel 16 nt + 4 q + r); the two 256-entry ADD tables or an empty array."""
+    wd = np.asarray(wd, np.int8)
+    C, (N, K) = wd.shape[2], w2.shape
+    assert K == C and C in (64, 128, 256) and N % 16 == 0
+    base = _tail_quad_base(C)
+    KS = C // 64
+    lane = np.arange(64)
+    m_, kq_ = lane & 15, lane >> 4
+    frag = np.zeros((N // 16, KS, 64, 16), np.int8)
+    for nt in range(N // 16):
+        for ks in range(KS):
+            for b in range(16):
+                pq = np.asarray(base)[kq_] + 4 * ks + (b >> 2)
+                frag[nt, ks, :, b] = w2[16 * nt + m_, 4 * pq + (b & 3)]
+    dwc = np.zeros((C // 4, 7, 4), np.int32)
+    ch = 4 * np.arange(C // 4)[:, None] + np.arange(4)[None, :]  # [quad][e]
+    rows = np.zeros((C // 4, 3, 4, 4), np.uint8)
+    for i in range(3):
+        for j in range(3):
+            rows[:, i, :, j] = wd[i, j][ch].view(np.uint8)
+    dwc[:, 0:3, :] = rows.view(np.int32).reshape(C // 4, 3, 4)
+    dwc[:, 3, :] = np.asarray(bdw, np.int32)[ch]
+    for k in range(3):
+        dwc[:, 4 + k, :] = rq_dw[k][ch]
+    cho = 16 * np.arange(N // 16)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :]  # [nt][q][r]
+    pwc = np.stack([np.asarray(b2, np.int32)[cho], rq_pw[0][cho], rq_pw[1][cho], rq_pw[2][cho]], axis=2)  # [nt][q][kind][r]
+    lut = np.concatenate(add_luts).astype(np.int32) if add_luts is not None else np.zeros(0, np.int32)
+    return frag.view(np.int32).reshape(-1), dwc.reshape(-1), pwc.astype(np.int32).reshape(-1), lut
+
+
+def tail_constants(blocks: list[dict], head: dict):
+    """Constant block and descriptor table of ``i8_tail_kernel`` (csrc/bn_i8_tail.hip) for the blocks behind stage 2 of the shipped
+    topology plus MEAN / FULLY_CONNECTED / LOGISTIC, or ``None`` when a block's arithmetic cannot take the kernel's forms.
+
+    Every block is a dict with the fields of the I8_DWPW operator it replaces (geometry, quantisation, weights with folded biases).
+    Descriptor words per block: H W Cin Cout S OH OW pt pl has_add zp_in dw_lo dw_hi pw_lo pw_hi add_m add_c1 add_e add_lo add_hi
+    g_w g_dwc g_pwc g_lut (the g_* are word offsets into the constant block; with the ADD the pointwise stage produces its value + 128,
+    the index of the second table).  Head words: mean zp_in mult shift zp_out | fc zp_out lo hi g_w g_bias g_mult g_shift | g_lut (-1 =
+    none) zp_fc zp_head P C."""
+    sections, desc = [], []
+    pos = 0
+
+    def put(arr):
+        nonlocal pos
+        a = np.ascontiguousarray(np.asarray(arr, np.int32).reshape(-1))
+        pad = (-a.size) % 4  # 16-byte pieces for the staging copies
+        a = np.concatenate([a, np.zeros(pad, np.int32)])
+        off = pos
+        sections.append(a)
+        pos += a.size
+        return off
+
+    for b in blocks:
+        C, N = b["C"], b["N"]
+        if C not in (64, 128, 256) or N % 64 or b["sh"] != b["sw"] or b["sh"] not in (1, 2) or (b["OH"] * b["OW"]) % 16 or b["OW"] not in (8, 16):
+            return None
+        wd64, w264 = np.asarray(b["wd"], np.int64), np.asarray(b["w2"], np.int64)
+        lo_dw = np.minimum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(b["bdw"], np.int64)
+        hi_dw = np.maximum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(b["bdw"], np.int64)
+        lo_pw = np.minimum(-128 * w264, 127 * w264).sum(axis=1) + np.asarray(b["b2"], np.int64)
+        hi_pw = np.maximum(-128 * w264, 127 * w264).sum(axis=1) + np.asarray(b["b2"], np.int64)
+        add = b["add"]
+        rq_dw = _strip_requant(b["mu"], b["sh_dw"], b["z_dw"], lo_dw, hi_dw)
+        rq_pw = _strip_requant(b["mu2"], b["sh2"], b["z_pw"] + (128 if add[0] else 0), lo_pw, hi_pw)
+        if rq_dw is None or rq_pw is None:
+            return None
+        luts, add_m, add_c1, add_e, add_lo, add_hi = None, 0, 0, 1, 0, 0
+        if add[0]:
+            _, z1, m1, s1, m2, s2, mo, so, zo, amin, amax = add
+            if mo < 0 or so >= 0 or -so > STRIP_MAX_SHIFT:
+                return None
+            res = np.arange(256).astype(np.uint8).view(np.int8).astype(np.int64)
+            own = np.arange(256, dtype=np.int64) - 128
+            sa = qz.requantize((res - z1) << 20, m1, s1)
+            sb = qz.requantize((own - b["z_pw"]) << 20, m2, s2)
+            if max(np.abs(sa).max(), np.abs(sb).max()) >= 2**29:
+                return None
+            luts = (sa, sb)
+            add_m, add_e = int(mo), int(-so)
+            add_c1 = (1 << (add_e - 1)) + (int(zo) << add_e)
+            add_lo, add_hi = int(amin), int(amax)
+        frag, dwc, pwc, lut = tail_layer_sections(b["wd"], b["bdw"], rq_dw, b["w2"], b["b2"], rq_pw, luts)
+        off = 128 if add[0] else 0
+        desc += [b["H"], b["W"], C, N, b["sh"], b["OH"], b["OW"], b["pt"], b["pl"], int(bool(add[0])), b["z_in"], b["dw_lo"], b["dw_hi"],
+                 b["pw_lo"] + off, b["pw_hi"] + off, add_m, add_c1, add_e, add_lo, add_hi, put(frag), put(dwc), put(pwc), put(lut) if lut.size else -1]
+    h = head
+    if h["C"] != 256 or h["C"] != blocks[-1]["N"] or h["P"] != blocks[-1]["OH"] * blocks[-1]["OW"] or TAIL_G * h["NC"] > 1024:
+        return None
+    desc += [h["mean_zp_in"], h["mean_mult"], h["mean_shift"], h["mean_zp_out"], h["fc_zp_out"], h["fc_lo"], h["fc_hi"],
+             put(np.ascontiguousarray(np.asarray(h["fc_w"], np.int8)).view(np.int32)), put(h["fc_b"]), put(h["fc_m"]), put(h["fc_s"]),
+             put(np.asarray(h["lut"], np.int8).view(np.int32)) if h["lut"] is not None else -1, h["zp_fc"], h["zp_head"], h["P"], h["C"]]
+    assert len(desc) == TAIL_LAYER_WORDS * len(blocks) + TAIL_HEAD_WORDS
+    return np.concatenate(sections).astype(np.int32), np.asarray(desc, np.int32)
+
+
 def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse; ``fuse=False`` keeps the
     baseline one-kernel-per-operator plan instead of the fused matrix-core blocks."""
@@ -314,8 +444,8 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     w_mel = np.zeros((M, Kp), np.int8)
     w_mel[:, :k_graph] = wt.data.reshape(M, k_graph)
     bias = g.const(mel.inputs[2]).astype(np.int64) - z_in * w_mel.astype(np.int64).sum(axis=1)
-    _expect(np.abs(bias).max() < 2**31, "folded bias overflows int32")
     mult, shift = qz.channel_multipliers(s_in, wt.scale, s_mel, M)
+    _expect_acc_range(w_mel, bias, 1, "mel mixer", mult, shift)
     lo, hi = qz.activation_bounds(mel.options["activation"], s_mel, z_mel)
     cur = mel.outputs[0]
     i += 1
@@ -367,6 +497,8 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
               out_shape=(M, W, 1), out_dtype="int8")
     val = {cur: v}
     shape = {cur: (M, W, 1)}
+    tail_blocks: list[dict] = []  # fused DW+PW blocks in graph order (candidates for the fused tail kernel)
+    tail_head: dict = {}
 
     def conv_common(op):
         s_i, z_i = g.q(op.inputs[0])
@@ -391,6 +523,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             OH, pt, _ = same_pad(H, 3, sh_)
             OW, pl, _ = same_pad(Wd, 3, sw_)
             w = np.transpose(wt_.data[:, :, :, 0], (1, 2, 0))  # [3][3][Cout]
+            _expect_acc_range(w, b - z_i * w.astype(np.int64).sum(axis=(0, 1)), (0, 1), f"stem conv of operator #{op.index}", mu, sh)
             # front block: stem -> depthwise stride 2 -> pointwise in one kernel
             d_op = ops[i + 1] if i + 1 < len(ops) else None
             p_op = ops[i + 2] if i + 2 < len(ops) else None
@@ -407,6 +540,8 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                     bd = bd - zd * wtd.data[0].astype(np.int64).sum(axis=(0, 1))
                     wpw = wtp.data.reshape(N, Cout)
                     bp = bp - zp_ * wpw.astype(np.int64).sum(axis=1)
+                    _expect_acc_range(wtd.data[0], bd, (0, 1), f"depthwise conv of operator #{d_op.index}", mud, shd)
+                    _expect_acc_range(wpw, bp, 1, f"pointwise conv of operator #{p_op.index}", mup, shp)
                     v = pb.value(BH * BW * N)
                     cst = front_strip_constants(w, b, mu, sh, z_i, z_o, wtd.data[0], bd, mud, shd, zdo, wpw, bp, mup, shp, zpo) if BW % 16 == 0 else None
                     pb.op(pk.I8_FRONT, val[src], v, p=[H, Wd, Cout, N, BH, BW, z_i, z_o, a_lo, a_hi, zdo, dlo, dhi, zpo, plo, phi, int(cst is not None)],
@@ -442,7 +577,8 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                 w2 = wt2.data.reshape(Cout, C)
                 b2 = b2 - z2 * w2.astype(np.int64).sum(axis=1)
                 bdw = b - z_i * wt_.data[0].astype(np.int64).sum(axis=(0, 1))  # padded taps load zp_in, so the fold is uniform
-                _expect(np.abs(b2).max() < 2**31 and np.abs(bdw).max() < 2**31, "folded bias overflows int32")
+                _expect_acc_range(w2, b2, 1, f"pointwise conv of operator #{nxt.index}", mu2, sh2)
+                _expect_acc_range(wt_.data[0], bdw, (0, 1), f"depthwise conv of operator #{op.index}", mu, sh)
                 add_p = [0] * 11
                 res_val = pk.SLOT_NONE
                 out_t = nxt.outputs[0]
@@ -472,6 +608,9 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                         and ((ow_ * sw_ - pl + 1 >= 0) & (ow_ * sw_ - pl + 1 < Wd)).all()):
                     cst = strip_constants(wt_.data[0], bdw, mu, sh, z_o, w2, b2, mu2, sh2, zo2, bool(add_p[0]), nw)
                 p = [H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi, Cout, zo2, lo2, hi2, *add_p, 1, 0, *tile, 0, int(cst is not None)]
+                tail_blocks.append(dict(op=len(plan.ops), src=val[src], res_is_input=(not add_p[0]) or res_val == val[src], H=H, W=Wd, C=C, N=Cout, sh=sh_, sw=sw_,
+                                        OH=OH, OW=OW, pt=pt, pl=pl, z_in=z_i, z_dw=z_o, dw_lo=a_lo, dw_hi=a_hi, z_pw=zo2, pw_lo=lo2, pw_hi=hi2, add=list(add_p),
+                                        wd=wt_.data[0], bdw=bdw, mu=mu, sh_dw=sh, w2=w2, b2=b2, mu2=mu2, sh2=sh2, macs=(OH * OW * C * 9, OH * OW * C * Cout)))
                 pb.op(pk.I8_DWPW, val[src], v, p=p, in1=res_val,
                       t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(bdw, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
                          pb.tensor(pack_i8_fragments(w2), np.int8), pb.tensor(b2, np.int32), pb.tensor(mu2, np.int32), pb.tensor(sh2, np.int32),
@@ -481,6 +620,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                 val[out_t], shape[out_t] = v, (OH, OW, Cout)
                 i += 2
             else:
+                _expect_acc_range(wt_.data[0], b - z_i * wt_.data[0].astype(np.int64).sum(axis=(0, 1)), (0, 1), f"depthwise conv of operator #{op.index}", mu, sh)
                 v = pb.value(OH * OW * C)
                 pb.op(pk.I8_DW, val[src], v, p=[H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi],
                       t=[pb.tensor(wt_.data[0], np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
@@ -493,7 +633,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             _expect(tuple(wt_.shape[1:3]) == (1, 1) and op.options["stride_h"] == 1 and op.options["stride_w"] == 1, "1x1 stride-1 CONV_2D")
             w = wt_.data.reshape(Cout, Cin)
             b = b - z_i * w.astype(np.int64).sum(axis=1)
-            _expect(np.abs(b).max() < 2**31, "folded bias overflows int32")
+            _expect_acc_range(w, b, 1, f"1x1 conv of operator #{op.index}", mu, sh)
             add_p = [0] * 11
             res_val = pk.SLOT_NONE
             out_t = op.outputs[0]
@@ -528,6 +668,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             s_o, z_o = g.q(op.outputs[0])
             mu, sh = qz.mean_multiplier(s_i, s_o, H * Wd)
             v = pb.value(C)
+            tail_head.update(mean_op=len(plan.ops), mean_src=val[src], P=H * Wd, C=C, mean_zp_in=z_i, mean_mult=mu, mean_shift=sh, mean_zp_out=z_o)
             pb.op(pk.I8_MEAN, val[src], v, p=[H * Wd, C, z_i, mu, sh, z_o], name=f"t{op.outputs[0]}", out_shape=(C,), out_dtype="int8")
             val[op.outputs[0]], shape[op.outputs[0]] = v, (C,)
             i += 1
@@ -541,7 +682,9 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             a_lo, a_hi = qz.activation_bounds(op.options["activation"], s_o, z_o)
             b = g.const(op.inputs[2]).astype(np.int64) if len(op.inputs) > 2 and op.inputs[2] >= 0 else np.zeros(Cout, np.int64)
             b = b - z_i * wt_.data.astype(np.int64).sum(axis=1)
+            _expect_acc_range(wt_.data, b, 1, f"fully connected operator #{op.index}", mu, sh)
             v = pb.value(Cout)
+            tail_head.update(fc_op=len(plan.ops), fc_cin=Cin, NC=Cout, fc_zp_out=z_o, fc_lo=a_lo, fc_hi=a_hi, fc_w=wt_.data, fc_b=b, fc_m=mu, fc_s=sh)
             pb.op(pk.I8_FC, val[src], v, p=[Cin, Cout, z_o, a_lo, a_hi],
                   t=[pb.tensor(wt_.data, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
                   name=f"t{op.outputs[0]}", out_shape=(Cout,), out_dtype="int8")
@@ -559,10 +702,48 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             else:
                 last = fc_out
             _expect(i < len(ops) and ops[i].name == "DEQUANTIZE" and ops[i].inputs[0] == last, "DEQUANTIZE must end the graph")
+            tail_head.update(head_op=len(plan.ops), lut=qz.logistic_table(s_fc, z_fc, s_h, z_h) if has else None, zp_fc=z_fc, zp_head=z_h, s_fc=s_fc, s_head=s_h)
             pb.op(pk.I8_HEAD, v, pk.SLOT_SCORES, p=[Cout, z_fc, z_h, has], f=[s_fc, s_h], t=[lut_t], name=f"t{ops[i].outputs[0]}",
                   out_shape=(Cout,))
             i += 1
             _expect(i == len(ops), "operators after DEQUANTIZE")
         else:
             _expect(False, f"operator #{op.index} {op.name} in the backbone")
+    if fuse and not keep_all:
+        _add_tail_op(pb, plan, tail_blocks, tail_head)
     return pb.finalize(reuse=not keep_all)
+
+
+def _add_tail_op(pb, plan, blocks: list[dict], head: dict) -> None:
+    """Append the fused tail operator (csrc/bn_i8_tail.hip) when the plan ends in the shipped topology's back half: a stride-2 block
+    from 64 channels onto a 16-wide map, then blocks of 128 / 256 channels on 16- and 8-wide maps (residual ADDs against the block
+    input), MEAN, FULLY_CONNECTED, head — as consecutive plan operators.  The per-block operators stay in the plan tagged p[TAIL_TAG]
+    = 1 (skipped while the tail kernel runs them), the tail operator is tagged 2 (skipped when the option ``i8_tail`` is off or the
+    library finds that the maps do not fit its LDS plan)."""
+    if not blocks or not {"mean_op", "fc_op", "head_op"} <= set(head):
+        return
+    start = next((i for i, b in enumerate(blocks) if (b["C"], b["sh"], b["OW"]) == (64, 2, 16) and not b["add"][0]), None)
+    if start is None:
+        return
+    chain = blocks[start:]
+    ops_idx = [b["op"] for b in chain] + [head["mean_op"], head["fc_op"], head["head_op"]]
+    if ops_idx != list(range(ops_idx[0], ops_idx[0] + len(ops_idx))) or ops_idx[-1] != len(plan.ops) - 1 or len(chain) > 8:
+        return
+    if not all(b["res_is_input"] for b in chain) or head["fc_cin"] != head["C"] or head["mean_src"] != plan.ops[chain[-1]["op"]].out:
+        return
+    for a, b in zip(chain, chain[1:]):  # each block reads the previous block's output
+        if b["src"] != plan.ops[a["op"]].out or (b["H"], b["W"], b["C"]) != (a["OH"], a["OW"], a["N"]):
+            return
+    packed = tail_constants(chain, head)
+    if packed is None:
+        return
+    cst, desc = packed
+    first = chain[0]
+    dw_macs = sum(b["macs"][0] for b in chain)
+    pw_macs = sum(b["macs"][1] for b in chain)
+    for k in ops_idx:
+        plan.ops[k].p[pk.TAIL_TAG] = pk.TAIL_COVERED
+    pb.op(pk.I8_TAIL, first["src"], pk.SLOT_SCORES,
+          p=[first["H"] * first["W"] * first["C"], pw_macs, dw_macs, head["P"] * head["C"] + head["C"] * head["NC"], head["NC"], len(chain),
+             first["H"], first["W"], first["C"], head["P"], head["C"], *([0] * (pk.TAIL_TAG - 11)), pk.TAIL_OP],
+          t=[pb.tensor(cst, np.int32), pb.tensor(desc, np.int32)], f=[head["s_fc"], head["s_head"]], name="tail", out_shape=(head["NC"],))

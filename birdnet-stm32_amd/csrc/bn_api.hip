@@ -92,6 +92,9 @@ struct bn_model {
     size_t consts_base = 0;              // blob offset of the first payload byte
     size_t consts_bytes = 0;
     std::vector<uint8_t> rq_right;       // per operator: all requantisation multipliers >= 0 and shifts < 0
+    std::vector<bn::Tail8Args> tails;    // per operator: arguments of the fused tail kernel (BN_OP_I8_TAIL operators only)
+    std::vector<uint8_t> tail_ok;        // per operator: BN_OP_I8_TAIL whose maps fit the kernel's LDS plan
+    bool has_tail = false;               // the plan holds a usable fused tail operator
     bool spec_tiled_ok = false;          // the plan's first operator reads the spectrogram through i8_mel_mfma_kernel<QIN>: bn_infer_audio
                                          // may hand it the tile-major layout the STFT writes fastest
     bool spec_tiled_now = false;         // set by bn_infer_audio around its bn_forward call
@@ -164,10 +167,13 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         if (id < 0 || id >= (int)m->d_slots.size()) return nullptr;
         return m->d_slots[id];
     };
+    const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
+        if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
+        if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
         char* in0 = slot_ptr(o.in0);
         char* in1 = slot_ptr(o.in1);
@@ -356,6 +362,16 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 bn::launch_i8_front(q, (const int8_t*)in0, (int8_t*)out, B, s);
                 break;
             }
+            case BN_OP_I8_TAIL: {
+                bn::Tail8Args ta = m->tails[oi];
+                ta.x = (const int8_t*)in0;
+                ta.scores = d_scores;
+                ta.logits = d_logits;
+                ta.cst = (const int32_t*)m->tensor(o.t[0]);
+                ta.B = B;
+                if (!bn::launch_i8_tail(ta, s)) return fail(BN_ERR_DEVICE, "could not raise the LDS limit of the fused tail kernel");
+                break;
+            }
             case BN_OP_I8_MEAN:
                 bn::launch_i8_mean((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], s);
                 break;
@@ -526,6 +542,24 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             lo = t.offset < lo ? (size_t)t.offset : lo;
             hi = t.offset + t.nbytes > hi ? (size_t)(t.offset + t.nbytes) : hi;
         }
+    // fused tail operators: build the kernel arguments and the LDS plan from the descriptor table
+    m->tails.resize(h.n_ops);
+    m->tail_ok.assign(h.n_ops, 0);
+    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+        const OpRec& o = m->ops[oi];
+        if (o.kind != BN_OP_I8_TAIL) continue;
+        bn::Tail8Args& ta = m->tails[oi];
+        ta = bn::Tail8Args{};
+        ta.NC = o.p[4];
+        ta.s_fc = o.f[0];
+        ta.s_head = o.f[1];
+        const TensorRec& td = m->tensors[o.t[1]];
+        const TensorRec& tc = m->tensors[o.t[0]];
+        const bool ok = (td.nbytes & 3) == 0 && bn::tail_plan((const int32_t*)(base + td.offset), (int)(td.nbytes / 4), o.p[5], ta) &&
+                        ta.L[0].H == o.p[6] && ta.L[0].W == o.p[7] && ta.L[0].Cin == o.p[8] && bn::tail_const_words(ta) * 4 <= (long)tc.nbytes;
+        m->tail_ok[oi] = ok;
+        m->has_tail = m->has_tail || ok;
+    }
     // INT8 blocks: can every requantisation of the operator take the branch-free right-shift form?
     m->rq_right.assign(h.n_ops, 0);
     for (const OpRec& o : m->ops)
@@ -912,7 +946,7 @@ int bn_get_option(const char* name, int* value) {
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\n"
            "i8_head_kernel";
 }
 

@@ -56,6 +56,13 @@ struct TensorRec {
     uint64_t nbytes;
 };
 
+// OpRec.p[BN_OP_TAIL_TAG]: BN_TAIL_COVERED = the operator is one of the blocks the plan's fused tail operator (BN_OP_I8_TAIL) also
+// covers — it is skipped while the tail kernel runs; BN_TAIL_OP marks the tail operator itself, skipped when the option i8_tail is
+// off or its maps do not fit the kernel's LDS plan.  Any other value: the operator always runs.
+#define BN_OP_TAIL_TAG 38
+#define BN_TAIL_COVERED 0x7A110001
+#define BN_TAIL_OP 0x7A110002
+
 #define BN_OP_NP 40
 #define BN_OP_NT 16
 #define BN_OP_NF 8
@@ -142,4 +149,9 @@ enum BnOpKind : int32_t {
     // p: H0 W0 C N OH OW | stem_zp_in stem_zp_out stem_amin stem_amax | dw_zp_out dw_amin dw_amax | pw_zp_out pw_amin pw_amax
     // t: stem_w stem_b stem_mult stem_shift dw_w dw_b(zp folded) dw_mult dw_shift pw_w(fragment order) pw_b(zp folded) pw_mult pw_shift
     BN_OP_I8_FRONT = 29,
+    // the back half of the INT8 graph in one kernel: n_layers blocks [DW 3x3 -> PW 1x1 (-> ADD)] with the maps in LDS, then MEAN,
+    // FULLY_CONNECTED and the head (bn_i8_tail.hip)
+    // p: in_bytes pw_macs dw_macs other_macs n_classes n_layers H0 W0 C0 P_last C_last   f: s_fc s_head
+    // t: constant block (int32 words), descriptor table (24 words per block + 16 head words; models/_lower_i8.py: tail_constants)
+    BN_OP_I8_TAIL = 30,
 };

@@ -1,0 +1,354 @@
+// bn_i8_tail.hip — the back half of the INT8 graph as ONE kernel: every block behind stage 2
+//
+//   DEPTHWISE_CONV_2D 3x3 (ReLU6) -> CONV_2D 1x1 on the int8 matrix cores [-> TFLite ADD with the block input]        (x n_layers)
+//   -> MEAN -> FULLY_CONNECTED -> LOGISTIC / DEQUANTIZE
+//
+// with the activation maps of kTailG chunks resident in LDS from the first block to the scores (reference operators: SURVEY.md
+// Appendix B ops #36-#55; models/dscnn.py:209-261 of the reference).  Same integer semantics as the per-block kernels
+// (bn_i8_strip.hip / bn_i8_fused.hip), bit-identical results; what changes is where the maps live and how the waves synchronise.
+//
+// The per-block kernels of these small maps (8 x 16 and 4 x 8 positions) spend 46-70 % of their wave cycles parked at the per-row
+// barrier that lets the waves of a strip exchange their depthwise outputs, and each of them reloads its constants per two chunks
+// (profiles/r02_i8_b4096_digest.md).  Here a workgroup of 16 waves owns kTailG = 4 chunks at a time:
+//
+//   * a WAVE owns a tile of 16 positions (one row of a 16-wide map, two rows of an 8-wide one) from the depthwise stage to the
+//     stored output: lane (n, kq) = (position n of the tile, lane group kq) reads the nine taps of ITS channels straight from the
+//     map in LDS (one ds_read_b32 per tap and channel quad, immediate offsets), and its depthwise outputs ARE its B fragments of
+//     v_mfma_i32_16x16x64_i8 for all Cin channels — no exchange between waves, so the only workgroup barrier is the one between
+//     blocks;
+//   * the pointwise weights of the block sit in LDS in fragment order (one ds_read_b128 per A operand, 1 KB per wave, conflict-free);
+//     the K order is permuted by the packer so that the quads of lane groups kq and kq ^ 1 lie 16 quads apart: with a map pitch of
+//     Cin + 4 bytes the 32 lanes of an LDS access cycle then hit 32 different banks;
+//   * output channels land four consecutive per lane (natural row order of the A operand): requantise, [ADD], pack, one
+//     ds_write_b32 into the next map.  The ADD cannot use the per-block kernels' 64 KB table here (the maps need the LDS): its two
+//     single-byte input rescales are 256-entry tables, the sum is requantised in registers;
+//   * SAME padding: a tap outside the map reads a row of zero points kept in LDS (an address select per tap and tile, no
+//     per-element test);
+//   * the first block streams its taps from global memory (its input map, 32 KB per chunk, never enters LDS);
+//   * after the last block: MEAN per (chunk, channel) thread, FULLY_CONNECTED per (chunk, class) thread, table + dequantise.
+//
+// LDS plan per block (computed on the host, bn::tail_plan): input map, output map, pointwise weights, depthwise / pointwise
+// constants, ADD tables, zero-point row — first fit into 160 KB; blocks whose maps do not fit make the plan fall back to the
+// per-block operators (bn_api.hip).
+#include "bn_kernels.h"
+#include "bn_requant.h"
+
+namespace bn {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int perm(int s0, int s1, uint32_t sel) { return (int)__builtin_amdgcn_perm((uint32_t)s0, (uint32_t)s1, sel); }
+__device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+__device__ __forceinline__ int med3(int v, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+// RoundingDivideByPOT(SRDHM(x, m), e) + zp with the rounding offset and the zero point in one addend (bn_i8_strip.hip: rq)
+__device__ __forceinline__ int rq(int x, int m, int c1, int e) {
+    const int v = srdhm_pos(x, m);
+    return (v + c1 + (v >> 31)) >> e;
+}
+
+// first channel quad of lane group kq (mirrors _tail_quad_base in models/_lower_i8.py)
+template <int CIN>
+__device__ __forceinline__ int pq_base(int kq) {
+    if constexpr (CIN == 128) return ((kq & 1) << 4) | ((kq >> 1) << 3);
+    else if constexpr (CIN == 256) return kq << 4;
+    else return kq << 2;
+}
+
+// One block for the kTailG chunks of the workgroup.  `lds` = the workgroup's LDS; maps are [chunk][position][C + 4 bytes].
+template <int CIN, int COUT, bool SRCG>
+__device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args& a, unsigned char* lds, int chunk0) {
+    constexpr int KS = CIN / 64;        // k-steps of v_mfma_i32_16x16x64_i8
+    constexpr int NTILES = COUT / 16;
+    constexpr int PIN = CIN + 4, POUT = COUT + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+
+    // ---- stage the block's constants: pointwise weights, depthwise / pointwise constants, ADD tables, zero-point row ----------
+    {
+        const v4i* g = reinterpret_cast<const v4i*>(a.cst);
+        v4i* dst = reinterpret_cast<v4i*>(lds + L.w_off);
+        for (int i = tid; i < CIN * COUT / 16; i += kTailThreads) dst[i] = g[L.g_w / 4 + i];
+        dst = reinterpret_cast<v4i*>(lds + L.dwc_off);
+        for (int i = tid; i < CIN * 7 / 4; i += kTailThreads) dst[i] = g[L.g_dwc / 4 + i];
+        dst = reinterpret_cast<v4i*>(lds + L.pwc_off);
+        for (int i = tid; i < COUT; i += kTailThreads) dst[i] = g[L.g_pwc / 4 + i];
+        if (L.has_add) {
+            dst = reinterpret_cast<v4i*>(lds + L.lut_off);
+            for (int i = tid; i < 128; i += kTailThreads) dst[i] = g[L.g_lut / 4 + i];
+        }
+        if (!SRCG && tid < PIN / 4) reinterpret_cast<int*>(lds + L.zp_off)[tid] = (L.zp_in & 0xff) * 0x01010101;
+    }
+    __syncthreads();
+
+    const int zp4 = (L.zp_in & 0xff) * 0x01010101;
+    const int per_chunk = L.OH * L.OW;          // output positions per chunk (a multiple of 16)
+    const int tiles = kTailG * per_chunk / 16;
+    const int ngrp = tiles >= kTailWaves ? 1 : kTailWaves / tiles;  // tiles are split over output-channel groups when there are few
+    const int nt_per = NTILES / ngrp;
+    const int qb = pq_base<CIN>(kq);
+    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.dwc_off) + qb * 7;
+    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.pwc_off);
+    const int* lut = reinterpret_cast<const int*>(lds + L.lut_off);
+
+    for (int u = wave; u < tiles * ngrp; u += kTailWaves) {
+        const int tile = u / ngrp, grp = u - tile * ngrp;
+        const int p = tile * 16 + n;                 // position over the kTailG chunks
+        const int g = p / per_chunk, pc = p - g * per_chunk;
+        const int oy = pc / L.OW, ox = pc - oy * L.OW;
+        int chunk = chunk0 + g;
+        if (chunk >= a.B) chunk = a.B - 1;           // ragged last group: the spare slots repeat the last chunk
+
+        // ---- depthwise 3x3 for all CIN channels of this lane's position -> B fragments --------------------------------------
+        v4i bf[KS];
+        {
+            int taddr[9];
+            bool tok[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int iy = oy * L.S - L.pt + dy, ix = ox * L.S - L.pl + dx;
+                    const bool ok = iy >= 0 && iy < L.H && ix >= 0 && ix < L.W;
+                    tok[dy * 3 + dx] = ok;
+                    if constexpr (SRCG) taddr[dy * 3 + dx] = ok ? (iy * L.W + ix) * CIN + 4 * qb : 0;
+                    else taddr[dy * 3 + dx] = (ok ? L.x_off + ((g * L.H + iy) * L.W + ix) * PIN : L.zp_off) + 4 * qb;
+                }
+            // (only the first block reads global memory; the other instantiations never use the descriptor)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * L.H * L.W * CIN : 0), 0, SRCG ? L.H * L.W * CIN : 0, 0x00020000);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                int frag[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qi = 4 * ks + j;   // quad qb + qi: channels 4 (qb + qi) ..
+                    int t[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        if constexpr (SRCG) {
+                            const int v = __builtin_amdgcn_raw_buffer_load_b32(rs, taddr[k] + 4 * qi, 0, 0);
+                            t[k] = tok[k] ? v : zp4;
+                        } else {
+                            t[k] = *reinterpret_cast<const int*>(lds + taddr[k] + 4 * qi);
+                        }
+                    }
+                    const v4i w0 = dwc[qi * 7 + 0], w1 = dwc[qi * 7 + 1], w2 = dwc[qi * 7 + 2], bias = dwc[qi * 7 + 3];
+                    const v4i m = dwc[qi * 7 + 4], c1 = dwc[qi * 7 + 5], sh = dwc[qi * 7 + 6];
+                    int T[3][4];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {  // bytes (tap0, tap1, tap2, 0) of each of the four channels
+                        const int r0 = t[dy * 3 + 0], r1 = t[dy * 3 + 1], r2 = t[dy * 3 + 2];
+                        const int lo = perm(r1, r0, 0x05010400u), hi = perm(r1, r0, 0x07030602u);
+                        T[dy][0] = perm(r2, lo, 0x0c040100u);
+                        T[dy][1] = perm(r2, lo, 0x0c050302u);
+                        T[dy][2] = perm(r2, hi, 0x0c060100u);
+                        T[dy][3] = perm(r2, hi, 0x0c070302u);
+                    }
+                    int qv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int acc = dot4(T[0][e], w0[e], bias[e]);
+                        acc = dot4(T[1][e], w1[e], acc);
+                        acc = dot4(T[2][e], w2[e], acc);
+                        qv[e] = med3(rq(acc, m[e], c1[e], sh[e]), L.dw_lo, L.dw_hi);
+                    }
+                    frag[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+                }
+                bf[ks] = (v4i){frag[0], frag[1], frag[2], frag[3]};
+            }
+        }
+
+        // ---- pointwise 1x1 on the matrix cores, requantise, [ADD], store into the next map ------------------------------------
+        const int q = kq;                                    // accumulator rows 4 q .. 4 q + 3 of a tile = output channels
+        const int yrow = L.y_off + p * POUT + 4 * q;
+        const int xrow = SRCG ? 0 : L.x_off + p * PIN + 4 * q;  // residual (blocks with the ADD have CIN == COUT, stride 1: same position)
+        const v4i* wl = reinterpret_cast<const v4i*>(lds + L.w_off) + lane;
+        for (int tt = 0; tt < nt_per; ++tt) {
+            const int nt = grp * nt_per + tt;
+            const v4i* pc4 = pwc + (nt * 4 + q) * 4;
+            v4i acc = pc4[0];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wl[(nt * KS + ks) * 64], bf[ks], acc, 0, 0, 0);
+            const v4i m = pc4[1], c1 = pc4[2], sh = pc4[3];
+            int res = 0;
+            if (L.has_add) res = *reinterpret_cast<const int*>(lds + xrow + 16 * nt);
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int v = med3(rq(acc[e], m[e], c1[e], sh[e]), L.pw_lo, L.pw_hi);  // with the ADD: value + 128 = index of the second table
+                if (L.has_add) {
+                    const int sa = lut[(res >> (8 * e)) & 0xff], sb = lut[256 + v];
+                    v = med3(rq(sa + sb, L.add_m, L.add_c1, L.add_e), L.add_lo, L.add_hi);
+                }
+                qv[e] = v;
+            }
+            *reinterpret_cast<int*>(lds + yrow + 16 * nt) = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kTailThreads) void i8_tail_kernel(Tail8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int ngroups = (a.B + kTailG - 1) / kTailG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int chunk0 = grp * kTailG;
+        for (int li = 0; li < a.n_layers; ++li) {
+            const Tail8Layer& L = a.L[li];
+            if (L.Cin == 64) tail_block<64, 128, true>(L, a, lds, chunk0);
+            else if (L.Cin == 128 && L.Cout == 128) tail_block<128, 128, false>(L, a, lds, chunk0);
+            else if (L.Cin == 128) tail_block<128, 256, false>(L, a, lds, chunk0);
+            else tail_block<256, 256, false>(L, a, lds, chunk0);
+        }
+        // ---- MEAN over the positions of the last map: one thread per (chunk slot, channel) ---------------------------------------
+        const Tail8Layer& L = a.L[a.n_layers - 1];
+        const int pitch = a.C + 4;
+        for (int i = tid; i < kTailG * a.C; i += kTailThreads) {
+            const int g = i / a.C, c = i - g * a.C;
+            const int8_t* src = reinterpret_cast<const int8_t*>(lds + L.y_off + g * a.P * pitch + c);
+            int s = 0;
+            for (int k = 0; k < a.P; ++k) s += src[k * pitch];
+            s -= a.mean_zp_in * a.P;
+            reinterpret_cast<int8_t*>(lds + a.mean_off)[i] = (int8_t)clampi(mbqm(s, a.mean_mult, a.mean_shift) + a.mean_zp_out, -128, 127);
+        }
+        __syncthreads();
+        // ---- FULLY_CONNECTED + head: one thread per (chunk slot, class) ----------------------------------------------------------
+        for (int i = tid; i < kTailG * a.NC; i += kTailThreads) {
+            const int g = i / a.NC, j = i - g * a.NC;
+            const int chunk = chunk0 + g;
+            if (chunk >= a.B) continue;
+            const int* xr = reinterpret_cast<const int*>(lds + a.mean_off + g * a.C);
+            const int* wr = a.cst + a.g_fcw + j * (a.C / 4);
+            int acc = a.cst[a.g_fcb + j];
+            for (int k = 0; k < a.C / 4; ++k) acc = dot4(xr[k], wr[k], acc);
+            const int qv = clampi(mbqm(acc, a.cst[a.g_fcm + j], a.cst[a.g_fcs + j]) + a.fc_zp_out, a.fc_lo, a.fc_hi);
+            const size_t o = (size_t)chunk * a.NC + j;
+            if (a.logits) a.logits[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
+            if (a.g_hlut >= 0) {
+                const int ov = reinterpret_cast<const int8_t*>(a.cst + a.g_hlut)[qv + 128];
+                a.scores[o] = (float)(ov - a.head_zp_out) * a.s_head;
+            } else {
+                a.scores[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
+            }
+        }
+        __syncthreads();  // the next group overwrites the maps
+    }
+}
+
+// first-fit allocator over the workgroup's LDS: `used` holds [begin, end) intervals that must stay intact
+struct Span {
+    int b, e;
+};
+int first_fit(std::vector<Span>& used, int bytes, int cap) {
+    bytes = (bytes + 15) & ~15;
+    int pos = 0;
+    for (;;) {
+        bool moved = false;
+        for (const Span& s : used)
+            if (pos < s.e && pos + bytes > s.b) {
+                pos = (s.e + 15) & ~15;
+                moved = true;
+            }
+        if (!moved) break;
+    }
+    if (pos + bytes > cap) return -1;
+    used.push_back({pos, pos + bytes});
+    return pos;
+}
+
+}  // namespace
+
+// Build the kernel arguments from the descriptor table the packer wrote (24 words per block + 16 head words) and plan the LDS of
+// every block.  Returns false when the topology is not one the kernel takes or a block's maps do not fit 160 KB.
+bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a) {
+    constexpr int LW = 24, HW = 16, CAP = 160 * 1024;
+    if (n_layers < 1 || n_layers > 8 || n_words != LW * n_layers + HW) return false;
+    a.n_layers = n_layers;
+    int cur_off = -1;   // where the current input map lives (-1: global memory)
+    int lds_need = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const int32_t* d = desc + LW * i;
+        Tail8Layer& L = a.L[i];
+        L.H = d[0]; L.W = d[1]; L.Cin = d[2]; L.Cout = d[3]; L.S = d[4]; L.OH = d[5]; L.OW = d[6]; L.pt = d[7]; L.pl = d[8]; L.has_add = d[9];
+        L.zp_in = d[10]; L.dw_lo = d[11]; L.dw_hi = d[12]; L.pw_lo = d[13]; L.pw_hi = d[14];
+        L.add_m = d[15]; L.add_c1 = d[16]; L.add_e = d[17]; L.add_lo = d[18]; L.add_hi = d[19];
+        L.g_w = d[20]; L.g_dwc = d[21]; L.g_pwc = d[22]; L.g_lut = d[23];
+        const bool first = i == 0;
+        const bool shape_ok = (first && L.Cin == 64 && L.Cout == 128) || (!first && L.Cin == 128 && (L.Cout == 128 || L.Cout == 256)) ||
+                              (!first && L.Cin == 256 && L.Cout == 256);
+        if (!shape_ok || (L.S != 1 && L.S != 2) || L.OH != (L.H + L.S - 1) / L.S || L.OW != (L.W + L.S - 1) / L.S || (L.OH * L.OW) % 16 ||
+            L.pt < 0 || L.pt > 1 || L.pl < 0 || L.pl > 1 || L.H < 1 || L.W < 1 || L.H * L.W > 4096)
+            return false;
+        if (L.has_add && (L.Cin != L.Cout || L.S != 1 || L.g_lut < 0 || L.add_e < 1 || L.add_e > 22 || L.add_m < 0)) return false;
+        if (i > 0 && (L.H != a.L[i - 1].OH || L.W != a.L[i - 1].OW || L.Cin != a.L[i - 1].Cout)) return false;
+        const int tiles = kTailG * L.OH * L.OW / 16;
+        if (tiles < kTailWaves && (kTailWaves % tiles || (L.Cout / 16) % (kTailWaves / tiles))) return false;
+        if ((L.g_w | L.g_dwc | L.g_pwc) & 3 || (L.has_add && (L.g_lut & 3))) return false;
+        std::vector<Span> used;
+        L.x_off = cur_off;
+        if (cur_off >= 0) used.push_back({cur_off, cur_off + kTailG * L.H * L.W * (L.Cin + 4)});
+        L.y_off = first_fit(used, kTailG * L.OH * L.OW * (L.Cout + 4), CAP);
+        L.w_off = first_fit(used, L.Cin * L.Cout, CAP);
+        L.dwc_off = first_fit(used, L.Cin * 28, CAP);
+        L.pwc_off = first_fit(used, L.Cout * 16, CAP);
+        L.lut_off = L.has_add ? first_fit(used, 2048, CAP) : 0;
+        L.zp_off = first_fit(used, L.Cin + 16, CAP);
+        if (L.y_off < 0 || L.w_off < 0 || L.dwc_off < 0 || L.pwc_off < 0 || L.lut_off < 0 || L.zp_off < 0) return false;
+        if (i == n_layers - 1) {
+            a.mean_off = first_fit(used, kTailG * L.Cout, CAP);
+            if (a.mean_off < 0) return false;
+        }
+        for (const Span& s : used) lds_need = s.e > lds_need ? s.e : lds_need;
+        cur_off = L.y_off;
+    }
+    const int32_t* h = desc + LW * n_layers;
+    a.mean_zp_in = h[0]; a.mean_mult = h[1]; a.mean_shift = h[2]; a.mean_zp_out = h[3];
+    a.fc_zp_out = h[4]; a.fc_lo = h[5]; a.fc_hi = h[6]; a.g_fcw = h[7]; a.g_fcb = h[8]; a.g_fcm = h[9]; a.g_fcs = h[10]; a.g_hlut = h[11];
+    a.head_zp_fc = h[12]; a.head_zp_out = h[13]; a.P = h[14]; a.C = h[15];
+    const Tail8Layer& last = a.L[n_layers - 1];
+    if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 4 || a.NC < 1 || kTailG * a.NC > kTailThreads * 4) return false;
+    a.lds_bytes = lds_need;
+    return true;
+}
+
+// words of the constant block the kernel reads (for the load-time check of the tensor's size)
+long tail_const_words(const Tail8Args& a) {
+    long need = 0;
+    auto upto = [&](long off, long words) { need = off + words > need ? off + words : need; };
+    for (int i = 0; i < a.n_layers; ++i) {
+        const Tail8Layer& L = a.L[i];
+        upto(L.g_w, (long)L.Cin * L.Cout / 4);
+        upto(L.g_dwc, (long)L.Cin * 7);
+        upto(L.g_pwc, (long)L.Cout * 4);
+        if (L.has_add) upto(L.g_lut, 512);
+    }
+    upto(a.g_fcw, (long)a.NC * a.C / 4);
+    upto(a.g_fcb, a.NC);
+    upto(a.g_fcm, a.NC);
+    upto(a.g_fcs, a.NC);
+    if (a.g_hlut >= 0) upto(a.g_hlut, 64);
+    return need;
+}
+
+bool launch_i8_tail(Tail8Args a, hipStream_t s) {
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(i8_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return false;
+        raised = true;
+    }
+    const int ngroups = (a.B + kTailG - 1) / kTailG;
+    int cus = 256;
+    const int grid = ngroups < cus ? ngroups : cus;  // one workgroup per CU (its LDS), each walks over its share of the chunk groups
+    hipLaunchKernelGGL(i8_tail_kernel, dim3(grid), dim3(kTailThreads), (size_t)a.lds_bytes, s, a);
+    return true;
+}
+
+}  // namespace bn

@@ -218,6 +218,33 @@ bool i8_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW);
 void launch_i8_front_strip(FrontStrip8Args a, hipStream_t s);
 bool i8_strip_supported(int Cin, int Cout, int stride, int OW, bool add);
 void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s);
+// The back half of the INT8 graph as one kernel with the maps in LDS (bn_i8_tail.hip).
+constexpr int kTailG = 4;          // chunks a workgroup holds at a time (models/_lower_i8.py: TAIL_G)
+constexpr int kTailWaves = 16;
+constexpr int kTailThreads = 64 * kTailWaves;
+struct Tail8Layer {
+    int H, W, Cin, Cout, S, OH, OW, pt, pl, has_add;
+    int zp_in, dw_lo, dw_hi, pw_lo, pw_hi;        // clamp bounds (pointwise: + 128 with the ADD)
+    int add_m, add_c1, add_e, add_lo, add_hi;     // output rescale of the ADD (zero point folded into c1) and its clamp
+    int g_w, g_dwc, g_pwc, g_lut;                 // word offsets of the block's sections in the constant block
+    int x_off, y_off, w_off, dwc_off, pwc_off, lut_off, zp_off;  // LDS byte offsets (x_off < 0: the input map is in global memory)
+};
+struct Tail8Args {
+    const int8_t* x;      // [B][H0][W0][C0]: input map of the first block
+    float* scores;        // [B][NC]
+    float* logits;        // [B][NC] or null
+    const int32_t* cst;   // constant block (models/_lower_i8.py: tail_constants)
+    int B, n_layers, NC, P, C;
+    int mean_zp_in, mean_mult, mean_shift, mean_zp_out, mean_off;
+    int fc_zp_out, fc_lo, fc_hi, g_fcw, g_fcb, g_fcm, g_fcs, g_hlut, head_zp_fc, head_zp_out;
+    float s_fc, s_head;
+    int lds_bytes;
+    Tail8Layer L[8];
+};
+bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a);  // a.NC must be set; false = not a topology / size the kernel takes
+long tail_const_words(const Tail8Args& a);
+bool launch_i8_tail(Tail8Args a, hipStream_t s);
+
 // INT8 stem 3x3 + depthwise 3x3 stride 2 + pointwise in one kernel (bn_i8_fused.hip)
 struct I8FrontParams {
     const int8_t* stem_w; const int32_t* stem_b; const int32_t* stem_mult; const int32_t* stem_shift;

@@ -237,6 +237,11 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                     c.tensor(10, 4LL * p[3], "pointwise multipliers") && c.tensor(11, 4LL * p[3], "pointwise shifts") && (!p[16] || o.t[12] < 0 || c.tensor(12, 496 * 4, "strip constants"));
                 if (c.ok && (p[4] != (p[0] + 1) / 2 || p[5] != ((p[1] + 1) / 2 + 1) / 2)) c.bad("front block output %dx%d does not follow from %dx%d", p[4], p[5], p[0], p[1]);
                 break;
+            case BN_OP_I8_TAIL:  // in_bytes pw_macs dw_macs other_macs n_classes n_layers H0 W0 C0 P_last C_last
+                c.dims({p[0], p[4], p[5], p[6], p[7], p[8]}, "fused tail") && c.slot(o.in0, 1LL * p[6] * p[7] * p[8], "input map") && c.slot(o.out, 4LL * p[4], "scores") &&
+                    c.tensor(0, 16, "constant block") && c.tensor(1, 4LL * (24 * p[5] + 16), "descriptor table");
+                if (c.ok && (p[4] != (int)h.num_classes || p[5] > 8 || p[BN_OP_TAIL_TAG] != BN_TAIL_OP)) c.bad("fused tail header");
+                break;  // the descriptor table itself is validated by bn::tail_plan at load (bn_api.hip)
             default:
                 c.bad("unknown operator kind");
                 break;

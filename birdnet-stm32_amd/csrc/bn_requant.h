@@ -2,8 +2,9 @@
 //
 //   MultiplyByQuantizedMultiplier(x, M0, shift) = RoundingDivideByPOT(SaturatingRoundingDoublingHighMul(x << left, M0), right)
 //
-// The fast forms below are algebraically identical to the reference definitions for M0 >= 0 and |x| < 2^30 (every
-// accumulator of the supported graphs: |x| <= K * 127 * 255 + |bias|, and (q - zp) << 20 < 2^28 in ADD):
+// The fast forms below are algebraically identical to the reference definitions for M0 >= 0 whenever |x| * M0 / 2^31 + 2^(e-1) + 1
+// stays below 2^31 (e = the right shift) — in particular for |x| < 2^30.  The lowering pass proves that bound per channel from the
+// weights and the folded bias before a plan is built (models/_lower_i8.py: _expect_acc_range; (q - zp) << 20 < 2^28 in ADD):
 //   SRDHM: trunc((x*M0 + nudge) / 2^31), nudge = 2^30 for x*M0 >= 0 and 1 - 2^30 otherwise, equals the ARITHMETIC shift
 //          (x*M0 + 2^30) >> 31 for both signs (for negatives trunc(y/2^31) = floor((y + 2^31 - 1)/2^31) and the nudges differ
 //          by exactly 2^31 - 1), i.e. one 32x32+64 -> 64 multiply-add (v_mad_i64_i32) and a funnel shift;

@@ -66,6 +66,39 @@ def cosine(a, b) -> float:
     return float(a @ b / (na * nb))
 
 
+I32_MIN, I32_MAX = -(1 << 31), (1 << 31) - 1
+
+
+# gemmlowp fixed-point definitions, literally, on Python integers (the yardstick for oracle/int8_graph.py and csrc/bn_requant.h)
+def srdhm_def(a: int, b: int) -> int:
+    """SaturatingRoundingDoublingHighMul (gemmlowp fixedpoint.h): saturate only for INT32_MIN x INT32_MIN, nudge by +-2^30, divide by
+    2^31 truncating toward zero."""
+    if a == b == I32_MIN:
+        return I32_MAX
+    ab = a * b
+    nudge = (1 << 30) if ab >= 0 else 1 - (1 << 30)
+    v = ab + nudge
+    return v // (1 << 31) if v >= 0 else -((-v) // (1 << 31))
+
+
+def rdivpot_def(x: int, e: int) -> int:
+    """RoundingDivideByPOT: arithmetic shift, ties away from zero."""
+    mask = (1 << e) - 1
+    rem = x & mask
+    thr = (mask >> 1) + (1 if x < 0 else 0)
+    return (x >> e) + (1 if rem > thr else 0)
+
+
+def wrap32(v: int) -> int:
+    return ((v + (1 << 31)) % (1 << 32)) - (1 << 31)
+
+
+def mbqm_def(x: int, m: int, shift: int) -> int:
+    left, right = max(shift, 0), max(-shift, 0)
+    return rdivpot_def(srdhm_def(wrap32(x * (1 << left)), m), right)
+
+
+
 @pytest.fixture(scope="session")
 def has_gpu():
     import torch

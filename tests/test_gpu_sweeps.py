@@ -16,12 +16,9 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import KERAS_PATH, TFLITE_PATH, cosine, synth_chunks
+from conftest import I32_MAX, I32_MIN, KERAS_PATH, TFLITE_PATH, cosine, mbqm_def, synth_chunks
 
 pytestmark = pytest.mark.gpu
-
-I32_MIN, I32_MAX = -(1 << 31), (1 << 31) - 1
-
 
 @pytest.fixture(scope="module")
 def torch_mod():
@@ -30,35 +27,6 @@ def torch_mod():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     return torch
-
-
-# ----------------------------------------------------------------------------- gemmlowp definitions, literally (Python integers)
-def srdhm_def(a: int, b: int) -> int:
-    """SaturatingRoundingDoublingHighMul (gemmlowp fixedpoint.h): saturate only for INT32_MIN x INT32_MIN, nudge by +-2^30, divide by
-    2^31 truncating toward zero."""
-    if a == b == I32_MIN:
-        return I32_MAX
-    ab = a * b
-    nudge = (1 << 30) if ab >= 0 else 1 - (1 << 30)
-    v = ab + nudge
-    return v // (1 << 31) if v >= 0 else -((-v) // (1 << 31))
-
-
-def rdivpot_def(x: int, e: int) -> int:
-    """RoundingDivideByPOT: arithmetic shift, ties away from zero."""
-    mask = (1 << e) - 1
-    rem = x & mask
-    thr = (mask >> 1) + (1 if x < 0 else 0)
-    return (x >> e) + (1 if rem > thr else 0)
-
-
-def wrap32(v: int) -> int:
-    return ((v + (1 << 31)) % (1 << 32)) - (1 << 31)
-
-
-def mbqm_def(x: int, m: int, shift: int) -> int:
-    left, right = max(shift, 0), max(-shift, 0)
-    return rdivpot_def(srdhm_def(wrap32(x * (1 << left)), m), right)
 
 
 def _requant_cases():
@@ -106,16 +74,21 @@ def test_requant_forms_match_gemmlowp_definitions(torch_mod):
         got = run(right, 3, zp)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, f"strip form, zp {zp}: first mismatch {right[bad[0]]}: got {got[bad[0]]}, want {want[bad[0]]}"
-    # the general forms outside the fast path's domain
+    # outside the fast forms' domain (|x| >= 2^30, left shifts, negative multipliers): the literal definitions (mode 1) everywhere,
+    # the dispatching form (mode 0) wherever |x| < 2^30 — the bound the lowering pass proves for every accumulator (_lower_i8.py)
     wide = [(I32_MIN, I32_MIN, 0), (I32_MIN, I32_MIN, -1), (I32_MIN, I32_MAX, 0), (I32_MAX, I32_MAX, 0), (I32_MAX, I32_MIN + 1, -3),
             (I32_MIN, 1 << 30, -31), (I32_MAX, (1 << 31) - 1, -31), (-1, 1 << 30, -31), (5, 1 << 30, 0), (-5, 1 << 30, 0),
             (1000, 1 << 30, 3), (-1000, 1 << 30, 3), (1 << 26, 1518500250, 4), (-(1 << 26), 1518500250, 4), (77, -(1 << 30), -2), (-77, -(1 << 30), -2),
-            (123456, -1518500250, -5), (-123456, -1518500250, 2), (0, 0, 0), (99, 0, -4)]
+            (123456, -1518500250, -5), (-123456, -1518500250, 2), (0, 0, 0), (99, 0, -4), ((1 << 30) - 1, (1 << 31) - 1, -31), (-(1 << 30) + 1, (1 << 31) - 1, -31),
+            ((1 << 30) - 1, (1 << 31) - 1, 0), (-(1 << 30) + 1, 1 << 30, -1)]
     want = np.array([mbqm_def(*c) for c in wide], np.int64)
-    for mode in (0, 1):
-        got = run(wide, mode)
-        bad = np.nonzero(got != want)[0]
-        assert bad.size == 0, f"mode {mode}: first mismatch {wide[bad[0]]}: got {got[bad[0]]}, want {want[bad[0]]}"
+    got = run(wide, 1)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"mode 1: first mismatch {wide[bad[0]]}: got {got[bad[0]]}, want {want[bad[0]]}"
+    inside = [i for i, c in enumerate(wide) if abs(c[0]) < (1 << 30)]
+    got = run([wide[i] for i in inside], 0)
+    bad = np.nonzero(got != want[inside])[0]
+    assert bad.size == 0, f"mode 0: first mismatch {wide[inside[bad[0]]]}: got {got[bad[0]]}, want {want[inside[bad[0]]]}"
     ctx.close()
 
 
@@ -301,3 +274,44 @@ def test_config5_full_batch_properties(torch_mod):
         assert 1.0 - cosine(got[b], ref[b]) < 1e-5
     big.close()
     small.close()
+
+
+# ------------------------------------------------------------------------------------------ fused INT8 tail
+def test_i8_fused_tail_matches_per_block_kernels_and_oracle(torch_mod):
+    """The back half of the INT8 graph as one kernel (i8_tail_kernel: stage 3-4 + MEAN + FULLY_CONNECTED + head, maps in LDS) against
+    the per-block kernels it replaces (option i8_tail = 0) and the oracle: scores and pre-sigmoid outputs bit for bit, for batch sizes
+    that leave the last group of four chunks ragged, repeated launches, and from audio."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models.runners import load_model_runner
+
+    path = _c_int8_path()
+    rng = np.random.default_rng(21)
+    S = np.empty((261, 257, 256, 1), np.float32)
+    S[:200] = path.spectrogram(synth_chunks(200, seed=5), 281, 256)
+    S[200:] = rng.random((61, 257, 256, 1), dtype=np.float32)
+    want = path.invoke(S)
+    runner = load_model_runner(TFLITE_PATH, max_batch=261)
+    tail = [o for o in runner.plan.ops if o.kind == pk.I8_TAIL]
+    assert len(tail) == 1 and sum(o.p[pk.TAIL_TAG] == pk.TAIL_COVERED for o in runner.plan.ops) == 9
+    x = torch.from_numpy(S.reshape(261, -1)).cuda()
+    with _hip.options(i8_tail=0):
+        base_s, base_l = (t.clone() for t in runner.predict_device(x, return_logits=True))
+    assert np.array_equal(base_s.cpu().numpy(), want)
+    for rep in range(6):
+        for nb in (261, 1, 2, 3, 5, 37, 64):
+            s, l = runner.predict_device(x[:nb], return_logits=True)
+            assert torch.equal(s, base_s[:nb]) and torch.equal(l, base_l[:nb]), f"batch {nb}, launch {rep}"
+    # profiling rows: the tail operator is the one that ran
+    runner.profile(True)
+    runner.predict_device(x)
+    rows = {r["kind"]: r["launches"] for r in runner.profile_collect() if r["launches"]}
+    runner.profile(False)
+    assert rows.get("i8_tail") == 1 and "i8_mean" not in rows
+    audio = torch.from_numpy(synth_chunks(70, seed=9)).cuda()
+    a1 = runner.infer_audio_device(audio).clone()
+    with _hip.options(i8_tail=0):
+        a0 = runner.infer_audio_device(audio)
+    assert torch.equal(a0, a1)
+    runner.close()

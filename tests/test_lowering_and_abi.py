@@ -32,7 +32,30 @@ def test_fused_plan_structure():
     assert (f32.ops[2].p[9], f32.ops[3].p[9]) == (0, 1)
     assert sum(1 for o in f32.ops if o.kind == pk.F32_DWPW and o.p[12]) == 7  # residual blocks
     kinds = [pk.KIND_NAMES[o.kind] for o in i8.ops]
-    assert kinds == ["i8_dwpw", "i8_front"] + ["i8_dwpw"] * 10 + ["i8_mean", "i8_fc", "i8_head"]
+    assert kinds == ["i8_dwpw", "i8_front"] + ["i8_dwpw"] * 10 + ["i8_mean", "i8_fc", "i8_head", "i8_tail"]
+    # the fused tail operator covers stage 3-4 + MEAN + FC + head (9 operators, kept in the plan for the i8_tail = 0 path)
+    tail = i8.ops[-1]
+    assert tail.p[pk.TAIL_TAG] == pk.TAIL_OP and [o.p[pk.TAIL_TAG] == pk.TAIL_COVERED for o in i8.ops[:-1]] == [False] * 6 + [True] * 9
+    assert tail.in0 == i8.ops[6].in0 and tail.out == pk.SLOT_SCORES and tail.p[:11] == [16 * 32 * 64, 10485760, 626688, 32 * 256 + 256 * 100, 100, 6, 16, 32, 64, 32, 256]
+    desc = i8.tensors[tail.t[1]]
+    assert desc.size == 24 * 6 + 16 and desc[:10].tolist() == [16, 32, 64, 128, 2, 8, 16, 0, 0, 0] and desc[24 * 5 : 24 * 5 + 10].tolist() == [4, 8, 256, 256, 1, 4, 8, 1, 1, 1]
+    # pointwise A fragments of a tail block: lane (m, kq), byte b of k-step ks = W[16 nt + m][4 (base[kq] + 4 ks + (b >> 2)) + (b & 3)]
+    from birdnet_stm32.models._lower_i8 import _tail_quad_base
+
+    blk = i8.ops[7]  # stage3_ds2: 128 -> 128
+    w2 = np.zeros((128, 128), np.int8)
+    fr_old = i8.tensors[blk.t[4]].reshape(2, 8, 64, 16)  # generic fragment order [K/64][N/16][lane][16]: lane (q, c) -> W[16 ct + c][64 s + 16 q ..]
+    for s_ in range(2):
+        for ct in range(8):
+            for lane in range(64):
+                w2[16 * ct + (lane & 15), 64 * s_ + 16 * (lane >> 4) : 64 * s_ + 16 * (lane >> 4) + 16] = fr_old[s_, ct, lane]
+    g_w = int(desc[24 * 1 + 20])
+    frag = i8.tensors[tail.t[0]][g_w : g_w + 128 * 128 // 4].view(np.int8).reshape(8, 2, 64, 16)
+    base = _tail_quad_base(128)
+    for nt, ks, lane, b in ((0, 0, 0, 0), (3, 1, 37, 9), (7, 1, 63, 15), (5, 0, 18, 6)):
+        assert frag[nt, ks, lane, b] == w2[16 * nt + (lane & 15), 4 * (base[lane >> 4] + 4 * ks + (b >> 2)) + (b & 3)]
+    _, i8_dbg2 = _plans(keep_all=True, fuse=True)
+    assert all(o.kind != pk.I8_TAIL for o in i8_dbg2.ops)  # keep_all plans keep every tensor visible: no fused tail
     mel = i8.ops[0]  # the mel mixer: QUANTIZE fused into its load (float32 spectrogram in), transposed output + PWL table
     assert mel.in0 == pk.SLOT_INPUT and mel.p[36] == 1 and mel.p[5] == 257 and mel.p[30] == 1 and mel.p[34] == 1 and mel.f[0] > 0
     _, i8_dbg = _plans(keep_all=True, fuse=True)  # debug plans keep QUANTIZE as its own operator (its tensor can be compared)

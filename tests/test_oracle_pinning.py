@@ -330,3 +330,45 @@ def test_c_int8_port_is_identical_to_the_numpy_interpreter():
     for k, v in env.items():
         assert np.array_equal(np.asarray(v), np.asarray(env_c[k])), f"tensor {k} differs"
     assert np.abs(port.spectrogram(x, 281, 256) - S).max() < 1e-6  # the C STFT of the float port
+
+
+def test_int8_primitives_match_gemmlowp_definitions_on_edge_cases():
+    """oracle/int8_graph.py's fixed-point primitives (and the lowering pass's own copies in models/_quant.py) against the published
+    gemmlowp definitions written out on Python integers (tests/conftest.py): INT32_MIN x INT32_MIN saturation, negative-half ties of the
+    rounding shift, shifts 0..31, left shifts with wrap-around, and QuantizeMultiplier where the mantissa rounds up to 2^31."""
+    from birdnet_stm32.models import _quant as qz
+    from conftest import I32_MAX, I32_MIN, mbqm_def, rdivpot_def, srdhm_def
+    from oracle import int8_graph as ig
+
+    rng = np.random.default_rng(8)
+    edge = [0, 1, -1, 2, -2, 3, -3, I32_MAX, I32_MIN, I32_MIN + 1, I32_MAX - 1, 1 << 30, -(1 << 30), (1 << 30) - 1, 12345, -12345]
+    pairs = [(a, b) for a in edge for b in edge] + list(zip(rng.integers(I32_MIN, I32_MAX, 4000).tolist(), rng.integers(I32_MIN, I32_MAX, 4000).tolist()))
+    a, b = np.array([p[0] for p in pairs], np.int64), np.array([p[1] for p in pairs], np.int64)
+    want = np.array([srdhm_def(*p) for p in pairs], np.int64)
+    assert np.array_equal(ig.srdhm(a, b), want) and np.array_equal(qz._high_mul(a, b), want)
+    assert srdhm_def(I32_MIN, I32_MIN) == I32_MAX and srdhm_def(I32_MIN, I32_MAX) == -I32_MAX
+    xs = edge + rng.integers(I32_MIN, I32_MAX, 2000).tolist()
+    for e in (0, 1, 2, 3, 7, 8, 20, 30, 31):
+        x = np.array(xs, np.int64)
+        want = np.array([rdivpot_def(v, e) for v in xs], np.int64)
+        assert np.array_equal(ig.rounding_divide_by_pot(x, e), want) and np.array_equal(qz._round_shift(x, e), want), e
+    # ties: -(2k+1) * 2^(e-1) rounds away from zero (towards -inf), the positive tie up
+    for e in (1, 4, 9):
+        h = 1 << (e - 1)
+        assert [rdivpot_def(v, e) for v in (-h, h, -3 * h, 3 * h)] == [-1, 1, -2, 2]
+        assert ig.rounding_divide_by_pot(np.array([-h, h, -3 * h, 3 * h]), e).tolist() == [-1, 1, -2, 2]
+    cases = [(x, m, s) for x in (5, -5, 1000, -1000, (1 << 29) + 3, -(1 << 29) - 3) for m in (1 << 30, 1518500250, I32_MAX, -(1 << 30), -1518500250)
+             for s in (-31, -12, -1, 0, 1, 3)]
+    for x, m, s in cases:
+        want = mbqm_def(x, m, s)
+        if abs(x << max(s, 0)) < (1 << 31):  # the numpy forms do not wrap a left shift; TFLite's int32 arithmetic would
+            assert int(ig.mbqm(np.array([x]), m, s)[0]) == want == int(qz.requantize(np.array([x]), m, s)[0]), (x, m, s)
+    # QuantizeMultiplier: mantissa in [2^30, 2^31), rounding up to 2^31 renormalises, tiny and huge reals saturate
+    for real, want in ((1.0, (1 << 30, 1)), (0.5, (1 << 30, 0)), (0.75, (3 << 29, 0)), (1.0 - 2.0**-33, (1 << 30, 1)), (0.0, (0, 0)),
+                       (2.0**-40, (0, 0)), (2.0**31, (I32_MAX, 30)), (6.0 / 255.0 * 0.0123 / (6.0 / 255.0), None)):
+        got = ig.quantize_multiplier(real)
+        assert got == qz.quantize_multiplier(real)
+        if want is not None:
+            assert got == want, (real, got)
+        else:
+            assert (1 << 30) <= got[0] < (1 << 31) and abs(got[0] * 2.0 ** (got[1] - 31) - real) <= real * 2.0**-31

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Digest rocprofv3 outputs of a bench.py run into the small tables kept under profiles/.
 
-    python tools/profile_digest.py <stats_dir> <fetch_dir> <write_dir> <sq_dir> <steps_in_pmc_runs> <out_md>
+    python tools/profile_digest.py <stats_dir> <fetch_dir> <write_dir> <sq_dir> <out_md> [<sq2_dir> [<bench_json>]]
+
+* kernel-trace --stats: calls, total / average duration per kernel (product kernels only);
+* SQ passes: instruction mix per wave; with the second pass (<sq2_dir>) the wave-cycle breakdown (parked in s_waitcnt / barrier,
+  issue-stalled, issuing) and the matrix-pipe busy share: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES);
+* with <bench_json> (the JSON line of the same bench.py command): each operator's 1x1-convolution OP/s as a fraction of the
+  dense matrix-core peak (5 POP/s int8, 157.3 TFLOP/s float32), from its HIP-event time;
 
 * kernel-trace --stats: calls, total / average duration per kernel (product kernels only);
 * --pmc FETCH_SIZE / WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes): HBM bytes per launch.
@@ -32,6 +38,8 @@ def pmc(dirname):
 
 def main():
     stats_dir, fetch_dir, write_dir, sq_dir, out = sys.argv[1:6]
+    sq2_dir = sys.argv[6] if len(sys.argv) > 6 else None
+    bench_json = sys.argv[7] if len(sys.argv) > 7 else None
     lines = ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for f in glob.glob(stats_dir + "/**/*kernel_stats.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -51,8 +59,39 @@ def main():
         hit = 100 * mean(h) / max(mean(h) + mean(ms), 1)
         lines.append(f"| {key[0]} | {key[1]} | {2*mean(f)/1024:.1f} | {mean(w)/1024:.1f} | {hit:.0f} | {mean(s.get('SQ_INSTS_VALU',[0]))/waves:.0f} | "
                      f"{mean(s.get('SQ_INSTS_MFMA',[0]))/waves:.1f} | {mean(s.get('SQ_LDS_BANK_CONFLICT',[0]))/waves:.0f} |")
-    # machine-readable HBM traffic per launch (bytes), read back by bench.py for roofline.traffic
     import json
+
+    if sq2_dir:
+        s2 = pmc(sq2_dir)
+        lines += ["", "| kernel | grid | wave cycles/wave | parked (s_waitcnt, barrier) % | issue-stalled % | issuing % | LDS insts/wave | matrix pipe busy % of CU-busy time |",
+                  "|---|---|---|---|---|---|---|---|"]
+        mean = lambda v: sum(v) / max(len(v), 1)  # noqa: E731
+        for key in sorted(s2):
+            c = s2[key]
+            a = sq.get(key, {})
+            waves = mean(c.get("SQ_WAVES", [1])) or 1
+            wc = mean(c.get("SQ_WAVE_CYCLES", [0])) or 1
+            busy_cu = mean(c.get("SQ_BUSY_CU_CYCLES", [0]))
+            mfma_busy = mean(a.get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))
+            # SQ_BUSY_CU_CYCLES counts quad-cycles per CU, SQ_VALU_MFMA_BUSY_CYCLES cycles per SIMD (MI355X_MICROARCH.md: units of SQ counters)
+            pipe = 100 * mfma_busy / max(16 * busy_cu, 1)
+            lines.append(f"| {key[0]} | {key[1]} | {4 * wc / waves:.0f} | {100 * mean(c.get('SQ_WAIT_ANY', [0])) / wc:.0f} | "
+                         f"{100 * mean(c.get('SQ_WAIT_INST_ANY', [0])) / wc:.0f} | {100 * mean(c.get('SQ_ACTIVE_INST_ANY', [0])) / wc:.0f} | "
+                         f"{mean(c.get('SQ_INSTS_LDS', [0])) / waves:.0f} | {pipe:.1f} |")
+    if bench_json:
+        try:
+            b = json.loads([ln for ln in open(bench_json).read().splitlines() if ln.startswith("{")][-1])
+            lines += ["", f"Per-operator times of the same command ({b['dtype']}, batch {b['config']['batch_per_gpu']}; HIP events on the launch stream): "
+                          "algorithmic HBM rate and 1x1-convolution matrix-core rate as fractions of peak (8 TB/s; 5 POP/s int8 / 157.3 TFLOP/s f32)", "",
+                      "| operator | kernel | avg ms | GB/s | % of HBM peak | TOP/s (all ops) | 1x1 OP/s as % of matrix-core peak |", "|---|---|---|---|---|---|---|"]
+            for st in b["stages"]:
+                lines.append(f"| {st['layer']} | {st.get('symbol', st['kernel'])} | {st['avg_ms']} | {st['GBps']} | {100 * st.get('hbm_frac', 0):.1f} | {st['Tops']} | {100 * st.get('mfma_frac', 0):.2f} |")
+            lines += ["", f"whole path: {b['value']} chunks/s, {b['ms_per_step']} ms/step, all matrix-core work (53.08 MOP/chunk) at "
+                          f"{100 * b.get('whole_path_mfma_frac', 0):.2f} % of peak"]
+        except Exception as e:  # pragma: no cover
+            lines += ["", f"(bench JSON not digested: {e})"]
+
+    # machine-readable HBM traffic per launch (bytes), read back by bench.py for roofline.traffic
 
     traffic = []
     for key in sorted(set(fe) | set(wr)):
