@@ -359,8 +359,8 @@ def tail_constants(blocks: list[dict], head: dict):
         add = b["add"]
         rq_dw = _strip_requant(b["mu"], b["sh_dw"], b["z_dw"], lo_dw, hi_dw)
         rq_pw = _strip_requant(b["mu2"], b["sh2"], b["z_pw"] + (128 if add[0] else 0), lo_pw, hi_pw)
-        if rq_dw is None or rq_pw is None:
-            return None
+        if rq_dw is None or rq_pw is None or b["dw_lo"] < b["z_dw"] or (not add[0] and b["pw_lo"] < b["z_pw"]):
+            return None  # (the kernel drops the sign term of the rounding shift where a negative result clamps to the zero point anyway)
         luts, add_m, add_c1, add_e, add_lo, add_hi = None, 0, 0, 1, 0, 0
         if add[0]:
             _, z1, m1, s1, m2, s2, mo, so, zo, amin, amax = add
@@ -543,7 +543,9 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                     _expect_acc_range(wtd.data[0], bd, (0, 1), f"depthwise conv of operator #{d_op.index}", mud, shd)
                     _expect_acc_range(wpw, bp, 1, f"pointwise conv of operator #{p_op.index}", mup, shp)
                     v = pb.value(BH * BW * N)
-                    cst = front_strip_constants(w, b, mu, sh, z_i, z_o, wtd.data[0], bd, mud, shd, zdo, wpw, bp, mup, shp, zpo) if BW % 16 == 0 else None
+                    # (the strip kernels drop the sign term of the rounding shift where a negative result clamps to the zero point anyway)
+                    relu_ok = a_lo >= z_o and dlo >= zdo and plo >= zpo
+                    cst = front_strip_constants(w, b, mu, sh, z_i, z_o, wtd.data[0], bd, mud, shd, zdo, wpw, bp, mup, shp, zpo) if BW % 16 == 0 and relu_ok else None
                     pb.op(pk.I8_FRONT, val[src], v, p=[H, Wd, Cout, N, BH, BW, z_i, z_o, a_lo, a_hi, zdo, dlo, dhi, zpo, plo, phi, int(cst is not None)],
                           t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
                              pb.tensor(wtd.data[0], np.int8), pb.tensor(bd, np.int32), pb.tensor(mud, np.int32), pb.tensor(shd, np.int32),
@@ -604,7 +606,8 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                 cst = None
                 ow_ = np.arange(OW)
                 nw = strip_waves(C, Cout, sh_, OW, bool(add_p[0])) if sh_ == sw_ and (OW != 8 or OH % 2 == 0) else 0
-                if (nw and (not add_p[0] or res_val == val[src])
+                relu_ok = a_lo >= z_o and (bool(add_p[0]) or lo2 >= zo2)  # see rq_relu in csrc/bn_i8_strip.hip
+                if (nw and relu_ok and (not add_p[0] or res_val == val[src])
                         and ((ow_ * sw_ - pl + 1 >= 0) & (ow_ * sw_ - pl + 1 < Wd)).all()):
                     cst = strip_constants(wt_.data[0], bdw, mu, sh, z_o, w2, b2, mu2, sh2, zo2, bool(add_p[0]), nw)
                 p = [H, Wd, C, sh_, sw_, 0, OH, OW, pt, pl, z_i, z_o, a_lo, a_hi, Cout, zo2, lo2, hi2, *add_p, 1, 0, *tile, 0, int(cst is not None)]

@@ -50,7 +50,8 @@ const OptName kOptions[] = {
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
-    {"stft_tpw", &bn::Options::stft_tpw},         {"ingest_blk", &bn::Options::ingest_blk},
+    {"stft_tpw", &bn::Options::stft_tpw},         {"stft_sub", &bn::Options::stft_sub},
+    {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
 
@@ -95,6 +96,7 @@ struct bn_model {
     std::vector<bn::Tail8Args> tails;    // per operator: arguments of the fused tail kernel (BN_OP_I8_TAIL operators only)
     std::vector<uint8_t> tail_ok;        // per operator: BN_OP_I8_TAIL whose maps fit the kernel's LDS plan
     bool has_tail = false;               // the plan holds a usable fused tail operator
+    bool first_reads_input_only = false; // operator 0 is the only reader of BN_SLOT_INPUT (it can run per sub-batch behind the STFT)
     bool spec_tiled_ok = false;          // the plan's first operator reads the spectrogram through i8_mel_mfma_kernel<QIN>: bn_infer_audio
                                          // may hand it the tile-major layout the STFT writes fastest
     bool spec_tiled_now = false;         // set by bn_infer_audio around its bn_forward call
@@ -156,8 +158,11 @@ struct ProfScope {
 };
 
 // Executes the plan for a batch slice.
+// `op_begin..op_end` restricts the run to a range of operators, `slot_b0` is the chunk index the slice starts at inside the
+// workspace slots (bn_infer_audio runs the first operator per sub-batch, the rest over the whole batch).
 int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, float* d_scores, float* d_logits,
-             hipStream_t s, const float* d_audio = nullptr, int T = 0, int hop = 0) {
+             hipStream_t s, const float* d_audio = nullptr, int T = 0, int hop = 0, size_t op_begin = 0, size_t op_end = (size_t)-1,
+             size_t slot_b0 = 0) {
     const int mode = d_audio ? BN_PATH_AUDIO : BN_PATH_INPUT;
     auto slot_ptr = [&](int id) -> char* {
         if (id == BN_SLOT_INPUT) return (char*)d_input;
@@ -165,10 +170,11 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         if (id == BN_SLOT_SCORES) return (char*)d_scores;
         if (id == BN_SLOT_LOGITS) return (char*)d_logits;
         if (id < 0 || id >= (int)m->d_slots.size()) return nullptr;
-        return m->d_slots[id];
+        return m->d_slots[id] + slot_b0 * m->slots[id].bytes_per_chunk;
     };
     const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
-    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+    if (op_end > m->ops.size()) op_end = m->ops.size();
+    for (size_t oi = op_begin; oi < op_end; ++oi) {
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
@@ -542,6 +548,11 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             lo = t.offset < lo ? (size_t)t.offset : lo;
             hi = t.offset + t.nbytes > hi ? (size_t)(t.offset + t.nbytes) : hi;
         }
+    {
+        int readers = 0;
+        for (const OpRec& o : m->ops) readers += (o.in0 == BN_SLOT_INPUT) + (o.in1 == BN_SLOT_INPUT);
+        m->first_reads_input_only = readers == 1 && !m->ops.empty() && m->ops[0].in0 == BN_SLOT_INPUT && m->ops[0].p[BN_OP_PATH] != BN_PATH_AUDIO;
+    }
     // fused tail operators: build the kernel arguments and the LDS plan from the descriptor table
     m->tails.resize(h.n_ops);
     m->tail_ok.assign(h.n_ops, 0);
@@ -769,15 +780,37 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
         return BN_OK;
     }
     // un-normalised magnitudes + per-chunk min/max; the plan's first operator normalises while loading
-    bool tiled = false;
-    {
-        ProfScope prof(m, (int)m->ops.size(), (hipStream_t)stream);
-        tiled = m->spec_tiled_ok && !bn::g_opt.stft_rowmajor;  // option stft_rowmajor: keep the reference layout (A/B)
-        if (int rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, tiled))
-            return rc;
-    }
+    if (int rc = check_device(m->ctx)) return rc;
+    if (!d_audio || !d_scores) return fail(BN_ERR_ARG, "null device pointer");
+    if (B == 0) return BN_OK;
+    const bool tiled = m->spec_tiled_ok && !bn::g_opt.stft_rowmajor;  // option stft_rowmajor: keep the reference layout (A/B)
+    hipStream_t s = (hipStream_t)stream;
+    const size_t in_stride = m->hdr.input_elems, C = m->hdr.num_classes;
+    // Sub-batches: the STFT of `sub` chunks is followed at once by the operator that consumes the spectrogram, so that its
+    // 263 KB per chunk are still in the 256 MB Infinity Cache when they are read back (option stft_sub; 0 = whole batch).
+    int sub = bn::g_opt.stft_sub > 0 ? bn::g_opt.stft_sub : B;
+    const bool first_only = sub < B && !m->ops.empty() && m->ops[0].in0 == BN_SLOT_INPUT && m->ops[0].out >= 0 && m->first_reads_input_only;
+    if (!first_only) sub = B;
     m->spec_tiled_now = tiled;
-    const int rc = bn_forward(m, m->d_spec, m->d_minmax, B, d_scores, d_logits, stream);
+    int rc = BN_OK;
+    for (int b0 = 0; b0 < B && rc == BN_OK; b0 += sub) {
+        const int nb = B - b0 < sub ? B - b0 : sub;
+        {
+            ProfScope prof(m, (int)m->ops.size(), s);
+            rc = stft_mag_impl(m->ctx, d_audio + (size_t)b0 * T, nb, T, kFft, hop, W, /*normalize=*/0, m->d_spec + b0 * in_stride,
+                               m->d_minmax + 2 * (size_t)b0, stream, tiled);
+        }
+        if (rc == BN_OK && first_only)
+            rc = run_plan(m, m->d_spec + b0 * in_stride, m->d_minmax + 2 * (size_t)b0, nb, d_scores, d_logits, s, nullptr, 0, 0, 0, 1, (size_t)b0);
+    }
+    if (rc == BN_OK) {
+        for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
+            const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+            rc = run_plan(m, m->d_spec + b0 * in_stride, m->d_minmax + 2 * (size_t)b0, nb, d_scores + b0 * C, d_logits ? d_logits + b0 * C : nullptr, s,
+                          nullptr, 0, 0, first_only ? 1 : 0, (size_t)-1, (size_t)b0);
+            if (rc != BN_OK) break;
+        }
+    }
     m->spec_tiled_now = false;
     return rc;
 }

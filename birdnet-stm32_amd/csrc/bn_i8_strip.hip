@@ -63,6 +63,13 @@ __device__ __forceinline__ int rq(int x, int m, int c1, int e) {
     return (v + c1 + (v >> 31)) >> e;
 }
 
+// The same where the clamp's lower bound is at or above the zero point (ReLU / ReLU6 outputs: the packer checks it): a negative v
+// gives a result <= zero point with or without the sign term (v + 2^(e-1) < 2^e), and both clamp to the same bound.
+__device__ __forceinline__ int rq_relu(int x, int m, int c1, int e) {
+    const int v = srdhm_pos(x, m);
+    return (v + c1) >> e;
+}
+
 template <int QL> struct RawRow { int t[3][QL]; };   // three taps (columns j = 0..2) of one input row, QL dwords each
 template <int QL> struct TRow { int c[QL][4]; };     // per channel: bytes (tap0, tap1, tap2, 0)
 
@@ -276,7 +283,7 @@ void i8_strip_kernel(Strip8Args a) {
                 int acc = dot4_first(T[i0].c[ql][e], w0[e], dwb[ql][e]);
                 acc = dot4(T[i1].c[ql][e], w1[e], acc);
                 acc = dot4(T[i2].c[ql][e], w2[e], acc);
-                qv[e] = med3(rq(acc, m[e], c1[e], sh[e]), a.dw_lo, a.dw_hi);
+                qv[e] = med3(rq_relu(acc, m[e], c1[e], sh[e]), a.dw_lo, a.dw_hi);
             }
             bfrag[ql] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         }
@@ -315,7 +322,8 @@ void i8_strip_kernel(Strip8Args a) {
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int v = med3(rq(acc[t][e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);  // ADD: value + 128 (table index), else the int8 value
+                // ADD: value + 128 (table index, any sign: full rounding), else the int8 value behind a ReLU6 clamp
+                int v = med3(ADD ? rq(acc[t][e], m[e], c1[e], sh[e]) : rq_relu(acc[t][e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);
                 if constexpr (ADD)  // the whole TFLite ADD (two input rescales, sum, output rescale, clamp) is a function of two bytes
                     v = add_tab[(uint32_t)perm(cenv[t % QL], v, 0x0c0c0400u + (e << 8))];
                 qv[e] = v;
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
                 const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(sta, (long)(uint32_t)x[j], stb, 0, 0, 0);
                 int qv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = med3(rq(acc[e], stm[e], stc1[e], ste[e]), a.st_lo, a.st_hi);
+                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu(acc[e], stm[e], stc1[e], ste[e]), a.st_lo, a.st_hi);
                 pk[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
             }
             if (right_st) pk[2] = zst4;
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
             int acc = dot4_first(T[i0].c[0][e], dww[0][e], dwb[e]);
             acc = dot4(T[i1].c[0][e], dww[1][e], acc);
             acc = dot4(T[i2].c[0][e], dww[2][e], acc);
-            qv[e] = med3(rq(acc, dwm[e], dwc1[e], dwe[e]), a.dw_lo, a.dw_hi);
+            qv[e] = med3(rq_relu(acc, dwm[e], dwc1[e], dwe[e]), a.dw_lo, a.dw_hi);
         }
         const long bf = (long)(uint32_t)perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         int outw[2];
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
             const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(pwa[t], bf, pwb[t], 0, 0, 0);
             int ov[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = med3(rq(acc[e], pwm[t][e], pwc1[t][e], pwe[t][e]), a.pw_lo, a.pw_hi);
+            for (int e = 0; e < 4; ++e) ov[e] = med3(rq_relu(acc[e], pwm[t][e], pwc1[t][e], pwe[t][e]), a.pw_lo, a.pw_hi);
             outw[t] = perm(perm(ov[3], ov[2], 0x0c0c0400u), perm(ov[1], ov[0], 0x0c0c0400u), 0x05040100u);
         }
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, oh * a.OW * 32, 0);

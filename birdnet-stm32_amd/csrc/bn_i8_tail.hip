@@ -51,6 +51,12 @@ __device__ __forceinline__ int rq(int x, int m, int c1, int e) {
     return (v + c1 + (v >> 31)) >> e;
 }
 
+// where the clamp's lower bound is at or above the zero point the sign term is not needed (bn_i8_strip.hip: rq_relu; the packer checks it)
+__device__ __forceinline__ int rq_relu(int x, int m, int c1, int e) {
+    const int v = srdhm_pos(x, m);
+    return (v + c1) >> e;
+}
+
 // first channel quad of lane group kq (mirrors _tail_quad_base in models/_lower_i8.py)
 template <int CIN>
 __device__ __forceinline__ int pq_base(int kq) {
@@ -60,11 +66,18 @@ __device__ __forceinline__ int pq_base(int kq) {
 }
 
 // One block for the kTailG chunks of the workgroup.  `lds` = the workgroup's LDS; maps are [chunk][position][C + 4 bytes].
-template <int CIN, int COUT, bool SRCG>
+// The geometry is a template parameter (H x W input map, stride S): positions turn into shifts and the padding tests into
+// comparisons with constants; tail_plan() only accepts the four shapes instantiated below.
+template <int CIN, int COUT, int S, int H, int W, bool ADD, bool SRCG>
 __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args& a, unsigned char* lds, int chunk0) {
     constexpr int KS = CIN / 64;        // k-steps of v_mfma_i32_16x16x64_i8
     constexpr int NTILES = COUT / 16;
     constexpr int PIN = CIN + 4, POUT = COUT + 4;
+    constexpr int OH = H / S, OW = W / S, PER_CHUNK = OH * OW;
+    constexpr int TILES = kTailG * PER_CHUNK / 16;
+    constexpr int NGRP = TILES >= kTailWaves ? 1 : kTailWaves / TILES;  // few tiles: split them over groups of output channels
+    constexpr int NT_PER = NTILES / NGRP;
+    constexpr int PT = S == 1 ? 1 : 0, PL = PT;  // TF SAME padding of a 3x3 window on even maps: 1 / 1 at stride 1, 0 / 1 at stride 2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -73,116 +86,108 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
     {
         const v4i* g = reinterpret_cast<const v4i*>(a.cst);
         v4i* dst = reinterpret_cast<v4i*>(lds + L.w_off);
-        for (int i = tid; i < CIN * COUT / 16; i += kTailThreads) dst[i] = g[L.g_w / 4 + i];
-        dst = reinterpret_cast<v4i*>(lds + L.dwc_off);
-        for (int i = tid; i < CIN * 7 / 4; i += kTailThreads) dst[i] = g[L.g_dwc / 4 + i];
-        dst = reinterpret_cast<v4i*>(lds + L.pwc_off);
-        for (int i = tid; i < COUT; i += kTailThreads) dst[i] = g[L.g_pwc / 4 + i];
-        if (L.has_add) {
-            dst = reinterpret_cast<v4i*>(lds + L.lut_off);
-            for (int i = tid; i < 128; i += kTailThreads) dst[i] = g[L.g_lut / 4 + i];
-        }
+#pragma unroll
+        for (int i = 0; i < (CIN * COUT / 16 + kTailThreads - 1) / kTailThreads; ++i)
+            if (i * kTailThreads + tid < CIN * COUT / 16) dst[i * kTailThreads + tid] = g[L.g_w / 4 + i * kTailThreads + tid];
+        if (tid < CIN * 7 / 4) reinterpret_cast<v4i*>(lds + L.dwc_off)[tid] = g[L.g_dwc / 4 + tid];
+        if (tid < COUT) reinterpret_cast<v4i*>(lds + L.pwc_off)[tid] = g[L.g_pwc / 4 + tid];
+        if (ADD && tid < 128) reinterpret_cast<v4i*>(lds + L.lut_off)[tid] = g[L.g_lut / 4 + tid];
         if (!SRCG && tid < PIN / 4) reinterpret_cast<int*>(lds + L.zp_off)[tid] = (L.zp_in & 0xff) * 0x01010101;
     }
     __syncthreads();
 
     const int zp4 = (L.zp_in & 0xff) * 0x01010101;
-    const int per_chunk = L.OH * L.OW;          // output positions per chunk (a multiple of 16)
-    const int tiles = kTailG * per_chunk / 16;
-    const int ngrp = tiles >= kTailWaves ? 1 : kTailWaves / tiles;  // tiles are split over output-channel groups when there are few
-    const int nt_per = NTILES / ngrp;
     const int qb = pq_base<CIN>(kq);
     const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.dwc_off) + qb * 7;
-    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.pwc_off);
+    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.pwc_off) + kq * 4;
     const int* lut = reinterpret_cast<const int*>(lds + L.lut_off);
+    const v4i* wl = reinterpret_cast<const v4i*>(lds + L.w_off) + lane;
+    const int dw_lo = L.dw_lo, dw_hi = L.dw_hi, pw_lo = L.pw_lo, pw_hi = L.pw_hi;
 
-    for (int u = wave; u < tiles * ngrp; u += kTailWaves) {
-        const int tile = u / ngrp, grp = u - tile * ngrp;
+    for (int u = wave; u < TILES * NGRP; u += kTailWaves) {
+        const int tile = u / NGRP, grp = u % NGRP;
         const int p = tile * 16 + n;                 // position over the kTailG chunks
-        const int g = p / per_chunk, pc = p - g * per_chunk;
-        const int oy = pc / L.OW, ox = pc - oy * L.OW;
-        int chunk = chunk0 + g;
-        if (chunk >= a.B) chunk = a.B - 1;           // ragged last group: the spare slots repeat the last chunk
+        const int g = p / PER_CHUNK, pc = p % PER_CHUNK;
+        const int oy = pc / OW, ox = pc % OW;
 
         // ---- depthwise 3x3 for all CIN channels of this lane's position -> B fragments --------------------------------------
-        v4i bf[KS];
-        {
-            int taddr[9];
-            bool tok[9];
+        int taddr[9];
+        unsigned okmask = 0;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int iy = oy * L.S - L.pt + dy, ix = ox * L.S - L.pl + dx;
-                    const bool ok = iy >= 0 && iy < L.H && ix >= 0 && ix < L.W;
-                    tok[dy * 3 + dx] = ok;
-                    if constexpr (SRCG) taddr[dy * 3 + dx] = ok ? (iy * L.W + ix) * CIN + 4 * qb : 0;
-                    else taddr[dy * 3 + dx] = (ok ? L.x_off + ((g * L.H + iy) * L.W + ix) * PIN : L.zp_off) + 4 * qb;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iy = oy * S - PT + dy, ix = ox * S - PL + dx;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                if constexpr (SRCG) {
+                    taddr[dy * 3 + dx] = ok ? (iy * W + ix) * CIN + 4 * qb : 0;
+                    okmask |= ok ? 1u << (dy * 3 + dx) : 0u;
+                } else {
+                    taddr[dy * 3 + dx] = (ok ? L.x_off + ((g * H + iy) * W + ix) * PIN : L.zp_off) + 4 * qb;
                 }
-            // (only the first block reads global memory; the other instantiations never use the descriptor)
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * L.H * L.W * CIN : 0), 0, SRCG ? L.H * L.W * CIN : 0, 0x00020000);
+            }
+        int chunk = chunk0 + g;
+        if (chunk >= a.B) chunk = a.B - 1;           // ragged last group: the spare slots repeat the last chunk
+        // (only the first block reads global memory; the other instantiations never use the descriptor)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * H * W * CIN : 0), 0, SRCG ? H * W * CIN : 0, 0x00020000);
+        v4i bf[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                int frag[4];
+        for (int ks = 0; ks < KS; ++ks) {
+            int frag[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int qi = 4 * ks + j;   // quad qb + qi: channels 4 (qb + qi) ..
-                    int t[9];
+            for (int j = 0; j < 4; ++j) {
+                const int qi = 4 * ks + j;   // quad qb + qi: channels 4 (qb + qi) ..
+                const v4i bias = dwc[qi * 7 + 3];
+                int acc[4] = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) {
+                for (int dy = 0; dy < 3; ++dy) {
+                    int r[3];
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
                         if constexpr (SRCG) {
-                            const int v = __builtin_amdgcn_raw_buffer_load_b32(rs, taddr[k] + 4 * qi, 0, 0);
-                            t[k] = tok[k] ? v : zp4;
+                            const int v = __builtin_amdgcn_raw_buffer_load_b32(rs, taddr[dy * 3 + dx] + 4 * qi, 0, 0);
+                            r[dx] = (okmask >> (dy * 3 + dx)) & 1 ? v : zp4;
                         } else {
-                            t[k] = *reinterpret_cast<const int*>(lds + taddr[k] + 4 * qi);
+                            r[dx] = *reinterpret_cast<const int*>(lds + taddr[dy * 3 + dx] + 4 * qi);
                         }
                     }
-                    const v4i w0 = dwc[qi * 7 + 0], w1 = dwc[qi * 7 + 1], w2 = dwc[qi * 7 + 2], bias = dwc[qi * 7 + 3];
-                    const v4i m = dwc[qi * 7 + 4], c1 = dwc[qi * 7 + 5], sh = dwc[qi * 7 + 6];
-                    int T[3][4];
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {  // bytes (tap0, tap1, tap2, 0) of each of the four channels
-                        const int r0 = t[dy * 3 + 0], r1 = t[dy * 3 + 1], r2 = t[dy * 3 + 2];
-                        const int lo = perm(r1, r0, 0x05010400u), hi = perm(r1, r0, 0x07030602u);
-                        T[dy][0] = perm(r2, lo, 0x0c040100u);
-                        T[dy][1] = perm(r2, lo, 0x0c050302u);
-                        T[dy][2] = perm(r2, hi, 0x0c060100u);
-                        T[dy][3] = perm(r2, hi, 0x0c070302u);
-                    }
-                    int qv[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int acc = dot4(T[0][e], w0[e], bias[e]);
-                        acc = dot4(T[1][e], w1[e], acc);
-                        acc = dot4(T[2][e], w2[e], acc);
-                        qv[e] = med3(rq(acc, m[e], c1[e], sh[e]), L.dw_lo, L.dw_hi);
-                    }
-                    frag[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+                    const v4i w = dwc[qi * 7 + dy];
+                    const int lo = perm(r[1], r[0], 0x05010400u), hi = perm(r[1], r[0], 0x07030602u);  // bytes (tap0, tap1, tap2, 0) per channel
+                    acc[0] = dot4(perm(r[2], lo, 0x0c040100u), w[0], acc[0]);
+                    acc[1] = dot4(perm(r[2], lo, 0x0c050302u), w[1], acc[1]);
+                    acc[2] = dot4(perm(r[2], hi, 0x0c060100u), w[2], acc[2]);
+                    acc[3] = dot4(perm(r[2], hi, 0x0c070302u), w[3], acc[3]);
                 }
-                bf[ks] = (v4i){frag[0], frag[1], frag[2], frag[3]};
+                const v4i m = dwc[qi * 7 + 4], c1 = dwc[qi * 7 + 5], sh = dwc[qi * 7 + 6];
+                int qv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu(acc[e], m[e], c1[e], sh[e]), dw_lo, dw_hi);
+                frag[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
             }
+            bf[ks] = (v4i){frag[0], frag[1], frag[2], frag[3]};
         }
 
         // ---- pointwise 1x1 on the matrix cores, requantise, [ADD], store into the next map ------------------------------------
-        const int q = kq;                                    // accumulator rows 4 q .. 4 q + 3 of a tile = output channels
-        const int yrow = L.y_off + p * POUT + 4 * q;
-        const int xrow = SRCG ? 0 : L.x_off + p * PIN + 4 * q;  // residual (blocks with the ADD have CIN == COUT, stride 1: same position)
-        const v4i* wl = reinterpret_cast<const v4i*>(lds + L.w_off) + lane;
-        for (int tt = 0; tt < nt_per; ++tt) {
-            const int nt = grp * nt_per + tt;
-            const v4i* pc4 = pwc + (nt * 4 + q) * 4;
+        // accumulator rows 4 kq .. 4 kq + 3 of tile nt = output channels 16 nt + 4 kq ..
+        const int yrow = L.y_off + p * POUT + 4 * kq;
+        const int xrow = L.x_off + p * PIN + 4 * kq;  // residual: blocks with the ADD have CIN == COUT and stride 1 (same position)
+#pragma unroll 2
+        for (int tt = 0; tt < NT_PER; ++tt) {
+            const int nt = grp * NT_PER + tt;
+            const v4i* pc4 = pwc + nt * 16;
             v4i acc = pc4[0];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wl[(nt * KS + ks) * 64], bf[ks], acc, 0, 0, 0);
             const v4i m = pc4[1], c1 = pc4[2], sh = pc4[3];
             int res = 0;
-            if (L.has_add) res = *reinterpret_cast<const int*>(lds + xrow + 16 * nt);
+            if constexpr (ADD) res = *reinterpret_cast<const int*>(lds + xrow + 16 * nt);
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int v = med3(rq(acc[e], m[e], c1[e], sh[e]), L.pw_lo, L.pw_hi);  // with the ADD: value + 128 = index of the second table
-                if (L.has_add) {
+                // with the ADD: value + 128 = index of the second table (any sign: full rounding)
+                int v = med3(ADD ? rq(acc[e], m[e], c1[e], sh[e]) : rq_relu(acc[e], m[e], c1[e], sh[e]), pw_lo, pw_hi);
+                if constexpr (ADD) {
                     const int sa = lut[(res >> (8 * e)) & 0xff], sb = lut[256 + v];
                     v = med3(rq(sa + sb, L.add_m, L.add_c1, L.add_e), L.add_lo, L.add_hi);
                 }
@@ -202,10 +207,10 @@ __global__ __launch_bounds__(kTailThreads) void i8_tail_kernel(Tail8Args a) {
         const int chunk0 = grp * kTailG;
         for (int li = 0; li < a.n_layers; ++li) {
             const Tail8Layer& L = a.L[li];
-            if (L.Cin == 64) tail_block<64, 128, true>(L, a, lds, chunk0);
-            else if (L.Cin == 128 && L.Cout == 128) tail_block<128, 128, false>(L, a, lds, chunk0);
-            else if (L.Cin == 128) tail_block<128, 256, false>(L, a, lds, chunk0);
-            else tail_block<256, 256, false>(L, a, lds, chunk0);
+            if (L.Cin == 64) tail_block<64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0);
+            else if (L.Cin == 128 && L.Cout == 128) tail_block<128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0);
+            else if (L.Cin == 128) tail_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0);
+            else tail_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0);
         }
         // ---- MEAN over the positions of the last map: one thread per (chunk slot, channel) ---------------------------------------
         const Tail8Layer& L = a.L[a.n_layers - 1];
@@ -281,8 +286,11 @@ bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a) {
         L.add_m = d[15]; L.add_c1 = d[16]; L.add_e = d[17]; L.add_lo = d[18]; L.add_hi = d[19];
         L.g_w = d[20]; L.g_dwc = d[21]; L.g_pwc = d[22]; L.g_lut = d[23];
         const bool first = i == 0;
-        const bool shape_ok = (first && L.Cin == 64 && L.Cout == 128) || (!first && L.Cin == 128 && (L.Cout == 128 || L.Cout == 256)) ||
-                              (!first && L.Cin == 256 && L.Cout == 256);
+        auto is = [&](int cin, int cout, int st, int hh, int ww, int add) {
+            return L.Cin == cin && L.Cout == cout && L.S == st && L.H == hh && L.W == ww && L.has_add == add && L.pt == (st == 1) && L.pl == (st == 1);
+        };
+        // the four instantiations of tail_block (bn_i8_tail.hip: i8_tail_kernel)
+        const bool shape_ok = (first && is(64, 128, 2, 16, 32, 0)) || (!first && (is(128, 128, 1, 8, 16, 1) || is(128, 256, 2, 8, 16, 0) || is(256, 256, 1, 4, 8, 1)));
         if (!shape_ok || (L.S != 1 && L.S != 2) || L.OH != (L.H + L.S - 1) / L.S || L.OW != (L.W + L.S - 1) / L.S || (L.OH * L.OW) % 16 ||
             L.pt < 0 || L.pt > 1 || L.pl < 0 || L.pl > 1 || L.H < 1 || L.W < 1 || L.H * L.W > 4096)
             return false;

@@ -144,7 +144,8 @@ def test_i8_from_audio_2048_chunks_top1_and_flipped_bytes(torch_mod):
     """From audio the GPU computes the STFT in float32, the oracle in float64 (librosa's arithmetic), so a few quantised input bytes differ
     by one step; everything behind the quantiser is exact.  Measured and asserted here on 2048 chunks: the share of flipped input bytes
     (<= 2e-3, each by exactly one LSB), exact top-1 of the pre-sigmoid outputs wherever the oracle's top-1 leads by more than one
-    output LSB, logit cosine >= 0.999 for every chunk, and scores within one LSB of the int8 sigmoid."""
+    output LSB, logit cosine >= 0.999 for every chunk, pre-sigmoid outputs within 2 LSB and scores within what that allows.
+    (Measured on MI355X: 3e-6 of the input bytes flip, 1 LSB at most behind them, every clear top-1 agrees.)"""
     torch = torch_mod
     from birdnet_stm32.models._tflite_reader import load_tflite
     from birdnet_stm32.models.runners import load_model_runner
@@ -193,7 +194,8 @@ def test_i8_from_audio_2048_chunks_top1_and_flipped_bytes(torch_mod):
     print(f"INT8 from audio, {N} chunks: flipped input bytes {flipped:.2e}, top-1 agreement {agree:.4f} ({int(clear.sum())} chunks with a clear "
           f"top-1: all agree), largest pre-sigmoid difference {lsb} LSB, worst logit cosine {worst_cos:.6f}")
     assert agree >= 0.99 and lsb <= 2 and worst_cos >= 0.999
-    assert np.abs(scores - ref_scores).max() <= 1.0 / 256 + 1e-7
+    # one LSB of the pre-sigmoid output (scale s_fc) moves the sigmoid by at most s_fc / 4, plus one LSB of the int8 sigmoid itself
+    assert np.abs(scores - ref_scores).max() <= lsb * s_fc / 4 + 1.0 / 256 + 1e-7
     runner.close()
 
 
