@@ -3,9 +3,11 @@
 Flags and flow follow the reference (reference: birdnet_stm32/cli/convert.py:23-72 flags, :74-200 flow: resolve the model
 config next to the checkpoint, stratified representative dataset from ``--data_path_train`` or random inputs without
 one, convert, validate float vs INT8 on a different subset, fail below ``--min_cosine_sim``, optional JSON report).
-The converter is this build's own (``birdnet_stm32.conversion.quantize``: no TensorFlow) and needs ``--template``: an
-existing ``.tflite`` of the same topology whose operator structure the output keeps (default: the shipped
-``birdnet_stm32n6_100.tflite``).  ``--quantization dynamic`` and ``--export_onnx`` are TensorFlow/tf2onnx features and are
+The converter is this build's own (no TensorFlow), in two forms: with ``--template`` (an existing ``.tflite`` of the same
+topology, default the shipped ``birdnet_stm32n6_100.tflite``) the output keeps that file's operator structure and frozen frontend
+(``conversion.quantize.requantize_like``); with ``--template none`` — and automatically when the checkpoint's topology does not
+match the template (squeeze-excite, inverted residuals, another width) — the graph is written from the model itself
+(``conversion.export.convert_netspec_to_int8`` + ``models._tflite_writer``).  ``--quantization dynamic`` and ``--export_onnx`` are TensorFlow/tf2onnx features and are
 refused.  Validation runs both models on the MI355X (``HipRunner``).
 """
 
@@ -36,7 +38,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--batch_validate", type=int, default=0, help="Run validation N times with different random seeds and report worst-case metrics (0 = off).")
     p.add_argument("--export_onnx", action="store_true", help="Not available in this build (requires tf2onnx).")
     p.add_argument("--report_json", type=str, default="", help="Path to save a structured JSON conversion report.")
-    p.add_argument("--template", type=str, default=_DEFAULT_TEMPLATE, help="Existing .tflite of the same topology (operator structure of the output)")
+    p.add_argument("--template", type=str, default=_DEFAULT_TEMPLATE,
+                   help="Existing .tflite of the same topology (operator structure of the output); 'none' writes the graph from the model itself")
+    p.add_argument("--frontend_norm", type=str, default="auto", choices=["auto", "off"],
+                   help="'off' exports the hybrid frontend without its per-sample max-normalisation (the shipped checkpoint's form)")
     p.add_argument("--device", type=int, default=0)
     return p
 
@@ -98,13 +103,24 @@ def main(argv=None):
 
     if not args.output_path:
         args.output_path = os.path.splitext(args.checkpoint_path)[0] + "_quantized.tflite"
-    template = load_tflite(args.template)
-    new = requantize_like(template, spec, rep, per_tensor=args.per_tensor)
     os.makedirs(os.path.dirname(args.output_path) or ".", exist_ok=True)
-    with open(args.template, "rb") as fh:
-        raw = fh.read()
+    new = None
+    if args.template.lower() != "none":
+        try:
+            new = requantize_like(load_tflite(args.template), spec, rep, per_tensor=args.per_tensor)
+            with open(args.template, "rb") as fh:
+                raw = patch_tflite(fh.read(), new)
+        except (ValueError, NotImplementedError) as e:
+            print(f"Template {os.path.basename(args.template)} does not fit this model ({e}); writing the graph from the model itself.")
+            new = None
+    if new is None:
+        from birdnet_stm32.conversion.export import convert_netspec_to_int8
+        from birdnet_stm32.models._tflite_writer import write_tflite
+
+        new = convert_netspec_to_int8(spec, rep, per_tensor=args.per_tensor, frontend_norm=False if args.frontend_norm == "off" else None)
+        raw = write_tflite(new)
     with open(args.output_path, "wb") as fh:
-        fh.write(patch_tflite(raw, new))
+        fh.write(raw)
     print(f"Quantization mode: {args.quantization}" + (" (per-tensor)" if args.per_tensor else ""))
     print(f"TFLite model saved to {args.output_path}")
 

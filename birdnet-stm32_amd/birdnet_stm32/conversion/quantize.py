@@ -176,10 +176,18 @@ def run_float(model: TfliteModel, consts: dict[int, np.ndarray], x: np.ndarray) 
             axes = tuple(int(a) % env[i[0]].ndim for a in np.atleast_1d(env[i[1]]))
             y = env[i[0]].mean(axis=axes, keepdims=bool(op.options.get("keep_dims")))
         elif n == "FULLY_CONNECTED":
-            y = _act(env[i[0]].reshape(env[i[0]].shape[0], -1) @ env[i[1]].T + (env[i[2]] if len(i) > 2 and i[2] >= 0 else 0.0),
-                     op.options.get("activation", "none"))
+            xin = env[i[0]]
+            flat = xin.reshape(-1, env[i[1]].shape[1])
+            y = _act(flat @ env[i[1]].T + (env[i[2]] if len(i) > 2 and i[2] >= 0 else 0.0), op.options.get("activation", "none"))
+            if op.options.get("keep_num_dims"):
+                y = y.reshape(*xin.shape[:-1], -1)
         elif n == "LOGISTIC":
             y = 1.0 / (1.0 + np.exp(-env[i[0]]))
+        elif n == "MUL":
+            y = _act(env[i[0]] * env[i[1]], op.options["activation"])
+        elif n == "SOFTMAX":
+            z = (env[i[0]] - env[i[0]].max(axis=-1, keepdims=True)) * op.options.get("beta", 1.0)
+            y = np.exp(z) / np.exp(z).sum(axis=-1, keepdims=True)
         else:
             raise NotImplementedError(f"operator {n} in float calibration")
         env[op.outputs[0]] = y.astype(np.float32) if y.dtype.kind == "f" else y
@@ -283,6 +291,21 @@ def requantize_like(template: TfliteModel, spec: ns.NetSpec, rep_data_gen, per_t
     for op in conv_ops[:first]:  # frontend: constants of the template, real-valued
         float_wb[op.index] = (consts[op.inputs[1]], consts[op.inputs[2]])
 
+    new = quantize_graph(template, consts, float_wb, rep_data_gen, per_tensor=per_tensor, fresh_weights={op.index for op in conv_ops[first:]})
+    new.description = (template.description or "") + " | requantised without TensorFlow (birdnet_stm32.conversion.quantize)"
+    return new
+
+
+def quantize_graph(template: TfliteModel, consts: dict[int, np.ndarray], float_wb: dict[int, tuple[np.ndarray, np.ndarray]], rep_data_gen,
+                   per_tensor: bool = False, fresh_weights: set[int] | None = None) -> TfliteModel:
+    """Calibrate and quantise: ``template`` gives the operator structure (its quantised tensors are re-parameterised), ``consts`` the
+    real-valued constants for the float run, ``float_wb[op.index]`` the real-valued (kernel in TFLite layout, bias) of every
+    convolution / fully-connected operator.  Operators in ``fresh_weights`` get new symmetric per-channel int8 weights; the others keep
+    the template's weight tensors (a frozen frontend) and only their biases are re-scaled."""
+    T = template.tensors
+    conv_ops = [op for op in template.ops if op.name in ("CONV_2D", "DEPTHWISE_CONV_2D", "FULLY_CONNECTED")]
+    if fresh_weights is None:
+        fresh_weights = {op.index for op in conv_ops}
     # ---- calibration: ranges of every activation tensor over the representative samples
     lo: dict[int, float] = {}
     hi: dict[int, float] = {}
@@ -344,7 +367,7 @@ def requantize_like(template: TfliteModel, spec: ns.NetSpec, rep_data_gen, per_t
         w, b = float_wb[op.index]
         wt, bt = N[op.inputs[1]], N[op.inputs[2]]
         s_in = float(N[op.inputs[0]].scale[0])
-        if op.index >= conv_ops[first].index:
+        if op.index in fresh_weights:
             axis = 3 if op.name == "DEPTHWISE_CONV_2D" else 0
             q, sw = quantize_weights(w, axis, per_tensor)
             wt.data, wt.scale, wt.zero_point, wt.quantized_dimension = q, sw, np.zeros(sw.shape, np.int64), axis
@@ -354,8 +377,9 @@ def requantize_like(template: TfliteModel, spec: ns.NetSpec, rep_data_gen, per_t
             sb = np.full(b.shape, sb.reshape(-1)[0])
         bt.data = np.clip(np.round(b.astype(np.float64) / sb), -(2**30), 2**30).astype(np.int32)  # the converter clamps biases to +-2^30
         bt.scale, bt.zero_point = sb.astype(np.float32), np.zeros(sb.shape, np.int64)
-    new.description = (template.description or "") + " | requantised without TensorFlow (birdnet_stm32.conversion.quantize)"
     return new
+
+
 
 
 def convert_to_int8(spec: ns.NetSpec, template_path: str, rep_data_gen, per_tensor: bool = False) -> TfliteModel:

@@ -676,40 +676,80 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             val[op.outputs[0]], shape[op.outputs[0]] = v, (C,)
             i += 1
         elif op.name == "FULLY_CONNECTED":
-            (Cin,) = shape[src]
+            # classifier ([C] -> classes) or a squeeze-excite Dense on the pooled vector ([.., C] -> [.., C']); a LOGISTIC that is the
+            # layer's only consumer is folded into it as a 256-entry table (exact: the int8 LOGISTIC is a table in TFLite too)
+            Cin = int(shape[src][-1])
+            _expect(int(np.prod(shape[src])) == Cin, "FULLY_CONNECTED input must be a vector per chunk")
             s_i, z_i = g.q(src)
             s_o, z_o = g.q(op.outputs[0])
             wt_ = t[op.inputs[1]]
             Cout = int(wt_.shape[0])
+            _expect(int(wt_.shape[1]) == Cin, "FULLY_CONNECTED weight shape")
             mu, sh = qz.channel_multipliers(s_i, wt_.scale, s_o, Cout)
             a_lo, a_hi = qz.activation_bounds(op.options["activation"], s_o, z_o)
             b = g.const(op.inputs[2]).astype(np.int64) if len(op.inputs) > 2 and op.inputs[2] >= 0 else np.zeros(Cout, np.int64)
             b = b - z_i * wt_.data.astype(np.int64).sum(axis=1)
             _expect_acc_range(wt_.data, b, 1, f"fully connected operator #{op.index}", mu, sh)
+            Kp = (Cin + 3) // 4 * 4
+            w_pad = np.zeros((Cout, Kp), np.int8)
+            w_pad[:, :Cin] = wt_.data
+            nxt = ops[i + 1] if i + 1 < len(ops) else None
+            fold_lut = (nxt is not None and nxt.name == "LOGISTIC" and nxt.inputs[0] == op.outputs[0] and g.consumers.get(op.outputs[0], []) == [nxt.index]
+                        and i + 2 < len(ops) and ops[i + 2].name != "DEQUANTIZE")
+            tt = [pb.tensor(w_pad, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)]
+            out_t = op.outputs[0]
+            if fold_lut:
+                s_h, z_h = g.q(nxt.outputs[0])
+                tt.append(pb.tensor(qz.logistic_table(s_o, z_o, s_h, z_h), np.int8))
+                out_t = nxt.outputs[0]
             v = pb.value(Cout)
-            tail_head.update(fc_op=len(plan.ops), fc_cin=Cin, NC=Cout, fc_zp_out=z_o, fc_lo=a_lo, fc_hi=a_hi, fc_w=wt_.data, fc_b=b, fc_m=mu, fc_s=sh)
-            pb.op(pk.I8_FC, val[src], v, p=[Cin, Cout, z_o, a_lo, a_hi],
-                  t=[pb.tensor(wt_.data, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
-                  name=f"t{op.outputs[0]}", out_shape=(Cout,), out_dtype="int8")
-            val[op.outputs[0]], shape[op.outputs[0]] = v, (Cout,)
-            fc_out = op.outputs[0]
+            if not fold_lut:
+                tail_head.update(fc_op=len(plan.ops), fc_cin=Cin, NC=Cout, fc_zp_out=z_o, fc_lo=a_lo, fc_hi=a_hi, fc_w=wt_.data, fc_b=b, fc_m=mu, fc_s=sh)
+            pb.op(pk.I8_FC, val[src], v, p=[Cin, Cout, z_o, a_lo, a_hi, int(fold_lut)], t=tt, name=f"t{out_t}", out_shape=(Cout,), out_dtype="int8")
+            val[out_t], shape[out_t] = v, (Cout,)
+            i += 2 if fold_lut else 1
+        elif op.name == "MUL":
+            # squeeze-excite scale: map [H, W, C] times a per-chunk gate [C] (either operand order)
+            a_t, b_t = op.inputs
+            if len(shape[a_t]) != 3:
+                a_t, b_t = b_t, a_t
+            _expect(len(shape[a_t]) == 3 and int(np.prod(shape[b_t])) == shape[a_t][2] and shape[a_t][2] % 4 == 0, "MUL must scale a map by a per-channel vector")
+            H, Wd, C = shape[a_t]
+            s1, z1 = g.q(a_t)
+            s2, z2 = g.q(b_t)
+            so, zo = g.q(op.outputs[0])
+            mu, sh = qz.quantize_multiplier(float(np.float32(s1)) * float(np.float32(s2)) / float(np.float32(so)))
+            lo_, hi_ = qz.activation_bounds(op.options["activation"], so, zo)
+            v = pb.value(H * Wd * C)
+            pb.op(pk.I8_SCALE, val[a_t], v, in1=val[b_t], p=[H * Wd, C, z1, z2, mu, sh, zo, lo_, hi_], name=f"t{op.outputs[0]}", out_shape=(H, Wd, C), out_dtype="int8")
+            val[op.outputs[0]], shape[op.outputs[0]] = v, (H, Wd, C)
             i += 1
-            # head: [LOGISTIC] -> DEQUANTIZE
+        elif op.name in ("LOGISTIC", "DEQUANTIZE"):
+            # head: [LOGISTIC ->] DEQUANTIZE [-> float32 SOFTMAX] ends the graph
+            fc_out = src
+            _expect(len(shape[fc_out]) == 1, "the head must follow the classifier")
+            Cout = shape[fc_out][0]
             s_fc, z_fc = g.q(fc_out)
             lut_t, s_h, z_h, has = -1, s_fc, z_fc, 0
-            if i < len(ops) and ops[i].name == "LOGISTIC":
-                s_h, z_h = g.q(ops[i].outputs[0])
+            if op.name == "LOGISTIC":
+                s_h, z_h = g.q(op.outputs[0])
                 lut_t, has = pb.tensor(qz.logistic_table(s_fc, z_fc, s_h, z_h), np.int8), 1
-                last = ops[i].outputs[0]
+                last = op.outputs[0]
                 i += 1
             else:
                 last = fc_out
             _expect(i < len(ops) and ops[i].name == "DEQUANTIZE" and ops[i].inputs[0] == last, "DEQUANTIZE must end the graph")
-            tail_head.update(head_op=len(plan.ops), lut=qz.logistic_table(s_fc, z_fc, s_h, z_h) if has else None, zp_fc=z_fc, zp_head=z_h, s_fc=s_fc, s_head=s_h)
-            pb.op(pk.I8_HEAD, v, pk.SLOT_SCORES, p=[Cout, z_fc, z_h, has], f=[s_fc, s_h], t=[lut_t], name=f"t{ops[i].outputs[0]}",
+            softmax, beta = 0, 1.0
+            if i + 1 < len(ops) and ops[i + 1].name == "SOFTMAX":
+                _expect(not has and ops[i + 1].inputs[0] == ops[i].outputs[0], "float32 SOFTMAX must read the dequantised classifier output")
+                softmax, beta = 1, float(ops[i + 1].options.get("beta", 1.0))
+                i += 1
+            if not softmax:
+                tail_head.update(head_op=len(plan.ops), lut=qz.logistic_table(s_fc, z_fc, s_h, z_h) if has else None, zp_fc=z_fc, zp_head=z_h, s_fc=s_fc, s_head=s_h)
+            pb.op(pk.I8_HEAD, val[fc_out], pk.SLOT_SCORES, p=[Cout, z_fc, z_h, has, softmax], f=[s_fc, s_h, beta], t=[lut_t], name=f"t{ops[i].outputs[0]}",
                   out_shape=(Cout,))
             i += 1
-            _expect(i == len(ops), "operators after DEQUANTIZE")
+            _expect(i == len(ops), "operators after the head")
         else:
             _expect(False, f"operator #{op.index} {op.name} in the backbone")
     if fuse and not keep_all:

@@ -36,8 +36,10 @@ BUILTIN_NAMES = {
     34: "PAD",
     39: "TRANSPOSE",
     40: "MEAN",
+    42: "DIV",
     45: "STRIDED_SLICE",
     77: "SHAPE",
+    82: "REDUCE_MAX",
     83: "PACK",
     94: "FILL",
     114: "QUANTIZE",
@@ -203,11 +205,11 @@ def _decode_options(name: str, t: _Table | None) -> dict:
             "dilation_w": t.scalar(5, "i", 1),
             "dilation_h": t.scalar(6, "i", 1),
         }
-    if name in ("ADD", "MUL"):
+    if name in ("ADD", "MUL", "DIV"):
         return {"activation": act(0)}
     if name == "FULLY_CONNECTED":
         return {"activation": act(0), "keep_num_dims": bool(t.scalar(2, "b", 0))}
-    if name == "MEAN":
+    if name in ("MEAN", "REDUCE_MAX"):
         return {"keep_dims": bool(t.scalar(0, "b", 0))}
     if name == "CONCATENATION":
         return {"axis": t.scalar(0, "i", 0), "activation": act(1)}

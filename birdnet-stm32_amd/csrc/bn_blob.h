@@ -136,9 +136,11 @@ enum BnOpKind : int32_t {
     BN_OP_I8_PW = 24,
     // [P][C] -> [C]  p: P C zp_in mult shift zp_out
     BN_OP_I8_MEAN = 25,
-    // [Cin] -> [Cout]  p: Cin Cout zp_out act_min act_max   t: w[Cout][Cin] bias(zp-folded) mult shift
+    // [Cin] -> [Cout]  p: Cin Cout zp_out act_min act_max has_lut   t: w[Cout][Cin rounded up to 4, zero padded] bias(zp-folded) mult shift lut[256]
+    // (lut: the int8 LOGISTIC behind the layer, squeeze-excite gates)
     BN_OP_I8_FC = 26,
-    // [C] int8 -> scores f32 (+ logits f32)  p: C zp_fc zp_out has_lut   f: s_fc s_out   t: lut[256]
+    // [C] int8 -> scores f32 (+ logits f32)  p: C zp_fc zp_out has_lut softmax   f: s_fc s_out beta   t: lut[256]
+    // softmax = 1: scores = float32 softmax of the dequantised input (DEQUANTIZE -> SOFTMAX graphs of conversion/export.py)
     BN_OP_I8_HEAD = 27,
     // fused [depthwise 3x3 ->] pointwise 1x1 on the int8 matrix cores (has_dw = 0: plain 1x1; transposed = 1: mel mixer)
     // p: H W Cin sh sw - OH OW pad_top pad_left | dw_zp_in dw_zp_out dw_amin dw_amax | Cout pw_zp_out pw_amin pw_amax
@@ -154,4 +156,7 @@ enum BnOpKind : int32_t {
     // p: in_bytes pw_macs dw_macs other_macs n_classes n_layers H0 W0 C0 P_last C_last   f: s_fc s_head
     // t: constant block (int32 words), descriptor table (24 words per block + 16 head words; models/_lower_i8.py: tail_constants)
     BN_OP_I8_TAIL = 30,
+    // int8 MUL of a map with a per-chunk gate vector (squeeze-excite): [P][C] * gate(in1)[C] -> [P][C]
+    // p: P C zp_x zp_gate mult shift zp_out act_min act_max
+    BN_OP_I8_SCALE = 31,
 };

@@ -250,20 +250,30 @@ __global__ void i8_mean_kernel(const int8_t* __restrict__ x, int8_t* __restrict_
 // FULLY_CONNECTED: a workgroup takes kFcChunks chunks, so a weight row is fetched once per kFcChunks chunks (the 25.6 KB matrix
 // was read from L2 once per chunk: 0.048 -> 0.02 ms per 4096 chunks); the activations of the chunks sit in LDS.
 constexpr int kFcChunks = 8;
-__global__ __launch_bounds__(128) void i8_fc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int B, int Cin, int Cout,
+// Cin = bytes per input row as the producer wrote them; Kp = Cin rounded up to a multiple of 4 = row length of the (zero-padded)
+// weight matrix.  lut (optional): the int8 LOGISTIC behind the layer (squeeze-excite gates), applied to the clamped result.
+__global__ __launch_bounds__(128) void i8_fc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int B, int Cin, int Kp, int Cout,
                                                     int zp_out, int amin, int amax, const int8_t* __restrict__ w,
                                                     const int32_t* __restrict__ bias, const int32_t* __restrict__ mult,
-                                                    const int32_t* __restrict__ shift) {
-    extern __shared__ int32_t fc_x[];  // [kFcChunks][Cin / 4]
+                                                    const int32_t* __restrict__ shift, const int8_t* __restrict__ lut) {
+    extern __shared__ int32_t fc_x[];  // [kFcChunks][Kp / 4]
     const int b0 = blockIdx.x * kFcChunks;
     const int nb = B - b0 < kFcChunks ? B - b0 : kFcChunks;
-    const int kq = Cin / 4;
-    const int32_t* xr = reinterpret_cast<const int32_t*>(x + (size_t)b0 * Cin);
-    for (int i = threadIdx.x; i < nb * kq; i += blockDim.x) fc_x[i] = xr[i];
-    for (int i = nb * kq + threadIdx.x; i < kFcChunks * kq; i += blockDim.x) fc_x[i] = 0;
+    const int kq = Kp / 4;
+    if (Cin == Kp) {
+        const int32_t* xr = reinterpret_cast<const int32_t*>(x + (size_t)b0 * Cin);
+        for (int i = threadIdx.x; i < nb * kq; i += blockDim.x) fc_x[i] = xr[i];
+        for (int i = nb * kq + threadIdx.x; i < kFcChunks * kq; i += blockDim.x) fc_x[i] = 0;
+    } else {  // rows that are not a whole number of dwords: byte copies, zero padding up to Kp (the padded weights are zero there)
+        int8_t* dst = reinterpret_cast<int8_t*>(fc_x);
+        for (int i = threadIdx.x; i < kFcChunks * Kp; i += blockDim.x) {
+            const int c = i / Kp, k = i - c * Kp;
+            dst[i] = (c < nb && k < Cin) ? x[(size_t)(b0 + c) * Cin + k] : (int8_t)0;
+        }
+    }
     __syncthreads();
     for (int n = threadIdx.x; n < Cout; n += blockDim.x) {
-        const int32_t* wr = reinterpret_cast<const int32_t*>(w + (size_t)n * Cin);
+        const int32_t* wr = reinterpret_cast<const int32_t*>(w + (size_t)n * Kp);
         int32_t acc[kFcChunks];
 #pragma unroll
         for (int c = 0; c < kFcChunks; ++c) acc[c] = bias[n];
@@ -275,7 +285,51 @@ __global__ __launch_bounds__(128) void i8_fc_kernel(const int8_t* __restrict__ x
         const int32_t m = mult[n], sh = shift[n];
 #pragma unroll
         for (int c = 0; c < kFcChunks; ++c)
-            if (c < nb) y[(size_t)(b0 + c) * Cout + n] = (int8_t)clampi(mbqm(acc[c], m, sh) + zp_out, amin, amax);
+            if (c < nb) {
+                int32_t q = clampi(mbqm(acc[c], m, sh) + zp_out, amin, amax);
+                if (lut) q = lut[q + 128];
+                y[(size_t)(b0 + c) * Cout + n] = (int8_t)q;
+            }
+    }
+}
+
+// MUL of a map with a per-chunk, per-channel gate (squeeze-excite): y = clamp(zo + MBQM((x - zx)(g - zg), m, shift)); one thread
+// per four channels of one position
+__global__ void i8_scale_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ gate, int8_t* __restrict__ y, int P, int C,
+                                int zx, int zg, int mult, int shift, int zo, int amin, int amax, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int cq = C / 4;
+    const long row = gid / cq;             // chunk * P + position
+    const int c4 = (int)(gid - row * cq);
+    const long b = row / P;
+    const uint32_t xv = *reinterpret_cast<const uint32_t*>(x + row * C + 4 * c4);
+    const uint32_t gv = *reinterpret_cast<const uint32_t*>(gate + b * C + 4 * c4);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int32_t a = (int32_t)(int8_t)(xv >> (8 * e)) - zx, g = (int32_t)(int8_t)(gv >> (8 * e)) - zg;
+        const int32_t q = clampi(mbqm(a * g, mult, shift) + zo, amin, amax);
+        packed |= ((uint32_t)(uint8_t)(int8_t)q) << (8 * e);
+    }
+    *reinterpret_cast<uint32_t*>(y + row * C + 4 * c4) = packed;
+}
+
+// DEQUANTIZE -> float32 SOFTMAX over the classes of a chunk: one wave per chunk (scores), logits = the dequantised input
+__global__ __launch_bounds__(64) void i8_head_softmax_kernel(const int8_t* __restrict__ x, float* __restrict__ scores, float* __restrict__ logits,
+                                                             int C, int zp_fc, float s_fc, float beta) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int8_t* row = x + (size_t)b * C;
+    float mx = -3.4e38f;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, (float)(row[c] - zp_fc) * s_fc);
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+    for (int c = lane; c < C; c += 64) sum += expf(((float)(row[c] - zp_fc) * s_fc - mx) * beta);
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int c = lane; c < C; c += 64) {
+        const float v = (float)(row[c] - zp_fc) * s_fc;
+        if (logits) logits[(size_t)b * C + c] = v;
+        scores[(size_t)b * C + c] = expf((v - mx) * beta) / sum;
     }
 }
 
@@ -338,9 +392,20 @@ void launch_i8_mean(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, 
 }
 
 void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_out, int amin, int amax, const int8_t* w,
-                  const int32_t* bias, const int32_t* mult, const int32_t* shift, hipStream_t s) {
-    hipLaunchKernelGGL(i8_fc_kernel, dim3((B + kFcChunks - 1) / kFcChunks), dim3(128), (size_t)kFcChunks * Cin, s, x, y, B, Cin, Cout, zp_out,
-                       amin, amax, w, bias, mult, shift);
+                  const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut, hipStream_t s) {
+    const int Kp = (Cin + 3) & ~3;
+    hipLaunchKernelGGL(i8_fc_kernel, dim3((B + kFcChunks - 1) / kFcChunks), dim3(128), (size_t)kFcChunks * Kp, s, x, y, B, Cin, Kp, Cout, zp_out,
+                       amin, amax, w, bias, mult, shift, lut);
+}
+
+void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int P, int C, int zx, int zg, int mult, int shift, int zo,
+                     int amin, int amax, hipStream_t s) {
+    const long total = (long)B * P * (C / 4);
+    hipLaunchKernelGGL(i8_scale_kernel, grid1d(total, 256), dim3(256), 0, s, x, gate, y, P, C, zx, zg, mult, shift, zo, amin, amax, total);
+}
+
+void launch_i8_head_softmax(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, float s_fc, float beta, hipStream_t s) {
+    hipLaunchKernelGGL(i8_head_softmax_kernel, dim3(B), dim3(64), 0, s, x, scores, logits, C, zp_fc, s_fc, beta);
 }
 
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,

@@ -160,8 +160,12 @@ void launch_i8_pw(const int8_t* x, const int8_t* res, int8_t* y, int B, int P, i
                   const int32_t* shift, hipStream_t s);
 void launch_i8_mean(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, int mult, int shift, int zp_out,
                     hipStream_t s);
+// w: [Cout][Cin rounded up to a multiple of 4], zero padded; lut: optional int8 table applied to the result (LOGISTIC behind the layer)
 void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_out, int amin, int amax, const int8_t* w,
-                  const int32_t* bias, const int32_t* mult, const int32_t* shift, hipStream_t s);
+                  const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut, hipStream_t s);
+void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int P, int C, int zx, int zg, int mult, int shift, int zo,
+                     int amin, int amax, hipStream_t s);
+void launch_i8_head_softmax(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, float s_fc, float beta, hipStream_t s);
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,
                     float s_out, const int8_t* lut, hipStream_t s);
 

@@ -198,7 +198,12 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                 break;
             case BN_OP_I8_FC:  // Cin Cout ...
                 c.dims({p[0], p[1]}, "fully connected") && c.slot(o.in0, 1LL * p[0], "input") && c.slot(o.out, 1LL * p[1], "output") &&
-                    c.tensor(0, 1LL * p[0] * p[1], "weights") && c.tensor(1, 4LL * p[1], "bias") && c.tensor(2, 4LL * p[1], "multipliers") && c.tensor(3, 4LL * p[1], "shifts");
+                    c.tensor(0, up(p[0], 4) * p[1], "weights") && c.tensor(1, 4LL * p[1], "bias") && c.tensor(2, 4LL * p[1], "multipliers") &&
+                    c.tensor(3, 4LL * p[1], "shifts") && (!p[5] || c.tensor(4, 256, "table"));
+                break;
+            case BN_OP_I8_SCALE:  // P C zp_x zp_gate mult shift zp_out act_min act_max
+                c.dims({p[0], p[1]}, "scale") && c.slot(o.in0, 1LL * p[0] * p[1], "input") && c.slot(o.in1, 1LL * p[1], "gate") && c.slot(o.out, 1LL * p[0] * p[1], "output");
+                if (c.ok && p[1] % 4) c.bad("channel count %d is not a multiple of 4", p[1]);
                 break;
             case BN_OP_I8_HEAD:  // C zp_fc zp_out has_lut
                 c.dims({p[0]}, "head") && c.slot(o.in0, 1LL * p[0], "input") && c.slot(o.out, 4LL * p[0], "scores") && (!p[3] || c.tensor(0, 256, "table"));

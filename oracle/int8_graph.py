@@ -19,6 +19,7 @@ Conventions restated:
       twice_max / (2^20 s_y), broadcasting allowed
 * MEAN  int32 sum - N zp_x ; multiplier (s_x / s_y) with the 1/N folded in as in reduce.h
 * LOGISTIC  256-entry float32 LUT ; DEQUANTIZE (q - zp) * s
+* MUL   zo + MBQM((q1 - z1)(q2 - z2), s1 s2 / so), broadcasting ; SOFTMAX only in float32 behind DEQUANTIZE
 * TRANSPOSE / STRIDED_SLICE / SHAPE / PACK / FILL / CONCATENATION are exact data movement.
 """
 
@@ -230,7 +231,24 @@ class Int8Interpreter:
             self._prep[key] = {"mult": mult, "shift": shift, "act": activation_range(op.options["activation"], s_out, zp_out)}
         p = self._prep[key]
         acc = (x.reshape(-1, w.shape[1]) - zp_in) @ w.T + bias
-        y = mbqm(acc, p["mult"], p["shift"]) + zp_out
+        y = np.clip(mbqm(acc, p["mult"], p["shift"]) + zp_out, *p["act"]).astype(np.int8)
+        if op.options.get("keep_num_dims"):  # [..., in] -> [..., out] (squeeze-excite Dense layers on [B, 1, 1, C])
+            y = y.reshape(*x.shape[:-1], w.shape[0])
+        return y
+
+    def _mul(self, op, env):
+        """int8 MUL (reference kernel mul.h): zo + MultiplyByQuantizedMultiplier((q1 - z1) * (q2 - z2), s1 * s2 / so), broadcasting."""
+        a = self._value(env, op.inputs[0]).astype(np.int64)
+        b = self._value(env, op.inputs[1]).astype(np.int64)
+        s1, z1 = self._q(op.inputs[0])
+        s2, z2 = self._q(op.inputs[1])
+        so, zo = self._q(op.outputs[0])
+        key = op.index
+        if key not in self._prep:
+            real = float(np.float32(s1)) * float(np.float32(s2)) / float(np.float32(so))
+            self._prep[key] = {"m": quantize_multiplier(real), "act": activation_range(op.options["activation"], so, zo)}
+        p = self._prep[key]
+        y = mbqm((a - z1) * (b - z2), *p["m"]) + zo
         return np.clip(y, *p["act"]).astype(np.int8)
 
     def logistic_lut(self, op) -> np.ndarray:
@@ -307,6 +325,15 @@ class Int8Interpreter:
             elif n == "LOGISTIC":
                 lut = self.logistic_lut(op)
                 y = lut[self._value(env, op.inputs[0]).astype(np.int32) + 128]
+            elif n == "MUL":
+                y = self._mul(op, env)
+            elif n == "SOFTMAX":  # float32 softmax behind DEQUANTIZE (the form this build's exporter writes): exp(beta (x - max)) / sum
+                xin = self._value(env, op.inputs[0])
+                if xin.dtype != np.float32:
+                    raise ValueError("int8 SOFTMAX is not restated; the exporter of this build dequantises first")
+                z = (xin - xin.max(axis=-1, keepdims=True)) * np.float32(op.options.get("beta", 1.0))
+                e = np.exp(z, dtype=np.float32)
+                y = (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
             else:
                 raise ValueError(f"operator {n} not handled by the oracle")
             env[op.outputs[0]] = y

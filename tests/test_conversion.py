@@ -193,3 +193,139 @@ def test_cli_convert_end_to_end(tmp_path):
     bad = subprocess.run(cmd[:4] + ["--checkpoint_path", KERAS_PATH, "--quantization", "dynamic"], capture_output=True, text=True,
                          env=dict(__import__("os").environ, PYTHONPATH=PKG), timeout=300)
     assert bad.returncode != 0 and "dynamic" in (bad.stderr + bad.stdout)
+
+
+# ------------------------------------------------------------------ template-free exporter (SE / inverted residuals / softmax)
+EXPORT_TOPOLOGIES = {
+    "ir_se_softmax": dict(),
+    "ds_se_emb_sigmoid": dict(use_inverted_residual=False, use_se=True, embeddings_size=128, class_activation="sigmoid"),
+    "alpha1.5_pcen": dict(alpha=1.5, mag_scale="pcen", num_classes=37),
+    "ir_deep_narrow_nomag": dict(use_se=False, depth_multiplier=2, alpha=0.5, mag_scale="none"),
+}
+
+
+def _export(kw, n_cal=4, seed=0):
+    from birdnet_stm32.conversion.export import convert_netspec_to_int8
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._tflite_reader import parse_tflite
+    from birdnet_stm32.models._tflite_writer import write_tflite
+    from oracle import stft
+
+    args = dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=10, randomize_bn=True, seed=7)
+    args.update(kw)
+    spec = build_model("dscnn", **args)
+    x = np.stack([stft.hybrid_spectrogram(a) for a in synth_chunks(n_cal + 3, seed=seed + 3)])[..., None].astype(np.float32)
+    graph = convert_netspec_to_int8(spec, lambda: ([x[i : i + 1]] for i in range(n_cal)), frontend_norm=False)
+    raw = write_tflite(graph)
+    return spec, parse_tflite(raw), raw, x
+
+
+@pytest.mark.parametrize("name", list(EXPORT_TOPOLOGIES))
+def test_exported_int8_graph_tracks_the_float_model(name):
+    """build_model(...) -> own PTQ -> .tflite bytes -> reader -> INT8 oracle: squeeze-excite (MEAN / FULLY_CONNECTED / LOGISTIC / MUL),
+    inverted residuals (ADD without activation), embedding conv, PWL / PCEN / no magnitude scaling, sigmoid and softmax heads.  The
+    quantised graph tracks the float oracle (reference bar: cosine > 0.8, tests/test_conversion.py:112-113 of the reference)."""
+    from oracle import float_graph
+    from oracle.int8_graph import Int8Interpreter
+
+    spec, model, raw, x = _export(EXPORT_TOPOLOGIES[name])
+    assert raw[4:8] == b"TFL3" and model.ops[0].name == "QUANTIZE" and model.tensors[model.inputs[0]].dtype == np.float32
+    names = {op.name for op in model.ops}
+    assert names <= {"QUANTIZE", "TRANSPOSE", "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "MUL", "MEAN", "FULLY_CONNECTED", "LOGISTIC", "DEQUANTIZE", "SOFTMAX"}
+    if EXPORT_TOPOLOGIES[name].get("use_se", True):
+        assert {"MUL", "MEAN", "LOGISTIC"} <= names
+    for t in model.tensors:  # converter rules: int8 activations per tensor, weights symmetric per channel, biases int32 at s_in * s_w
+        if t.dtype == np.int8 and t.data is not None:
+            assert np.all(t.zero_point == 0) and np.abs(t.data.astype(np.int32)).max() <= 127
+    for op in model.ops:
+        if op.name in ("CONV_2D", "DEPTHWISE_CONV_2D", "FULLY_CONNECTED"):
+            w, b = model.tensors[op.inputs[1]], model.tensors[op.inputs[2]]
+            assert b.dtype == np.int32 and np.allclose(b.scale, np.float32(model.tensors[op.inputs[0]].scale[0]) * w.scale, rtol=1e-6)
+    for op in model.ops:
+        if op.name == "LOGISTIC":
+            assert model.tensors[op.outputs[0]].scale[0] == pytest.approx(1 / 256) and model.tensors[op.outputs[0]].zero_point[0] == -128
+    got = Int8Interpreter(model).invoke(x)
+    spec.frontend.attrs["norm"] = False
+    ref = float_graph.forward(spec, x, np.float64)
+    assert got.shape == ref.shape and np.all(np.isfinite(got))
+    for b in range(x.shape[0]):
+        assert cosine(got[b], ref[b]) > 0.98, (name, b, cosine(got[b], ref[b]))
+    if spec.layers[-1].attrs["activation"] == "softmax":
+        assert np.allclose(got.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_exporter_refuses_what_it_cannot_express():
+    from birdnet_stm32.conversion.export import netspec_to_graph
+    from birdnet_stm32.models import build_model
+
+    args = dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=10)
+    with pytest.raises(NotImplementedError, match="max-normalisation"):
+        netspec_to_graph(build_model("dscnn", **args))  # current hybrid frontends normalise per sample
+    with pytest.raises(NotImplementedError, match="hybrid frontend"):
+        netspec_to_graph(build_model("dscnn", audio_frontend="raw", **args))
+    with pytest.raises(NotImplementedError, match="attention pooling"):
+        netspec_to_graph(build_model("dscnn", use_attention_pooling=True, **args), frontend_norm=False)
+
+
+def test_tflite_writer_round_trips_the_shipped_file():
+    """models/_tflite_writer.write_tflite is the inverse of the reader: the shipped graph written out and read back is identical
+    (tensors, shapes, dtypes, quantisation, constant data, operators, options, versions, inputs / outputs)."""
+    from birdnet_stm32.models._tflite_reader import load_tflite, parse_tflite
+    from birdnet_stm32.models._tflite_writer import write_tflite
+
+    m = load_tflite(TFLITE_PATH)
+    raw = write_tflite(m)
+    assert raw[4:8] == b"TFL3" and len(raw) % 16 == 0
+    m2 = parse_tflite(raw)
+    assert (m2.version, m2.inputs, m2.outputs, len(m2.tensors), len(m2.ops)) == (3, m.inputs, m.outputs, len(m.tensors), len(m.ops))
+    for a, b in zip(m.tensors, m2.tensors):
+        assert (a.name, a.shape, a.dtype, a.quantized_dimension) == (b.name, b.shape, b.dtype, b.quantized_dimension)
+        assert np.array_equal(a.scale, b.scale) and np.array_equal(a.zero_point, b.zero_point)
+        assert (a.data is None) == (b.data is None) and (a.data is None or np.array_equal(a.data, b.data))
+    for a, b in zip(m.ops, m2.ops):
+        assert (a.name, a.version, a.inputs, a.outputs, a.options) == (b.name, b.version, b.inputs, b.outputs, b.options)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(EXPORT_TOPOLOGIES))
+def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
+    """The device plan lowered from an exported graph against the INT8 oracle on the same graph: every int8 tensor bit for bit
+    (squeeze-excite gates, MUL, ADD without activation, padded FULLY_CONNECTED rows included), sigmoid scores exactly, softmax
+    scores (float32 behind DEQUANTIZE) to 1e-6; the production plan (slots recycled, fused blocks) gives the debug plan's scores."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from birdnet_stm32.models._lower_i8 import lower_i8
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle.int8_graph import Int8Interpreter
+
+    spec, model, _, x = _export(EXPORT_TOPOLOGIES[name])
+    ref, env = Int8Interpreter(model).invoke(x, return_all=True)
+    B = x.shape[0]
+    for fuse in (True, False):
+        runner = HipRunner(lower_i8(model, keep_all=True, fuse=fuse), max_batch=B)
+        got = runner.predict(x)
+        checked = 0
+        for oi, op in enumerate(runner.plan.ops):
+            if op.out < 0 or not op.name.startswith("t"):
+                continue
+            ti = int(op.name[1:])
+            a = runner.op_output(oi, B)
+            r = env[ti]
+            if op.kind == 20:  # quantised, transposed, zero-padded spectrogram
+                r = r.reshape(B, a.shape[1], -1)
+                a = a[:, :, : r.shape[2]]
+            r = r.reshape(a.shape)
+            bad = int((a != r).sum())
+            assert bad == 0, f"{name} fuse={fuse}: tensor {op.name} (plan op {oi}, kind {op.kind}): {bad} of {a.size} values differ"
+            checked += 1
+        assert checked >= 20
+        softmax = spec.layers[-1].attrs["activation"] == "softmax"
+        assert np.allclose(got, ref, atol=1e-6) if softmax else np.array_equal(got, ref)
+        runner.close()
+    prod = HipRunner(lower_i8(model), max_batch=B)
+    assert np.array_equal(prod.predict(x), got)
+    for nb in (1, 3):
+        assert np.array_equal(prod.predict(x[:nb]), got[:nb])
+    prod.close()
