@@ -104,96 +104,124 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
     const v4i* wl = reinterpret_cast<const v4i*>(lds + L.w_off) + lane;
     const int dw_lo = L.dw_lo, dw_hi = L.dw_hi, pw_lo = L.pw_lo, pw_hi = L.pw_hi;
 
-    for (int u = wave; u < TILES * NGRP; u += kTailWaves) {
-        const int tile = u / NGRP, grp = u % NGRP;
-        const int p = tile * 16 + n;                 // position over the kTailG chunks
-        const int g = p / PER_CHUNK, pc = p % PER_CHUNK;
-        const int oy = pc / OW, ox = pc % OW;
-
-        // ---- depthwise 3x3 for all CIN channels of this lane's position -> B fragments --------------------------------------
-        int taddr[9];
+    // A wave takes UPW tiles at a time (two when every wave has two): the depthwise / pointwise constants and the A operands are
+    // read from LDS once for both (the LDS pipe is the second-busiest unit of this kernel after the vector ALU).
+    constexpr int UPW = (TILES * NGRP) % (2 * kTailWaves) == 0 && !SRCG ? 2 : 1;
+    for (int u0 = wave * UPW; u0 < TILES * NGRP; u0 += kTailWaves * UPW) {
+        int p[UPW], grp[UPW];
+        int taddr[UPW][9];
         unsigned okmask = 0;
+        int chunk = 0;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int t = 0; t < UPW; ++t) {
+            const int u = u0 + t;
+            const int tile = u / NGRP;
+            grp[t] = u % NGRP;
+            p[t] = tile * 16 + n;                    // position over the kTailG chunks
+            const int g = p[t] / PER_CHUNK, pc = p[t] % PER_CHUNK;
+            const int oy = pc / OW, ox = pc % OW;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int iy = oy * S - PT + dy, ix = ox * S - PL + dx;
-                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                if constexpr (SRCG) {
-                    taddr[dy * 3 + dx] = ok ? (iy * W + ix) * CIN + 4 * qb : 0;
-                    okmask |= ok ? 1u << (dy * 3 + dx) : 0u;
-                } else {
-                    taddr[dy * 3 + dx] = (ok ? L.x_off + ((g * H + iy) * W + ix) * PIN : L.zp_off) + 4 * qb;
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int iy = oy * S - PT + dy, ix = ox * S - PL + dx;
+                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    if constexpr (SRCG) {
+                        taddr[t][dy * 3 + dx] = ok ? (iy * W + ix) * CIN + 4 * qb : 0;
+                        okmask |= ok ? 1u << (dy * 3 + dx) : 0u;
+                    } else {
+                        taddr[t][dy * 3 + dx] = (ok ? L.x_off + ((g * H + iy) * W + ix) * PIN : L.zp_off) + 4 * qb;
+                    }
                 }
-            }
-        int chunk = chunk0 + g;
-        if (chunk >= a.B) chunk = a.B - 1;           // ragged last group: the spare slots repeat the last chunk
+            chunk = chunk0 + g;
+            if (chunk >= a.B) chunk = a.B - 1;       // ragged last group: the spare slots repeat the last chunk
+        }
         // (only the first block reads global memory; the other instantiations never use the descriptor)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * H * W * CIN : 0), 0, SRCG ? H * W * CIN : 0, 0x00020000);
-        v4i bf[KS];
+
+        // ---- depthwise 3x3 for all CIN channels of this lane's position(s) -> B fragments -------------------------------------
+        v4i bf[UPW][KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            int frag[4];
+            int frag[UPW][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int qi = 4 * ks + j;   // quad qb + qi: channels 4 (qb + qi) ..
                 const v4i bias = dwc[qi * 7 + 3];
-                int acc[4] = {bias[0], bias[1], bias[2], bias[3]};
+                int acc[UPW][4];
+#pragma unroll
+                for (int t = 0; t < UPW; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][e] = bias[e];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    int r[3];
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        if constexpr (SRCG) {
-                            const int v = __builtin_amdgcn_raw_buffer_load_b32(rs, taddr[dy * 3 + dx] + 4 * qi, 0, 0);
-                            r[dx] = (okmask >> (dy * 3 + dx)) & 1 ? v : zp4;
-                        } else {
-                            r[dx] = *reinterpret_cast<const int*>(lds + taddr[dy * 3 + dx] + 4 * qi);
-                        }
-                    }
                     const v4i w = dwc[qi * 7 + dy];
-                    const int lo = perm(r[1], r[0], 0x05010400u), hi = perm(r[1], r[0], 0x07030602u);  // bytes (tap0, tap1, tap2, 0) per channel
-                    acc[0] = dot4(perm(r[2], lo, 0x0c040100u), w[0], acc[0]);
-                    acc[1] = dot4(perm(r[2], lo, 0x0c050302u), w[1], acc[1]);
-                    acc[2] = dot4(perm(r[2], hi, 0x0c060100u), w[2], acc[2]);
-                    acc[3] = dot4(perm(r[2], hi, 0x0c070302u), w[3], acc[3]);
+#pragma unroll
+                    for (int t = 0; t < UPW; ++t) {
+                        int r[3];
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            if constexpr (SRCG) {
+                                const int v = __builtin_amdgcn_raw_buffer_load_b32(rs, taddr[t][dy * 3 + dx] + 4 * qi, 0, 0);
+                                r[dx] = (okmask >> (dy * 3 + dx)) & 1 ? v : zp4;
+                            } else {
+                                r[dx] = *reinterpret_cast<const int*>(lds + taddr[t][dy * 3 + dx] + 4 * qi);
+                            }
+                        }
+                        const int lo = perm(r[1], r[0], 0x05010400u), hi = perm(r[1], r[0], 0x07030602u);  // bytes (tap0, tap1, tap2, 0) per channel
+                        acc[t][0] = dot4(perm(r[2], lo, 0x0c040100u), w[0], acc[t][0]);
+                        acc[t][1] = dot4(perm(r[2], lo, 0x0c050302u), w[1], acc[t][1]);
+                        acc[t][2] = dot4(perm(r[2], hi, 0x0c060100u), w[2], acc[t][2]);
+                        acc[t][3] = dot4(perm(r[2], hi, 0x0c070302u), w[3], acc[t][3]);
+                    }
                 }
                 const v4i m = dwc[qi * 7 + 4], c1 = dwc[qi * 7 + 5], sh = dwc[qi * 7 + 6];
-                int qv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu(acc[e], m[e], c1[e], sh[e]), dw_lo, dw_hi);
-                frag[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+                for (int t = 0; t < UPW; ++t) {
+                    int qv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu(acc[t][e], m[e], c1[e], sh[e]), dw_lo, dw_hi);
+                    frag[t][j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+                }
             }
-            bf[ks] = (v4i){frag[0], frag[1], frag[2], frag[3]};
+#pragma unroll
+            for (int t = 0; t < UPW; ++t) bf[t][ks] = (v4i){frag[t][0], frag[t][1], frag[t][2], frag[t][3]};
         }
 
         // ---- pointwise 1x1 on the matrix cores, requantise, [ADD], store into the next map ------------------------------------
-        // accumulator rows 4 kq .. 4 kq + 3 of tile nt = output channels 16 nt + 4 kq ..
-        const int yrow = L.y_off + p * POUT + 4 * kq;
-        const int xrow = L.x_off + p * PIN + 4 * kq;  // residual: blocks with the ADD have CIN == COUT and stride 1 (same position)
-#pragma unroll 2
+        // accumulator rows 4 kq .. 4 kq + 3 of tile nt = output channels 16 nt + 4 kq ..; the tiles of a wave share the channel group
         for (int tt = 0; tt < NT_PER; ++tt) {
-            const int nt = grp * NT_PER + tt;
+            const int nt = grp[0] * NT_PER + tt;
             const v4i* pc4 = pwc + nt * 16;
-            v4i acc = pc4[0];
+            v4i acc[UPW];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wl[(nt * KS + ks) * 64], bf[ks], acc, 0, 0, 0);
-            const v4i m = pc4[1], c1 = pc4[2], sh = pc4[3];
-            int res = 0;
-            if constexpr (ADD) res = *reinterpret_cast<const int*>(lds + xrow + 16 * nt);
-            int qv[4];
+            for (int t = 0; t < UPW; ++t) acc[t] = pc4[0];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // with the ADD: value + 128 = index of the second table (any sign: full rounding)
-                int v = med3(ADD ? rq(acc[e], m[e], c1[e], sh[e]) : rq_relu(acc[e], m[e], c1[e], sh[e]), pw_lo, pw_hi);
-                if constexpr (ADD) {
-                    const int sa = lut[(res >> (8 * e)) & 0xff], sb = lut[256 + v];
-                    v = med3(rq(sa + sb, L.add_m, L.add_c1, L.add_e), L.add_lo, L.add_hi);
-                }
-                qv[e] = v;
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i af = wl[(nt * KS + ks) * 64];
+#pragma unroll
+                for (int t = 0; t < UPW; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[t][ks], acc[t], 0, 0, 0);
             }
-            *reinterpret_cast<int*>(lds + yrow + 16 * nt) = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+            const v4i m = pc4[1], c1 = pc4[2], sh = pc4[3];
+#pragma unroll
+            for (int t = 0; t < UPW; ++t) {
+                const int yrow = L.y_off + p[t] * POUT + 4 * kq;
+                int res = 0;
+                if constexpr (ADD) res = *reinterpret_cast<const int*>(lds + L.x_off + p[t] * PIN + 4 * kq + 16 * nt);  // residual: same position
+                int qv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // with the ADD: value + 128 = index of the second table (any sign: full rounding)
+                    int v = med3(ADD ? rq(acc[t][e], m[e], c1[e], sh[e]) : rq_relu(acc[t][e], m[e], c1[e], sh[e]), pw_lo, pw_hi);
+                    if constexpr (ADD) {
+                        const int sa = lut[(res >> (8 * e)) & 0xff], sb = lut[256 + v];
+                        v = med3(rq(sa + sb, L.add_m, L.add_c1, L.add_e), L.add_lo, L.add_hi);
+                    }
+                    qv[e] = v;
+                }
+                *reinterpret_cast<int*>(lds + yrow + 16 * nt) = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+            }
         }
     }
     __syncthreads();
