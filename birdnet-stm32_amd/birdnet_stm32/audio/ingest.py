@@ -86,6 +86,22 @@ def read_pcm_window(path: str, max_duration: float | None = 30, chunk_duration: 
                     return None
                 view = np.frombuffer(raw, np.uint8, count * frame, off + first * frame)
                 return PcmWindow(view, fmt, ch, sr0)
+        if path.lower().endswith(".flac"):  # decoded on the host (entropy coding is serial); mixing / resampling / scaling stay on the device
+            from birdnet_stm32.audio import _flac
+
+            with open(path, "rb") as fh:
+                raw = fh.read()
+            sr0, ch, bps, total = _flac.flac_info(raw)
+            if total == 0:
+                total = int(_flac.decode_flac(raw, verify_md5=False)[0].shape[0])
+            first, count = _window_frames(total, sr0, max_duration, chunk_duration, random_offset)
+            if count <= 0:
+                return None
+            ints = _flac.decode_flac(raw, first, count, verify_md5=False)[0]
+            if bps == 16:
+                return PcmWindow(np.ascontiguousarray(ints.astype(np.int16)).reshape(-1).view(np.uint8), PCM_S16, ch, sr0)
+            if bps <= 32 and bps != 16:  # libsndfile's scaling x / 2^(bps-1) == (x << (32 - bps)) / 2^31: the device's 32-bit PCM path
+                return PcmWindow(np.ascontiguousarray(ints << (32 - bps) if bps < 32 else ints).astype(np.int32).reshape(-1).view(np.uint8), PCM_S32, ch, sr0)
         frames, sr0 = _io._read_window(path, max_duration, chunk_duration, random_offset)
         if frames.size == 0:
             return None

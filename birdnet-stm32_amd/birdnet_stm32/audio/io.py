@@ -14,8 +14,10 @@ per file (reference: birdnet_stm32/evaluation/metrics.py:44-46):
 
 The reference decodes through libsndfile (``soundfile``); that package is not on the MI355X image, so
 RIFF/WAVE files (PCM 8/16/24/32-bit, IEEE float 32/64, plain or WAVE_FORMAT_EXTENSIBLE) are parsed
-here with libsndfile's scaling (int16 / 32768 etc.).  Other containers are handed to ``soundfile``
-when it is importable and otherwise count as unreadable.
+here with libsndfile's scaling (int16 / 32768 etc.) and native FLAC streams are decoded by the plain-C
+decoder of this build (``audio/_flac.py`` -> ``csrc/host/bn_flac.c``).  Other containers (Ogg, MP3, M4A)
+are handed to ``soundfile`` when it is importable and otherwise count as unreadable; ``evaluate`` says
+how many files it skipped for that reason.
 """
 
 from __future__ import annotations
@@ -119,6 +121,15 @@ def _read_window(path: str, max_duration, chunk_duration: float, random_offset: 
         code, ch, sr0, bits, off, nbytes = _wav_layout(raw)
         total = nbytes // max(1, (bits // 8) * ch)
         reader = lambda first, count: _decode_frames(raw, code, ch, bits, off, nbytes, first, count)  # noqa: E731
+    elif path.lower().endswith(".flac"):
+        from birdnet_stm32.audio import _flac
+
+        with open(path, "rb") as fh:
+            raw = fh.read()
+        sr0, _ch, _bps, total = _flac.flac_info(raw)
+        if total == 0:  # length not recorded in STREAMINFO: decode once to learn it
+            total = int(_flac.decode_flac(raw, verify_md5=False)[0].shape[0])
+        reader = lambda first, count: _flac.read_flac_window(raw, first, count)[0]  # noqa: E731
     else:
         import soundfile as sf  # not installed on the MI355X image: such files count as unreadable
 

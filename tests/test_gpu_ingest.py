@@ -6,6 +6,8 @@ tests/test_oracle_pinning.py); mean and max pooling bit-exact, log-mean-exp with
 (``exp``/``log`` differ in the last bits between libm and the device).
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -384,3 +386,41 @@ def test_evaluate_raw_frontend_device_pipeline(tmp_path):
     assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
     assert np.array_equal(ys_dev, ys_ref)
     runner.close()
+
+
+def test_device_ingest_reads_flac_like_wav(tmp_path):
+    """A FLAC file (16-bit stereo, 44.1 kHz; decoded on the host by csrc/host/bn_flac.c, uploaded as PCM) through the device ingest gives
+    the chunks of the same samples in a WAV file, bit for bit — and the 24-bit form the chunks of the float oracle."""
+    import struct
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import flac_writer as fw
+
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.audio import ingest
+    from oracle import ingest as oi
+
+    rng = np.random.default_rng(4)
+    n = 44100 * 4
+    t = np.arange(n)
+    x = np.stack([8000 * np.sin(2 * np.pi * 1000 * t / 44100) + rng.normal(0, 500, n), 6000 * np.sin(2 * np.pi * 300 * t / 44100) + rng.normal(0, 400, n)], axis=1)
+    pcm = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    frames = [{"n": 4096, "mode": "ms", "sub": [dict(kind="fixed", order=2, po=3), dict(kind="fixed", order=2, po=3)]} for _ in range(n // 4096)]
+    if n % 4096:
+        frames.append({"n": n % 4096, "mode": "indep", "sub": [dict(kind="fixed", order=1, po=0), dict(kind="fixed", order=1, po=0)]})
+    (tmp_path / "a.flac").write_bytes(fw.encode(pcm.astype(np.int64), 44100, 16, frames))
+    payload = pcm.astype("<i2").tobytes()
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(payload), b"WAVE", b"fmt ", 16, 1, 2, 44100, 44100 * 4, 4, 16, b"data", len(payload))
+    (tmp_path / "a.wav").write_bytes(hdr + payload)
+    x24 = (pcm.astype(np.int64) << 8) + rng.integers(-100, 100, size=pcm.shape)
+    (tmp_path / "b.flac").write_bytes(fw.encode(x24, 44100, 24, frames))
+    ctx = _hip.Context(0, 64)
+    chunks, counts = ingest.load_audio_files_device(ctx, [str(tmp_path / "a.flac"), str(tmp_path / "a.wav"), str(tmp_path / "b.flac")], 24000, 30, 3.0, 0.0)
+    assert counts[0] == counts[1] == counts[2] > 0
+    c = chunks.cpu().numpy()
+    k = counts[0]
+    assert np.array_equal(c[:k].view(np.uint32), c[k : 2 * k].view(np.uint32))
+    want = oi.split_chunks(oi.ingest_window((x24.astype(np.float64) / float(1 << 23)).astype(np.float32), 44100, 24000), 24000, 3.0, 0.0)
+    assert np.array_equal(c[2 * k :].view(np.uint32), want.view(np.uint32))
+    ctx.close()

@@ -383,3 +383,83 @@ def test_polyphase_filter_layout_and_chunk_table(tmp_path):
     assert ingest.read_pcm_window(str(tmp_path / "nope.wav")) is None
     io.save_wav(np.zeros(10, np.float32), p, 24000, subtype="FLOAT")
     assert ingest.read_pcm_window(p).fmt == ingest.PCM_F32
+
+
+# ------------------------------------------------------------------------------- FLAC decode (audio/_flac.py, csrc/host/bn_flac.c)
+def _flac_cases():
+    import flac_writer as fw  # noqa: F401
+
+    rng = np.random.default_rng(12)
+    n = 4096 + 1152 + 200 + 16
+    t = np.arange(n)
+    left = (9000 * np.sin(2 * np.pi * 440 * t / 22050) + rng.normal(0, 300, n)).astype(np.int64)
+    right = (0.6 * left + 2500 * np.sin(2 * np.pi * 97 * t / 22050) + rng.normal(0, 200, n)).astype(np.int64)
+    stereo = np.clip(np.stack([left, right], axis=1), -32768, 32767)
+    frames = [
+        {"n": 4096, "mode": "ms", "sub": [dict(kind="fixed", order=2, po=3), dict(kind="fixed", order=1, po=0)]},
+        {"n": 1152, "mode": "ls", "sub": [dict(kind="lpc", lpc=([1900, -900], 12, 10), po=2, rice2=True), dict(kind="fixed", order=4, po=1, escape_parts=(1,))]},
+        {"n": 200, "mode": "sr", "sub": [dict(kind="fixed", order=3, po=0), dict(kind="verbatim")], "explicit_bps": True},
+        {"n": 16, "mode": "indep", "sub": [dict(kind="fixed", order=0, po=2), dict(kind="fixed", order=2, po=0, escape_parts=(0,))]},
+    ]
+    yield "stereo16", stereo, 22050, 16, frames, {}
+    mono = (rng.integers(-(1 << 21), 1 << 21, size=(300 + 4608, 1)) >> 4) << 4  # 24-bit, four wasted bits
+    mono[300:900] = 4096  # a constant stretch
+    frames = [{"n": 300, "sub": [dict(kind="fixed", order=1, po=0, wasted=4)], "number": 0},
+              {"n": 600, "sub": [dict(kind="constant")], "number": 1},
+              {"n": 4008, "sub": [dict(kind="lpc", lpc=([7, 3, -2], 5, 4), po=3, wasted=4)], "number": 2}]
+    yield "mono24_wasted", mono, 48000, 24, frames, {"id3": True}
+    many = np.clip(rng.normal(0, 1000, size=(192 * 140, 1)), -32768, 32767).astype(np.int64)  # frame numbers above 127: two-byte coded numbers
+    frames = [{"n": 192, "sub": [dict(kind="fixed", order=2, po=1)]} for _ in range(140)]
+    yield "many_frames", many, 16000, 16, frames, {"total_known": False, "with_md5": False}
+
+
+def test_flac_decoder_matches_the_encoded_samples(tmp_path):
+    """csrc/host/bn_flac.c on streams written by tests/flac_writer.py (both from RFC 9639): every subframe type, Rice / Rice2 / escape
+    partitions, wasted bits, the three stereo modes, explicit block sizes, multi-byte frame numbers, ID3 prefix, unknown total length,
+    window reads, MD5 and CRC checks — then the host loader and the chunker on a .flac file against the same samples in a .wav."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import flac_writer as fw
+
+    from birdnet_stm32.audio import _flac
+    from birdnet_stm32.audio.io import load_audio_file, load_audio_window
+
+    for name, x, sr, bps, frames, kw in _flac_cases():
+        raw = fw.encode(x, sr, bps, frames, **kw)
+        info = _flac.flac_info(raw)
+        assert info[:3] == (sr, x.shape[1], bps) and info[3] == (x.shape[0] if kw.get("total_known", True) else 0), name
+        ints, sr2, bps2 = _flac.decode_flac(raw)
+        assert (sr2, bps2) == (sr, bps) and np.array_equal(ints, x), name
+        a, b = 1000, 1500
+        part = _flac.decode_flac(raw, a, b, verify_md5=False)[0]
+        assert np.array_equal(part, x[a : a + b]), name
+        f32, _, _, _ = _flac.read_flac_window(raw, 0, x.shape[0])
+        assert f32.dtype == np.float32 and np.array_equal(f32, (x / float(1 << (bps - 1))).astype(np.float32)), name
+    # corruption is detected: a flipped payload bit fails the frame CRC, a wrong MD5 the stream check
+    name, x, sr, bps, frames, kw = next(_flac_cases())
+    raw = bytearray(fw.encode(x, sr, bps, frames))
+    raw[len(raw) // 2] ^= 0x10
+    with pytest.raises(ValueError, match="checksum|malformed"):
+        _flac.decode_flac(bytes(raw))
+    good = bytearray(fw.encode(x, sr, bps, frames))
+    good[8 + 18 + 4] ^= 0xFF  # first MD5 byte inside STREAMINFO
+    with pytest.raises(ValueError, match="MD5"):
+        _flac.decode_flac(bytes(good))
+    with pytest.raises(ValueError, match="malformed"):
+        _flac.flac_info(b"RIFF" + bytes(40))
+    # the loader: same audio as .flac and as .wav gives the same chunks (mono mean, resampling, peak normalisation, chunking)
+    from birdnet_stm32.audio.io import save_wav
+
+    pcm = x[:, 0].astype(np.int16)
+    (tmp_path / "a.flac").write_bytes(fw.encode(pcm[:, None].astype(np.int64), 22050, 16, [{"n": 4096, "sub": [dict(kind="fixed", order=2, po=2)]},
+                                                                                          {"n": pcm.size - 4096, "sub": [dict(kind="fixed", order=1, po=0)]}]))
+    import struct
+
+    payload = pcm.astype("<i2").tobytes()
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(payload), b"WAVE", b"fmt ", 16, 1, 1, 22050, 44100, 2, 16, b"data", len(payload))
+    (tmp_path / "a.wav").write_bytes(hdr + payload)
+    ya, yb = load_audio_window(str(tmp_path / "a.flac"), 24000), load_audio_window(str(tmp_path / "a.wav"), 24000)
+    assert ya.size > 0 and np.array_equal(ya, yb)
+    ca, cb = load_audio_file(str(tmp_path / "a.flac"), 24000, chunk_duration=0.1), load_audio_file(str(tmp_path / "a.wav"), 24000, chunk_duration=0.1)
+    assert len(ca) == len(cb) > 1 and np.array_equal(np.asarray(ca), np.asarray(cb))
