@@ -658,9 +658,19 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                 out_t = nxt.outputs[0]
                 i += 1
             v = pb.value(H * Wd * Cout)
-            pb.op(pk.I8_PW, val[src], v, p=[H * Wd, Cin, Cout, z_o, a_lo, a_hi, *add_p], in1=res_val,
-                  t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
-                  name=f"t{out_t}", out_shape=(H, Wd, Cout), out_dtype="int8")
+            tile = pick_tile(H, Wd)
+            if fuse and tile is not None and Cin % 4 == 0 and Cout % 16 == 0:
+                # plain 1x1 convolution (inverted-residual expand / project, embedding conv) on the int8 matrix cores: the fused block kernel
+                # without its depthwise stage
+                zero = pb.tensor(np.zeros(4, np.int32), np.int32)
+                pp = [H, Wd, Cin, 1, 1, 0, H, Wd, 0, 0, 0, 0, 0, 0, Cout, z_o, a_lo, a_hi, *add_p, 0, 0, *tile, 0, 0]
+                pb.op(pk.I8_DWPW, val[src], v, p=pp, in1=res_val,
+                      t=[zero, zero, zero, zero, pb.tensor(pack_i8_fragments(w), np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                      name=f"t{out_t}", out_shape=(H, Wd, Cout), out_dtype="int8")
+            else:
+                pb.op(pk.I8_PW, val[src], v, p=[H * Wd, Cin, Cout, z_o, a_lo, a_hi, *add_p], in1=res_val,
+                      t=[pb.tensor(w, np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                      name=f"t{out_t}", out_shape=(H, Wd, Cout), out_dtype="int8")
             val[out_t], shape[out_t] = v, (H, Wd, Cout)
             i += 1
         elif op.name == "MEAN":
