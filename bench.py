@@ -172,16 +172,16 @@ def pmc_traffic(dom: dict, batch: int, dtype: str):
     want = output_bytes(dom["kernel"], dom["p"], batch, dtype)
     paths = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{dtype}_b{batch}_traffic.json")),
                    key=lambda q: int(re.search(r"r(\d+)_", os.path.basename(q)).group(1)), reverse=True)
-    if want is None:
-        return None, None
     base = kernel_symbol(dom["kernel"], dom["p"])
     for path in paths:
+        rows = [row for row in json.load(open(path)) if row["kernel"].split("<")[0] == base]
         best = None
-        for row in json.load(open(path)):
-            name = row["kernel"].split("<")[0]
-            if name == base and abs(row["write_bytes"] - want) <= 0.05 * want:
-                if best is None or abs(row["write_bytes"] - want) < abs(best["write_bytes"] - want):
+        if want is not None:  # several launches of one kernel template: the one whose written bytes match this operator's output
+            for row in rows:
+                if abs(row["write_bytes"] - want) <= 0.05 * want and (best is None or abs(row["write_bytes"] - want) < abs(best["write_bytes"] - want)):
                     best = row
+        elif len(rows) == 1:  # a kernel that is launched once per step (the fused tail)
+            best = rows[0]
         if best is not None:
             return int(best["read_bytes"] + best["write_bytes"]), "profiles/" + os.path.basename(path) + " (committed rocprofv3 --pmc run of this workload, replayed)"
     return None, None

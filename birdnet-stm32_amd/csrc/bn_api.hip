@@ -51,6 +51,7 @@ const OptName kOptions[] = {
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
     {"stft_tpw", &bn::Options::stft_tpw},         {"stft_sub", &bn::Options::stft_sub},
+    {"dual_stream", &bn::Options::dual_stream},
     {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
@@ -81,6 +82,9 @@ struct bn_ctx {
     bn::StftTables tables{};
     float* d_block_peaks = nullptr;  // bn_ingest_resample: per-workgroup maxima, grown on demand
     size_t block_peaks_elems = 0;
+    // second stream of bn_infer_audio's two-half pipeline (option dual_stream), created on first use
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_stft = nullptr, ev_join = nullptr;
 };
 
 struct bn_model {
@@ -488,6 +492,10 @@ void bn_ctx_destroy(bn_ctx* c) {
     (void)hipFree(c->d_tw256);
     (void)hipFree(c->d_tw512);
     (void)hipFree(c->d_block_peaks);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_stft) (void)hipEventDestroy(c->ev_stft);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -800,6 +808,35 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     if (!first_only) sub = B;
     m->spec_tiled_now = tiled;
     int rc = BN_OK;
+    // Two halves on two streams, the second one skewed by one STFT (option dual_stream): the STFT of half 1 (vector-ALU issue bound) runs
+    // beside the mel mixer / front block of half 0 (parked on memory most of their time), and so on down the plan.
+    if (bn::g_opt.dual_stream && B >= 512 && B <= kMaxGridBatch && !m->profiling) {
+        bn_ctx* c = m->ctx;
+        if (!c->aux) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        const int h0 = (B / 2 + 3) & ~3, h1 = B - h0;
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        rc = stft_mag_impl(c, d_audio, h0, T, kFft, hop, W, 0, m->d_spec, m->d_minmax, (void*)s, tiled);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_stft, s));
+        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_stft, 0));
+        rc = stft_mag_impl(c, d_audio + (size_t)h0 * T, h1, T, kFft, hop, W, 0, m->d_spec + h0 * in_stride, m->d_minmax + 2 * (size_t)h0, (void*)c->aux, tiled);
+        if (rc) return rc;
+        rc = run_plan(m, m->d_spec, m->d_minmax, h0, d_scores, d_logits, s, nullptr, 0, 0, 0, (size_t)-1, 0);
+        if (rc) return rc;
+        rc = run_plan(m, m->d_spec + h0 * in_stride, m->d_minmax + 2 * (size_t)h0, h1, d_scores + h0 * C, d_logits ? d_logits + h0 * C : nullptr, c->aux,
+                      nullptr, 0, 0, 0, (size_t)-1, (size_t)h0);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_join, c->aux));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+        m->spec_tiled_now = false;
+        return BN_OK;
+    }
     for (int b0 = 0; b0 < B && rc == BN_OK; b0 += sub) {
         const int nb = B - b0 < sub ? B - b0 : sub;
         {

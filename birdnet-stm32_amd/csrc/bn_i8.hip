@@ -234,16 +234,49 @@ __global__ void i8_pw_kernel(const int8_t* __restrict__ x, const int8_t* __restr
     *reinterpret_cast<uint32_t*>(y + row * Cout + 4 * ng) = packed;
 }
 
-// MEAN over positions: int32 sum - P*zp, then the folded multiplier; blockIdx.x = chunk
-__global__ void i8_mean_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int P, int C, int zp_in, int mult,
-                               int shift, int zp_out) {
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int8_t* p = x + (size_t)b * P * C + c;
-        int32_t s = 0;
-        for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
-        s -= zp_in * P;
-        y[(size_t)b * C + c] = (int8_t)clampi(mbqm(s, mult, shift) + zp_out, -128, 127);
+// MEAN over positions: int32 sum - P*zp, then the folded multiplier; blockIdx.x = chunk.  Thread (slice, channel quad): the 256 threads
+// split the positions into 256 / (C / 4) slices (coalesced dword loads, four channels per thread), the slices meet in LDS.
+__global__ __launch_bounds__(256) void i8_mean_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int P, int C, int zp_in, int mult,
+                                                      int shift, int zp_out) {
+    __shared__ int part[256][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int cq = C >> 2;
+    if ((C & 3) || cq > 256) {  // odd channel counts: one thread per channel, all positions
+        for (int c = tid; c < C; c += blockDim.x) {
+            const int8_t* p = x + (size_t)b * P * C + c;
+            int32_t s = 0;
+            for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
+            s -= zp_in * P;
+            y[(size_t)b * C + c] = (int8_t)clampi(mbqm(s, mult, shift) + zp_out, -128, 127);
+        }
+        return;
+    }
+    const int slices = 256 / cq;             // >= 1
+    const int q = tid % cq, sl = tid / cq;
+    int acc[4] = {0, 0, 0, 0};
+    if (sl < slices) {
+        const int32_t* row = reinterpret_cast<const int32_t*>(x + (size_t)b * P * C) + q;
+        for (int i = sl; i < P; i += slices) {
+            const int32_t v = row[(size_t)i * cq];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (int32_t)(int8_t)(v >> (8 * e));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[tid][e] = acc[e];
+    __syncthreads();
+    if (tid < cq) {
+        int s4[4] = {0, 0, 0, 0};
+        for (int k = 0; k < slices; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] += part[k * cq + tid][e];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int32_t qv = clampi(mbqm(s4[e] - zp_in * P, mult, shift) + zp_out, -128, 127);
+            packed |= ((uint32_t)(uint8_t)(int8_t)qv) << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(y + (size_t)b * C + 4 * tid) = packed;
     }
 }
 

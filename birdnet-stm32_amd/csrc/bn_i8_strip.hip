@@ -70,6 +70,17 @@ __device__ __forceinline__ int rq_relu(int x, int m, int c1, int e) {
     return (v + c1) >> e;
 }
 
+// ... and with the addend folded into the 64-bit multiply-add: ((x*m + 2^30) >> 31 + c1) >> e == (x*m + 2^30 + c1 * 2^31) >> (31 + e)
+// (nested floors), i.e. v_mad_i64_i32 with a per-channel 64-bit constant, one funnel shift, one arithmetic shift: 3 instructions + clamp.
+// cl / ch = low / high dword of 2^30 + c1 * 2^31 (rq64_lo / rq64_hi below), computed once per kernel where the constants live in registers.
+__device__ __forceinline__ int rq64_lo(int c1) { return (int)(((uint32_t)c1 << 31) | 0x40000000u); }
+__device__ __forceinline__ int rq64_hi(int c1) { return c1 >> 1; }
+__device__ __forceinline__ int rq_relu64(int x, int m, int cl, int ch, int e) {
+    const long c = ((long)ch << 32) | (uint32_t)cl;
+    const long d = (long)x * (long)m + c;
+    return (int)(d >> 31) >> e;
+}
+
 template <int QL> struct RawRow { int t[3][QL]; };   // three taps (columns j = 0..2) of one input row, QL dwords each
 template <int QL> struct TRow { int c[QL][4]; };     // per channel: bytes (tap0, tap1, tap2, 0)
 
@@ -450,6 +461,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
     const long sta = (long)(uint32_t)a.cst[kF_STA + lane];
     const v4i stb = c4[kF_STB / 4 + kq];
     const v4i stm = c4[kF_STC / 4 + kq * 3 + 0], stc1 = c4[kF_STC / 4 + kq * 3 + 1], ste = c4[kF_STC / 4 + kq * 3 + 2];
+    const v4i stcl = {rq64_lo(stc1.x), rq64_lo(stc1.y), rq64_lo(stc1.z), rq64_lo(stc1.w)}, stch = {rq64_hi(stc1.x), rq64_hi(stc1.y), rq64_hi(stc1.z), rq64_hi(stc1.w)};
     int dww[3][4];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -458,8 +470,9 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
     }
     const v4i dwb = c4[kF_DWB / 4 + kq];
     const v4i dwm = c4[kF_DWC / 4 + kq * 3 + 0], dwc1 = c4[kF_DWC / 4 + kq * 3 + 1], dwe = c4[kF_DWC / 4 + kq * 3 + 2];
+    const v4i dwcl = {rq64_lo(dwc1.x), rq64_lo(dwc1.y), rq64_lo(dwc1.z), rq64_lo(dwc1.w)}, dwch = {rq64_hi(dwc1.x), rq64_hi(dwc1.y), rq64_hi(dwc1.z), rq64_hi(dwc1.w)};
     long pwa[2];
-    v4i pwb[2], pwm[2], pwc1[2], pwe[2];
+    v4i pwb[2], pwm[2], pwc1[2], pwe[2], pwcl[2], pwch[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         pwa[t] = (long)(uint32_t)a.cst[kF_PWA + t * 64 + lane];
@@ -467,6 +480,8 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
         pwm[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 0];
         pwc1[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 1];
         pwe[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 2];
+        pwcl[t] = (v4i){rq64_lo(pwc1[t].x), rq64_lo(pwc1[t].y), rq64_lo(pwc1[t].z), rq64_lo(pwc1[t].w)};
+        pwch[t] = (v4i){rq64_hi(pwc1[t].x), rq64_hi(pwc1[t].y), rq64_hi(pwc1[t].z), rq64_hi(pwc1[t].w)};
     }
 
     const int zfe4 = (a.zp_fe & 0xff) * 0x01010101;
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
                 const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(sta, (long)(uint32_t)x[j], stb, 0, 0, 0);
                 int qv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu(acc[e], stm[e], stc1[e], ste[e]), a.st_lo, a.st_hi);
+                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu64(acc[e], stm[e], stcl[e], stch[e], ste[e]), a.st_lo, a.st_hi);
                 pk[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
             }
             if (right_st) pk[2] = zst4;
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
             int acc = dot4_first(T[i0].c[0][e], dww[0][e], dwb[e]);
             acc = dot4(T[i1].c[0][e], dww[1][e], acc);
             acc = dot4(T[i2].c[0][e], dww[2][e], acc);
-            qv[e] = med3(rq_relu(acc, dwm[e], dwc1[e], dwe[e]), a.dw_lo, a.dw_hi);
+            qv[e] = med3(rq_relu64(acc, dwm[e], dwcl[e], dwch[e], dwe[e]), a.dw_lo, a.dw_hi);
         }
         const long bf = (long)(uint32_t)perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         int outw[2];
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
             const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(pwa[t], bf, pwb[t], 0, 0, 0);
             int ov[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = med3(rq_relu(acc[e], pwm[t][e], pwc1[t][e], pwe[t][e]), a.pw_lo, a.pw_hi);
+            for (int e = 0; e < 4; ++e) ov[e] = med3(rq_relu64(acc[e], pwm[t][e], pwcl[t][e], pwch[t][e], pwe[t][e]), a.pw_lo, a.pw_hi);
             outw[t] = perm(perm(ov[3], ov[2], 0x0c0c0400u), perm(ov[1], ov[0], 0x0c0c0400u), 0x05040100u);
         }
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, oh * a.OW * 32, 0);
