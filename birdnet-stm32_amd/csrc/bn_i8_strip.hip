@@ -71,14 +71,26 @@ __device__ __forceinline__ int rq_relu(int x, int m, int c1, int e) {
 }
 
 // ... and with the addend folded into the 64-bit multiply-add: ((x*m + 2^30) >> 31 + c1) >> e == (x*m + 2^30 + c1 * 2^31) >> (31 + e)
-// (nested floors), i.e. v_mad_i64_i32 with a per-channel 64-bit constant, one funnel shift, one arithmetic shift: 3 instructions + clamp.
-// cl / ch = low / high dword of 2^30 + c1 * 2^31 (rq64_lo / rq64_hi below), computed once per kernel where the constants live in registers.
-__device__ __forceinline__ int rq64_lo(int c1) { return (int)(((uint32_t)c1 << 31) | 0x40000000u); }
-__device__ __forceinline__ int rq64_hi(int c1) { return c1 >> 1; }
-__device__ __forceinline__ int rq_relu64(int x, int m, int cl, int ch, int e) {
-    const long c = ((long)ch << 32) | (uint32_t)cl;
+// (nested floors) == hi32(x*m + C) >> (e - 1) for e >= 1: v_mad_i64_i32 with a per-channel 64-bit constant C = 2^30 + c1 * 2^31, then ONE
+// arithmetic shift of the high dword — 2 instructions + clamp instead of 5 + clamp.  rq64(c1) builds C; kernels keep (C, e - 1) per channel.
+__device__ __forceinline__ long rq64(int c1) { return ((long)c1 << 31) + 0x40000000L; }
+__device__ __forceinline__ int rq_hi(int x, int m, long c, int e1) {
     const long d = (long)x * (long)m + c;
-    return (int)(d >> 31) >> e;
+    return (int)(d >> 32) >> e1;
+}
+// The same with the four shifts of a channel quad packed into the bytes of ONE register (SDWA picks byte `e` as the shift
+// count: no unpacking instruction, three registers less per quad)
+__device__ __forceinline__ int pack_shifts(v4i sh) { return sh.x | (sh.y << 8) | (sh.z << 16) | (sh.w << 24); }
+__device__ __forceinline__ int rq_hi(int x, int m, long c, int e1_packed, int e) {
+    const int hi = (int)(((long)x * (long)m + c) >> 32);
+    int r;
+    switch (e) {  // e is a compile-time constant after unrolling
+        case 0: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+        case 1: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+        case 2: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+        default: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+    }
+    return r;
 }
 
 template <int QL> struct RawRow { int t[3][QL]; };   // three taps (columns j = 0..2) of one input row, QL dwords each
@@ -127,15 +139,33 @@ void i8_strip_kernel(Strip8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
     const unsigned char* add_tab = lds_all;   // [residual byte pattern][own value + 128] -> output byte (packer: add_table)
     v4i* c_dw = reinterpret_cast<v4i*>(lds_all + (ADD ? 65536 : 0));
-    v4i* c_pw = c_dw + NW * nDWC / 4;
-    v4i* c_dww = c_pw + NW * nPWC / 4;                          // depthwise weights (only when the waves split the channels)
+    v4i* c_pw = c_dw + NW * nDWC / 3;                           // staged as 16 words per quad: multiplier, (C lo, C hi) x 4, shift - 1 (rq_hi)
+    v4i* c_dww = c_pw + NW * nPWC / 3;                          // depthwise weights (only when the waves split the channels)
     constexpr bool DWW_LDS = NW > 1;                            // 24 long-lived registers less per lane; LDS reads are free here
     v2i* xchg = reinterpret_cast<v2i*>(c_dww + (DWW_LDS ? NW * nDWW / 4 : 0));  // [buffer][wave of the workgroup][lane]: B fragments
     const int tid = threadIdx.x;
     {
         const v4i* src = reinterpret_cast<const v4i*>(a.cst);
-        for (int i = tid; i < NW * nDWC / 4; i += NTHREADS) c_dw[i] = src[kDWC / 4 + i];
-        for (int i = tid; i < NW * nPWC / 4; i += NTHREADS) c_pw[i] = src[kPWC / 4 + i];
+        // requantisation constants: (multiplier, c1, shift) per quad in the blob -> (multiplier, 64-bit addends, shift - 1) for rq_hi;
+        // the pointwise stage of a residual block keeps (multiplier, c1, shift): its values feed the ADD table with their sign (rq)
+        auto stage = [&](v4i* dst, const v4i* q3, int n_quads, bool fold) {
+            for (int i = tid; i < n_quads; i += NTHREADS) {
+                const v4i m = q3[3 * i], c1 = q3[3 * i + 1], sh = q3[3 * i + 2];
+                dst[4 * i] = m;
+                if (fold) {
+                    const long c[4] = {rq64(c1.x), rq64(c1.y), rq64(c1.z), rq64(c1.w)};
+                    dst[4 * i + 1] = (v4i){(int)c[0], (int)(c[0] >> 32), (int)c[1], (int)(c[1] >> 32)};
+                    dst[4 * i + 2] = (v4i){(int)c[2], (int)(c[2] >> 32), (int)c[3], (int)(c[3] >> 32)};
+                    dst[4 * i + 3] = (v4i){pack_shifts(sh - 1), 0, 0, 0};
+                } else {
+                    dst[4 * i + 1] = c1;
+                    dst[4 * i + 2] = sh;
+                    dst[4 * i + 3] = (v4i){0, 0, 0, 0};
+                }
+            }
+        };
+        stage(c_dw, src + kDWC / 4, NW * nDWC / 12, true);
+        stage(c_pw, src + kPWC / 4, NW * nPWC / 12, !ADD);
         if constexpr (DWW_LDS)
             for (int i = tid; i < NW * nDWW / 4; i += NTHREADS) c_dww[i] = src[kDWW / 4 + i];
         if constexpr (ADD) {
@@ -204,8 +234,8 @@ void i8_strip_kernel(Strip8Args a) {
         pwb[t] = reinterpret_cast<const v4i*>(a.cst + kPWB + w * nPWB)[kq * NT + t];
     }
     const v4i* my_dww = c_dww + w * (nDWW / 4) + kq * QL * 3;
-    const v4i* my_dw = c_dw + w * (nDWC / 4);
-    const v4i* my_pw = c_pw + w * (nPWC / 4);
+    const v4i* my_dw = c_dw + w * (nDWC / 3);
+    const v4i* my_pw = c_pw + w * (nPWC / 3);
 
     const int zp4 = (a.zp_in & 0xff) * 0x01010101;
     const int zprow = (a.zp_in & 0xff) * 0x00010101;
@@ -279,7 +309,10 @@ void i8_strip_kernel(Strip8Args a) {
                                         // ~48 registers (the kernel is bound by vector-ALU issue, LDS reads are free)
 #pragma unroll
         for (int ql = 0; ql < QL; ++ql) {
-            const v4i m = my_dw[(kq * QL + ql) * 3 + 0], c1 = my_dw[(kq * QL + ql) * 3 + 1], sh = my_dw[(kq * QL + ql) * 3 + 2];
+            const v4i m = my_dw[(kq * QL + ql) * 4 + 0], c01 = my_dw[(kq * QL + ql) * 4 + 1], c23 = my_dw[(kq * QL + ql) * 4 + 2];
+            const int e1 = reinterpret_cast<const int*>(my_dw + (kq * QL + ql) * 4 + 3)[0];
+            const long cc[4] = {__builtin_bit_cast(long, (v2i){c01.x, c01.y}), __builtin_bit_cast(long, (v2i){c01.z, c01.w}),
+                                __builtin_bit_cast(long, (v2i){c23.x, c23.y}), __builtin_bit_cast(long, (v2i){c23.z, c23.w})};
             int qv[4];
             v4i w0, w1, w2;
             if constexpr (DWW_LDS) {
@@ -294,7 +327,7 @@ void i8_strip_kernel(Strip8Args a) {
                 int acc = dot4_first(T[i0].c[ql][e], w0[e], dwb[ql][e]);
                 acc = dot4(T[i1].c[ql][e], w1[e], acc);
                 acc = dot4(T[i2].c[ql][e], w2[e], acc);
-                qv[e] = med3(rq_relu(acc, m[e], c1[e], sh[e]), a.dw_lo, a.dw_hi);
+                qv[e] = med3(rq_hi(acc, m[e], cc[e], e1, e), a.dw_lo, a.dw_hi);
             }
             bfrag[ql] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         }
@@ -329,12 +362,16 @@ void i8_strip_kernel(Strip8Args a) {
         int outw[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const v4i m = my_pw[(kq * NT + t) * 3 + 0], c1 = my_pw[(kq * NT + t) * 3 + 1], sh = my_pw[(kq * NT + t) * 3 + 2];
+            // ADD: (multiplier, c1, shift, -); else (multiplier, C01, C23, packed shifts - 1)
+            const v4i m = my_pw[(kq * NT + t) * 4 + 0], c1 = my_pw[(kq * NT + t) * 4 + 1], sh = my_pw[(kq * NT + t) * 4 + 2];
+            const int e1 = ADD ? 0 : reinterpret_cast<const int*>(my_pw + (kq * NT + t) * 4 + 3)[0];
+            const long cc[4] = {__builtin_bit_cast(long, (v2i){c1.x, c1.y}), __builtin_bit_cast(long, (v2i){c1.z, c1.w}),
+                                __builtin_bit_cast(long, (v2i){sh.x, sh.y}), __builtin_bit_cast(long, (v2i){sh.z, sh.w})};
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 // ADD: value + 128 (table index, any sign: full rounding), else the int8 value behind a ReLU6 clamp
-                int v = med3(ADD ? rq(acc[t][e], m[e], c1[e], sh[e]) : rq_relu(acc[t][e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);
+                int v = med3(ADD ? rq(acc[t][e], m[e], c1[e], sh[e]) : rq_hi(acc[t][e], m[e], cc[e], e1, e), a.pw_lo, a.pw_hi);
                 if constexpr (ADD)  // the whole TFLite ADD (two input rescales, sum, output rescale, clamp) is a function of two bytes
                     v = add_tab[(uint32_t)perm(cenv[t % QL], v, 0x0c0c0400u + (e << 8))];
                 qv[e] = v;
@@ -413,7 +450,7 @@ template <int CW, int NW, int COUT, int S, bool ADD, bool W8 = false>
 void launch_strip(const Strip8Args& a, hipStream_t s) {
     constexpr int SPB = ADD ? 8 / NW : (NW == 1 ? 4 : 1);
     constexpr int QL = CW / 16, NT = COUT / NW / 16;
-    constexpr size_t smem = (ADD ? 65536 : 0) + (size_t)NW * (4 * QL * 12 + 4 * NT * 12) * 4 + (NW > 1 ? NW * 4 * QL * 12 * 4 + 2 * SPB * NW * 64 * 8 : 0);
+    constexpr size_t smem = (ADD ? 65536 : 0) + (size_t)NW * (4 * QL * 16 + 4 * NT * 16) * 4 + (NW > 1 ? NW * 4 * QL * 12 * 4 + 2 * SPB * NW * 64 * 8 : 0);
     const long per_chunk = (long)(W8 ? 1 : a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
     const long blocks = NW == 1 ? (a.B * per_chunk + SPB - 1) / SPB : ((a.B + SPB - 1) / SPB) * per_chunk;
     auto kern = i8_strip_kernel<CW, NW, COUT, S, ADD, W8>;
@@ -461,7 +498,8 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
     const long sta = (long)(uint32_t)a.cst[kF_STA + lane];
     const v4i stb = c4[kF_STB / 4 + kq];
     const v4i stm = c4[kF_STC / 4 + kq * 3 + 0], stc1 = c4[kF_STC / 4 + kq * 3 + 1], ste = c4[kF_STC / 4 + kq * 3 + 2];
-    const v4i stcl = {rq64_lo(stc1.x), rq64_lo(stc1.y), rq64_lo(stc1.z), rq64_lo(stc1.w)}, stch = {rq64_hi(stc1.x), rq64_hi(stc1.y), rq64_hi(stc1.z), rq64_hi(stc1.w)};
+    const long stc[4] = {rq64(stc1.x), rq64(stc1.y), rq64(stc1.z), rq64(stc1.w)};
+    const int ste1 = pack_shifts(ste - 1);
     int dww[3][4];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -470,18 +508,21 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
     }
     const v4i dwb = c4[kF_DWB / 4 + kq];
     const v4i dwm = c4[kF_DWC / 4 + kq * 3 + 0], dwc1 = c4[kF_DWC / 4 + kq * 3 + 1], dwe = c4[kF_DWC / 4 + kq * 3 + 2];
-    const v4i dwcl = {rq64_lo(dwc1.x), rq64_lo(dwc1.y), rq64_lo(dwc1.z), rq64_lo(dwc1.w)}, dwch = {rq64_hi(dwc1.x), rq64_hi(dwc1.y), rq64_hi(dwc1.z), rq64_hi(dwc1.w)};
+    const long dwc[4] = {rq64(dwc1.x), rq64(dwc1.y), rq64(dwc1.z), rq64(dwc1.w)};
+    const int dwe1 = pack_shifts(dwe - 1);
     long pwa[2];
-    v4i pwb[2], pwm[2], pwc1[2], pwe[2], pwcl[2], pwch[2];
+    v4i pwb[2], pwm[2], pwc1[2];
+    int pwe1[2];
+    long pwc[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         pwa[t] = (long)(uint32_t)a.cst[kF_PWA + t * 64 + lane];
         pwb[t] = c4[kF_PWB / 4 + kq * 2 + t];
         pwm[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 0];
         pwc1[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 1];
-        pwe[t] = c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 2];
-        pwcl[t] = (v4i){rq64_lo(pwc1[t].x), rq64_lo(pwc1[t].y), rq64_lo(pwc1[t].z), rq64_lo(pwc1[t].w)};
-        pwch[t] = (v4i){rq64_hi(pwc1[t].x), rq64_hi(pwc1[t].y), rq64_hi(pwc1[t].z), rq64_hi(pwc1[t].w)};
+        pwe1[t] = pack_shifts(c4[kF_PWC / 4 + (kq * 2 + t) * 3 + 2] - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pwc[t][e] = rq64(pwc1[t][e]);
     }
 
     const int zfe4 = (a.zp_fe & 0xff) * 0x01010101;
@@ -523,7 +564,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
                 const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(sta, (long)(uint32_t)x[j], stb, 0, 0, 0);
                 int qv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu64(acc[e], stm[e], stcl[e], stch[e], ste[e]), a.st_lo, a.st_hi);
+                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_hi(acc[e], stm[e], stc[e], ste1, e), a.st_lo, a.st_hi);
                 pk[j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
             }
             if (right_st) pk[2] = zst4;
@@ -545,7 +586,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
             int acc = dot4_first(T[i0].c[0][e], dww[0][e], dwb[e]);
             acc = dot4(T[i1].c[0][e], dww[1][e], acc);
             acc = dot4(T[i2].c[0][e], dww[2][e], acc);
-            qv[e] = med3(rq_relu64(acc, dwm[e], dwcl[e], dwch[e], dwe[e]), a.dw_lo, a.dw_hi);
+            qv[e] = med3(rq_hi(acc, dwm[e], dwc[e], dwe1, e), a.dw_lo, a.dw_hi);
         }
         const long bf = (long)(uint32_t)perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         int outw[2];
@@ -554,7 +595,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
             const v4i acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(pwa[t], bf, pwb[t], 0, 0, 0);
             int ov[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = med3(rq_relu64(acc[e], pwm[t][e], pwcl[t][e], pwch[t][e], pwe[t][e]), a.pw_lo, a.pw_hi);
+            for (int e = 0; e < 4; ++e) ov[e] = med3(rq_hi(acc[e], pwm[t][e], pwc[t][e], pwe1[t], e), a.pw_lo, a.pw_hi);
             outw[t] = perm(perm(ov[3], ov[2], 0x0c0c0400u), perm(ov[1], ov[0], 0x0c0c0400u), 0x05040100u);
         }
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, oh * a.OW * 32, 0);

@@ -37,6 +37,7 @@ namespace bn {
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int perm(int s0, int s1, uint32_t sel) { return (int)__builtin_amdgcn_perm((uint32_t)s0, (uint32_t)s1, sel); }
 __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
@@ -51,11 +52,31 @@ __device__ __forceinline__ int rq(int x, int m, int c1, int e) {
     return (v + c1 + (v >> 31)) >> e;
 }
 
-// where the clamp's lower bound is at or above the zero point the sign term is not needed (bn_i8_strip.hip: rq_relu; the packer checks it)
-__device__ __forceinline__ int rq_relu(int x, int m, int c1, int e) {
-    const int v = srdhm_pos(x, m);
-    return (v + c1) >> e;
+// where the clamp's lower bound is at or above the zero point the sign term is not needed, the addend folds into the 64-bit
+// multiply-add and the result is the HIGH dword shifted by e - 1 (bn_i8_strip.hip: rq_hi; the packer checks the clamp and e >= 1).
+// The four shifts of a channel quad sit in the bytes of one register, SDWA picks byte `e`.
+__device__ __forceinline__ long rq64(int c1) { return ((long)c1 << 31) + 0x40000000L; }
+__device__ __forceinline__ int pack_shifts(v4i sh) { return sh.x | (sh.y << 8) | (sh.z << 16) | (sh.w << 24); }
+__device__ __forceinline__ int rq_hi(int x, int m, long c, int e1_packed, int e) {
+    const int hi = (int)(((long)x * (long)m + c) >> 32);
+    int r;
+    switch (e) {  // e is a compile-time constant after unrolling
+        case 0: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+        case 1: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+        case 2: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+        default: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(e1_packed), "v"(hi)); break;
+    }
+    return r;
 }
+// (multiplier, c1, shift) of the constant block -> (multiplier, C01, C23, packed shifts - 1) in LDS
+__device__ __forceinline__ void stage_rq(v4i* dst, v4i m, v4i c1, v4i sh) {
+    const long c[4] = {rq64(c1.x), rq64(c1.y), rq64(c1.z), rq64(c1.w)};
+    dst[0] = m;
+    dst[1] = (v4i){(int)c[0], (int)(c[0] >> 32), (int)c[1], (int)(c[1] >> 32)};
+    dst[2] = (v4i){(int)c[2], (int)(c[2] >> 32), (int)c[3], (int)(c[3] >> 32)};
+    dst[3] = (v4i){pack_shifts(sh - 1), 0, 0, 0};
+}
+__device__ __forceinline__ long pair(int lo, int hi) { return __builtin_bit_cast(long, (v2i){lo, hi}); }
 
 // first channel quad of lane group kq (mirrors _tail_quad_base in models/_lower_i8.py)
 template <int CIN>
@@ -89,8 +110,19 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 #pragma unroll
         for (int i = 0; i < (CIN * COUT / 16 + kTailThreads - 1) / kTailThreads; ++i)
             if (i * kTailThreads + tid < CIN * COUT / 16) dst[i * kTailThreads + tid] = g[L.g_w / 4 + i * kTailThreads + tid];
-        if (tid < CIN * 7 / 4) reinterpret_cast<v4i*>(lds + L.dwc_off)[tid] = g[L.g_dwc / 4 + tid];
-        if (tid < COUT) reinterpret_cast<v4i*>(lds + L.pwc_off)[tid] = g[L.g_pwc / 4 + tid];
+        if (tid < CIN / 4) {   // per channel quad: three weight rows, bias, then the requantisation constants in rq_hi form (8 x 16 bytes)
+            const v4i* q = g + L.g_dwc / 4 + tid * 7;
+            v4i* d = reinterpret_cast<v4i*>(lds + L.dwc_off) + tid * 8;
+            d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3];
+            stage_rq(d + 4, q[4], q[5], q[6]);
+        }
+        if (tid < COUT / 4) {  // per (tile, lane group): bias + constants (5 x 16 bytes); a residual block keeps (multiplier, c1, shift) for rq
+            const v4i* q = g + L.g_pwc / 4 + tid * 4;
+            v4i* d = reinterpret_cast<v4i*>(lds + L.pwc_off) + tid * 5;
+            d[0] = q[0];
+            if constexpr (ADD) { d[1] = q[1]; d[2] = q[2]; d[3] = q[3]; d[4] = (v4i){0, 0, 0, 0}; }
+            else stage_rq(d + 1, q[1], q[2], q[3]);
+        }
         if (ADD && tid < 128) reinterpret_cast<v4i*>(lds + L.lut_off)[tid] = g[L.g_lut / 4 + tid];
         if (!SRCG && tid < PIN / 4) reinterpret_cast<int*>(lds + L.zp_off)[tid] = (L.zp_in & 0xff) * 0x01010101;
     }
@@ -98,8 +130,8 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 
     const int zp4 = (L.zp_in & 0xff) * 0x01010101;
     const int qb = pq_base<CIN>(kq);
-    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.dwc_off) + qb * 7;
-    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.pwc_off) + kq * 4;
+    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.dwc_off) + qb * 8;
+    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.pwc_off) + kq * 5;
     const int* lut = reinterpret_cast<const int*>(lds + L.lut_off);
     const v4i* wl = reinterpret_cast<const v4i*>(lds + L.w_off) + lane;
     const int dw_lo = L.dw_lo, dw_hi = L.dw_hi, pw_lo = L.pw_lo, pw_hi = L.pw_hi;
@@ -148,7 +180,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int qi = 4 * ks + j;   // quad qb + qi: channels 4 (qb + qi) ..
-                const v4i bias = dwc[qi * 7 + 3];
+                const v4i bias = dwc[qi * 8 + 3];
                 int acc[UPW][4];
 #pragma unroll
                 for (int t = 0; t < UPW; ++t)
@@ -156,7 +188,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
                     for (int e = 0; e < 4; ++e) acc[t][e] = bias[e];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    const v4i w = dwc[qi * 7 + dy];
+                    const v4i w = dwc[qi * 8 + dy];
 #pragma unroll
                     for (int t = 0; t < UPW; ++t) {
                         int r[3];
@@ -176,12 +208,14 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
                         acc[t][3] = dot4(perm(r[2], hi, 0x0c070302u), w[3], acc[t][3]);
                     }
                 }
-                const v4i m = dwc[qi * 7 + 4], c1 = dwc[qi * 7 + 5], sh = dwc[qi * 7 + 6];
+                const v4i m = dwc[qi * 8 + 4], c01 = dwc[qi * 8 + 5], c23 = dwc[qi * 8 + 6];
+                const int e1 = reinterpret_cast<const int*>(dwc + qi * 8 + 7)[0];
+                const long cc[4] = {pair(c01.x, c01.y), pair(c01.z, c01.w), pair(c23.x, c23.y), pair(c23.z, c23.w)};
 #pragma unroll
                 for (int t = 0; t < UPW; ++t) {
                     int qv[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) qv[e] = med3(rq_relu(acc[t][e], m[e], c1[e], sh[e]), dw_lo, dw_hi);
+                    for (int e = 0; e < 4; ++e) qv[e] = med3(rq_hi(acc[t][e], m[e], cc[e], e1, e), dw_lo, dw_hi);
                     frag[t][j] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
                 }
             }
@@ -193,7 +227,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
         // accumulator rows 4 kq .. 4 kq + 3 of tile nt = output channels 16 nt + 4 kq ..; the tiles of a wave share the channel group
         for (int tt = 0; tt < NT_PER; ++tt) {
             const int nt = grp[0] * NT_PER + tt;
-            const v4i* pc4 = pwc + nt * 16;
+            const v4i* pc4 = pwc + nt * 20;
             v4i acc[UPW];
 #pragma unroll
             for (int t = 0; t < UPW; ++t) acc[t] = pc4[0];
@@ -203,7 +237,9 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 #pragma unroll
                 for (int t = 0; t < UPW; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[t][ks], acc[t], 0, 0, 0);
             }
-            const v4i m = pc4[1], c1 = pc4[2], sh = pc4[3];
+            const v4i m = pc4[1], c1 = pc4[2], sh = pc4[3];  // ADD: (multiplier, c1, shift); else (multiplier, C01, C23) + packed shifts
+            const int e1 = ADD ? 0 : reinterpret_cast<const int*>(pc4 + 4)[0];
+            const long cc[4] = {pair(c1.x, c1.y), pair(c1.z, c1.w), pair(sh.x, sh.y), pair(sh.z, sh.w)};
 #pragma unroll
             for (int t = 0; t < UPW; ++t) {
                 const int yrow = L.y_off + p[t] * POUT + 4 * kq;
@@ -213,7 +249,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // with the ADD: value + 128 = index of the second table (any sign: full rounding)
-                    int v = med3(ADD ? rq(acc[t][e], m[e], c1[e], sh[e]) : rq_relu(acc[t][e], m[e], c1[e], sh[e]), pw_lo, pw_hi);
+                    int v = med3(ADD ? rq(acc[t][e], m[e], c1[e], sh[e]) : rq_hi(acc[t][e], m[e], cc[e], e1, e), pw_lo, pw_hi);
                     if constexpr (ADD) {
                         const int sa = lut[(res >> (8 * e)) & 0xff], sb = lut[256 + v];
                         v = med3(rq(sa + sb, L.add_m, L.add_c1, L.add_e), L.add_lo, L.add_hi);
@@ -332,8 +368,8 @@ bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a) {
         if (cur_off >= 0) used.push_back({cur_off, cur_off + kTailG * L.H * L.W * (L.Cin + 4)});
         L.y_off = first_fit(used, kTailG * L.OH * L.OW * (L.Cout + 4), CAP);
         L.w_off = first_fit(used, L.Cin * L.Cout, CAP);
-        L.dwc_off = first_fit(used, L.Cin * 28, CAP);
-        L.pwc_off = first_fit(used, L.Cout * 16, CAP);
+        L.dwc_off = first_fit(used, L.Cin * 32, CAP);   // staged in rq_hi form: 8 x 16 bytes per channel quad,
+        L.pwc_off = first_fit(used, L.Cout * 20, CAP);  // 5 x 16 bytes per four output channels
         L.lut_off = L.has_add ? first_fit(used, 2048, CAP) : 0;
         L.zp_off = first_fit(used, L.Cin + 16, CAP);
         if (L.y_off < 0 || L.w_off < 0 || L.dwc_off < 0 || L.pwc_off < 0 || L.lut_off < 0 || L.zp_off < 0) return false;
