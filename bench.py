@@ -69,6 +69,9 @@ def synth_audio_device(torch, batch: int, first_chunk: int, device, seed: int):
     return x.contiguous()
 
 
+FRONT2_HEAD, FRONT2_COVERED = 0x7A110003, 0x7A110004  # OpRec.p[38] tags of a front block / residual block pair (csrc/bn_blob.h)
+
+
 def kernel_symbol(kind: str, p: list) -> str:
     """The device kernel an operator launches (the launchers' choices: strip kernels for the wide early blocks)."""
     if kind in ("stft512", "f32_stftmel"):
@@ -190,12 +193,20 @@ def pmc_traffic(dom: dict, batch: int, dtype: str):
 def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> tuple[dict, list[dict]]:
     stages = []
     peak_compute = F32_MFMA_PEAK_TFLOPS if dtype == "f32" else I8_MFMA_PEAK_TOPS
+    by_op = {r["op"]: r for r in rows}
     for r in rows:
         if not r["launches"]:
             continue
         avg_ms = r["ms"] / r["launches"]
         nbytes, nops, mops = algorithmic_work(r, batch, dtype)
-        stages.append({"kernel": r["kind"], "symbol": kernel_symbol(r["kind"], r["p"]), "layer": r["name"], "avg_ms": round(avg_ms, 4),
+        symbol, layer = kernel_symbol(r["kind"], r["p"]), r["name"]
+        # front block + the residual block behind it as one kernel (f32_front2_kernel): the second operator did not launch, its
+        # arithmetic belongs to this launch; the bytes stay input map + ONE 32-channel map (the one between them stays in LDS)
+        nxt = by_op.get(r["op"] + r["p"][37]) if r["kind"] == "f32_front" and r["p"] and r["p"][38] == FRONT2_HEAD else None
+        if nxt is not None and not nxt["launches"] and nxt["p"][38] == FRONT2_COVERED:
+            _, o2, m2 = algorithmic_work(nxt, batch, dtype)
+            nops, mops, symbol, layer = nops + o2, mops + m2, "f32_front2_kernel", r["name"] + " + " + nxt["name"]
+        stages.append({"kernel": r["kind"], "symbol": symbol, "layer": layer, "avg_ms": round(avg_ms, 4),
                        "GBps": round(nbytes / avg_ms / 1e6, 1), "hbm_frac": round(nbytes / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
                        "Tops": round(nops / avg_ms / 1e9, 2), "mfma_frac": round(mops / avg_ms / 1e9 / peak_compute, 4),
                        "bytes": nbytes, "ops": nops, "p": r["p"], "op": r["op"]})

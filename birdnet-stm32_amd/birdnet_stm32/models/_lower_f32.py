@@ -409,4 +409,37 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
                   t=[pb.tensor(ly.weights["kernel"], np.float32), pb.tensor(bias, np.float32)], name=ly.name, out_shape=(cout,))
         else:
             raise NotImplementedError(f"layer {ly.name} of kind {k} cannot be lowered on its own")
+    if fuse and not keep_all:
+        _tag_front2(pb)
     return pb.finalize(reuse=not keep_all)
+
+
+def _tag_front2(pb: pk.PlanBuilder) -> None:
+    """Mark (front block, residual block 32 -> 32 behind it) pairs the library may run as ONE kernel (``f32_front2_kernel``).
+
+    The pair qualifies when the residual block (reference: the second ``ds_conv_block`` of stage 1, ``models/dscnn.py:209-226``)
+    reads nothing but the front block's output — as its input and as its residual — and no other operator reads that map:
+    the fused kernel keeps it in LDS and never writes it.  Debug plans (``keep_all``) are left alone, every tensor stays readable.
+    """
+    ops = pb.plan.ops
+    gate_slots = {ops[oi].p[pi] for oi, pi in pb._gate_refs}
+    for i, o in enumerate(ops):
+        q = o.p
+        if not (o.kind == pk.F32_DWPW and q[15] == 1 and q[2] == 32 and q[10] == 32 and q[3] == 1 and q[4] == 1 and q[12] == 1
+                and q[13] == 0 and o.in0 == o.in1 and o.in0 >= 0):
+            continue
+        v = o.in0
+        fronts = [j for j in range(i) if ops[j].kind == pk.F32_FRONT and ops[j].out == v]
+        readers = [k for k, r in enumerate(ops) if k != i and (r.in0 == v or r.in1 == v)]
+        writers = [k for k, r in enumerate(ops) if r.out == v]
+        if not fronts or readers or writers != fronts or v in gate_slots:
+            continue
+        if any(ops[j].p[2] != 16 or ops[j].p[3] != 32 or ops[j].p[4] != q[0] or ops[j].p[5] != q[1] or q[1] % 16 or q[1] // 16 > 4
+               or i - j >= 8 for j in fronts):
+            continue
+        for j in fronts:
+            ops[j].p[pk.TAIL_TAG] = pk.FRONT2_HEAD
+            ops[j].p[pk.FRONT2_DIST] = i - j
+            if ops[j].in0 >= 0:  # the fused kernel reads the front block's input while it writes this block's output: no slot sharing
+                pb._extra_uses.append((i, ops[j].in0))
+        q[pk.TAIL_TAG] = pk.FRONT2_COVERED

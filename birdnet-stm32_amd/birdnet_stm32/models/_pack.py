@@ -32,6 +32,8 @@ F32_SEGATE, F32_SCALE, F32_GAP, F32_DENSE, F32_ATTNPOOL, F32_DWPW, F32_STFTMEL, 
 I8_QUANT, I8_MEL, I8_STEM, I8_DW, I8_PW, I8_MEAN, I8_FC, I8_HEAD, I8_DWPW, I8_FRONT, I8_TAIL, I8_SCALE = 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31
 TAIL_TAG = 38  # OpRec.p[TAIL_TAG] = TAIL_COVERED: the operator is covered by the plan's fused tail operator; TAIL_OP: it is that operator
 TAIL_COVERED, TAIL_OP = 0x7A110001, 0x7A110002  # (bn_blob.h; values no other use of p[38] can take)
+FRONT2_HEAD, FRONT2_COVERED = 0x7A110003, 0x7A110004  # front block + the residual block FRONT2_DIST operators further on may run as one kernel
+FRONT2_DIST = 37
 
 KIND_NAMES = {
     F32_MEL: "f32_mel", F32_MAG: "f32_mag", F32_RAWFE: "f32_rawfe", F32_STEM: "f32_stem", F32_DW: "f32_dw",
@@ -89,7 +91,8 @@ class PlanBuilder:
     Lowering passes call :meth:`value` for every operator output and refer to values by id.
     :meth:`finalize` runs a linear scan over the operator list: with ``reuse=True`` a slot is
     recycled once the last reader of its value has run (an output never aliases a value that
-    is still live, so no kernel runs in place unless its operator says so); with
+    is still live, so no kernel runs in place unless its operator says so; ``_extra_uses`` keeps
+    the inputs of an operator alive up to a later operator that may run fused with it); with
     ``reuse=False`` every value keeps its own slot so that tests can read each intermediate
     activation back through ``bn_debug_op_output``.
     """
@@ -98,6 +101,7 @@ class PlanBuilder:
         self.plan = plan
         self._value_bytes: list[int] = []
         self._gate_refs: list[tuple[int, int]] = []  # (op index, p index) holding a value id
+        self._extra_uses: list[tuple[int, int]] = []  # (op index, value id): the value must stay live until that operator has run
 
     def tensor(self, arr: np.ndarray, dtype) -> int:
         a = np.ascontiguousarray(np.asarray(arr).astype(dtype))
@@ -132,6 +136,10 @@ class PlanBuilder:
             for v in [o.in0, o.in1, o.out] + [o.p[pi] for pi in refs.get(oi, [])]:
                 if v >= 0:
                     last_use[v] = oi
+        extra: dict[int, list[int]] = {}
+        for oi, v in self._extra_uses:
+            last_use[v] = max(last_use.get(v, oi), oi)
+            extra.setdefault(oi, []).append(v)
         slot_of: dict[int, int] = {}
         slot_bytes: list[int] = []
         free: list[int] = []
@@ -147,7 +155,7 @@ class PlanBuilder:
                     sid = len(slot_bytes) - 1
                 slot_of[o.out] = sid
             if reuse:
-                for v in {o.in0, o.in1, o.out, *[o.p[pi] for pi in refs.get(oi, [])]}:
+                for v in {o.in0, o.in1, o.out, *[o.p[pi] for pi in refs.get(oi, [])], *extra.get(oi, [])}:
                     if v >= 0 and last_use[v] == oi and v in slot_of and slot_of[v] not in free:
                         free.append(slot_of[v])
         for oi, o in enumerate(ops):

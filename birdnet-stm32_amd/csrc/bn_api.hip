@@ -46,7 +46,7 @@ struct OptName {
 };
 const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
-    {"f32_front_staged", &bn::Options::f32_front_staged}, {"front_tpw", &bn::Options::front_tpw},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
@@ -178,10 +178,28 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
     };
     const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
     if (op_end > m->ops.size()) op_end = m->ops.size();
+    size_t front2_done = (size_t)-1;  // operator that the fused front kernel of this run has already covered
+    auto dwpw_args = [&](const OpRec& d) {
+        bn::DwPwArgs a{};
+        const int* q = d.p;
+        a.x = (const float*)slot_ptr(d.in0);
+        a.res = q[12] ? (const float*)slot_ptr(d.in1) : nullptr;
+        a.gate = q[13] ? (const float*)slot_ptr(q[14]) : nullptr;
+        a.y = (float*)slot_ptr(d.out);
+        a.dw_w = (const float*)m->tensor(d.t[0]);
+        a.dw_b = (const float*)m->tensor(d.t[1]);
+        a.pw_w = (const float*)m->tensor(d.t[2]);
+        a.pw_b = (const float*)m->tensor(d.t[3]);
+        a.B = B; a.H = q[0]; a.W = q[1]; a.Cin = q[2]; a.sh = q[3]; a.sw = q[4]; a.dw_act = q[5];
+        a.OH = q[6]; a.OW = q[7]; a.pt = q[8]; a.pl = q[9]; a.Cout = q[10]; a.pw_act = q[11];
+        a.has_dw = q[15]; a.TH = q[16]; a.TW = q[17]; a.NB = q[18];
+        return a;
+    };
     for (size_t oi = op_begin; oi < op_end; ++oi) {
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
+        if (oi == front2_done) continue;  // ran inside the front kernel
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
@@ -229,18 +247,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                   (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
                 break;
             case BN_OP_F32_DWPW: {
-                bn::DwPwArgs a{};
-                a.x = (const float*)in0;
-                a.res = p[12] ? (const float*)in1 : nullptr;
-                a.gate = p[13] ? (const float*)slot_ptr(p[14]) : nullptr;
-                a.y = (float*)out;
-                a.dw_w = (const float*)m->tensor(o.t[0]);
-                a.dw_b = (const float*)m->tensor(o.t[1]);
-                a.pw_w = (const float*)m->tensor(o.t[2]);
-                a.pw_b = (const float*)m->tensor(o.t[3]);
-                a.B = B; a.H = p[0]; a.W = p[1]; a.Cin = p[2]; a.sh = p[3]; a.sw = p[4]; a.dw_act = p[5];
-                a.OH = p[6]; a.OW = p[7]; a.pt = p[8]; a.pl = p[9]; a.Cout = p[10]; a.pw_act = p[11];
-                a.has_dw = p[15]; a.TH = p[16]; a.TW = p[17]; a.NB = p[18];
+                const bn::DwPwArgs a = dwpw_args(o);
                 if (!bn::f32_dwpw_supported(a.Cin, a.Cout) || (a.has_dw && a.Cin % 16) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported fused block geometry", oi);
                 bn::launch_f32_dwpw(a, s);
@@ -249,6 +256,24 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
             case BN_OP_F32_FRONT:
                 if (!bn::f32_front_supported(p[0], p[1], p[2], p[3], p[4], p[5]))
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported front-block geometry", oi);
+                if (p[BN_OP_TAIL_TAG] == BN_FRONT2_HEAD && bn::g_opt.f32_front2 && bn::g_opt.f32_strip && bn::g_opt.f32_front_staged &&
+                    p[BN_OP_FRONT2_DIST] > 0 && oi + (size_t)p[BN_OP_FRONT2_DIST] < op_end) {
+                    // front block + the residual block behind it as one kernel: the 32-channel map between them stays in LDS
+                    const OpRec& d = m->ops[oi + (size_t)p[BN_OP_FRONT2_DIST]];
+                    if (d.kind == BN_OP_F32_DWPW && d.p[BN_OP_TAIL_TAG] == BN_FRONT2_COVERED && d.in0 == o.out && d.out != o.in0) {  // (never in place)
+                        const bn::F32FrontStripArgs f{(const float*)in0, nullptr,
+                                                      (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]),
+                                                      (const float*)m->tensor(o.t[2]), (const float*)m->tensor(o.t[3]),
+                                                      (const float*)m->tensor(o.t[4]), (const float*)m->tensor(o.t[5]),
+                                                      p[9] ? m->d_minmax : nullptr, (const float*)m->tensor(o.t[6]),
+                                                      (const float*)m->tensor(o.t[7]), B, p[0], p[1], p[4], p[5], 0, p[6], p[7], p[8], p[10]};
+                        const bn::DwPwArgs da = dwpw_args(d);
+                        if (p[2] == 16 && p[3] == 32 && bn::f32_front2_supported(f, da) && bn::launch_f32_front2(f, da, s)) {
+                            front2_done = oi + (size_t)p[BN_OP_FRONT2_DIST];
+                            break;
+                        }
+                    }
+                }
                 bn::launch_f32_front((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8],
                                      (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]),
                                      (const float*)m->tensor(o.t[2]), (const float*)m->tensor(o.t[3]),

@@ -62,6 +62,12 @@ struct TensorRec {
 #define BN_OP_TAIL_TAG 38
 #define BN_TAIL_COVERED 0x7A110001
 #define BN_TAIL_OP 0x7A110002
+// BN_FRONT2_HEAD on a BN_OP_F32_FRONT operator: the operator p[BN_OP_FRONT2_DIST] places further on (tagged BN_FRONT2_COVERED) is the
+// residual block 32 -> 32 that reads nothing but this operator's output; both may run as one kernel (option f32_front2), which
+// writes only the second operator's output.  The packer sets the tags only when no other operator reads the map between them.
+#define BN_FRONT2_HEAD 0x7A110003
+#define BN_FRONT2_COVERED 0x7A110004
+#define BN_OP_FRONT2_DIST 37
 
 #define BN_OP_NP 40
 #define BN_OP_NT 16

@@ -404,6 +404,254 @@ __global__ __launch_bounds__(STAGED ? 1024 : 256) __attribute__((amdgpu_waves_pe
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Front block + the first residual block (stage1_ds2: depthwise 3x3 stride 1 -> pointwise 32 -> 32 -> + input -> activation) in ONE
+// kernel: the 32-channel map between them (256 KB per chunk written and read back: 512 MiB of the 2.9 GiB a 1024-chunk step moves)
+// never exists in HBM.  One workgroup per chunk, 3 x OW/16 waves in two roles that meet at ONE barrier per output row:
+//   * producers (one wave per strip of 16 columns): the front-strip row loop as above, input map staged in LDS once; the finished
+//     row goes into a two-row ring in LDS ([row & 1][column + 1][32 + 4 floats], zero border columns = the SAME padding);
+//   * consumers (two waves per strip, 16 channels each — f32_strip_kernel<2, 32, 1, true>): at step t they take row t - 1 from the
+//     ring into their register window, run the depthwise stage of row t - 2, swap B fragments through LDS, store row t - 3 (whose
+//     MFMAs were issued right behind the previous barrier) and meet the producers at the barrier.
+// The residual is the centre tap a consumer lane already holds.  Per SIMD one producer and two consumer waves: the matrix
+// instructions of one role run under the vector instructions of the other.
+struct F32Front2Args {
+    F32FrontStripArgs f;   // f.y unused
+    const float* dw_w; const float* dw_b;   // [3][3][32], [32]
+    const float* pw_w; const float* pw_b;   // fragment order [2][2][64][4], [32]
+    float* y;              // [B][OH][OW][32]
+    int dw_act, pw_act;
+};
+
+__global__ __launch_bounds__(768) void f32_front2_kernel(F32Front2Args A) {
+    const F32FrontStripArgs& a = A.f;
+    extern __shared__ __attribute__((aligned(16))) float lds2[];
+    __shared__ float rowc[64][12];
+    __shared__ v4f dw_lds[9][4];
+    __shared__ v4f dw2_lds[9][8];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int strips_x = a.OW >> 4;
+    const int tile_w = a.W0 + 8, nr = a.H0 + 4;
+    constexpr int RP = 36;                              // ring pitch per column (floats): 32 channels + 4
+    float* fe_tile = lds2;                              // [H0 + 4][W0 + 8], rows -1 .., zero outside the map
+    float* ring = fe_tile + nr * tile_w;                // [2][OW + 2][RP]
+    v4f* xchg = reinterpret_cast<v4f*>(ring + 2 * (a.OW + 2) * RP);  // [strip][2][2][64]
+    const bool fin = a.minmax != nullptr;
+    const int chunk = xcd_tile(blockIdx.x, gridDim.x);
+    if (fin)
+        for (int i = tid; i < a.H0 * 12; i += nthreads) {
+            const int rr = i / 12, c = i - rr * 12;
+            rowc[rr][c] = c == 0 ? a.wsum[rr] : (c <= 10 ? a.magp[(c - 1) * a.H0 + rr] : 0.0f);
+        }
+    if (tid < 36) (&dw_lds[0][0])[tid] = reinterpret_cast<const v4f*>(a.dw_w)[tid];
+    if (tid >= 64 && tid < 64 + 72) (&dw2_lds[0][0])[tid - 64] = reinterpret_cast<const v4f*>(A.dw_w)[tid - 64];
+    for (int i = tid; i < 4 * RP; i += nthreads) {      // the ring's border columns stay zero: SAME padding of the second block
+        const int rrow = i / (2 * RP), rest = i - rrow * 2 * RP;
+        ring[(rrow * (a.OW + 2) + (rest < RP ? 0 : a.OW + 1)) * RP + (rest % RP)] = 0.0f;
+    }
+    __syncthreads();
+    float mn = 0.0f, inv_rng = 1.0f;
+    if (fin) {
+        mn = a.minmax[2 * chunk];
+        inv_rng = 1.0f / (float)((double)(a.minmax[2 * chunk + 1] - mn) + 1e-10);
+    }
+    {   // the whole input map, finalised once per element on the way (same arithmetic as f32_front_strip_kernel<true>); the loads of a
+        // thread are all in flight before the first is used (six per thread for the 64 x 256 map: one HBM round trip, not six)
+        const int quads = a.W0 >> 2, total = nr * (quads + 2);
+        constexpr int kInFlight = 6;
+        for (int i0 = tid; i0 < total; i0 += kInFlight * nthreads) {
+            v4f vin[kInFlight];
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                const int i = i0 + u * nthreads;
+                const int row = i / (quads + 2), c = i - row * (quads + 2), fr = row - 1;
+                vin[u] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                if (i < total && c < quads && fr >= 0 && fr < a.H0)
+                    vin[u] = *reinterpret_cast<const v4f*>(a.fe + ((size_t)chunk * a.H0 + fr) * a.W0 + 4 * c);
+            }
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                const int i = i0 + u * nthreads;
+                if (i >= total) break;
+                const int row = i / (quads + 2), c = i - row * (quads + 2), fr = row - 1;
+                v4f v = vin[u];
+                if (fin && c < quads && fr >= 0 && fr < a.H0) {
+                    const v4f c0 = *reinterpret_cast<const v4f*>(&rowc[fr][0]), c1 = *reinterpret_cast<const v4f*>(&rowc[fr][4]),
+                              c2 = *reinterpret_cast<const v4f*>(&rowc[fr][8]);
+                    const float off = mn * c0.x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = fmaxf((v[e] - off) * inv_rng, 0.0f);
+                        float r = y;
+                        if (a.mag == 1) {
+                            r = y * c0.y;
+                            r += c0.z * fmaxf(c1.y * y + c2.x, 0.0f);
+                            r += c0.w * fmaxf(c1.z * y + c2.y, 0.0f);
+                            r += c1.x * fmaxf(c1.w * y + c2.z, 0.0f);
+                        } else if (a.mag == 2) {
+                            const float y0 = fmaxf(y - c0.y * y, 0.0f);
+                            r = fmaxf(c0.z * y0 + c1.y * fmaxf(c0.w * y0 + c1.x, 0.0f), 0.0f);
+                        } else if (a.mag == 3) {
+                            r = 10.0f * logf(fmaxf(y, 1e-6f)) / logf(10.0f);
+                        }
+                        v[e] = r;
+                    }
+                }
+                *reinterpret_cast<v4f*>(fe_tile + row * tile_w + 4 * c) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int OH = a.OH;
+    auto step_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    if (wave < strips_x) {
+        // ---------------------------------------------------------------- producer: front block rows -> ring
+        const int ow = wave * 16 + n;
+        const ActBounds st_bounds = act_bounds(a.stem_act), dw_bounds = act_bounds(a.dw_act), pw_bounds = act_bounds(a.pw_act);
+        float sa[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sa[j] = kq < 3 ? a.stem_w[(kq * 3 + j) * 16 + n] : 0.0f;
+        const v4f stb = *reinterpret_cast<const v4f*>(a.stem_b + 4 * kq);
+        const v4f dwb = *reinterpret_cast<const v4f*>(a.dw_b + 4 * kq);
+        v4f pa[2], pb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ch = 8 * (n >> 2) + 4 * t + (n & 3);
+            pa[t] = reinterpret_cast<const v4f*>(a.pw_w)[(ch >> 4) * 64 + kq * 16 + (ch & 15)];
+            pb[t] = *reinterpret_cast<const v4f*>(a.pw_b + 8 * kq + 4 * t);
+        }
+        const bool right_st = 2 * ow + 2 >= a.W0 / 2;
+        const int rows_needed = 2 * (OH - 1) + 3;
+        Row4 T[3];
+        auto stem_row = [&](int srel, int ti) {
+            if (srel < rows_needed && srel < a.H0) {
+                const float* trow = fe_tile + (srel + kq) * tile_w + 4 * ow;  // input row srel - 1 + kq
+                const v4f lo = *reinterpret_cast<const v4f*>(trow), hi = *reinterpret_cast<const v4f*>(trow + 4);
+                const float x[7] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
+                v4f st[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    st[c] = stb;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) mfma_acc(st[c], sa[j], x[2 * c + j]);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) T[ti].t[c] = act4(st[c], st_bounds);
+                if (right_st) T[ti].t[2] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) T[ti].t[c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        };
+        auto emit = [&](int i0, int i1, int i2, int oh) {
+            asm volatile("" ::: "memory");
+            const v4f* dw = &dw_lds[0][kq];
+            v4f d = dwb;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                d = __builtin_elementwise_fma(T[i0].t[j], dw[(0 + j) * 4], d);
+                d = __builtin_elementwise_fma(T[i1].t[j], dw[(3 + j) * 4], d);
+                d = __builtin_elementwise_fma(T[i2].t[j], dw[(6 + j) * 4], d);
+            }
+            d = act4(d, dw_bounds);
+            float* dst = ring + (((oh & 1) * (a.OW + 2)) + ow + 1) * RP + 8 * kq;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                v4f o = pb[t];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mfma_acc(o, pa[t][g], d[g]);
+                *reinterpret_cast<v4f*>(dst + 4 * t) = act4(o, pw_bounds);
+            }
+            step_barrier();
+        };
+        // (queueing the next row's stem matrix instructions before this row's ring write and barrier changed nothing: 0.198 vs 0.190 ms)
+        stem_row(0, 0);
+        for (int k = 0; k < OH; k += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (k + u >= OH) break;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int rs = 1 + 2 * u + s2;
+                    stem_row(2 * k + rs, rs % 3);
+                }
+                emit((2 * u) % 3, (2 * u + 1) % 3, (2 * u + 2) % 3, k + u);
+            }
+        }
+        step_barrier();  // the consumers' two trailing steps
+        step_barrier();
+    } else {
+        // ---------------------------------------------------------------- consumer: the residual block on 16 of the 32 channels
+        const int cw = wave - strips_x;
+        const int sx = cw >> 1, w = cw & 1;
+        const int ow = sx * 16 + n;
+        const int c0 = 16 * w + 4 * kq;
+        const ActBounds dw_bounds = act_bounds(A.dw_act), pw_bounds = act_bounds(A.pw_act);
+        const v4f* dw = &dw2_lds[0][c0 >> 2];
+        const v4f dwb = *reinterpret_cast<const v4f*>(A.dw_b + c0);
+        v4f pa[2];
+        {
+            const int ch = 16 * w + 4 * (n >> 2) + (n & 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pa[ks] = reinterpret_cast<const v4f*>(A.pw_w)[(ks * 2 + (ch >> 4)) * 64 + kq * 16 + (ch & 15)];
+        }
+        const v4f pb = *reinterpret_cast<const v4f*>(A.pw_b + 16 * w + 4 * kq);
+        const __amdgpu_buffer_rsrc_t rs_out =
+            __builtin_amdgcn_make_buffer_rsrc(A.y + (size_t)chunk * OH * a.OW * 32, 0, OH * a.OW * 32 * 4, 0x00020000);
+        const int voff_out = (ow * 32 + 16 * w + 4 * kq) * 4;
+        const float* rcol = ring + ow * RP + c0;          // tap j of row r: rcol[((r & 1) * (OW + 2) + j) * RP]
+        v4f* xs = xchg + sx * 256;                        // [2][2][64]
+        Row4 T[3];
+        v4f pacc = {0.0f, 0.0f, 0.0f, 0.0f}, pcen = pacc;
+        const int steps = OH + 2;
+        for (int t0 = 0; t0 < steps; t0 += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = t0 + u;
+                if (t >= steps) break;
+                // window slot u <- map row t - 1 (zero rows above and below the map)
+                if (t >= 1 && t <= OH) {
+                    const float* rp = rcol + (((t - 1) & 1) * (a.OW + 2)) * RP;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) T[u].t[j] = *reinterpret_cast<const v4f*>(rp + j * RP);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) T[u].t[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                const int i0 = (u + 1) % 3, i1 = (u + 2) % 3, i2 = u;   // rows t - 3, t - 2, t - 1
+                if (t >= 2) {
+                    asm volatile("" ::: "memory");
+                    v4f acc = dwb;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        acc = __builtin_elementwise_fma(T[i0].t[j], dw[(0 + j) * 8], acc);
+                        acc = __builtin_elementwise_fma(T[i1].t[j], dw[(3 + j) * 8], acc);
+                        acc = __builtin_elementwise_fma(T[i2].t[j], dw[(6 + j) * 8], acc);
+                    }
+                    xs[((t & 1) * 2 + w) * 64 + lane] = act4(acc, dw_bounds);
+                }
+                if (t >= 3) store16(rs_out, act4(pacc + pcen, pw_bounds), voff_out, (t - 3) * a.OW * 32 * 4);
+                step_barrier();
+                if (t >= 2) {
+                    const v4f f0 = xs[((t & 1) * 2 + 0) * 64 + lane], f1 = xs[((t & 1) * 2 + 1) * 64 + lane];
+                    pacc = pb;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mfma_acc(pacc, pa[0][g], f0[g]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mfma_acc(pacc, pa[1][g], f1[g]);
+                    pcen = T[i1].t[1];
+                }
+            }
+        }
+        store16(rs_out, act4(pacc + pcen, pw_bounds), voff_out, (OH - 1) * a.OW * 32 * 4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Stand-alone depthwise 3x3 (the inverted-residual blocks: expand 1x1 -> DEPTHWISE -> squeeze-excite -> project 1x1) as a
 // row-streaming kernel.  The one-thread-per-output-quad kernel (bn_f32.hip) loads nine taps per output: 2.4 TB/s.  Here a wave
 // owns NCOL = 64 / CQ columns x CQ channel quads (CQ = the largest of 16, 8, 4, 2, 1 dividing C / 4, so that a tap load of the
@@ -574,6 +822,29 @@ void launch_f32_front_strip(F32FrontStripArgs a, hipStream_t s) {
     }
     const long waves = blocks * (a.OW / 16);
     hipLaunchKernelGGL(f32_front_strip_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+}
+
+// front block + stage1_ds2 in one kernel: same geometry limits as the strip kernels, the whole chunk's input map in LDS
+bool f32_front2_supported(const F32FrontStripArgs& f, const DwPwArgs& d) {
+    if (!f32_front_strip_supported(f.H0, f.W0, 16, 32, f.OH, f.OW) || f.W0 % 4 || f.OW / 16 > 4) return false;
+    if (!d.has_dw || d.gate || d.res != d.x || d.Cin != 32 || d.Cout != 32 || d.sh != 1 || d.sw != 1 || d.H != f.OH || d.W != f.OW ||
+        d.OH != f.OH || d.OW != f.OW || d.pt != 1 || d.pl != 1)
+        return false;
+    const size_t smem = ((size_t)(f.H0 + 4) * (f.W0 + 8) + 2 * (f.OW + 2) * 36) * 4 + (size_t)(f.OW / 16) * 256 * 16;
+    return smem <= 150 * 1024 && (long)f.OH * f.OW * 32 * 4 < 0x7fff0000L;
+}
+
+bool launch_f32_front2(const F32FrontStripArgs& f, const DwPwArgs& d, hipStream_t s) {
+    const size_t smem = ((size_t)(f.H0 + 4) * (f.W0 + 8) + 2 * (f.OW + 2) * 36) * 4 + (size_t)(f.OW / 16) * 256 * 16;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(f32_front2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return false;
+        raised = true;
+    }
+    F32Front2Args A{f, d.dw_w, d.dw_b, d.pw_w, d.pw_b, d.y, d.dw_act, d.pw_act};
+    hipLaunchKernelGGL(f32_front2_kernel, dim3((unsigned)f.B), dim3(192 * (f.OW / 16)), smem, s, A);
+    return true;
 }
 
 void launch_f32_strip(DwPwArgs a, hipStream_t s) {

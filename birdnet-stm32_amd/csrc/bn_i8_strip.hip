@@ -63,22 +63,13 @@ __device__ __forceinline__ int rq(int x, int m, int c1, int e) {
     return (v + c1 + (v >> 31)) >> e;
 }
 
-// The same where the clamp's lower bound is at or above the zero point (ReLU / ReLU6 outputs: the packer checks it): a negative v
-// gives a result <= zero point with or without the sign term (v + 2^(e-1) < 2^e), and both clamp to the same bound.
-__device__ __forceinline__ int rq_relu(int x, int m, int c1, int e) {
-    const int v = srdhm_pos(x, m);
-    return (v + c1) >> e;
-}
-
-// ... and with the addend folded into the 64-bit multiply-add: ((x*m + 2^30) >> 31 + c1) >> e == (x*m + 2^30 + c1 * 2^31) >> (31 + e)
+// Where the clamp's lower bound is at or above the zero point (ReLU / ReLU6 outputs: the packer checks it) a negative v gives a result
+// <= zero point with or without the sign term (v + 2^(e-1) < 2^e) and both clamp to the same bound: (v + c1) >> e,
+// and with the addend folded into the 64-bit multiply-add: ((x*m + 2^30) >> 31 + c1) >> e == (x*m + 2^30 + c1 * 2^31) >> (31 + e)
 // (nested floors) == hi32(x*m + C) >> (e - 1) for e >= 1: v_mad_i64_i32 with a per-channel 64-bit constant C = 2^30 + c1 * 2^31, then ONE
 // arithmetic shift of the high dword — 2 instructions + clamp instead of 5 + clamp.  rq64(c1) builds C; kernels keep (C, e - 1) per channel.
 __device__ __forceinline__ long rq64(int c1) { return ((long)c1 << 31) + 0x40000000L; }
-__device__ __forceinline__ int rq_hi(int x, int m, long c, int e1) {
-    const long d = (long)x * (long)m + c;
-    return (int)(d >> 32) >> e1;
-}
-// The same with the four shifts of a channel quad packed into the bytes of ONE register (SDWA picks byte `e` as the shift
+// The four shifts of a channel quad are packed into the bytes of ONE register (SDWA picks byte `e` as the shift
 // count: no unpacking instruction, three registers less per quad)
 __device__ __forceinline__ int pack_shifts(v4i sh) { return sh.x | (sh.y << 8) | (sh.z << 16) | (sh.w << 24); }
 __device__ __forceinline__ int rq_hi(int x, int m, long c, int e1_packed, int e) {

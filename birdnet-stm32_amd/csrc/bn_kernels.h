@@ -16,6 +16,7 @@ struct Options {
     int f32_strip = 1;         // float32 row-streaming strip kernels (0: tile kernels everywhere)
     int f32_strip_th = 0;      // force the rows per strip (0: the launcher's choice)
     int f32_front_staged = 1;  // LDS-staged form of the float32 front strip kernel
+    int f32_front2 = 1;        // front block + first residual block as one kernel (the map between them stays in LDS)
     int front_tpw = 0;         // tiles per workgroup of the float32 front tile kernel (0: auto)
     int wave_dwpw = 1;         // wave-autonomous variant of the small float32 fused block
     int i8_strip = 1;          // INT8 strip kernels (0: generic fused block everywhere)
@@ -139,6 +140,9 @@ bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, 
                           const float* w, const float* bias, hipStream_t s);
 bool f32_strip_supported(const DwPwArgs& a);
 void launch_f32_strip(DwPwArgs a, hipStream_t s);
+// front block + the residual block behind it (32 -> 32, stride 1) in one kernel, the map between them in LDS (bn_f32_strip.hip)
+bool f32_front2_supported(const F32FrontStripArgs& f, const DwPwArgs& d);
+bool launch_f32_front2(const F32FrontStripArgs& f, const DwPwArgs& d, hipStream_t s);
 
 // ---- INT8 plan -----------------------------------------------------------------------------
 void launch_i8_quant(const float* spec, const float* minmax, int8_t* out, int B, int F, int W, int Kp, int zp,

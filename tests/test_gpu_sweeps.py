@@ -317,3 +317,47 @@ def test_i8_fused_tail_matches_per_block_kernels_and_oracle(torch_mod):
         a0 = runner.infer_audio_device(audio)
     assert torch.equal(a0, a1)
     runner.close()
+
+
+# --------------------------------------------------------------------------------------- float32: front block + stage1_ds2 as one kernel
+def test_f32_front2_fused_kernel_matches_the_two_strip_kernels(torch_mod):
+    """``f32_front2_kernel`` (front block + the residual block behind it, the 32-channel map in LDS) does the arithmetic of
+    ``f32_front_strip_kernel<true>`` followed by ``f32_strip_kernel<2, 32, 1, true>`` in the same order: scores are compared
+    BIT FOR BIT with the two-kernel path (option ``f32_front2`` = 0) — from spectrograms and from audio (the finalising variant of
+    the front block), batch sizes that leave workgroups idle, repeated launches — and within float32 noise of the tile kernels."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models.runners import load_model_runner
+
+    runner = load_model_runner(KERAS_PATH, max_batch=300)
+    heads = [o for o in runner.plan.ops if o.kind == pk.F32_FRONT and o.p[pk.TAIL_TAG] == pk.FRONT2_HEAD]
+    covered = [o for o in runner.plan.ops if o.p[pk.TAIL_TAG] == pk.FRONT2_COVERED]
+    assert len(heads) == 2 and len(covered) == 1 and covered[0].kind == pk.F32_DWPW  # spectrogram entry, audio entry -> one residual block
+    rng = np.random.default_rng(33)
+    spec = torch.from_numpy(rng.random((300, 257 * 256), dtype=np.float32)).cuda()
+    audio = torch.from_numpy(synth_chunks(300, seed=12)).cuda()
+    with _hip.options(f32_front2=0):
+        base_s, base_l = (t.clone() for t in runner.predict_device(spec, return_logits=True))
+        base_a = runner.infer_audio_device(audio).clone()
+    with _hip.options(f32_strip=0):
+        tile_s = runner.predict_device(spec).clone()
+    assert float((tile_s - base_s).abs().max()) < 5e-6
+    for rep in range(8):
+        for nb in (300, 1, 2, 7, 255, 256, 257):
+            s, l = runner.predict_device(spec[:nb], return_logits=True)
+            assert torch.equal(s, base_s[:nb]) and torch.equal(l, base_l[:nb]), f"spectrogram path, batch {nb}, launch {rep}"
+            assert torch.equal(runner.infer_audio_device(audio[:nb]), base_a[:nb]), f"audio path, batch {nb}, launch {rep}"
+    # the profile shows the pair as one launch on the front operator
+    runner.profile(True)
+    runner.predict_device(spec)
+    rows = [r for r in runner.profile_collect() if r["launches"]]
+    runner.profile(False)
+    assert not any(r["name"] == covered[0].name and r["kind"] == "f32_dwpw" for r in rows)
+    with _hip.options(f32_front2=0):
+        runner.profile(True)
+        runner.predict_device(spec)
+        rows0 = [r for r in runner.profile_collect() if r["launches"]]
+        runner.profile(False)
+    assert len(rows0) == len(rows) + 1
+    runner.close()

@@ -122,6 +122,27 @@ def test_slots_never_alias_live_values():
     assert len(outs) == len(set(outs))  # debug plans keep every activation
 
 
+def test_front_block_pair_is_tagged_and_never_runs_in_place():
+    """The front block and the residual block behind it may run as one kernel (``f32_front2_kernel``): the packer tags the pair only in
+    production plans, and keeps the front block's INPUT slots apart from the pair's output slot — the fused kernel reads the input of
+    chunk 4 b .. 4 b + 3 while another workgroup already writes the (four times larger) output of chunk b."""
+    from birdnet_stm32.models import _pack as pk
+
+    plan = _plans(fuse=True)[0]
+    heads = [(i, o) for i, o in enumerate(plan.ops) if o.p[pk.TAIL_TAG] == pk.FRONT2_HEAD]
+    covered = [(i, o) for i, o in enumerate(plan.ops) if o.p[pk.TAIL_TAG] == pk.FRONT2_COVERED]
+    assert len(heads) == 2 and len(covered) == 1  # spectrogram entry and audio entry share the residual block
+    ci, c = covered[0]
+    assert c.kind == pk.F32_DWPW and c.in0 == c.in1
+    for hi, h in heads:
+        assert h.kind == pk.F32_FRONT and hi + h.p[pk.FRONT2_DIST] == ci and h.out == c.in0
+        assert c.out != h.in0 and c.out != h.out
+    # nobody else reads the map between them
+    assert not [i for i, o in enumerate(plan.ops) if heads[0][0] < i < ci and c.in0 in (o.in0, o.in1)]
+    for other in (_plans()[0], _plans(keep_all=True)[0]):  # unfused lowering, debug plan: no tags
+        assert not [o for o in other.ops if o.p[pk.TAIL_TAG] in (pk.FRONT2_HEAD, pk.FRONT2_COVERED)]
+
+
 def test_residual_source_survives_until_the_add():
     from birdnet_stm32.models import _pack as pk
 
@@ -264,7 +285,7 @@ def test_launcher_options_round_trip_without_a_device():
     default, values round-trip, unknown names are refused, and no launcher reads the environment any more."""
     from birdnet_stm32 import _hip
 
-    defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_th": 0,
+    defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "f32_front2": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_th": 0,
                 "i8_tail": 1, "i8_mel_generic": 0, "stft_rowmajor": 0, "stft_tpw": 0, "stft_sub": 0, "dual_stream": 0, "ingest_blk": 0, "ingest_generic": 0}
     assert sorted(defaults) == sorted(_hip.OPTION_NAMES)
     hdr = open(os.path.join(REPO, "include", "birdnet_hip.h")).read()
