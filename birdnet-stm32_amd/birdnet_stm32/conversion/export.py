@@ -10,7 +10,8 @@ as an ordinary `.tflite` file that ``load_model_runner`` reads back.
 
 Operator vocabulary of the emitted graphs (all int8 between QUANTIZE and DEQUANTIZE):
 
-* frontend (hybrid): QUANTIZE -> TRANSPOSE -> CONV_2D 1x1 (mel mixer, ReLU) -> element-wise magnitude scaling as 1x1
+* frontend (hybrid): QUANTIZE -> TRANSPOSE -> CONV_2D 1x1 (mel mixer, ReLU) -> [per-sample max normalisation of current hybrid
+  frontends: REDUCE_MAX -> ADD 1e-6 -> DIV, reference models/frontend.py:338-342] -> element-wise magnitude scaling as 1x1
   DEPTHWISE_CONV_2D / ADD operators (PWL: ``k0 x + sum_i k_i relu(w_i x + b_i)``, reference models/magnitude.py:179-192; PCEN:
   ``relu(k1 y0 + k2 relu(w y0 + b))`` with ``y0 = relu((1 - a) x)``, :166-177) -> TRANSPOSE;
 * backbone: CONV_2D / DEPTHWISE_CONV_2D with BatchNorm folded and ReLU6 fused (reference models/dscnn.py:28-84,198-246,
@@ -20,8 +21,7 @@ Operator vocabulary of the emitted graphs (all int8 between QUANTIZE and DEQUANT
   (softmax; the TFLite converter would keep the softmax in int8 — a deliberate difference: the float softmax is exact on the
   dequantised logits and needs no fixed-point exponential).
 
-Not emitted (``NotImplementedError``): the per-sample max-normalisation of current hybrid frontends (pass ``frontend_norm=False``,
-the shipped checkpoint's form), raw / precomputed frontends, attention pooling.
+Not emitted (``NotImplementedError``): raw / precomputed frontends, attention pooling.
 """
 
 from __future__ import annotations
@@ -89,9 +89,6 @@ def netspec_to_graph(spec: ns.NetSpec, frontend_norm: bool | None = None):
     if fa["mode"] != "hybrid":
         raise NotImplementedError(f"own INT8 export covers the hybrid frontend, not '{fa['mode']}'")
     norm = fa.get("norm", False) if frontend_norm is None else frontend_norm
-    if norm:
-        raise NotImplementedError("the per-sample max-normalisation of the hybrid frontend has no INT8 form in this build: export with "
-                                  "frontend_norm=False (the shipped checkpoint's frontend)")
     g = _GraphBuilder()
     F, W = spec.layers[0].out_shape[0], spec.layers[0].out_shape[1]
     M = int(fa["mel_bins"])
@@ -115,6 +112,17 @@ def netspec_to_graph(spec: ns.NetSpec, frontend_norm: bool | None = None):
         g.op("ADD", [a, b], o, {"activation": act})
         return o
 
+    if norm:
+        # per-sample normalisation to [0, 1] (reference models/frontend.py:338-342: y / (reduce_max(y, [1, 2, 3]) + 1e-6)) as the
+        # three operators the TFLite converter writes for it: REDUCE_MAX (keep_dims) -> ADD epsilon -> DIV with the scalar broadcast
+        axes = g.const("frontend/norm_axes", np.array([1, 2, 3], np.int32), np.int32, False)
+        ymax = g.act("frontend/norm_max", (1, 1, 1, 1))
+        g.op("REDUCE_MAX", [y, axes], ymax, {"keep_dims": True})
+        eps = g.const("frontend/norm_eps", np.full((1, 1, 1, 1), 1e-6, np.float32), np.int8, True, real=np.full((1, 1, 1, 1), 1e-6, np.float32))
+        den = add(ymax, eps, "frontend/norm_den", shape=(1, 1, 1, 1))
+        yn = g.act("frontend/norm", (1, 1, W, M))
+        g.op("DIV", [y, den], yn, {"activation": "none"})
+        y = yn
     mag = fa.get("mag_scale", "none")
     fw = fe.weights
     if mag == "pwl":

@@ -32,7 +32,7 @@ import numpy as np
 from birdnet_stm32.models import _netspec as ns
 from birdnet_stm32.models._tflite_reader import TfliteModel, TfliteTensor
 
-_MOVERS = ("TRANSPOSE", "STRIDED_SLICE", "CONCATENATION", "RESHAPE")
+_MOVERS = ("TRANSPOSE", "STRIDED_SLICE", "CONCATENATION", "RESHAPE", "REDUCE_MAX")  # output shares the input's quantisation
 _PLAIN_KINDS = (ns.INPUT, ns.FRONTEND, ns.CONV, ns.DWCONV, ns.BN, ns.RELU, ns.ADD, ns.GAP, ns.DENSE, ns.IDENTITY)
 
 
@@ -185,6 +185,11 @@ def run_float(model: TfliteModel, consts: dict[int, np.ndarray], x: np.ndarray) 
             y = 1.0 / (1.0 + np.exp(-env[i[0]]))
         elif n == "MUL":
             y = _act(env[i[0]] * env[i[1]], op.options["activation"])
+        elif n == "REDUCE_MAX":
+            axes = tuple(int(a) % env[i[0]].ndim for a in np.atleast_1d(env[i[1]]))
+            y = env[i[0]].max(axis=axes, keepdims=bool(op.options.get("keep_dims")))
+        elif n == "DIV":
+            y = _act(env[i[0]] / env[i[1]], op.options.get("activation", "none"))
         elif n == "SOFTMAX":
             z = (env[i[0]] - env[i[0]].max(axis=-1, keepdims=True)) * op.options.get("beta", 1.0)
             y = np.exp(z) / np.exp(z).sum(axis=-1, keepdims=True)
@@ -361,6 +366,17 @@ def quantize_graph(template: TfliteModel, consts: dict[int, np.ndarray], float_w
             for k in (op.inputs[1], op.outputs[0]):
                 N[k].scale, N[k].zero_point = np.asarray([s], np.float32), np.asarray([z], np.int64)
             N[op.inputs[1]].data = np.full(T[op.inputs[1]].data.shape, np.clip(np.round(val / s) + z, -128, 127), np.int8)
+
+    # quantised scalar / vector constants of element-wise operators (the epsilon of the frontend's max normalisation): own range
+    weight_like = {k for op in conv_ops for k in op.inputs[1:3]}
+    for op in template.ops:
+        if op.name in ("ADD", "MUL", "DIV"):
+            for k in op.inputs:
+                if T[k].data is not None and T[k].is_quantized and k not in weight_like and k in consts:
+                    v = np.asarray(consts[k], np.float64)
+                    sc, z = choose_activation_params(float(v.min()), float(v.max()))
+                    N[k].scale, N[k].zero_point = np.asarray([sc], np.float32), np.asarray([z], np.int64)
+                    N[k].data = np.clip(np.round(v / sc) + z, -128, 127).astype(np.int8).reshape(T[k].data.shape)
 
     # ---- weights and biases
     for op in conv_ops:

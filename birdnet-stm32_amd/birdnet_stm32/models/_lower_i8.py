@@ -457,6 +457,31 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     region = ops[i:j]
     lut = None
     front_out = cur
+    maxnorm = None
+    if region and region[0].name == "REDUCE_MAX":
+        # per-sample max normalisation of current hybrid frontends (reference models/frontend.py:338-342): REDUCE_MAX over the whole map
+        # -> ADD epsilon -> DIV by that scalar.  Everything behind the maximum is a function of bytes: the denominator byte per maximum
+        # byte (the quantised ADD) and the DIV of every byte by every denominator byte become tables (models/_quant.py: div_table)
+        _expect(len(region) >= 3 and region[1].name == "ADD" and region[2].name == "DIV", "REDUCE_MAX must be followed by ADD and DIV")
+        rmax, addop, divop = region[:3]
+        axes = sorted(int(a) % 4 for a in np.atleast_1d(g.const(rmax.inputs[1])))
+        _expect(rmax.inputs[0] == cur and axes == [1, 2, 3] and g.q(rmax.outputs[0]) == g.q(cur), "REDUCE_MAX over the whole map, same quantisation")
+        _expect(rmax.outputs[0] in addop.inputs and divop.inputs[0] == cur and divop.inputs[1] == addop.outputs[0], "max normalisation wiring")
+        eps_i = [k for k in addop.inputs if k != rmax.outputs[0]]
+        _expect(len(eps_i) == 1 and t[eps_i[0]].data is not None and t[eps_i[0]].data.size == 1, "ADD of a scalar constant to the maximum")
+        eps_q = int(np.asarray(t[eps_i[0]].data).reshape(-1)[0])
+        (s_m, z_m), (s_e, z_e), (s_d, z_d) = g.q(rmax.outputs[0]), g.q(eps_i[0]), g.q(addop.outputs[0])
+        mx = np.arange(-128, 128, dtype=np.int64)
+        if addop.inputs[0] == rmax.outputs[0]:
+            den_tab = qz.AddParams(s_m, z_m, s_e, z_e, s_d, z_d, addop.options["activation"]).apply(mx, np.full(256, eps_q, np.int64))
+        else:
+            den_tab = qz.AddParams(s_e, z_e, s_m, z_m, s_d, z_d, addop.options["activation"]).apply(np.full(256, eps_q, np.int64), mx)
+        s_o, z_o = g.q(divop.outputs[0])
+        div_tab = qz.div_table(s_mel, z_mel, s_d, z_d, s_o, z_o, divop.options.get("activation", "none"))
+        maxnorm = (den_tab.astype(np.int8), div_tab)
+        region = region[3:]
+        cur = divop.outputs[0]
+        front_out = cur
     if region:
         front_out = ops[j].inputs[0]
         lut = _pwl_table(g, region, cur, front_out, M)
@@ -471,6 +496,9 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     plan = pk.Plan(pk.DTYPE_I8, pk.INPUT_SPECTROGRAM, F * W, F, W, int(t[model.outputs[0]].shape[-1]), meta={"tflite_ops": len(ops)})
     pb = pk.PlanBuilder(plan)
     tens = [pb.tensor(w_mel, np.int8), pb.tensor(bias, np.int32), pb.tensor(mult, np.int32), pb.tensor(shift, np.int32)]
+    norm_lut = lut if maxnorm is not None else None  # with the max normalisation the per-channel table sits behind the DIV, not behind the mixer
+    if maxnorm is not None:
+        lut = None
     if lut is not None:
         tens.append(pb.tensor(lut, np.int8))
     mel_tile = pick_tile(1, W)
@@ -495,6 +523,13 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     else:
         pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
               out_shape=(M, W, 1), out_dtype="int8")
+    if maxnorm is not None:
+        _expect((M * W) % 1024 == 0 and W % 4 == 0, "max normalisation kernel: maps of a multiple of 1024 bytes")
+        pb.plan.ops[-1].name = "mel_mixer"  # (its [W][M] graph tensor is not compared by name: the plan keeps [M][W])
+        v_n = pb.value(M * W)
+        tt = [pb.tensor(maxnorm[0], np.int8), pb.tensor(maxnorm[1], np.int8)] + ([pb.tensor(norm_lut, np.int8)] if norm_lut is not None else [])
+        pb.op(pk.I8_MAXNORM, v, v_n, p=[M, W, int(norm_lut is not None)], t=tt, name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
+        v = v_n
     val = {cur: v}
     shape = {cur: (M, W, 1)}
     tail_blocks: list[dict] = []  # fused DW+PW blocks in graph order (candidates for the fused tail kernel)

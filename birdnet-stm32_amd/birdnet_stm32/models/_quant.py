@@ -138,3 +138,46 @@ def logistic_table(s_in: float, z_in: int, s_out: float, z_out: int) -> np.ndarr
     t = np.trunc(r)
     r = np.where(np.abs(r - t) >= 0.5, t + np.sign(r), t)
     return np.clip(r.astype(np.int64) + z_out, -128, 127).astype(np.int8)
+
+
+# -- int8 DIV as a table (the per-sample max normalisation of current hybrid frontends) --------------------------------------
+def _clz32(x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, np.int64) & 0xFFFFFFFF
+    n = np.full(x.shape, 32, np.int64)
+    for bit in range(32):
+        n = np.where((x >> bit) & 1 == 1, 31 - bit, n)
+    return n
+
+
+def _reciprocal_q31(x: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """1 / x for int32 x > 0 the way TFLite's ``GetReciprocal(x, 31, ...)`` computes it: x is normalised to 1 + f with f in [0, 1)
+    (Q0.31), ``1 / (1 + f)`` comes from gemmlowp's Newton-Raphson division (start 48/17 - 32/17 d on the half denominator d, three
+    iterations, Q2.29), the result is a Q0.31 mantissa and the number of bits x lies above 1."""
+    x = np.asarray(x, np.int64)
+    lz = _clz32(x)
+    f = ((x << lz) & 0xFFFFFFFF) - (1 << 31)
+    half_den = (f + _I32_MAX + 1) // 2                     # RoundingHalfSum(f, One()) with One() = 2^31 - 1; the sum is >= 0
+    est = 1515870810 + _high_mul(half_den, -1010580540)    # 48/17 - 32/17 d
+    for _ in range(3):
+        err = (1 << 29) - _high_mul(half_den, est)         # 1 - d x   (Q2.29)
+        est = est + np.clip(_high_mul(est, err) << 2, _I32_MIN, _I32_MAX)
+    return np.clip(est << 1, _I32_MIN, _I32_MAX), 31 - lz
+
+
+def div_table(s1: float, z1: int, s2: float, z2: int, so: float, zo: int, act: str = "none") -> np.ndarray:
+    """The TFLite int8 DIV (kernels/internal/reference/div.h) for every pair of bytes: int8 ``[256][256]``, row = divisor byte + 128,
+    column = dividend byte + 128.  A zero divisor (undefined in TFLite) divides by 1."""
+    mo, sho = quantize_multiplier(float(np.float32(s1)) / (float(np.float32(s2)) * float(np.float32(so))))
+    amin, amax = activation_bounds(act, so, zo)
+    x1 = (np.arange(-128, 128, dtype=np.int64) - int(z1))[None, :].repeat(256, axis=0)
+    x2 = (np.arange(-128, 128, dtype=np.int64) - int(z2))[:, None].repeat(256, axis=1)
+    neg = x2 < 0
+    x1 = np.where(neg, -x1, x1)
+    x2 = np.where(neg, -x2, x2)
+    x2 = np.where(x2 == 0, 1, x2)
+    inv, bits = _reciprocal_q31(x2)
+    mag = np.where(x1 < 0, 2 * (-x1) - 1, x1)
+    headroom = np.where(x1 < 0, _clz32(mag), _clz32(mag) - 1)          # CountLeadingSignBits
+    quotient = _high_mul(x1 << headroom, inv)
+    y = requantize(quotient, mo, sho - bits - headroom) + int(zo)
+    return np.clip(y, amin, amax).astype(np.int8)

@@ -165,4 +165,9 @@ enum BnOpKind : int32_t {
     // int8 MUL of a map with a per-chunk gate vector (squeeze-excite): [P][C] * gate(in1)[C] -> [P][C]
     // p: P C zp_x zp_gate mult shift zp_out act_min act_max
     BN_OP_I8_SCALE = 31,
+    // per-chunk max normalisation of an int8 map (REDUCE_MAX over the whole map -> ADD epsilon -> DIV by that scalar) followed by an
+    // optional per-channel 256-entry table (the PWL behind it): [C][W] -> [C][W].  Everything after the max is a function of bytes:
+    // p: C W has_lut   t: denominator byte per max byte (256), DIV table [256 denominators][256 values] (row/column = byte + 128),
+    //    per-channel table [C][256] (has_lut)
+    BN_OP_I8_MAXNORM = 32,
 };

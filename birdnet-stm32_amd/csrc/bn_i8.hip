@@ -348,6 +348,46 @@ __global__ void i8_scale_kernel(const int8_t* __restrict__ x, const int8_t* __re
     *reinterpret_cast<uint32_t*>(y + row * C + 4 * c4) = packed;
 }
 
+// Per-sample max normalisation of current hybrid frontends in INT8 (reference models/frontend.py:338-342; TFLite writes REDUCE_MAX ->
+// ADD 1e-6 -> DIV): one workgroup per chunk.  The only data-dependent quantity is the map's maximum byte; the quantised ADD of the
+// epsilon is a 256-entry table of it, and the int8 DIV by the resulting scalar is one row of a [256][256] byte table (both built by
+// the packer from the operators' parameters, models/_quant.py: div_table) — the kernel does no fixed-point division at all.
+__global__ __launch_bounds__(256) void i8_maxnorm_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int C, int W,
+                                                         const int8_t* __restrict__ den_tab, const int8_t* __restrict__ div_tab,
+                                                         const int8_t* __restrict__ lut) {
+    __shared__ int red[4];
+    __shared__ uint8_t row[256];
+    const int tid = threadIdx.x;
+    const int n4 = C * W / 4;  // dwords per chunk, a multiple of 256
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(x + (size_t)blockIdx.x * C * W);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(y + (size_t)blockIdx.x * C * W);
+    int mx = -128;
+    for (int i = tid; i < n4; i += 256) {
+        const uint32_t v = src[i];
+        mx = max(max(mx, (int)(int8_t)v), max((int)(int8_t)(v >> 8), max((int)(int8_t)(v >> 16), (int)(int8_t)(v >> 24))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = max(max(red[0], red[1]), max(red[2], red[3]));
+    const int den = den_tab[mx + 128];
+    row[tid] = (uint8_t)div_tab[(den + 128) * 256 + tid];
+    __syncthreads();
+    for (int i = tid; i < n4; i += 256) {
+        const uint32_t v = src[i];
+        const int c = (4 * i) / W;  // W is a multiple of 4: the four bytes share the channel
+        uint32_t o = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t q = row[((v >> (8 * e)) & 0xff) ^ 0x80];  // byte + 128
+            if (lut) q = (uint8_t)lut[c * 256 + ((q & 0xff) ^ 0x80)];
+            o |= (q & 0xff) << (8 * e);
+        }
+        dst[i] = o;
+    }
+}
+
 // DEQUANTIZE -> float32 SOFTMAX over the classes of a chunk: one wave per chunk (scores), logits = the dequantised input
 __global__ __launch_bounds__(64) void i8_head_softmax_kernel(const int8_t* __restrict__ x, float* __restrict__ scores, float* __restrict__ logits,
                                                              int C, int zp_fc, float s_fc, float beta) {
@@ -435,6 +475,10 @@ void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int 
                      int amin, int amax, hipStream_t s) {
     const long total = (long)B * P * (C / 4);
     hipLaunchKernelGGL(i8_scale_kernel, grid1d(total, 256), dim3(256), 0, s, x, gate, y, P, C, zx, zg, mult, shift, zo, amin, amax, total);
+}
+
+void launch_i8_maxnorm(const int8_t* x, int8_t* y, int B, int C, int W, const int8_t* den_tab, const int8_t* div_tab, const int8_t* lut, hipStream_t s) {
+    hipLaunchKernelGGL(i8_maxnorm_kernel, dim3(B), dim3(256), 0, s, x, y, C, W, den_tab, div_tab, lut);
 }
 
 void launch_i8_head_softmax(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, float s_fc, float beta, hipStream_t s) {

@@ -20,6 +20,11 @@ Conventions restated:
 * MEAN  int32 sum - N zp_x ; multiplier (s_x / s_y) with the 1/N folded in as in reduce.h
 * LOGISTIC  256-entry float32 LUT ; DEQUANTIZE (q - zp) * s
 * MUL   zo + MBQM((q1 - z1)(q2 - z2), s1 s2 / so), broadcasting ; SOFTMAX only in float32 behind DEQUANTIZE
+* REDUCE_MAX  max of the int8 values (input and output share scale and zero point, as the converter guarantees)
+* DIV   (reference kernel div.h, int8): x1 = q1 - z1, x2 = q2 - z2 (signs flipped so that x2 > 0); 1 / x2 by gemmlowp's fixed-point
+      Newton-Raphson (GetReciprocal: x2 normalised to [1, 2), three iterations from 48/17 - 32/17 d, Q0.31 result + exponent);
+      quotient = SRDHM(x1 << headroom(x1), reciprocal), then MBQM with s1 / (s2 so) and the collected shifts, + zo, clamp.
+      A zero divisor (undefined in TFLite: debug assertion) is taken as 1 here — a silent chunk divides 0 by it
 * TRANSPOSE / STRIDED_SLICE / SHAPE / PACK / FILL / CONCATENATION are exact data movement.
 """
 
@@ -85,6 +90,56 @@ def mbqm(x, multiplier, shift):
     left = np.maximum(shift, 0)
     right = np.maximum(-shift, 0)
     return rounding_divide_by_pot(srdhm(np.asarray(x, dtype=np.int64) << left, multiplier), right)
+
+
+def _sat_mul_pot(x, exponent: int):
+    """gemmlowp ``SaturatingRoundingMultiplyByPOT<exponent>`` for exponent > 0: x * 2^exponent, saturated to int32."""
+    x = np.asarray(x, dtype=np.int64)
+    return np.clip(x << exponent, INT32_MIN, INT32_MAX)
+
+
+def one_over_one_plus_x_for_x_in_0_1(a):
+    """gemmlowp fixedpoint.h ``one_over_one_plus_x_for_x_in_0_1``: a = x in [0, 1) as Q0.31 raw -> 1 / (1 + x) as Q0.31 raw.
+
+    Newton-Raphson division on the half denominator d = (1 + x) / 2 in [1/2, 1): x0 = 48/17 - 32/17 d (Q2.29), three steps
+    x <- x + x (1 - d x), result x / 2.  Products of FixedPoint<.., A> and FixedPoint<.., B> are SRDHM of the raw values with A + B
+    integer bits; Rescale multiplies by a saturating power of two."""
+    a = np.asarray(a, dtype=np.int64)
+    s = a + INT32_MAX                                   # RoundingHalfSum(a, F0::One()), One() = 2^31 - 1
+    half_den = (s + np.where(s >= 0, 1, -1)) // 2       # truncating: s >= 0 here
+    x = 1515870810 + srdhm(half_den, -1010580540)       # Q2.29: 48/17 + d * (-32/17)
+    one_q2 = 1 << 29
+    for _ in range(3):
+        hdx = srdhm(half_den, x)                        # Q2.29
+        x = x + _sat_mul_pot(srdhm(x, one_q2 - hdx), 2)  # x (1 - d x) is Q4.27 -> Rescale<2>
+    return _sat_mul_pot(x, 1)                           # ExactMulByPot<-1> (Q1.30 view of the same raw) -> Rescale<0>
+
+
+def count_leading_zeros32(x):
+    x = np.asarray(x, dtype=np.int64) & 0xFFFFFFFF
+    n = np.zeros(x.shape, np.int64)
+    for sh in (16, 8, 4, 2, 1):
+        big = x >> sh
+        take = big != 0
+        x = np.where(take, big, x)
+        n = n + np.where(take, sh, 0)
+    return np.where(x == 0, 32, 31 - n)
+
+
+def count_leading_sign_bits32(x):
+    """TFLite ``CountLeadingSignBits``: redundant sign bits of an int32 (31 for 0)."""
+    x = np.asarray(x, dtype=np.int64)
+    neg = x < 0
+    mag = np.where(neg, 2 * (-x) - 1, x)
+    return np.where(x == INT32_MIN, 0, np.where(neg, count_leading_zeros32(mag), count_leading_zeros32(mag) - 1))
+
+
+def get_reciprocal(x):
+    """TFLite common.h ``GetReciprocal(x, 31, &num_bits_over_unit)`` for x > 0: (Q0.31 reciprocal of x normalised to [1, 2), exponent)."""
+    x = np.asarray(x, dtype=np.int64)
+    lz = count_leading_zeros32(x)
+    shifted = ((x << lz) & 0xFFFFFFFF) - (1 << 31)
+    return one_over_one_plus_x_for_x_in_0_1(shifted), 31 - lz
 
 
 def activation_range(act: str, scale: float, zp: int, qmin=-128, qmax=127) -> tuple[int, int]:
@@ -251,6 +306,36 @@ class Int8Interpreter:
         y = mbqm((a - z1) * (b - z2), *p["m"]) + zo
         return np.clip(y, *p["act"]).astype(np.int8)
 
+    def _reduce_max(self, op, env):
+        x = self._value(env, op.inputs[0])
+        axes = tuple(int(a) % x.ndim for a in np.atleast_1d(self._value(env, op.inputs[1])))
+        if self._q(op.inputs[0]) != self._q(op.outputs[0]):
+            raise ValueError("REDUCE_MAX with differing input / output quantisation")
+        return x.max(axis=axes, keepdims=bool(op.options.get("keep_dims")))
+
+    def div_params(self, op):
+        s1, z1 = self._q(op.inputs[0])
+        s2, z2 = self._q(op.inputs[1])
+        so, zo = self._q(op.outputs[0])
+        real = float(np.float32(s1)) / (float(np.float32(s2)) * float(np.float32(so)))
+        return z1, z2, zo, quantize_multiplier(real), activation_range(op.options.get("activation", "none"), so, zo)
+
+    def _div(self, op, env):
+        """int8 DIV (reference kernel div.h: DivElementwise / BroadcastDivSlow), broadcasting."""
+        a = self._value(env, op.inputs[0]).astype(np.int64)
+        b = self._value(env, op.inputs[1]).astype(np.int64)
+        z1, z2, zo, (mo, so), act = self.div_params(op)
+        x1, x2 = np.broadcast_arrays(a - z1, b - z2)
+        neg = x2 < 0
+        x1 = np.where(neg, -x1, x1)
+        x2 = np.where(neg, -x2, x2)
+        x2 = np.where(x2 == 0, 1, x2)  # undefined in TFLite (see the header)
+        inv, recip_shift = get_reciprocal(x2)
+        headroom = count_leading_sign_bits32(x1)
+        unscaled = srdhm(x1 << headroom, inv)
+        y = mbqm(unscaled, mo, so - recip_shift - headroom) + zo
+        return np.clip(y, *act).astype(np.int8)
+
     def logistic_lut(self, op) -> np.ndarray:
         """int8->int8 table indexed by ``q + 128`` (LUTPopulate in float32)."""
         s_in, zp_in = self._q(op.inputs[0])
@@ -327,6 +412,10 @@ class Int8Interpreter:
                 y = lut[self._value(env, op.inputs[0]).astype(np.int32) + 128]
             elif n == "MUL":
                 y = self._mul(op, env)
+            elif n == "REDUCE_MAX":
+                y = self._reduce_max(op, env)
+            elif n == "DIV":
+                y = self._div(op, env)
             elif n == "SOFTMAX":  # float32 softmax behind DEQUANTIZE (the form this build's exporter writes): exp(beta (x - max)) / sum
                 xin = self._value(env, op.inputs[0])
                 if xin.dtype != np.float32:
