@@ -524,7 +524,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
         pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
               out_shape=(M, W, 1), out_dtype="int8")
     if maxnorm is not None:
-        _expect((M * W) % 1024 == 0 and W % 4 == 0, "max normalisation kernel: maps of a multiple of 1024 bytes")
+        _expect(W % 4 == 0, "max normalisation kernel: map width must be a multiple of 4")
         pb.plan.ops[-1].name = "mel_mixer"  # (its [W][M] graph tensor is not compared by name: the plan keeps [M][W])
         v_n = pb.value(M * W)
         tt = [pb.tensor(maxnorm[0], np.int8), pb.tensor(maxnorm[1], np.int8)] + ([pb.tensor(norm_lut, np.int8)] if norm_lut is not None else [])

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void i8_maxnorm_kernel(const int8_t* __restric
     __shared__ int red[4];
     __shared__ uint8_t row[256];
     const int tid = threadIdx.x;
-    const int n4 = C * W / 4;  // dwords per chunk, a multiple of 256
+    const int n4 = C * W / 4;  // dwords per chunk
     const uint32_t* src = reinterpret_cast<const uint32_t*>(x + (size_t)blockIdx.x * C * W);
     uint32_t* dst = reinterpret_cast<uint32_t*>(y + (size_t)blockIdx.x * C * W);
     int mx = -128;

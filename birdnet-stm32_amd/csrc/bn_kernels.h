@@ -170,7 +170,7 @@ void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_o
                   const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut, hipStream_t s);
 void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int P, int C, int zx, int zg, int mult, int shift, int zo,
                      int amin, int amax, hipStream_t s);
-// per-chunk max -> denominator byte -> DIV table row [-> per-channel table]: [C][W] int8 -> [C][W] int8 (C * W a multiple of 1024)
+// per-chunk max -> denominator byte -> DIV table row [-> per-channel table]: [C][W] int8 -> [C][W] int8 (W a multiple of 4)
 void launch_i8_maxnorm(const int8_t* x, int8_t* y, int B, int C, int W, const int8_t* den_tab, const int8_t* div_tab, const int8_t* lut, hipStream_t s);
 void launch_i8_head_softmax(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, float s_fc, float beta, hipStream_t s);
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,

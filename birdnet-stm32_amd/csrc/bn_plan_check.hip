@@ -208,7 +208,7 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
             case BN_OP_I8_MAXNORM:  // C W has_lut
                 c.dims({p[0], p[1]}, "max normalisation") && c.slot(o.in0, 1LL * p[0] * p[1], "input") && c.slot(o.out, 1LL * p[0] * p[1], "output") &&
                     c.tensor(0, 256, "denominator table") && c.tensor(1, 65536, "division table") && (!p[2] || c.tensor(2, 256LL * p[0], "channel table"));
-                if (c.ok && (p[0] * p[1]) % 1024) c.bad("map of %d x %d bytes is not a multiple of 1024", p[0], p[1]);
+                if (c.ok && p[1] % 4) c.bad("map width %d is not a multiple of 4 (the kernel reads dwords of one channel)", p[1]);
                 break;
             case BN_OP_I8_HEAD:  // C zp_fc zp_out has_lut
                 c.dims({p[0]}, "head") && c.slot(o.in0, 1LL * p[0], "input") && c.slot(o.out, 4LL * p[0], "scores") && (!p[3] || c.tensor(0, 256, "table"));

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of BASELINE configs[4]'s backbone in INT8 on one MI355X: alpha = 1.5 DS-CNN with squeeze-excite and inverted residuals
 and PCEN magnitude scaling (seeded random weights), quantised by this build's own exporter (conversion/export.py) — with the
-HYBRID frontend without per-sample normalisation, because the raw learned-filterbank frontend and the max-normalisation have no
-INT8 export yet (stated in DESIGN.md).  3 s @ 24 kHz chunks, spectrogram geometry of the shipped model.
+HYBRID frontend of current reference code (per-sample max normalisation: REDUCE_MAX -> ADD -> DIV), because the raw learned-filterbank
+frontend has no INT8 export (stated in DESIGN.md).  3 s @ 24 kHz chunks, spectrogram geometry of the shipped model.
 
     python tools/config5_i8_bench.py [batch] [steps]
 
@@ -26,7 +26,8 @@ spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chun
                    audio_frontend="hybrid", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
 rng = np.random.default_rng(0)
 cal = [rng.random((1, 257, 256, 1), dtype=np.float32) ** 4 for _ in range(8)]
-model = parse_tflite(write_tflite(convert_netspec_to_int8(spec, lambda: ([c] for c in cal), frontend_norm=False)))
+spec.frontend.attrs["norm"] = True
+model = parse_tflite(write_tflite(convert_netspec_to_int8(spec, lambda: ([c] for c in cal), frontend_norm=True)))
 r = HipRunner(lower_i8(model), max_batch=B)
 x = torch.randn((B, 72000), device="cuda")
 x = x / x.abs().amax(dim=1, keepdim=True)
@@ -47,7 +48,7 @@ by_kind = {}
 for q in rows:
     by_kind[q["kind"]] = by_kind.get(q["kind"], 0.0) + q["ms"]
 top = sorted(rows, key=lambda q: -q["ms"])[:6]
-print(json.dumps({"workload": "configs[4] backbone in INT8: alpha=1.5 IR/SE DS-CNN + PCEN, hybrid frontend (norm off), 3 s @ 24 kHz, seeded weights, own PTQ",
+print(json.dumps({"workload": "configs[4] backbone in INT8: alpha=1.5 IR/SE DS-CNN + PCEN, hybrid frontend with per-sample max normalisation, 3 s @ 24 kHz, seeded weights, own PTQ",
                   "batch": B, "ms_per_step": round(dt * 1e3, 3), "chunks_per_s": round(B / dt, 1), "tflite_ops": len(model.ops), "plan_ops": len(r.plan.ops),
                   "ms_by_kernel_kind": {k: round(v, 3) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
                   "slowest_ops": [{"kind": q["kind"], "name": q["name"], "ms": round(q["ms"], 3)} for q in top]}))
