@@ -361,3 +361,37 @@ def test_f32_front2_fused_kernel_matches_the_two_strip_kernels(torch_mod):
         runner.profile(False)
     assert len(rows0) == len(rows) + 1
     runner.close()
+
+
+# --------------------------------------------------------------------------------------- INT8: row-streaming depthwise kernel
+def test_i8_dw_stream_kernel_matches_the_baseline_kernel(torch_mod):
+    """``i8_dw_stream_kernel`` (stand-alone depthwise 3x3 of exported inverted-residual graphs, stride 1 and 2, channel counts that
+    are not multiples of 16) against ``i8_dw_kernel``: every depthwise tensor of a debug plan bit for bit, for strip heights that
+    move the strip borders, odd batch sizes and repeated launches (the store pattern is one dword per lane)."""
+    torch = torch_mod
+    from test_conversion import EXPORT_TOPOLOGIES, _export
+
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models._lower_i8 import lower_i8
+    from birdnet_stm32.models.runners import HipRunner
+
+    for name in ("alpha1.5_pcen", "ir_se_softmax"):  # (without squeeze-excite the depthwise stage fuses with the projection)
+        _, model, _, x = _export(EXPORT_TOPOLOGIES[name])
+        x = np.concatenate([x] * 3)[:19]
+        B = x.shape[0]
+        runner = HipRunner(lower_i8(model, keep_all=True), max_batch=B)
+        dw_ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.I8_DW]
+        assert len(dw_ops) >= 4 and {runner.plan.ops[oi].p[3] for oi in dw_ops} == {1, 2}  # both strides occur
+        with _hip.options(i8_strip=0):
+            want_scores = runner.predict(x)
+            want = {oi: runner.op_output(oi, B) for oi in dw_ops}
+        for th in (0, 1, 3, 5, 64) * 4:
+            with _hip.options(i8_strip=1, i8_strip_th=th):
+                got_scores = runner.predict(x)
+                for oi in dw_ops:
+                    assert np.array_equal(runner.op_output(oi, B), want[oi]), f"{name}: rows per strip {th or 'auto'}: {runner.plan.ops[oi].name}"
+                assert np.array_equal(got_scores, want_scores)
+        for nb in (1, 2, 7):
+            assert np.array_equal(runner.predict(x[:nb]), want_scores[:nb])
+        runner.close()
