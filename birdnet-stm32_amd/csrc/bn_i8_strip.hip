@@ -739,6 +739,114 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
     }
 }
 
+// The stem of exported graphs (3x3 convolution of the single-channel map, any stride, C output channels) in the same row-streaming
+// form: lane = (column, channel quad), the three window bytes of an input row packed into ONE dword that serves all four channels
+// of the lane (three v_dot4_i32_i8 per output instead of nine sign-extend + multiply-add triples), three byte loads per input row.
+template <int S>
+__global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, int SW) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int CQ = a.CQ, NCOL = 64 / CQ;
+    const int cq = lane % CQ, n = lane / CQ;
+    const int groups = a.C / (4 * CQ);
+    const int strips_x = (a.OW + NCOL - 1) / NCOL;
+    const int rblocks = (a.OH + a.TH - 1) / a.TH;
+    long wid = (long)xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wid >= (long)a.B * groups * strips_x * rblocks) return;
+    const int g = (int)(wid % groups);
+    wid /= groups;
+    const int sx = (int)(wid % strips_x);
+    wid /= strips_x;
+    const int ry = (int)(wid % rblocks);
+    const int chunk = (int)(wid / rblocks);
+    const int oh0 = ry * a.TH;
+    const int nrows = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
+    const int ow = sx * NCOL + n;
+    const bool live = ow < a.OW;
+    const int c0 = 4 * (g * CQ + cq);
+    int wr[3][4], bias[4], mult[4], shift[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k0 = a.w[(i * 3 + 0) * a.C + c0 + e], k1 = a.w[(i * 3 + 1) * a.C + c0 + e], k2 = a.w[(i * 3 + 2) * a.C + c0 + e];
+            wr[i][e] = (k0 & 0xff) | ((k1 & 0xff) << 8) | ((k2 & 0xff) << 16);
+            sum += k0 + k1 + k2;
+        }
+        bias[e] = a.bias[c0 + e] - a.zp_in * sum;
+        mult[e] = a.mult[c0 + e];
+        shift[e] = a.shift[c0 + e];
+    }
+    const int zp = a.zp_in & 0xff, zprow = zp * 0x00010101;
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x) + (size_t)chunk * a.H * a.W, 0, a.H * a.W, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)chunk * a.OH * a.OW * a.C, 0, a.OH * a.OW * a.C, 0x00020000);
+    const int iw0 = ow * SW - a.pl;
+    bool pad[3];
+    int voff_in[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        pad[j] = !live || iw0 + j < 0 || iw0 + j >= a.W;
+        voff_in[j] = pad[j] ? 0 : iw0 + j;
+    }
+    const int voff_out = live ? ow * a.C + c0 : 0x7fff0000;
+    const int ir0 = oh0 * S - a.pt;
+    const int rows_needed = S * (nrows - 1) + 3;
+    int raw[2][3], T[3];
+    auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
+    auto issue = [&](int slot, int rr) {
+        if (row_ok(rr)) {
+            const int soff = (ir0 + rr) * a.W;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) raw[slot][j] = __builtin_amdgcn_raw_buffer_load_b8(rs_in, voff_in[j], soff, 0);
+        }
+    };
+    auto consume = [&](int slot, int rr, int ti) {
+        if (row_ok(rr)) {
+            const int b0 = pad[0] ? zp : (raw[slot][0] & 0xff), b1 = pad[1] ? zp : (raw[slot][1] & 0xff), b2 = pad[2] ? zp : (raw[slot][2] & 0xff);
+            T[ti] = b0 | (b1 << 8) | (b2 << 16);
+        } else {
+            T[ti] = zprow;
+        }
+    };
+    auto emit = [&](int i0, int i1, int i2, int oh) {
+        int qv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int acc = dot4_first(T[i0], wr[0][e], bias[e]);
+            acc = dot4(T[i1], wr[1][e], acc);
+            acc = dot4(T[i2], wr[2][e], acc);
+            qv[e] = med3(mbqm(acc, mult[e], shift[e]) + a.zp_out, a.amin, a.amax);
+        }
+        const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+        __builtin_amdgcn_raw_buffer_store_b32(word, rs_out, voff_out, oh * a.OW * a.C, 0);
+    };
+    constexpr int P = 3 - S;
+    issue(0, 0);
+    issue(1, 1);
+#pragma unroll
+    for (int rr = 0; rr < P; ++rr) {
+        consume(rr & 1, rr, rr % 3);
+        issue(rr & 1, rr + 2);
+    }
+    constexpr int U = 6 / S;
+    for (int k = 0; k < nrows; k += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k + u >= nrows) break;
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) {
+                const int rs = P + S * u + s2;
+                consume(rs & 1, S * k + rs, rs % 3);
+                issue(rs & 1, S * k + rs + 2);
+            }
+            emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
+        }
+    }
+}
+
 }  // namespace
 
 // channel split of a block: waves per strip (1 = a wave holds all input channels); 0 = no strip kernel for this shape
@@ -828,6 +936,27 @@ bool launch_i8_dw_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g,
         hipLaunchKernelGGL(i8_dw_stream_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(i8_dw_stream_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    return true;
+}
+
+bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias, const int32_t* mult,
+                           const int32_t* shift, hipStream_t s) {
+    if (!g_opt.i8_strip || (g.sh != 1 && g.sh != 2) || g.sw < 1 || g.sw > 2 || g.C % 4 || (long)g.OH * g.OW * g.C >= 0x7fff0000L) return false;
+    int cq = 16;
+    while ((g.C / 4) % cq) cq >>= 1;
+    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq};
+    const int ncol = 64 / cq;
+    const long per_row_block = (long)B * (g.C / (4 * cq)) * ((g.OW + ncol - 1) / ncol);
+    int th = g.OH;
+    while (th > 16) th = (th + 1) / 2;
+    while (th > 4 && per_row_block * ((g.OH + th - 1) / th) < 8192) th = (th + 1) / 2;
+    if (const int v = g_opt.i8_strip_th; v >= 1) th = v < g.OH ? v : g.OH;
+    a.TH = th;
+    const long waves = per_row_block * ((g.OH + th - 1) / th);
+    if (g.sh == 1)
+        hipLaunchKernelGGL(i8_stem_stream_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, g.sw);
+    else
+        hipLaunchKernelGGL(i8_stem_stream_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, g.sw);
     return true;
 }
 

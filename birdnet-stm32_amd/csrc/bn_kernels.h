@@ -160,6 +160,8 @@ void launch_i8_dw(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const 
 // the same as a row-streaming kernel (bn_i8_strip.hip); false = shape not taken, use launch_i8_dw
 bool launch_i8_dw_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias, const int32_t* mult,
                          const int32_t* shift, hipStream_t s);
+bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias, const int32_t* mult,
+                           const int32_t* shift, hipStream_t s);  // the single-channel 3x3 stem in the same form
 struct I8AddParams {
     int enabled, z1, m1, s1, m2, s2, mo, so, zo, amin, amax;
 };

@@ -366,7 +366,7 @@ def test_f32_front2_fused_kernel_matches_the_two_strip_kernels(torch_mod):
 # --------------------------------------------------------------------------------------- INT8: row-streaming depthwise kernel
 def test_i8_dw_stream_kernel_matches_the_baseline_kernel(torch_mod):
     """``i8_dw_stream_kernel`` (stand-alone depthwise 3x3 of exported inverted-residual graphs, stride 1 and 2, channel counts that
-    are not multiples of 16) against ``i8_dw_kernel``: every depthwise tensor of a debug plan bit for bit, for strip heights that
+    are not multiples of 16) and ``i8_stem_stream_kernel`` against ``i8_dw_kernel`` / ``i8_stem_kernel``: every such tensor of a debug plan bit for bit, for strip heights that
     move the strip borders, odd batch sizes and repeated launches (the store pattern is one dword per lane)."""
     torch = torch_mod
     from test_conversion import EXPORT_TOPOLOGIES, _export
@@ -381,8 +381,8 @@ def test_i8_dw_stream_kernel_matches_the_baseline_kernel(torch_mod):
         x = np.concatenate([x] * 3)[:19]
         B = x.shape[0]
         runner = HipRunner(lower_i8(model, keep_all=True), max_batch=B)
-        dw_ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.I8_DW]
-        assert len(dw_ops) >= 4 and {runner.plan.ops[oi].p[3] for oi in dw_ops} == {1, 2}  # both strides occur
+        dw_ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind in (pk.I8_DW, pk.I8_STEM)]  # the stem streams its rows the same way
+        assert len(dw_ops) >= 5 and {runner.plan.ops[oi].p[3] for oi in dw_ops} == {1, 2} and pk.I8_STEM in {runner.plan.ops[oi].kind for oi in dw_ops}
         with _hip.options(i8_strip=0):
             want_scores = runner.predict(x)
             want = {oi: runner.op_output(oi, B) for oi in dw_ops}
