@@ -606,6 +606,164 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
     }
 }
 
+// Plain 1x1 convolution (the expand / project convolutions of exported inverted-residual graphs, Cin up to 256) without LDS tiles and
+// workgroup barriers in the data path: a wave owns 16 consecutive positions.  The activations are the B operand as they lie in memory
+// (lane (position r, k quarter q) loads the 16 channel bytes 64 s + 16 q .. of its position with one 16-byte load; bytes past Cin
+// meet zero weights), the weight fragments the packer already writes for the tile kernel are the A operand, so the accumulators of
+// lane (r, q) are the four CONSECUTIVE output channels 16 ct + 4 q .. of position r: requantise, [ADD], one dword store per tile.
+// Per-channel constants are staged in LDS once per workgroup.
+template <bool ADD, int NCT, int KS>  // NCT > 0: the tile / k-step counts are compile-time constants and the weight fragments live in registers
+__global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos, int lds_w16) {
+    constexpr bool AREG = NCT > 0;
+    extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+    v4i* cst = reinterpret_cast<v4i*>(lds_raw);  // [Cout / 4][bias, multiplier, shift]
+    __shared__ int add_lut[2][256];
+    const int tid = threadIdx.x;
+    const int K = a.Cin, N = a.Cout;
+    const bool rq = a.rq_right != 0;
+    for (int i = tid; i < N / 4; i += 256) {
+        cst[3 * i + 0] = *reinterpret_cast<const v4i*>(a.pw_b + 4 * i);
+        cst[3 * i + 1] = *reinterpret_cast<const v4i*>(a.pw_mult + 4 * i);
+        cst[3 * i + 2] = *reinterpret_cast<const v4i*>(a.pw_shift + 4 * i);
+    }
+    if (ADD) {
+        const int v = (int)(int8_t)tid;
+        add_lut[0][tid] = mbqm((v - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);
+        add_lut[1][tid] = mbqm((v - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);
+    }
+    // layers with more fragments than registers: the whole weight matrix (fragment order, up to 48 KB) is staged in LDS once per
+    // workgroup when the launcher made room for it — a 16-byte LDS read per tile and k-step instead of a trip to L1 / L2
+    v4i* wl = cst + 3 * (N / 4);
+    const bool w_in_lds = !AREG && lds_w16 > 0;
+    if (w_in_lds)
+        for (int i = tid; i < lds_w16; i += 256) wl[i] = reinterpret_cast<const v4i*>(a.pw_w)[i];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x), 0, (int)(n_pos * K), 0x00020000);
+    const int ksteps = AREG ? KS : (K + 63) >> 6, n_ct = AREG ? NCT : N >> 4;
+    const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);  // [Kp/64][N/16][64 lanes] x 16 bytes
+    // a wave walks over groups of 16 positions (the constants above are staged once per workgroup, not once per 64 positions); the
+    // activations of the next group are requested before the current one is multiplied
+    const long n_groups = n_pos / 16, stride = (long)gridDim.x * 4;
+    auto fetch = [&](long grp, v4i (&dst)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int koff = 64 * s + 16 * q;
+            dst[s] = (v4i){0, 0, 0, 0};
+            if (grp < n_groups && s < ksteps && koff < K)
+                dst[s] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((grp * 16 + r) * K) + koff, 0, 0));
+        }
+    };
+    long grp = (long)blockIdx.x * 4 + wave;
+    v4i bfr[4], bnx[4];
+    fetch(grp, bfr);
+    // AREG (at most six weight fragments: the wide early layers, 24 -> 48, 48 -> 96, 96 -> 48): the A operands live in registers for the
+    // whole walk — the counters showed the waves 61 % of their time waiting on memory with a fragment fetch in front of every tile
+    v4i areg[AREG ? NCT * KS : 1];
+    if constexpr (AREG) {
+        const int cpl0 = N >> 2;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const int ch = cpl0 * (r >> 2) + (r & 3) + 4 * ct;
+                areg[ct * KS + s_] = wp[((size_t)s_ * NCT + (ch >> 4)) * 64 + q * 16 + (ch & 15)];
+            }
+    }
+    for (; grp < n_groups; grp += stride) {
+    fetch(grp + stride, bnx);
+    const long pos = grp * 16 + r;
+    // Tile ct computes the channels (N / 4) (i >> 2) + 4 ct + (i & 3) in its rows i (the A fragment of row i is fetched from wherever
+    // the packer put that channel), so lane (r, q) ends up with the N / 4 CONSECUTIVE channels (N / 4) q .. of its position: the four
+    // lanes of a position write one contiguous run of N bytes, in 16-byte pieces where the tile count allows.
+    const int cpl = N >> 2;                         // channels per lane
+    int8_t* yrow = a.y + pos * N + cpl * q;
+    const int8_t* rrow = ADD ? a.res + pos * N + cpl * q : nullptr;
+    const int ch_r = cpl * (r >> 2) + (r & 3);      // + 4 ct: the channel of this lane's A row
+    for (int ct0 = 0; ct0 < n_ct; ct0 += 4) {
+        int outw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ct = ct0 + u;
+            outw[u] = 0;
+            if (ct >= n_ct) break;
+            const int ch = ch_r + 4 * ct;
+            const int cidx = ((cpl * q) >> 2) + ct;  // constants of the lane's four channels (N / 4) q + 4 ct ..
+            v4i acc = cst[cidx * 3 + 0];
+            if constexpr (AREG) {
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[ct * KS + s_], bfr[s_], acc, 0, 0, 0);
+            } else {
+                const v4i* wsrc = w_in_lds ? wl : wp;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < ksteps) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wsrc[((size_t)s * n_ct + (ch >> 4)) * 64 + q * 16 + (ch & 15)], bfr[s], acc, 0, 0, 0);
+            }
+            const v4i m = cst[cidx * 3 + 1], sh = cst[cidx * 3 + 2];
+            int rv = 0;
+            if (ADD) rv = *reinterpret_cast<const int*>(rrow + 4 * ct);
+            int packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int qv = clampi(mbqm_u(acc[e], m[e], sh[e], rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                if (ADD) {
+                    const int sa = add_lut[0][(rv >> (8 * e)) & 0xff];
+                    const int sb = add_lut[1][qv & 0xff];
+                    qv = clampi(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);
+                }
+                packed |= (qv & 0xff) << (8 * e);
+            }
+            outw[u] = packed;
+            if constexpr (AREG) asm volatile("" : "+v"(outw[u]) :: "memory");  // one tile at a time: the unrolled tiles must not all be in flight (288 registers)
+        }
+        const int left = n_ct - ct0;
+        if (left >= 4 && (cpl & 15) == 0) {
+            *reinterpret_cast<v4i*>(yrow + 4 * ct0) = (v4i){outw[0], outw[1], outw[2], outw[3]};
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < left) *reinterpret_cast<int*>(yrow + 4 * (ct0 + u)) = outw[u];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bfr[s] = bnx[s];
+    }
+}
+
+bool i8_pw_wave_supported(const DwPw8Args& a) {
+    const long n_pos = (long)a.B * a.OH * a.OW;
+    return g_opt.i8_strip && !a.has_dw && !a.transposed && !a.lut && !a.qx && a.sh == 1 && a.sw == 1 && a.H == a.OH && a.W == a.OW && a.Cin <= 256 &&
+           a.Cin % 4 == 0 && a.Cout % 16 == 0 && n_pos % 16 == 0 && n_pos * a.Cin < 0x7fff0000L;
+}
+
+void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {
+    const long n_pos = (long)a.B * a.OH * a.OW;
+    const long wanted = (n_pos / 16 + 3) / 4;
+    const long cap = (long)256 * ((a.Cout / 16) * ((a.Cin + 63) / 64) > 6 ? 6 : 16);  // persistent; fewer workgroups where each stages the weights
+    const unsigned blocks = (unsigned)(wanted < cap ? wanted : cap);
+    const int nct = a.Cout / 16, ks = (a.Cin + 63) / 64;
+    const size_t smem = (size_t)a.Cout * 12;
+    size_t w_bytes = (size_t)ks * 64 * a.Cout;  // the fragment-ordered weight matrix
+    if (w_bytes > 48 * 1024) w_bytes = 0;
+#define BN_PWW(ADDV, NCTV, KSV) hipLaunchKernelGGL((i8_pw_wave_kernel<ADDV, NCTV, KSV>), dim3(blocks), dim3(256), smem + (NCTV ? 0 : w_bytes), s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16))
+#define BN_PWW2(NCTV, KSV)                    \
+    if (nct == NCTV && ks == KSV) {           \
+        if (a.add.enabled) BN_PWW(true, NCTV, KSV); \
+        else BN_PWW(false, NCTV, KSV);        \
+        return;                               \
+    }
+    BN_PWW2(3, 1)
+    BN_PWW2(6, 1)
+    BN_PWW2(3, 2)
+    BN_PWW2(2, 1)
+    BN_PWW2(4, 1)
+#undef BN_PWW2
+    if (a.add.enabled) BN_PWW(true, 0, 0);
+    else BN_PWW(false, 0, 0);
+#undef BN_PWW
+}
+
 template <int RG, int CT>
 void launch_cfg8(const DwPw8Args& a, hipStream_t s) {
     const int tiles = (a.OH / a.TH) * (a.OW / a.TW) * ((a.B + a.NB - 1) / a.NB);
@@ -652,6 +810,7 @@ void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
             hipLaunchKernelGGL(i8_mel_mfma_kernel<false>, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);
         return;
     }
+    if (i8_pw_wave_supported(a)) return launch_i8_pw_wave(a, s);
     const int ct_total = a.Cout / 16;
     static const int kSlices[] = {16, 12, 8, 6, 4, 3, 2, 1};
     int slice = 1;
