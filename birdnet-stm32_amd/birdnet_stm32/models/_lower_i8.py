@@ -799,7 +799,28 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
             _expect(False, f"operator #{op.index} {op.name} in the backbone")
     if fuse and not keep_all:
         _add_tail_op(pb, plan, tail_blocks, tail_head)
+        _tag_scale_pairs(pb)
     return pb.finalize(reuse=not keep_all)
+
+
+def _tag_scale_pairs(pb: pk.PlanBuilder) -> None:
+    """Squeeze-excite MUL followed by the projection 1x1 convolution (reference models/blocks.py:27-46,104-118): when that
+    convolution is the only reader of the scaled map the pair is tagged, and the library applies the gate while the convolution
+    loads its input (``i8_pw_wave_kernel``) instead of writing the scaled map out and reading it back."""
+    ops = pb.plan.ops
+    for i in range(len(ops) - 1):
+        a, b = ops[i], ops[i + 1]
+        if a.kind != pk.I8_SCALE or b.kind != pk.I8_DWPW or b.p[29] or b.p[30] or b.p[34] or b.p[36] or b.in0 != a.out:
+            continue
+        if b.p[2] != a.p[1] or b.p[0] * b.p[1] != a.p[0] or b.p[2] > 256 or (b.p[3], b.p[4]) != (1, 1):
+            continue
+        readers = [k for k, o in enumerate(ops) if k != i + 1 and a.out in (o.in0, o.in1)]
+        if readers or b.in1 == a.out:
+            continue
+        a.p[pk.TAIL_TAG] = pk.SCALE_HEAD
+        b.p[pk.TAIL_TAG] = pk.SCALE_COVERED
+        pb._extra_uses.append((i + 1, a.in0))  # the fused kernel reads the unscaled map and the gate while it writes the convolution's output
+        pb._extra_uses.append((i + 1, a.in1))
 
 
 def _add_tail_op(pb, plan, blocks: list[dict], head: dict) -> None:

@@ -34,6 +34,7 @@ TAIL_TAG = 38  # OpRec.p[TAIL_TAG] = TAIL_COVERED: the operator is covered by th
 TAIL_COVERED, TAIL_OP = 0x7A110001, 0x7A110002  # (bn_blob.h; values no other use of p[38] can take)
 FRONT2_HEAD, FRONT2_COVERED = 0x7A110003, 0x7A110004  # front block + the residual block FRONT2_DIST operators further on may run as one kernel
 FRONT2_DIST = 37
+SCALE_HEAD, SCALE_COVERED = 0x7A110005, 0x7A110006  # an I8_SCALE operator and the plain 1x1 convolution right behind it, its only reader: may run as one kernel
 
 KIND_NAMES = {
     F32_MEL: "f32_mel", F32_MAG: "f32_mag", F32_RAWFE: "f32_rawfe", F32_STEM: "f32_stem", F32_DW: "f32_dw",

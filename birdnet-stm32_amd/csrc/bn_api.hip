@@ -195,11 +195,35 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         a.has_dw = q[15]; a.TH = q[16]; a.TW = q[17]; a.NB = q[18];
         return a;
     };
+    size_t scale_done = (size_t)-1;  // 1x1 convolution that already ran with the squeeze-excite MUL in front of it applied on load
+    auto dwpw8_args = [&](const OpRec& d, size_t di) {
+        bn::DwPw8Args a{};
+        const int* q = d.p;
+        a.x = (const int8_t*)slot_ptr(d.in0);
+        a.res = q[18] ? (const int8_t*)slot_ptr(d.in1) : nullptr;
+        a.y = (int8_t*)slot_ptr(d.out);
+        a.dw_w = (const int8_t*)m->tensor(d.t[0]);
+        a.dw_b = (const int32_t*)m->tensor(d.t[1]);
+        a.dw_mult = (const int32_t*)m->tensor(d.t[2]);
+        a.dw_shift = (const int32_t*)m->tensor(d.t[3]);
+        a.pw_w = (const int8_t*)m->tensor(d.t[4]);
+        a.pw_b = (const int32_t*)m->tensor(d.t[5]);
+        a.pw_mult = (const int32_t*)m->tensor(d.t[6]);
+        a.pw_shift = (const int32_t*)m->tensor(d.t[7]);
+        a.lut = q[34] ? (const int8_t*)m->tensor(d.t[8]) : nullptr;
+        a.B = B; a.H = q[0]; a.W = q[1]; a.Cin = q[2]; a.sh = q[3]; a.sw = q[4]; a.OH = q[6]; a.OW = q[7];
+        a.pt = q[8]; a.pl = q[9]; a.dw_zp_in = q[10]; a.dw_zp_out = q[11]; a.dw_amin = q[12]; a.dw_amax = q[13];
+        a.Cout = q[14]; a.pw_zp_out = q[15]; a.pw_amin = q[16]; a.pw_amax = q[17];
+        a.add = bn::I8AddParams{q[18], q[19], q[20], q[21], q[22], q[23], q[24], q[25], q[26], q[27], q[28]};
+        a.has_dw = q[29]; a.transposed = q[30]; a.TH = q[31]; a.TW = q[32]; a.NB = q[33];
+        a.rq_right = m->rq_right[di];
+        return a;
+    };
     for (size_t oi = op_begin; oi < op_end; ++oi) {
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
-        if (oi == front2_done) continue;  // ran inside the front kernel
+        if (oi == front2_done || oi == scale_done) continue;  // ran inside the preceding operator's kernel
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
@@ -336,25 +360,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 break;
             }
             case BN_OP_I8_DWPW: {
-                bn::DwPw8Args a{};
-                a.x = (const int8_t*)in0;
-                a.res = p[18] ? (const int8_t*)in1 : nullptr;
-                a.y = (int8_t*)out;
-                a.dw_w = (const int8_t*)m->tensor(o.t[0]);
-                a.dw_b = (const int32_t*)m->tensor(o.t[1]);
-                a.dw_mult = (const int32_t*)m->tensor(o.t[2]);
-                a.dw_shift = (const int32_t*)m->tensor(o.t[3]);
-                a.pw_w = (const int8_t*)m->tensor(o.t[4]);
-                a.pw_b = (const int32_t*)m->tensor(o.t[5]);
-                a.pw_mult = (const int32_t*)m->tensor(o.t[6]);
-                a.pw_shift = (const int32_t*)m->tensor(o.t[7]);
-                a.lut = p[34] ? (const int8_t*)m->tensor(o.t[8]) : nullptr;
-                a.B = B; a.H = p[0]; a.W = p[1]; a.Cin = p[2]; a.sh = p[3]; a.sw = p[4]; a.OH = p[6]; a.OW = p[7];
-                a.pt = p[8]; a.pl = p[9]; a.dw_zp_in = p[10]; a.dw_zp_out = p[11]; a.dw_amin = p[12]; a.dw_amax = p[13];
-                a.Cout = p[14]; a.pw_zp_out = p[15]; a.pw_amin = p[16]; a.pw_amax = p[17];
-                a.add = bn::I8AddParams{p[18], p[19], p[20], p[21], p[22], p[23], p[24], p[25], p[26], p[27], p[28]};
-                a.has_dw = p[29]; a.transposed = p[30]; a.TH = p[31]; a.TW = p[32]; a.NB = p[33];
-                a.rq_right = m->rq_right[oi];
+                bn::DwPw8Args a = dwpw8_args(o, oi);
                 if (a.transposed && p[36]) {  // QUANTIZE fused into the mel mixer: the input slot holds the float32 spectrogram
                     a.qx = (const float*)in0;
                     a.qminmax = mm;
@@ -425,6 +431,22 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                  p[5] ? (const int8_t*)m->tensor(o.t[4]) : nullptr, s);
                 break;
             case BN_OP_I8_SCALE:
+                if (p[BN_OP_TAIL_TAG] == BN_SCALE_HEAD && bn::g_opt.i8_strip && oi + 1 < op_end) {
+                    // the projection convolution behind the gate applies it while loading (the scaled map is never written)
+                    const OpRec& d = m->ops[oi + 1];
+                    if (d.kind == BN_OP_I8_DWPW && d.p[BN_OP_TAIL_TAG] == BN_SCALE_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.in1 &&
+                        d.p[2] == p[1] && d.p[6] * d.p[7] == p[0]) {
+                        bn::DwPw8Args a2 = dwpw8_args(d, oi + 1);
+                        a2.x = (const int8_t*)in0;
+                        a2.gate = (const int8_t*)in1;
+                        a2.g_zx = p[2]; a2.g_zg = p[3]; a2.g_mult = p[4]; a2.g_shift = p[5]; a2.g_zo = p[6]; a2.g_amin = p[7]; a2.g_amax = p[8];
+                        if (!a2.has_dw && !a2.transposed && bn::i8_pw_wave_takes(a2)) {
+                            bn::launch_i8_dwpw(a2, s);
+                            scale_done = oi + 1;
+                            break;
+                        }
+                    }
+                }
                 bn::launch_i8_scale((const int8_t*)in0, (const int8_t*)in1, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], s);
                 break;
             case BN_OP_I8_MAXNORM:

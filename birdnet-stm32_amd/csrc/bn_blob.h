@@ -68,6 +68,10 @@ struct TensorRec {
 #define BN_FRONT2_HEAD 0x7A110003
 #define BN_FRONT2_COVERED 0x7A110004
 #define BN_OP_FRONT2_DIST 37
+// BN_SCALE_HEAD on a BN_OP_I8_SCALE operator: the next operator (tagged BN_SCALE_COVERED) is a plain 1x1 convolution that is the only
+// reader of the scaled map; the library may apply the gate while that convolution loads its input (i8_pw_wave_kernel) and skip the MUL.
+#define BN_SCALE_HEAD 0x7A110005
+#define BN_SCALE_COVERED 0x7A110006
 
 #define BN_OP_NP 40
 #define BN_OP_NT 16

@@ -671,9 +671,34 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
                 areg[ct * KS + s_] = wp[((size_t)s_ * NCT + (ch >> 4)) * 64 + q * 16 + (ch & 15)];
             }
     }
+    const int P = a.OH * a.OW;
     for (; grp < n_groups; grp += stride) {
     fetch(grp + stride, bnx);
     const long pos = grp * 16 + r;
+    if (a.gate) {
+        // squeeze-excite MUL on the way in: the 16 bytes of every k-step times the chunk's gate bytes, requantised exactly as
+        // i8_scale_kernel does (the scaled map is never written); a group of 16 positions lies inside one chunk (P % 16 == 0)
+        const int8_t* gb = a.gate + (grp * 16 / P) * K;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int koff = 64 * s + 16 * q;
+            if (s < ksteps && koff < K) {
+                const v4i gv = *reinterpret_cast<const v4i*>(gb + koff);
+                v4i o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    int packed = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int xv = (int)(int8_t)(bfr[s][d] >> (8 * e)) - a.g_zx, g = (int)(int8_t)(gv[d] >> (8 * e)) - a.g_zg;
+                        packed |= (clampi(mbqm(xv * g, a.g_mult, a.g_shift) + a.g_zo, a.g_amin, a.g_amax) & 0xff) << (8 * e);
+                    }
+                    o[d] = packed;
+                }
+                bfr[s] = o;
+            }
+        }
+    }
     // Tile ct computes the channels (N / 4) (i >> 2) + 4 ct + (i & 3) in its rows i (the A fragment of row i is fetched from wherever
     // the packer put that channel), so lane (r, q) ends up with the N / 4 CONSECUTIVE channels (N / 4) q .. of its position: the four
     // lanes of a position write one contiguous run of N bytes, in 16-byte pieces where the tile count allows.
@@ -733,6 +758,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
 
 bool i8_pw_wave_supported(const DwPw8Args& a) {
     const long n_pos = (long)a.B * a.OH * a.OW;
+    if (a.gate && (a.Cin % 16 || ((long)a.OH * a.OW) % 16)) return false;  // gate rows are read 16 bytes at a time, a group stays inside a chunk
     return g_opt.i8_strip && !a.has_dw && !a.transposed && !a.lut && !a.qx && a.sh == 1 && a.sw == 1 && a.H == a.OH && a.W == a.OW && a.Cin <= 256 &&
            a.Cin % 4 == 0 && a.Cout % 16 == 0 && n_pos % 16 == 0 && n_pos * a.Cin < 0x7fff0000L;
 }
@@ -801,6 +827,8 @@ bool i8_mel_mfma_supported(const DwPw8Args& a) {
 
 bool i8_dwpw_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 16 == 0 && Cin >= 4; }
 
+bool i8_pw_wave_takes(const DwPw8Args& a) { return i8_pw_wave_supported(a); }
+
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
     const bool mel_kernel = !g_opt.i8_mel_generic;
     if (a.qx || (mel_kernel && i8_mel_mfma_supported(a))) {  // (the packer only fuses QUANTIZE for shapes this kernel takes)
@@ -811,6 +839,7 @@ void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
         return;
     }
     if (i8_pw_wave_supported(a)) return launch_i8_pw_wave(a, s);
+    // (a gate is only ever set by the caller after i8_pw_wave_takes() said yes)
     const int ct_total = a.Cout / 16;
     static const int kSlices[] = {16, 12, 8, 6, 4, 3, 2, 1};
     int slice = 1;

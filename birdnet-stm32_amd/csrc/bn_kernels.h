@@ -208,9 +208,12 @@ struct DwPw8Args {
     const float* qminmax;  // [B][2] per-chunk min / max for the (S - min) / (max - min + 1e-10) normalisation, or null
     float qscale;
     int qzp, qfill, qF;
-    int qtiled;            // the spectrogram is tile-major [W/16][qF][16] (written by launch_stft512(..., tile_major))
+    int qtiled;            // the spectrogram is tile-major [W/16][qF][16] (written by launch_stft512(..., tile_major))    // plain 1x1 convolution behind a squeeze-excite MUL (i8_pw_wave_kernel only): x is the UNSCALED map, the gate is applied on load
+    const int8_t* gate;    // [B][Cin] or null
+    int g_zx, g_zg, g_mult, g_shift, g_zo, g_amin, g_amax;
 };
 bool i8_dwpw_supported(int Cin, int Cout);
+bool i8_pw_wave_takes(const DwPw8Args& a);  // the wave-level 1x1 convolution kernel (the only one that applies DwPw8Args::gate) runs this operator
 bool i8_mel_mfma_supported(const DwPw8Args& a);
 // Wave-autonomous strip kernel for the same block at Cin, Cout in {32, 64} (bn_i8_strip.hip); `cst` is the constant block
 // the packer prepares (models/_lower_i8.py: strip_constants).  With the ADD the residual must be the block input x.

@@ -296,6 +296,24 @@ def test_int8_div_and_reduce_max_restatements():
         assert np.abs(tab - real).max() <= 1 and (tab != real).mean() < 0.02
 
 
+def test_squeeze_excite_scale_is_paired_with_its_projection():
+    """Production plans of exported squeeze-excite graphs tag every MUL whose only reader is the plain 1x1 projection behind it
+    (the library then applies the gate while that convolution loads its input); the pair never shares a slot with the unscaled
+    map or the gate it still reads, and debug plans carry no tags."""
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models._lower_i8 import lower_i8
+
+    _, model, _, _ = _export(EXPORT_TOPOLOGIES["ir_se_softmax"])
+    plan = lower_i8(model)
+    heads = [i for i, o in enumerate(plan.ops) if o.kind == pk.I8_SCALE and o.p[pk.TAIL_TAG] == pk.SCALE_HEAD]
+    assert len(heads) >= 8 and len(heads) == sum(o.kind == pk.I8_SCALE and o.p[1] <= 256 for o in plan.ops)  # (the kernel takes up to 256 input channels)
+    for i in heads:
+        a, b = plan.ops[i], plan.ops[i + 1]
+        assert b.kind == pk.I8_DWPW and b.p[pk.TAIL_TAG] == pk.SCALE_COVERED and b.p[29] == 0 and b.in0 == a.out
+        assert b.out not in (a.in0, a.in1) and b.p[2] == a.p[1] and b.p[2] % 16 == 0
+    assert not [o for o in lower_i8(model, keep_all=True).ops if o.p[pk.TAIL_TAG] in (pk.SCALE_HEAD, pk.SCALE_COVERED)]
+
+
 def test_exporter_refuses_what_it_cannot_express():
     from birdnet_stm32.conversion.export import netspec_to_graph
     from birdnet_stm32.models import build_model
