@@ -256,10 +256,17 @@ __global__ __launch_bounds__(256) void i8_mean_kernel(const int8_t* __restrict__
     int acc[4] = {0, 0, 0, 0};
     if (sl < slices) {
         const int32_t* row = reinterpret_cast<const int32_t*>(x + (size_t)b * P * C) + q;
-        for (int i = sl; i < P; i += slices) {
-            const int32_t v = row[(size_t)i * cq];
+        for (int i0 = sl; i0 < P; i0 += 8 * slices) {  // eight loads in flight per thread: one workgroup per chunk has to cover the latency itself
+            int32_t v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += (int32_t)(int8_t)(v >> (8 * e));
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * slices;
+                v[u] = i < P ? row[(size_t)i * cq] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += (int32_t)(int8_t)(v[u] >> (8 * e));
         }
     }
 #pragma unroll
