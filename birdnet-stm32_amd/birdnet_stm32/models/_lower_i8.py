@@ -800,7 +800,26 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     if fuse and not keep_all:
         _add_tail_op(pb, plan, tail_blocks, tail_head)
         _tag_scale_pairs(pb)
+        _tag_se_gates(pb)
     return pb.finalize(reuse=not keep_all)
+
+
+def _tag_se_gates(pb: pk.PlanBuilder) -> None:
+    """MEAN -> FULLY_CONNECTED (ReLU) -> FULLY_CONNECTED (+ LOGISTIC table): the gate of a squeeze-excite block (reference
+    models/blocks.py:27-46).  When each of the three feeds only the next, the library runs them as one kernel per chunk."""
+    ops = pb.plan.ops
+    for i in range(len(ops) - 2):
+        a, f1, f2 = ops[i], ops[i + 1], ops[i + 2]
+        if a.kind != pk.I8_MEAN or f1.kind != pk.I8_FC or f2.kind != pk.I8_FC or f1.in0 != a.out or f2.in0 != f1.out:
+            continue
+        if f1.p[0] != a.p[1] or f2.p[0] != f1.p[1] or f1.p[1] > 256 or a.p[1] > 1024 or a.p[1] % 4:
+            continue
+        others = [k for k, o in enumerate(ops) if (k != i + 1 and a.out in (o.in0, o.in1)) or (k != i + 2 and f1.out in (o.in0, o.in1))]
+        if others or a.out < 0 or f1.out < 0 or f2.out < 0:
+            continue
+        a.p[pk.TAIL_TAG] = pk.SEGATE_HEAD
+        f1.p[pk.TAIL_TAG] = f2.p[pk.TAIL_TAG] = pk.SEGATE_COVERED
+        pb._extra_uses.append((i + 2, a.in0))  # the pooled map is read while the gate is written
 
 
 def _tag_scale_pairs(pb: pk.PlanBuilder) -> None:

@@ -195,6 +195,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         a.has_dw = q[15]; a.TH = q[16]; a.TW = q[17]; a.NB = q[18];
         return a;
     };
+    size_t segate_done[2] = {(size_t)-1, (size_t)-1};  // the two dense layers of a squeeze-excite gate that ran inside the pooling kernel
     size_t scale_done = (size_t)-1;  // 1x1 convolution that already ran with the squeeze-excite MUL in front of it applied on load
     auto dwpw8_args = [&](const OpRec& d, size_t di) {
         bn::DwPw8Args a{};
@@ -223,7 +224,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
-        if (oi == front2_done || oi == scale_done) continue;  // ran inside the preceding operator's kernel
+        if (oi == front2_done || oi == scale_done || oi == segate_done[0] || oi == segate_done[1]) continue;  // ran inside a preceding operator's kernel
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
@@ -422,6 +423,21 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 break;
             }
             case BN_OP_I8_MEAN:
+                if (p[BN_OP_TAIL_TAG] == BN_SEGATE_HEAD && bn::g_opt.i8_strip && oi + 2 < op_end) {
+                    const OpRec& f1 = m->ops[oi + 1];
+                    const OpRec& f2 = m->ops[oi + 2];
+                    if (f1.kind == BN_OP_I8_FC && f2.kind == BN_OP_I8_FC && f1.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED && f2.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED &&
+                        f1.in0 == o.out && f2.in0 == f1.out && f1.p[0] == p[1] && f2.p[0] == f1.p[1] && f2.p[1] == p[1] && p[1] % 4 == 0 && f2.out != o.in0) {
+                        bn::launch_i8_segate((const int8_t*)in0, (int8_t*)slot_ptr(f2.out), B, p[0], p[1], p[2], p[3], p[4], p[5], f1.p[1], f1.p[2], f1.p[3], f1.p[4],
+                                             (const int8_t*)m->tensor(f1.t[0]), (const int32_t*)m->tensor(f1.t[1]), (const int32_t*)m->tensor(f1.t[2]),
+                                             (const int32_t*)m->tensor(f1.t[3]), f1.p[5] ? (const int8_t*)m->tensor(f1.t[4]) : nullptr, f2.p[2], f2.p[3], f2.p[4],
+                                             (const int8_t*)m->tensor(f2.t[0]), (const int32_t*)m->tensor(f2.t[1]), (const int32_t*)m->tensor(f2.t[2]),
+                                             (const int32_t*)m->tensor(f2.t[3]), f2.p[5] ? (const int8_t*)m->tensor(f2.t[4]) : nullptr, s);
+                        segate_done[0] = oi + 1;
+                        segate_done[1] = oi + 2;
+                        break;
+                    }
+                }
                 bn::launch_i8_mean((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], s);
                 break;
             case BN_OP_I8_FC:
@@ -1082,7 +1098,7 @@ int bn_get_option(const char* name, int* value) {
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }
 

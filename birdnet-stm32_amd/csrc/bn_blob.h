@@ -72,6 +72,10 @@ struct TensorRec {
 // reader of the scaled map; the library may apply the gate while that convolution loads its input (i8_pw_wave_kernel) and skip the MUL.
 #define BN_SCALE_HEAD 0x7A110005
 #define BN_SCALE_COVERED 0x7A110006
+// BN_SEGATE_HEAD on a BN_OP_I8_MEAN operator: the next two operators (tagged BN_SEGATE_COVERED) are the FULLY_CONNECTED layers of a
+// squeeze-excite gate, each the only reader of its predecessor: pooling and both layers may run as one kernel per chunk.
+#define BN_SEGATE_HEAD 0x7A110007
+#define BN_SEGATE_COVERED 0x7A110008
 
 #define BN_OP_NP 40
 #define BN_OP_NT 16

@@ -287,6 +287,84 @@ __global__ __launch_bounds__(256) void i8_mean_kernel(const int8_t* __restrict__
     }
 }
 
+// Squeeze-excite gate in one kernel per chunk: MEAN over the positions (as i8_mean_kernel) -> FULLY_CONNECTED C -> R (fused ReLU
+// clamp) -> FULLY_CONNECTED R -> C with the LOGISTIC table: three launches of ~10 us each (the two dense layers are a few
+// hundred multiply-adds) become one; the pooled vector and the hidden vector stay in LDS.
+struct SeGate8Args {
+    const int8_t* x; int8_t* y;   // [B][P][C] -> gate [B][C]
+    int P, C, zp_in, mean_mult, mean_shift, mean_zp;
+    int R, Kp1, zo1, amin1, amax1;
+    const int8_t* w1; const int32_t* b1; const int32_t* m1; const int32_t* s1; const int8_t* lut1;
+    int Kp2, zo2, amin2, amax2;
+    const int8_t* w2; const int32_t* b2; const int32_t* m2; const int32_t* s2; const int8_t* lut2;
+};
+
+__global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
+    __shared__ int part[256][4];
+    extern __shared__ int32_t se_vec[];  // pooled vector (Kp1 bytes) then hidden vector (Kp2 bytes), as dwords
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int C = a.C, P = a.P, cq = C >> 2;
+    int8_t* pooled = reinterpret_cast<int8_t*>(se_vec);
+    int8_t* hidden = pooled + a.Kp1;
+    for (int i = tid; i < (a.Kp1 + a.Kp2) / 4; i += 256) se_vec[i] = 0;
+    __syncthreads();
+    const int32_t* row0 = reinterpret_cast<const int32_t*>(a.x + (size_t)b * P * C);
+    for (int q0 = 0; q0 < cq; q0 += 256) {  // channel quads beyond 256 go round again
+        const int nq = cq - q0 < 256 ? cq - q0 : 256;
+        const int slices = 256 / nq;
+        const int q = tid % nq, sl = tid / nq;
+        int acc[4] = {0, 0, 0, 0};
+        if (sl < slices) {
+            const int32_t* row = row0 + q0 + q;
+            for (int i0 = sl; i0 < P; i0 += 8 * slices) {
+                int32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * slices;
+                    v[u] = i < P ? row[(size_t)i * cq] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += (int32_t)(int8_t)(v[u] >> (8 * e));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[tid][e] = acc[e];
+        __syncthreads();
+        if (tid < nq) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int s4 = 0;
+                for (int k = 0; k < slices; ++k) s4 += part[k * nq + tid][e];
+                const int32_t qv = clampi(mbqm(s4 - a.zp_in * P, a.mean_mult, a.mean_shift) + a.mean_zp, -128, 127);
+                packed |= ((uint32_t)(uint8_t)(int8_t)qv) << (8 * e);
+            }
+            se_vec[q0 + tid] = (int32_t)packed;
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < a.R; n += 256) {
+        const int32_t* wr = reinterpret_cast<const int32_t*>(a.w1 + (size_t)n * a.Kp1);
+        int32_t acc = a.b1[n];
+        for (int k = 0; k < a.Kp1 / 4; ++k) acc = dot4(se_vec[k], wr[k], acc);
+        int32_t qv = clampi(mbqm(acc, a.m1[n], a.s1[n]) + a.zo1, a.amin1, a.amax1);
+        if (a.lut1) qv = a.lut1[qv + 128];
+        hidden[n] = (int8_t)qv;
+    }
+    __syncthreads();
+    const int32_t* hv = se_vec + a.Kp1 / 4;
+    for (int n = tid; n < C; n += 256) {
+        const int32_t* wr = reinterpret_cast<const int32_t*>(a.w2 + (size_t)n * a.Kp2);
+        int32_t acc = a.b2[n];
+        for (int k = 0; k < a.Kp2 / 4; ++k) acc = dot4(hv[k], wr[k], acc);
+        int32_t qv = clampi(mbqm(acc, a.m2[n], a.s2[n]) + a.zo2, a.amin2, a.amax2);
+        if (a.lut2) qv = a.lut2[qv + 128];
+        a.y[(size_t)b * C + n] = (int8_t)qv;
+    }
+}
+
 // FULLY_CONNECTED: a workgroup takes kFcChunks chunks, so a weight row is fetched once per kFcChunks chunks (the 25.6 KB matrix
 // was read from L2 once per chunk: 0.048 -> 0.02 ms per 4096 chunks); the activations of the chunks sit in LDS.
 constexpr int kFcChunks = 8;
@@ -476,6 +554,14 @@ void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_o
     const int Kp = (Cin + 3) & ~3;
     hipLaunchKernelGGL(i8_fc_kernel, dim3((B + kFcChunks - 1) / kFcChunks), dim3(128), (size_t)kFcChunks * Kp, s, x, y, B, Cin, Kp, Cout, zp_out,
                        amin, amax, w, bias, mult, shift, lut);
+}
+
+void launch_i8_segate(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, int mean_mult, int mean_shift, int mean_zp, int R, int zo1, int amin1,
+                      int amax1, const int8_t* w1, const int32_t* b1, const int32_t* m1, const int32_t* s1, const int8_t* lut1, int zo2, int amin2,
+                      int amax2, const int8_t* w2, const int32_t* b2, const int32_t* m2, const int32_t* s2, const int8_t* lut2, hipStream_t s) {
+    const int Kp1 = (C + 3) & ~3, Kp2 = (R + 3) & ~3;
+    SeGate8Args a{x, y, P, C, zp_in, mean_mult, mean_shift, mean_zp, R, Kp1, zo1, amin1, amax1, w1, b1, m1, s1, lut1, Kp2, zo2, amin2, amax2, w2, b2, m2, s2, lut2};
+    hipLaunchKernelGGL(i8_segate_kernel, dim3(B), dim3(256), (size_t)(Kp1 + Kp2), s, a);
 }
 
 void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int P, int C, int zx, int zg, int mult, int shift, int zo,

@@ -173,6 +173,10 @@ void launch_i8_mean(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, 
 // w: [Cout][Cin rounded up to a multiple of 4], zero padded; lut: optional int8 table applied to the result (LOGISTIC behind the layer)
 void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_out, int amin, int amax, const int8_t* w,
                   const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut, hipStream_t s);
+// MEAN -> FULLY_CONNECTED -> FULLY_CONNECTED (optional tables behind each) of a squeeze-excite gate as one kernel per chunk (C % 4 == 0)
+void launch_i8_segate(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, int mean_mult, int mean_shift, int mean_zp, int R, int zo1, int amin1,
+                      int amax1, const int8_t* w1, const int32_t* b1, const int32_t* m1, const int32_t* s1, const int8_t* lut1, int zo2, int amin2,
+                      int amax2, const int8_t* w2, const int32_t* b2, const int32_t* m2, const int32_t* s2, const int8_t* lut2, hipStream_t s);
 void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int P, int C, int zx, int zg, int mult, int shift, int zo,
                      int amin, int amax, hipStream_t s);
 // per-chunk max -> denominator byte -> DIV table row [-> per-channel table]: [C][W] int8 -> [C][W] int8 (W a multiple of 4)

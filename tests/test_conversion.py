@@ -311,7 +311,16 @@ def test_squeeze_excite_scale_is_paired_with_its_projection():
         a, b = plan.ops[i], plan.ops[i + 1]
         assert b.kind == pk.I8_DWPW and b.p[pk.TAIL_TAG] == pk.SCALE_COVERED and b.p[29] == 0 and b.in0 == a.out
         assert b.out not in (a.in0, a.in1) and b.p[2] == a.p[1] and b.p[2] % 16 == 0
-    assert not [o for o in lower_i8(model, keep_all=True).ops if o.p[pk.TAIL_TAG] in (pk.SCALE_HEAD, pk.SCALE_COVERED)]
+    # ... and the gate itself (MEAN -> FULLY_CONNECTED -> FULLY_CONNECTED + LOGISTIC table) is tagged to run as one kernel per chunk
+    gates = [i for i, o in enumerate(plan.ops) if o.kind == pk.I8_MEAN and o.p[pk.TAIL_TAG] == pk.SEGATE_HEAD]
+    assert len(gates) == sum(o.kind == pk.I8_SCALE for o in plan.ops)
+    for i in gates:
+        m_, f1, f2 = plan.ops[i : i + 3]
+        assert f1.kind == f2.kind == pk.I8_FC and f1.p[pk.TAIL_TAG] == f2.p[pk.TAIL_TAG] == pk.SEGATE_COVERED
+        assert f1.in0 == m_.out and f2.in0 == f1.out and f2.p[1] == m_.p[1] and f2.p[5] == 1 and f2.out != m_.in0
+    assert plan.ops[-3].kind == pk.I8_MEAN and plan.ops[-3].p[pk.TAIL_TAG] != pk.SEGATE_HEAD  # the classifier's pooling is not a gate
+    assert not [o for o in lower_i8(model, keep_all=True).ops
+                if o.p[pk.TAIL_TAG] in (pk.SCALE_HEAD, pk.SCALE_COVERED, pk.SEGATE_HEAD, pk.SEGATE_COVERED)]
 
 
 def test_exporter_refuses_what_it_cannot_express():
