@@ -219,7 +219,8 @@ def _export(kw, n_cal=4, seed=0):
     norm = bool(args.pop("frontend_norm", False))
     spec = build_model("dscnn", **args)
     spec.frontend.attrs["norm"] = norm
-    x = np.stack([stft.hybrid_spectrogram(a) for a in synth_chunks(n_cal + 3, seed=seed + 3)])[..., None].astype(np.float32)
+    chunks = synth_chunks(n_cal + 3, sr=args["sample_rate"], seconds=args["chunk_duration"], seed=seed + 3)
+    x = np.stack([stft.hybrid_spectrogram(a, spec_width=args["spec_width"]) for a in chunks])[..., None].astype(np.float32)
     graph = convert_netspec_to_int8(spec, lambda: ([x[i : i + 1]] for i in range(n_cal)), frontend_norm=norm)
     raw = write_tflite(graph)
     return spec, parse_tflite(raw), raw, x
@@ -396,4 +397,45 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
     assert np.array_equal(prod.predict(x), got)
     for nb in (1, 3):
         assert np.array_equal(prod.predict(x[:nb]), got[:nb])
+    prod.close()
+
+
+ODD_GEOMETRIES = {
+    "mels32_w128_a0.75_2s": dict(num_mels=32, spec_width=128, alpha=0.75, chunk_duration=2),
+    "mels48_w192_a1.25": dict(num_mels=48, spec_width=192, alpha=1.25, use_se=True),
+    "mels64_w320_ds_se": dict(num_mels=64, spec_width=320, alpha=1.0, use_inverted_residual=False, use_se=True, class_activation="sigmoid"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ODD_GEOMETRIES))
+def test_exported_graphs_of_other_geometries_match_the_oracle_on_the_gpu(name):
+    """Spectrogram sizes and width multipliers other than the shipped ones (maps that are not multiples of the kernels' strip
+    widths, channel counts like 24 / 40 / 120): the production plan — row-streaming depthwise and stem kernels, the wave-level 1x1
+    convolution, the fused squeeze-excite gate and MUL — and the debug plan both reproduce the INT8 oracle."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from birdnet_stm32.models._lower_i8 import lower_i8
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle.int8_graph import Int8Interpreter
+
+    spec, model, _, x = _export(ODD_GEOMETRIES[name], n_cal=3)
+    ref, env = Int8Interpreter(model).invoke(x, return_all=True)
+    B = x.shape[0]
+    softmax = spec.layers[-1].attrs["activation"] == "softmax"
+    dbg = HipRunner(lower_i8(model, keep_all=True), max_batch=B)
+    got = dbg.predict(x)
+    for oi, op in enumerate(dbg.plan.ops):
+        if op.out < 0 or not op.name.startswith("t") or op.kind == 20:
+            continue
+        a = dbg.op_output(oi, B)
+        assert np.array_equal(a, env[int(op.name[1:])].reshape(a.shape)), f"{name}: tensor {op.name} (plan op {oi}, kind {op.kind})"
+    assert np.allclose(got, ref, atol=1e-6) if softmax else np.array_equal(got, ref)
+    dbg.close()
+    prod = HipRunner(lower_i8(model), max_batch=B)
+    for nb in (B, 1, 2):
+        p = prod.predict(x[:nb])
+        assert np.allclose(p, ref[:nb], atol=1e-6) if softmax else np.array_equal(p, ref[:nb])
     prod.close()
