@@ -50,8 +50,7 @@ const OptName kOptions[] = {
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
-    {"stft_tpw", &bn::Options::stft_tpw},         {"stft_sub", &bn::Options::stft_sub},
-    {"dual_stream", &bn::Options::dual_stream},
+    {"stft_tpw", &bn::Options::stft_tpw},
     {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
@@ -82,9 +81,6 @@ struct bn_ctx {
     bn::StftTables tables{};
     float* d_block_peaks = nullptr;  // bn_ingest_resample: per-workgroup maxima, grown on demand
     size_t block_peaks_elems = 0;
-    // second stream of bn_infer_audio's two-half pipeline (option dual_stream), created on first use
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_stft = nullptr, ev_join = nullptr;
 };
 
 struct bn_model {
@@ -100,7 +96,6 @@ struct bn_model {
     std::vector<bn::Tail8Args> tails;    // per operator: arguments of the fused tail kernel (BN_OP_I8_TAIL operators only)
     std::vector<uint8_t> tail_ok;        // per operator: BN_OP_I8_TAIL whose maps fit the kernel's LDS plan
     bool has_tail = false;               // the plan holds a usable fused tail operator
-    bool first_reads_input_only = false; // operator 0 is the only reader of BN_SLOT_INPUT (it can run per sub-batch behind the STFT)
     bool spec_tiled_ok = false;          // the plan's first operator reads the spectrogram through i8_mel_mfma_kernel<QIN>: bn_infer_audio
                                          // may hand it the tile-major layout the STFT writes fastest
     bool spec_tiled_now = false;         // set by bn_infer_audio around its bn_forward call
@@ -567,10 +562,6 @@ void bn_ctx_destroy(bn_ctx* c) {
     (void)hipFree(c->d_tw256);
     (void)hipFree(c->d_tw512);
     (void)hipFree(c->d_block_peaks);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_stft) (void)hipEventDestroy(c->ev_stft);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -638,11 +629,6 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             lo = t.offset < lo ? (size_t)t.offset : lo;
             hi = t.offset + t.nbytes > hi ? (size_t)(t.offset + t.nbytes) : hi;
         }
-    {
-        int readers = 0;
-        for (const OpRec& o : m->ops) readers += (o.in0 == BN_SLOT_INPUT) + (o.in1 == BN_SLOT_INPUT);
-        m->first_reads_input_only = readers == 1 && !m->ops.empty() && m->ops[0].in0 == BN_SLOT_INPUT && m->ops[0].p[BN_OP_PATH] != BN_PATH_AUDIO;
-    }
     // fused tail operators: build the kernel arguments and the LDS plan from the descriptor table
     m->tails.resize(h.n_ops);
     m->tail_ok.assign(h.n_ops, 0);
@@ -876,57 +862,19 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     const bool tiled = m->spec_tiled_ok && !bn::g_opt.stft_rowmajor;  // option stft_rowmajor: keep the reference layout (A/B)
     hipStream_t s = (hipStream_t)stream;
     const size_t in_stride = m->hdr.input_elems, C = m->hdr.num_classes;
-    // Sub-batches: the STFT of `sub` chunks is followed at once by the operator that consumes the spectrogram, so that its
-    // 263 KB per chunk are still in the 256 MB Infinity Cache when they are read back (option stft_sub; 0 = whole batch).
-    int sub = bn::g_opt.stft_sub > 0 ? bn::g_opt.stft_sub : B;
-    const bool first_only = sub < B && !m->ops.empty() && m->ops[0].in0 == BN_SLOT_INPUT && m->ops[0].out >= 0 && m->first_reads_input_only;
-    if (!first_only) sub = B;
+    // (Sub-batching the STFT -> first operator pair for the Infinity Cache and a two-stream skewed schedule were measured and removed:
+    // slower / no gain)
     m->spec_tiled_now = tiled;
     int rc = BN_OK;
-    // Two halves on two streams, the second one skewed by one STFT (option dual_stream): the STFT of half 1 (vector-ALU issue bound) runs
-    // beside the mel mixer / front block of half 0 (parked on memory most of their time), and so on down the plan.
-    if (bn::g_opt.dual_stream && B >= 512 && B <= kMaxGridBatch && !m->profiling) {
-        bn_ctx* c = m->ctx;
-        if (!c->aux) {
-            HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        }
-        const int h0 = (B / 2 + 3) & ~3, h1 = B - h0;
-        HIP_TRY(hipEventRecord(c->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-        rc = stft_mag_impl(c, d_audio, h0, T, kFft, hop, W, 0, m->d_spec, m->d_minmax, (void*)s, tiled);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(c->ev_stft, s));
-        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_stft, 0));
-        rc = stft_mag_impl(c, d_audio + (size_t)h0 * T, h1, T, kFft, hop, W, 0, m->d_spec + h0 * in_stride, m->d_minmax + 2 * (size_t)h0, (void*)c->aux, tiled);
-        if (rc) return rc;
-        rc = run_plan(m, m->d_spec, m->d_minmax, h0, d_scores, d_logits, s, nullptr, 0, 0, 0, (size_t)-1, 0);
-        if (rc) return rc;
-        rc = run_plan(m, m->d_spec + h0 * in_stride, m->d_minmax + 2 * (size_t)h0, h1, d_scores + h0 * C, d_logits ? d_logits + h0 * C : nullptr, c->aux,
-                      nullptr, 0, 0, 0, (size_t)-1, (size_t)h0);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(c->ev_join, c->aux));
-        HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-        m->spec_tiled_now = false;
-        return BN_OK;
-    }
-    for (int b0 = 0; b0 < B && rc == BN_OK; b0 += sub) {
-        const int nb = B - b0 < sub ? B - b0 : sub;
-        {
-            ProfScope prof(m, (int)m->ops.size(), s);
-            rc = stft_mag_impl(m->ctx, d_audio + (size_t)b0 * T, nb, T, kFft, hop, W, /*normalize=*/0, m->d_spec + b0 * in_stride,
-                               m->d_minmax + 2 * (size_t)b0, stream, tiled);
-        }
-        if (rc == BN_OK && first_only)
-            rc = run_plan(m, m->d_spec + b0 * in_stride, m->d_minmax + 2 * (size_t)b0, nb, d_scores, d_logits, s, nullptr, 0, 0, 0, 1, (size_t)b0);
+    {
+        ProfScope prof(m, (int)m->ops.size(), s);
+        rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, tiled);
     }
     if (rc == BN_OK) {
         for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
             const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
             rc = run_plan(m, m->d_spec + b0 * in_stride, m->d_minmax + 2 * (size_t)b0, nb, d_scores + b0 * C, d_logits ? d_logits + b0 * C : nullptr, s,
-                          nullptr, 0, 0, first_only ? 1 : 0, (size_t)-1, (size_t)b0);
+                          nullptr, 0, 0, 0, (size_t)-1, (size_t)b0);
             if (rc != BN_OK) break;
         }
     }

@@ -25,8 +25,6 @@ struct Options {
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
     int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
     int stft_tpw = 0;          // STFT tiles per workgroup (0: auto)
-    int stft_sub = 0;          // bn_infer_audio: chunks per STFT -> first-operator sub-batch (0: the whole batch at once)
-    int dual_stream = 0;       // bn_infer_audio: two half batches on two streams, the second skewed by one STFT
     int ingest_blk = 0;        // outputs per workgroup of the resampler (0: auto)
     int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
 };

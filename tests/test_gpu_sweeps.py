@@ -12,6 +12,7 @@ All comparisons go through the C ABI (ctypes -> libbirdnet_hip.so).
 """
 
 import ctypes
+import os
 
 import numpy as np
 import pytest
