@@ -346,14 +346,9 @@ void launch_minmax_init(float* minmax, int B, hipStream_t s) {
     hipLaunchKernelGGL(minmax_init_kernel, dim3((B + 255) / 256), dim3(256), 0, s, minmax, B);
 }
 
-// tiles a workgroup walks; one is fastest on MI355X (a loop that prefetches the next tile's samples needs > 170 VGPRs and
-// drops the kernel to 2 waves per SIMD; measured 0.27 ms against 0.20 ms per 1024 chunks)
-static int stft_tiles_per_wg(int B, int n_tiles) {
-    const int forced = g_opt.stft_tpw;
-    (void)B;
-    (void)n_tiles;
-    return forced > 0 ? forced : 1;
-}
+// One tile per workgroup: a loop that prefetches the next tile's samples needs > 170 VGPRs and drops the kernel to 2 waves per SIMD
+// (measured 0.27 ms against 0.20 ms per 1024 chunks); the kernel's last argument only carries the tile-major flag (-1) now.
+static int stft_tiles_per_wg(int, int) { return 1; }
 
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, float* minmax,
                     hipStream_t s, bool tile_major) {

@@ -396,3 +396,43 @@ def test_i8_dw_stream_kernel_matches_the_baseline_kernel(torch_mod):
         for nb in (1, 2, 7):
             assert np.array_equal(runner.predict(x[:nb]), want_scores[:nb])
         runner.close()
+
+
+# --------------------------------------------------------------------------------------- the remaining launcher options
+def test_every_other_launcher_option_reproduces_the_default_results(torch_mod):
+    """The A/B switches that no other test flips (older kernel variants kept for measurements): ``f32_front_staged``, ``front_tpw``,
+    ``wave_dwpw`` on the float32 plan (float32 round-off of each other: the FMA order differs), ``i8_mel_generic`` on
+    the INT8 plan and ``ingest_blk`` / ``ingest_generic`` on the ingest kernels (bit-identical)."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.audio import ingest
+    from birdnet_stm32.models.runners import load_model_runner
+
+    audio = torch.from_numpy(synth_chunks(130, seed=23)).cuda()
+    f32 = load_model_runner(KERAS_PATH, max_batch=130)
+    spec = f32.stft_device(audio)
+    want_a, want_s = f32.infer_audio_device(audio).clone(), f32.predict_device(spec.reshape(130, -1)).clone()
+    for opts in (dict(f32_front_staged=0), dict(f32_strip=0, front_tpw=1), dict(f32_strip=0, front_tpw=4), dict(f32_strip=0, wave_dwpw=0),
+                 dict(wave_dwpw=0)):
+        with _hip.options(**opts):
+            for nb in (130, 3):
+                assert float((f32.infer_audio_device(audio[:nb]) - want_a[:nb]).abs().max()) < 5e-6, opts
+                assert float((f32.predict_device(spec[:nb].reshape(nb, -1)) - want_s[:nb]).abs().max()) < 5e-6, opts
+    f32.close()
+    i8 = load_model_runner(TFLITE_PATH, max_batch=130)
+    want_a, want_s = i8.infer_audio_device(audio).clone(), i8.predict_device(spec.reshape(130, -1)).clone()
+    with _hip.options(i8_mel_generic=1):
+        for nb in (130, 3):
+            assert torch.equal(i8.predict_device(spec[:nb].reshape(nb, -1)), want_s[:nb])
+            assert torch.equal(i8.infer_audio_device(audio[:nb]), want_a[:nb])
+    i8.close()
+    ctx = _hip.Context(0, 64)
+    rng = np.random.default_rng(5)
+    for sr_in in (48000, 44100, 32000):
+        wins = [ingest.window_from_int16(rng.integers(-20000, 20000, (n, ch)).astype(np.int16), sr_in)
+                for n, ch in ((int(sr_in * 4.1), 1), (int(sr_in * 0.7), 2), (999, 1))]
+        base = ingest.ingest_windows_device(ctx, wins, 24000, 3.0, 0.5)[0].clone()
+        for opts in (dict(ingest_generic=1), dict(ingest_blk=1024), dict(ingest_blk=2048, ingest_generic=1)):
+            with _hip.options(**opts):
+                assert torch.equal(ingest.ingest_windows_device(ctx, wins, 24000, 3.0, 0.5)[0], base), (sr_in, opts)
+    ctx.close()
