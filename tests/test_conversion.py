@@ -404,6 +404,9 @@ ODD_GEOMETRIES = {
     "mels32_w128_a0.75_2s": dict(num_mels=32, spec_width=128, alpha=0.75, chunk_duration=2),
     "mels48_w192_a1.25": dict(num_mels=48, spec_width=192, alpha=1.25, use_se=True),
     "mels64_w320_ds_se": dict(num_mels=64, spec_width=320, alpha=1.0, use_inverted_residual=False, use_se=True, class_activation="sigmoid"),
+    # mel counts that are not a multiple of 16: the mel mixer and most blocks fall back to the one-operator kernels
+    "mels40_w128_ds": dict(num_mels=40, spec_width=128, alpha=0.5, use_se=False, use_inverted_residual=False),
+    "mels24_w64_se": dict(num_mels=24, spec_width=64, alpha=0.5, use_se=True),
 }
 
 
