@@ -323,6 +323,50 @@ def test_f32_current_code_topologies(torch_mod, oracle_specs, kw):
     runner.close()
 
 
+F32_GEOMETRIES = {
+    "mels32_w128_a0.75_2s": dict(num_mels=32, spec_width=128, alpha=0.75, chunk_duration=2),
+    "mels48_w192_a1.25_se": dict(num_mels=48, spec_width=192, alpha=1.25, use_se=True),
+    "mels40_w128_ds": dict(num_mels=40, spec_width=128, alpha=0.5, use_se=False, use_inverted_residual=False),
+    "mels64_w320_ds_se_norm": dict(num_mels=64, spec_width=320, use_inverted_residual=False, use_se=True, frontend_norm=True),
+}
+
+
+@pytest.mark.parametrize("name", list(F32_GEOMETRIES))
+def test_f32_other_geometries_per_layer(torch_mod, name):
+    """Spectrogram sizes, mel counts and width multipliers other than the shipped ones (maps the strip kernels do not take, mel
+    counts that are not multiples of 16): the float32 plan against the float oracle per layer, debug and production plans."""
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle import float_graph, stft
+
+    args = dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=10, randomize_bn=True, seed=11)
+    args.update(F32_GEOMETRIES[name])
+    norm = bool(args.pop("frontend_norm", False))
+    spec = build_model("dscnn", **args)
+    spec.frontend.attrs["norm"] = norm
+    chunks = synth_chunks(5, sr=args["sample_rate"], seconds=args["chunk_duration"], seed=4)
+    x = np.stack([stft.hybrid_spectrogram(a, spec_width=args["spec_width"]) for a in chunks])[..., None].astype(np.float32)
+    ref_scores, _, acts = float_graph.forward(spec, x, np.float64, return_all=True, return_logits=True)
+    runner = HipRunner(lower_f32(spec, keep_all=True), max_batch=5)
+    got = runner.predict(x)
+    checked = 0
+    for oi, op in enumerate(runner.plan.ops):
+        if op.out < 0 or op.name not in acts:
+            continue
+        a = runner.op_output(oi, 5)
+        r = acts[op.name].reshape(a.shape)
+        err = np.abs(a - r).max() / (np.abs(r).max() + 1e-12)
+        assert err < 5e-4, f"{name}: layer {op.name}: relative-to-peak error {err:.3e}"
+        checked += 1
+    assert checked >= 8 and np.abs(got - ref_scores).max() < 1e-4
+    runner.close()
+    prod = HipRunner(lower_f32(spec), max_batch=5)
+    for nb in (5, 1, 2):
+        assert np.abs(prod.predict(x[:nb]) - got[:nb]).max() < 2e-6
+    prod.close()
+
+
 # --------------------------------------------------------------------------------- full-size properties
 def test_full_batch_properties(torch_mod):
     """BASELINE sizes (B=1024 float32, B=4096 INT8) through size-independent properties: the result of a chunk does not
