@@ -436,3 +436,29 @@ def test_every_other_launcher_option_reproduces_the_default_results(torch_mod):
             with _hip.options(**opts):
                 assert torch.equal(ingest.ingest_windows_device(ctx, wins, 24000, 3.0, 0.5)[0], base), (sr_in, opts)
     ctx.close()
+
+
+# --------------------------------------------------------------------------------------- batches beyond one launch group
+def test_batches_beyond_one_launch_group(torch_mod):
+    """More chunks than one launch group takes (32 768: the grid's y limit): ``bn_infer_audio`` and ``bn_forward`` walk the batch in
+    slices; every chunk still gets the scores it gets in a small batch, for the float32 and the INT8 plan."""
+    torch = torch_mod
+    from birdnet_stm32.models.runners import load_model_runner
+
+    B = 32768 + 1500
+    base = torch.from_numpy(synth_chunks(48, seed=31)).cuda()
+    idx = torch.randint(0, 48, (B,), generator=torch.Generator().manual_seed(3)).cuda()
+    audio = base[idx].contiguous()
+    for path in (KERAS_PATH, TFLITE_PATH):
+        small = load_model_runner(path, max_batch=48)
+        ref = small.infer_audio_device(base).clone()
+        ref_spec_scores = small.predict_device(small.stft_device(base).reshape(48, -1)).clone()
+        small.close()
+        big = load_model_runner(path, max_batch=B)
+        got = big.infer_audio_device(audio)
+        assert torch.equal(got, ref[idx]), os.path.basename(path)
+        spec = big.stft_device(audio).reshape(B, -1)
+        assert torch.equal(big.predict_device(spec), ref_spec_scores[idx]), os.path.basename(path)
+        del spec, got
+        big.close()
+        torch.cuda.empty_cache()
