@@ -462,3 +462,30 @@ def test_batches_beyond_one_launch_group(torch_mod):
         del spec, got
         big.close()
         torch.cuda.empty_cache()
+
+
+# --------------------------------------------------------------------------------------- other chunk lengths from audio
+def test_from_audio_at_the_training_sample_rate(torch_mod):
+    """22.05 kHz x 3 s chunks (66 150 samples, hop 258: the rate the shipped network was trained at) through ``bn_infer_audio``:
+    the INT8 plan gives exactly what it gives for the spectrogram ``bn_stft_mag`` writes (same kernel, other layout), the float32
+    audio path (STFT + mel mixer fused, normalisation applied behind the mixer) stays within 1e-5 of its spectrogram path and
+    both track the CPU oracle's spectrogram path."""
+    torch = torch_mod
+    from birdnet_stm32.models.runners import load_model_runner
+    from oracle import stft
+
+    chunks = synth_chunks(24, sr=22050, seed=8)
+    audio = torch.from_numpy(chunks).cuda()
+    S = np.stack([stft.hybrid_spectrogram(a) for a in chunks])[..., None].astype(np.float32)
+    i8 = load_model_runner(TFLITE_PATH, max_batch=24)
+    spec = i8.stft_device(audio)
+    assert tuple(spec.shape) == (24, 257, 256)
+    assert torch.equal(i8.infer_audio_device(audio), i8.predict_device(spec.reshape(24, -1)))
+    agree = (i8.infer_audio_device(audio).cpu().numpy().argmax(1) == i8.predict(S).argmax(1)).mean()
+    assert agree == 1.0
+    i8.close()
+    f32 = load_model_runner(KERAS_PATH, max_batch=24)
+    a, b = f32.infer_audio_device(audio), f32.predict_device(f32.stft_device(audio).reshape(24, -1))
+    assert float((a - b).abs().max()) < 1e-5
+    assert np.abs(a.cpu().numpy() - f32.predict(S)).max() < 1e-4
+    f32.close()
