@@ -489,3 +489,34 @@ def test_from_audio_at_the_training_sample_rate(torch_mod):
     assert float((a - b).abs().max()) < 1e-5
     assert np.abs(a.cpu().numpy() - f32.predict(S)).max() < 1e-4
     f32.close()
+
+
+# --------------------------------------------------------------------------------------- launches on the caller's stream
+def test_everything_runs_on_the_callers_stream(torch_mod):
+    """The C ABI takes the stream from the caller: on a non-default torch stream, with the input produced on that stream right
+    before the call (no synchronisation in between) and the default stream kept busy, the results equal those of the default
+    stream — a kernel launched on the wrong stream would read the input before it exists."""
+    torch = torch_mod
+    from birdnet_stm32.models.runners import load_model_runner
+
+    base = torch.from_numpy(synth_chunks(200, seed=41)).cuda()
+    for path in (KERAS_PATH, TFLITE_PATH):
+        runner = load_model_runner(path, max_batch=200)
+        want = runner.infer_audio_device(base).clone()
+        want_spec = runner.predict_device(runner.stft_device(base).reshape(200, -1)).clone()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        busy = torch.randn(4096, 4096, device="cuda")
+        for rep in range(3):
+            for _ in range(4):
+                busy = busy @ busy * 1e-3  # keeps the default stream occupied
+            with torch.cuda.stream(side):
+                x = torch.zeros_like(base)
+                x.copy_(base.flip(0)).mul_(1.0)  # the input comes into being on the side stream
+                x = x.flip(0).contiguous()
+                got = runner.infer_audio_device(x)
+                got_spec = runner.predict_device(runner.stft_device(x).reshape(200, -1))
+            side.synchronize()
+            assert torch.equal(got, want) and torch.equal(got_spec, want_spec), f"{os.path.basename(path)}, repetition {rep}"
+        torch.cuda.synchronize()
+        runner.close()
