@@ -520,3 +520,31 @@ def test_everything_runs_on_the_callers_stream(torch_mod):
             assert torch.equal(got, want) and torch.equal(got_spec, want_spec), f"{os.path.basename(path)}, repetition {rep}"
         torch.cuda.synchronize()
         runner.close()
+
+
+# --------------------------------------------------------------------------------------- load / free cycles
+def test_contexts_and_models_give_their_memory_back(torch_mod):
+    """Thirty load -> infer -> free cycles of both model files (own context each time): the device's free memory returns to where it
+    was (bn_ctx_create / bn_model_load allocate with hipMalloc outside torch's allocator; a leak would show here) and the scores of
+    the last cycle equal those of the first."""
+    torch = torch_mod
+    from birdnet_stm32.models.runners import load_model_runner
+
+    audio = torch.from_numpy(synth_chunks(16, seed=2)).cuda()
+    first = {}
+
+    def cycles(n):
+        for cycle in range(n):
+            for path in (KERAS_PATH, TFLITE_PATH):
+                runner = load_model_runner(path, max_batch=64 + 8 * (cycle % 3))
+                s = runner.infer_audio_device(audio).clone()
+                first.setdefault(path, s)
+                assert torch.equal(s, first[path])
+                del s
+                runner.close()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    free0 = cycles(5)   # code objects, torch's cached blocks and the HIP runtime's pools are in place after the first cycles
+    free1 = cycles(30)
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back over 30 cycles"
