@@ -548,3 +548,42 @@ def test_contexts_and_models_give_their_memory_back(torch_mod):
     free0 = cycles(5)   # code objects, torch's cached blocks and the HIP runtime's pools are in place after the first cycles
     free1 = cycles(30)
     assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back over 30 cycles"
+
+
+# --------------------------------------------------------------------------------------- the C ABI refuses bad calls
+def test_c_abi_refuses_bad_calls_with_an_error_code(torch_mod):
+    """Straight through ctypes: batches beyond max_batch, null pointers, audio geometries that give too few frames, a damaged blob —
+    every call returns its error code with a message in bn_last_error() and leaves the context usable."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models.runners import load_model_runner, lower_model_file
+
+    runner = load_model_runner(TFLITE_PATH, max_batch=8)
+    lib, mh = runner.lib, runner.model.handle
+    audio = torch.from_numpy(synth_chunks(9, seed=1)).cuda()
+    scores = torch.empty((9, runner.num_classes), device="cuda")
+    spec = torch.rand((9, 257 * 256), device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def err():
+        return lib.bn_last_error().decode()
+
+    assert lib.bn_infer_audio(mh, audio.data_ptr(), 9, 72000, 281, scores.data_ptr(), None, stream) != 0 and "max_batch" in err()
+    assert lib.bn_forward(mh, spec.data_ptr(), None, 9, scores.data_ptr(), None, stream) != 0 and "max_batch" in err()
+    assert lib.bn_infer_audio(mh, None, 4, 72000, 281, scores.data_ptr(), None, stream) != 0 and "null" in err()
+    assert lib.bn_forward(mh, spec.data_ptr(), None, 4, None, None, stream) != 0 and "null" in err()
+    assert lib.bn_infer_audio(mh, audio.data_ptr(), 4, 72000, 20000, scores.data_ptr(), None, stream) != 0  # 4 frames, the model wants 256
+    assert lib.bn_infer_audio(mh, audio.data_ptr(), 4, 0, 281, scores.data_ptr(), None, stream) != 0
+    assert lib.bn_infer_audio(None, audio.data_ptr(), 4, 72000, 281, scores.data_ptr(), None, stream) != 0 and "null model" in err()
+    blob = bytearray(pk.pack_plan(lower_model_file(TFLITE_PATH)))
+    blob[40:44] = (0x7FFFFFFF).to_bytes(4, "little")  # a header count far beyond the blob
+    out = ctypes.c_void_p()
+    assert lib.bn_model_load(runner.ctx.handle, bytes(blob), len(blob), ctypes.byref(out)) != 0 and not out.value
+    assert lib.bn_model_load(runner.ctx.handle, bytes(blob[:100]), 100, ctypes.byref(out)) != 0 and not out.value
+    # the context and the model still work
+    want = runner.infer_audio_device(audio[:8])
+    assert torch.isfinite(want).all() and lib.bn_infer_audio(mh, audio.data_ptr(), 8, 72000, 281, scores.data_ptr(), None, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(scores[:8], want)
+    runner.close()
