@@ -899,8 +899,9 @@ int bn_ingest_resample(bn_ctx* ctx, const void* d_pcm, int sample_format, int ch
         return fail(BN_ERR_UNSUPPORTED, "window too long for the 32-bit polyphase index (%lld samples, up=%d, down=%d)",
                     (long long)max_in_len, up, down);
     const size_t lds = bn::ingest_resample_lds_bytes(up, down, taps_per_phase, bn::ingest_resample_block(up, down, taps_per_phase));
-    if (lds > 64 * 1024)
-        return fail(BN_ERR_UNSUPPORTED, "resampling ratio %d/%d needs %zu bytes of LDS per workgroup (limit 65536)", up, down, lds);
+    const bool fast_kernel = (up == 1 && (down == 2 || down == 4)) || (up > 1 && up <= 256 && (taps_per_phase == 21 || taps_per_phase == 29 || taps_per_phase == 39));
+    if (lds > (fast_kernel ? 64 : 156) * 1024)  // (only the generic kernel's limit is raised to the CU's 160 KB)
+        return fail(BN_ERR_UNSUPPORTED, "resampling ratio %d/%d needs %zu bytes of LDS per workgroup (limit %d)", up, down, lds, (fast_kernel ? 64 : 156) * 1024);
     hipStream_t s = (hipStream_t)stream;
     const size_t need = bn::ingest_partial_elems(n_windows, (long)max_out_len, up, down, taps_per_phase);
     if (need > ctx->block_peaks_elems) {  // growing frees the old buffer, which waits for launches still using it

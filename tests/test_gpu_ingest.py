@@ -424,3 +424,23 @@ def test_device_ingest_reads_flac_like_wav(tmp_path):
     want = oi.split_chunks(oi.ingest_window((x24.astype(np.float64) / float(1 << 23)).astype(np.float32), 44100, 24000), 24000, 3.0, 0.0)
     assert np.array_equal(c[2 * k :].view(np.uint32), want.view(np.uint32))
     ctx.close()
+
+
+@pytest.mark.parametrize("sr_in,sr_out", [(96000, 22050), (11025, 32000), (37800, 16000)])
+def test_ingest_ratios_whose_filter_needs_more_than_64_kb_of_lds(ctx, sr_in, sr_out):
+    """Ratios like 147/640 and 1280/441: the generic polyphase kernel keeps the whole filter (up to ~110 KB) in LDS, the launcher
+    raises the kernel's dynamic LDS limit to what the launch needs — chunks bit for bit against the scipy-pinned oracle."""
+    from birdnet_stm32.audio import ingest
+
+    rng = np.random.default_rng(sr_in + sr_out)
+    pcm = [_pcm16(rng, n, ch) for n, ch in ((int(sr_in * 4.2), 1), (int(sr_in * 0.9), 2))]
+    wins = [ingest.window_from_int16(p, sr_in) for p in pcm]
+    for rep in range(2):
+        chunks, counts = ingest.ingest_windows_device(ctx, wins, sr_out, 3.0, 0.5)[:2]
+        chunks = chunks.cpu().numpy()
+        at = 0
+        for i, p in enumerate(pcm):
+            want, _ = _oracle_chunks(p.astype(np.float32) / 32768.0, sr_in, sr_out, 3.0, 0.5)
+            got = chunks[at : at + counts[i]]
+            at += counts[i]
+            assert counts[i] == want.shape[0] and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sr_in, sr_out, i, rep)
