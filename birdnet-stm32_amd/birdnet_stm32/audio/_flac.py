@@ -48,7 +48,14 @@ def flac_info(raw: bytes) -> tuple[int, int, int, int]:
 def decode_flac(raw: bytes, first: int = 0, count: int | None = None, verify_md5: bool = True) -> tuple[np.ndarray, int, int]:
     """Decode frames ``[first, first + count)``: ``(int32 [n, channels], sample rate, bits per sample)``."""
     sr, ch, bps, total = flac_info(raw)
-    want = count if count is not None else (max(total - first, 0) if total else len(raw) * 8)  # unknown length: bound by the file size
+    if count is not None:
+        want = count
+    elif total:
+        want = max(total - first, 0)
+    else:  # the stream does not state its length (total = 0): count by decoding once without storing — no bound follows from the file size
+        want = _load().bn_flac_decode(raw, len(raw), int(first), (1 << 62), None)  # (a constant subframe holds 65 535 samples in a few bytes)
+        if want < 0:
+            raise ValueError(_ERRORS.get(int(want), f"FLAC error {want}"))
     out = np.empty((max(int(want), 0), ch), np.int32)
     n = _load().bn_flac_decode(raw, len(raw), int(first), int(out.shape[0]), out.ctypes.data_as(ctypes.c_void_p))
     if n < 0:

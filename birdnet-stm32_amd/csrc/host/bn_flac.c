@@ -203,7 +203,8 @@ int bn_flac_info(const uint8_t* data, size_t n, int* sample_rate, int* channels,
 }
 
 /* Decode frames [first, first + max_frames) (inter-channel sample frames) into out[frames][channels]; returns the number of frames
- * written or a negative error.  A stream whose STREAMINFO holds total = 0 (unknown) is decoded to its end. */
+ * written or a negative error.  A stream whose STREAMINFO holds total = 0 (unknown) is decoded to its end.  out == NULL: nothing is stored,
+ * the frames are only counted (the length of a stream that does not state it: frames carry no byte length, they have to be decoded). */
 int64_t bn_flac_decode(const uint8_t* data, size_t n, int64_t first, int64_t max_frames, int32_t* out) {
     StreamInfo si;
     int rc = parse_header(data, n, &si);
@@ -270,7 +271,8 @@ int64_t bn_flac_decode(const uint8_t* data, size_t n, int64_t first, int64_t max
             }
         for (int i = 0; i < blocksize && written < max_frames; ++i, ++at) {
             if (at < first) continue;
-            for (int c = 0; c < ch; ++c) out[written * ch + c] = buf[(size_t)c * 65536 + i];
+            if (out)
+                for (int c = 0; c < ch; ++c) out[written * ch + c] = buf[(size_t)c * 65536 + i];
             ++written;
         }
         pos = body_end + 2;

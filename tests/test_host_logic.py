@@ -411,6 +411,12 @@ def _flac_cases():
     many = np.clip(rng.normal(0, 1000, size=(192 * 140, 1)), -32768, 32767).astype(np.int64)  # frame numbers above 127: two-byte coded numbers
     frames = [{"n": 192, "sub": [dict(kind="fixed", order=2, po=1)]} for _ in range(140)]
     yield "many_frames", many, 16000, 16, frames, {"total_known": False, "with_md5": False}
+    # a stream that does not state its length and compresses far below one bit per sample: constant subframes (found by tools/fuzz/flac_fuzz.py —
+    # the wrapper used to bound the unknown length by the file size)
+    flat = np.full((1000 + 4608, 1), -321, np.int64)
+    flat[1000:] = 77
+    frames = [{"n": 1000, "sub": [dict(kind="constant")]}, {"n": 4608, "sub": [dict(kind="constant")]}]
+    yield "unknown_length_constant", flat, 8000, 24, frames, {"total_known": False}
 
 
 def test_flac_decoder_matches_the_encoded_samples(tmp_path):
