@@ -229,6 +229,9 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                         c.tensor(2, 4LL * p[2], "depthwise multipliers") && c.tensor(3, 4LL * p[2], "depthwise shifts");
                 if (c.ok && !p[29] && (p[0] != p[6] || p[1] != p[7])) c.bad("plain 1x1 convolution must keep the map size");
                 if (c.ok && (p[31] < 1 || p[32] < 1 || p[33] < 1)) c.bad("tile %dx%dx%d", p[31], p[32], p[33]);
+                // the transposed form is the mel mixer: a plain 1x1 over the frames of one chunk, no residual; only it takes a table or float32 input
+                if (c.ok && p[30] && (p[29] || p[18] || p[0] != 1 || p[6] != 1 || p[33] != 1)) c.bad("transposed output on a block that is not a mel mixer");
+                if (c.ok && !p[30] && (p[34] || p[36])) c.bad("table / fused QUANTIZE on a block without transposed output");
                 if (c.ok && p[35] && o.t[9] >= 0) {  // constant block of the strip kernel (bn_i8_strip.hip: kPWC + NW * nPWC words)
                     const int nw = p[3] == p[4] ? i8_strip_waves(p[2], p[14], p[3], p[7], p[18] != 0) : 0;
                     if (nw) {

@@ -377,6 +377,13 @@ def test_blob_check_accepts_every_lowered_plan_and_refuses_damaged_ones():
     oj = next(i for i, o in enumerate(bad.ops) if o.kind == pk.I8_DWPW and o.p[18])
     bad.ops[oj].in1 = pk.SLOT_NONE
     refused(bad, "residual")
+    # 6b) flags that select a kernel form the block's other fields do not describe
+    bad = copy.deepcopy(i8)
+    bad.ops[oi].p[30] = 1  # transposed output on a depthwise + pointwise block
+    refused(bad, "not a mel mixer")
+    bad = copy.deepcopy(i8)
+    bad.ops[oi].p[34] = 1  # per-channel table on a block whose kernel has none
+    refused(bad, "table")
     # 7) truncated blob, bad magic
     blob = i8.to_blob()
     for cut in (10, 63, 200, len(blob) // 2):
