@@ -10,6 +10,8 @@ as an ordinary `.tflite` file that ``load_model_runner`` reads back.
 
 Operator vocabulary of the emitted graphs (all int8 between QUANTIZE and DEQUANTIZE):
 
+* frontend (raw): QUANTIZE of the waveform -> [PAD] -> RESHAPE [1, 1, T, 1] -> CONV_2D 1x16, stride ceil(T / W), VALID, BatchNorm folded,
+  ReLU6 (reference models/frontend.py:138-164,347-358) -> magnitude scaling as below -> TRANSPOSE;
 * frontend (hybrid): QUANTIZE -> TRANSPOSE -> CONV_2D 1x1 (mel mixer, ReLU) -> [per-sample max normalisation of current hybrid
   frontends: REDUCE_MAX -> ADD 1e-6 -> DIV, reference models/frontend.py:338-342] -> element-wise magnitude scaling as 1x1
   DEPTHWISE_CONV_2D / ADD operators (PWL: ``k0 x + sum_i k_i relu(w_i x + b_i)``, reference models/magnitude.py:179-192; PCEN:
@@ -21,7 +23,7 @@ Operator vocabulary of the emitted graphs (all int8 between QUANTIZE and DEQUANT
   (softmax; the TFLite converter would keep the softmax in int8 — a deliberate difference: the float softmax is exact on the
   dequantised logits and needs no fixed-point exponential).
 
-Not emitted (``NotImplementedError``): raw / precomputed frontends, attention pooling.
+Not emitted (``NotImplementedError``): precomputed frontends (their graphs start at the stem: nothing to quantise in front), attention pooling.
 """
 
 from __future__ import annotations
@@ -86,21 +88,49 @@ def netspec_to_graph(spec: ns.NetSpec, frontend_norm: bool | None = None):
 
     fe = spec.frontend
     fa = fe.attrs
-    if fa["mode"] != "hybrid":
-        raise NotImplementedError(f"own INT8 export covers the hybrid frontend, not '{fa['mode']}'")
+    if fa["mode"] not in ("hybrid", "raw"):
+        raise NotImplementedError(f"own INT8 export covers the hybrid and raw frontends, not '{fa['mode']}'")
     norm = fa.get("norm", False) if frontend_norm is None else frontend_norm
     g = _GraphBuilder()
-    F, W = spec.layers[0].out_shape[0], spec.layers[0].out_shape[1]
+    W = int(fa["spec_width"])
     M = int(fa["mel_bins"])
-    x_in = g.act(spec.layers[0].name, (1, F, W, 1), quantized=False)
-    q = g.act("quantized_input", (1, F, W, 1))
-    g.op("QUANTIZE", [x_in], q)
     perm = g.const("perm_0321", np.array([0, 3, 2, 1], np.int32), np.int32, False)
-    xt = g.act("frontend/transpose_in", (1, 1, W, F))
-    g.op("TRANSPOSE", [q, perm], xt)
-    mel = np.asarray(fe.weights["mel"], np.float32)          # [F (padded), M]
-    w_mel = np.transpose(mel[:F], (1, 0)).reshape(M, 1, 1, F)
-    y = g.conv("CONV_2D", xt, "frontend/mel_mixer", w_mel, np.zeros(M, np.float32), (1, 1, W, M), _conv_opts(act="relu"))
+    if fa["mode"] == "raw":
+        # reference models/frontend.py:347-358: [B, T, 1] -> symmetric zero pad -> expand_dims -> Conv2D (1 x 16, stride ceil(T / W), VALID,
+        # no bias) -> BatchNorm -> ReLU6; the converter writes expand_dims as RESHAPE and folds the BatchNorm into the convolution
+        T = int(fa["sample_rate"] * fa["chunk_duration"])
+        stride = -(-T // W)
+        pad_total = max(0, stride * (W - 1) + 16 - T)
+        x_in = g.act(spec.layers[0].name, (1, T, 1), quantized=False)
+        q = g.act("quantized_input", (1, T, 1))
+        g.op("QUANTIZE", [x_in], q)
+        cur = q
+        if pad_total:
+            pads = g.const("frontend/paddings", np.array([[0, 0], [pad_total // 2, pad_total - pad_total // 2], [0, 0]], np.int32), np.int32, False)
+            xp = g.act("frontend/pad", (1, T + pad_total, 1))
+            g.op("PAD", [cur, pads], xp)
+            cur = xp
+        shp = g.const("frontend/expand_shape", np.array([1, 1, T + pad_total, 1], np.int32), np.int32, False)
+        xr = g.act("frontend/expand_dims", (1, 1, T + pad_total, 1))
+        g.op("RESHAPE", [cur, shp], xr)
+        fwt = fe.weights
+        g_ = fwt["fb_gamma"].astype(np.float64) / np.sqrt(fwt["fb_var"].astype(np.float64) + float(fa.get("fb_eps", 1e-3)))
+        fb = (fwt["fb"].astype(np.float64) * g_).astype(np.float32)                      # [16, M], BatchNorm folded
+        fbias = (fwt["fb_beta"].astype(np.float64) - fwt["fb_mean"].astype(np.float64) * g_).astype(np.float32)
+        opts = _conv_opts((1, stride), "relu6")
+        opts["padding"] = "VALID"
+        y = g.conv("CONV_2D", xr, "frontend/raw_fb2d", np.transpose(fb, (1, 0)).reshape(M, 1, 16, 1), fbias, (1, 1, W, M), opts)
+        norm = False
+    else:
+        F = spec.layers[0].out_shape[0]
+        x_in = g.act(spec.layers[0].name, (1, F, W, 1), quantized=False)
+        q = g.act("quantized_input", (1, F, W, 1))
+        g.op("QUANTIZE", [x_in], q)
+        xt = g.act("frontend/transpose_in", (1, 1, W, F))
+        g.op("TRANSPOSE", [q, perm], xt)
+        mel = np.asarray(fe.weights["mel"], np.float32)          # [F (padded), M]
+        w_mel = np.transpose(mel[:F], (1, 0)).reshape(M, 1, 1, F)
+        y = g.conv("CONV_2D", xt, "frontend/mel_mixer", w_mel, np.zeros(M, np.float32), (1, 1, W, M), _conv_opts(act="relu"))
     zeros = np.zeros(M, np.float32)
 
     def dw1(src, name, w, b=zeros, act="none"):

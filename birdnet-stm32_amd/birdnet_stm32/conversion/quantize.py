@@ -32,7 +32,7 @@ import numpy as np
 from birdnet_stm32.models import _netspec as ns
 from birdnet_stm32.models._tflite_reader import TfliteModel, TfliteTensor
 
-_MOVERS = ("TRANSPOSE", "STRIDED_SLICE", "CONCATENATION", "RESHAPE", "REDUCE_MAX")  # output shares the input's quantisation
+_MOVERS = ("TRANSPOSE", "STRIDED_SLICE", "CONCATENATION", "RESHAPE", "REDUCE_MAX", "PAD")  # output shares the input's quantisation
 _PLAIN_KINDS = (ns.INPUT, ns.FRONTEND, ns.CONV, ns.DWCONV, ns.BN, ns.RELU, ns.ADD, ns.GAP, ns.DENSE, ns.IDENTITY)
 
 
@@ -103,31 +103,33 @@ def _act(y: np.ndarray, kind: str) -> np.ndarray:
     raise NotImplementedError(f"fused activation {kind}")
 
 
-def _windows(x: np.ndarray, kh: int, kw: int, sh: int, sw: int):
-    """SAME-padded sliding windows ``[B, OH, OW, C, kh, kw]`` of an NHWC array."""
+def _windows(x: np.ndarray, kh: int, kw: int, sh: int, sw: int, padding: str = "SAME"):
+    """Sliding windows ``[B, OH, OW, C, kh, kw]`` of an NHWC array (SAME: TensorFlow's asymmetric zero padding; VALID: none)."""
     _, H, W, _ = x.shape
-    _, pt, pb = _same_pad(H, kh, sh)
-    _, pl, pr = _same_pad(W, kw, sw)
-    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    xp = x
+    if padding == "SAME":
+        _, pt, pb = _same_pad(H, kh, sh)
+        _, pl, pr = _same_pad(W, kw, sw)
+        xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
     win = np.lib.stride_tricks.sliding_window_view(xp, (kh, kw), axis=(1, 2))
     return win[:, ::sh, ::sw]
 
 
-def _conv2d(x, w, b, sh, sw, act):  # w [Cout, kh, kw, Cin] (TFLite layout)
+def _conv2d(x, w, b, sh, sw, act, padding="SAME"):  # w [Cout, kh, kw, Cin] (TFLite layout)
     cout, kh, kw, _ = w.shape
     if (kh, kw) == (1, 1) and (sh, sw) == (1, 1):
         y = x @ w[:, 0, 0, :].T
     else:
-        y = np.einsum("bhwcij,oijc->bhwo", _windows(x, kh, kw, sh, sw), w, optimize=True)
+        y = np.einsum("bhwcij,oijc->bhwo", _windows(x, kh, kw, sh, sw, padding), w, optimize=True)
     return _act(y + b, act)
 
 
-def _dwconv2d(x, w, b, sh, sw, act):  # w [1, kh, kw, C]
+def _dwconv2d(x, w, b, sh, sw, act, padding="SAME"):  # w [1, kh, kw, C]
     _, kh, kw, _ = w.shape
     if (kh, kw) == (1, 1) and (sh, sw) == (1, 1):
         y = x * w[0, 0, 0]
     else:
-        y = np.einsum("bhwcij,ijc->bhwc", _windows(x, kh, kw, sh, sw), w[0], optimize=True)
+        y = np.einsum("bhwcij,ijc->bhwc", _windows(x, kh, kw, sh, sw, padding), w[0], optimize=True)
     return _act(y + b, act)
 
 
@@ -165,11 +167,13 @@ def run_float(model: TfliteModel, consts: dict[int, np.ndarray], x: np.ndarray) 
         elif n == "CONCATENATION":
             y = np.concatenate([env[k] for k in i], axis=op.options["axis"])
         elif n == "RESHAPE":
-            y = env[i[0]].reshape([int(v) for v in env[i[1]]])
+            y = env[i[0]].reshape([env[i[0]].shape[0]] + [int(v) for v in env[i[1]]][1:])
+        elif n == "PAD":
+            y = np.pad(env[i[0]], [(int(a), int(b)) for a, b in np.asarray(env[i[1]]).reshape(-1, 2)])
         elif n == "CONV_2D":
-            y = _conv2d(env[i[0]], env[i[1]], env[i[2]], op.options["stride_h"], op.options["stride_w"], op.options["activation"])
+            y = _conv2d(env[i[0]], env[i[1]], env[i[2]], op.options["stride_h"], op.options["stride_w"], op.options["activation"], op.options.get("padding", "SAME"))
         elif n == "DEPTHWISE_CONV_2D":
-            y = _dwconv2d(env[i[0]], env[i[1]], env[i[2]], op.options["stride_h"], op.options["stride_w"], op.options["activation"])
+            y = _dwconv2d(env[i[0]], env[i[1]], env[i[2]], op.options["stride_h"], op.options["stride_w"], op.options["activation"], op.options.get("padding", "SAME"))
         elif n == "ADD":
             y = _act(env[i[0]] + env[i[1]], op.options["activation"])
         elif n == "MEAN":

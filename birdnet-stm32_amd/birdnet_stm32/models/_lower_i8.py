@@ -400,136 +400,196 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
     t = g.t
     _expect(len(model.inputs) == 1 and len(model.outputs) == 1, "single input / single output")
     in_shape = t[model.inputs[0]].shape
-    _expect(len(in_shape) == 4 and in_shape[3] == 1, "input must be [B, F, W, 1]")
-    F, W = int(in_shape[1]), int(in_shape[2])
-
-    i = 0
-    _expect(ops[i].name == "QUANTIZE" and ops[i].inputs[0] == model.inputs[0], "graph must start with QUANTIZE of the input")
-    q_scale, q_zp = g.q(ops[i].outputs[0])
-    cur = ops[i].outputs[0]
-    i += 1
-    _expect(ops[i].name == "TRANSPOSE" and list(g.const(ops[i].inputs[1])) == [0, 3, 2, 1], "TRANSPOSE [0,3,2,1] after QUANTIZE")
-    cur = ops[i].outputs[0]
-    i += 1
-    if ops[i].name == "STRIDED_SLICE":
-        _expect(tuple(t[ops[i].outputs[0]].shape[1:]) == (1, W, F), "frontend STRIDED_SLICE must keep [1, W, F]")
+    if len(in_shape) == 3:
+        # ---- raw frontend of an exported graph (conversion/export.py; reference models/frontend.py:138-164,347-358): QUANTIZE of the
+        # waveform -> [PAD] -> RESHAPE (expand_dims) -> CONV_2D 1 x 16 strided VALID (ReLU6) -> magnitude scaling -> TRANSPOSE = ONE operator
+        _expect(in_shape[2] == 1, "waveform input must be [B, T, 1]")
+        T = int(in_shape[1])
+        i = 0
+        _expect(ops[i].name == "QUANTIZE" and ops[i].inputs[0] == model.inputs[0], "graph must start with QUANTIZE of the input")
+        q_scale, q_zp = g.q(ops[i].outputs[0])
         cur = ops[i].outputs[0]
         i += 1
-    fill_value = q_zp
-    k_graph = F
-    if ops[i].name == "SHAPE":
+        pad_left = pad_right = 0
+        for _ in range(2):  # PAD and RESHAPE in either order
+            if ops[i].name == "PAD" and ops[i].inputs[0] == cur:
+                pads = np.asarray(g.const(ops[i].inputs[1])).reshape(-1, 2)
+                axis = int(np.argmax(t[ops[i].inputs[0]].shape))
+                _expect(all(int(pads[a].sum()) == 0 for a in range(len(pads)) if a != axis) and g.q(ops[i].outputs[0]) == (q_scale, q_zp), "PAD along the time axis only")
+                pad_left, pad_right = int(pads[axis][0]), int(pads[axis][1])
+                cur = ops[i].outputs[0]
+                i += 1
+            elif ops[i].name == "RESHAPE" and ops[i].inputs[0] == cur:
+                shp = tuple(int(v) for v in t[ops[i].outputs[0]].shape)
+                _expect(len(shp) == 4 and shp[1] == 1 and shp[3] == 1, "expand_dims of the waveform to [1, 1, T, 1]")
+                cur = ops[i].outputs[0]
+                i += 1
+        conv = ops[i]
+        _expect(conv.name == "CONV_2D" and conv.inputs[0] == cur and tuple(t[cur].shape) == (1, 1, T + pad_left + pad_right, 1), "filterbank CONV_2D on [1, 1, T, 1]")
+        wt = t[conv.inputs[1]]
+        M = int(wt.shape[0])
+        _expect(tuple(wt.shape[1:]) == (1, 16, 1) and conv.options["padding"] == "VALID" and conv.options["stride_h"] == 1, "filterbank must be 1 x 16, VALID")
+        stride = int(conv.options["stride_w"])
+        W = int(t[conv.outputs[0]].shape[2])
+        _expect((T + pad_left + pad_right - 16) // stride + 1 == W and W % 4 == 0, "filterbank output width (a multiple of 4 frames)")
+        _expect(g.q(conv.inputs[0]) == (q_scale, q_zp), "filterbank input quantisation")
+        s_fb, z_fb = g.q(conv.outputs[0])
+        w_fb = wt.data.reshape(M, 16).astype(np.int8)
+        bias = g.const(conv.inputs[2]).astype(np.int64) - q_zp * w_fb.astype(np.int64).sum(axis=1)
+        mult, shift = qz.channel_multipliers(q_scale, wt.scale, s_fb, M)
+        _expect_acc_range(w_fb, bias, 1, "raw filterbank", mult, shift)
+        lo, hi = qz.activation_bounds(conv.options["activation"], s_fb, z_fb)
+        cur = conv.outputs[0]
+        i += 1
         j = i
-        while ops[j].name != "CONCATENATION":
-            _expect(ops[j].name in ("SHAPE", "STRIDED_SLICE", "PACK", "FILL"), f"{ops[j].name} in the channel-padding block")
-            if ops[j].name == "FILL":
-                fill_value = int(np.asarray(g.const(ops[j].inputs[1])).reshape(-1)[0])
+        while ops[j].name != "TRANSPOSE":
             j += 1
-        cat = ops[j]
-        _expect(cat.inputs[0] == cur and cat.options["axis"] in (-1, 3), "CONCATENATION must pad the channel axis")
-        _expect(g.q(cat.inputs[0]) == g.q(cat.inputs[1]) == g.q(cat.outputs[0]), "CONCATENATION operands must share quantisation")
-        k_graph = int(t[cat.outputs[0]].shape[3])
-        cur = cat.outputs[0]
+        lut = None
+        if j > i:
+            lut = _pwl_table(g, ops[i:j], cur, ops[j].inputs[0], M)
+        _expect(list(g.const(ops[j].inputs[1])) == [0, 3, 2, 1], "TRANSPOSE [0,3,2,1] after the frontend")
+        cur = ops[j].outputs[0]
         i = j + 1
+        F = 0
+        plan = pk.Plan(pk.DTYPE_I8, pk.INPUT_WAVEFORM, T, 0, W, int(t[model.outputs[0]].shape[-1]), meta={"tflite_ops": len(ops)})
+        pb = pk.PlanBuilder(plan)
+        tt = [pb.tensor(w_fb, np.int8), pb.tensor(bias, np.int32), pb.tensor(mult, np.int32), pb.tensor(shift, np.int32)]
+        if lut is not None:
+            tt.append(pb.tensor(lut, np.int8))
+        v = pb.value(M * W)
+        pb.op(pk.I8_RAWFE, pk.SLOT_INPUT, v, p=[T, W, M, stride, pad_left, q_zp, z_fb, lo, hi, int(lut is not None)], t=tt, f=[q_scale], name=f"t{cur}",
+              out_shape=(M, W, 1), out_dtype="int8")
+    else:
+        _expect(len(in_shape) == 4 and in_shape[3] == 1, "input must be [B, F, W, 1]")
+        F, W = int(in_shape[1]), int(in_shape[2])
 
-    # ---- mel mixer ------------------------------------------------------------------------
-    mel = ops[i]
-    _expect(mel.name == "CONV_2D" and mel.inputs[0] == cur, "mel mixer CONV_2D")
-    wt = t[mel.inputs[1]]
-    M = int(wt.shape[0])
-    _expect(tuple(wt.shape[1:3]) == (1, 1) and int(wt.shape[3]) == k_graph, "mel mixer must be 1x1 over the padded bins")
-    s_in, z_in = g.q(mel.inputs[0])
-    _expect((s_in, z_in) == (q_scale, q_zp), "mel mixer input quantisation")
-    s_mel, z_mel = g.q(mel.outputs[0])
-    Kp = (k_graph + K_ALIGN - 1) // K_ALIGN * K_ALIGN
-    w_mel = np.zeros((M, Kp), np.int8)
-    w_mel[:, :k_graph] = wt.data.reshape(M, k_graph)
-    bias = g.const(mel.inputs[2]).astype(np.int64) - z_in * w_mel.astype(np.int64).sum(axis=1)
-    mult, shift = qz.channel_multipliers(s_in, wt.scale, s_mel, M)
-    _expect_acc_range(w_mel, bias, 1, "mel mixer", mult, shift)
-    lo, hi = qz.activation_bounds(mel.options["activation"], s_mel, z_mel)
-    cur = mel.outputs[0]
-    i += 1
-
-    # ---- element-wise region up to the TRANSPOSE back ---------------------------------------
-    j = i
-    while ops[j].name != "TRANSPOSE":
-        j += 1
-    region = ops[i:j]
-    lut = None
-    front_out = cur
-    maxnorm = None
-    if region and region[0].name == "REDUCE_MAX":
-        # per-sample max normalisation of current hybrid frontends (reference models/frontend.py:338-342): REDUCE_MAX over the whole map
-        # -> ADD epsilon -> DIV by that scalar.  Everything behind the maximum is a function of bytes: the denominator byte per maximum
-        # byte (the quantised ADD) and the DIV of every byte by every denominator byte become tables (models/_quant.py: div_table)
-        _expect(len(region) >= 3 and region[1].name == "ADD" and region[2].name == "DIV", "REDUCE_MAX must be followed by ADD and DIV")
-        rmax, addop, divop = region[:3]
-        axes = sorted(int(a) % 4 for a in np.atleast_1d(g.const(rmax.inputs[1])))
-        _expect(rmax.inputs[0] == cur and axes == [1, 2, 3] and g.q(rmax.outputs[0]) == g.q(cur), "REDUCE_MAX over the whole map, same quantisation")
-        _expect(rmax.outputs[0] in addop.inputs and divop.inputs[0] == cur and divop.inputs[1] == addop.outputs[0], "max normalisation wiring")
-        eps_i = [k for k in addop.inputs if k != rmax.outputs[0]]
-        _expect(len(eps_i) == 1 and t[eps_i[0]].data is not None and t[eps_i[0]].data.size == 1, "ADD of a scalar constant to the maximum")
-        eps_q = int(np.asarray(t[eps_i[0]].data).reshape(-1)[0])
-        (s_m, z_m), (s_e, z_e), (s_d, z_d) = g.q(rmax.outputs[0]), g.q(eps_i[0]), g.q(addop.outputs[0])
-        mx = np.arange(-128, 128, dtype=np.int64)
-        if addop.inputs[0] == rmax.outputs[0]:
-            den_tab = qz.AddParams(s_m, z_m, s_e, z_e, s_d, z_d, addop.options["activation"]).apply(mx, np.full(256, eps_q, np.int64))
-        else:
-            den_tab = qz.AddParams(s_e, z_e, s_m, z_m, s_d, z_d, addop.options["activation"]).apply(np.full(256, eps_q, np.int64), mx)
-        s_o, z_o = g.q(divop.outputs[0])
-        div_tab = qz.div_table(s_mel, z_mel, s_d, z_d, s_o, z_o, divop.options.get("activation", "none"))
-        maxnorm = (den_tab.astype(np.int8), div_tab)
-        region = region[3:]
-        cur = divop.outputs[0]
-        front_out = cur
-    if region:
-        front_out = ops[j].inputs[0]
-        lut = _pwl_table(g, region, cur, front_out, M)
-    _expect(list(g.const(ops[j].inputs[1])) == [0, 3, 2, 1], "TRANSPOSE [0,3,2,1] after the frontend")
-    cur = ops[j].outputs[0]
-    i = j + 1
-    if ops[i].name == "STRIDED_SLICE":
-        _expect(tuple(t[ops[i].outputs[0]].shape[1:]) == (M, W, 1), "post-frontend STRIDED_SLICE must keep [M, W, 1]")
+        i = 0
+        _expect(ops[i].name == "QUANTIZE" and ops[i].inputs[0] == model.inputs[0], "graph must start with QUANTIZE of the input")
+        q_scale, q_zp = g.q(ops[i].outputs[0])
         cur = ops[i].outputs[0]
         i += 1
+        _expect(ops[i].name == "TRANSPOSE" and list(g.const(ops[i].inputs[1])) == [0, 3, 2, 1], "TRANSPOSE [0,3,2,1] after QUANTIZE")
+        cur = ops[i].outputs[0]
+        i += 1
+        if ops[i].name == "STRIDED_SLICE":
+            _expect(tuple(t[ops[i].outputs[0]].shape[1:]) == (1, W, F), "frontend STRIDED_SLICE must keep [1, W, F]")
+            cur = ops[i].outputs[0]
+            i += 1
+        fill_value = q_zp
+        k_graph = F
+        if ops[i].name == "SHAPE":
+            j = i
+            while ops[j].name != "CONCATENATION":
+                _expect(ops[j].name in ("SHAPE", "STRIDED_SLICE", "PACK", "FILL"), f"{ops[j].name} in the channel-padding block")
+                if ops[j].name == "FILL":
+                    fill_value = int(np.asarray(g.const(ops[j].inputs[1])).reshape(-1)[0])
+                j += 1
+            cat = ops[j]
+            _expect(cat.inputs[0] == cur and cat.options["axis"] in (-1, 3), "CONCATENATION must pad the channel axis")
+            _expect(g.q(cat.inputs[0]) == g.q(cat.inputs[1]) == g.q(cat.outputs[0]), "CONCATENATION operands must share quantisation")
+            k_graph = int(t[cat.outputs[0]].shape[3])
+            cur = cat.outputs[0]
+            i = j + 1
 
-    plan = pk.Plan(pk.DTYPE_I8, pk.INPUT_SPECTROGRAM, F * W, F, W, int(t[model.outputs[0]].shape[-1]), meta={"tflite_ops": len(ops)})
-    pb = pk.PlanBuilder(plan)
-    tens = [pb.tensor(w_mel, np.int8), pb.tensor(bias, np.int32), pb.tensor(mult, np.int32), pb.tensor(shift, np.int32)]
-    norm_lut = lut if maxnorm is not None else None  # with the max normalisation the per-channel table sits behind the DIV, not behind the mixer
-    if maxnorm is not None:
+        # ---- mel mixer ------------------------------------------------------------------------
+        mel = ops[i]
+        _expect(mel.name == "CONV_2D" and mel.inputs[0] == cur, "mel mixer CONV_2D")
+        wt = t[mel.inputs[1]]
+        M = int(wt.shape[0])
+        _expect(tuple(wt.shape[1:3]) == (1, 1) and int(wt.shape[3]) == k_graph, "mel mixer must be 1x1 over the padded bins")
+        s_in, z_in = g.q(mel.inputs[0])
+        _expect((s_in, z_in) == (q_scale, q_zp), "mel mixer input quantisation")
+        s_mel, z_mel = g.q(mel.outputs[0])
+        Kp = (k_graph + K_ALIGN - 1) // K_ALIGN * K_ALIGN
+        w_mel = np.zeros((M, Kp), np.int8)
+        w_mel[:, :k_graph] = wt.data.reshape(M, k_graph)
+        bias = g.const(mel.inputs[2]).astype(np.int64) - z_in * w_mel.astype(np.int64).sum(axis=1)
+        mult, shift = qz.channel_multipliers(s_in, wt.scale, s_mel, M)
+        _expect_acc_range(w_mel, bias, 1, "mel mixer", mult, shift)
+        lo, hi = qz.activation_bounds(mel.options["activation"], s_mel, z_mel)
+        cur = mel.outputs[0]
+        i += 1
+
+        # ---- element-wise region up to the TRANSPOSE back ---------------------------------------
+        j = i
+        while ops[j].name != "TRANSPOSE":
+            j += 1
+        region = ops[i:j]
         lut = None
-    if lut is not None:
-        tens.append(pb.tensor(lut, np.int8))
-    mel_tile = pick_tile(1, W)
-    mfma_mel = fuse and mel_tile is not None and M % 16 == 0
-    # production plans quantise inside the mel mixer's load (i8_mel_mfma_kernel<QIN>: one pass over the float32 spectrogram, no int8
-    # copy of it in HBM); keep_all plans keep QUANTIZE as its own operator so that its tensor can be compared
-    quant_in_mel = mfma_mel and not keep_all and M == 64 and Kp % 64 == 0 and W % 64 == 0
-    v_q = pk.SLOT_INPUT
-    if not quant_in_mel:
-        v_q = pb.value(W * Kp)
-        pb.op(pk.I8_QUANT, pk.SLOT_INPUT, v_q, p=[F, W, Kp, q_zp, fill_value], f=[q_scale], name=f"t{mel.inputs[0]}",
-              out_shape=(W, Kp), out_dtype="int8")
-    v = pb.value(M * W)
-    if mfma_mel:
-        zero = pb.tensor(np.zeros(4, np.int32), np.int32)
-        p = [1, W, Kp, 1, 1, F if quant_in_mel else 0, 1, W, 0, 0, 0, 0, 0, 0, M, z_mel, lo, hi, *([0] * 11), 0, 1, *mel_tile, int(lut is not None),
-             0, int(quant_in_mel), q_zp, fill_value]
-        tt = [zero, zero, zero, zero, pb.tensor(pack_i8_fragments(w_mel), np.int8), tens[1], tens[2], tens[3]]
+        front_out = cur
+        maxnorm = None
+        if region and region[0].name == "REDUCE_MAX":
+            # per-sample max normalisation of current hybrid frontends (reference models/frontend.py:338-342): REDUCE_MAX over the whole map
+            # -> ADD epsilon -> DIV by that scalar.  Everything behind the maximum is a function of bytes: the denominator byte per maximum
+            # byte (the quantised ADD) and the DIV of every byte by every denominator byte become tables (models/_quant.py: div_table)
+            _expect(len(region) >= 3 and region[1].name == "ADD" and region[2].name == "DIV", "REDUCE_MAX must be followed by ADD and DIV")
+            rmax, addop, divop = region[:3]
+            axes = sorted(int(a) % 4 for a in np.atleast_1d(g.const(rmax.inputs[1])))
+            _expect(rmax.inputs[0] == cur and axes == [1, 2, 3] and g.q(rmax.outputs[0]) == g.q(cur), "REDUCE_MAX over the whole map, same quantisation")
+            _expect(rmax.outputs[0] in addop.inputs and divop.inputs[0] == cur and divop.inputs[1] == addop.outputs[0], "max normalisation wiring")
+            eps_i = [k for k in addop.inputs if k != rmax.outputs[0]]
+            _expect(len(eps_i) == 1 and t[eps_i[0]].data is not None and t[eps_i[0]].data.size == 1, "ADD of a scalar constant to the maximum")
+            eps_q = int(np.asarray(t[eps_i[0]].data).reshape(-1)[0])
+            (s_m, z_m), (s_e, z_e), (s_d, z_d) = g.q(rmax.outputs[0]), g.q(eps_i[0]), g.q(addop.outputs[0])
+            mx = np.arange(-128, 128, dtype=np.int64)
+            if addop.inputs[0] == rmax.outputs[0]:
+                den_tab = qz.AddParams(s_m, z_m, s_e, z_e, s_d, z_d, addop.options["activation"]).apply(mx, np.full(256, eps_q, np.int64))
+            else:
+                den_tab = qz.AddParams(s_e, z_e, s_m, z_m, s_d, z_d, addop.options["activation"]).apply(np.full(256, eps_q, np.int64), mx)
+            s_o, z_o = g.q(divop.outputs[0])
+            div_tab = qz.div_table(s_mel, z_mel, s_d, z_d, s_o, z_o, divop.options.get("activation", "none"))
+            maxnorm = (den_tab.astype(np.int8), div_tab)
+            region = region[3:]
+            cur = divop.outputs[0]
+            front_out = cur
+        if region:
+            front_out = ops[j].inputs[0]
+            lut = _pwl_table(g, region, cur, front_out, M)
+        _expect(list(g.const(ops[j].inputs[1])) == [0, 3, 2, 1], "TRANSPOSE [0,3,2,1] after the frontend")
+        cur = ops[j].outputs[0]
+        i = j + 1
+        if ops[i].name == "STRIDED_SLICE":
+            _expect(tuple(t[ops[i].outputs[0]].shape[1:]) == (M, W, 1), "post-frontend STRIDED_SLICE must keep [M, W, 1]")
+            cur = ops[i].outputs[0]
+            i += 1
+
+        plan = pk.Plan(pk.DTYPE_I8, pk.INPUT_SPECTROGRAM, F * W, F, W, int(t[model.outputs[0]].shape[-1]), meta={"tflite_ops": len(ops)})
+        pb = pk.PlanBuilder(plan)
+        tens = [pb.tensor(w_mel, np.int8), pb.tensor(bias, np.int32), pb.tensor(mult, np.int32), pb.tensor(shift, np.int32)]
+        norm_lut = lut if maxnorm is not None else None  # with the max normalisation the per-channel table sits behind the DIV, not behind the mixer
+        if maxnorm is not None:
+            lut = None
         if lut is not None:
-            tt.append(tens[4])
-        pb.op(pk.I8_DWPW, v_q, v, p=p, t=tt, f=[q_scale], name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
-    else:
-        pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
-              out_shape=(M, W, 1), out_dtype="int8")
-    if maxnorm is not None:
-        _expect(W % 4 == 0, "max normalisation kernel: map width must be a multiple of 4")
-        pb.plan.ops[-1].name = "mel_mixer"  # (its [W][M] graph tensor is not compared by name: the plan keeps [M][W])
-        v_n = pb.value(M * W)
-        tt = [pb.tensor(maxnorm[0], np.int8), pb.tensor(maxnorm[1], np.int8)] + ([pb.tensor(norm_lut, np.int8)] if norm_lut is not None else [])
-        pb.op(pk.I8_MAXNORM, v, v_n, p=[M, W, int(norm_lut is not None)], t=tt, name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
-        v = v_n
+            tens.append(pb.tensor(lut, np.int8))
+        mel_tile = pick_tile(1, W)
+        mfma_mel = fuse and mel_tile is not None and M % 16 == 0
+        # production plans quantise inside the mel mixer's load (i8_mel_mfma_kernel<QIN>: one pass over the float32 spectrogram, no int8
+        # copy of it in HBM); keep_all plans keep QUANTIZE as its own operator so that its tensor can be compared
+        quant_in_mel = mfma_mel and not keep_all and M == 64 and Kp % 64 == 0 and W % 64 == 0
+        v_q = pk.SLOT_INPUT
+        if not quant_in_mel:
+            v_q = pb.value(W * Kp)
+            pb.op(pk.I8_QUANT, pk.SLOT_INPUT, v_q, p=[F, W, Kp, q_zp, fill_value], f=[q_scale], name=f"t{mel.inputs[0]}",
+                  out_shape=(W, Kp), out_dtype="int8")
+        v = pb.value(M * W)
+        if mfma_mel:
+            zero = pb.tensor(np.zeros(4, np.int32), np.int32)
+            p = [1, W, Kp, 1, 1, F if quant_in_mel else 0, 1, W, 0, 0, 0, 0, 0, 0, M, z_mel, lo, hi, *([0] * 11), 0, 1, *mel_tile, int(lut is not None),
+                 0, int(quant_in_mel), q_zp, fill_value]
+            tt = [zero, zero, zero, zero, pb.tensor(pack_i8_fragments(w_mel), np.int8), tens[1], tens[2], tens[3]]
+            if lut is not None:
+                tt.append(tens[4])
+            pb.op(pk.I8_DWPW, v_q, v, p=p, t=tt, f=[q_scale], name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
+        else:
+            pb.op(pk.I8_MEL, v_q, v, p=[W, Kp, M, z_mel, lo, hi, int(lut is not None)], t=tens, name=f"t{cur}",
+                  out_shape=(M, W, 1), out_dtype="int8")
+        if maxnorm is not None:
+            _expect(W % 4 == 0, "max normalisation kernel: map width must be a multiple of 4")
+            pb.plan.ops[-1].name = "mel_mixer"  # (its [W][M] graph tensor is not compared by name: the plan keeps [M][W])
+            v_n = pb.value(M * W)
+            tt = [pb.tensor(maxnorm[0], np.int8), pb.tensor(maxnorm[1], np.int8)] + ([pb.tensor(norm_lut, np.int8)] if norm_lut is not None else [])
+            pb.op(pk.I8_MAXNORM, v, v_n, p=[M, W, int(norm_lut is not None)], t=tt, name=f"t{cur}", out_shape=(M, W, 1), out_dtype="int8")
+            v = v_n
     val = {cur: v}
     shape = {cur: (M, W, 1)}
     tail_blocks: list[dict] = []  # fused DW+PW blocks in graph order (candidates for the fused tail kernel)

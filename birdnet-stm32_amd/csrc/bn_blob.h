@@ -178,4 +178,9 @@ enum BnOpKind : int32_t {
     // p: C W has_lut   t: denominator byte per max byte (256), DIV table [256 denominators][256 values] (row/column = byte + 128),
     //    per-channel table [C][256] (has_lut)
     BN_OP_I8_MAXNORM = 32,
+    // raw frontend of an exported INT8 graph: QUANTIZE of the float32 waveform [T] -> [PAD] -> CONV_2D 1x16 stride s VALID (ReLU6 clamp)
+    // -> optional per-channel table (magnitude scaling) -> [M][W] int8
+    // p: T W M stride pad_left q_zp zp_out act_min act_max has_lut   f: q_scale
+    // t: weights [M][16] int8, bias (zero point of the input folded), multipliers, shifts, table [M][256] (has_lut)
+    BN_OP_I8_RAWFE = 33,
 };

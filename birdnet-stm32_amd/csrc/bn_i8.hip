@@ -99,6 +99,61 @@ __global__ __launch_bounds__(256) void i8_quant_kernel(const float* __restrict__
     }
 }
 
+// Raw frontend of an exported INT8 graph (reference models/frontend.py:138-164,347-358): QUANTIZE of the waveform -> [PAD] ->
+// CONV_2D 1 x 16, stride `stride`, VALID (BatchNorm folded, ReLU6 clamp) -> per-channel table of the magnitude scaling behind it ->
+// output transposed to [M][W].  A workgroup = 256 consecutive frames of one chunk; a thread owns four consecutive frames (one dword
+// of every output row) and quantises their 4 x 16 samples once; wave v walks the filters v, v + 4, ... (filter constants are
+// wave-uniform: scalar loads).  Samples outside the waveform are the zero point (the PAD's fill; the bias carries -zp sum(w)).
+__global__ __launch_bounds__(256) void i8_rawfe_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int T, int W, int M, int stride,
+                                                       int pad_left, float q_scale, int q_zp, int zp_out, int amin, int amax,
+                                                       const int8_t* __restrict__ w, const int32_t* __restrict__ bias,
+                                                       const int32_t* __restrict__ mult, const int32_t* __restrict__ shift,
+                                                       const int8_t* __restrict__ lut) {
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 256 + 4 * (threadIdx.x & 63);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (t0 >= W) return;
+    const float* xb = x + (size_t)b * T;
+    int32_t win[4][4];  // [frame][4 samples per dword]
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const long s0 = (long)(t0 + f) * stride - pad_left;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            int32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long si = s0 + 4 * d + e;
+                const int q = (si >= 0 && si < T && t0 + f < W) ? quant_one(xb[si], false, 0.f, 1.f, q_scale, q_zp) : q_zp;
+                packed |= (q & 0xff) << (8 * e);
+            }
+            win[f][d] = packed;
+        }
+    }
+    for (int m = wave; m < M; m += 4) {
+        const int32_t* wr = reinterpret_cast<const int32_t*>(w + (size_t)m * 16);
+        const int32_t w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+        const int32_t bm = bias[m], mm = mult[m], sm = shift[m];
+        int32_t packed = 0;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            int32_t acc = dot4(win[f][0], w0, bm);
+            acc = dot4(win[f][1], w1, acc);
+            acc = dot4(win[f][2], w2, acc);
+            acc = dot4(win[f][3], w3, acc);
+            int32_t q = clampi(mbqm(acc, mm, sm) + zp_out, amin, amax);
+            if (lut) q = lut[m * 256 + q + 128];
+            packed |= (q & 0xff) << (8 * f);
+        }
+        int8_t* dst = y + ((size_t)b * M + m) * W + t0;
+        if (t0 + 3 < W) {
+            *reinterpret_cast<int32_t*>(dst) = packed;
+        } else {
+            for (int f = 0; f < 4 && t0 + f < W; ++f) dst[f] = (int8_t)(packed >> (8 * f));
+        }
+    }
+}
+
 // mel mixer (CONV_2D 1x1 over Kp frequency columns) + ReLU clamp + the PWL chain as a per-channel
 // 256-entry table; output transposed to [M][W].  One thread = one (t, m); lanes run along t.
 __global__ void i8_mel_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int W, int Kp, int M, int zp_out,
@@ -568,6 +623,12 @@ void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int 
                      int amin, int amax, hipStream_t s) {
     const long total = (long)B * P * (C / 4);
     hipLaunchKernelGGL(i8_scale_kernel, grid1d(total, 256), dim3(256), 0, s, x, gate, y, P, C, zx, zg, mult, shift, zo, amin, amax, total);
+}
+
+void launch_i8_rawfe(const float* x, int8_t* y, int B, int T, int W, int M, int stride, int pad_left, float q_scale, int q_zp, int zp_out, int amin,
+                     int amax, const int8_t* w, const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut, hipStream_t s) {
+    hipLaunchKernelGGL(i8_rawfe_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, x, y, T, W, M, stride, pad_left, q_scale, q_zp, zp_out, amin, amax, w,
+                       bias, mult, shift, lut);
 }
 
 void launch_i8_maxnorm(const int8_t* x, int8_t* y, int B, int C, int W, const int8_t* den_tab, const int8_t* div_tab, const int8_t* lut, hipStream_t s) {

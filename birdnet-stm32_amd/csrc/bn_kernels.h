@@ -177,6 +177,8 @@ void launch_i8_segate(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in
 void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int P, int C, int zx, int zg, int mult, int shift, int zo,
                      int amin, int amax, hipStream_t s);
 // per-chunk max -> denominator byte -> DIV table row [-> per-channel table]: [C][W] int8 -> [C][W] int8 (W a multiple of 4)
+void launch_i8_rawfe(const float* x, int8_t* y, int B, int T, int W, int M, int stride, int pad_left, float q_scale, int q_zp, int zp_out, int amin,
+                     int amax, const int8_t* w, const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut, hipStream_t s);
 void launch_i8_maxnorm(const int8_t* x, int8_t* y, int B, int C, int W, const int8_t* den_tab, const int8_t* div_tab, const int8_t* lut, hipStream_t s);
 void launch_i8_head_softmax(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, float s_fc, float beta, hipStream_t s);
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,

@@ -210,6 +210,12 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                     c.tensor(0, 256, "denominator table") && c.tensor(1, 65536, "division table") && (!p[2] || c.tensor(2, 256LL * p[0], "channel table"));
                 if (c.ok && p[1] % 4) c.bad("map width %d is not a multiple of 4 (the kernel reads dwords of one channel)", p[1]);
                 break;
+            case BN_OP_I8_RAWFE:  // T W M stride pad_left q_zp zp_out act_min act_max has_lut
+                c.dims({p[0], p[1], p[2], p[3]}, "raw frontend") && c.slot(o.in0, 4LL * p[0], "waveform") && c.slot(o.out, 1LL * p[2] * p[1], "output") &&
+                    c.tensor(0, 16LL * p[2], "filterbank") && c.tensor(1, 4LL * p[2], "bias") && c.tensor(2, 4LL * p[2], "multipliers") &&
+                    c.tensor(3, 4LL * p[2], "shifts") && (!p[9] || c.tensor(4, 256LL * p[2], "table"));
+                if (c.ok && p[4] < 0) c.bad("negative left padding");
+                break;
             case BN_OP_I8_HEAD:  // C zp_fc zp_out has_lut
                 c.dims({p[0]}, "head") && c.slot(o.in0, 1LL * p[0], "input") && c.slot(o.out, 4LL * p[0], "scores") && (!p[3] || c.tensor(0, 256, "table"));
                 if (c.ok && p[0] != (int)h.num_classes) c.bad("classifier width %d, header says %u classes", p[0], h.num_classes);

@@ -25,7 +25,8 @@ Conventions restated:
       Newton-Raphson (GetReciprocal: x2 normalised to [1, 2), three iterations from 48/17 - 32/17 d, Q0.31 result + exponent);
       quotient = SRDHM(x1 << headroom(x1), reciprocal), then MBQM with s1 / (s2 so) and the collected shifts, + zo, clamp.
       A zero divisor (undefined in TFLite: debug assertion) is taken as 1 here — a silent chunk divides 0 by it
-* TRANSPOSE / STRIDED_SLICE / SHAPE / PACK / FILL / CONCATENATION are exact data movement.
+* TRANSPOSE / STRIDED_SLICE / SHAPE / PACK / FILL / CONCATENATION / RESHAPE are exact data movement; PAD fills with the zero point
+      (real 0.0).  Convolutions: SAME (TensorFlow's asymmetric padding) or VALID (the raw frontend's 1 x 16 filterbank).
 """
 
 from __future__ import annotations
@@ -208,8 +209,8 @@ class Int8Interpreter:
         s_in, zp_in = self._q(op.inputs[0])
         s_out, zp_out = self._q(op.outputs[0])
         o = op.options
-        if o["padding"] != "SAME" or o.get("dilation_w", 1) != 1 or o.get("dilation_h", 1) != 1:
-            raise ValueError("only SAME, undilated convolutions occur in the reference graphs")
+        if o["padding"] not in ("SAME", "VALID") or o.get("dilation_w", 1) != 1 or o.get("dilation_h", 1) != 1:
+            raise ValueError("only undilated convolutions occur in the reference graphs")
         sh, sw = o["stride_h"], o["stride_w"]
         B, H, W, Cin = x.shape
         if depthwise:
@@ -223,8 +224,12 @@ class Int8Interpreter:
             mult, shift = _per_channel_multipliers(s_in, wt.scale, s_out, cout)
             self._prep[key] = {"mult": mult, "shift": shift, "act": activation_range(o["activation"], s_out, zp_out)}
         p = self._prep[key]
-        oh, pt, pb = _same(H, kh, sh)
-        ow, pl, pr = _same(W, kw, sw)
+        if o["padding"] == "SAME":
+            oh, pt, pb = _same(H, kh, sh)
+            ow, pl, pr = _same(W, kw, sw)
+        else:  # VALID (the raw frontend's 1 x 16 filterbank, reference models/frontend.py:147-155): no padding, floor((in - k) / s) + 1 outputs
+            oh, pt, pb = (H - kh) // sh + 1, 0, 0
+            ow, pl, pr = (W - kw) // sw + 1, 0, 0
         xc = x - zp_in  # padded cells contribute (zp - zp) = 0, as the reference kernels skip them
         xp = np.pad(xc, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
         acc = np.zeros((B, oh, ow, cout), dtype=np.int64)
@@ -397,6 +402,15 @@ class Int8Interpreter:
                 if len(qs) != 1:
                     raise ValueError("CONCATENATION with differing quantisation needs requantisation")
                 y = np.concatenate(parts, axis=op.options["axis"])
+            elif n == "RESHAPE":
+                xin = self._value(env, op.inputs[0])  # (the graph states batch 1; the batch dimension follows the input here)
+                y = xin.reshape([xin.shape[0]] + [int(v) for v in self._value(env, op.inputs[1])][1:])
+            elif n == "PAD":  # int8 PAD fills with the zero point (real 0.0): TFLite reference_ops::Pad with pad_value = output zero point
+                s_, zp = self._q(op.outputs[0])
+                if self._q(op.inputs[0]) != (s_, zp):
+                    raise ValueError("PAD input and output must share quantisation")
+                pads = [(int(a), int(b)) for a, b in np.asarray(self._value(env, op.inputs[1])).reshape(-1, 2)]
+                y = np.pad(self._value(env, op.inputs[0]), pads, constant_values=zp)
             elif n == "CONV_2D":
                 y = self._conv(op, env, depthwise=False)
             elif n == "DEPTHWISE_CONV_2D":

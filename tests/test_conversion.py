@@ -204,6 +204,11 @@ EXPORT_TOPOLOGIES = {
     # current hybrid frontends: per-sample max normalisation (REDUCE_MAX -> ADD epsilon -> DIV) in front of the PWL
     "maxnorm_pwl_ds": dict(use_inverted_residual=False, use_se=False, frontend_norm=True),
     "maxnorm_nomag_ir": dict(use_se=False, mag_scale="none", alpha=0.5, frontend_norm=True),
+    # raw frontend (QUANTIZE of the waveform -> [PAD] -> RESHAPE -> CONV_2D 1x16 strided VALID): BASELINE configs[4]'s frontend with PCEN, and a
+    # geometry whose chunk is shorter than stride * (W - 1) + 16 samples (symmetric zero padding in front of the filterbank)
+    "raw_pcen_ir_se": dict(audio_frontend="raw", mag_scale="pcen", chunk_duration=2, alpha=0.5),
+    "raw_pad_nomag_ds": dict(audio_frontend="raw", mag_scale="none", sample_rate=6000, chunk_duration=0.5, spec_width=128, num_mels=32,
+                             use_se=False, use_inverted_residual=False),
 }
 
 
@@ -220,7 +225,10 @@ def _export(kw, n_cal=4, seed=0):
     spec = build_model("dscnn", **args)
     spec.frontend.attrs["norm"] = norm
     chunks = synth_chunks(n_cal + 3, sr=args["sample_rate"], seconds=args["chunk_duration"], seed=seed + 3)
-    x = np.stack([stft.hybrid_spectrogram(a, spec_width=args["spec_width"]) for a in chunks])[..., None].astype(np.float32)
+    if args.get("audio_frontend") == "raw":  # the host side of the raw frontend: x / (max |x| + 1e-6) (reference evaluation/metrics.py:62-69)
+        x = np.stack([a / (np.abs(a).max() + 1e-6) for a in chunks])[..., None].astype(np.float32)
+    else:
+        x = np.stack([stft.hybrid_spectrogram(a, spec_width=args["spec_width"]) for a in chunks])[..., None].astype(np.float32)
     graph = convert_netspec_to_int8(spec, lambda: ([x[i : i + 1]] for i in range(n_cal)), frontend_norm=norm)
     raw = write_tflite(graph)
     return spec, parse_tflite(raw), raw, x
@@ -238,7 +246,7 @@ def test_exported_int8_graph_tracks_the_float_model(name):
     assert raw[4:8] == b"TFL3" and model.ops[0].name == "QUANTIZE" and model.tensors[model.inputs[0]].dtype == np.float32
     names = {op.name for op in model.ops}
     assert names <= {"QUANTIZE", "TRANSPOSE", "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "MUL", "MEAN", "FULLY_CONNECTED", "LOGISTIC", "DEQUANTIZE", "SOFTMAX",
-                     "REDUCE_MAX", "DIV"}
+                     "REDUCE_MAX", "DIV", "RESHAPE", "PAD"}
     if EXPORT_TOPOLOGIES[name].get("frontend_norm"):
         assert {"REDUCE_MAX", "DIV"} <= names
         div = next(op for op in model.ops if op.name == "DIV")
@@ -329,8 +337,8 @@ def test_exporter_refuses_what_it_cannot_express():
     from birdnet_stm32.models import build_model
 
     args = dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=10)
-    with pytest.raises(NotImplementedError, match="hybrid frontend"):
-        netspec_to_graph(build_model("dscnn", audio_frontend="raw", **args))
+    with pytest.raises(NotImplementedError, match="hybrid and raw frontends"):
+        netspec_to_graph(build_model("dscnn", audio_frontend="librosa", **args))
     with pytest.raises(NotImplementedError, match="attention pooling"):
         netspec_to_graph(build_model("dscnn", use_attention_pooling=True, **args), frontend_norm=False)
 
