@@ -411,7 +411,31 @@ def lower_f32(spec: ns.NetSpec, keep_all: bool = False, fuse: bool = True) -> pk
             raise NotImplementedError(f"layer {ly.name} of kind {k} cannot be lowered on its own")
     if fuse and not keep_all:
         _tag_front2(pb)
+        _tag_pwdw(pb)
     return pb.finalize(reuse=not keep_all)
+
+
+def _tag_pwdw(pb: pk.PlanBuilder) -> None:
+    """Mark (expand 1x1, depthwise 3x3) pairs of inverted-residual blocks (reference models/blocks.py:88-110) that the library may run as
+    ONE kernel (``f32_pwdw_kernel``): the depthwise stage directly follows, is the only reader of the expanded map, and nothing gates
+    or adds to the expand convolution.  The fused kernel reads the block input while it writes the depthwise output: no slot sharing."""
+    ops = pb.plan.ops
+    gate_slots = {ops[oi].p[pi] for oi, pi in pb._gate_refs}
+    for i in range(len(ops) - 1):
+        e, d = ops[i], ops[i + 1]
+        if not (e.kind == pk.F32_DWPW and e.p[15] == 0 and e.p[12] == 0 and e.p[13] == 0 and d.kind == pk.F32_DW and d.in0 == e.out and e.out >= 0):
+            continue
+        if e.p[pk.TAIL_TAG] or d.p[pk.TAIL_TAG] or e.p[pk.OP_PATH] != d.p[pk.OP_PATH]:
+            continue
+        v = e.out
+        readers = [k for k, r in enumerate(ops) if k != i + 1 and (r.in0 == v or r.in1 == v)]
+        writers = [k for k, r in enumerate(ops) if r.out == v]
+        if readers or writers != [i] or v in gate_slots or d.p[2] != e.p[10] or (d.p[0], d.p[1]) != (e.p[6], e.p[7]):
+            continue
+        e.p[pk.TAIL_TAG] = pk.PWDW_HEAD
+        d.p[pk.TAIL_TAG] = pk.PWDW_COVERED
+        if e.in0 >= 0:
+            pb._extra_uses.append((i + 1, e.in0))
 
 
 def _tag_front2(pb: pk.PlanBuilder) -> None:

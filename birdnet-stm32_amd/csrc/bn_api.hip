@@ -46,7 +46,7 @@ struct OptName {
 };
 const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
-    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"front_tpw", &bn::Options::front_tpw},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
@@ -172,6 +172,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
     };
     const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
     if (op_end > m->ops.size()) op_end = m->ops.size();
+    size_t pwdw_done = (size_t)-1;    // depthwise stage that ran inside the expand convolution in front of it
     size_t front2_done = (size_t)-1;  // operator that the fused front kernel of this run has already covered
     auto dwpw_args = [&](const OpRec& d) {
         bn::DwPwArgs a{};
@@ -218,7 +219,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
-        if (oi == front2_done || oi == scale_done || oi == segate_done[0] || oi == segate_done[1]) continue;  // ran inside a preceding operator's kernel
+        if (oi == front2_done || oi == pwdw_done || oi == scale_done || oi == segate_done[0] || oi == segate_done[1]) continue;  // ran inside a preceding operator's kernel
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
@@ -267,6 +268,18 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 break;
             case BN_OP_F32_DWPW: {
                 const bn::DwPwArgs a = dwpw_args(o);
+                if (p[BN_OP_TAIL_TAG] == BN_PWDW_HEAD && bn::g_opt.f32_pwdw && bn::g_opt.f32_strip && oi + 1 < op_end) {
+                    // inverted-residual block: the expand convolution runs inside the depthwise kernel behind it (the expanded map stays in LDS)
+                    const OpRec& d = m->ops[oi + 1];
+                    const int* q = d.p;
+                    if (d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out &&
+                        bn::f32_pwdw_supported(a, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&
+                        bn::launch_f32_pwdw(a, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7], q[8],
+                                            q[9], q[5], s)) {
+                        pwdw_done = oi + 1;
+                        break;
+                    }
+                }
                 if (!bn::f32_dwpw_supported(a.Cin, a.Cout) || (a.has_dw && a.Cin % 16) || a.TH * a.TW * a.NB != 64 || a.OH % a.TH || a.OW % a.TW)
                     return fail(BN_ERR_FORMAT, "operator %zu: unsupported fused block geometry", oi);
                 bn::launch_f32_dwpw(a, s);
@@ -1050,7 +1063,7 @@ int bn_get_option(const char* name, int* value) {
 
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
-           "f32_pw_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
+           "f32_pw_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }

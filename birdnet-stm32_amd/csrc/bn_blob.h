@@ -76,6 +76,10 @@ struct TensorRec {
 // squeeze-excite gate, each the only reader of its predecessor: pooling and both layers may run as one kernel per chunk.
 #define BN_SEGATE_HEAD 0x7A110007
 #define BN_SEGATE_COVERED 0x7A110008
+// BN_PWDW_HEAD on a plain 1x1 BN_OP_F32_DWPW operator (the expand convolution of an inverted-residual block): the next operator
+// (BN_OP_F32_DW, tagged BN_PWDW_COVERED) is the only reader of its output and may run inside the same kernel (f32_pwdw_kernel)
+#define BN_PWDW_HEAD 0x7A110009
+#define BN_PWDW_COVERED 0x7A11000A
 
 #define BN_OP_NP 40
 #define BN_OP_NT 16

@@ -762,6 +762,217 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Inverted-residual blocks (reference models/blocks.py:88-110): expand 1x1 (+bias, activation) -> depthwise 3x3 stride S (+bias,
+// activation) in ONE kernel.  The expanded map is the largest tensor of the block (hid = 2 Cin channels at the INPUT resolution:
+// 1.5 MB per chunk in stage 1); written by one kernel and read back by the next it is two thirds of the pair's HBM traffic.  Here a
+// workgroup owns RB output rows of one chunk and walks down the rows, ten waves in three roles that meet at ONE barrier per hidden row:
+//   * loaders (waves 8-9): keep three input rows in flight (768 float4 per row, six per thread) and copy the row that arrived two
+//     steps after its request into a three-row staging ring in LDS ([W][Cin + 4]);
+//   * producers (waves 0-3): hidden row = W positions x hid channels on the f32 matrix cores.  Every wave owns two position tiles x
+//     three channel tiles (W x hid = 6144 in every stage of the alpha = 1.5 net: 128 x 48, 64 x 96, 32 x 192), its A fragments (the
+//     packer's fragment-ordered weights) pinned in registers for the whole walk, B fragments read from the staging ring (one
+//     16-byte LDS read per lane and 16 channels), the six accumulator chains interleaved; the finished row goes into a four-row ring
+//     in LDS, position-major with a pitch of hid + 4 floats and zero border columns (the SAME padding of the hidden map; 16-byte
+//     tile writes and tap reads both spread over all banks);
+//   * consumers (waves 4-7): a thread owns ONE channel quad (nine taps + bias in registers) and every (240 / quads)-th column, the
+//     quad running along the lanes: nine 16-byte LDS reads in flight, the summation order of f32_dw_stream_kernel, one 16-byte store
+//     coalesced along the channels.
+// At step t the producers write hidden row t while the consumers run the output row that ends at hidden row t - 1.
+// Measured (configs[4], 1024 chunks): the six pairs it takes 3.18 -> 1.79 ms (3.0 TB/s on the 2 : 1 write-heavy traffic that is left,
+// matrix pipe 35 % busy).  Variants that changed nothing (within 3 %): the producers loading their own B fragments one or two rows
+// ahead, the epilogue of row t between the matrix instructions of row t + 1, chains not interleaved.  Slower: two sequential
+// workgroups per CU without roles (2.1 ms), taps behind per-lane bounds tests (2.4 ms: nine dependent LDS round trips per output).
+struct F32PwDwArgs {
+    const float* x;       // [B][H][W][Cin]
+    float* y;             // [B][OH][OW][hid]
+    const float* pw_w;    // fragment order [Kp/16][hid/16][64][4]
+    const float* pw_b;    // [hid]
+    const float* dw_w;    // [3][3][hid]
+    const float* dw_b;    // [hid]
+    int B, H, W, Cin, hid, OH, OW, pt, pl, pw_act, dw_act, RB;
+};
+
+template <int NJ, int S>
+__global__ __launch_bounds__(640) void f32_pwdw_kernel(F32PwDwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ring3[];  // [4][W + 2][hid + 4] (column hx at index hx + 1), then [3][W][Cin + 4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int P = a.hid + 4, PI = a.Cin + 4;
+    float* stage = ring3 + 4 * (a.W + 2) * P;
+    const int rblocks = (a.OH + a.RB - 1) / a.RB;
+    const int wid = xcd_tile(blockIdx.x, gridDim.x);
+    const int ry = wid % rblocks, chunk = wid / rblocks;
+    const int oh0 = ry * a.RB;
+    const int nrows = (a.OH - oh0) < a.RB ? (a.OH - oh0) : a.RB;
+    const int h_lo = S * oh0 - a.pt;
+    const int nhid = S * (nrows - 1) + 3;          // hidden rows h_lo .. h_lo + nhid - 1 (those outside the map are skipped)
+    const int nsteps = nhid + 1;
+    auto row_ok = [&](int k) { return k >= 0 && k < nhid && h_lo + k >= 0 && h_lo + k < a.H; };
+
+    for (int i = tid; i < 8 * P; i += 640) {       // border columns of the four ring slots
+        const int slot = i / (2 * P), rest = i - slot * 2 * P;
+        ring3[(slot * (a.W + 2) + (rest < P ? 0 : a.W + 1)) * P + (rest % P)] = 0.0f;
+    }
+
+    if (w < 4) {
+        // ------------------------------------------------------------------------------------------------ producers
+        const int npp = a.W >> 5;
+        const int pp = w % npp, tc = w / npp;      // positions 32 pp + 16 u + n, hidden channels 48 tc + 16 c + 4 kq + e
+        const int nct = a.hid >> 4;
+        const ActBounds pw_bounds = act_bounds(a.pw_act);
+        v4f pa[3][NJ], pbias[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) pa[c][j] = reinterpret_cast<const v4f*>(a.pw_w)[(j * nct + 3 * tc + c) * 64 + lane];
+            pbias[c] = *reinterpret_cast<const v4f*>(a.pw_b + 48 * tc + 16 * c + 4 * kq);
+        }
+        bool chan_ok[NJ];                           // channels beyond Cin: the zero-padded k-step of Cin = 24
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) chan_ok[j] = 16 * j + 4 * kq < a.Cin;
+        const int src_off = (32 * pp + n) * PI + 4 * kq;
+        const int dst_off = (1 + 32 * pp + n) * P + 48 * tc + 4 * kq;
+        __syncthreads();                            // staging row 0 and the ring's border columns are in place
+        for (int t = 0; t < nsteps; ++t) {
+            if (row_ok(t)) {
+                const float* src = stage + (t % 3) * a.W * PI + src_off;
+                v4f bf[2][NJ];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        bf[u][j] = chan_ok[j] ? *reinterpret_cast<const v4f*>(src + 16 * u * PI + 16 * j) : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                float* dst = ring3 + (((h_lo + t) & 3) * (a.W + 2)) * P + dst_off;
+                v4f acc[2][3];  // the six tiles' chains interleaved: consecutive matrix instructions never depend on each other
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[u][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) mfma_acc(acc[u][c], pa[c][j][g], bf[u][j][g]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)  // bias behind the sum, as the stand-alone 1x1 kernels add it: the pair stays bit-identical to them
+                        *reinterpret_cast<v4f*>(dst + 16 * u * P + 16 * c) = act4(acc[u][c] + pbias[c], pw_bounds);
+            }
+            __syncthreads();
+        }
+    } else if (w < 8) {
+        // ------------------------------------------------------------------------------------------------ consumers
+        const int dt = tid - 256;
+        const ActBounds dw_bounds = act_bounds(a.dw_act);
+        const int quads = a.hid >> 2;
+        const int groups = 240 / quads;
+        const bool dw_live = dt < 240;
+        const int q = dw_live ? dt % quads : 0, cg = dw_live ? dt / quads : 0;
+        v4f wt[3][3], dwb = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) wt[dy][dx] = dw_live ? *reinterpret_cast<const v4f*>(a.dw_w + (dy * 3 + dx) * a.hid + 4 * q) : dwb;
+        if (dw_live) dwb = *reinterpret_cast<const v4f*>(a.dw_b + 4 * q);
+        float* ybase = a.y + ((size_t)chunk * a.OH) * a.OW * a.hid + 4 * q;
+        auto depthwise = [&](int oh) {
+            if (!dw_live) return;
+            const int hr0 = S * oh - a.pt;
+            const float* rows[3];
+            bool rok[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int hr = hr0 + dy;
+                rok[dy] = hr >= 0 && hr < a.H;
+                rows[dy] = ring3 + (size_t)((rok[dy] ? hr & 3 : 0) * (a.W + 2) + 1 - a.pl) * P + 4 * q;  // tap dx of output column ox at [(S ox + dx) P]
+            }
+            const bool interior = rok[0] && rok[1] && rok[2];
+            for (int ox = cg; ox < a.OW; ox += groups) {
+                const int off = S * ox * P;
+                v4f acc = dwb;
+                if (interior) {  // nine loads in flight, then the same summation order as below
+                    v4f v[3][3];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) v[dy][dx] = *reinterpret_cast<const v4f*>(rows[dy] + off + dx * P);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) acc = __builtin_elementwise_fma(v[dy][dx], wt[dy][dx], acc);
+                } else {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+                            if (rok[dy]) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(rows[dy] + off + dx * P), wt[dy][dx], acc);
+                }
+                *reinterpret_cast<v4f*>(ybase + ((size_t)oh * a.OW + ox) * a.hid) = act4(acc, dw_bounds);
+            }
+        };
+        __syncthreads();
+        for (int t = 0; t < nsteps; ++t) {
+            if (t >= 3 && (t - 3) % S == 0) depthwise(oh0 + (t - 3) / S);
+            __syncthreads();
+        }
+    } else {
+        // ------------------------------------------------------------------------------------------------ loaders (two waves)
+        // keep THREE input rows in flight (a row is W Cin / 4 = 768 float4: six per thread): row t + 3 is requested at step t and copied
+        // into the staging ring at step t + 2, two steps later — the HBM latency (~2 k cycles) is longer than a step.  Row indices are
+        // clamped into the map instead of tested: no branch between the loads, so the waits on a register set count exactly the two
+        // younger sets; rows outside the map are never read by the producers.
+        const int lt = tid - 512;
+        const int cq4 = a.Cin >> 2;
+        const float* xc = a.x + ((size_t)chunk * a.H) * a.W * a.Cin + 4 * lt;
+        int st_off[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int idx = lt + 128 * e, pos = idx / cq4;
+            st_off[e] = pos * PI + 4 * (idx - pos * cq4);
+        }
+        auto request = [&](v4f (&r)[6], int k) {
+            int hr = h_lo + k;
+            hr = hr < 0 ? 0 : (hr >= a.H ? a.H - 1 : hr);
+            const float* src = xc + (size_t)hr * a.W * a.Cin;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const v4f*>(src + 512 * e);
+        };
+        auto deposit = [&](const v4f (&r)[6], int k) {
+            float* dst = stage + (k % 3) * a.W * PI;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) *reinterpret_cast<v4f*>(dst + st_off[e]) = r[e];
+        };
+        v4f r0[6], r1[6], r2[6];
+        request(r0, 0);
+        request(r1, 1);
+        request(r2, 2);
+        deposit(r0, 0);
+        __syncthreads();
+        for (int t = 0; t < nsteps; t += 3) {       // at the top of step t: staging slot t % 3 holds row t, rows t + 1 and t + 2 are in flight
+            request(r0, t + 3);
+            deposit(r1, t + 1);
+            __syncthreads();
+            if (t + 1 < nsteps) {
+                request(r1, t + 4);
+                deposit(r2, t + 2);
+                __syncthreads();
+            }
+            if (t + 2 < nsteps) {
+                request(r2, t + 5);
+                deposit(r0, t + 3);
+                __syncthreads();
+            }
+        }
+    }
+}
+
 template <int NW, int COUT, int S, bool RES>
 void launch_strip(const DwPwArgs& a, hipStream_t s) {
     const long strips = (long)a.B * (a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
@@ -798,6 +1009,42 @@ bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, 
     else
         hipLaunchKernelGGL(f32_dw_stream_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
     return true;
+}
+
+// expand 1x1 + depthwise 3x3 of an inverted-residual block as one kernel (f32_pwdw_kernel): four waves x (2 position tiles x 3 channel tiles)
+bool f32_pwdw_supported(const DwPwArgs& e, int dH, int dW, int dC, int dsh, int dsw, int dOH, int dOW) {
+    if (e.has_dw || e.res || e.gate || e.H != e.OH || e.W != e.OW || e.Cout != dC || e.H != dH || e.W != dW) return false;
+    if (dsh != dsw || (dsh != 1 && dsh != 2) || dW % 32 || dC % 48 || (dW / 32) * (dC / 48) != 4 || e.Cin % 4 || 240 % (dC / 4)) return false;
+    const int nj = (e.Cin + 15) / 16;
+    if (nj != 2 && nj != 3 && nj != 6) return false;
+    if (dOH != (dH + dsh - 1) / dsh || dOW != (dW + dsw - 1) / dsw) return false;
+    const size_t smem = ((size_t)4 * (dW + 2) * (dC + 4) + (size_t)3 * dW * (e.Cin + 4)) * sizeof(float);
+    return smem <= 156 * 1024 && dW * e.Cin == 3072 && (long)e.H * e.W * e.Cin * 4 < 0x7fff0000L;
+}
+
+bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
+                     hipStream_t s) {
+    const size_t smem = ((size_t)4 * (e.W + 2) * (e.Cout + 4) + (size_t)3 * e.W * (e.Cin + 4)) * sizeof(float);
+    int rb = dOH;
+    while (rb > 16) rb = (rb + 1) / 2;
+    F32PwDwArgs a{e.x, y, e.pw_w, e.pw_b, dw_w, dw_b, e.B, e.H, e.W, e.Cin, e.Cout, dOH, dOW, dpt, dpl, e.pw_act, dw_act, rb};
+    const unsigned blocks = (unsigned)((long)e.B * ((dOH + rb - 1) / rb));
+    const int nj = (e.Cin + 15) / 16;
+#define BN_PWDW(NJV, SV)                                                                                                                    \
+    if (nj == NJV && dsh == SV) {                                                                                                           \
+        static size_t allowed = 0;                                                                                                          \
+        if (smem > allowed) {                                                                                                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(f32_pwdw_kernel<NJV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                    (int)smem) != hipSuccess)                                                                               \
+                return false;                                                                                                               \
+            allowed = smem;                                                                                                                 \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV>), dim3(blocks), dim3(640), smem, s, a);                                                \
+        return true;                                                                                                                        \
+    }
+    BN_PWDW(2, 1) BN_PWDW(2, 2) BN_PWDW(3, 1) BN_PWDW(3, 2) BN_PWDW(6, 1) BN_PWDW(6, 2)
+#undef BN_PWDW
+    return false;
 }
 
 bool f32_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW) {

@@ -16,6 +16,7 @@ struct Options {
     int f32_strip = 1;         // float32 row-streaming strip kernels (0: tile kernels everywhere)
     int f32_strip_th = 0;      // force the rows per strip (0: the launcher's choice)
     int f32_front_staged = 1;  // LDS-staged form of the float32 front strip kernel
+    int f32_pwdw = 1;          // expand 1x1 + depthwise 3x3 of inverted-residual blocks as one kernel (the expanded map stays in LDS)
     int f32_front2 = 1;        // front block + first residual block as one kernel (the map between them stays in LDS)
     int front_tpw = 0;         // tiles per workgroup of the float32 front tile kernel (0: auto)
     int wave_dwpw = 1;         // wave-autonomous variant of the small float32 fused block
@@ -138,6 +139,9 @@ bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, 
 bool f32_strip_supported(const DwPwArgs& a);
 void launch_f32_strip(DwPwArgs a, hipStream_t s);
 // front block + the residual block behind it (32 -> 32, stride 1) in one kernel, the map between them in LDS (bn_f32_strip.hip)
+bool f32_pwdw_supported(const DwPwArgs& expand, int dH, int dW, int dC, int dsh, int dsw, int dOH, int dOW);
+bool launch_f32_pwdw(const DwPwArgs& expand, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
+                     hipStream_t s);
 bool f32_front2_supported(const F32FrontStripArgs& f, const DwPwArgs& d);
 bool launch_f32_front2(const F32FrontStripArgs& f, const DwPwArgs& d, hipStream_t s);
 

@@ -364,6 +364,54 @@ def test_f32_front2_fused_kernel_matches_the_two_strip_kernels(torch_mod):
     runner.close()
 
 
+# --------------------------------------------------------------------------------------- float32: expand 1x1 + depthwise 3x3 as one kernel
+def test_f32_pwdw_fused_kernel_matches_the_two_kernels(torch_mod):
+    """``f32_pwdw_kernel`` (inverted-residual blocks: the expand convolution runs inside the depthwise kernel, the expanded map stays in
+    LDS) against the two-kernel path (option ``f32_pwdw`` = 0) on BASELINE configs[4]'s topology (alpha = 1.5: all three fused shapes,
+    stride 1 and 2, the zero-padded k-step of Cin = 24): BIT FOR BIT (same summation orders), odd batch sizes, repeated launches; and against
+    the float64 oracle."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle import float_graph
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+    runner = HipRunner(lower_f32(spec), max_batch=70)
+    ops = runner.plan.ops
+    heads = [i for i, o in enumerate(ops) if o.p[pk.TAIL_TAG] == pk.PWDW_HEAD]
+    assert len(heads) == 11 and all(ops[i].kind == pk.F32_DWPW and ops[i + 1].kind == pk.F32_DW and ops[i + 1].p[pk.TAIL_TAG] == pk.PWDW_COVERED
+                                    and ops[i + 1].out != ops[i].in0 for i in heads)  # every inverted-residual block is tagged
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((70, 48000)).astype(np.float32)
+    x /= np.abs(x).max(axis=1, keepdims=True) + 1e-6
+    xd = torch.from_numpy(x).cuda()
+    with _hip.options(f32_pwdw=0):
+        base_s, base_l = (t.clone() for t in runner.predict_device(xd, return_logits=True))
+        runner.profile(True)
+        runner.predict_device(xd)
+        rows0 = [r for r in runner.profile_collect() if r["launches"]]
+        runner.profile(False)
+    runner.profile(True)
+    runner.predict_device(xd)
+    rows = [r for r in runner.profile_collect() if r["launches"]]
+    runner.profile(False)
+    fused = len(rows0) - len(rows)
+    assert fused == 6, fused  # stages 1-2 and the first block of stage 3 (input maps 32+ columns wide); the narrow late stages keep two kernels
+    for rep in range(4):
+        for nb in (70, 1, 3, 64, 65):
+            s, l = runner.predict_device(xd[:nb], return_logits=True)
+            assert torch.equal(s, base_s[:nb]) and torch.equal(l, base_l[:nb]), f"batch {nb}, launch {rep}"  # same summation orders: bit for bit
+    ref = float_graph.forward(spec, x[:6, :, None], np.float64)
+    got = runner.predict_device(xd[:6]).cpu().numpy()
+    for b in range(6):
+        assert cosine(got[b], ref[b]) > 1 - 1e-6
+    runner.close()
+
+
 # --------------------------------------------------------------------------------------- INT8: row-streaming depthwise kernel
 def test_i8_dw_stream_kernel_matches_the_baseline_kernel(torch_mod):
     """``i8_dw_stream_kernel`` (stand-alone depthwise 3x3 of exported inverted-residual graphs, stride 1 and 2, channel counts that

@@ -285,7 +285,7 @@ def test_launcher_options_round_trip_without_a_device():
     default, values round-trip, unknown names are refused, and no launcher reads the environment any more."""
     from birdnet_stm32 import _hip
 
-    defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "f32_front2": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_th": 0,
+    defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "f32_front2": 1, "f32_pwdw": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_th": 0,
                 "i8_tail": 1, "i8_mel_generic": 0, "stft_rowmajor": 0, "ingest_blk": 0, "ingest_generic": 0}
     assert sorted(defaults) == sorted(_hip.OPTION_NAMES)
     hdr = open(os.path.join(REPO, "include", "birdnet_hip.h")).read()
@@ -322,6 +322,27 @@ def _all_plans():
         spec = build_model("dscnn", **{**base, **kw})
         for fuse in (True, False):
             yield f"dscnn {kw} fuse={fuse}", lower_f32(spec, fuse=fuse)
+
+
+def test_inverted_residual_pairs_are_tagged_and_never_run_in_place():
+    """Expand 1x1 + depthwise 3x3 of inverted-residual blocks may run as one kernel (``f32_pwdw_kernel``): the packer tags the pair only in
+    production plans, only when the depthwise stage is the sole reader of the expanded map, and keeps the block input's slot away from
+    the depthwise output (the fused kernel reads one while it writes the other)."""
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=10,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True)
+    plan = lower_f32(spec)
+    heads = [i for i, o in enumerate(plan.ops) if o.p[pk.TAIL_TAG] == pk.PWDW_HEAD]
+    assert len(heads) == 11
+    for i in heads:
+        e, d = plan.ops[i], plan.ops[i + 1]
+        assert e.kind == pk.F32_DWPW and e.p[15] == 0 and e.p[12] == 0 and e.p[13] == 0 and d.kind == pk.F32_DW and d.p[pk.TAIL_TAG] == pk.PWDW_COVERED
+        assert d.in0 == e.out and d.out != e.in0 and d.out != e.out and d.p[2] == e.p[10]
+    for kw in (dict(keep_all=True), dict(fuse=False)):
+        assert not any(o.p[pk.TAIL_TAG] in (pk.PWDW_HEAD, pk.PWDW_COVERED) for o in lower_f32(spec, **kw).ops)
 
 
 def test_blob_check_accepts_every_lowered_plan_and_refuses_damaged_ones():
