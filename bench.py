@@ -339,6 +339,37 @@ def quick_rate(torch, dtype: str, batch: int, device, local_rank: int, steps: in
             "ms_per_step": round(dt / steps * 1e3, 4)}
 
 
+def config4_rate(torch, device, local_rank: int, batch: int = 1024, steps: int = 10) -> dict:
+    """BASELINE configs[4] on this GPU, beside the main measurement: raw-waveform learned filterbank + PCEN + alpha = 1.5 DS-CNN with
+    squeeze-excite and inverted residuals, seeded random weights (there is no checkpoint of it), 2 s @ 24 kHz chunks (the geometry the
+    reference's raw frontend builds at), float32 — one step = per-chunk peak normalisation + the whole plan over ``batch`` waveform chunks
+    resident in HBM.  The N-GPU form of the config is the same plan on every rank over its own chunks (no collective until the scores)."""
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+    runner = HipRunner(lower_f32(spec), device=local_rank, max_batch=batch)
+    g = torch.Generator(device=device).manual_seed(4)
+    x = torch.randn((batch, 48000), device=device, generator=g)
+    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
+    for _ in range(2):
+        runner.infer_audio_device(x, out=scores)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.infer_audio_device(x, out=scores)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    finite = bool(torch.isfinite(scores).all().item())
+    runner.close()
+    del x, scores
+    return {"workload": "BASELINE configs[4] topology: raw frontend + PCEN + alpha=1.5 IR/SE DS-CNN, seeded random weights, 2 s @ 24 kHz", "dtype": "f32",
+            "batch_per_gpu": batch, "value": round(batch * steps / dt, 1), "unit": "chunks/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "MMAC_per_chunk": 200.8, "TFLOP_per_s": round(2 * 200.8e6 * batch * steps / dt / 1e12, 1), "scores_finite": finite}
+
+
 def timed_job(score_batch, steps: int, batch: int, n_classes: int, device, barrier, sync):
     """The timed region: this rank's ``steps`` batches through ``evaluation/sharding.py: run_sharded`` (one process: all of
     them) and the ONE all-gather of the scores; bracketed by barrier + device synchronisation on both sides.
@@ -507,6 +538,10 @@ def main() -> None:
             torch.cuda.empty_cache()
             other = "i8" if args.dtype == "f32" else "f32"
             out["also_measured"] = quick_rate(torch, other, 4096 if other == "i8" else 1024, device, local_rank)
+            try:  # a second reported extra: a failure here must not cost the main line
+                out["also_measured_configs4"] = config4_rate(torch, device, local_rank)
+            except Exception as e:  # noqa: BLE001
+                out["also_measured_configs4"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.dtype)
         print(json.dumps(out))
