@@ -436,6 +436,15 @@ def _tag_pwdw(pb: pk.PlanBuilder) -> None:
         d.p[pk.TAIL_TAG] = pk.PWDW_COVERED
         if e.in0 >= 0:
             pb._extra_uses.append((i + 1, e.in0))
+        # a stem convolution right in front whose map nothing else reads: the fused kernel computes its rows too
+        if i and ops[i - 1].kind == pk.F32_STEM and ops[i - 1].out == e.in0 and e.in0 >= 0 and not ops[i - 1].p[pk.TAIL_TAG]:
+            st = ops[i - 1]
+            others = [k for k, r in enumerate(ops) if k != i and (r.in0 == e.in0 or r.in1 == e.in0)]
+            if not others and [k for k, r in enumerate(ops) if r.out == e.in0] == [i - 1] and e.in0 not in gate_slots \
+                    and (st.p[6], st.p[7], st.p[2]) == (e.p[0], e.p[1], e.p[2]) and st.p[pk.OP_PATH] == e.p[pk.OP_PATH]:
+                st.p[pk.TAIL_TAG] = pk.PWDW_STEM
+                if st.in0 >= 0:
+                    pb._extra_uses.append((i + 1, st.in0))
 
 
 def _tag_front2(pb: pk.PlanBuilder) -> None:

@@ -172,6 +172,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
     };
     const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
     if (op_end > m->ops.size()) op_end = m->ops.size();
+    size_t pwdw_head_done = (size_t)-1;  // expand convolution that ran inside the fused kernel of the stem operator in front of it
     size_t pwdw_done = (size_t)-1;    // depthwise stage that ran inside the expand convolution in front of it
     size_t front2_done = (size_t)-1;  // operator that the fused front kernel of this run has already covered
     auto dwpw_args = [&](const OpRec& d) {
@@ -219,7 +220,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
-        if (oi == front2_done || oi == pwdw_done || oi == scale_done || oi == segate_done[0] || oi == segate_done[1]) continue;  // ran inside a preceding operator's kernel
+        if (oi == front2_done || oi == pwdw_done || oi == pwdw_head_done || oi == scale_done || oi == segate_done[0] || oi == segate_done[1]) continue;  // ran inside a preceding operator's kernel
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
@@ -254,6 +255,26 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 bn::launch_f32_mag((float*)out, m->d_smax, B, p[0], p[1], (const float*)m->tensor(o.t[2]), p[2], s);
                 break;
             case BN_OP_F32_STEM:
+                if (p[BN_OP_TAIL_TAG] == BN_PWDW_STEM && bn::g_opt.f32_pwdw && bn::g_opt.f32_strip && oi + 2 < op_end) {
+                    // stem -> expand 1x1 -> depthwise 3x3 as ONE kernel: neither the stem map nor the expanded map is written
+                    const OpRec& e = m->ops[oi + 1];
+                    const OpRec& d = m->ops[oi + 2];
+                    const int* q = d.p;
+                    if (e.kind == BN_OP_F32_DWPW && e.p[BN_OP_TAIL_TAG] == BN_PWDW_HEAD && d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED &&
+                        e.in0 == o.out && d.in0 == e.out && d.out != o.in0 && d.out != o.out && d.out != e.out && e.p[0] == p[6] && e.p[1] == p[7] &&
+                        e.p[2] == p[2]) {
+                        const bn::DwPwArgs ea = dwpw_args(e);
+                        const bn::F32StemIn st{(const float*)in0, (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), p[0], p[1], p[3], p[4],
+                                               p[8], p[9], p[5]};
+                        if (ea.W == 128 && ea.Cin % 8 == 0 && bn::f32_pwdw_supported(ea, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&  // (one stem position per loader thread)
+                            bn::launch_f32_pwdw(ea, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7],
+                                                q[8], q[9], q[5], &st, s)) {
+                            pwdw_head_done = oi + 1;
+                            pwdw_done = oi + 2;
+                            break;
+                        }
+                    }
+                }
                 bn::launch_f32_stem((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
                                     p[8], p[9], (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
                 break;
@@ -275,7 +296,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     if (d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out &&
                         bn::f32_pwdw_supported(a, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&
                         bn::launch_f32_pwdw(a, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7], q[8],
-                                            q[9], q[5], s)) {
+                                            q[9], q[5], nullptr, s)) {
                         pwdw_done = oi + 1;
                         break;
                     }

@@ -80,6 +80,9 @@ struct TensorRec {
 // (BN_OP_F32_DW, tagged BN_PWDW_COVERED) is the only reader of its output and may run inside the same kernel (f32_pwdw_kernel)
 #define BN_PWDW_HEAD 0x7A110009
 #define BN_PWDW_COVERED 0x7A11000A
+// BN_PWDW_STEM on a BN_OP_F32_STEM operator: the next two operators are a BN_PWDW_HEAD / BN_PWDW_COVERED pair that is the only reader of the
+// stem map; the fused kernel may compute the stem rows itself (the stem map is never written)
+#define BN_PWDW_STEM 0x7A11000B
 
 #define BN_OP_NP 40
 #define BN_OP_NT 16

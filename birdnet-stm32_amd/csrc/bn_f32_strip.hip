@@ -791,10 +791,14 @@ struct F32PwDwArgs {
     const float* dw_w;    // [3][3][hid]
     const float* dw_b;    // [hid]
     int B, H, W, Cin, hid, OH, OW, pt, pl, pw_act, dw_act, RB;
+    // optional stem in front (fe != nullptr): x is not read; the loaders compute row hr of CONV 3x3 (1 -> Cin channels, stride ssh x ssw, SAME) from
+    // the frontend map fe [B][H0][W0] instead of loading it — the stem map (786 KB per chunk in configs[4]) never exists in HBM either
+    const float* fe; const float* stem_w; const float* stem_b;   // [3][3][Cin], [Cin]
+    int H0, W0, ssh, ssw, spt, spl, stem_act;
 };
 
 template <int NJ, int S>
-__global__ __launch_bounds__(640) void f32_pwdw_kernel(F32PwDwArgs a) {
+__global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ring3[];  // [4][W + 2][hid + 4] (column hx at index hx + 1), then [3][W][Cin + 4]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(640) void f32_pwdw_kernel(F32PwDwArgs a) {
     const int nsteps = nhid + 1;
     auto row_ok = [&](int k) { return k >= 0 && k < nhid && h_lo + k >= 0 && h_lo + k < a.H; };
 
-    for (int i = tid; i < 8 * P; i += 640) {       // border columns of the four ring slots
+    for (int i = tid; i < 8 * P; i += (int)blockDim.x) {  // border columns of the four ring slots
         const int slot = i / (2 * P), rest = i - slot * 2 * P;
         ring3[(slot * (a.W + 2) + (rest < P ? 0 : a.W + 1)) * P + (rest % P)] = 0.0f;
     }
@@ -949,6 +953,59 @@ __global__ __launch_bounds__(640) void f32_pwdw_kernel(F32PwDwArgs a) {
 #pragma unroll
             for (int e = 0; e < 6; ++e) *reinterpret_cast<v4f*>(dst + st_off[e]) = r[e];
         };
+        if (a.fe) {
+            // stem mode (W = 128 positions, 256 loader threads): a thread computes half the channels of ITS position of stem row k, one step
+            // before the producers multiply it.  Its nine taps of the frontend map (64 KB per chunk, cache resident) are requested a step ahead;
+            // the weights are wave-uniform and come as LDS broadcasts.  Summation order of f32_stem_kernel: bias, then the taps row by row
+            // (a tap outside the map contributes an exact 0 instead of being skipped).
+            const float* fmap = a.fe + (size_t)chunk * a.H0 * a.W0;
+            const ActBounds st_bounds = act_bounds(a.stem_act);
+            float* swl = stage + 3 * a.W * PI;               // [9][Cin] stem weights, then [Cin] bias
+            // (each of the loader waves writes the whole table itself — the same values — and reads it behind its own writes: no barrier)
+            for (int i = lane; i < 10 * a.Cin; i += 64) swl[i] = i < 9 * a.Cin ? a.stem_w[i] : a.stem_b[i - 9 * a.Cin];
+            const int spos = lt & 127, half = lt >> 7;        // four loader waves in this mode: two threads per position, half the channel quads each
+            const int qpt = cq4 >> 1;
+            const int iw0 = spos * a.ssw - a.spl;
+            auto taps = [&](float (&v)[9], int k) {
+                const int ih0 = (h_lo + k) * a.ssh - a.spt;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int ih = ih0 + i, iw = iw0 + j;
+                        const bool ok = row_ok(k) && ih >= 0 && ih < a.H0 && iw >= 0 && iw < a.W0;
+                        v[i * 3 + j] = ok ? fmap[ih * a.W0 + iw] : 0.0f;
+                    }
+            };
+            auto stem_row = [&](const float (&v)[9], int k) {
+                if (!row_ok(k)) return;
+                float* dst = stage + (k % 3) * a.W * PI + spos * PI;
+#pragma unroll 3
+                for (int quad = half * qpt; quad < (half + 1) * qpt; ++quad) {
+                    v4f acc = *reinterpret_cast<const v4f*>(swl + 9 * a.Cin + 4 * quad);
+#pragma unroll
+                    for (int t9 = 0; t9 < 9; ++t9)
+                        acc = __builtin_elementwise_fma((v4f){v[t9], v[t9], v[t9], v[t9]}, *reinterpret_cast<const v4f*>(swl + t9 * a.Cin + 4 * quad), acc);
+                    *reinterpret_cast<v4f*>(dst + 4 * quad) = act4(acc, st_bounds);
+                }
+            };
+            float va[9], vb[9];
+            taps(va, 0);
+            taps(vb, 1);
+            stem_row(va, 0);
+            __syncthreads();
+            for (int t = 0; t < nsteps; t += 2) {
+                taps(va, t + 2);
+                stem_row(vb, t + 1);
+                __syncthreads();
+                if (t + 1 < nsteps) {
+                    taps(vb, t + 3);
+                    stem_row(va, t + 2);
+                    __syncthreads();
+                }
+            }
+            return;
+        }
         v4f r0[6], r1[6], r2[6];
         request(r0, 0);
         request(r1, 1);
@@ -1023,11 +1080,16 @@ bool f32_pwdw_supported(const DwPwArgs& e, int dH, int dW, int dC, int dsh, int 
 }
 
 bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
-                     hipStream_t s) {
-    const size_t smem = ((size_t)4 * (e.W + 2) * (e.Cout + 4) + (size_t)3 * e.W * (e.Cin + 4)) * sizeof(float);
+                     const F32StemIn* stem, hipStream_t s) {
+    const size_t smem = ((size_t)4 * (e.W + 2) * (e.Cout + 4) + (size_t)3 * e.W * (e.Cin + 4) + (stem ? 10 * e.Cin : 0)) * sizeof(float);
     int rb = dOH;
     while (rb > 16) rb = (rb + 1) / 2;
-    F32PwDwArgs a{e.x, y, e.pw_w, e.pw_b, dw_w, dw_b, e.B, e.H, e.W, e.Cin, e.Cout, dOH, dOW, dpt, dpl, e.pw_act, dw_act, rb};
+    F32PwDwArgs a{e.x, y, e.pw_w, e.pw_b, dw_w, dw_b, e.B, e.H, e.W, e.Cin, e.Cout, dOH, dOW, dpt, dpl, e.pw_act, dw_act, rb,
+                  nullptr, nullptr, nullptr, 0, 0, 1, 1, 0, 0, 0};
+    if (stem) {
+        a.fe = stem->fe; a.stem_w = stem->w; a.stem_b = stem->b; a.H0 = stem->H0; a.W0 = stem->W0; a.ssh = stem->sh; a.ssw = stem->sw;
+        a.spt = stem->pt; a.spl = stem->pl; a.stem_act = stem->act;
+    }
     const unsigned blocks = (unsigned)((long)e.B * ((dOH + rb - 1) / rb));
     const int nj = (e.Cin + 15) / 16;
 #define BN_PWDW(NJV, SV)                                                                                                                    \
@@ -1039,7 +1101,7 @@ bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, fl
                 return false;                                                                                                               \
             allowed = smem;                                                                                                                 \
         }                                                                                                                                   \
-        hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV>), dim3(blocks), dim3(640), smem, s, a);                                                \
+        hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV>), dim3(blocks), dim3(stem ? 768 : 640), smem, s, a);                                                \
         return true;                                                                                                                        \
     }
     BN_PWDW(2, 1) BN_PWDW(2, 2) BN_PWDW(3, 1) BN_PWDW(3, 2) BN_PWDW(6, 1) BN_PWDW(6, 2)

@@ -140,8 +140,14 @@ bool f32_strip_supported(const DwPwArgs& a);
 void launch_f32_strip(DwPwArgs a, hipStream_t s);
 // front block + the residual block behind it (32 -> 32, stride 1) in one kernel, the map between them in LDS (bn_f32_strip.hip)
 bool f32_pwdw_supported(const DwPwArgs& expand, int dH, int dW, int dC, int dsh, int dsw, int dOH, int dOW);
+struct F32StemIn {  // a stem convolution (3x3, one input channel) computed inside f32_pwdw_kernel instead of being read from memory
+    const float* fe;  // [B][H0][W0]
+    const float* w;   // [3][3][C]
+    const float* b;   // [C]
+    int H0, W0, sh, sw, pt, pl, act;
+};
 bool launch_f32_pwdw(const DwPwArgs& expand, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
-                     hipStream_t s);
+                     const F32StemIn* stem, hipStream_t s);
 bool f32_front2_supported(const F32FrontStripArgs& f, const DwPwArgs& d);
 bool launch_f32_front2(const F32FrontStripArgs& f, const DwPwArgs& d, hipStream_t s);
 

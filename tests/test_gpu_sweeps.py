@@ -400,7 +400,8 @@ def test_f32_pwdw_fused_kernel_matches_the_two_kernels(torch_mod):
     rows = [r for r in runner.profile_collect() if r["launches"]]
     runner.profile(False)
     fused = len(rows0) - len(rows)
-    assert fused == 6, fused  # stages 1-2 and the first block of stage 3 (input maps 32+ columns wide); the narrow late stages keep two kernels
+    assert fused == 7, fused  # stages 1-2 and the first block of stage 3 (input maps 32+ columns wide; the narrow late stages keep two kernels) + the stem
+    assert sum(1 for o in ops if o.kind == pk.F32_STEM and o.p[pk.TAIL_TAG] == pk.PWDW_STEM) == 1
     for rep in range(4):
         for nb in (70, 1, 3, 64, 65):
             s, l = runner.predict_device(xd[:nb], return_logits=True)

@@ -341,8 +341,10 @@ def test_inverted_residual_pairs_are_tagged_and_never_run_in_place():
         e, d = plan.ops[i], plan.ops[i + 1]
         assert e.kind == pk.F32_DWPW and e.p[15] == 0 and e.p[12] == 0 and e.p[13] == 0 and d.kind == pk.F32_DW and d.p[pk.TAIL_TAG] == pk.PWDW_COVERED
         assert d.in0 == e.out and d.out != e.in0 and d.out != e.out and d.p[2] == e.p[10]
+    stems = [i for i, o in enumerate(plan.ops) if o.p[pk.TAIL_TAG] == pk.PWDW_STEM]  # the stem in front of the first pair: computed inside the fused kernel
+    assert len(stems) == 1 and plan.ops[stems[0]].kind == pk.F32_STEM and stems[0] + 1 == heads[0] and plan.ops[stems[0] + 2].out != plan.ops[stems[0]].in0
     for kw in (dict(keep_all=True), dict(fuse=False)):
-        assert not any(o.p[pk.TAIL_TAG] in (pk.PWDW_HEAD, pk.PWDW_COVERED) for o in lower_f32(spec, **kw).ops)
+        assert not any(o.p[pk.TAIL_TAG] in (pk.PWDW_HEAD, pk.PWDW_COVERED, pk.PWDW_STEM) for o in lower_f32(spec, **kw).ops)
 
 
 def test_blob_check_accepts_every_lowered_plan_and_refuses_damaged_ones():
