@@ -122,34 +122,42 @@ __global__ __launch_bounds__(256) void f32_melfin_kernel(const float* __restrict
 }
 
 // raw-waveform frontend: symmetric zero pad, VALID strided 1x16 convolution (BatchNorm folded), ReLU6, magnitude scaling,
-// output transposed to [M][W] (reference: birdnet_stm32/models/frontend.py:138-164,347-358).  Thread = (frame t, 4 filters).
-__global__ void f32_rawfe_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int W, int M, int stride, int pad_left,
-                                 const float* __restrict__ fb, const float* __restrict__ bias, const float* __restrict__ magp, int mag,
-                                 long total) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int t = (int)(gid % W);
-    long r = gid / W;
-    const int mq = (int)(r % (M / 4));
-    const long b = r / (M / 4);
-    const float* xin = x + b * T;
-    float4 acc = *reinterpret_cast<const float4*>(bias + 4 * mq);
+// output transposed to [M][W] (reference: birdnet_stm32/models/frontend.py:138-164,347-358).  A thread owns ONE frame: it loads its 16
+// samples once (64 contiguous bytes; the kernel touches 16 of every `stride` samples) and walks over all M filters, whose taps are
+// wave-uniform LDS broadcasts ([M][16], transposed while staging); every store of a wave is one run of 64 consecutive frames of a
+// filter row.  (First version: thread = (frame, 4 filters) — every sample was loaded by M / 4 threads in sixteen 4-byte pieces at a
+// stride of `stride` samples between lanes: 0.24 ms per 1024 chunks at 0.8 TB/s; this form: see DESIGN.md.)  Same summation order.
+__global__ __launch_bounds__(256) void f32_rawfe_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int W, int M, int stride,
+                                                        int pad_left, const float* __restrict__ fb, const float* __restrict__ bias,
+                                                        const float* __restrict__ magp, int mag) {
+    extern __shared__ __attribute__((aligned(16))) float fbt[];  // [M][16] taps, then [M] bias
+    for (int i = threadIdx.x; i < 16 * M; i += 256) fbt[(i % M) * 16 + i / M] = fb[i];  // fb is [16][M]
+    for (int i = threadIdx.x; i < M; i += 256) fbt[16 * M + i] = bias[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= W) return;
+    const float* xin = x + (size_t)b * T;
     const int s0 = t * stride - pad_left;
+    float v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int g = s0 + k;
-        const float v = (g >= 0 && g < T) ? xin[g] : 0.0f;
-        const float4 w = *reinterpret_cast<const float4*>(fb + k * M + 4 * mq);
-        acc.x = fmaf(v, w.x, acc.x);
-        acc.y = fmaf(v, w.y, acc.y);
-        acc.z = fmaf(v, w.z, acc.z);
-        acc.w = fmaf(v, w.w, acc.w);
+        v[k] = (g >= 0 && g < T) ? xin[g] : 0.0f;
     }
-    const float o[4] = {acc.x, acc.y, acc.z, acc.w};
+    float* o = out + (size_t)b * M * W + t;
+    for (int m = 0; m < M; ++m) {
+        const float4* wr = reinterpret_cast<const float4*>(fbt + 16 * m);
+        float acc = fbt[16 * M + m];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int m = 4 * mq + e;
-        out[(b * M + m) * W + t] = mag_scale(fminf(fmaxf(o[e], 0.0f), 6.0f), m, M, magp, mag);
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 w4 = wr[k4];
+            acc = fmaf(v[4 * k4 + 0], w4.x, acc);
+            acc = fmaf(v[4 * k4 + 1], w4.y, acc);
+            acc = fmaf(v[4 * k4 + 2], w4.z, acc);
+            acc = fmaf(v[4 * k4 + 3], w4.w, acc);
+        }
+        o[(size_t)m * W] = mag_scale(fminf(fmaxf(acc, 0.0f), 6.0f), m, M, magp, mag);
     }
 }
 
@@ -492,9 +500,8 @@ void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const floa
 
 void launch_f32_rawfe(const float* x, float* out, int B, int T, int W, int M, int stride, int pad_left, const float* fb,
                       const float* bias, const float* magp, int mag, hipStream_t s) {
-    const long total = (long)B * (M / 4) * W;
-    hipLaunchKernelGGL(f32_rawfe_kernel, grid1d(total, 256), dim3(256), 0, s, x, out, T, W, M, stride, pad_left, fb, bias, magp, mag,
-                       total);
+    hipLaunchKernelGGL(f32_rawfe_kernel, dim3((W + 255) / 256, B), dim3(256), (size_t)17 * M * sizeof(float), s, x, out, T, W, M, stride, pad_left, fb,
+                       bias, magp, mag);
 }
 
 void launch_f32_melfin(const float* melraw, const float* minmax, float* out, int B, int M, int W, const float* wsum,
