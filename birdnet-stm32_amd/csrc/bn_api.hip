@@ -102,6 +102,8 @@ struct bn_model {
     float* d_spec = nullptr;             // [max_batch][F][W] for bn_infer_audio
     float* d_minmax = nullptr;           // [max_batch][2]
     float* d_smax = nullptr;             // [max_batch] per-sample maxima of the frontend
+    float* d_gap_part = nullptr;         // [max_batch][gap_part_elems] channel sums per row block from f32_pwdw_kernel for the squeeze-excite gate behind it
+    size_t gap_part_elems = 0;
     size_t workspace_bytes = 0;
     // per-operator HIP-event timing (bn_profile_*): one (start, stop) pair per launch group
     bool profiling = false;
@@ -172,6 +174,24 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
     };
     const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
     if (op_end > m->ops.size()) op_end = m->ops.size();
+    size_t gap_for = (size_t)-1;      // squeeze-excite gate whose pooling comes as row-block sums from the fused kernel in front of it
+    int gap_R = 0, cand_R = 0;
+    size_t cand_for = (size_t)-1;     // (candidate: becomes gap_for once the fused kernel has been launched)
+    // the gate right behind a fused (expand, depthwise) pair pools the depthwise map: the fused kernel hands it per-row-block channel sums
+    auto gap_target = [&](size_t di) -> float* {
+        const OpRec& d = m->ops[di];
+        cand_for = (size_t)-1;
+        if (bn::g_opt.f32_pwdw < 2 || !m->d_gap_part || di + 1 >= op_end) return nullptr;
+        const OpRec& g = m->ops[di + 1];
+        const int rb = bn::f32_pwdw_rows(d.p[6]);
+        const int R = (d.p[6] + rb - 1) / rb;
+        if (g.kind != BN_OP_F32_SEGATE || g.in0 != d.out || g.p[1] != d.p[2] || g.p[0] != d.p[6] * d.p[7] || (size_t)R * d.p[2] > m->gap_part_elems ||
+            (g.p[BN_OP_PATH] != BN_PATH_BOTH && g.p[BN_OP_PATH] != mode))
+            return nullptr;
+        cand_for = di + 1;
+        cand_R = R;
+        return m->d_gap_part;
+    };
     size_t pwdw_head_done = (size_t)-1;  // expand convolution that ran inside the fused kernel of the stem operator in front of it
     size_t pwdw_done = (size_t)-1;    // depthwise stage that ran inside the expand convolution in front of it
     size_t front2_done = (size_t)-1;  // operator that the fused front kernel of this run has already covered
@@ -268,9 +288,11 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                                p[8], p[9], p[5]};
                         if (ea.W == 128 && ea.Cin % 8 == 0 && bn::f32_pwdw_supported(ea, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&  // (one stem position per loader thread)
                             bn::launch_f32_pwdw(ea, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7],
-                                                q[8], q[9], q[5], &st, s)) {
+                                                q[8], q[9], q[5], &st, gap_target(oi + 2), s)) {
                             pwdw_head_done = oi + 1;
                             pwdw_done = oi + 2;
+                            gap_for = cand_for;
+                            gap_R = cand_R;
                             break;
                         }
                     }
@@ -296,8 +318,10 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     if (d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out &&
                         bn::f32_pwdw_supported(a, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&
                         bn::launch_f32_pwdw(a, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7], q[8],
-                                            q[9], q[5], nullptr, s)) {
+                                            q[9], q[5], nullptr, gap_target(oi + 1), s)) {
                         pwdw_done = oi + 1;
+                        gap_for = cand_for;
+                        gap_R = cand_R;
                         break;
                     }
                 }
@@ -338,8 +362,8 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                          (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
                 break;
             case BN_OP_F32_SEGATE:
-                bn::launch_f32_segate((const float*)in0, (float*)out, B, p[0], p[1], p[2],
-                                      (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
+                bn::launch_f32_segate((const float*)in0, (float*)out, B, p[0], p[1], p[2], (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]),
+                                      oi == gap_for ? m->d_gap_part : nullptr, gap_R, s);
                 break;
             case BN_OP_F32_SCALE:
                 bn::launch_f32_scale((const float*)in0, (const float*)in1, (float*)out, B, p[0], p[1], s);
@@ -744,6 +768,18 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
         hipMalloc(&m->d_smax, mb * sizeof(float)) != hipSuccess)
         return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of reduction scratch failed"));
     m->workspace_bytes += mb * 3 * sizeof(float);
+    for (size_t i = 0; i + 1 < m->ops.size(); ++i)  // row-block channel sums of fused inverted-residual pairs (largest pair decides)
+        if (m->ops[i].kind == BN_OP_F32_DWPW && m->ops[i].p[BN_OP_TAIL_TAG] == BN_PWDW_HEAD && m->ops[i + 1].kind == BN_OP_F32_DW) {
+            const int* q = m->ops[i + 1].p;
+            const int rb = bn::f32_pwdw_rows(q[6]);
+            const size_t need = (size_t)((q[6] + rb - 1) / rb) * (size_t)q[2];
+            if (need > m->gap_part_elems) m->gap_part_elems = need;
+        }
+    if (m->gap_part_elems) {
+        if (hipMalloc(&m->d_gap_part, mb * m->gap_part_elems * sizeof(float)) != hipSuccess)
+            return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of pooling scratch failed"));
+        m->workspace_bytes += mb * m->gap_part_elems * sizeof(float);
+    }
     *out = m;
     return BN_OK;
 }
@@ -756,6 +792,7 @@ void bn_model_free(bn_model* m) {
     (void)hipFree(m->d_spec);
     (void)hipFree(m->d_minmax);
     (void)hipFree(m->d_smax);
+    (void)hipFree(m->d_gap_part);
     for (auto& r : m->ev_used) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);

@@ -299,14 +299,21 @@ __global__ void f32_gap_kernel(const float* __restrict__ x, float* __restrict__ 
 // (g, cq) adds the float4 channel quad cq of positions g, g + G, ... (G = 256 / (C/4) position groups, eight loads in
 // flight), the G partial sums are then added in group order.  (The first version used one thread per channel: 48 of 256.)
 __global__ __launch_bounds__(256) void f32_segate_kernel(const float* __restrict__ x, float* __restrict__ gate, int P, int C, int Cr,
-                                                         const float* __restrict__ w1, const float* __restrict__ w2) {
+                                                         const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ part_in,
+                                                         int R) {
     extern __shared__ float sm[];  // [C] means, [Cr] hidden, [G][C] partial sums
     float* mean = sm;
     float* hid = sm + C;
     float* part = hid + Cr;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Cq = C >> 2;
-    if ((C & 3) == 0 && Cq <= 256) {
+    if (part_in) {  // R partial sums per chunk from the kernel that wrote the map (f32_pwdw_kernel): added in row-block order
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.0f;
+            for (int r = 0; r < R; ++r) s += part_in[((size_t)b * R + r) * C + c];
+            mean[c] = s / (float)P;
+        }
+    } else if ((C & 3) == 0 && Cq <= 256) {
         const int G = 256 / Cq;
         const int g = tid / Cq, cq = tid - g * Cq;
         if (g < G) {
@@ -531,10 +538,10 @@ void launch_f32_pw(const float* x, const float* res, const float* gate, float* y
                        total);
 }
 
-void launch_f32_segate(const float* x, float* gate, int B, int P, int C, int Cr, const float* w1, const float* w2,
+void launch_f32_segate(const float* x, float* gate, int B, int P, int C, int Cr, const float* w1, const float* w2, const float* part, int R,
                        hipStream_t s) {
     const int groups = (C & 3) == 0 && C / 4 <= 256 ? 256 / (C / 4) : 0;
-    hipLaunchKernelGGL(f32_segate_kernel, dim3(B), dim3(256), (C + Cr + (size_t)groups * C) * sizeof(float), s, x, gate, P, C, Cr, w1, w2);
+    hipLaunchKernelGGL(f32_segate_kernel, dim3(B), dim3(256), (C + Cr + (size_t)groups * C) * sizeof(float), s, x, gate, P, C, Cr, w1, w2, part, R);
 }
 
 void launch_f32_scale(const float* x, const float* gate, float* y, int B, int P, int C, hipStream_t s) {

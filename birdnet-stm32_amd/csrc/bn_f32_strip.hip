@@ -795,6 +795,9 @@ struct F32PwDwArgs {
     // the frontend map fe [B][H0][W0] instead of loading it — the stem map (786 KB per chunk in configs[4]) never exists in HBM either
     const float* fe; const float* stem_w; const float* stem_b;   // [3][3][Cin], [Cin]
     int H0, W0, ssh, ssw, spt, spl, stem_act;
+    // optional (gap_part != nullptr): per-workgroup channel sums of the depthwise output, [B][row blocks][hid] — the squeeze-excite gate behind
+    // the block pools them (f32_segate_kernel) instead of reading the whole map again
+    float* gap_part;
 };
 
 template <int NJ, int S>
@@ -871,6 +874,7 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
             }
             __syncthreads();
         }
+        __syncthreads();                            // (the consumers' channel sums pass through LDS behind the last row)
     } else if (w < 8) {
         // ------------------------------------------------------------------------------------------------ consumers
         const int dt = tid - 256;
@@ -886,6 +890,7 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
             for (int dx = 0; dx < 3; ++dx) wt[dy][dx] = dw_live ? *reinterpret_cast<const v4f*>(a.dw_w + (dy * 3 + dx) * a.hid + 4 * q) : dwb;
         if (dw_live) dwb = *reinterpret_cast<const v4f*>(a.dw_b + 4 * q);
         float* ybase = a.y + ((size_t)chunk * a.OH) * a.OW * a.hid + 4 * q;
+        v4f gsum = {0.0f, 0.0f, 0.0f, 0.0f};
         auto depthwise = [&](int oh) {
             if (!dw_live) return;
             const int hr0 = S * oh - a.pt;
@@ -918,13 +923,23 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
                         for (int dy = 0; dy < 3; ++dy)
                             if (rok[dy]) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(rows[dy] + off + dx * P), wt[dy][dx], acc);
                 }
-                *reinterpret_cast<v4f*>(ybase + ((size_t)oh * a.OW + ox) * a.hid) = act4(acc, dw_bounds);
+                const v4f o = act4(acc, dw_bounds);
+                gsum += o;
+                *reinterpret_cast<v4f*>(ybase + ((size_t)oh * a.OW + ox) * a.hid) = o;
             }
         };
         __syncthreads();
         for (int t = 0; t < nsteps; ++t) {
             if (t >= 3 && (t - 3) % S == 0) depthwise(oh0 + (t - 3) / S);
             __syncthreads();
+        }
+        // channel sums of this workgroup's rows: the column groups' sums meet in LDS (the ring is free now) and are added in a fixed order
+        if (a.gap_part && dw_live) *reinterpret_cast<v4f*>(ring3 + cg * a.hid + 4 * q) = gsum;
+        __syncthreads();
+        if (a.gap_part && dt < quads) {
+            v4f tot = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int g2 = 0; g2 < groups; ++g2) tot += *reinterpret_cast<const v4f*>(ring3 + g2 * a.hid + 4 * dt);
+            *reinterpret_cast<v4f*>(a.gap_part + ((size_t)chunk * rblocks + ry) * a.hid + 4 * dt) = tot;
         }
     } else {
         // ------------------------------------------------------------------------------------------------ loaders (two waves)
@@ -1004,6 +1019,7 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
                     __syncthreads();
                 }
             }
+            __syncthreads();
             return;
         }
         v4f r0[6], r1[6], r2[6];
@@ -1027,6 +1043,7 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
                 __syncthreads();
             }
         }
+        __syncthreads();
     }
 }
 
@@ -1079,13 +1096,18 @@ bool f32_pwdw_supported(const DwPwArgs& e, int dH, int dW, int dC, int dsh, int 
     return smem <= 156 * 1024 && dW * e.Cin == 3072 && (long)e.H * e.W * e.Cin * 4 < 0x7fff0000L;
 }
 
-bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
-                     const F32StemIn* stem, hipStream_t s) {
-    const size_t smem = ((size_t)4 * (e.W + 2) * (e.Cout + 4) + (size_t)3 * e.W * (e.Cin + 4) + (stem ? 10 * e.Cin : 0)) * sizeof(float);
+int f32_pwdw_rows(int dOH) {  // output rows per workgroup
     int rb = dOH;
     while (rb > 16) rb = (rb + 1) / 2;
+    return rb;
+}
+
+bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
+                     const F32StemIn* stem, float* gap_part, hipStream_t s) {
+    const size_t smem = ((size_t)4 * (e.W + 2) * (e.Cout + 4) + (size_t)3 * e.W * (e.Cin + 4) + (stem ? 10 * e.Cin : 0)) * sizeof(float);
+    const int rb = f32_pwdw_rows(dOH);
     F32PwDwArgs a{e.x, y, e.pw_w, e.pw_b, dw_w, dw_b, e.B, e.H, e.W, e.Cin, e.Cout, dOH, dOW, dpt, dpl, e.pw_act, dw_act, rb,
-                  nullptr, nullptr, nullptr, 0, 0, 1, 1, 0, 0, 0};
+                  nullptr, nullptr, nullptr, 0, 0, 1, 1, 0, 0, 0, gap_part};
     if (stem) {
         a.fe = stem->fe; a.stem_w = stem->w; a.stem_b = stem->b; a.H0 = stem->H0; a.W0 = stem->W0; a.ssh = stem->sh; a.ssw = stem->sw;
         a.spt = stem->pt; a.spl = stem->pl; a.stem_act = stem->act;

@@ -16,7 +16,8 @@ struct Options {
     int f32_strip = 1;         // float32 row-streaming strip kernels (0: tile kernels everywhere)
     int f32_strip_th = 0;      // force the rows per strip (0: the launcher's choice)
     int f32_front_staged = 1;  // LDS-staged form of the float32 front strip kernel
-    int f32_pwdw = 1;          // expand 1x1 + depthwise 3x3 of inverted-residual blocks as one kernel (the expanded map stays in LDS)
+    int f32_pwdw = 2;          // expand 1x1 + depthwise 3x3 of inverted-residual blocks as one kernel (the expanded map stays in LDS); 2: it also
+                               // hands the squeeze-excite gate behind it per-row-block channel sums (1: the gate pools the map itself, bit-identical to 0)
     int f32_front2 = 1;        // front block + first residual block as one kernel (the map between them stays in LDS)
     int front_tpw = 0;         // tiles per workgroup of the float32 front tile kernel (0: auto)
     int wave_dwpw = 1;         // wave-autonomous variant of the small float32 fused block
@@ -92,7 +93,7 @@ void launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh,
 void launch_f32_pw(const float* x, const float* res, const float* gate, float* y, int B, int P, int Cin, int Cout,
                    int act, const float* w, const float* bias, hipStream_t s);
 void launch_f32_segate(const float* x, float* gate, int B, int P, int C, int Cr, const float* w1, const float* w2,
-                       hipStream_t s);
+                       const float* part /* [B][R][C] partial channel sums instead of x, or null */, int R, hipStream_t s);
 void launch_f32_scale(const float* x, const float* gate, float* y, int B, int P, int C, hipStream_t s);
 void launch_f32_gap(const float* x, float* y, int B, int P, int C, hipStream_t s);
 void launch_f32_dense(const float* x, float* scores, float* logits, int B, int Cin, int Cout, int act, const float* w,
@@ -147,7 +148,8 @@ struct F32StemIn {  // a stem convolution (3x3, one input channel) computed insi
     int H0, W0, sh, sw, pt, pl, act;
 };
 bool launch_f32_pwdw(const DwPwArgs& expand, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
-                     const F32StemIn* stem, hipStream_t s);
+                     const F32StemIn* stem, float* gap_part /* [B][ceil(dOH / f32_pwdw_rows(dOH))][hid] or null */, hipStream_t s);
+int f32_pwdw_rows(int dOH);
 bool f32_front2_supported(const F32FrontStripArgs& f, const DwPwArgs& d);
 bool launch_f32_front2(const F32FrontStripArgs& f, const DwPwArgs& d, hipStream_t s);
 
