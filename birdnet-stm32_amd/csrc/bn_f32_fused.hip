@@ -29,7 +29,9 @@ __device__ __forceinline__ float act_f(float v, int act) {
     return v;
 }
 
-constexpr int kKC = 256;  // contraction channels staged in LDS at a time
+constexpr int kKC = 128;  // contraction channels staged in LDS at a time (256: one barrier pair less per 256 channels, but 64 KB tiles — measured slower:
+                          // configs[4] 7.04 -> 6.86 ms, shipped float32 net 0.945 -> 0.923 ms per 1024 chunks; the epilogue in two column passes
+                          // for still more workgroups per CU changed nothing)
 
 // Per-position bookkeeping, computed once per workgroup (integer divisions are costly on the vector ALU).
 struct PosInfo {
@@ -677,8 +679,12 @@ void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s) {
     }
     static const int kSlices[] = {24, 16, 12, 8, 6, 4, 3, 2, 1};
     int slice = 1;
+    // 24 tiles (384 output channels) in one slice need 99 KB of LDS for the epilogue: one workgroup of four waves per CU, nothing overlaps
+    // its load / multiply / store phases.  Two slices of 12 read the input tile twice but run two workgroups per CU: 384-wide layers of the
+    // alpha = 1.5 net 0.289 -> 0.234 ms (measured; three slices of 8 and four of 6 are slower again)
+    const int cap = g_opt.f32_tile_slice > 0 ? g_opt.f32_tile_slice : 16;
     for (int v : kSlices)
-        if (ct_total % v == 0) {
+        if (ct_total % v == 0 && v <= cap) {
             slice = v;
             break;
         }

@@ -16,6 +16,7 @@ struct Options {
     int f32_strip = 1;         // float32 row-streaming strip kernels (0: tile kernels everywhere)
     int f32_strip_th = 0;      // force the rows per strip (0: the launcher's choice)
     int f32_front_staged = 1;  // LDS-staged form of the float32 front strip kernel
+    int f32_tile_slice = 0;    // > 0: cap on the 16-column tiles per workgroup slice of the f32 tile kernel (0: the default cap of 16)
     int f32_pwdw = 2;          // expand 1x1 + depthwise 3x3 of inverted-residual blocks as one kernel (the expanded map stays in LDS); 2: it also
                                // hands the squeeze-excite gate behind it per-row-block channel sums (1: the gate pools the map itself, bit-identical to 0)
     int f32_front2 = 1;        // front block + first residual block as one kernel (the map between them stays in LDS)

@@ -19,6 +19,11 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
                    audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
 r = HipRunner(lower_f32(spec), max_batch=B)
+if os.environ.get("BN_OPTS"):  # launcher options for experiments: BN_OPTS="f32_tile_slice=12,f32_pwdw=1"
+    from birdnet_stm32 import _hip
+    for kv in os.environ["BN_OPTS"].split(","):
+        k, v = kv.split("=")
+        _hip.set_option(k, int(v))
 x = torch.randn((B, 48000), device="cuda")
 for _ in range(2):
     r.infer_audio_device(x)
