@@ -800,7 +800,8 @@ struct F32PwDwArgs {
     float* gap_part;
 };
 
-template <int NJ, int S>
+// NCW = channel tiles per producer wave: 3 for hid % 48 == 0 (alpha = 1.5: W x hid = 6144), 2 for hid % 32 == 0 (alpha = 1: W x hid = 4096)
+template <int NJ, int S, int NCW>
 __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ring3[];  // [4][W + 2][hid + 4] (column hx at index hx + 1), then [3][W][Cin + 4]
     const int tid = threadIdx.x;
@@ -827,21 +828,21 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
     if (w < 4) {
         // ------------------------------------------------------------------------------------------------ producers
         const int npp = a.W >> 5;
-        const int pp = w % npp, tc = w / npp;      // positions 32 pp + 16 u + n, hidden channels 48 tc + 16 c + 4 kq + e
+        const int pp = w % npp, tc = w / npp;      // positions 32 pp + 16 u + n, hidden channels 16 NCW tc + 16 c + 4 kq + e
         const int nct = a.hid >> 4;
         const ActBounds pw_bounds = act_bounds(a.pw_act);
-        v4f pa[3][NJ], pbias[3];
+        v4f pa[NCW][NJ], pbias[NCW];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < NCW; ++c) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) pa[c][j] = reinterpret_cast<const v4f*>(a.pw_w)[(j * nct + 3 * tc + c) * 64 + lane];
-            pbias[c] = *reinterpret_cast<const v4f*>(a.pw_b + 48 * tc + 16 * c + 4 * kq);
+            for (int j = 0; j < NJ; ++j) pa[c][j] = reinterpret_cast<const v4f*>(a.pw_w)[(j * nct + NCW * tc + c) * 64 + lane];
+            pbias[c] = *reinterpret_cast<const v4f*>(a.pw_b + 16 * NCW * tc + 16 * c + 4 * kq);
         }
         bool chan_ok[NJ];                           // channels beyond Cin: the zero-padded k-step of Cin = 24
 #pragma unroll
         for (int j = 0; j < NJ; ++j) chan_ok[j] = 16 * j + 4 * kq < a.Cin;
         const int src_off = (32 * pp + n) * PI + 4 * kq;
-        const int dst_off = (1 + 32 * pp + n) * P + 48 * tc + 4 * kq;
+        const int dst_off = (1 + 32 * pp + n) * P + 16 * NCW * tc + 4 * kq;
         __syncthreads();                            // staging row 0 and the ring's border columns are in place
         for (int t = 0; t < nsteps; ++t) {
             if (row_ok(t)) {
@@ -853,11 +854,11 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
                     for (int j = 0; j < NJ; ++j)
                         bf[u][j] = chan_ok[j] ? *reinterpret_cast<const v4f*>(src + 16 * u * PI + 16 * j) : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
                 float* dst = ring3 + (((h_lo + t) & 3) * (a.W + 2)) * P + dst_off;
-                v4f acc[2][3];  // the six tiles' chains interleaved: consecutive matrix instructions never depend on each other
+                v4f acc[2][NCW];  // the tiles' chains interleaved: consecutive matrix instructions never depend on each other
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) acc[u][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int c = 0; c < NCW; ++c) acc[u][c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -865,11 +866,11 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) mfma_acc(acc[u][c], pa[c][j][g], bf[u][j][g]);
+                            for (int c = 0; c < NCW; ++c) mfma_acc(acc[u][c], pa[c][j][g], bf[u][j][g]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)  // bias behind the sum, as the stand-alone 1x1 kernels add it: the pair stays bit-identical to them
+                    for (int c = 0; c < NCW; ++c)  // bias behind the sum, as the stand-alone 1x1 kernels add it: the pair stays bit-identical to them
                         *reinterpret_cast<v4f*>(dst + 16 * u * P + 16 * c) = act4(acc[u][c] + pbias[c], pw_bounds);
             }
             __syncthreads();
@@ -880,8 +881,9 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
         const int dt = tid - 256;
         const ActBounds dw_bounds = act_bounds(a.dw_act);
         const int quads = a.hid >> 2;
-        const int groups = 240 / quads;
-        const bool dw_live = dt < 240;
+        const int dwn = NCW == 3 ? 240 : 256;        // threads of the depthwise stage: a multiple of the quads per position (12 / 24 / 48 or 8 / 16 / 32)
+        const int groups = dwn / quads;
+        const bool dw_live = dt < dwn;
         const int q = dw_live ? dt % quads : 0, cg = dw_live ? dt / quads : 0;
         v4f wt[3][3], dwb = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -950,23 +952,24 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
         const int lt = tid - 512;
         const int cq4 = a.Cin >> 2;
         const float* xc = a.x + ((size_t)chunk * a.H) * a.W * a.Cin + 4 * lt;
-        int st_off[6];
+        constexpr int NLD = NCW == 3 ? 6 : 4;         // float4 per thread and row: W Cin / 4 = 768 (alpha = 1.5) or 512 (alpha = 1)
+        int st_off[NLD];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
+        for (int e = 0; e < NLD; ++e) {
             const int idx = lt + 128 * e, pos = idx / cq4;
             st_off[e] = pos * PI + 4 * (idx - pos * cq4);
         }
-        auto request = [&](v4f (&r)[6], int k) {
+        auto request = [&](v4f (&r)[NLD], int k) {
             int hr = h_lo + k;
             hr = hr < 0 ? 0 : (hr >= a.H ? a.H - 1 : hr);
             const float* src = xc + (size_t)hr * a.W * a.Cin;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) r[e] = *reinterpret_cast<const v4f*>(src + 512 * e);
+            for (int e = 0; e < NLD; ++e) r[e] = *reinterpret_cast<const v4f*>(src + 512 * e);
         };
-        auto deposit = [&](const v4f (&r)[6], int k) {
+        auto deposit = [&](const v4f (&r)[NLD], int k) {
             float* dst = stage + (k % 3) * a.W * PI;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) *reinterpret_cast<v4f*>(dst + st_off[e]) = r[e];
+            for (int e = 0; e < NLD; ++e) *reinterpret_cast<v4f*>(dst + st_off[e]) = r[e];
         };
         if (a.fe) {
             // stem mode (W = 128 positions, 256 loader threads): a thread computes half the channels of ITS position of stem row k, one step
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
             auto stem_row = [&](const float (&v)[9], int k) {
                 if (!row_ok(k)) return;
                 float* dst = stage + (k % 3) * a.W * PI + spos * PI;
-#pragma unroll 3
+#pragma unroll 2
                 for (int quad = half * qpt; quad < (half + 1) * qpt; ++quad) {
                     v4f acc = *reinterpret_cast<const v4f*>(swl + 9 * a.Cin + 4 * quad);
 #pragma unroll
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
             __syncthreads();
             return;
         }
-        v4f r0[6], r1[6], r2[6];
+        v4f r0[NLD], r1[NLD], r2[NLD];
         request(r0, 0);
         request(r1, 1);
         request(r2, 2);
@@ -1086,14 +1089,22 @@ bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, 
 }
 
 // expand 1x1 + depthwise 3x3 of an inverted-residual block as one kernel (f32_pwdw_kernel): four waves x (2 position tiles x 3 channel tiles)
+static int pwdw_ncw(int dW, int dC) {  // channel tiles per producer wave: four waves x (2 position tiles x NCW channel tiles) cover a hidden row
+    if (dW % 32 || dW < 32) return 0;
+    if (dC % 48 == 0 && (dW / 32) * (dC / 48) == 4) return 3;
+    if (dC % 32 == 0 && (dW / 32) * (dC / 32) == 4) return 2;
+    return 0;
+}
+
 bool f32_pwdw_supported(const DwPwArgs& e, int dH, int dW, int dC, int dsh, int dsw, int dOH, int dOW) {
     if (e.has_dw || e.res || e.gate || e.H != e.OH || e.W != e.OW || e.Cout != dC || e.H != dH || e.W != dW) return false;
-    if (dsh != dsw || (dsh != 1 && dsh != 2) || dW % 32 || dC % 48 || (dW / 32) * (dC / 48) != 4 || e.Cin % 4 || 240 % (dC / 4)) return false;
+    const int ncw = pwdw_ncw(dW, dC);
+    if (dsh != dsw || (dsh != 1 && dsh != 2) || !ncw || e.Cin % 4) return false;
     const int nj = (e.Cin + 15) / 16;
-    if (nj != 2 && nj != 3 && nj != 6) return false;
+    if (ncw == 3 ? (nj != 2 && nj != 3 && nj != 6) || dW * e.Cin != 3072 : (nj != 1 && nj != 2 && nj != 4) || dW * e.Cin != 2048) return false;
     if (dOH != (dH + dsh - 1) / dsh || dOW != (dW + dsw - 1) / dsw) return false;
     const size_t smem = ((size_t)4 * (dW + 2) * (dC + 4) + (size_t)3 * dW * (e.Cin + 4)) * sizeof(float);
-    return smem <= 156 * 1024 && dW * e.Cin == 3072 && (long)e.H * e.W * e.Cin * 4 < 0x7fff0000L;
+    return smem <= 156 * 1024 && (long)e.H * e.W * e.Cin * 4 < 0x7fff0000L;
 }
 
 int f32_pwdw_rows(int dOH) {  // output rows per workgroup
@@ -1113,20 +1124,21 @@ bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, fl
         a.spt = stem->pt; a.spl = stem->pl; a.stem_act = stem->act;
     }
     const unsigned blocks = (unsigned)((long)e.B * ((dOH + rb - 1) / rb));
-    const int nj = (e.Cin + 15) / 16;
-#define BN_PWDW(NJV, SV)                                                                                                                    \
-    if (nj == NJV && dsh == SV) {                                                                                                           \
+    const int nj = (e.Cin + 15) / 16, ncw = pwdw_ncw(e.W, e.Cout);
+#define BN_PWDW(NJV, SV, NCWV)                                                                                                              \
+    if (nj == NJV && dsh == SV && ncw == NCWV) {                                                                                            \
         static size_t allowed = 0;                                                                                                          \
         if (smem > allowed) {                                                                                                               \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(f32_pwdw_kernel<NJV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(f32_pwdw_kernel<NJV, SV, NCWV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)smem) != hipSuccess)                                                                               \
                 return false;                                                                                                               \
             allowed = smem;                                                                                                                 \
         }                                                                                                                                   \
-        hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV>), dim3(blocks), dim3(stem ? 768 : 640), smem, s, a);                                                \
+        hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV, NCWV>), dim3(blocks), dim3(stem ? 768 : 640), smem, s, a);                             \
         return true;                                                                                                                        \
     }
-    BN_PWDW(2, 1) BN_PWDW(2, 2) BN_PWDW(3, 1) BN_PWDW(3, 2) BN_PWDW(6, 1) BN_PWDW(6, 2)
+    BN_PWDW(2, 1, 3) BN_PWDW(2, 2, 3) BN_PWDW(3, 1, 3) BN_PWDW(3, 2, 3) BN_PWDW(6, 1, 3) BN_PWDW(6, 2, 3)
+    BN_PWDW(1, 1, 2) BN_PWDW(1, 2, 2) BN_PWDW(2, 1, 2) BN_PWDW(2, 2, 2) BN_PWDW(4, 1, 2) BN_PWDW(4, 2, 2)
 #undef BN_PWDW
     return false;
 }

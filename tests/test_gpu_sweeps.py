@@ -365,10 +365,12 @@ def test_f32_front2_fused_kernel_matches_the_two_strip_kernels(torch_mod):
 
 
 # --------------------------------------------------------------------------------------- float32: expand 1x1 + depthwise 3x3 as one kernel
-def test_f32_pwdw_fused_kernel_matches_the_two_kernels(torch_mod):
+@pytest.mark.parametrize("alpha", [1.5, 1.0])
+def test_f32_pwdw_fused_kernel_matches_the_two_kernels(torch_mod, alpha):
     """``f32_pwdw_kernel`` (inverted-residual blocks: the expand convolution runs inside the depthwise kernel, the expanded map stays in
     LDS) against the two-kernel path (option ``f32_pwdw`` = 0) on BASELINE configs[4]'s topology (alpha = 1.5: all three fused shapes,
-    stride 1 and 2, the zero-padded k-step of Cin = 24): BIT FOR BIT (same summation orders), odd batch sizes, repeated launches; and against
+    stride 1 and 2, the zero-padded k-step of Cin = 24) and on the reference builder's default width (alpha = 1: two channel tiles per
+    producer wave, 256 depthwise threads): BIT FOR BIT (same summation orders), odd batch sizes, repeated launches; and against
     the float64 oracle."""
     torch = torch_mod
     from birdnet_stm32 import _hip
@@ -379,7 +381,7 @@ def test_f32_pwdw_fused_kernel_matches_the_two_kernels(torch_mod):
     from oracle import float_graph
 
     spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
-                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+                       audio_frontend="raw", mag_scale="pcen", alpha=alpha, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
     runner = HipRunner(lower_f32(spec), max_batch=70)
     ops = runner.plan.ops
     heads = [i for i, o in enumerate(ops) if o.p[pk.TAIL_TAG] == pk.PWDW_HEAD]
