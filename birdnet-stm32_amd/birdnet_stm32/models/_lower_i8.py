@@ -861,6 +861,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
         _add_tail_op(pb, plan, tail_blocks, tail_head)
         _tag_scale_pairs(pb)
         _tag_se_gates(pb)
+        _tag_pwdw_pairs(pb)
     return pb.finalize(reuse=not keep_all)
 
 
@@ -880,6 +881,29 @@ def _tag_se_gates(pb: pk.PlanBuilder) -> None:
         a.p[pk.TAIL_TAG] = pk.SEGATE_HEAD
         f1.p[pk.TAIL_TAG] = f2.p[pk.TAIL_TAG] = pk.SEGATE_COVERED
         pb._extra_uses.append((i + 2, a.in0))  # the pooled map is read while the gate is written
+
+
+def _tag_pwdw_pairs(pb: pk.PlanBuilder) -> None:
+    """Expand CONV_2D 1x1 followed by the DEPTHWISE_CONV_2D 3x3 of an inverted-residual block (reference models/blocks.py:88-110): when the
+    depthwise stage is the only reader of the expanded map the pair is tagged and the library may run it as one kernel (``i8_pwdw_kernel``)
+    that never writes the expanded map.  The fused kernel reads the block input while it writes the depthwise output: no slot sharing."""
+    ops = pb.plan.ops
+    for i in range(len(ops) - 1):
+        e, d = ops[i], ops[i + 1]
+        if e.kind != pk.I8_DWPW or d.kind != pk.I8_DW or e.p[29] or e.p[30] or e.p[18] or e.p[34] or e.p[36] or d.in0 != e.out or e.out < 0:
+            continue
+        if e.p[pk.TAIL_TAG] or d.p[pk.TAIL_TAG] or e.p[pk.OP_PATH] != d.p[pk.OP_PATH]:
+            continue
+        if d.p[2] != e.p[14] or (d.p[0], d.p[1]) != (e.p[6], e.p[7]) or d.p[10] != e.p[15]:
+            continue
+        readers = [k for k, o in enumerate(ops) if k != i + 1 and e.out in (o.in0, o.in1)]
+        writers = [k for k, o in enumerate(ops) if o.out == e.out]
+        if readers or writers != [i]:
+            continue
+        e.p[pk.TAIL_TAG] = pk.PWDW8_HEAD
+        d.p[pk.TAIL_TAG] = pk.PWDW8_COVERED
+        if e.in0 >= 0:
+            pb._extra_uses.append((i + 1, e.in0))
 
 
 def _tag_scale_pairs(pb: pk.PlanBuilder) -> None:

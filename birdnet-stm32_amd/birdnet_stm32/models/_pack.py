@@ -34,6 +34,7 @@ TAIL_TAG = 38  # OpRec.p[TAIL_TAG] = TAIL_COVERED: the operator is covered by th
 TAIL_COVERED, TAIL_OP = 0x7A110001, 0x7A110002  # (bn_blob.h; values no other use of p[38] can take)
 FRONT2_HEAD, FRONT2_COVERED = 0x7A110003, 0x7A110004  # front block + the residual block FRONT2_DIST operators further on may run as one kernel
 FRONT2_DIST = 37
+PWDW8_HEAD, PWDW8_COVERED = 0x7A11000C, 0x7A11000D  # the INT8 counterpart (i8_pwdw_kernel)
 PWDW_STEM = 0x7A11000B  # a stem convolution whose only reader is a PWDW pair: the fused kernel may compute the stem rows itself
 PWDW_HEAD, PWDW_COVERED = 0x7A110009, 0x7A11000A  # expand 1x1 + the depthwise 3x3 behind it (inverted-residual blocks) may run as one kernel
 SEGATE_HEAD, SEGATE_COVERED = 0x7A110007, 0x7A110008  # an I8_MEAN operator and the two I8_FC operators of a squeeze-excite gate behind it: may run as one kernel

@@ -46,7 +46,7 @@ struct OptName {
 };
 const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
-    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"front_tpw", &bn::Options::front_tpw},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
@@ -414,6 +414,20 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
             }
             case BN_OP_I8_DWPW: {
                 bn::DwPw8Args a = dwpw8_args(o, oi);
+                if (p[BN_OP_TAIL_TAG] == BN_PWDW8_HEAD && bn::g_opt.i8_pwdw && bn::g_opt.i8_strip && oi + 1 < op_end) {
+                    // inverted-residual block of an exported graph: expand convolution + depthwise stage as one kernel (the expanded map stays in LDS)
+                    const OpRec& d = m->ops[oi + 1];
+                    const int* q = d.p;
+                    if (d.kind == BN_OP_I8_DW && q[BN_OP_TAIL_TAG] == BN_PWDW8_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out) {
+                        const bn::I8ConvGeom g{q[0], q[1], q[2], q[3], q[4], q[6], q[7], q[8], q[9], q[10], q[11], q[12], q[13]};
+                        if (bn::i8_pwdw_supported(a, g) &&
+                            bn::launch_i8_pwdw(a, g, (const int8_t*)m->tensor(d.t[0]), (const int32_t*)m->tensor(d.t[1]), (const int32_t*)m->tensor(d.t[2]),
+                                               (const int32_t*)m->tensor(d.t[3]), (int8_t*)slot_ptr(d.out), s)) {
+                            pwdw_done = oi + 1;
+                            break;
+                        }
+                    }
+                }
                 if (a.transposed && p[36]) {  // QUANTIZE fused into the mel mixer: the input slot holds the float32 spectrogram
                     a.qx = (const float*)in0;
                     a.qminmax = mm;
@@ -1122,7 +1136,7 @@ int bn_get_option(const char* name, int* value) {
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }
 

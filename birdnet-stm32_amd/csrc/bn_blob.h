@@ -83,6 +83,9 @@ struct TensorRec {
 // BN_PWDW_STEM on a BN_OP_F32_STEM operator: the next two operators are a BN_PWDW_HEAD / BN_PWDW_COVERED pair that is the only reader of the
 // stem map; the fused kernel may compute the stem rows itself (the stem map is never written)
 #define BN_PWDW_STEM 0x7A11000B
+// the INT8 counterpart: BN_PWDW8_HEAD on a plain 1x1 BN_OP_I8_DWPW operator, BN_PWDW8_COVERED on the BN_OP_I8_DW operator behind it (i8_pwdw_kernel)
+#define BN_PWDW8_HEAD 0x7A11000C
+#define BN_PWDW8_COVERED 0x7A11000D
 
 #define BN_OP_NP 40
 #define BN_OP_NT 16

@@ -916,6 +916,224 @@ void launch_i8_front_strip(FrontStrip8Args a, hipStream_t s) {
     hipLaunchKernelGGL(i8_front_strip_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Inverted-residual blocks of exported graphs: expand CONV_2D 1x1 (fused activation) -> DEPTHWISE_CONV_2D 3x3 stride S in ONE kernel, the
+// INT8 sibling of f32_pwdw_kernel (bn_f32_strip.hip).  The expanded map (hid = 2 Cin channels at the input resolution) is the largest
+// tensor of the block; here it lives two rows at a time in LDS.  A workgroup of twelve waves owns RB output rows of one chunk; every
+// thread works in both stages, ONE barrier per hidden row:
+//   * expand: the hidden row's (W / 16) x (hid / 16) tiles on the int8 matrix cores, two per wave (A = the packer's weight fragments,
+//     pinned in registers; B = 16 bytes per lane straight from the input row, the next row requested before this one is multiplied;
+//     bytes beyond Cin meet zero weight columns), exact requantisation, the four channels of a lane as one dword into the ring
+//     [2][W + 2][hid] (border columns = the zero point: the SAME padding of the hidden map);
+//   * depthwise: i8_dw_stream_kernel's walk with the ring in place of memory — a thread owns (column, channel quad) items, the 3 x 3
+//     window byte-transposed in registers (a hidden row is read from LDS exactly once, right behind the barrier of its own step, so two
+//     ring rows are enough), three v_dot4_i32_i8 per output, exact requantisation, dword stores coalesced along the channels.
+// Bit-identical to i8_pw_wave_kernel / i8_dwpw_kernel followed by i8_dw_stream_kernel (same integer arithmetic).
+// MEASURED SLOWER than those two (configs[4] in INT8, 1024 chunks: the six pairs 1.18 -> 1.83 ms; 0.566 vs 0.315 ms on the widest): the int8
+// maps are a quarter of the float32 ones, so the two kernels were never far from their vector-ALU time, and here that work (exact
+// requantisation of 1.5 outputs per input byte) runs at ~36 % ALU utilisation between one barrier per row.  Kept behind option i8_pwdw
+// (default 0) with its tests; the float32 sibling is where the fusion pays (bn_f32_strip.hip).
+struct PwDw8Args {
+    const int8_t* x; int8_t* y;
+    const int8_t* pw_w; const int32_t* pw_b; const int32_t* pw_mult; const int32_t* pw_shift;  // fragments [KS][hid/16][64][16]; [hid] x 3
+    const int8_t* dw_w; const int32_t* dw_b; const int32_t* dw_mult; const int32_t* dw_shift;  // [3][3][hid]; [hid] x 3
+    int B, H, W, Cin, hid, OH, OW, pt, pl, RB;
+    int h_zp, h_amin, h_amax;      // the hidden map's quantisation: output of the expand convolution = input of the depthwise one
+    int o_zp, o_amin, o_amax;
+};
+
+template <int S, int KS>
+__global__ __launch_bounds__(768) void i8_pwdw_kernel(PwDw8Args a) {
+    extern __shared__ __attribute__((aligned(16))) int ring8[];  // [2][W + 2][hid / 4] dwords, then the constant tables
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int hq = a.hid >> 2;                      // channel quads (dwords) per position
+    const int rowd = (a.W + 2) * hq;                // dwords per ring row
+    const int rblocks = (a.OH + a.RB - 1) / a.RB;
+    const int wid = xcd_tile(blockIdx.x, gridDim.x);
+    const int ry = wid % rblocks, chunk = wid / rblocks;
+    const int oh0 = ry * a.RB;
+    const int nrows = (a.OH - oh0) < a.RB ? (a.OH - oh0) : a.RB;
+    const int h_lo = S * oh0 - a.pt;
+    const int nhid = S * (nrows - 1) + 3;
+    auto row_ok = [&](int k) { return k >= 0 && k < nhid && h_lo + k >= 0 && h_lo + k < a.H; };
+    const int zp4 = (a.h_zp & 0xff) * 0x01010101, zprow = (a.h_zp & 0xff) * 0x00010101;
+
+    // per-quad constants in LDS (in registers they spilled: 72 dwords per thread): depthwise [hq][6 x v4i] = the three weight rows as
+    // (tap0, tap1, tap2, 0) bytes per channel, bias with the hidden zero point folded in, multipliers, shifts; expand [hq][3 x v4i]
+    v4i* dwt = reinterpret_cast<v4i*>(ring8 + 2 * rowd);
+    v4i* pwt = dwt + 6 * hq;
+    for (int quad = tid; quad < hq; quad += 768) {
+        const int c0 = 4 * quad;
+        v4i wrow[3], bb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int sum = 0;
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {
+                const int k0 = a.dw_w[(ii * 3 + 0) * a.hid + c0 + e], k1 = a.dw_w[(ii * 3 + 1) * a.hid + c0 + e], k2 = a.dw_w[(ii * 3 + 2) * a.hid + c0 + e];
+                wrow[ii][e] = (k0 & 0xff) | ((k1 & 0xff) << 8) | ((k2 & 0xff) << 16);
+                sum += k0 + k1 + k2;
+            }
+            bb[e] = a.dw_b[c0 + e] - a.h_zp * sum;
+        }
+        dwt[6 * quad + 0] = wrow[0]; dwt[6 * quad + 1] = wrow[1]; dwt[6 * quad + 2] = wrow[2]; dwt[6 * quad + 3] = bb;
+        dwt[6 * quad + 4] = *reinterpret_cast<const v4i*>(a.dw_mult + c0);
+        dwt[6 * quad + 5] = *reinterpret_cast<const v4i*>(a.dw_shift + c0);
+        pwt[3 * quad + 0] = *reinterpret_cast<const v4i*>(a.pw_b + c0);
+        pwt[3 * quad + 1] = *reinterpret_cast<const v4i*>(a.pw_mult + c0);
+        pwt[3 * quad + 2] = *reinterpret_cast<const v4i*>(a.pw_shift + c0);
+    }
+    for (int i = tid; i < 4 * hq; i += 768) {       // border columns of both ring rows
+        const int slot = i / (2 * hq), rest = i - slot * 2 * hq;
+        ring8[slot * rowd + (rest < hq ? 0 : (a.W + 1) * hq) + (rest % hq)] = zp4;
+    }
+
+    // ---- expand stage: tiles t = 2 wave + u -> position tile t % npt, channel tile t / npt
+    const int npt = a.W >> 4, nct = a.hid >> 4, ntiles = npt * nct;
+    v4i af[2][KS];
+    int pos_t[2], dst_t[2], cq_t[2];
+    bool live_t[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = 2 * wave + u;
+        live_t[u] = t < ntiles;
+        const int ptile = live_t[u] ? t % npt : 0, ct = live_t[u] ? t / npt : 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[u][ks] = reinterpret_cast<const v4i*>(a.pw_w)[((size_t)ks * nct + ct) * 64 + lane];
+        cq_t[u] = 4 * ct + q;                       // the lane's channel quad of this tile
+        pos_t[u] = 16 * ptile + r;
+        dst_t[u] = (pos_t[u] + 1) * hq + 4 * ct + q;
+    }
+    const int row_bytes = a.W * a.Cin;
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x) + (size_t)chunk * a.H * row_bytes, 0, a.H * row_bytes, 0x00020000);
+    auto request = [&](v4i (&bf)[2][KS], int k) {
+        if (!row_ok(k)) return;
+        const int soff = (h_lo + k) * row_bytes;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int koff = 64 * ks + 16 * q;
+                bf[u][ks] = (v4i){0, 0, 0, 0};
+                if (live_t[u] && koff < a.Cin) bf[u][ks] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_in, pos_t[u] * a.Cin + koff, soff, 0));
+            }
+    };
+    auto expand = [&](const v4i (&bf)[2][KS], int k) {
+        if (!row_ok(k)) return;
+        int* dst = ring8 + (k & 1) * rowd;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live_t[u]) continue;
+            v4i acc = pwt[3 * cq_t[u] + 0];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u][ks], bf[u][ks], acc, 0, 0, 0);
+            const v4i cm = pwt[3 * cq_t[u] + 1], cs = pwt[3 * cq_t[u] + 2];
+            int packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) packed |= (med3(mbqm(acc[e], cm[e], cs[e]) + a.h_zp, a.h_amin, a.h_amax) & 0xff) << (8 * e);
+            dst[dst_t[u]] = packed;
+        }
+    };
+
+    // ---- depthwise stage: items i = tid + 768 u -> (column i / hq, channel quad i % hq)
+    const int items = a.OW * hq;
+    int T[2][3][4], src_d[2], out_off[2], quad_i[2];
+    bool live_i[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 768 * u;
+        live_i[u] = i < items;
+        const int ow = live_i[u] ? i / hq : 0, quad = live_i[u] ? i - ow * hq : 0;
+        quad_i[u] = quad;
+        src_d[u] = (S * ow - a.pl + 1) * hq + quad;           // tap j of a ring row at [src_d + j hq]
+        out_off[u] = ow * a.hid + 4 * quad;
+    }
+    int8_t* ybase = a.y + (size_t)chunk * a.OH * a.OW * a.hid;
+    auto consume = [&](int k, int ti) {                       // hidden row k -> window slot ti of every item
+        const int* src = ring8 + (k & 1) * rowd;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live_i[u]) continue;
+            if (row_ok(k)) {
+                const int r0 = src[src_d[u]], r1 = src[src_d[u] + hq], r2 = src[src_d[u] + 2 * hq];
+                const int lo = perm(r1, r0, 0x05010400u), hi = perm(r1, r0, 0x07030602u);
+                T[u][ti][0] = perm(r2, lo, 0x0c040100u);
+                T[u][ti][1] = perm(r2, lo, 0x0c050302u);
+                T[u][ti][2] = perm(r2, hi, 0x0c060100u);
+                T[u][ti][3] = perm(r2, hi, 0x0c070302u);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[u][ti][e] = zprow;
+            }
+        }
+    };
+    auto emit = [&](int i0, int i1, int i2, int oh) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live_i[u]) continue;
+            const v4i* c = dwt + 6 * quad_i[u];
+            const v4i w0 = c[0], w1 = c[1], w2 = c[2], bb = c[3], mm = c[4], ss = c[5];
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int acc = dot4_first(T[u][i0][e], w0[e], bb[e]);
+                acc = dot4(T[u][i1][e], w1[e], acc);
+                acc = dot4(T[u][i2][e], w2[e], acc);
+                qv[e] = med3(mbqm(acc, mm[e], ss[e]) + a.o_zp, a.o_amin, a.o_amax);
+            }
+            const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+            *reinterpret_cast<int*>(ybase + (size_t)oh * a.OW * a.hid + out_off[u]) = word;
+        }
+    };
+
+    // ---- the walk: step k = expand row k (its B fragments were requested a step ago), barrier, rows into the windows, output row if due
+    v4i bfa[2][KS], bfb[2][KS];
+    request(bfa, 0);
+    __syncthreads();                                          // border columns
+    auto step = [&](const v4i (&cur)[2][KS], v4i (&nxt)[2][KS], int k, int ti, int i0, int i1) {
+        request(nxt, k + 1);
+        expand(cur, k);
+        __syncthreads();
+        consume(k, ti);
+        if (k >= 2 && (k - 2) % S == 0 && (k - 2) / S < nrows) emit(i0, i1, ti, oh0 + (k - 2) / S);
+    };
+    for (int k = 0; k < nhid; k += 6) {                       // (window slots and the two B buffers rotate with periods 3 and 2)
+        step(bfa, bfb, k + 0, 0, 1, 2);
+        if (k + 1 < nhid) step(bfb, bfa, k + 1, 1, 2, 0);
+        if (k + 2 < nhid) step(bfa, bfb, k + 2, 2, 0, 1);
+        if (k + 3 < nhid) step(bfb, bfa, k + 3, 0, 1, 2);
+        if (k + 4 < nhid) step(bfa, bfb, k + 4, 1, 2, 0);
+        if (k + 5 < nhid) step(bfb, bfa, k + 5, 2, 0, 1);
+    }
+}
+
+bool i8_pwdw_supported(const DwPw8Args& e, const I8ConvGeom& d) {
+    if (!g_opt.i8_strip || e.has_dw || e.transposed || e.add.enabled || e.lut || e.qx || e.gate || e.H != e.OH || e.W != e.OW) return false;
+    if (d.H != e.H || d.W != e.W || d.C != e.Cout || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.zp_in != e.pw_zp_out) return false;
+    if (e.W % 16 || e.Cout % 16 || e.Cin % 4 || e.Cin > 128 || (e.W / 16) * (e.Cout / 16) > 24) return false;
+    if ((long)d.OW * (e.Cout / 4) > 2 * 768 || (size_t)2 * (e.W + 2) * e.Cout > 60000) return false;
+    return (long)e.H * e.W * e.Cin < 0x7fff0000L && (long)d.OH * d.OW * d.C < 0x7fff0000L;
+}
+
+bool launch_i8_pwdw(const DwPw8Args& e, const I8ConvGeom& d, const int8_t* dw_w, const int32_t* dw_b, const int32_t* dw_mult, const int32_t* dw_shift,
+                    int8_t* y, hipStream_t s) {
+    int rb = d.OH;
+    while (rb > 16) rb = (rb + 1) / 2;
+    PwDw8Args a{e.x, y, e.pw_w, e.pw_b, e.pw_mult, e.pw_shift, dw_w, dw_b, dw_mult, dw_shift, e.B, e.H, e.W, e.Cin, e.Cout, d.OH, d.OW, d.pt, d.pl, rb,
+                e.pw_zp_out, e.pw_amin, e.pw_amax, d.zp_out, d.amin, d.amax};
+    const unsigned blocks = (unsigned)((long)e.B * ((d.OH + rb - 1) / rb));
+    const size_t smem = (size_t)2 * (e.W + 2) * e.Cout + (size_t)(e.Cout / 4) * 9 * 16;  // ring + per-quad constants
+    const int ks = (e.Cin + 63) / 64;
+#define BN_PWDW8(SV, KSV) \
+    if (d.sh == SV && ks == KSV) { hipLaunchKernelGGL((i8_pwdw_kernel<SV, KSV>), dim3(blocks), dim3(768), smem, s, a); return true; }
+    BN_PWDW8(1, 1) BN_PWDW8(2, 1) BN_PWDW8(1, 2) BN_PWDW8(2, 2)
+#undef BN_PWDW8
+    return false;
+}
+
 bool launch_i8_dw_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias, const int32_t* mult,
                          const int32_t* shift, hipStream_t s) {
     if (!g_opt.i8_strip || g.sh != g.sw || (g.sh != 1 && g.sh != 2) || g.C % 4 || (long)g.H * g.W * g.C >= 0x7fff0000L ||

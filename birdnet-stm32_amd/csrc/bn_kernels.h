@@ -16,6 +16,8 @@ struct Options {
     int f32_strip = 1;         // float32 row-streaming strip kernels (0: tile kernels everywhere)
     int f32_strip_th = 0;      // force the rows per strip (0: the launcher's choice)
     int f32_front_staged = 1;  // LDS-staged form of the float32 front strip kernel
+    int i8_pwdw = 0;           // 1: expand 1x1 + depthwise 3x3 of exported inverted-residual graphs as one kernel (i8_pwdw_kernel; bit-identical, but
+                               // measured 1.5-1.8 x SLOWER than the two kernels: off by default)
     int f32_tile_slice = 0;    // > 0: cap on the 16-column tiles per workgroup slice of the f32 tile kernel (0: the default cap of 16)
     int f32_pwdw = 2;          // expand 1x1 + depthwise 3x3 of inverted-residual blocks as one kernel (the expanded map stays in LDS); 2: it also
                                // hands the squeeze-excite gate behind it per-row-block channel sums (1: the gate pools the map itself, bit-identical to 0)
@@ -229,6 +231,9 @@ struct DwPw8Args {
     int g_zx, g_zg, g_mult, g_shift, g_zo, g_amin, g_amax;
 };
 bool i8_dwpw_supported(int Cin, int Cout);
+bool i8_pwdw_supported(const DwPw8Args& expand, const I8ConvGeom& dw);
+bool launch_i8_pwdw(const DwPw8Args& expand, const I8ConvGeom& dw, const int8_t* dw_w, const int32_t* dw_b, const int32_t* dw_mult, const int32_t* dw_shift,
+                    int8_t* y, hipStream_t s);
 bool i8_pw_wave_takes(const DwPw8Args& a);  // the wave-level 1x1 convolution kernel (the only one that applies DwPw8Args::gate) runs this operator
 bool i8_mel_mfma_supported(const DwPw8Args& a);
 // Wave-autonomous strip kernel for the same block at Cin, Cout in {32, 64} (bn_i8_strip.hip); `cst` is the constant block

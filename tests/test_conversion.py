@@ -405,6 +405,11 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
     assert np.array_equal(prod.predict(x), got)
     for nb in (1, 3):
         assert np.array_equal(prod.predict(x[:nb]), got[:nb])
+    from birdnet_stm32 import _hip
+
+    with _hip.options(i8_pwdw=1):  # expand + depthwise of inverted-residual blocks as one kernel (off by default: measured slower), same integers
+        assert np.array_equal(prod.predict(x), got)
+        assert np.array_equal(prod.predict(x[:3]), got[:3])
     prod.close()
 
 

@@ -38,6 +38,11 @@ else:
     spec.frontend.attrs["norm"] = True
     model = parse_tflite(write_tflite(convert_netspec_to_int8(spec, lambda: ([c] for c in cal), frontend_norm=True)))
 r = HipRunner(lower_i8(model), max_batch=B)
+if os.environ.get("BN_OPTS"):  # launcher options for experiments: BN_OPTS="i8_pwdw=0"
+    from birdnet_stm32 import _hip
+    for kv in os.environ["BN_OPTS"].split(","):
+        k, v = kv.split("=")
+        _hip.set_option(k, int(v))
 x = torch.randn((B, 48000 if raw else 72000), device="cuda")
 x = x / x.abs().amax(dim=1, keepdim=True)
 for _ in range(2):
