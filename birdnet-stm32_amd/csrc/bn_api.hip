@@ -391,6 +391,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
             case BN_OP_I8_STEM:
             case BN_OP_I8_DW: {
                 bn::I8ConvGeom g{p[0], p[1], p[2], p[3], p[4], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13]};
+                g.rq_right = m->rq_right[oi];
                 if (o.kind == BN_OP_I8_DW &&  // row-streaming form (three loads per input row instead of nine per output) where the shape allows
                     bn::launch_i8_dw_stream((const int8_t*)in0, (int8_t*)out, B, g, (const int8_t*)m->tensor(o.t[0]), (const int32_t*)m->tensor(o.t[1]),
                                             (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]), s))
@@ -747,6 +748,8 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             bool ok = all_right(o.t[6], o.t[7]) && (!p[29] || all_right(o.t[2], o.t[3]));
             if (p[18]) ok = ok && p[20] >= 0 && p[21] < 0 && p[22] >= 0 && p[23] < 0 && p[24] >= 0 && p[25] < 0;  // ADD: m1 s1 m2 s2 mo so
             m->rq_right[oi] = ok;
+        } else if (o.kind == BN_OP_I8_DW || o.kind == BN_OP_I8_STEM) {
+            m->rq_right[oi] = all_right(o.t[2], o.t[3]);
         } else if (o.kind == BN_OP_I8_FRONT) {
             m->rq_right[oi] = all_right(o.t[2], o.t[3]) && all_right(o.t[6], o.t[7]) && all_right(o.t[10], o.t[11]);
         }

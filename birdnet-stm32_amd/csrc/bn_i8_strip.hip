@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
 struct DwStream8Args {
     const int8_t* x; int8_t* y;
     const int8_t* w; const int32_t* bias; const int32_t* mult; const int32_t* shift;   // [3][3][C], [C], [C], [C]
-    int B, H, W, C, OH, OW, TH, pt, pl, zp_in, zp_out, amin, amax, CQ;
+    int B, H, W, C, OH, OW, TH, pt, pl, zp_in, zp_out, amin, amax, CQ, rq_right;
 };
 
 template <int S>
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             int acc = dot4_first(T[i0][e], wr[0][e], bias[e]);
             acc = dot4(T[i1][e], wr[1][e], acc);
             acc = dot4(T[i2][e], wr[2][e], acc);
-            qv[e] = med3(mbqm(acc, mult[e], shift[e]) + a.zp_out, a.amin, a.amax);
+            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], a.rq_right != 0) + a.zp_out, a.amin, a.amax);
         }
         const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         __builtin_amdgcn_raw_buffer_store_b32(word, rs_out, voff_out, oh * a.OW * a.C, 0);
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, in
             int acc = dot4_first(T[i0], wr[0][e], bias[e]);
             acc = dot4(T[i1], wr[1][e], acc);
             acc = dot4(T[i2], wr[2][e], acc);
-            qv[e] = med3(mbqm(acc, mult[e], shift[e]) + a.zp_out, a.amin, a.amax);
+            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], a.rq_right != 0) + a.zp_out, a.amin, a.amax);
         }
         const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         __builtin_amdgcn_raw_buffer_store_b32(word, rs_out, voff_out, oh * a.OW * a.C, 0);
@@ -1141,7 +1141,7 @@ bool launch_i8_dw_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g,
         return false;
     int cq = 16;
     while ((g.C / 4) % cq) cq >>= 1;
-    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq};
+    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq, g.rq_right};
     const int ncol = 64 / cq;
     const long per_row_block = (long)B * (g.C / (4 * cq)) * ((g.OW + ncol - 1) / ncol);
     int th = g.OH;
@@ -1162,7 +1162,7 @@ bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& 
     if (!g_opt.i8_strip || (g.sh != 1 && g.sh != 2) || g.sw < 1 || g.sw > 2 || g.C % 4 || (long)g.OH * g.OW * g.C >= 0x7fff0000L) return false;
     int cq = 16;
     while ((g.C / 4) % cq) cq >>= 1;
-    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq};
+    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq, g.rq_right};
     const int ncol = 64 / cq;
     const long per_row_block = (long)B * (g.C / (4 * cq)) * ((g.OW + ncol - 1) / ncol);
     int th = g.OH;

@@ -164,6 +164,7 @@ void launch_i8_mel(const int8_t* x, int8_t* y, int B, int W, int Kp, int M, int 
                    hipStream_t s);
 struct I8ConvGeom {
     int H, W, C, sh, sw, OH, OW, pt, pl, zp_in, zp_out, amin, amax;
+    int rq_right = 0;  // every multiplier >= 0 and every shift < 0 (set at load): the row-streaming kernels take the branch-free requantisation
 };
 void launch_i8_stem(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias,
                     const int32_t* mult, const int32_t* shift, hipStream_t s);
