@@ -672,6 +672,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
             }
     }
     const int P = a.OH * a.OW;
+    const bool g_right = a.g_mult >= 0 && a.g_shift < 0;  // (uniform) the gate's MUL requantises with a plain right shift: branch-free form
     for (; grp < n_groups; grp += stride) {
     fetch(grp + stride, bnx);
     const long pos = grp * 16 + r;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int xv = (int)(int8_t)(bfr[s][d] >> (8 * e)) - a.g_zx, g = (int)(int8_t)(gv[d] >> (8 * e)) - a.g_zg;
-                        packed |= (clampi(mbqm(xv * g, a.g_mult, a.g_shift) + a.g_zo, a.g_amin, a.g_amax) & 0xff) << (8 * e);
+                        packed |= (clampi(mbqm_u(xv * g, a.g_mult, a.g_shift, g_right) + a.g_zo, a.g_amin, a.g_amax) & 0xff) << (8 * e);
                     }
                     o[d] = packed;
                 }
