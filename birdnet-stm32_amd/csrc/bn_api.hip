@@ -286,7 +286,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                         const bn::DwPwArgs ea = dwpw_args(e);
                         const bn::F32StemIn st{(const float*)in0, (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), p[0], p[1], p[3], p[4],
                                                p[8], p[9], p[5]};
-                        if (ea.W == 128 && ea.Cin % 8 == 0 && bn::f32_pwdw_supported(ea, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&  // (one stem position per loader thread)
+                        if (ea.Cin <= 32 && bn::f32_pwdw_supported(ea, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&  // (the stem on the matrix cores feeds at most two channel tiles)
                             bn::launch_f32_pwdw(ea, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7],
                                                 q[8], q[9], q[5], &st, gap_target(oi + 2), s)) {
                             pwdw_head_done = oi + 1;

@@ -802,7 +802,7 @@ struct F32PwDwArgs {
 
 // NCW = channel tiles per producer wave: 3 for hid % 48 == 0 (alpha = 1.5: W x hid = 6144), 2 for hid % 32 == 0 (alpha = 1: W x hid = 4096)
 template <int NJ, int S, int NCW>
-__global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
+__global__ __launch_bounds__(640) void f32_pwdw_kernel(F32PwDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ring3[];  // [4][W + 2][hid + 4] (column hx at index hx + 1), then [3][W][Cin + 4]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -843,16 +843,59 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
         for (int j = 0; j < NJ; ++j) chan_ok[j] = 16 * j + 4 * kq < a.Cin;
         const int src_off = (32 * pp + n) * PI + 4 * kq;
         const int dst_off = (1 + 32 * pp + n) * P + 16 * NCW * tc + 4 * kq;
+        // stem mode (a.fe): the wave computes the stem outputs of ITS two position tiles itself, on the matrix cores — the contraction index of
+        // MFMA i is the window column (lane group kq < 3), window row i per instruction, so a lane's accumulators end up as the stem channels
+        // 16 j + 4 kq .. + 3 of its position: exactly its B fragments of the expand convolution.  Taps of the frontend map (64 KB per chunk,
+        // cache resident) are requested a row ahead.  f32_stem_kernel's summation order (bias, taps row by row; a tap outside the map adds 0).
+        constexpr bool STEM_OK = NJ <= 2;           // (a stem feeds at most 32 channels; the wide instantiations do not carry this code)
+        constexpr int NJS = STEM_OK ? NJ : 1;
+        float sa[3][NJS], tcur[2][3], tnext[2][3];
+        v4f sbias[NJS];
+        const bool stem = STEM_OK && a.fe != nullptr;
+        const ActBounds st_bounds = act_bounds(a.stem_act);
+        const float* fmap = stem ? a.fe + (size_t)chunk * a.H0 * a.W0 : nullptr;
+        auto taps = [&](float (&v)[2][3], int k) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int ih = (h_lo + k) * a.ssh - a.spt + i, iw = (32 * pp + 16 * u + n) * a.ssw - a.spl + kq;
+                    v[u][i] = (row_ok(k) && kq < 3 && ih >= 0 && ih < a.H0 && iw >= 0 && iw < a.W0) ? fmap[ih * a.W0 + iw] : 0.0f;
+                }
+        };
+        if (stem) {
+#pragma unroll
+            for (int j = 0; j < NJS; ++j) {
+                const int ch = 16 * j + n;           // A operand row = stem channel
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sa[i][j] = (kq < 3 && ch < a.Cin) ? a.stem_w[(i * 3 + kq) * a.Cin + ch] : 0.0f;
+                sbias[j] = chan_ok[j] ? *reinterpret_cast<const v4f*>(a.stem_b + 16 * j + 4 * kq) : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            taps(tcur, 0);
+        }
         __syncthreads();                            // staging row 0 and the ring's border columns are in place
         for (int t = 0; t < nsteps; ++t) {
+            if (stem) taps(tnext, t + 1);
             if (row_ok(t)) {
                 const float* src = stage + (t % 3) * a.W * PI + src_off;
                 v4f bf[2][NJ];
+                if (stem) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        bf[u][j] = chan_ok[j] ? *reinterpret_cast<const v4f*>(src + 16 * u * PI + 16 * j) : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                        for (int j = 0; j < NJS; ++j) {
+                            v4f st = sbias[j];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) mfma_acc(st, sa[i][j], tcur[u][i]);
+                            bf[u][j] = act4(st, st_bounds);
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            bf[u][j] = chan_ok[j] ? *reinterpret_cast<const v4f*>(src + 16 * u * PI + 16 * j) : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+                }
                 float* dst = ring3 + (((h_lo + t) & 3) * (a.W + 2)) * P + dst_off;
                 v4f acc[2][NCW];  // the tiles' chains interleaved: consecutive matrix instructions never depend on each other
 #pragma unroll
@@ -872,6 +915,12 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
 #pragma unroll
                     for (int c = 0; c < NCW; ++c)  // bias behind the sum, as the stand-alone 1x1 kernels add it: the pair stays bit-identical to them
                         *reinterpret_cast<v4f*>(dst + 16 * u * P + 16 * c) = act4(acc[u][c] + pbias[c], pw_bounds);
+            }
+            if (stem) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) tcur[u][i] = tnext[u][i];
             }
             __syncthreads();
         }
@@ -971,60 +1020,6 @@ __global__ __launch_bounds__(768) void f32_pwdw_kernel(F32PwDwArgs a) {
 #pragma unroll
             for (int e = 0; e < NLD; ++e) *reinterpret_cast<v4f*>(dst + st_off[e]) = r[e];
         };
-        if (a.fe) {
-            // stem mode (W = 128 positions, 256 loader threads): a thread computes half the channels of ITS position of stem row k, one step
-            // before the producers multiply it.  Its nine taps of the frontend map (64 KB per chunk, cache resident) are requested a step ahead;
-            // the weights are wave-uniform and come as LDS broadcasts.  Summation order of f32_stem_kernel: bias, then the taps row by row
-            // (a tap outside the map contributes an exact 0 instead of being skipped).
-            const float* fmap = a.fe + (size_t)chunk * a.H0 * a.W0;
-            const ActBounds st_bounds = act_bounds(a.stem_act);
-            float* swl = stage + 3 * a.W * PI;               // [9][Cin] stem weights, then [Cin] bias
-            // (each of the loader waves writes the whole table itself — the same values — and reads it behind its own writes: no barrier)
-            for (int i = lane; i < 10 * a.Cin; i += 64) swl[i] = i < 9 * a.Cin ? a.stem_w[i] : a.stem_b[i - 9 * a.Cin];
-            const int spos = lt & 127, half = lt >> 7;        // four loader waves in this mode: two threads per position, half the channel quads each
-            const int qpt = cq4 >> 1;
-            const int iw0 = spos * a.ssw - a.spl;
-            auto taps = [&](float (&v)[9], int k) {
-                const int ih0 = (h_lo + k) * a.ssh - a.spt;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int ih = ih0 + i, iw = iw0 + j;
-                        const bool ok = row_ok(k) && ih >= 0 && ih < a.H0 && iw >= 0 && iw < a.W0;
-                        v[i * 3 + j] = ok ? fmap[ih * a.W0 + iw] : 0.0f;
-                    }
-            };
-            auto stem_row = [&](const float (&v)[9], int k) {
-                if (!row_ok(k)) return;
-                float* dst = stage + (k % 3) * a.W * PI + spos * PI;
-#pragma unroll 2
-                for (int quad = half * qpt; quad < (half + 1) * qpt; ++quad) {
-                    v4f acc = *reinterpret_cast<const v4f*>(swl + 9 * a.Cin + 4 * quad);
-#pragma unroll
-                    for (int t9 = 0; t9 < 9; ++t9)
-                        acc = __builtin_elementwise_fma((v4f){v[t9], v[t9], v[t9], v[t9]}, *reinterpret_cast<const v4f*>(swl + t9 * a.Cin + 4 * quad), acc);
-                    *reinterpret_cast<v4f*>(dst + 4 * quad) = act4(acc, st_bounds);
-                }
-            };
-            float va[9], vb[9];
-            taps(va, 0);
-            taps(vb, 1);
-            stem_row(va, 0);
-            __syncthreads();
-            for (int t = 0; t < nsteps; t += 2) {
-                taps(va, t + 2);
-                stem_row(vb, t + 1);
-                __syncthreads();
-                if (t + 1 < nsteps) {
-                    taps(vb, t + 3);
-                    stem_row(va, t + 2);
-                    __syncthreads();
-                }
-            }
-            __syncthreads();
-            return;
-        }
         v4f r0[NLD], r1[NLD], r2[NLD];
         request(r0, 0);
         request(r1, 1);
@@ -1115,7 +1110,7 @@ int f32_pwdw_rows(int dOH) {  // output rows per workgroup
 
 bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, float* y, int dsh, int dOH, int dOW, int dpt, int dpl, int dw_act,
                      const F32StemIn* stem, float* gap_part, hipStream_t s) {
-    const size_t smem = ((size_t)4 * (e.W + 2) * (e.Cout + 4) + (size_t)3 * e.W * (e.Cin + 4) + (stem ? 10 * e.Cin : 0)) * sizeof(float);
+    const size_t smem = ((size_t)4 * (e.W + 2) * (e.Cout + 4) + (size_t)3 * e.W * (e.Cin + 4)) * sizeof(float);
     const int rb = f32_pwdw_rows(dOH);
     F32PwDwArgs a{e.x, y, e.pw_w, e.pw_b, dw_w, dw_b, e.B, e.H, e.W, e.Cin, e.Cout, dOH, dOW, dpt, dpl, e.pw_act, dw_act, rb,
                   nullptr, nullptr, nullptr, 0, 0, 1, 1, 0, 0, 0, gap_part};
@@ -1134,7 +1129,7 @@ bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, fl
                 return false;                                                                                                               \
             allowed = smem;                                                                                                                 \
         }                                                                                                                                   \
-        hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV, NCWV>), dim3(blocks), dim3(stem ? 768 : 640), smem, s, a);                             \
+        hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV, NCWV>), dim3(blocks), dim3(stem ? 512 : 640), smem, s, a);  /* stem mode: no loader waves */                             \
         return true;                                                                                                                        \
     }
     BN_PWDW(2, 1, 3) BN_PWDW(2, 2, 3) BN_PWDW(3, 1, 3) BN_PWDW(3, 2, 3) BN_PWDW(6, 1, 3) BN_PWDW(6, 2, 3)
