@@ -300,10 +300,24 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 bn::launch_f32_stem((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
                                     p[8], p[9], (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
                 break;
-            case BN_OP_F32_DW:
-                bn::launch_f32_dw((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
-                                  p[8], p[9], (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), s);
+            case BN_OP_F32_DW: {
+                // a squeeze-excite gate right behind the stage pools per-strip channel sums written by the depthwise kernel (as behind fused pairs)
+                float* gp = nullptr;
+                int R = 0;
+                if (bn::g_opt.f32_pwdw >= 2 && m->d_gap_part && oi + 1 < op_end) {
+                    const OpRec& g = m->ops[oi + 1];
+                    R = bn::f32_dw_stream_strips(B, p[2], p[6], p[7]);
+                    if (g.kind == BN_OP_F32_SEGATE && g.in0 == o.out && g.p[1] == p[2] && g.p[0] == p[6] * p[7] && (size_t)R * p[2] <= m->gap_part_elems &&
+                        (g.p[BN_OP_PATH] == BN_PATH_BOTH || g.p[BN_OP_PATH] == mode))
+                        gp = m->d_gap_part;
+                }
+                if (bn::launch_f32_dw((const float*)in0, (float*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9],
+                                      (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]), gp, s) && gp) {
+                    gap_for = oi + 1;
+                    gap_R = R;
+                }
                 break;
+            }
             case BN_OP_F32_PW:
                 bn::launch_f32_pw((const float*)in0, p[4] ? (const float*)in1 : nullptr,
                                   p[5] ? (const float*)slot_ptr(p[6]) : nullptr, (float*)out, B, p[0], p[1], p[2], p[3],
@@ -790,6 +804,15 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             const int* q = m->ops[i + 1].p;
             const int rb = bn::f32_pwdw_rows(q[6]);
             const size_t need = (size_t)((q[6] + rb - 1) / rb) * (size_t)q[2];
+            if (need > m->gap_part_elems) m->gap_part_elems = need;
+        }
+    for (size_t i = 0; i + 1 < m->ops.size(); ++i)  // stand-alone depthwise stage -> gate: one partial sum per strip (at most OH / 4 row blocks)
+        if (m->ops[i].kind == BN_OP_F32_DW && m->ops[i + 1].kind == BN_OP_F32_SEGATE && m->ops[i + 1].in0 == m->ops[i].out) {
+            const int* q = m->ops[i].p;
+            int cq = 16;
+            while ((q[2] / 4) % cq) cq >>= 1;
+            const int ncol = 64 / cq;
+            const size_t need = (size_t)((q[7] + ncol - 1) / ncol) * (size_t)((q[6] + 3) / 4) * (size_t)q[2];
             if (need > m->gap_part_elems) m->gap_part_elems = need;
         }
     if (m->gap_part_elems) {

@@ -523,12 +523,13 @@ void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, in
                        pl, w, bias, total);
 }
 
-void launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW,
-                   int pt, int pl, const float* w, const float* bias, hipStream_t s) {
-    if (launch_f32_dw_stream(x, y, B, H, W, C, sh, sw, act, OH, OW, pt, pl, w, bias, s)) return;
+bool launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW,
+                   int pt, int pl, const float* w, const float* bias, float* gap_part, hipStream_t s) {
+    if (launch_f32_dw_stream(x, y, B, H, W, C, sh, sw, act, OH, OW, pt, pl, w, bias, gap_part, s)) return true;
     const long total = (long)B * OH * OW * (C / 4);
     hipLaunchKernelGGL(f32_dw_kernel, grid1d(total, 256), dim3(256), 0, s, x, y, H, W, C, sh, sw, act, OH, OW, pt, pl,
                        w, bias, total);
+    return false;
 }
 
 void launch_f32_pw(const float* x, const float* res, const float* gate, float* y, int B, int P, int Cin, int Cout,

@@ -663,6 +663,7 @@ struct DwStreamArgs {
     const float* w;     // [3][3][C]
     const float* bias;  // [C]
     int B, H, W, C, OH, OW, TH, pt, pl, act, CQ;
+    float* gap_part;    // optional: [B][strips_x * row blocks][C] channel sums of every wave's strip, for the squeeze-excite gate behind the stage
 };
 
 template <int S>
@@ -728,6 +729,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             for (int j = 0; j < 3; ++j) T[ti].t[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
         }
     };
+    v4f gsum = {0.0f, 0.0f, 0.0f, 0.0f};
     auto emit = [&](int i0, int i1, int i2, int oh) {
         v4f acc = b4;
 #pragma unroll
@@ -736,7 +738,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             acc = __builtin_elementwise_fma(T[i1].t[j], wt[1][j], acc);
             acc = __builtin_elementwise_fma(T[i2].t[j], wt[2][j], acc);
         }
-        store16(rs_out, act4(acc, bounds), voff_out, oh * a.OW * a.C * 4);
+        const v4f o = act4(acc, bounds);
+        if (live) gsum += o;
+        store16(rs_out, o, voff_out, oh * a.OW * a.C * 4);
     };
     constexpr int P = 3 - S;
     issue(0, 0);
@@ -759,6 +763,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
             }
             emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
         }
+    }
+    if (a.gap_part) {  // the strip's channel sums: the NCOL columns of a quad are lanes cq, cq + CQ, ...: a butterfly over the lane bits above CQ
+        for (int m = CQ; m < 64; m <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gsum[e] += __shfl_xor(gsum[e], m, 64);
+        }
+        if (n == 0) *reinterpret_cast<v4f*>(a.gap_part + ((size_t)chunk * strips_x * rblocks + (size_t)ry * strips_x + sx) * a.C + c0) = gsum;
     }
 }
 
@@ -1061,19 +1072,38 @@ bool f32_strip_supported(const DwPwArgs& a) {
     return shape && (long)a.H * a.W * a.Cin * 4 < 0x7fff0000L;
 }
 
-bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW, int pt, int pl,
-                          const float* w, const float* bias, hipStream_t s) {
-    if (sh != sw || (sh != 1 && sh != 2) || C % 4 || (long)H * W * C * 4 >= 0x7fff0000L || (long)OH * OW * C * 4 >= 0x7fff0000L) return false;
-    if (!g_opt.f32_strip) return false;
+// rows per strip of the stand-alone depthwise kernel and the strips per chunk that follow from them (the squeeze-excite gate behind the stage
+// adds up one partial sum per strip: f32_dw_stream_strips is what its scratch must hold per chunk and channel)
+// (with partial sums the strip height must not depend on the batch size: a chunk's scores may not change with the size of the batch it sits in)
+static void dw_stream_plan(int B, int C, int OH, int OW, bool batch_independent, int* cq_out, int* th_out) {
     int cq = 16;
     while ((C / 4) % cq) cq >>= 1;
-    DwStreamArgs a{x, y, w, bias, B, H, W, C, OH, OW, 0, pt, pl, act, cq};
     const int ncol = 64 / cq;
     const long per_row_block = (long)B * (C / (4 * cq)) * ((OW + ncol - 1) / ncol);
     int th = OH;
     while (th > 16) th = (th + 1) / 2;
-    while (th > 4 && per_row_block * ((OH + th - 1) / th) < 8192) th = (th + 1) / 2;
+    while (!batch_independent && th > 4 && per_row_block * ((OH + th - 1) / th) < 8192) th = (th + 1) / 2;
     if (const int v = g_opt.f32_strip_th; v >= 1) th = v < OH ? v : OH;
+    *cq_out = cq;
+    *th_out = th;
+}
+
+int f32_dw_stream_strips(int B, int C, int OH, int OW) {
+    int cq, th;
+    dw_stream_plan(B, C, OH, OW, true, &cq, &th);
+    const int ncol = 64 / cq;
+    return ((OW + ncol - 1) / ncol) * ((OH + th - 1) / th);
+}
+
+bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW, int pt, int pl,
+                          const float* w, const float* bias, float* gap_part, hipStream_t s) {
+    if (sh != sw || (sh != 1 && sh != 2) || C % 4 || (long)H * W * C * 4 >= 0x7fff0000L || (long)OH * OW * C * 4 >= 0x7fff0000L) return false;
+    if (!g_opt.f32_strip) return false;
+    int cq, th;
+    dw_stream_plan(B, C, OH, OW, gap_part != nullptr, &cq, &th);
+    DwStreamArgs a{x, y, w, bias, B, H, W, C, OH, OW, 0, pt, pl, act, cq, gap_part};
+    const int ncol = 64 / cq;
+    const long per_row_block = (long)B * (C / (4 * cq)) * ((OW + ncol - 1) / ncol);
     a.TH = th;
     const long waves = per_row_block * ((OH + th - 1) / th);
     if (sh == 1)

@@ -91,8 +91,9 @@ void launch_f32_mag(float* x, const float* smax, int B, int M, int W, const floa
 void launch_u32_fill(uint32_t* p, uint32_t v, int n, hipStream_t s);
 void launch_f32_stem(const float* x, float* y, int B, int H, int W, int Cout, int sh, int sw, int act, int OH, int OW,
                      int pt, int pl, const float* w, const float* bias, hipStream_t s);
-void launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW,
-                   int pt, int pl, const float* w, const float* bias, hipStream_t s);
+// returns true when the row-streaming kernel ran (only it writes gap_part, the per-strip channel sums for a squeeze-excite gate behind the stage)
+bool launch_f32_dw(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW,
+                   int pt, int pl, const float* w, const float* bias, float* gap_part, hipStream_t s);
 void launch_f32_pw(const float* x, const float* res, const float* gate, float* y, int B, int P, int Cin, int Cout,
                    int act, const float* w, const float* bias, hipStream_t s);
 void launch_f32_segate(const float* x, float* gate, int B, int P, int C, int Cr, const float* w1, const float* w2,
@@ -138,8 +139,9 @@ struct F32FrontStripArgs {
 bool f32_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW);
 void launch_f32_front_strip(F32FrontStripArgs a, hipStream_t s);
 // stand-alone depthwise 3x3 as a row-streaming kernel (bn_f32_strip.hip); false = shape not taken, use launch_f32_dw's own kernel
+int f32_dw_stream_strips(int B, int C, int OH, int OW);  // partial sums per chunk and channel that launch_f32_dw_stream writes into gap_part
 bool launch_f32_dw_stream(const float* x, float* y, int B, int H, int W, int C, int sh, int sw, int act, int OH, int OW, int pt, int pl,
-                          const float* w, const float* bias, hipStream_t s);
+                          const float* w, const float* bias, float* gap_part /* [B][f32_dw_stream_strips][C] or null */, hipStream_t s);
 bool f32_strip_supported(const DwPwArgs& a);
 void launch_f32_strip(DwPwArgs a, hipStream_t s);
 // front block + the residual block behind it (32 -> 32, stride 1) in one kernel, the map between them in LDS (bn_f32_strip.hip)
