@@ -176,7 +176,34 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
         };
         if (HAS_DW && fixed_cq) load_consts(cq_fixed);
         int* lds32 = lds_raw;
-        for (int item = tid; item < 64 * kq; item += 256) {
+        const bool copy16 = !HAS_DW && (K & 15) == 0 && (kc & 15) == 0;
+        if (copy16) {
+            // plain 1x1 convolution: the tile is a copy.  16 bytes per item, four items of a thread requested before the first is stored (one
+            // dword per item, one memory round trip each: sixteen round trips per 256-channel slice and thread)
+            const int k16 = kc >> 4;
+            v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);
+            constexpr int NPF = 4;
+            for (int item0 = tid; item0 < 64 * k16; item0 += 256 * NPF) {
+                v4i v[NPF];
+#pragma unroll
+                for (int u = 0; u < NPF; ++u) {
+                    const int item = item0 + 256 * u;
+                    v[u] = (v4i){0, 0, 0, 0};
+                    if (item < 64 * k16) {
+                        const int p = item / k16, c16 = item - p * k16;
+                        if (pos[p].mask) v[u] = *reinterpret_cast<const v4i*>(a.x + (long)pos[p].in_base + k0 + 16 * c16);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NPF; ++u) {
+                    const int item = item0 + 256 * u;
+                    if (item >= 64 * k16) break;
+                    const int p = item / k16, c16 = item - p * k16;
+                    lds16[p * S16 + c16] = v[u];
+                }
+            }
+        }
+        for (int item = tid; !copy16 && item < 64 * kq; item += 256) {
             const int p = item / kq;
             const int cq = fixed_cq ? cq_fixed : item - p * kq;
             const PosInfo8 pi = pos[p];
