@@ -168,7 +168,47 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
                 }
             }
         }
-        for (int item = tid; HAS_DW && item < items; item += 256) {
+        if (HAS_DW && fixed_cq) {
+            // depthwise stage, a thread keeps its channel quad: the taps of TWO positions are requested before the first is multiplied (one
+            // position at a time every output paid a full memory round trip: eight per 128-channel slice)
+            auto taps = [&](const PosInfo& pi, float4 (&v9)[9]) {
+                const float* xin = a.x + (long)pi.in_base + k0 + 4 * cq_fixed;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int t = i * 3 + j;
+                        v9[t] = (pi.mask >> t) & 1 ? *reinterpret_cast<const float4*>(xin + (i * a.W + j) * K) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            };
+            auto finish = [&](const PosInfo& pi, const float4 (&v9)[9], int p) {
+                float4 accv = bias;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    accv.x = fmaf(v9[t].x, wgt[t].x, accv.x);
+                    accv.y = fmaf(v9[t].y, wgt[t].y, accv.y);
+                    accv.z = fmaf(v9[t].z, wgt[t].z, accv.z);
+                    accv.w = fmaf(v9[t].w, wgt[t].w, accv.w);
+                }
+                accv.x = act_f(accv.x, a.dw_act);
+                accv.y = act_f(accv.y, a.dw_act);
+                accv.z = act_f(accv.z, a.dw_act);
+                accv.w = act_f(accv.w, a.dw_act);
+                if (pi.mask == 0) accv = make_float4(0.f, 0.f, 0.f, 0.f);
+                lds4[p * S4 + cq_fixed] = (f32x4){accv.x, accv.y, accv.z, accv.w};
+            };
+            for (int item0 = tid; item0 < items; item0 += 512) {
+                const int p0 = item0 / kq, p1 = (item0 + 256) / kq;
+                const bool two = item0 + 256 < items;
+                const PosInfo pi0 = pos[p0], pi1 = pos[two ? p1 : p0];
+                float4 va[9], vb[9];
+                taps(pi0, va);
+                if (two) taps(pi1, vb);
+                finish(pi0, va, p0);
+                if (two) finish(pi1, vb, p1);
+            }
+        }
+        for (int item = tid; HAS_DW && !fixed_cq && item < items; item += 256) {
             const int p = item / kq;  // power-of-two kq in the fixed case: a shift
             const int cq = fixed_cq ? cq_fixed : item - p * kq;
             const PosInfo pi = pos[p];
