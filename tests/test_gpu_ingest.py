@@ -444,3 +444,29 @@ def test_ingest_ratios_whose_filter_needs_more_than_64_kb_of_lds(ctx, sr_in, sr_
             got = chunks[at : at + counts[i]]
             at += counts[i]
             assert counts[i] == want.shape[0] and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sr_in, sr_out, i, rep)
+
+
+@pytest.mark.gpu
+def test_chunk_peak_normalize_lengths_and_alignment(ctx):
+    """bn_chunk_peak_normalize (the raw frontend's host-side step, reference evaluation/metrics.py:62-69: x / (max|x| + 1e-6)) bit for bit
+    against numpy: chunk lengths that are / are not multiples of 4 (16-byte path + scalar tail), a buffer whose chunks start at odd
+    addresses (scalar path), in place."""
+    import ctypes
+
+    import torch
+
+    from birdnet_stm32 import _hip
+
+    lib = _hip.load_library()
+    rng = np.random.default_rng(17)
+    for T, off in ((48000, 0), (47999, 0), (7, 0), (66150, 0), (1028, 1), (4096, 2)):
+        host = rng.standard_normal((5, T)).astype(np.float32)
+        host[3] = 0.0  # a silent chunk: 0 / 1e-6
+        flat = torch.empty(5 * T + off, dtype=torch.float32, device="cuda")  # contiguous [5, T] chunks, `off` floats behind an aligned address
+        x = flat[off:].view(5, T)
+        x.copy_(torch.from_numpy(host))
+        ref = (x.cpu().numpy() / (np.abs(x.cpu().numpy()).max(axis=1, keepdims=True) + np.float32(1e-6))).astype(np.float32)
+        y = torch.empty_like(x) if not off else x
+        _hip.check(lib.bn_chunk_peak_normalize(ctx.handle, x.data_ptr(), 5, T, ctypes.c_float(1e-6), y.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy(), ref), (T, off)
