@@ -113,7 +113,34 @@ __global__ __launch_bounds__(256) void f32_melfin_kernel(const float* __restrict
         __syncthreads();
         peak = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) + 1e-6f;
     }
-    for (int i = threadIdx.x; i < M * W; i += 256) {
+    // (16-byte accesses, four in flight per thread, when rows are whole float4s — same arithmetic per element; element by element every
+    // iteration paid a memory round trip: 64 of them per thread and chunk)
+    const int n = M * W;
+    const int n4 = (W & 3) == 0 ? n >> 2 : 0;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < n4) v[u] = s4[i0 + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i >= n4) break;
+            const int m = (4 * i) / W;
+            const float off = mn * wsum[m];
+            float y[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = fmaxf((y[e] - off) / rng, 0.0f);
+                if (norm) t = t / peak;
+                y[e] = mag_scale(t, m, M, magp, mag);
+            }
+            d4[i] = make_float4(y[0], y[1], y[2], y[3]);
+        }
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) {
         const int m = i / W;
         float y = fmaxf((src[i] - mn * wsum[m]) / rng, 0.0f);
         if (norm) y = y / peak;
