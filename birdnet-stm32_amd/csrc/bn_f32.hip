@@ -371,15 +371,33 @@ __global__ __launch_bounds__(256) void f32_segate_kernel(const float* __restrict
         }
     }
     __syncthreads();
+    // (the two dense layers: sixteen weight loads in flight per thread, summed in the same order — one at a time the C = 256 .. 768 terms of a
+    // hidden unit were as many dependent cache round trips: 0.035 of the kernel's 0.04 ms behind a fused block)
     for (int r = tid; r < Cr; r += 256) {
         float s = 0.0f;
-        for (int c = 0; c < C; ++c) s = fmaf(mean[c], w1[c * Cr + r], s);
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w1[(c + u) * Cr + r];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = fmaf(mean[c + u], wv[u], s);
+        }
+        for (; c < C; ++c) s = fmaf(mean[c], w1[c * Cr + r], s);
         hid[r] = fmaxf(s, 0.0f);
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float s = 0.0f;
-        for (int r = 0; r < Cr; ++r) s = fmaf(hid[r], w2[r * C + c], s);
+        int r = 0;
+        for (; r + 16 <= Cr; r += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w2[(r + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = fmaf(hid[r + u], wv[u], s);
+        }
+        for (; r < Cr; ++r) s = fmaf(hid[r], w2[r * C + c], s);
         gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
     }
 }
