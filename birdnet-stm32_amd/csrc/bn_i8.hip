@@ -354,6 +354,21 @@ struct SeGate8Args {
     const int8_t* w2; const int32_t* b2; const int32_t* m2; const int32_t* s2; const int8_t* lut2;
 };
 
+// dot product of an int8 vector in LDS with a weight row in memory, `nd` dwords: sixteen weight dwords requested before the first is
+// used (integer sums: any order gives the same result); one dword per iteration was one cache round trip per four channels
+__device__ __forceinline__ int32_t row_dot(const int32_t* __restrict__ v, const int32_t* __restrict__ wr, int nd, int32_t acc) {
+    int k = 0;
+    for (; k + 16 <= nd; k += 16) {
+        int32_t w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = wr[k + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = dot4(v[k + u], w[u], acc);
+    }
+    for (; k < nd; ++k) acc = dot4(v[k], wr[k], acc);
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
     __shared__ int part[256][4];
     extern __shared__ int32_t se_vec[];  // pooled vector (Kp1 bytes) then hidden vector (Kp2 bytes), as dwords
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
     for (int n = tid; n < a.R; n += 256) {
         const int32_t* wr = reinterpret_cast<const int32_t*>(a.w1 + (size_t)n * a.Kp1);
         int32_t acc = a.b1[n];
-        for (int k = 0; k < a.Kp1 / 4; ++k) acc = dot4(se_vec[k], wr[k], acc);
+        acc = row_dot(se_vec, wr, a.Kp1 / 4, acc);
         int32_t qv = clampi(mbqm(acc, a.m1[n], a.s1[n]) + a.zo1, a.amin1, a.amax1);
         if (a.lut1) qv = a.lut1[qv + 128];
         hidden[n] = (int8_t)qv;
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
     for (int n = tid; n < C; n += 256) {
         const int32_t* wr = reinterpret_cast<const int32_t*>(a.w2 + (size_t)n * a.Kp2);
         int32_t acc = a.b2[n];
-        for (int k = 0; k < a.Kp2 / 4; ++k) acc = dot4(hv[k], wr[k], acc);
+        acc = row_dot(hv, wr, a.Kp2 / 4, acc);
         int32_t qv = clampi(mbqm(acc, a.m2[n], a.s2[n]) + a.zo2, a.amin2, a.amax2);
         if (a.lut2) qv = a.lut2[qv + 128];
         a.y[(size_t)b * C + n] = (int8_t)qv;
