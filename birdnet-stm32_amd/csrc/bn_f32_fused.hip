@@ -266,23 +266,50 @@ __global__ __launch_bounds__(256) void f32_dwpw_kernel(DwPwArgs a) {
         f32x4 bf[CT], bnext[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) bf[c] = wp[((size_t)j0 * n_ct + ct0 + c) * 64 + lane];
-        for (int j = 0; j < ksteps; ++j) {
-            if (j + 1 < ksteps) {
+        // plain 1x1 convolutions: the A fragments one k-step ahead as well (the LDS read of step j + 1 is issued before the matrix instructions of
+        // step j); the depthwise variants have no registers to spare for it (264 > 256: one workgroup per CU) and keep the read inside the step
+        if constexpr (!HAS_DW) {
+            f32x4 af[RG], afn[RG];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) bnext[c] = wp[((size_t)(j0 + j + 1) * n_ct + ct0 + c) * 64 + lane];
+            for (int g = 0; g < RG; ++g) af[g] = lds4[(row0 + 16 * g + r) * S4 + q];
+            for (int j = 0; j < ksteps; ++j) {
+                if (j + 1 < ksteps) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) bnext[c] = wp[((size_t)(j0 + j + 1) * n_ct + ct0 + c) * 64 + lane];
+#pragma unroll
+                    for (int g = 0; g < RG; ++g) afn[g] = lds4[(row0 + 16 * g + r) * S4 + 4 * (j + 1) + q];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < RG; ++g)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bf[c][e], acc[g][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) bf[c] = bnext[c];
+#pragma unroll
+                for (int g = 0; g < RG; ++g) af[g] = afn[g];
             }
-            f32x4 af[RG];
+        } else {
+            for (int j = 0; j < ksteps; ++j) {
+                if (j + 1 < ksteps) {
 #pragma unroll
-            for (int g = 0; g < RG; ++g) af[g] = lds4[(row0 + 16 * g + r) * S4 + 4 * j + q];
+                    for (int c = 0; c < CT; ++c) bnext[c] = wp[((size_t)(j0 + j + 1) * n_ct + ct0 + c) * 64 + lane];
+                }
+                f32x4 af[RG];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int g = 0; g < RG; ++g) af[g] = lds4[(row0 + 16 * g + r) * S4 + 4 * j + q];
 #pragma unroll
-                for (int g = 0; g < RG; ++g)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bf[c][e], acc[g][c], 0, 0, 0);
+                    for (int g = 0; g < RG; ++g)
 #pragma unroll
-            for (int c = 0; c < CT; ++c) bf[c] = bnext[c];
+                        for (int c = 0; c < CT; ++c)
+                            acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][e], bf[c][e], acc[g][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) bf[c] = bnext[c];
+            }
         }
     }
 
