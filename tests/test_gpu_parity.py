@@ -508,6 +508,35 @@ def test_f32_raw_frontend_config5_topology(torch_mod):
     runner.close()
 
 
+def test_f32_raw_frontend_padded_and_odd_widths(torch_mod):
+    """The raw filterbank kernel (one frame per thread over all filters) at geometries the configs[4] test does not reach: a chunk
+    shorter than stride (W - 1) + 16 samples (symmetric zero padding in front of the filterbank, reference models/frontend.py:147-155),
+    a frame count that is not a multiple of the workgroup, filter counts that are not multiples of 16 — frontend map and scores
+    against the float64 oracle."""
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle import float_graph
+
+    for sr, cd, W, M, mag in ((6000, 0.5, 128, 32, "none"), (8000, 1.0, 96, 24, "pwl"), (24000, 2.0, 320, 40, "pcen")):
+        spec = build_model("dscnn", num_mels=M, spec_width=W, sample_rate=sr, chunk_duration=cd, embeddings_size=64, num_classes=7, alpha=0.5,
+                           audio_frontend="raw", mag_scale=mag, use_se=False, use_inverted_residual=False, randomize_bn=True, seed=3)
+        T = int(sr * cd)
+        rng = np.random.default_rng(T)
+        x = rng.standard_normal((3, T)).astype(np.float32)
+        x = (x / (np.abs(x).max(axis=1, keepdims=True) + 1e-6)).astype(np.float32)[..., None]
+        ref_scores, _, acts = float_graph.forward(spec, x, np.float64, return_all=True, return_logits=True)
+        runner = HipRunner(lower_f32(spec, keep_all=True), max_batch=4)
+        got = runner.predict(x)
+        fe = next(oi for oi, op in enumerate(runner.plan.ops) if op.kind == 3)  # F32_RAWFE
+        a = runner.op_output(fe, 3)
+        r = acts[runner.plan.ops[fe].name].reshape(a.shape)
+        assert np.abs(a - r).max() / (np.abs(r).max() + 1e-12) < 5e-5, (sr, cd, W, M)
+        for b in range(3):
+            assert 1.0 - cosine(got[b], ref_scores[b]) < 1e-5, (sr, cd, W, M)
+        runner.close()
+
+
 @pytest.mark.parametrize(
     "kw",
     [
