@@ -7,7 +7,7 @@ and PCEN magnitude scaling (seeded random weights), quantised by this build's ow
     raw               configs[4]'s own frontend: learned 1 x 16 filterbank on the peak-normalised waveform (2 s @ 24 kHz, the geometry the
                       reference's raw frontend builds at); one step = peak normalisation + the whole INT8 plan
 
-    python tools/config5_i8_bench.py [batch] [steps] [hybrid|raw]
+    python tools/config5_i8_bench.py [batch] [steps] [hybrid|raw] [alpha]
 
 """
 import json, os, sys, time
@@ -25,9 +25,10 @@ from birdnet_stm32.models.runners import HipRunner
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 fe = sys.argv[3] if len(sys.argv) > 3 else "hybrid"
+alpha = float(sys.argv[4]) if len(sys.argv) > 4 else 1.5
 raw = fe == "raw"
 spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2 if raw else 3, embeddings_size=256, num_classes=100,
-                   audio_frontend=fe, mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+                   audio_frontend=fe, mag_scale="pcen", alpha=alpha, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
 rng = np.random.default_rng(0)
 if raw:
     cal = [rng.standard_normal((1, 48000, 1)).astype(np.float32) for _ in range(8)]
@@ -62,7 +63,7 @@ by_kind = {}
 for q in rows:
     by_kind[q["kind"]] = by_kind.get(q["kind"], 0.0) + q["ms"]
 top = sorted(rows, key=lambda q: -q["ms"])[:6]
-print(json.dumps({"workload": "configs[4] in INT8: alpha=1.5 IR/SE DS-CNN + PCEN, " + ("raw learned-filterbank frontend, 2 s @ 24 kHz" if raw else
+print(json.dumps({"workload": f"alpha={alpha} IR/SE DS-CNN + PCEN in INT8" + (" (configs[4])" if alpha == 1.5 else "") + ", " + ("raw learned-filterbank frontend, 2 s @ 24 kHz" if raw else
                               "hybrid frontend with per-sample max normalisation, 3 s @ 24 kHz") + ", seeded weights, own PTQ",
                   "batch": B, "ms_per_step": round(dt * 1e3, 3), "chunks_per_s": round(B / dt, 1), "tflite_ops": len(model.ops), "plan_ops": len(r.plan.ops),
                   "ms_by_kernel_kind": {k: round(v, 3) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
