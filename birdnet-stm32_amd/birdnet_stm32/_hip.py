@@ -28,12 +28,12 @@ EXPORTS = (
     "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
     "bn_kernel_names", "bn_profile_enable", "bn_profile_collect", "bn_ingest_resample", "bn_ingest_chunks",
     "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize", "bn_set_option", "bn_get_option",
-    "bn_blob_check", "bn_debug_requant",
+    "bn_blob_check", "bn_debug_requant", "bn_stft_mag_exact", "bn_debug_input_bytes", "bn_debug_guard_stats",
 )  # fmt: skip
 
 # launcher switches of bn_set_option (include/birdnet_hip.h); the production defaults are what a fresh process has
 OPTION_NAMES = ("f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "i8_pwdw", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th", "i8_tail",
-                "i8_mel_generic", "stft_rowmajor", "ingest_blk", "ingest_generic")
+                "i8_mel_generic", "stft_rowmajor", "stft_exact", "ingest_blk", "ingest_generic")
 
 
 class BnModelInfo(ctypes.Structure):
@@ -79,6 +79,9 @@ def load_library(path: str | None = None):
     lib.bn_model_free.restype = None
     lib.bn_model_get_info.argtypes = [c_void_p, POINTER(BnModelInfo)]
     lib.bn_stft_mag.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.bn_stft_mag_exact.argtypes = lib.bn_stft_mag.argtypes
+    lib.bn_debug_input_bytes.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+    lib.bn_debug_guard_stats.argtypes = [c_void_p, c_int, POINTER(c_int64)]
     lib.bn_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     lib.bn_infer_audio.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.bn_debug_op_output.argtypes = [c_void_p, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]

@@ -45,8 +45,12 @@ def normalize(S: np.ndarray) -> np.ndarray:
     return (S - lo) / (S.max() - lo + 1e-10)
 
 
-def spectrograms_from_chunks(chunks: np.ndarray, n_fft: int = 512, spec_width: int = 256, normalize_out: bool = True) -> np.ndarray:
-    """``[B, T]`` float32 chunks -> ``[B, n_fft//2+1, spec_width]`` float32, one GPU launch group."""
+def spectrograms_from_chunks(chunks: np.ndarray, n_fft: int = 512, spec_width: int = 256, normalize_out: bool = True,
+                             exact: bool = True) -> np.ndarray:
+    """``[B, T]`` float32 chunks -> ``[B, n_fft//2+1, spec_width]`` float32, one GPU launch group.
+
+    ``exact`` (default): ``bn_stft_mag_exact`` — librosa's float64 arithmetic value for value, so that an INT8 runner behind this
+    host-side call quantises the bytes the reference quantises; ``exact=False`` is the float32 FFT (2e-6 of the peak, ten times faster)."""
     import torch
 
     from birdnet_stm32.models.runners import stft_device
@@ -56,7 +60,7 @@ def spectrograms_from_chunks(chunks: np.ndarray, n_fft: int = 512, spec_width: i
         raise ValueError("chunks must be [B, T]")
     ctx = _context()  # raises when no MI355X is present: there is no CPU fallback
     d = torch.from_numpy(x).cuda()
-    out = stft_device(ctx, d, n_fft=n_fft, spec_width=spec_width, normalize=normalize_out)
+    out = stft_device(ctx, d, n_fft=n_fft, spec_width=spec_width, normalize=normalize_out, exact=exact)
     return out.cpu().numpy()
 
 

@@ -168,9 +168,10 @@ class HipRunner:
                 )  # fmt: skip
         return (scores, logits) if return_logits else scores
 
-    def stft_device(self, audio, n_fft: int = 512, hop: int | None = None, spec_width: int | None = None, normalize: bool = True):
+    def stft_device(self, audio, n_fft: int = 512, hop: int | None = None, spec_width: int | None = None, normalize: bool = True,
+                    exact: bool = False):
         """Batched ``get_spectrogram_from_audio(mel_bins=-1)`` on the GPU: ``[B, T]`` -> ``[B, n_fft//2+1, W]``."""
-        return stft_device(self.ctx, audio, n_fft, hop, spec_width or self.spec_width, normalize)
+        return stft_device(self.ctx, audio, n_fft, hop, spec_width or self.spec_width, normalize, exact=exact)
 
     def op_output(self, op_index: int, B: int) -> np.ndarray:
         """Test hook: activation written by plan operator ``op_index`` in the last forward call."""
@@ -186,6 +187,20 @@ class HipRunner:
         n = int(np.prod(op.out_shape))
         dt = np.dtype(op.out_dtype)
         return raw[: B * n * dt.itemsize].copy().view(dt).reshape(B, *op.out_shape)
+
+    def input_bytes(self, B: int) -> np.ndarray:
+        """Test hook: the int8 bytes QUANTIZE made of the spectrograms of the last ``infer_audio_device`` call, ``[B, 257, W]``."""
+        torch = self._torch
+        out = torch.empty((B, self.fft_bins, self.spec_width), dtype=torch.int8, device=self.device)
+        _hip.check(self.lib.bn_debug_input_bytes(self.model.handle, B, out.data_ptr(), self._stream()))
+        torch.cuda.synchronize(self.device)
+        return out.cpu().numpy()
+
+    def guard_stats(self, B: int) -> dict:
+        """Test hook: counters of the exactness pass of the last ``infer_audio_device`` call (INT8 plans)."""
+        out = (ctypes.c_int64 * 5)()
+        _hip.check(self.lib.bn_debug_guard_stats(self.model.handle, B, out))
+        return {"listed": int(out[0]), "listed_max": int(out[1]), "dirty_blocks": int(out[2]), "whole_minmax": int(out[3]), "whole_fix": int(out[4])}
 
     # -- per-operator timing (HIP events on the launch stream) ------------------------------------
     def profile(self, enable: bool) -> None:
@@ -216,8 +231,10 @@ class HipRunner:
 
 
 def stft_device(ctx: _hip.Context, audio, n_fft: int = 512, hop: int | None = None, spec_width: int = 256, normalize: bool = True,
-                return_minmax: bool = False):
-    """``bn_stft_mag`` on CUDA tensors: float32 ``[B, T]`` -> float32 ``[B, n_fft//2+1, spec_width]``."""
+                return_minmax: bool = False, exact: bool = False):
+    """``bn_stft_mag`` on CUDA tensors: float32 ``[B, T]`` -> float32 ``[B, n_fft//2+1, spec_width]``.
+
+    ``exact=True`` calls ``bn_stft_mag_exact``: the reference's float64 arithmetic value for value (about ten times slower)."""
     import torch
 
     if not (audio.is_cuda and audio.dtype == torch.float32 and audio.is_contiguous() and audio.dim() == 2):
@@ -228,8 +245,8 @@ def stft_device(ctx: _hip.Context, audio, n_fft: int = 512, hop: int | None = No
     minmax = torch.empty((B, 2), dtype=torch.float32, device=audio.device)
     with torch.cuda.device(audio.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(audio.device).cuda_stream)
-        _hip.check(ctx.lib.bn_stft_mag(ctx.handle, audio.data_ptr(), B, T, n_fft, hop, spec_width, int(normalize), spec.data_ptr(),
-                                       minmax.data_ptr(), stream))
+        fn = ctx.lib.bn_stft_mag_exact if exact else ctx.lib.bn_stft_mag
+        _hip.check(fn(ctx.handle, audio.data_ptr(), B, T, n_fft, hop, spec_width, int(normalize), spec.data_ptr(), minmax.data_ptr(), stream))
     return (spec, minmax) if return_minmax else spec
 
 

@@ -50,6 +50,7 @@ const OptName kOptions[] = {
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
+    {"stft_exact", &bn::Options::stft_exact},
     {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
@@ -77,6 +78,7 @@ struct bn_ctx {
     float* d_window = nullptr;
     float4* d_tw256 = nullptr;
     float4* d_tw512 = nullptr;
+    double* d_f64tab = nullptr;      // hann64[512], cs64[512] (bn_stft_exact.hip)
     bn::StftTables tables{};
     float* d_block_peaks = nullptr;  // bn_ingest_resample: per-workgroup maxima, grown on demand
     size_t block_peaks_elems = 0;
@@ -101,6 +103,13 @@ struct bn_model {
     std::vector<char*> d_slots;          // max_batch * bytes_per_chunk each
     float* d_spec = nullptr;             // [max_batch][F][W] for bn_infer_audio
     float* d_minmax = nullptr;           // [max_batch][2]
+    char* d_guard = nullptr;             // buffers of the exactness pass (INT8 plans whose first operator quantises the spectrogram)
+    bn::StftGuard guard{};
+    bool last_tiled = false;             // layout of d_spec after the last bn_infer_audio call (bn_debug_input_bytes)
+    int last_B = 0;
+    bool guard_now = false;              // set by bn_infer_audio: the first operator lists doubtful bytes, the float64 pass follows it
+    const float* guard_audio = nullptr;
+    int guard_T = 0, guard_hop = 0;
     float* d_smax = nullptr;             // [max_batch] per-sample maxima of the frontend
     float* d_gap_part = nullptr;         // [max_batch][gap_part_elems] channel sums per row block from f32_pwdw_kernel for the squeeze-excite gate behind it
     size_t gap_part_elems = 0;
@@ -156,6 +165,18 @@ struct ProfScope {
         if (stop) (void)hipEventRecord(stop, s);
     }
 };
+
+// The exactness pass's buffers for the chunks from b0 on (the work list is shared: one launch group at a time uses it).
+bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
+    bn::StftGuard g = m->guard;
+    const size_t W = m->hdr.spec_width;
+    g.eps += b0 * W;
+    g.rec += b0 * ((W + 15) / 16) * bn::kGuardRec;
+    g.list += b0 * (size_t)g.cap;
+    g.count += b0;
+    g.dirty += b0;
+    return g;
+}
 
 // Executes the plan for a batch slice.
 // `op_begin..op_end` restricts the run to a range of operators, `slot_b0` is the chunk index the slice starts at inside the
@@ -453,6 +474,18 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     a.qtiled = (m->spec_tiled_now && o.in0 == BN_SLOT_INPUT) ? 1 : 0;
                     a.x = nullptr;
                     if (!bn::i8_mel_mfma_supported(a)) return fail(BN_ERR_FORMAT, "operator %zu: fused QUANTIZE needs the mel-mixer kernel's geometry", oi);
+                    if (m->guard_now && a.qtiled && mm) {
+                        // audio path: list the bytes the float32 STFT leaves in doubt, recompute those elements in float64, run the
+                        // blocks whose bytes changed once more (bn_stft_exact.hip)
+                        a.qguard = guard_slice(m, slot_b0);
+                        a.qmode = 1;
+                        bn::launch_i8_dwpw(a, s);
+                        bn::launch_stft_fix(m->ctx->tables, m->guard_audio, B, m->guard_T, m->guard_hop, a.W, (float*)in0, true, a.qguard, mm, a.qscale,
+                                            a.qzp, s);
+                        a.qmode = 2;
+                        bn::launch_i8_dwpw(a, s);
+                        break;
+                    }
                 }
                 // wide early layers: wave-autonomous strip kernel when the packer prepared its constant block
                 if (p[35] && o.t[9] >= 0 && bn::g_opt.i8_strip && a.has_dw && !a.transposed && a.sh == a.sw &&
@@ -635,7 +668,20 @@ int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
     HIP_TRY(hipMemcpy(c->d_window, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_tw256, t256.data(), t256.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_tw512, t512.data(), t512.size() * sizeof(float4), hipMemcpyHostToDevice));
-    c->tables = bn::StftTables{c->d_window, c->d_tw256, c->d_tw512};
+    // float64 tables of the exactness pass: cos(2 pi j / 512) with the symmetries exact (cs[128] = 0, cs[j] = -cs[256 - j], ...),
+    // the reference's periodic Hann window 0.5 - 0.5 cos(2 pi n / 512) from it
+    std::vector<double> f64tab(1024);
+    for (int j = 0; j < 512; ++j) {
+        const int a2 = j <= 256 ? j : 512 - j;                 // cos is even about pi
+        const int a3 = a2 <= 128 ? a2 : 256 - a2;              // and odd about pi / 2
+        const double v = a3 <= 64 ? cos(two_pi * a3 / 512.0) : sin(two_pi * (128 - a3) / 512.0);
+        f64tab[512 + j] = a2 <= 128 ? v : -v;
+        if (a3 == 128) f64tab[512 + j] = 0.0;
+    }
+    for (int n = 0; n < 512; ++n) f64tab[n] = 0.5 - 0.5 * f64tab[512 + n];
+    HIP_TRY(hipMalloc(&c->d_f64tab, f64tab.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(c->d_f64tab, f64tab.data(), f64tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->tables = bn::StftTables{c->d_window, c->d_tw256, c->d_tw512, c->d_f64tab, c->d_f64tab + 512};
     // bn_ingest_resample's per-workgroup peak scratch (one float per >= 1024 resampled samples): sized here for windows that
     // yield max_batch 3 s chunks at 24 kHz (72 blocks per chunk) with headroom, so that the ingest call itself does not allocate
     // (no hidden device sync on that path); a call that needs more still grows it, once.
@@ -652,6 +698,7 @@ void bn_ctx_destroy(bn_ctx* c) {
     (void)hipFree(c->d_window);
     (void)hipFree(c->d_tw256);
     (void)hipFree(c->d_tw512);
+    (void)hipFree(c->d_f64tab);
     (void)hipFree(c->d_block_peaks);
     delete c;
 }
@@ -795,6 +842,24 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu spectrogram workspace bytes failed", bytes));
         m->workspace_bytes += bytes;
     }
+    if (m->spec_tiled_ok && h.dtype == BN_DTYPE_I8) {
+        // exactness pass of the audio path: per chunk W bounds, W / 16 tile records, a list of flagged elements, counters
+        const size_t W = h.spec_width, n_tiles = (W + 15) / 16, t64 = (W + 63) / 64;
+        const int cap = 1024;
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            const size_t o = off;
+            off += (bytes + 255) & ~(size_t)255;
+            return o;
+        };
+        const size_t o_eps = take(mb * W * 4), o_rec = take(mb * n_tiles * bn::kGuardRec * 4), o_list = take(mb * cap * 4), o_cnt = take(mb * 4),
+                     o_dirty = take(mb * 4), o_work = take(mb * t64 * 4), o_nw = take(4), o_hard = take(2 * mb * 4), o_nh = take(8);
+        if (hipMalloc(&m->d_guard, off) != hipSuccess) return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu exactness-pass bytes failed", off));
+        m->workspace_bytes += off;
+        char* g = m->d_guard;
+        m->guard = bn::StftGuard{(float*)(g + o_eps), (int*)(g + o_rec), (int*)(g + o_list), (int*)(g + o_cnt), cap, (int*)(g + o_dirty),
+                                 (int*)(g + o_work), (int*)(g + o_nw), (int*)(g + o_hard), (int*)(g + o_nh), (int)mb};
+    }
     if (hipMalloc(&m->d_minmax, mb * 2 * sizeof(float)) != hipSuccess ||
         hipMalloc(&m->d_smax, mb * sizeof(float)) != hipSuccess)
         return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of reduction scratch failed"));
@@ -831,6 +896,7 @@ void bn_model_free(bn_model* m) {
     for (char* p : m->d_slots) (void)hipFree(p);
     (void)hipFree(m->d_spec);
     (void)hipFree(m->d_minmax);
+    (void)hipFree(m->d_guard);
     (void)hipFree(m->d_smax);
     (void)hipFree(m->d_gap_part);
     for (auto& r : m->ev_used) {
@@ -857,16 +923,21 @@ int bn_model_get_info(const bn_model* m, bn_model_info* out) {
 }
 
 static int stft_mag_impl(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize, float* d_spec,
-                         float* d_minmax, void* stream, bool tile_major);
+                         float* d_minmax, void* stream, bool tile_major, bool exact = false);
 
 int bn_stft_mag(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize,
                 float* d_spec, float* d_minmax, void* stream) {
     return stft_mag_impl(ctx, d_audio, B, T, n_fft, hop, W, normalize, d_spec, d_minmax, stream, false);
 }
 
+int bn_stft_mag_exact(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize,
+                      float* d_spec, float* d_minmax, void* stream) {
+    return stft_mag_impl(ctx, d_audio, B, T, n_fft, hop, W, normalize, d_spec, d_minmax, stream, false, true);
+}
+
 // tile_major: spectrogram as [W/16][257][16] per chunk (private to bn_infer_audio; the public entry point keeps [257][W])
 static int stft_mag_impl(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W, int normalize, float* d_spec,
-                         float* d_minmax, void* stream, bool tile_major) {
+                         float* d_minmax, void* stream, bool tile_major, bool exact) {
     if (int rc = check_device(ctx)) return rc;
     if (!d_audio || !d_spec || !d_minmax) return fail(BN_ERR_ARG, "null device pointer");
     if (n_fft != kFft) return fail(BN_ERR_UNSUPPORTED, "n_fft=%d: only 512 is implemented", n_fft);
@@ -879,8 +950,12 @@ static int stft_mag_impl(bn_ctx* ctx, const float* d_audio, int B, int T, int n_
     for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
         const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
         bn::launch_minmax_init(d_minmax + 2 * (size_t)b0, nb, s);
-        bn::launch_stft512(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, d_spec + b0 * per_chunk,
-                           d_minmax + 2 * (size_t)b0, s, tile_major);
+        if (exact)  // every bin as a float64 DFT: the reference's values (bn_stft_exact.hip)
+            bn::launch_stft512_f64(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, d_spec + b0 * per_chunk, d_minmax + 2 * (size_t)b0, s,
+                                   tile_major);
+        else
+            bn::launch_stft512(ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, d_spec + b0 * per_chunk,
+                               d_minmax + 2 * (size_t)b0, s, tile_major);
         if (normalize)
             bn::launch_spec_normalize(d_spec + b0 * per_chunk, d_minmax + 2 * (size_t)b0, nb, (int)per_chunk, s);
     }
@@ -977,24 +1052,86 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     const bool tiled = m->spec_tiled_ok && !bn::g_opt.stft_rowmajor;  // option stft_rowmajor: keep the reference layout (A/B)
     hipStream_t s = (hipStream_t)stream;
     const size_t in_stride = m->hdr.input_elems, C = m->hdr.num_classes;
+    // INT8 plans: the quantised input bytes must be the reference's (float64 STFT).  Production form: float32 STFT with error bounds,
+    // exact min / max, doubtful bytes listed by the first operator and recomputed in float64 behind it (bn_stft_exact.hip);
+    // plans / options outside that form (debug plans, row-major layout, generic mel kernel) take the float64 STFT for every bin.
+    const bool i8 = m->hdr.dtype == BN_DTYPE_I8;
+    const int exact_opt = i8 ? bn::g_opt.stft_exact : 0;
+    const bool guarded = exact_opt == 2 && tiled && m->d_guard && !bn::g_opt.i8_mel_generic && W % 16 == 0 && W <= 1024;
     // (Sub-batching the STFT -> first operator pair for the Infinity Cache and a two-stream skewed schedule were measured and removed:
     // slower / no gain)
     m->spec_tiled_now = tiled;
     int rc = BN_OK;
     {
         ProfScope prof(m, (int)m->ops.size(), s);
-        rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, tiled);
+        if (guarded) {
+            if (T <= 0 || hop <= 0 || 1 + T / hop < W) rc = fail(BN_ERR_ARG, "T=%d hop=%d gives %d frames, fewer than spec_width=%d", T, hop, hop > 0 ? 1 + T / hop : 0, W);
+            for (int b0 = 0; rc == BN_OK && b0 < B; b0 += kMaxGridBatch) {
+                const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+                bn::StftGuard g = guard_slice(m, (size_t)b0);
+                bn::launch_stft512(m->ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, m->d_spec + b0 * in_stride, m->d_minmax + 2 * (size_t)b0, s,
+                                   true, &g);
+                bn::launch_stft_minmax_exact(m->ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, m->d_spec + b0 * in_stride, true, g,
+                                             m->d_minmax + 2 * (size_t)b0, s);
+            }
+        } else {
+            rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, tiled, exact_opt != 0);
+        }
     }
     if (rc == BN_OK) {
         for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
             const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+            m->guard_now = guarded;
+            m->guard_audio = d_audio + (size_t)b0 * T;
+            m->guard_T = T;
+            m->guard_hop = hop;
             rc = run_plan(m, m->d_spec + b0 * in_stride, m->d_minmax + 2 * (size_t)b0, nb, d_scores + b0 * C, d_logits ? d_logits + b0 * C : nullptr, s,
                           nullptr, 0, 0, 0, (size_t)-1, (size_t)b0);
             if (rc != BN_OK) break;
         }
     }
+    m->guard_now = false;
     m->spec_tiled_now = false;
+    m->last_tiled = tiled;
+    m->last_B = rc == BN_OK ? B : 0;
     return rc;
+}
+
+int bn_debug_guard_stats(bn_model* m, int B, int64_t* out) {
+    if (!m || !out) return fail(BN_ERR_ARG, "null argument");
+    if (int rc = check_device(m->ctx)) return rc;
+    if (!m->d_guard) return fail(BN_ERR_UNSUPPORTED, "the plan has no exactness pass");
+    if (B <= 0 || B > m->last_B || B > kMaxGridBatch) return fail(BN_ERR_ARG, "B=%d: the last bn_infer_audio call left %d spectrograms", B, m->last_B);
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<int> cnt((size_t)B);
+    int nw = 0, nh[2] = {0, 0};
+    HIP_TRY(hipMemcpy(cnt.data(), m->guard.count, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&nw, m->guard.n_work, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nh, m->guard.n_hard, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    int64_t total = 0, mx = 0;
+    for (int c : cnt) {
+        total += c;
+        if (c > mx) mx = c;
+    }
+    out[0] = total;
+    out[1] = mx;
+    out[2] = nw;
+    out[3] = nh[0];
+    out[4] = nh[1];
+    return BN_OK;
+}
+
+int bn_debug_input_bytes(bn_model* m, int B, int8_t* d_out, void* stream) {
+    if (!m || !d_out) return fail(BN_ERR_ARG, "null argument");
+    if (int rc = check_device(m->ctx)) return rc;
+    const OpRec* first = nullptr;
+    for (const OpRec& o : m->ops)
+        if (o.in0 == BN_SLOT_INPUT && o.kind == BN_OP_I8_DWPW && o.p[36] && o.p[30]) first = &o;
+    if (!first || !m->d_spec) return fail(BN_ERR_UNSUPPORTED, "the plan's first operator is not the mel mixer with QUANTIZE fused into its load");
+    if (B <= 0 || B > m->last_B || B > kMaxGridBatch) return fail(BN_ERR_ARG, "B=%d: the last bn_infer_audio call left %d spectrograms", B, m->last_B);
+    bn::launch_spec_bytes(m->d_spec, m->d_minmax, B, (int)m->hdr.spec_width, m->last_tiled, first->f[0], first->p[37], d_out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
 }
 
 int bn_ingest_resample(bn_ctx* ctx, const void* d_pcm, int sample_format, int channels, const int64_t* d_in_off,

@@ -22,6 +22,7 @@
 
 #include "bn_kernels.h"
 #include "bn_requant.h"
+#include "bn_quant_in.h"
 
 namespace bn {
 namespace {
@@ -480,40 +481,35 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
 // generic kernel spends its time on position tables and item loops, here the 64 x Kp activation tile of a workgroup is ONE
 // contiguous 20 KB run of the [W][Kp] input (plain 16-byte copies into LDS), each wave owns 16 mel bins, and a lane requantises
 // four consecutive frames of one bin (one dword store into the transposed output).
-// Exact float32 division by a constant whose correctly rounded reciprocal y = RN(1 / b) is known: q0 = RN(a y),
-// r = fma(-b, q0, a) (exact residual), q = fma(r, y, q0) is RN(a / b) (Markstein's correction step; no underflow or overflow
-// occurs for the operands here: a / b lies in [0, 256]).  Three instructions instead of the ~10 of the IEEE division sequence;
-// tests compare it with true division on 10^8 operand pairs and the fused kernel with the separate QUANTIZE bit for bit.
-__device__ __forceinline__ float div_by_const(float a, float b, float y) {
-    const float q0 = a * y;
-    return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
-}
-
-// roundf(v) + zp clamped to int8.  With zp = -128 (every quantised spectrogram input: the value range starts at 0) negative v
-// lands on -128 whichever way a tie goes, and for v >= 0 round-half-away-from-zero is floor(v + 0.5) — one v_cvt_rpi_i32_f32
-// instead of the seven instructions of roundf + cvt.  Other zero points take the general form.
-__device__ __forceinline__ int quantise_i8_zp128(float v) {
-    int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
-    return min(max(r, 0), 255) - 128;  // v_med3_i32
-}
-__device__ __forceinline__ int quantise_i8(float v, int zp) {
-    return zp == -128 ? quantise_i8_zp128(v) : clampi((int32_t)roundf(v) + zp, -128, 127);
-}
-
 // QIN: QUANTIZE fused into the load — the input is the float32 spectrogram [B][qF][W] (frequency-major like the reference's
 // array); a 64 x 64 block is read as float4 along the frames, normalised with the chunk's min / max (audio path), quantised
 // with the same roundf(v / scale) + zp as i8_quant_kernel and written into the activation tile transposed.
-template <bool QIN>
-__global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
+// MODE (tile-major audio path only, bn_stft_exact.hip): 1 = also list every element whose byte could differ from the reference's
+// within the STFT's error bound (the quantiser is monotone, so the test is the distance of its argument to the next rounding
+// boundary: 4 instructions per element); 2 = run only the (chunk, block) pairs of the work list (the blocks whose bytes the
+// float64 pass changed), nothing is listed.
+constexpr int kMelFlagCap = 1022;  // flagged elements a workgroup keeps in LDS before it hands them to the chunk's list
+template <bool QIN, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 4, 8))) void i8_mel_mfma_kernel(DwPw8Args a) {
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+    __shared__ int flag_n, flag_base, flags[MODE == 1 ? kMelFlagCap : 1];
     v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);
     const int Kp = a.Cin, W = a.W, M = a.Cout;
     const int S16 = (Kp >> 4) + 1;  // row stride in 16-byte units (one unit of padding: conflict-free 16-byte reads along rows)
     const int tid = threadIdx.x;
     const int tiles_x = W >> 6;
-    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int n_items = MODE == 2 ? *a.qguard.n_work : 1;
+    for (int item = MODE == 2 ? blockIdx.x : 0; item < n_items; item += MODE == 2 ? gridDim.x : 1) {
+    const int bid = MODE == 2 ? a.qguard.work[item] : xcd_tile(blockIdx.x, gridDim.x);
     const int chunk = bid / tiles_x, t0 = (bid - chunk * tiles_x) << 6;
+    if (MODE == 1 && tid == 0) {
+        flag_n = 0;
+        if (blockIdx.x == 0) {  // counters of the passes behind this one
+            *a.qguard.n_work = 0;
+            a.qguard.n_hard[1] = 0;
+        }
+    }
+    if (MODE != 0) __syncthreads();  // (MODE 2: the previous item's tile has been consumed)
     if constexpr (!QIN) {
         const v4i* src = reinterpret_cast<const v4i*>(a.x + ((size_t)chunk * W + t0) * Kp);
         const int per_row = Kp >> 4;
@@ -525,14 +521,9 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
         int8_t* tile = reinterpret_cast<int8_t*>(lds_raw);
         const int stride = S16 * 16;
         const float* S = a.qx + (size_t)chunk * a.qF * W + t0;
-        float mn = 0.0f, rng = 1.0f, y_rng = 1.0f;
-        const bool renorm = a.qminmax != nullptr;
-        if (renorm) {
-            mn = a.qminmax[2 * chunk];
-            rng = (float)((double)(a.qminmax[2 * chunk + 1] - mn) + 1e-10);
-            y_rng = (float)(1.0 / (double)rng);
-        }
-        const float scale = a.qscale, y_scale = (float)(1.0 / (double)a.qscale);
+        QuantIn qi;
+        qi.set(a.qminmax ? a.qminmax + 2 * chunk : nullptr, a.qscale, a.qzp);
+        const bool renorm = qi.renorm;
         if (a.qtiled) {
             // tile-major spectrogram [W/16][qF][16]: wave wv reads ITS 16-frame block as 1 KB runs (16 frequency rows x 64 bytes);
             // lane = (row fr within the group of 16, frame quad ft).  Measured alternatives, all slower or equal:
@@ -541,6 +532,18 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
             const int lane = tid & 63, wv = tid >> 6;
             const int ft = lane & 3, fr = lane >> 2;
             const float* Sb = a.qx + (size_t)chunk * a.qF * W + (size_t)(t0 / 16 + wv) * a.qF * 16 + 4 * ft;
+            // half-width of the band around a rounding boundary inside which the reference's byte may differ (bn_quant_in.h)
+            float dband[4] = {0.f, 0.f, 0.f, 0.f}, crel = 0.f;
+            if (MODE == 1) {
+                crel = kGuardRel * (qi.y_rng * qi.y_scale * 1.000001f);
+                const float4 e = *reinterpret_cast<const float4*>(a.qguard.eps + (size_t)chunk * W + t0 + 16 * wv + 4 * ft);
+                const float dsc = qi.y_rng * qi.y_scale * 1.000001f;
+                // (a bound of 0 = the frame is exact: zeros, or a chunk recomputed as a whole in float64 — nothing to list)
+                dband[0] = e.x > 0.0f ? 0.5f - (e.x * dsc + kQuantSlack) : 0.75f;
+                dband[1] = e.y > 0.0f ? 0.5f - (e.y * dsc + kQuantSlack) : 0.75f;
+                dband[2] = e.z > 0.0f ? 0.5f - (e.z * dsc + kQuantSlack) : 0.75f;
+                dband[3] = e.w > 0.0f ? 0.5f - (e.w * dsc + kQuantSlack) : 0.75f;
+            }
             // renormalisation and the zero-point fast path are wave-uniform: picked once, outside the per-element code
             auto run = [&](auto RN, auto FAST) {
                 constexpr int kBatch = 20;  // Kp <= 320 (257 bins padded to 320): every load of the wave's block is issued before the first use
@@ -560,10 +563,18 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float x = e[k];
-                            if (RN.value) x = div_by_const(x - mn, rng, y_rng);
-                            x = div_by_const(x, scale, y_scale);
-                            const int q = FAST.value ? quantise_i8_zp128(x) : clampi((int32_t)roundf(x) + a.qzp, -128, 127);
+                            if (RN.value) x = div_by_const(x - qi.mn, qi.rng, qi.y_rng);
+                            x = div_by_const(x, qi.scale, qi.y_scale);
+                            const int q = FAST.value ? quantise_i8_zp128(x) : quantise_i8_any(x, a.qzp);
                             tile[(16 * wv + 4 * ft + k) * stride + f] = (int8_t)(f < a.qF ? q : a.qfill);
+                            if (MODE == 1) {
+                                // in doubt: distance of the quantiser's argument to the next rounding boundary <= what eps(S') = eps_f + kGuardRel S' moves it
+                                const float tt = x + 0.5f;
+                                if (__builtin_fmaf(e[k], crel, fabsf(__builtin_amdgcn_fractf(tt) - 0.5f)) >= dband[k] && f < a.qF) {
+                                    const int sl = atomicAdd(&flag_n, 1);
+                                    if (sl < kMelFlagCap) flags[sl] = ((t0 + 16 * wv + 4 * ft + k) << 16) | f;
+                                }
+                            }
                         }
                     }
                 }
@@ -586,11 +597,7 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
                     const float4 v = *reinterpret_cast<const float4*>(S + (size_t)f * W + 4 * c4);
                     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float x = e[k];
-                        if (renorm) x = div_by_const(x - mn, rng, y_rng);
-                        q[k] = quantise_i8(div_by_const(x, scale, y_scale), a.qzp);
-                    }
+                    for (int k = 0; k < 4; ++k) q[k] = qi.q(e[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) tile[(4 * c4 + k) * stride + f] = (int8_t)q[k];
@@ -599,6 +606,14 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
         }
     }
     __syncthreads();
+    if (MODE == 1) {
+        // hand the flagged elements to the chunk's list; a workgroup that flagged more than it could keep makes the chunk's count
+        // exceed the list's capacity, which sends stft_fix_kernel over the whole chunk
+        if (tid == 0) {
+            const int n = flag_n;
+            flag_base = n ? atomicAdd(a.qguard.count + chunk, n <= kMelFlagCap ? n : a.qguard.cap + 1) : 0;
+        }
+    }
     const int lane = tid & 63, wv = tid >> 6;  // wave wv: mel bins 16 wv .. 16 wv + 15
     const int r = lane & 15, q = lane >> 4;
     const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);  // [Kp/64][M/16][64 lanes] x 16 bytes
@@ -630,6 +645,14 @@ __global__ __launch_bounds__(256) void i8_mel_mfma_kernel(DwPw8Args a) {
             packed |= (qv & 0xff) << (8 * e);
         }
         *reinterpret_cast<int*>(yrow + 16 * g) = packed;
+    }
+    if (MODE == 1) {
+        __syncthreads();  // flag_base
+        const int n = min(flag_n, kMelFlagCap), base = flag_base;
+        int* list = a.qguard.list + (size_t)chunk * a.qguard.cap;
+        for (int i = tid; i < n; i += 256)
+            if (base + i < a.qguard.cap) list[base + i] = flags[i];
+    }
     }
 }
 
@@ -860,10 +883,16 @@ bool i8_pw_wave_takes(const DwPw8Args& a) { return i8_pw_wave_supported(a); }
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
     const bool mel_kernel = !g_opt.i8_mel_generic;
     if (a.qx || (mel_kernel && i8_mel_mfma_supported(a))) {  // (the packer only fuses QUANTIZE for shapes this kernel takes)
-        if (a.qx)
-            hipLaunchKernelGGL(i8_mel_mfma_kernel<true>, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);
+        const unsigned nb = (unsigned)(a.B * (a.W / 64));
+        const size_t lds = (size_t)64 * (a.Cin + 16);
+        if (a.qx && a.qmode == 1 && a.qtiled)
+            hipLaunchKernelGGL((i8_mel_mfma_kernel<true, 1>), dim3(nb), dim3(256), lds, s, a);
+        else if (a.qx && a.qmode == 2 && a.qtiled)  // dirty blocks only: a modest grid walks the work list
+            hipLaunchKernelGGL((i8_mel_mfma_kernel<true, 2>), dim3(nb < 2048u ? nb : 2048u), dim3(256), lds, s, a);
+        else if (a.qx)
+            hipLaunchKernelGGL((i8_mel_mfma_kernel<true, 0>), dim3(nb), dim3(256), lds, s, a);
         else
-            hipLaunchKernelGGL(i8_mel_mfma_kernel<false>, dim3((unsigned)(a.B * (a.W / 64))), dim3(256), (size_t)64 * (a.Cin + 16), s, a);
+            hipLaunchKernelGGL((i8_mel_mfma_kernel<false, 0>), dim3(nb), dim3(256), lds, s, a);
         return;
     }
     if (i8_pw_wave_supported(a)) return launch_i8_pw_wave(a, s);

@@ -29,6 +29,9 @@ struct Options {
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
     int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
+    int stft_exact = 2;        // INT8 plans from audio: 2 = float32 STFT + float64 pass over the doubtful elements (bit-exact input bytes,
+                               // bn_stft_exact.hip; plans / options the guarded kernels do not cover take 1), 1 = every bin as a float64
+                               // DFT (same bytes, ~10 x slower), 0 = plain float32 STFT (round 2: ~3e-6 of the input bytes off by one)
     int ingest_blk = 0;        // outputs per workgroup of the resampler (0: auto)
     int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
 };
@@ -52,13 +55,41 @@ struct StftTables {
                             //         th_je = 2 pi (2 j + e) / 512; the 1/2 of the real-FFT split is folded into the window
     const float4* tw256;    // [256] (w, w_rot): w = exp(-2 pi i p / 256), w_rot = (-w.y, w.x)
     const float4* tw512;    // [16] per-lane split-pass base: (-sin a_j, -cos a_j, -cos a_j, sin a_j), a_j = 2 pi j / 512
+    const double* hann64;   // [512] 0.5 - 0.5 cos(2 pi n / 512): the reference's float64 window (bn_stft_exact.hip)
+    const double* cs64;     // [512] cos(2 pi j / 512) with exact symmetries (sin by index shift)
+};
+
+// Exactness pass of the INT8 audio path (bn_stft_exact.hip explains the five kernels).
+constexpr int kGuardRec = 128;   // ints per (chunk, 16-frame tile) record: L bits, U bits, n_max, n_min, 30 + 30 thread ids, 4 unused, 30 + 30 values
+constexpr int kGuardCand = 30;
+constexpr int kGuardBudget = 48;  // float64 re-evaluations stft_minmax_exact_kernel spends on one chunk's extrema before it gives the chunk up
+struct StftGuard {
+    float* eps;    // [B][W] per-frame bound on |S' - S|
+    int* rec;      // [B][ceil(W / 16)][kGuardRec]
+    int* list;     // [B][cap] flagged elements (frame << 16 | bin)
+    int* count;    // [B]
+    int cap;
+    int* dirty;    // [B] bit per 64-frame block whose quantised bytes changed
+    int* work;     // [B * ceil(W / 64)] dirty (chunk, block) pairs
+    int* n_work;   // [1]
+    int* hard;     // [2][hard_cap] chunks recomputed as whole float64 spectrograms: behind the min / max pass, behind the fix pass
+    int* n_hard;   // [2]
+    int hard_cap;
 };
 
 // ---- STFT ------------------------------------------------------------------------------
 void launch_minmax_init(float* minmax, int B, hipStream_t s);
 // tile_major: spectrogram written as [W/16][257][16] instead of [257][W] (needs W % 16 == 0; private layout of bn_infer_audio)
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec,
-                    float* minmax, hipStream_t s, bool tile_major = false);
+                    float* minmax, hipStream_t s, bool tile_major = false, const StftGuard* guard = nullptr);
+// every bin as a float64 DFT, |.| by numpy's formula: the reference's values (bn_stft_exact.hip); minmax as launch_stft512
+void launch_stft512_f64(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, float* minmax, hipStream_t s,
+                        bool tile_major = false);
+void launch_spec_bytes(const float* spec, const float* minmax, int B, int W, bool tile_major, float qscale, int qzp, int8_t* out, hipStream_t s);
+void launch_stft_minmax_exact(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, bool tile_major,
+                              const StftGuard& g, float* minmax, hipStream_t s);
+void launch_stft_fix(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, bool tile_major, const StftGuard& g,
+                     const float* minmax, float qscale, int qzp, hipStream_t s);
 bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
                         const float* wvals, const int* bands, float* minmax, hipStream_t s, int square = 0);
 // per-chunk finishing pass of the precomputed-frontend spectrogram modes (bn_melspec.hip)
@@ -229,7 +260,12 @@ struct DwPw8Args {
     const float* qminmax;  // [B][2] per-chunk min / max for the (S - min) / (max - min + 1e-10) normalisation, or null
     float qscale;
     int qzp, qfill, qF;
-    int qtiled;            // the spectrogram is tile-major [W/16][qF][16] (written by launch_stft512(..., tile_major))    // plain 1x1 convolution behind a squeeze-excite MUL (i8_pw_wave_kernel only): x is the UNSCALED map, the gate is applied on load
+    int qtiled;            // the spectrogram is tile-major [W/16][qF][16] (written by launch_stft512(..., tile_major))
+    // exactness pass of the audio path (bn_stft_exact.hip): qmode 1 lists the elements whose byte may differ from the reference's,
+    // qmode 2 runs only the (chunk, 64-frame block) pairs of qguard.work
+    int qmode;
+    StftGuard qguard;
+    // plain 1x1 convolution behind a squeeze-excite MUL (i8_pw_wave_kernel only): x is the UNSCALED map, the gate is applied on load
     const int8_t* gate;    // [B][Cin] or null
     int g_zx, g_zg, g_mult, g_shift, g_zo, g_amin, g_amax;
 };

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "bn_kernels.h"
+#include "bn_quant_in.h"
 
 namespace bn {
 
@@ -106,10 +107,31 @@ __device__ __forceinline__ void frame_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool MEL_OUT>
+// reductions over the 16 lanes of a frame (one DPP row): quad swaps, then rotations by 4 and 8 — vector-ALU only, no LDS traffic
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    const int i = __builtin_bit_cast(int, v);  // (every source lane of these controls exists: with bound_ctrl the compiler may fold the move into the ALU op)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, true));
+}
+#define BN_ROW16(OP, v)                \
+    v = OP(v, dpp_f<0xB1>(v));  /* quad_perm [1,0,3,2] */ \
+    v = OP(v, dpp_f<0x4E>(v));  /* quad_perm [2,3,0,1] */ \
+    v = OP(v, dpp_f<0x124>(v)); /* row_ror:4 */           \
+    v = OP(v, dpp_f<0x128>(v)); /* row_ror:8 */
+__device__ __forceinline__ float addf(float a, float b) { return a + b; }
+__device__ __forceinline__ float row16_sum(float v) { BN_ROW16(addf, v) return v; }
+__device__ __forceinline__ float row16_max(float v) { BN_ROW16(fmaxf, v) return v; }
+__device__ __forceinline__ float row16_min(float v) { BN_ROW16(fminf, v) return v; }
+
+// GUARD (INT8 audio path, bn_stft_exact.hip): besides the magnitudes S' the kernel writes, per frame, the bound eps_t of
+// bn_quant_in.h on |S' - S| against the reference's float64 evaluation and, per tile, a record of the THREADS (frame, 16 bins)
+// that can hold the chunk's largest / smallest value: with Lt = max (S' - eps) and Ut = min (S' + eps) over the tile, those whose
+// largest element reaches Lt within the bound, resp. whose smallest comes down to Ut.  The chunk's min / max themselves are left
+// to stft_minmax_exact_kernel (no atomics here).
+template <bool MEL_OUT, bool GUARD = false>
 __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop,
                                                           int W, float* __restrict__ spec, float* minmax, MelOut mel,
-                                                          int tiles_per_wg) {
+                                                          int tiles_per_wg, StftGuard guard) {
     // The magnitude tile [257][kFT + 1] (17.5 KB) re-uses the exchange buffer (34.8 KB): every lane takes its sixteen conjugate
     // partners into registers, one workgroup barrier later the buffer is free.  35 KB instead of 52 KB of LDS = four
     // workgroups per CU instead of three.
@@ -120,6 +142,9 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
     float (*mag)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(&xch[0][0]);
     static_assert(sizeof(float) * 257 * (kFT + 1) <= sizeof(float) * kFT * kFS, "magnitude tile must fit the exchange buffer");
     __shared__ float red_min[4], red_max[4];
+    __shared__ float g_red[2][kFT], g_eps[kFT];  // GUARD: per-frame (lower end of the largest, upper end of the smallest element), eps (-1: frame beyond W)
+    __shared__ int g_cnt[2], g_rec[2 * kGuardCand];
+    __shared__ float g_recv[2 * kGuardCand], g_LU[2];
     // mel mixer tables (MEL_OUT): up to 1024 band-sparse values and 3 x 128 band entries (the launcher refuses more mel bins)
     constexpr int kMelW = MEL_OUT ? 1024 : 1, kMelT = MEL_OUT ? 384 : 1;
     __shared__ float mel_w[kMelW];
@@ -170,6 +195,14 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
         // pass 1: lane j owns z[16 n1 + j], n1 = 0..15
         v2f a[16];
         fetch(tile, a);
+        if (GUARD && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) guard.n_hard[0] = 0;  // (stft_minmax_exact_kernel's list of given-up chunks)
+        float frame_ss = 0.0f;  // GUARD: sum of the frame's squared samples
+        if constexpr (GUARD) {
+            v2f ss = {0.0f, 0.0f};
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) ss = __builtin_elementwise_fma(a[n1], a[n1], ss);
+            frame_ss = row16_sum(ss.x + ss.y);
+        }
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const v2f wn = __builtin_elementwise_fma(wsn, (v2f){kSin8[n1], kSin8[n1]},
@@ -260,7 +293,46 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
             lmin = fminf(lmin, tmin);
             lmax = fmaxf(lmax, tmax);
         }
+        if constexpr (GUARD) {
+            // the frame's bound on |S' - S| (bn_quant_in.h): eps(S') = eps_f + kGuardRel S' with eps_f = kGuardL2 ||x||_2 + kGuardPeak max_k S'
+            const float peak = row16_max(tmax), low = row16_min(tmin);
+            const float eps_f = __builtin_amdgcn_sqrtf(frame_ss) * kGuardL2 + peak * kGuardPeak;
+            if (j == 0) {
+                g_red[0][f] = live ? guard_lo(peak, eps_f) : 0.0f;
+                g_red[1][f] = live ? guard_hi(low, eps_f) : __uint_as_float(0x7f800000u);
+                g_eps[f] = live ? eps_f : -1.0f;
+                if (live) guard.eps[(size_t)b * W + t] = eps_f;
+            }
+            if (threadIdx.x < 2) g_cnt[threadIdx.x] = 0;
+        }
         __syncthreads();
+        if constexpr (GUARD) {
+            const float Lt = fmaxf(row16_max(g_red[0][threadIdx.x & 15]), 0.0f), Ut = row16_min(g_red[1][threadIdx.x & 15]);
+            g_LU[0] = Lt;  // (every thread writes the same two values: read back for the record below)
+            g_LU[1] = Ut;
+            // candidates for the chunk's extrema: a THREAD whose largest (smallest) of its 16 bins j + 16 k2 of frame f comes within the
+            // bound of the tile's extremum is recorded as (j, f) with the upper (lower) end of what that element can be;
+            // stft_minmax_exact_kernel looks at its bins (re-reading the tile here, even only in the waves with a hit, cost 30 us of
+            // the kernel's 450)
+            const float e_f = g_eps[f];
+            if (e_f > 0.0f) {  // (frames of zeros are exact, frames beyond W do not count)
+                const float top = guard_hi(tmax, e_f), bot = guard_lo(tmin, e_f);
+                if (top >= Lt) {
+                    const int sl = atomicAdd(&g_cnt[0], 1);
+                    if (sl < kGuardCand) {
+                        g_rec[sl] = threadIdx.x;
+                        g_recv[sl] = top;
+                    }
+                }
+                if (bot <= Ut) {
+                    const int sl = atomicAdd(&g_cnt[1], 1);
+                    if (sl < kGuardCand) {
+                        g_rec[kGuardCand + sl] = threadIdx.x;
+                        g_recv[kGuardCand + sl] = bot;
+                    }
+                }
+            }
+        }
 
         if (!MEL_OUT) {
             // frequency-major rows, 16 consecutive frames each
@@ -275,6 +347,15 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
             for (int idx = threadIdx.x; idx < 257 * kFT; idx += 256) {
                 const int k = idx / kFT, ff = idx % kFT;
                 if (t0 + ff < W) out[(size_t)k * W + t0 + ff] = mag[k][ff];
+            }
+            if constexpr (GUARD) {
+                __syncthreads();
+                if (threadIdx.x < kGuardRec) {
+                    const int i = threadIdx.x;
+                    const int v = i < 2 ? __float_as_int(g_LU[i]) : i < 4 ? g_cnt[i - 2] : i < 64 ? g_rec[i - 4] : i < 68 ? 0 : __float_as_int(g_recv[i - 68]);
+                    guard.rec[((size_t)b * gridDim.x + blockIdx.x) * kGuardRec + i] = v;
+                }
+                return;  // min / max of the chunk: stft_minmax_exact_kernel
             }
         } else {
             // thread = (frame ff, mel bins j, 31 - j, 32 + j, ...): the serpentine order gives every thread about the same number of
@@ -351,11 +432,15 @@ void launch_minmax_init(float* minmax, int B, hipStream_t s) {
 static int stft_tiles_per_wg(int, int) { return 1; }
 
 void launch_stft512(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, float* minmax,
-                    hipStream_t s, bool tile_major) {
+                    hipStream_t s, bool tile_major, const StftGuard* guard) {
     const int n_tiles = (W + kFT - 1) / kFT;
     const int tpw = stft_tiles_per_wg(B, n_tiles);
-    hipLaunchKernelGGL((stft512_mag_kernel<false>), dim3((n_tiles + tpw - 1) / tpw, B), dim3(256), 0, s, tb, audio, T, hop, W, spec,
-                       minmax, MelOut{}, (tile_major && W % kFT == 0) ? -1 : tpw);
+    if (guard)
+        hipLaunchKernelGGL((stft512_mag_kernel<false, true>), dim3(n_tiles, B), dim3(256), 0, s, tb, audio, T, hop, W, spec, minmax, MelOut{},
+                           (tile_major && W % kFT == 0) ? -1 : tpw, *guard);
+    else
+        hipLaunchKernelGGL((stft512_mag_kernel<false>), dim3((n_tiles + tpw - 1) / tpw, B), dim3(256), 0, s, tb, audio, T, hop, W, spec,
+                           minmax, MelOut{}, (tile_major && W % kFT == 0) ? -1 : tpw, StftGuard{});
 }
 
 bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* mel_out, int M,
@@ -364,7 +449,7 @@ bool launch_stft512_mel(const StftTables& tb, const float* audio, int B, int T, 
     const int n_tiles = (W + kFT - 1) / kFT;
     const int tpw = stft_tiles_per_wg(B, n_tiles);
     hipLaunchKernelGGL((stft512_mag_kernel<true>), dim3((n_tiles + tpw - 1) / tpw, B), dim3(256), 0, s, tb, audio, T, hop, W, nullptr,
-                       minmax, MelOut{wvals, bands, mel_out, M, square}, tpw);
+                       minmax, MelOut{wvals, bands, mel_out, M, square}, tpw, StftGuard{});
     return true;
 }
 

@@ -1,0 +1,433 @@
+// bn_stft_exact.hip — the float64 side of the STFT: what makes the INT8 path from audio BIT-EXACT with the reference's arithmetic.
+//
+// The reference computes a chunk's spectrogram as np.abs(librosa.stft(y, 512, hop)) — window product and real FFT in float64,
+// the result stored as complex64, |.| by numpy's float32 formula (birdnet_stm32/audio/spectrogram.py:106-115) — normalises it with
+// its float32 min / max (:12-21) and the INT8 graph's QUANTIZE (op #0) rounds it to bytes.  The production STFT
+// (stft512_mag_kernel, bn_stft.hip) is a float32 FFT: its magnitudes S' differ from the reference's S by ~1e-6 of the peak, which
+// flipped 3e-6 of the quantised bytes in round 2.  Integer work has to be identical, so bn_infer_audio now runs
+//
+//   K1  stft512_mag_kernel<false, GUARD>   S' + a per-frame bound eps_t >= |S' - S| (bn_quant_in.h) + per-tile candidates for the
+//                                          chunk's extrema (elements within the bound of the tile's largest / smallest value)
+//   K2  stft_minmax_exact_kernel           the candidates that can still be the chunk's max / min re-evaluated in float64
+//                                          (512-term DFT per element, a wave per element) -> the EXACT float32 min / max
+//   K3  i8_mel_mfma_kernel<QIN, flagging>  quantises S' with the exact min / max and lists every element whose byte could differ
+//                                          for some S within [S' - eps, S' + eps] (the quantiser is monotone: test the distance
+//                                          of its argument to the next rounding boundary)
+//   K4  stft_fix_kernel                    listed elements in float64 -> exact S patched into the spectrogram; a changed byte
+//                                          marks its (chunk, 64-frame block) dirty
+//   K5  i8_mel_mfma_kernel<QIN, worklist>  the mel mixer again for the dirty blocks only.
+//
+// Elements that are not listed have the same byte for every S the bound allows, listed ones are exact: the bytes equal the
+// oracle's (oracle/stft.py + oracle/int8_graph.py) as long as the float64 DFT here and numpy's float64 FFT round to the same
+// complex64 value (they differ by ~1e-16 relative; an element for which that matters is a ~1e-9 event).
+//
+// stft512_f64_kernel computes a WHOLE spectrogram that way (every bin a float64 DFT): the public bn_stft_mag_exact, and
+// bn_infer_audio's INT8 route whenever the guarded fast path does not apply (debug plans, layout / kernel A-B options).
+#include "bn_kernels.h"
+#include "bn_quant_in.h"
+
+#pragma clang fp contract(off)
+
+namespace bn {
+
+namespace {
+
+constexpr int kFT = 16;  // frames per tile (= stft512_mag_kernel's workgroup)
+
+__device__ __forceinline__ size_t spec_offset(int W, bool tile_major, int k, int t) {
+    return tile_major ? (size_t)(t / kFT) * 257 * kFT + (size_t)k * kFT + (t % kFT) : (size_t)k * W + t;
+}
+
+// float64 sums over the 16 lanes of a DPP row (quad swaps, rotations by 4 and 8): no LDS traffic
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long bits = __builtin_bit_cast(long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row16_sum_d(double v) {
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x124>(v);
+    v += dpp_d<0x128>(v);
+    return v;
+}
+
+// LDS copy of the twiddles as (cos, sin) pairs: ONE 16-byte gather per term.  Entry e sits at slot e + (e >> 4): a lane group walks the
+// table with stride k, and without the skew every k that is a multiple of 16 would put its 16 lanes on one bank.
+struct ExactTabs {
+    double2 cs[512 + 32];
+};
+__device__ __forceinline__ int cs_slot(int e) { return e + (e >> 4); }
+__device__ __forceinline__ void stage_tabs(ExactTabs& tl, const StftTables& tb) {
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) tl.cs[cs_slot(i)] = make_double2(tb.cs64[i], tb.cs64[(i + 384) & 511]);  // sin(a) = cos(a - pi/2); sin(0) = 0 exactly
+}
+// the window values of a lane's 16 sample pairs n = (lane & 15) + 16 i (hann[512 - n] = hann[n]): fetched once, kept in registers
+struct LaneWindow {
+    double w[16];
+    __device__ __forceinline__ void load(const StftTables& tb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = tb.hann64[(threadIdx.x & 15) + 16 * i];
+    }
+};
+
+// |X_k| of frame t the way the reference evaluates it: float64 window product, float64 DFT, complex64, numpy's |.|.
+// A GROUP of 16 lanes (one DPP row) evaluates one element; the four groups of a wave work on four elements at once.  Samples
+// n and 512 - n share their cosine and have opposite sines (and the same window value), so a lane takes 16 such pairs:
+//   re = sum_n (xw[n] + xw[512 - n]) cos(2 pi k n / 512),   im = -sum_n (xw[n] - xw[512 - n]) sin(2 pi k n / 512),   n = 1..255,
+// with xw[0] + (-1)^k xw[256] riding on n = 0 (cos = 1, sin = 0).  Tree sum inside the row; every lane of the group returns the value.
+__device__ __forceinline__ float exact_mag_row(const ExactTabs& tl, const LaneWindow& lw, const float* __restrict__ x, int T, int hop, int t, int k) {
+    const int gl = threadIdx.x & 15;
+    // range-checked raw buffer loads over exactly this chunk: samples before / behind it read as 0 (librosa's centre padding) with no
+    // branch around the load, so all 32 loads of a lane are in flight together (as conditional loads they ran one round trip at a time:
+    // 20 us per element)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
+    const int base = (t * hop - 256) * 4;  // byte offset of the frame's first sample (negative = out of range as unsigned)
+    float xa[16], xb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = gl + 16 * i;
+        xa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * n, 0, 0));
+        xb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * (n == 0 ? 256 : 512 - n), 0, 0));
+    }
+    double re = 0.0, im = 0.0;
+    int idx = k * gl;  // k n mod 512, n = gl + 16 i
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double va = (double)xa[i] * lw.w[i];
+        double vb = (double)xb[i] * ((i == 0 && gl == 0) ? 1.0 : lw.w[i]);  // n = 0 pairs with n = 256: hann[256] = 1
+        if (i == 0 && gl == 0 && (k & 1)) vb = -vb;
+        const double2 c = tl.cs[cs_slot(idx & 511)];
+        re = fma(va + vb, c.x, re);
+        im = fma(va - vb, c.y, im);
+        idx += 16 * k;
+    }
+    re = row16_sum_d(re);
+    im = row16_sum_d(im);
+    return numpy_cabsf((float)re, (float)im);
+}
+
+// ------------------------------------------------------------------------------------------------ whole spectrogram in float64
+struct F64Lds {
+    double cs[512];
+    double xw[512];
+    double2 sd[256];  // n = 1..255: (xw[n] + xw[512 - n], xw[n] - xw[512 - n])
+    double red[4];
+    float red_min[4], red_max[4];
+};
+
+// The 16 frames of tile (b, tile) with every bin a float64 DFT; 256 threads, thread k = bin k.  cs must be staged.
+__device__ __forceinline__ void f64_tile(F64Lds& L, const StftTables& tb, const float* __restrict__ audio, int T, int hop, int W,
+                                         float* __restrict__ spec, float* minmax, bool tile_major, int b, int tile) {
+    const int tid = threadIdx.x, t0 = tile * kFT;
+    const float* x = audio + (size_t)b * T;
+    float* out = spec + (size_t)b * 257 * W;
+    float lmin = __uint_as_float(0x7f800000u), lmax = 0.0f;
+    for (int ff = 0; ff < kFT && t0 + ff < W; ++ff) {
+        const int t = t0 + ff;
+        const long base = (long)t * hop - 256;
+        __syncthreads();  // previous frame done with xw / sd (and cs staged)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = tid + 256 * h;
+            const long pos = base + n;
+            const float xv = (pos >= 0 && pos < T) ? x[pos] : 0.0f;
+            L.xw[n] = (double)xv * tb.hann64[n];
+        }
+        __syncthreads();
+        double alt;  // this thread's term of the Nyquist bin sum_n (-1)^n xw[n]
+        if (tid == 0) {
+            alt = L.xw[0] + L.xw[256];
+        } else {
+            const double p = L.xw[tid], q = L.xw[512 - tid];
+            L.sd[tid] = make_double2(p + q, p - q);
+            alt = (tid & 1) ? -(p + q) : (p + q);
+        }
+        __syncthreads();
+        // bin k = tid: re = xw[0] + (-1)^k xw[256] + sum_n s_n cos(2 pi k n / 512), im = -sum_n d_n sin(2 pi k n / 512)
+        double re = 0.0, im = 0.0;
+        for (int n = 1; n < 256; ++n) {
+            const int idx = (tid * n) & 511;
+            const double2 v = L.sd[n];
+            re = fma(v.x, L.cs[idx], re);
+            im = fma(v.y, L.cs[(idx + 384) & 511], im);
+        }
+        re += (tid & 1) ? (L.xw[0] - L.xw[256]) : (L.xw[0] + L.xw[256]);
+        const float m = numpy_cabsf((float)re, (float)im);
+        out[spec_offset(W, tile_major, tid, t)] = m;
+        lmin = fminf(lmin, m);
+        lmax = fmaxf(lmax, m);
+        // Nyquist bin
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) alt += __shfl_xor(alt, off);
+        if ((tid & 63) == 0) L.red[tid >> 6] = alt;
+        __syncthreads();
+        if (tid == 0) {
+            const float ny = numpy_cabsf((float)((L.red[0] + L.red[1]) + (L.red[2] + L.red[3])), 0.0f);
+            out[spec_offset(W, tile_major, 256, t)] = ny;
+            lmin = fminf(lmin, ny);
+            lmax = fmaxf(lmax, ny);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lmin = fminf(lmin, __shfl_xor(lmin, off));
+        lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        L.red_min[tid >> 6] = lmin;
+        L.red_max[tid >> 6] = lmax;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float mn = fminf(fminf(L.red_min[0], L.red_min[1]), fminf(L.red_min[2], L.red_min[3]));
+        const float mx = fmaxf(fmaxf(L.red_max[0], L.red_max[1]), fmaxf(L.red_max[2], L.red_max[3]));
+        atomicMin(reinterpret_cast<unsigned int*>(minmax + 2 * b), __float_as_uint(mn));  // magnitudes are >= 0
+        atomicMax(reinterpret_cast<unsigned int*>(minmax + 2 * b + 1), __float_as_uint(mx));
+    }
+}
+
+__global__ __launch_bounds__(256) void stft512_f64_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
+                                                          float* __restrict__ spec, float* minmax, int tile_major) {
+    __shared__ F64Lds L;
+    for (int i = threadIdx.x; i < 512; i += 256) L.cs[i] = tb.cs64[i];
+    f64_tile(L, tb, audio, T, hop, W, spec, minmax, tile_major != 0, blockIdx.y, blockIdx.x);
+}
+
+// The chunks of a list (those the guarded pass gives up on: flat spectra, pure tones, signals far below the error bound — more
+// elements in doubt than is worth recomputing one by one) as whole float64 spectrograms; their frames' bounds become 0 = exact.
+__global__ __launch_bounds__(256) void stft512_f64_list_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
+                                                               float* __restrict__ spec, float* minmax, int tile_major, const int* __restrict__ list,
+                                                               const int* __restrict__ n_list, float* __restrict__ eps) {
+    __shared__ F64Lds L;
+    const int n_tiles = (W + kFT - 1) / kFT, n = *n_list * n_tiles;
+    if ((int)blockIdx.x >= n) return;
+    for (int i = threadIdx.x; i < 512; i += 256) L.cs[i] = tb.cs64[i];
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int b = list[w / n_tiles], tile = w % n_tiles;
+        f64_tile(L, tb, audio, T, hop, W, spec, minmax, tile_major != 0, b, tile);
+        if (eps && threadIdx.x < kFT && tile * kFT + threadIdx.x < W) eps[(size_t)b * W + tile * kFT + threadIdx.x] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K2: exact per-chunk min / max
+// One WAVE per chunk, four chunks per workgroup (they share the float64 tables in LDS and nothing else: wave-level syncs only).
+// L = max over tiles of (largest S' - eps) is a lower bound of the true maximum, so only elements with S' + eps >= L can be it;
+// U = min (smallest S' + eps) likewise for the minimum.  A frame of zeros (eps = 0) has S' = S = 0 exactly and is never listed: it
+// shows as U = 0 (then the minimum is 0) and cannot hold the maximum unless every frame is zero.  The tiles' records name THREADS
+// of stft512_mag_kernel (frame f = id >> 4, bins j + 16 k2 with j = id & 15, thread j = 0 also bin 256) whose largest / smallest value
+// came within the bound of the tile's extremum; the lanes test those threads' bins against L / U in parallel and the few that pass
+// are re-evaluated in float64 four at a time.  A chunk with more than kGuardBudget of them (or an overflowing record: flat spectra,
+// pure stationary tones, signals far below the bound) goes to stft512_f64_list_kernel as a whole.
+constexpr int kK2Thr = 192;  // candidate threads a wave keeps
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
+                                                                float* __restrict__ spec, int tile_major, StftGuard g, int n_tiles,
+                                                                float* __restrict__ minmax, int B) {
+    __shared__ ExactTabs tl;
+    LaneWindow lw;
+    lw.load(tb);
+    __shared__ int cand_s[4][kGuardBudget + 64];  // passing candidates: is_max << 31 | frame << 16 | bin
+    __shared__ int thr_s[4][kK2Thr + 64];         // candidate threads: is_max << 31 | tile << 8 | thread id
+    stage_tabs(tl, tb);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    int* cand = cand_s[wave];
+    int* thr = thr_s[wave];
+    const float* x = audio + (size_t)b * T;
+    float* S = spec + (size_t)b * 257 * W;
+    const float* eps = g.eps + (size_t)b * W;
+    const int* rec = g.rec + (size_t)b * n_tiles * kGuardRec;
+    if (lane == 0) {  // (stft_fix_kernel / the first operator's flagging start from clean counters)
+        g.count[b] = 0;
+        g.dirty[b] = 0;
+    }
+    float L = 0.0f, U = __uint_as_float(0x7f800000u);
+    int n_max = 0, n_min = 0;  // lane = tile
+    if (lane < n_tiles) {
+        const int4 h = *reinterpret_cast<const int4*>(rec + lane * kGuardRec);
+        L = fmaxf(__int_as_float(h.x), 0.0f);
+        U = __int_as_float(h.y);
+        n_max = h.z;
+        n_min = h.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        L = fmaxf(L, __shfl_xor(L, off));
+        U = fminf(U, __shfl_xor(U, off));
+    }
+    const bool min_is_zero = U == 0.0f;
+    if (min_is_zero) n_min = 0;
+    bool hard = __ballot(n_max > kGuardCand || n_min > kGuardCand) != 0;
+    // 1. collect the recorded threads: lane = tile, slot s of its record per step
+    int n_thr = 0;
+    for (int s_ = 0; s_ < kGuardCand && !hard; ++s_) {
+        // (the record holds, per thread, the upper / lower end of what its extreme element can be: most tiles' entries stop here)
+        if (!__ballot(s_ < n_max || s_ < n_min)) break;
+        const bool p_max = s_ < n_max && __int_as_float(rec[lane * kGuardRec + 68 + s_]) >= L;
+        const bool p_min = s_ < n_min && __int_as_float(rec[lane * kGuardRec + 68 + kGuardCand + s_]) <= U;
+        const unsigned long long m_max = __ballot(p_max), m_min = __ballot(p_min);
+        const unsigned long long below = (1ull << lane) - 1;
+        if (n_thr + __popcll(m_max) + __popcll(m_min) > kK2Thr) {
+            hard = true;
+            break;
+        }
+        if (p_max) thr[n_thr + __popcll(m_max & below)] = (int)0x80000000 | (lane << 8) | rec[lane * kGuardRec + 4 + s_];
+        n_thr += __popcll(m_max);
+        if (p_min) thr[n_thr + __popcll(m_min & below)] = (lane << 8) | rec[lane * kGuardRec + 4 + kGuardCand + s_];
+        n_thr += __popcll(m_min);
+    }
+    wave_sync();
+    // 2. their bins against L / U
+    int n_cand = 0;
+    for (int e0 = 0; e0 < n_thr * 17 && !hard; e0 += 64) {
+        const int e = e0 + lane;
+        bool pred = false;
+        int code = 0;
+        if (e < n_thr * 17) {
+            const int c = thr[e / 17], k2 = e % 17;
+            const int id = c & 0xff, tile = (c >> 8) & 0x7fff, j = id & 15, t = tile * kFT + (id >> 4);
+            const int k = j + 16 * k2;
+            if (k2 < 16 || j == 0) {
+                const float s1 = S[spec_offset(W, tile_major != 0, k, t)], ee = eps[t];
+                pred = c < 0 ? (guard_hi(s1, ee) >= L) : (guard_lo(s1, ee) <= U);
+                code = (c & (int)0x80000000) | (t << 16) | k;
+            }
+        }
+        const unsigned long long mask = __ballot(pred);
+        const int pos = n_cand + __popcll(mask & ((1ull << lane) - 1));
+        n_cand += __popcll(mask);
+        if (n_cand > kGuardBudget) hard = true;
+        else if (pred) cand[pos] = code;
+    }
+    wave_sync();
+    float mx = 0.0f, mn = min_is_zero ? 0.0f : __uint_as_float(0x7f800000u);
+    if (!hard) {
+        const int grp = lane >> 4, gl = lane & 15;
+        for (int c0 = 0; c0 < n_cand; c0 += 4) {
+            const bool act = c0 + grp < n_cand;
+            const int code = act ? cand[c0 + grp] : 0;
+            const int t = (code >> 16) & 0x7fff, k = code & 0xffff;
+            const float ex = exact_mag_row(tl, lw, x, T, hop, t, k);
+            if (act) {
+                if (gl == 0) S[spec_offset(W, tile_major != 0, k, t)] = ex;
+                if (code < 0) mx = fmaxf(mx, ex); else mn = fminf(mn, ex);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+            mn = fminf(mn, __shfl_xor(mn, off));
+        }
+    }
+    if (lane == 0) {
+        if (hard) {  // the whole chunk in float64 (stft512_f64_list_kernel reduces into minmax)
+            mn = __uint_as_float(0x7f800000u);
+            mx = 0.0f;
+            g.hard[atomicAdd(g.n_hard, 1)] = b;
+        }
+        minmax[2 * b] = mn;
+        minmax[2 * b + 1] = mx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K4: listed elements in float64
+__global__ __launch_bounds__(256) void stft_fix_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
+                                                       float* __restrict__ spec, int tile_major, StftGuard g,
+                                                       const float* __restrict__ minmax, float qscale, int qzp) {
+    __shared__ ExactTabs tl;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = g.count[b];
+    if (n == 0) return;
+    const int tiles64 = (W + 63) / 64;
+    if (n > g.cap) {
+        // more flagged elements than the chunk's list holds: the whole chunk in float64 (stft512_f64_list_kernel on the second list),
+        // every block of it through the mel mixer again
+        if (tid == 0) {
+            g.hard[g.hard_cap + atomicAdd(g.n_hard + 1, 1)] = b;
+            const int all = tiles64 >= 32 ? -1 : (1 << tiles64) - 1;
+            const int old = atomicOr(g.dirty + b, all);
+            for (int i = 0; i < tiles64; ++i)
+                if (!(old >> i & 1)) g.work[atomicAdd(g.n_work, 1)] = b * tiles64 + i;
+        }
+        return;
+    }
+    stage_tabs(tl, tb);
+    LaneWindow lw;
+    lw.load(tb);
+    const float* x = audio + (size_t)b * T;
+    float* S = spec + (size_t)b * 257 * W;
+    QuantIn qi;
+    qi.set(minmax + 2 * b, qscale, qzp);
+    const int* list = g.list + (size_t)b * g.cap;
+    __syncthreads();
+    const int grp = tid >> 4, gl = tid & 15;  // 16 groups of 16 lanes: 16 elements at a time
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        const bool act = i0 + grp < n;
+        const int e = act ? list[i0 + grp] : 0;
+        const int t = e >> 16, k = e & 0xffff;
+        const size_t off = spec_offset(W, tile_major != 0, k, t);
+        const float old = act ? S[off] : 0.0f;
+        const float ex = exact_mag_row(tl, lw, x, T, hop, t, k);
+        if (act && gl == 0) {
+            S[off] = ex;
+            if (qi.q(old) != qi.q(ex)) {
+                const int bit = 1 << (t / 64);
+                if (!(atomicOr(g.dirty + b, bit) & bit)) g.work[atomicAdd(g.n_work, 1)] = b * tiles64 + t / 64;
+            }
+        }
+    }
+}
+
+// test hook: the bytes QUANTIZE makes of the spectrogram as it lies in the workspace, [B][257][W] frequency-major
+__global__ void spec_bytes_kernel(const float* __restrict__ spec, const float* __restrict__ minmax, int W, int tile_major, float qscale, int qzp,
+                                  int8_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    QuantIn qi;
+    qi.set(minmax + 2 * b, qscale, qzp);
+    const float* S = spec + (size_t)b * 257 * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 257 * W; i += gridDim.x * blockDim.x) {
+        const int k = i / W, t = i - k * W;
+        out[(size_t)b * 257 * W + i] = (int8_t)qi.q(S[spec_offset(W, tile_major != 0, k, t)]);
+    }
+}
+
+}  // namespace
+
+void launch_stft512_f64(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, float* minmax, hipStream_t s,
+                        bool tile_major) {
+    const int n_tiles = (W + kFT - 1) / kFT;
+    hipLaunchKernelGGL(stft512_f64_kernel, dim3(n_tiles, B), dim3(256), 0, s, tb, audio, T, hop, W, spec, minmax,
+                       (tile_major && W % kFT == 0) ? 1 : 0);
+}
+
+void launch_spec_bytes(const float* spec, const float* minmax, int B, int W, bool tile_major, float qscale, int qzp, int8_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(spec_bytes_kernel, dim3(32, B), dim3(256), 0, s, spec, minmax, W, tile_major ? 1 : 0, qscale, qzp, out);
+}
+
+void launch_stft_minmax_exact(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, bool tile_major,
+                              const StftGuard& g, float* minmax, hipStream_t s) {
+    hipLaunchKernelGGL(stft_minmax_exact_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tb, audio, T, hop, W, spec, tile_major ? 1 : 0, g,
+                       (W + kFT - 1) / kFT, minmax, B);  // (the caller keeps W <= 1024: one lane per tile record)
+    // chunks the wave gave up on (none for ordinary audio: the 256 workgroups read the count and leave)
+    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(128), dim3(256), 0, s, tb, audio, T, hop, W, spec, minmax, tile_major ? 1 : 0, g.hard, g.n_hard,
+                       g.eps);
+}
+
+void launch_stft_fix(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, bool tile_major, const StftGuard& g,
+                     const float* minmax, float qscale, int qzp, hipStream_t s) {
+    hipLaunchKernelGGL(stft_fix_kernel, dim3(B), dim3(256), 0, s, tb, audio, T, hop, W, spec, tile_major ? 1 : 0, g, minmax, qscale, qzp);
+    // (minmax is exact already: the atomics of this pass find the same values)
+    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(128), dim3(256), 0, s, tb, audio, T, hop, W, spec, const_cast<float*>(minmax), tile_major ? 1 : 0,
+                       g.hard + g.hard_cap, g.n_hard + 1, (float*)nullptr);
+}
+
+}  // namespace bn

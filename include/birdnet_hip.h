@@ -9,6 +9,7 @@
  * replaces (paths relative to the reference repository birdnet-team/birdnet-stm32):
  *
  *   bn_stft_mag      <- birdnet_stm32/audio/spectrogram.py:24-33,61,106-115,133,149
+ *   bn_stft_mag_exact   (the same call site, float64 arithmetic like librosa's)
  *                       get_spectrogram_from_audio(audio, n_fft, mel_bins=-1, spec_width)
  *                       as called per chunk by evaluation/metrics.py:55-61
  *   bn_model_load    <- birdnet_stm32/models/runners.py:98-114 load_model_runner(model_path)
@@ -116,6 +117,13 @@ BN_API int bn_model_get_info(const bn_model* model, bn_model_info* out);
  * Only n_fft = 512 is implemented (the reference's firmware FFT has the same limit). */
 BN_API int bn_stft_mag(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W,
                 int normalize, float* d_spec, float* d_minmax, void* stream);
+
+/* The same spectrogram with the reference's arithmetic, value for value: window product and DFT of every bin in float64, the
+ * result rounded to complex64, |.| by numpy's float32 formula (birdnet_stm32/audio/spectrogram.py:106-115: np.abs(librosa.stft(...))),
+ * float32 min-max normalisation (:12-21).  About ten times slower than bn_stft_mag (a float32 FFT, within 2e-6 of the peak of
+ * these values); bn_infer_audio reaches the same INT8 input bytes at full speed by recomputing only the elements in doubt. */
+BN_API int bn_stft_mag_exact(bn_ctx* ctx, const float* d_audio, int B, int T, int n_fft, int hop, int W,
+                      int normalize, float* d_spec, float* d_minmax, void* stream);
 
 /* Forward pass from the runner boundary.
  *   d_input   [B, input_elems] float32 (model_info.input_kind says what it is)
@@ -228,6 +236,14 @@ BN_API int bn_debug_op_output(bn_model* model, int op_index, int B, void* d_dst,
  * right-shift form (needs multiplier >= 0, shift < 0); 3: the strip kernels' form with rounding offset and zero_point folded into
  * one addend (same preconditions, shift >= -22), zero point subtracted again.  (Reference: the int8 kernels inside
  * tf.lite.Interpreter.invoke, birdnet_stm32/models/runners.py:93.) */
+/* Test hook: the int8 bytes the graph's QUANTIZE (op #0) made of the spectrograms of the last bn_infer_audio call on an INT8 plan,
+ * d_out [B, 257, W] frequency-major (the production plan never stores them: QUANTIZE is fused into the mel mixer's load). */
+BN_API int bn_debug_input_bytes(bn_model* model, int B, int8_t* d_out, void* stream);
+/* Test hook (synchronises the device): counters of the exactness pass of the last bn_infer_audio call on an INT8 plan (first launch group) —
+ * out[0] elements listed as in doubt (sum over the B chunks), out[1] the largest count of one chunk, out[2] (chunk, 64-frame block) pairs
+ * whose bytes changed, out[3] / out[4] chunks recomputed as whole float64 spectrograms behind the min / max pass and behind the fix pass. */
+BN_API int bn_debug_guard_stats(bn_model* model, int B, int64_t* out);
+
 BN_API int bn_debug_requant(bn_ctx* ctx, const int32_t* d_x, const int32_t* d_mult, const int32_t* d_shift, int n, int mode,
                      int zero_point, int32_t* d_out, void* stream);
 
@@ -244,7 +260,7 @@ BN_API int bn_profile_collect(bn_model* model, double* total_ms, int64_t* launch
 
 /* Run-time switches of the kernel launchers, for A/B measurements and tests (process-wide; the defaults are the production
  * choices).  Names: "f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "i8_pwdw", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th",
- * "i8_tail", "i8_mel_generic", "stft_rowmajor", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
+ * "i8_tail", "i8_mel_generic", "stft_rowmajor", "stft_exact", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
  * what each selects).  An environment variable BN_<NAME IN CAPITALS> seeds the value once when the library is loaded; no
  * launch reads the environment.  The reference has no counterpart (tf.lite.Interpreter's delegates / num_threads arguments,
  * birdnet_stm32/models/runners.py:57, are the closest thing).  Unknown name: BN_ERR_ARG. */

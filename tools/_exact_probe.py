@@ -1,0 +1,41 @@
+import os, sys, time
+import numpy as np, torch
+REPO="/root/repo" if os.path.isdir("/root/repo/tests") else os.environ.get("GRAFT_REPO_ROOT",".")
+sys.path[:0]=[REPO, os.path.join(REPO,"birdnet-stm32_amd"), os.path.join(REPO,"tests")]
+from conftest import TFLITE_PATH, synth_chunks
+from oracle import stft, cport
+from birdnet_stm32.models._tflite_reader import load_tflite
+from birdnet_stm32.models.runners import load_model_runner
+from birdnet_stm32 import _hip
+N=int(sys.argv[1]) if len(sys.argv)>1 else 256
+audio=synth_chunks(N, seed=77)
+audio[:4]=0.0; audio[4:8]*=1e-3
+PLAIN=len(sys.argv)>2
+t=np.arange(72000)/24000
+if not PLAIN: audio[8]=np.sin(2*np.pi*440*t).astype(np.float32)   # pure tone
+if not PLAIN: audio[9]=1.0   # DC
+if not PLAIN: audio[10]=0; audio[10][:30000]=audio[11][:30000]   # zero tail
+if not PLAIN: audio[12]=0; audio[12][5000]=1.0  # impulse
+S_ref=np.stack([stft.hybrid_spectrogram(a,512,256) for a in audio])[...,None].astype(np.float32)
+model=load_tflite(TFLITE_PATH)
+path=cport.CpuInt8Path(model)
+qin=model.ops[0].outputs[0]; fc=model.ops[53].outputs[0]
+ref_scores, ref_q = [], []
+for i in range(0,N,256):
+    sc, env = path.invoke(S_ref[i:i+256], return_all=True)
+    ref_scores.append(sc); ref_q.append(env[qin].reshape(len(sc),-1))
+ref_scores=np.concatenate(ref_scores); ref_q=np.concatenate(ref_q)
+runner=load_model_runner(TFLITE_PATH, max_batch=N)
+d=torch.from_numpy(audio).cuda()
+for mode in (2,1,0):
+    with _hip.options(stft_exact=mode):
+        scores=runner.infer_audio_device(d).cpu().numpy()
+        q=runner.input_bytes(N).reshape(N,-1)
+        # ref_q layout? env[qin] shape [B,257,256,1] presumably
+        dq=(q.astype(np.int32)-ref_q.astype(np.int32))
+        bad_chunks=np.nonzero((dq!=0).any(axis=1))[0]
+        print(f"stft_exact={mode}: flipped bytes {(dq!=0).sum()} in chunks {bad_chunks[:10]}, scores equal: {np.array_equal(scores, ref_scores)}, max score diff {np.abs(scores-ref_scores).max():.3e}", flush=True)
+        if mode==2: print("   guard:", runner.guard_stats(N))
+        torch.cuda.synchronize(); t0=time.time()
+        for _ in range(5): runner.infer_audio_device(d)
+        torch.cuda.synchronize(); print(f"   {(time.time()-t0)/5*1e3:.3f} ms per call of {N}")
