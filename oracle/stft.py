@@ -14,6 +14,15 @@ zeros each side), periodic Hann (``scipy.signal.get_window('hann', n, fftbins=Tr
 ``0.5 - 0.5 cos(2 pi k / n)``), frame *t* covers padded samples ``[t*hop, t*hop + n_fft)``,
 ``1 + len(y)//hop`` frames, window*frame and the real FFT evaluated in float64, the
 result stored as complex64, and ``np.abs`` of complex64 returning float32.
+
+``np.abs`` of a complex64 array is not the correctly rounded magnitude: numpy >= 1.25 on x86 with
+FMA3 evaluates ``larger * sqrt(fma(ratio, ratio, 1))`` with ``ratio = smaller / larger`` of
+(|re|, |im|), every step rounded to float32 (``simd_cabsf`` in numpy's
+``loops_unary_complex.dispatch.c.src``).  ``cabs_numpy_simd`` restates that formula; it is **pinned**
+to the installed numpy (tests/test_oracle_pinning.py: identical on 5e6 random complex64 values) and
+is what the GPU's float64 pass reproduces (csrc/bn_quant_in.h: ``numpy_cabsf``).  ``stft_magnitude``
+keeps calling ``np.abs`` itself — on a CPU without FMA3 numpy's result (and the reference's) would
+differ from the restatement in the last bit of ~1e-2 of the values.
 """
 
 from __future__ import annotations
@@ -25,6 +34,19 @@ def hann_periodic(n: int) -> np.ndarray:
     """Periodic Hann window in float64."""
     k = np.arange(n, dtype=np.float64)
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
+
+
+def cabs_numpy_simd(z: np.ndarray) -> np.ndarray:
+    """``np.abs`` of a complex64 array as numpy's SIMD loop evaluates it (x86 + FMA3), restated step by step in float32."""
+    z = np.asarray(z, dtype=np.complex64)
+    re, im = np.abs(z.real), np.abs(z.imag)
+    larger, smaller = np.maximum(re, im), np.minimum(im, re)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(larger == 0, np.float32(0), smaller / larger).astype(np.float32)
+    # fma(ratio, ratio, 1) rounded once to float32: ratio^2 is exact in float64 (48 bits); the sum may round in float64 first, which
+    # could only matter on an exact tie of the second rounding (never seen: the pin test compares with numpy itself)
+    t = (ratio.astype(np.float64) ** 2 + 1.0).astype(np.float32)
+    return (np.sqrt(t) * larger).astype(np.float32)
 
 
 def stft_magnitude(y: np.ndarray, n_fft: int, hop: int) -> np.ndarray:

@@ -275,9 +275,11 @@ def test_i8_from_audio_top1_and_cosine(torch_mod, audio24, oracle_specs):
     runner = load_model_runner(TFLITE_PATH, max_batch=16)
     scores, logits = runner.infer_audio_device(torch.from_numpy(audio24).cuda(), return_logits=True)
     scores, logits = scores.cpu().numpy(), logits.cpu().numpy()
-    for b in range(audio24.shape[0]):
-        assert cosine(logits[b], ref_logits[b]) >= 0.999
-        assert logits[b].argmax() == ref_logits[b].argmax()
+    # bit-exact from audio (float64 pass behind the float32 STFT, csrc/bn_stft_exact.hip): scores, pre-sigmoid outputs, quantised input
+    assert np.array_equal(scores, ref)
+    assert np.array_equal(logits, ref_logits)
+    qin = model.ops[0].outputs[0]
+    assert np.array_equal(runner.input_bytes(audio24.shape[0]).reshape(audio24.shape[0], -1), env[qin].reshape(audio24.shape[0], -1))
     runner.close()
 
 
@@ -440,13 +442,16 @@ def test_evaluate_device_pipeline_matches_reference_loop(torch_mod, tmp_path):
     m_ref, pf_ref, _, ys_ref = evaluate(runner, files, classes, cfg, pooling="lme", batch_size=5, measure_latency=True, device_pipeline=False)
     assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
     assert m_dev["total_chunks"] == m_ref["total_chunks"] == 12 + 4 * 3
-    np.testing.assert_allclose(ys_dev, ys_ref, atol=1.5 / 256)  # host-normalised float spectrograms vs normalise-at-load: <= 1 LSB of the int8 sigmoid
-    # top-1 per file: identical wherever the reference loop's best pooled score leads by more than the 1-LSB tolerance on both sides
-    top = np.sort(ys_ref, axis=1)
-    clear = (top[:, -1] - top[:, -2]) > 3.0 / 256
-    assert (ys_dev.argmax(axis=1) == ys_ref.argmax(axis=1))[clear].all()
+    # Both routes quantise the reference's bytes (the loop through bn_stft_mag_exact, the device pipeline through the float64 pass behind
+    # the float32 STFT), so the chunk scores are identical; the pooled scores differ only by the device's expf / logf in log-mean-exp
+    # (<= 2e-6, tests/test_gpu_ingest.py) and not at all under mean pooling.
+    np.testing.assert_allclose(ys_dev, ys_ref, atol=4e-6, rtol=0)
+    assert (ys_dev.argmax(axis=1) == ys_ref.argmax(axis=1)).all()
     for k in ("latency_mean_ms", "latency_p99_ms"):
         assert m_dev[k] > 0 and m_ref[k] > 0
+    _, _, _, avg_dev = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=5)
+    _, _, _, avg_ref = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=5, device_pipeline=False)
+    assert np.array_equal(avg_dev, avg_ref)
     runner.close()
 
 

@@ -372,3 +372,21 @@ def test_int8_primitives_match_gemmlowp_definitions_on_edge_cases():
             assert got == want, (real, got)
         else:
             assert (1 << 30) <= got[0] < (1 << 31) and abs(got[0] * 2.0 ** (got[1] - 31) - real) <= real * 2.0**-31
+
+
+def test_numpy_cabs_restatement_is_pinned_to_the_installed_numpy():
+    """``oracle.stft.cabs_numpy_simd`` (what csrc/bn_quant_in.h: numpy_cabsf reproduces on the GPU) == ``np.abs`` of complex64 on this
+    machine's numpy, over magnitudes spanning 20 octaves, exact zeros and axis-aligned values; and it is NOT the correctly rounded
+    magnitude, so the restatement cannot be replaced by one."""
+    from oracle.stft import cabs_numpy_simd
+
+    rng = np.random.default_rng(0)
+    n = 5_000_000
+    z = (rng.standard_normal(n) * np.exp(rng.uniform(-10, 10, n)) + 1j * rng.standard_normal(n) * np.exp(rng.uniform(-10, 10, n))).astype(np.complex64)
+    z[:4] = [0, 1, 1j, -3 - 4j]
+    got, want = cabs_numpy_simd(z), np.abs(z)
+    assert want.dtype == np.float32
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} of {n} differ, first {z[bad[0]]}: {got[bad[0]]} vs {want[bad[0]]}"
+    exact = np.sqrt(z.real.astype(np.float64) ** 2 + z.imag.astype(np.float64) ** 2).astype(np.float32)
+    assert 0.2 < (want != exact).mean() < 0.5

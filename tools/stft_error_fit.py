@@ -30,7 +30,7 @@ ctx = _hip.Context(0, N)
 u = 2.0**-24
 edges = [0, 0.25, 0.5, 1, 2, 4, 8, 16, 64]
 tot = np.zeros(len(edges) - 1)
-combos = [(48, 20, 0), (32, 5, 12), (32, 8, 8), (16, 8, 8), (32, 4, 8), (24, 6, 6), (64, 0, 16), (32, 0, 16), (64, 8, 0)]
+combos = [(48, 20, 0), (48, 8, 14), (48, 7, 14), (40, 8, 16), (48, 6, 16), (32, 10, 14), (48, 8, 12), (56, 6, 14), (64, 4, 14), (48, 5, 14), (64, 6, 12)]
 worst = np.zeros(len(combos))
 for name, x in fam.items():
     x = (x / max(np.abs(x).max(), 1e-30)).astype(np.float32)
