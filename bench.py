@@ -17,6 +17,12 @@ already resident in HBM:  windowed STFT magnitude -> hybrid mel mixer -> PWL -> 
   ``[K * 4096, 100]`` buffer (``evaluation/sharding.py: run_sharded`` — the same function ``evaluate`` shards with) and
   the job ends with ONE RCCL all-gather of those scores (12.8 MB per rank at K = 8), inside the timed region.
 
+The timed job (K steps between barrier + device synchronisation on both sides, MAX over ranks) is REPEATED ``--repeats`` R times
+(default 25: more than a second of timed work at the default sizes); ``value`` / ``ms_per_step`` are the MEDIAN repeat, ``value_min`` /
+``value_max`` the slowest / fastest one.  ``--collective`` initialises RCCL even on one GPU and runs the all-gather inside the timed
+region at world size 1 (the collective code path on hardware without a second GPU); without it a one-GPU run still probes RCCL after
+the measurement and reports what it saw under ``collective``.
+
 Every rank keeps ``min(K, 8)`` distinct synthetic batches in HBM (9.4 GB) and walks them round-robin, so no step re-reads a
 cache-warm input.  Rank 0 prints ONE JSON line: the throughput contract fields plus ``roofline`` (dominant kernel — named by
 the fully profiled warm-up steps, then timed with HIP events on the launch stream during the timed region, where it is the
@@ -54,6 +60,8 @@ I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 = 2x bf16
 MOP_PER_CHUNK = 53.08  # 26 539 008 MAC per chunk (mel mixer + backbone), 2 ops per MAC
 STFT_MFLOP_PER_CHUNK = 3.35
 MAX_DISTINCT_BATCHES = 8
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 39.3 T lane-op/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X_MICROARCH.md)
+PWDW_HEAD, PWDW_COVERED = 0x7A110009, 0x7A11000A  # expand 1x1 + depthwise 3x3 of an inverted-residual block as one kernel (csrc/bn_blob.h)
 
 
 def synth_audio_device(torch, batch: int, first_chunk: int, device, seed: int):
@@ -166,6 +174,34 @@ def output_bytes(kind: str, p: list, batch: int, dtype: str):
     return None
 
 
+def digests(dtype: str, batch: int, what: str) -> list[str]:
+    """Committed digests ``profiles/rNN_<dtype>_b<batch>_<what>.json`` of THIS workload, newest round first (the name is matched as a
+    whole: ``r02_config5_f32_b1024_traffic.json`` is another network's digest)."""
+    pat = re.compile(rf"^r(\d+)_{dtype}_b{batch}_{what}\.json$")
+    found = [(int(m.group(1)), q) for q in glob.glob(os.path.join(REPO, "profiles", "*.json")) if (m := pat.match(os.path.basename(q)))]
+    return [q for _, q in sorted(found, reverse=True)]
+
+
+def sq_counters(dom: dict, batch: int, dtype: str) -> dict:
+    """The roof that binds the integer kernels is vector-ALU issue, not the matrix pipe: ``valu_issue_frac`` = VALU lane-ops of one
+    launch (SQ_INSTS_VALU x 64, committed ``rocprofv3 --pmc`` SQ pass of this workload, replayed) / 39.3 T lane-op/s / this run's launch
+    time; ``lds_wait`` = the share of the kernel's wave cycles parked in s_waitcnt / barriers and its LDS bank-conflict cycles per wave
+    from the same pass.  Empty when no digest of the workload names the kernel."""
+    base = kernel_symbol(dom["kernel"], dom["p"])
+    for path in digests(dtype, batch, "sq"):
+        rows = [r for r in json.load(open(path)) if r["kernel"].split("<")[0] == base]
+        if not rows:
+            continue
+        r = max(rows, key=lambda q: q["valu_insts"])  # several instantiations: the heaviest launch is the one bench names dominant
+        out = {"valu_issue_frac": round(r["valu_insts"] * 64 / VALU_PEAK_LANE_OPS / (dom["avg_ms"] * 1e-3), 4),
+               "valu_insts_per_wave": r["valu_insts_per_wave"], "mfma_insts_per_wave": r["mfma_insts_per_wave"],
+               "lds_wait": {"parked_frac": r.get("parked_frac"), "issue_stalled_frac": r.get("issue_stalled_frac"),
+                            "lds_bank_conflict_cycles_per_wave": r.get("lds_conflict_cycles_per_wave"), "lds_insts_per_wave": r.get("lds_insts_per_wave")},
+               "sq_source": "profiles/" + os.path.basename(path) + " (committed rocprofv3 --pmc SQ passes of this workload, replayed)"}
+        return out
+    return {}
+
+
 def pmc_traffic(dom: dict, batch: int, dtype: str):
     """(HBM bytes per launch of the dominant kernel, source file) from the newest committed PMC digest of this workload
     (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
@@ -173,8 +209,7 @@ def pmc_traffic(dom: dict, batch: int, dtype: str):
     the committed profile — ``traffic_source`` names the file — and null when no digest of the same workload (dtype, batch,
     kernel, output size) is on disk."""
     want = output_bytes(dom["kernel"], dom["p"], batch, dtype)
-    paths = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{dtype}_b{batch}_traffic.json")),
-                   key=lambda q: int(re.search(r"r(\d+)_", os.path.basename(q)).group(1)), reverse=True)
+    paths = digests(dtype, batch, "traffic")
     base = kernel_symbol(dom["kernel"], dom["p"])
     for path in paths:
         rows = [row for row in json.load(open(path)) if row["kernel"].split("<")[0] == base]
@@ -208,14 +243,17 @@ def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> t
             nops, mops, symbol, layer = nops + o2, mops + m2, "f32_front2_kernel", r["name"] + " + " + nxt["name"]
         stages.append({"kernel": r["kind"], "symbol": symbol, "layer": layer, "avg_ms": round(avg_ms, 4),
                        "GBps": round(nbytes / avg_ms / 1e6, 1), "hbm_frac": round(nbytes / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
-                       "Tops": round(nops / avg_ms / 1e9, 2), "mfma_frac": round(mops / avg_ms / 1e9 / peak_compute, 4),
+                       "Tops": round(nops / avg_ms / 1e9, 2), "mfma_Tops": round(mops / avg_ms / 1e9, 2),
+                       "mfma_frac": round(mops / avg_ms / 1e9 / peak_compute, 4),
                        "bytes": nbytes, "ops": nops, "p": r["p"], "op": r["op"]})
     picked = [s for s in stages if s["op"] == dom_op]
     dom = picked[0] if picked else max(stages, key=lambda s: s["avg_ms"])
     ridge = peak_compute * 1e12 / (HBM_PEAK_GBS * 1e9)
     intensity = dom["ops"] / max(dom["bytes"], 1.0)
     if intensity > ridge and (dom["kernel"].endswith("pw") or dom["kernel"] == "i8_tail"):
-        roof = {"bound": "mfma", "achieved": dom["Tops"], "peak": peak_compute, "unit": "TFLOP/s" if dtype == "f32" else "TOP/s"}
+        # matrix-core work only (the 1x1 convolutions): depthwise / dense arithmetic runs on the vector ALU and does not count against this roof
+        roof = {"bound": "mfma", "achieved": dom["mfma_Tops"], "peak": peak_compute, "unit": "TFLOP/s" if dtype == "f32" else "TOP/s",
+                "all_ops_Tops": dom["Tops"]}
     else:
         roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
@@ -225,6 +263,7 @@ def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> t
     roof["avg_launch_ms"] = dom["avg_ms"]
     roof["algorithmic_bytes_per_launch"] = dom["bytes"]
     roof["timing"] = "HIP events on the launch stream around this kernel only, averaged over the timed region"
+    roof.update(sq_counters(dom, batch, dtype))
     # the two longest kernels of the INT8 path (STFT, fused tail) are within a few per cent of each other and swap places from run to
     # run: the runner-up is named with its own roof (from the warm-up profile) so that the line reads the same either way
     rest = sorted((s for s in stages if s is not dom), key=lambda s: -s["avg_ms"])
@@ -232,11 +271,24 @@ def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> t
         ru = rest[0]
         ru_mfma = ru["ops"] / max(ru["bytes"], 1.0) > ridge and (ru["kernel"].endswith("pw") or ru["kernel"] == "i8_tail")
         roof["runner_up"] = {"kernel": ru["symbol"], "avg_launch_ms": ru["avg_ms"], "bound": "mfma" if ru_mfma else "hbm",
-                             "frac": round(ru["Tops"] / peak_compute, 4) if ru_mfma else ru["hbm_frac"],
+                             "frac": ru["mfma_frac"] if ru_mfma else ru["hbm_frac"],
                              "timing": "warm-up profile (every operator bracketed by events)"}
     for s in stages:
         s.pop("bytes"), s.pop("ops"), s.pop("p"), s.pop("op")
     return roof, stages
+
+
+def physical_cores() -> int:
+    """Physical cores of this host (``cpu_baseline.cores``; the OpenMP thread count is reported beside it as ``threads``)."""
+    try:
+        import psutil
+
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:  # pragma: no cover
+        pass
+    return os.cpu_count() or 1
 
 
 def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
@@ -281,7 +333,7 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
             fn(x)
             done += 256
         dt = time.perf_counter() - t0
-        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": threads, "kind": "port", "gops": gops(done / dt),
+        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": physical_cores(), "threads": threads, "kind": "port", "gops": gops(done / dt),
                 "sample": f"{done} synthetic 3 s @ 24 kHz chunks, {what}, {threads} threads, {dt:.1f} s"}
 
     if dtype == "f32" and os.path.isfile(cport.CPU_LIB):
@@ -310,64 +362,106 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
         per = work(chunks(16)) / 16
         n = int(max(64, min(4096, seconds_budget / per // 64 * 64)))
         dt = work(chunks(n))
-    return {"value": round(n / dt, 2), "unit": "chunks/s", "cores": 1, "kind": "port", "gops": gops(n / dt),
+    return {"value": round(n / dt, 2), "unit": "chunks/s", "cores": 1, "threads": 1, "kind": "port", "gops": gops(n / dt),
             "sample": f"{n} synthetic 3 s @ 24 kHz chunks, numpy oracle (oracle/stft.py + "
                       f"{'float_graph' if dtype == 'f32' else 'int8_graph'}.py), 1 thread, {dt:.1f} s"}
 
 
+def side_measure(torch, runner, audio, dtype: str, batch: int, device, steps: int = 10, repeats: int = 5, hop=None) -> dict:
+    """Whole-path throughput of another configuration on this GPU (input resident in HBM), reported beside the main measurement:
+    two warm-up steps, one step with every operator bracketed by HIP events (names the dominant operator and gives its time), then
+    ``repeats`` x ``steps`` timed steps between device synchronisations (median repeat)."""
+    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
+    kw = {"hop": hop} if hop else {}
+    for _ in range(2):
+        runner.infer_audio_device(audio, out=scores, **kw)
+    torch.cuda.synchronize(device)
+    runner.profile(True)
+    runner.infer_audio_device(audio, out=scores, **kw)
+    torch.cuda.synchronize(device)
+    rows = runner.profile_collect()
+    runner.profile(False)
+    times = []
+    for _ in range(repeats):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.infer_audio_device(audio, out=scores, **kw)
+        torch.cuda.synchronize(device)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    finite = bool(torch.isfinite(scores).all().item())
+    return {"dtype": dtype, "batch_per_gpu": batch, "value": round(batch * steps / dt, 1), "unit": "chunks/s", "steps": steps, "repeats": repeats,
+            "ms_per_step": round(dt / steps * 1e3, 4), "scores_finite": finite, "_rows": rows}
+
+
 def quick_rate(torch, dtype: str, batch: int, device, local_rank: int, steps: int = 10) -> dict:
-    """Whole-path throughput of another BASELINE configuration on this GPU (same synthetic audio, resident in HBM), reported
-    beside the main measurement: two warm-up steps, then `steps` timed steps between device synchronisations."""
+    """The other single-GPU BASELINE configuration of the shipped network, with the roofline of ITS dominant kernel."""
     from birdnet_stm32.models.runners import load_model_runner
 
     ckpt = os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100" + (".keras" if dtype == "f32" else ".tflite"))
     runner = load_model_runner(ckpt, device=local_rank, max_batch=batch)
     audio = synth_audio_device(torch, batch, 0, device, 42)
-    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
-    for _ in range(2):
-        runner.infer_audio_device(audio, hop=HOP, out=scores)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.infer_audio_device(audio, hop=HOP, out=scores)
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
+    out = side_measure(torch, runner, audio, dtype, batch, device, steps, hop=HOP)
     runner.close()
-    del audio, scores
-    return {"workload": ("birdnet_stm32n6_100 float32 DS-CNN" if dtype == "f32" else "birdnet_stm32n6_100 INT8 DS-CNN") + ", hybrid+pwl frontend",
-            "dtype": dtype, "batch_per_gpu": batch, "value": round(batch * steps / dt, 1), "unit": "chunks/s", "steps": steps,
-            "ms_per_step": round(dt / steps * 1e3, 4)}
+    roof, _ = roofline_of(out.pop("_rows"), batch, dtype)
+    roof["timing"] = "one profiled step (every operator bracketed by HIP events)"
+    out["workload"] = ("birdnet_stm32n6_100 float32 DS-CNN" if dtype == "f32" else "birdnet_stm32n6_100 INT8 DS-CNN") + ", hybrid+pwl frontend"
+    out["roofline"] = roof
+    return out
 
 
-def config4_rate(torch, device, local_rank: int, batch: int = 1024, steps: int = 10) -> dict:
+C4_PW_MAC, C4_MMAC = 191_889_408, 200.8  # SURVEY.md §8d: configs[4] pointwise multiply-accumulates / all MACs per chunk
+
+
+def config4_rate(torch, device, local_rank: int, seconds: int = 2, int8: bool = False, batch: int = 1024, steps: int = 10) -> dict:
     """BASELINE configs[4] on this GPU, beside the main measurement: raw-waveform learned filterbank + PCEN + alpha = 1.5 DS-CNN with
-    squeeze-excite and inverted residuals, seeded random weights (there is no checkpoint of it), 2 s @ 24 kHz chunks (the geometry the
-    reference's raw frontend builds at), float32 — one step = per-chunk peak normalisation + the whole plan over ``batch`` waveform chunks
-    resident in HBM.  The N-GPU form of the config is the same plan on every rank over its own chunks (no collective until the scores)."""
+    squeeze-excite and inverted residuals, seeded random weights (there is no checkpoint of it).  ``seconds`` = 2: the geometry the
+    reference's raw frontend builds at (its T < 65536 guard, models/dscnn.py:144-151); 3: the metric's chunk length, with the guard lifted
+    (``raw_length_limit=None``).  float32, or INT8 through this build's own exporter.  One step = per-chunk peak normalisation + the
+    whole plan over ``batch`` waveform chunks resident in HBM.  The roofline is the whole step's: all 1x1-convolution work (95.6 % of the
+    network's MACs) against the dense matrix-core peak of the dtype, plus the slowest operator of one profiled step.  The N-GPU form of
+    the config is the same plan on every rank over its own chunks (no collective until the scores)."""
     from birdnet_stm32.models import build_model
-    from birdnet_stm32.models._lower_f32 import lower_f32
     from birdnet_stm32.models.runners import HipRunner
 
-    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
-                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
-    runner = HipRunner(lower_f32(spec), device=local_rank, max_batch=batch)
+    T4 = 24000 * seconds
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=seconds, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42,
+                       **({"raw_length_limit": None} if seconds != 2 else {}))
+    if int8:
+        from birdnet_stm32.conversion.export import convert_netspec_to_int8
+        from birdnet_stm32.models._lower_i8 import lower_i8
+        from birdnet_stm32.models._tflite_reader import parse_tflite
+        from birdnet_stm32.models._tflite_writer import write_tflite
+
+        rng = np.random.default_rng(0)
+        cal = [rng.standard_normal((1, T4, 1)).astype(np.float32) for _ in range(8)]
+        cal = [c / (np.abs(c).max() + 1e-6) for c in cal]
+        plan = lower_i8(parse_tflite(write_tflite(convert_netspec_to_int8(spec, lambda: ([c] for c in cal)))))
+    else:
+        from birdnet_stm32.models._lower_f32 import lower_f32
+
+        plan = lower_f32(spec)
+    runner = HipRunner(plan, device=local_rank, max_batch=batch)
     g = torch.Generator(device=device).manual_seed(4)
-    x = torch.randn((batch, 48000), device=device, generator=g)
-    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
-    for _ in range(2):
-        runner.infer_audio_device(x, out=scores)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.infer_audio_device(x, out=scores)
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    finite = bool(torch.isfinite(scores).all().item())
+    x = torch.randn((batch, T4), device=device, generator=g)
+    dtype = "i8" if int8 else "f32"
+    out = side_measure(torch, runner, x, dtype, batch, device, steps)
     runner.close()
-    del x, scores
-    return {"workload": "BASELINE configs[4] topology: raw frontend + PCEN + alpha=1.5 IR/SE DS-CNN, seeded random weights, 2 s @ 24 kHz", "dtype": "f32",
-            "batch_per_gpu": batch, "value": round(batch * steps / dt, 1), "unit": "chunks/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-            "MMAC_per_chunk": 200.8, "TFLOP_per_s": round(2 * 200.8e6 * batch * steps / dt / 1e12, 1), "scores_finite": finite}
+    rows = [r for r in out.pop("_rows") if r["launches"]]
+    slow = max(rows, key=lambda r: r["ms"])
+    peak = I8_MFMA_PEAK_TOPS if int8 else F32_MFMA_PEAK_TFLOPS
+    rate = 2.0 * C4_PW_MAC * batch / (out["ms_per_step"] * 1e-3) / 1e12
+    out.update({"workload": f"BASELINE configs[4] topology: raw frontend + PCEN + alpha=1.5 IR/SE DS-CNN, seeded random weights, {seconds} s @ 24 kHz"
+                            + (", INT8 (own PTQ exporter)" if int8 else ""),
+                "MMAC_per_chunk": C4_MMAC, ("TOP_per_s" if int8 else "TFLOP_per_s"): round(2 * C4_MMAC * 1e6 * batch / (out["ms_per_step"] * 1e-3) / 1e12, 1),
+                "roofline": {"bound": "mfma", "achieved": round(rate, 2), "peak": peak, "unit": "TOP/s" if int8 else "TFLOP/s", "frac": round(rate / peak, 4),
+                             "scope": "whole step: the 1x1 convolutions' 2 x 191.9 MMAC per chunk / step time (the network has no single dominant kernel)",
+                             "slowest_operator": {"kind": slow["kind"], "layer": slow["name"], "ms": round(slow["ms"], 4),
+                                                  "share_of_step": round(slow["ms"] / out["ms_per_step"], 3)},
+                             "timing": "wall clock between device synchronisations; slowest operator from one profiled step"}})
+    return out
 
 
 def timed_job(score_batch, steps: int, batch: int, n_classes: int, device, barrier, sync):
@@ -418,18 +512,40 @@ def self_launch(args, argv: list[str]) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def collective_block(torch, dist, device, rows: int, n_classes: int, reps: int = 5) -> dict:
+    """What RCCL saw: backend, ranks, library version, and the all-gather of ``[rows, n_classes]`` float32 per rank on its own
+    (one warm-up, then ``reps`` timed calls between device synchronisations + barriers; MAX over ranks is not taken: rank 0's clock)."""
+    world = dist.get_world_size()
+    local = torch.zeros((rows, n_classes), dtype=torch.float32, device=device)
+    out = torch.empty((world * rows, n_classes), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, local)
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(out, local)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / reps
+    ver = torch.cuda.nccl.version()
+    return {"backend": dist.get_backend(), "ranks_seen": world, "nccl_version": ".".join(str(v) for v in ver) if isinstance(ver, tuple) else str(ver),
+            "all_gather_ms": round(dt * 1e3, 4), "bytes_per_rank": rows * n_classes * 4, "op": "all_gather_into_tensor"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 20 on one GPU, 8 = BASELINE configs[3] on several)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps per repeat (default 20 on one GPU, 8 = BASELINE configs[3] on several)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=25, help="how often the timed job of --steps steps is repeated (value = the median repeat)")
     ap.add_argument("--dtype", choices=["f32", "i8"], default="i8")
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (default 4096 i8, 1024 f32)")
+    ap.add_argument("--collective", action="store_true", help="initialise RCCL even on one GPU and run the all-gather inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
     steps = args.steps or (20 if args.gpus == 1 else 8)
+    repeats = max(1, args.repeats)
 
     import torch
     import torch.distributed as dist
@@ -443,9 +559,24 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+
+    def init_rccl():
+        import socket
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    use_dist = world > 1 or args.collective
+    if use_dist:
+        init_rccl()
+        if world == 1:  # run the collective at world size 1 instead of returning the local tensor (evaluation/sharding.py)
+            from birdnet_stm32.evaluation import sharding
+
+            sharding.COLLECTIVE_AT_WORLD_1 = True
 
     from birdnet_stm32.models.runners import load_model_runner
 
@@ -458,7 +589,7 @@ def main() -> None:
     scratch = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # Warm-up steps carry an event pair around EVERY operator: they give the per-stage table and name the dominant kernel.
@@ -469,7 +600,7 @@ def main() -> None:
             torch.cuda.synchronize(device)
             runner.profile_collect()
         runner.infer_audio_device(pool[w % n_distinct], hop=HOP, out=scratch)
-    if world > 1:  # warm the RCCL communicator (and its buffers for this message size) outside the timed region
+    if use_dist:  # warm the RCCL communicator (and its buffers for this message size) outside the timed region
         warm = torch.empty((world * steps * batch, runner.num_classes), dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(warm, warm[rank * steps * batch : (rank + 1) * steps * batch].clone())
         del warm
@@ -478,9 +609,14 @@ def main() -> None:
     dom_op = max((r for r in warm_rows if r["launches"]), key=lambda r: r["ms"] / r["launches"])["op"] if args.warmup else -1
     runner.profile_only(dom_op)
 
-    elapsed, gathered = timed_job(lambda k, out: runner.infer_audio_device(pool[k % n_distinct], hop=HOP, out=out), steps, batch,
-                                  runner.num_classes, device, barrier, lambda: torch.cuda.synchronize(device))
-    assert gathered.shape == (world * steps * batch, runner.num_classes)
+    elapsed_all, finite = [], True
+    for _ in range(repeats):
+        elapsed, gathered = timed_job(lambda k, out: runner.infer_audio_device(pool[k % n_distinct], hop=HOP, out=out), steps, batch,
+                                      runner.num_classes, device, barrier, lambda: torch.cuda.synchronize(device))
+        assert gathered.shape == (world * steps * batch, runner.num_classes)
+        elapsed_all.append(elapsed)
+    finite = bool(torch.isfinite(gathered).all().item())
+    del gathered
     runner.profile(False)
     rows = runner.profile_collect()
     runner.profile_only(-1)
@@ -488,12 +624,12 @@ def main() -> None:
         timed = {r["op"]: r for r in rows if r["launches"]}
         rows = [timed.get(r["op"], r) if r["op"] == dom_op else r for r in warm_rows]
 
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:  # every repeat's time is the MAX over the ranks
+        tt = torch.tensor(elapsed_all, dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    finite = bool(torch.isfinite(gathered).all().item())
-    del gathered
+        elapsed_all = [float(v) for v in tt.cpu()]
+    elapsed = float(np.median(elapsed_all))
+    coll = collective_block(torch, dist, device, steps * batch, runner.num_classes) if use_dist else None
 
     if rank == 0:
         roof, stages = roofline_of(rows, batch, args.dtype, dom_op)
@@ -501,6 +637,8 @@ def main() -> None:
         name = "birdnet_stm32n6_100 " + ("float32" if args.dtype == "f32" else "INT8") + " DS-CNN, hybrid+pwl frontend"
         if world > 1:
             name += f": {total_chunks} synthetic chunks sharded over {world} GPUs (BASELINE configs[3] is 262144 over 8), one RCCL all-gather of the scores"
+        gather_note = (f" -> ONE RCCL all-gather of [{steps * batch}, {runner.num_classes}] f32 per rank "
+                       f"({steps * batch * runner.num_classes * 4 / 1e6:.1f} MB), inside the timed region" if use_dist else "")
         out = {
             "metric": "audio chunks/sec (3 s @ 24 kHz)",
             "value": round(total_chunks / elapsed, 1),
@@ -514,16 +652,20 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (peak-normalised tone + gaussian noise, generated on device); shipped birdnet_stm32n6_100 weights",
+            "repeats": repeats,
+            "value_min": round(total_chunks / max(elapsed_all), 1),
+            "value_max": round(total_chunks / min(elapsed_all), 1),
+            "timed_s_total": round(sum(elapsed_all), 3),
+            "timed_region": f"{repeats} repeats of {steps} steps, each between barrier + device synchronisation (MAX over ranks); value = the median repeat",
             "config": {
                 "workload": name,
                 "batch_per_gpu": batch,
                 "global_batch": world * batch,
                 "chunks_total": total_chunks,
                 "chunk": "3 s @ 24 kHz (72000 samples), n_fft 512, hop 281, 257x256 spectrogram",
-                "path": "audio in HBM -> STFT -> mel+PWL -> DS-CNN -> scores in HBM" + (
-                    f" -> ONE RCCL all-gather of [{steps * batch}, {runner.num_classes}] f32 per rank "
-                    f"({steps * batch * runner.num_classes * 4 / 1e6:.1f} MB), inside the timed region" if world > 1 else ""),
+                "path": "audio in HBM -> STFT -> mel+PWL -> DS-CNN -> scores in HBM" + gather_note,
                 "distinct_input_batches_per_gpu": n_distinct,
+                "int8_input_bytes": "identical to the reference's float64 STFT (float64 pass behind the float32 STFT, inside the timed region)" if args.dtype == "i8" else None,
             },
             "scores_finite": finite,
             "whole_path_mfma_frac": round(total_chunks / world * MOP_PER_CHUNK * 1e6 / elapsed / 1e12 /
@@ -531,21 +673,33 @@ def main() -> None:
             "roofline": roof,
             "stages": stages,
         }
-        if world == 1 and not args.batch:  # the other single-GPU BASELINE configuration, for reference (not the reported value)
+        if coll is not None:
+            coll["in_timed_region"] = True
+            out["collective"] = coll
+        if world == 1 and not args.batch:  # the other single-GPU BASELINE configurations, for reference (not the reported value)
             runner.close()
             runner = None
             del pool
             torch.cuda.empty_cache()
             other = "i8" if args.dtype == "f32" else "f32"
             out["also_measured"] = quick_rate(torch, other, 4096 if other == "i8" else 1024, device, local_rank)
-            try:  # a second reported extra: a failure here must not cost the main line
-                out["also_measured_configs4"] = config4_rate(torch, device, local_rank)
+            for key, kw in (("also_measured_configs4", {}), ("also_measured_configs4_3s", {"seconds": 3}), ("also_measured_configs4_int8", {"int8": True})):
+                try:  # reported extras: a failure here must not cost the main line
+                    out[key] = config4_rate(torch, device, local_rank, **kw)
+                except Exception as e:  # noqa: BLE001
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not use_dist:
+            # one GPU, no collective in the path: still show that RCCL comes up on this box and moves the score tensor (outside the timed region)
+            try:
+                init_rccl()
+                out["collective"] = dict(collective_block(torch, dist, device, steps * batch, 100), in_timed_region=False,
+                                         note="probe behind the measurement; `--collective` puts the all-gather inside the timed region")
             except Exception as e:  # noqa: BLE001
-                out["also_measured_configs4"] = {"error": f"{type(e).__name__}: {e}"}
+                out["collective"] = {"backend": None, "ranks_seen": 1, "error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.dtype)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     if runner is not None:
         runner.close()

@@ -14,6 +14,16 @@ in contiguous blocks, the chunk scores of all files meet in one all-gather, pool
 
 from __future__ import annotations
 
+# With a process group of ONE rank the gathers below return the local tensor.  Set to True (bench.py --collective, the GPU test of the
+# RCCL path) to run the collective anyway: the same calls as on 8 GPUs, executed on hardware that has a single one.
+COLLECTIVE_AT_WORLD_1 = False
+
+
+def _local_only(world: int) -> bool:
+    import torch.distributed as dist
+
+    return world == 1 and not (COLLECTIVE_AT_WORLD_1 and dist.is_available() and dist.is_initialized())
+
 
 def world_info(group=None) -> tuple[int, int]:
     """(rank, world size) of the initialised process group, (0, 1) without one."""
@@ -39,9 +49,9 @@ def all_gather_scores(local_scores, n_items: int, group=None):
     import torch.distributed as dist
 
     rank, world = world_info(group)
-    if world == 1:
-        if local_scores.shape[0] != n_items:
-            raise ValueError("single-process call must hold all items")
+    if world == 1 and local_scores.shape[0] != n_items:
+        raise ValueError("single-process call must hold all items")
+    if _local_only(world):
         return local_scores
     lo, hi = shard_bounds(n_items, rank, world)
     if local_scores.shape[0] != hi - lo:
@@ -98,7 +108,7 @@ def all_gather_ragged(local, group=None):
     import torch.distributed as dist
 
     rank, world = world_info(group)
-    if world == 1:
+    if _local_only(world):
         return local, [int(local.shape[0])]
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = torch.empty(world, dtype=torch.int64, device=local.device)
@@ -133,7 +143,7 @@ def score_files_sharded(n_files: int, score_files_fn, width: int, device=None, g
         scores, per_file = torch.empty((0, width), dtype=torch.float32, device=device), []
     if len(per_file) != hi - lo or scores.shape[0] != sum(per_file):
         raise ValueError("score_files_fn must return one chunk count per file and as many rows as chunks")
-    if world == 1:
+    if _local_only(world):
         return scores, list(per_file)
     all_scores, _ = all_gather_ragged(scores, group=group)
     longest = -(-n_files // world)

@@ -211,8 +211,9 @@ class HipRunner:
         _hip.check(self.lib.bn_profile_only(self.model.handle, int(op_index)))
 
     def profile_collect(self) -> list[dict]:
-        """Elapsed time per plan operator since the last collect; the extra last entry is the STFT stage."""
-        n = len(self.plan.ops) + 1
+        """Elapsed time per plan operator since the last collect; behind the operators: the STFT stage and (INT8 plans from audio)
+        the two float64 passes of the exactness pass (csrc/bn_stft_exact.hip)."""
+        n = len(self.plan.ops) + 3
         ms = (ctypes.c_double * n)()
         cnt = (ctypes.c_int64 * n)()
         _hip.check(self.lib.bn_profile_collect(self.model.handle, ms, cnt, n))
@@ -222,7 +223,8 @@ class HipRunner:
                 op = self.plan.ops[i]
                 rows.append({"op": i, "kind": pk.KIND_NAMES[op.kind], "name": op.name, "ms": ms[i], "launches": int(cnt[i]), "p": list(op.p)})
             else:
-                rows.append({"op": i, "kind": "stft512", "name": "stft", "ms": ms[i], "launches": int(cnt[i]), "p": []})
+                kind, name = (("stft512", "stft"), ("stft_minmax_exact", "exact min/max"), ("stft_fix", "float64 pass + redo"))[i - len(self.plan.ops)]
+                rows.append({"op": i, "kind": kind, "name": name, "ms": ms[i], "launches": int(cnt[i]), "p": []})
         return rows
 
     def close(self):

@@ -161,9 +161,11 @@ struct ProfScope {
         (void)hipEventRecord(start, s);
         m->ev_used.push_back({op, start, stop});
     }
-    ~ProfScope() {
+    void end() {
         if (stop) (void)hipEventRecord(stop, s);
+        stop = nullptr;
     }
+    ~ProfScope() { end(); }
 };
 
 // The exactness pass's buffers for the chunks from b0 on (the work list is shared: one launch group at a time uses it).
@@ -480,6 +482,8 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                         a.qguard = guard_slice(m, slot_b0);
                         a.qmode = 1;
                         bn::launch_i8_dwpw(a, s);
+                        prof.end();  // (the operator's own launch; the float64 pass has its own profiling entry)
+                        ProfScope fix(m, (int)m->ops.size() + 2, s);
                         bn::launch_stft_fix(m->ctx->tables, m->guard_audio, B, m->guard_T, m->guard_hop, a.W, (float*)in0, true, a.qguard, mm, a.qscale,
                                             a.qzp, s);
                         a.qmode = 2;
@@ -1062,21 +1066,24 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     // slower / no gain)
     m->spec_tiled_now = tiled;
     int rc = BN_OK;
-    {
-        ProfScope prof(m, (int)m->ops.size(), s);
-        if (guarded) {
-            if (T <= 0 || hop <= 0 || 1 + T / hop < W) rc = fail(BN_ERR_ARG, "T=%d hop=%d gives %d frames, fewer than spec_width=%d", T, hop, hop > 0 ? 1 + T / hop : 0, W);
-            for (int b0 = 0; rc == BN_OK && b0 < B; b0 += kMaxGridBatch) {
-                const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
-                bn::StftGuard g = guard_slice(m, (size_t)b0);
+    if (guarded) {
+        // profiling entries: n_ops = the float32 STFT kernel, n_ops + 1 = exact min / max, n_ops + 2 = the float64 pass behind the first operator
+        if (T <= 0 || hop <= 0 || 1 + T / hop < W) rc = fail(BN_ERR_ARG, "T=%d hop=%d gives %d frames, fewer than spec_width=%d", T, hop, hop > 0 ? 1 + T / hop : 0, W);
+        for (int b0 = 0; rc == BN_OK && b0 < B; b0 += kMaxGridBatch) {
+            const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
+            bn::StftGuard g = guard_slice(m, (size_t)b0);
+            {
+                ProfScope prof(m, (int)m->ops.size(), s);
                 bn::launch_stft512(m->ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, m->d_spec + b0 * in_stride, m->d_minmax + 2 * (size_t)b0, s,
                                    true, &g);
-                bn::launch_stft_minmax_exact(m->ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, m->d_spec + b0 * in_stride, true, g,
-                                             m->d_minmax + 2 * (size_t)b0, s);
             }
-        } else {
-            rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, tiled, exact_opt != 0);
+            ProfScope prof(m, (int)m->ops.size() + 1, s);
+            bn::launch_stft_minmax_exact(m->ctx->tables, d_audio + (size_t)b0 * T, nb, T, hop, W, m->d_spec + b0 * in_stride, true, g,
+                                         m->d_minmax + 2 * (size_t)b0, s);
         }
+    } else {
+        ProfScope prof(m, (int)m->ops.size(), s);
+        rc = stft_mag_impl(m->ctx, d_audio, B, T, kFft, hop, W, /*normalize=*/0, m->d_spec, m->d_minmax, stream, tiled, exact_opt != 0);
     }
     if (rc == BN_OK) {
         for (int b0 = 0; b0 < B; b0 += kMaxGridBatch) {
@@ -1250,7 +1257,7 @@ int bn_profile_enable(bn_model* m, int enable) {
 
 int bn_profile_only(bn_model* m, int op_index) {
     if (!m) return fail(BN_ERR_ARG, "null model");
-    if (op_index < -1 || op_index > (int)m->ops.size()) return fail(BN_ERR_ARG, "op_index %d out of range", op_index);
+    if (op_index < -1 || op_index > (int)m->ops.size() + 2) return fail(BN_ERR_ARG, "op_index %d out of range", op_index);
     m->prof_only = op_index;
     return BN_OK;
 }
@@ -1267,8 +1274,9 @@ int bn_profile_collect(bn_model* m, double* total_ms, int64_t* launches, int n) 
         HIP_TRY(hipEventSynchronize(r.stop));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
-        total_ms[r.op] += ms;
-        launches[r.op] += 1;
+        const int slot = r.op < n ? r.op : (int)m->ops.size();  // a caller without room for the exactness-pass entries gets them under the STFT stage
+        total_ms[slot] += ms;
+        launches[slot] += 1;
         m->ev_free.push_back(r.start);
         m->ev_free.push_back(r.stop);
     }
