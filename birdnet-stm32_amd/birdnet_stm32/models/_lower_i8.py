@@ -364,8 +364,8 @@ def tail_constants(blocks: list[dict], head: dict):
         luts, add_m, add_c1, add_e, add_lo, add_hi = None, 0, 0, 1, 0, 0
         if add[0]:
             _, z1, m1, s1, m2, s2, mo, so, zo, amin, amax = add
-            if mo < 0 or so >= 0 or -so > STRIP_MAX_SHIFT:
-                return None
+            if mo < 0 or so >= 0 or -so > STRIP_MAX_SHIFT or amin < zo:
+                return None  # (amin >= zo: the kernel's rescale of the sum drops the sign term of the rounding shift like the other stages)
             res = np.arange(256).astype(np.uint8).view(np.int8).astype(np.int64)
             own = np.arange(256, dtype=np.int64) - 128
             sa = qz.requantize((res - z1) << 20, m1, s1)

@@ -168,6 +168,10 @@ struct ProfScope {
     ~ProfScope() { end(); }
 };
 
+// A fused kernel runs its head operator and the partner(s) the packer tagged as ONE launch: only when both belong to the same entry path
+// (a partner of the other path would be skipped by the operator loop on its own, or run without its head: separate launches then).
+inline bool same_path(const OpRec& head, const OpRec& partner) { return head.p[BN_OP_PATH] == partner.p[BN_OP_PATH]; }
+
 // The exactness pass's buffers for the chunks from b0 on (the work list is shared: one launch group at a time uses it).
 bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
     bn::StftGuard g = m->guard;
@@ -303,7 +307,8 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     const OpRec& e = m->ops[oi + 1];
                     const OpRec& d = m->ops[oi + 2];
                     const int* q = d.p;
-                    if (e.kind == BN_OP_F32_DWPW && e.p[BN_OP_TAIL_TAG] == BN_PWDW_HEAD && d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED &&
+                    if (same_path(o, e) && same_path(o, d) &&
+                        e.kind == BN_OP_F32_DWPW && e.p[BN_OP_TAIL_TAG] == BN_PWDW_HEAD && d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED &&
                         e.in0 == o.out && d.in0 == e.out && d.out != o.in0 && d.out != o.out && d.out != e.out && e.p[0] == p[6] && e.p[1] == p[7] &&
                         e.p[2] == p[2]) {
                         const bn::DwPwArgs ea = dwpw_args(e);
@@ -352,7 +357,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     // inverted-residual block: the expand convolution runs inside the depthwise kernel behind it (the expanded map stays in LDS)
                     const OpRec& d = m->ops[oi + 1];
                     const int* q = d.p;
-                    if (d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out &&
+                    if (same_path(o, d) && d.kind == BN_OP_F32_DW && q[BN_OP_TAIL_TAG] == BN_PWDW_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out &&
                         bn::f32_pwdw_supported(a, q[0], q[1], q[2], q[3], q[4], q[6], q[7]) &&
                         bn::launch_f32_pwdw(a, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7], q[8],
                                             q[9], q[5], nullptr, gap_target(oi + 1), s)) {
@@ -374,7 +379,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     p[BN_OP_FRONT2_DIST] > 0 && oi + (size_t)p[BN_OP_FRONT2_DIST] < op_end) {
                     // front block + the residual block behind it as one kernel: the 32-channel map between them stays in LDS
                     const OpRec& d = m->ops[oi + (size_t)p[BN_OP_FRONT2_DIST]];
-                    if (d.kind == BN_OP_F32_DWPW && d.p[BN_OP_TAIL_TAG] == BN_FRONT2_COVERED && d.in0 == o.out && d.out != o.in0) {  // (never in place)
+                    if (same_path(o, d) && d.kind == BN_OP_F32_DWPW && d.p[BN_OP_TAIL_TAG] == BN_FRONT2_COVERED && d.in0 == o.out && d.out != o.in0) {  // (never in place)
                         const bn::F32FrontStripArgs f{(const float*)in0, nullptr,
                                                       (const float*)m->tensor(o.t[0]), (const float*)m->tensor(o.t[1]),
                                                       (const float*)m->tensor(o.t[2]), (const float*)m->tensor(o.t[3]),
@@ -456,7 +461,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                     // inverted-residual block of an exported graph: expand convolution + depthwise stage as one kernel (the expanded map stays in LDS)
                     const OpRec& d = m->ops[oi + 1];
                     const int* q = d.p;
-                    if (d.kind == BN_OP_I8_DW && q[BN_OP_TAIL_TAG] == BN_PWDW8_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out) {
+                    if (same_path(o, d) && d.kind == BN_OP_I8_DW && q[BN_OP_TAIL_TAG] == BN_PWDW8_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.out) {
                         const bn::I8ConvGeom g{q[0], q[1], q[2], q[3], q[4], q[6], q[7], q[8], q[9], q[10], q[11], q[12], q[13]};
                         if (bn::i8_pwdw_supported(a, g) &&
                             bn::launch_i8_pwdw(a, g, (const int8_t*)m->tensor(d.t[0]), (const int32_t*)m->tensor(d.t[1]), (const int32_t*)m->tensor(d.t[2]),
@@ -544,7 +549,8 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 if (p[BN_OP_TAIL_TAG] == BN_SEGATE_HEAD && bn::g_opt.i8_strip && oi + 2 < op_end) {
                     const OpRec& f1 = m->ops[oi + 1];
                     const OpRec& f2 = m->ops[oi + 2];
-                    if (f1.kind == BN_OP_I8_FC && f2.kind == BN_OP_I8_FC && f1.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED && f2.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED &&
+                    if (same_path(o, f1) && same_path(o, f2) &&
+                        f1.kind == BN_OP_I8_FC && f2.kind == BN_OP_I8_FC && f1.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED && f2.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED &&
                         f1.in0 == o.out && f2.in0 == f1.out && f1.p[0] == p[1] && f2.p[0] == f1.p[1] && f2.p[1] == p[1] && p[1] % 4 == 0 && f2.out != o.in0) {
                         bn::launch_i8_segate((const int8_t*)in0, (int8_t*)slot_ptr(f2.out), B, p[0], p[1], p[2], p[3], p[4], p[5], f1.p[1], f1.p[2], f1.p[3], f1.p[4],
                                              (const int8_t*)m->tensor(f1.t[0]), (const int32_t*)m->tensor(f1.t[1]), (const int32_t*)m->tensor(f1.t[2]),
@@ -568,7 +574,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 if (p[BN_OP_TAIL_TAG] == BN_SCALE_HEAD && bn::g_opt.i8_strip && oi + 1 < op_end) {
                     // the projection convolution behind the gate applies it while loading (the scaled map is never written)
                     const OpRec& d = m->ops[oi + 1];
-                    if (d.kind == BN_OP_I8_DWPW && d.p[BN_OP_TAIL_TAG] == BN_SCALE_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.in1 &&
+                    if (same_path(o, d) && d.kind == BN_OP_I8_DWPW && d.p[BN_OP_TAIL_TAG] == BN_SCALE_COVERED && d.in0 == o.out && d.out != o.in0 && d.out != o.in1 &&
                         d.p[2] == p[1] && d.p[6] * d.p[7] == p[0]) {
                         bn::DwPw8Args a2 = dwpw8_args(d, oi + 1);
                         a2.x = (const int8_t*)in0;

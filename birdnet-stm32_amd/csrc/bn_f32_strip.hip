@@ -666,8 +666,10 @@ struct DwStreamArgs {
     float* gap_part;    // optional: [B][strips_x * row blocks][C] channel sums of every wave's strip, for the squeeze-excite gate behind the stage
 };
 
+// (stride 2 keeps two windows of taps: at the 128 registers of four waves per SIMD it spilled 14 of them — 48 B of scratch per lane —,
+// so that instantiation is built for three waves per SIMD)
 template <int S>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f32_dw_stream_kernel(DwStreamArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 2 ? 3 : 4))) void f32_dw_stream_kernel(DwStreamArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

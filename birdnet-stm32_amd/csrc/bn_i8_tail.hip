@@ -99,7 +99,10 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
     constexpr int NGRP = TILES >= kTailWaves ? 1 : kTailWaves / TILES;  // few tiles: split them over groups of output channels
     constexpr int NT_PER = NTILES / NGRP;
     constexpr int PT = S == 1 ? 1 : 0, PL = PT;  // TF SAME padding of a 3x3 window on even maps: 1 / 1 at stride 1, 0 / 1 at stride 2
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // everything derived from the thread id is recomputed per block: hoisted to the top of the kernel (64-bit
+                                   // staging pointers, tap bases) it stayed live across all blocks and two registers spilled at the 128 cap
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
 
@@ -135,6 +138,8 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
     const int* lut = reinterpret_cast<const int*>(lds + L.lut_off);
     const v4i* wl = reinterpret_cast<const v4i*>(lds + L.w_off) + lane;
     const int dw_lo = L.dw_lo, dw_hi = L.dw_hi, pw_lo = L.pw_lo, pw_hi = L.pw_hi;
+    const int add_m = L.add_m, add_e1 = L.add_e - 1;
+    const long add_c = rq64(L.add_c1);
 
     // A wave takes UPW tiles at a time (two when every wave has two): the depthwise / pointwise constants and the A operands are
     // read from LDS once for both (the LDS pipe is the second-busiest unit of this kernel after the vector ALU).
@@ -161,7 +166,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
                     if constexpr (SRCG) {
                         taddr[t][dy * 3 + dx] = ok ? (iy * W + ix) * CIN + 4 * qb : 0;
                         okmask |= ok ? 1u << (dy * 3 + dx) : 0u;
-                    } else {
+                    } else if constexpr (!(UPW == 2 && S == 1 && OW == 16)) {  // (the shared-row form below has its own twelve addresses)
                         taddr[t][dy * 3 + dx] = (ok ? L.x_off + ((g * H + iy) * W + ix) * PIN : L.zp_off) + 4 * qb;
                     }
                 }
@@ -174,6 +179,23 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 
         // ---- depthwise 3x3 for all CIN channels of this lane's position(s) -> B fragments -------------------------------------
         v4i bf[UPW][KS];
+        // Two tiles of a wave at stride 1 on a 16-wide map are two vertically adjacent output rows of one chunk (u0 is even, a chunk has
+        // an even number of rows): they share two of their three input rows.  Four rows of taps are read and byte-transposed once for
+        // both (12 LDS reads and 24 permutes per channel quad instead of 18 and 36), and 12 tap addresses stay live instead of 18 —
+        // that form ran into the 128-register cap of the 16-wave workgroup (16 spilled registers, 68 B of scratch per lane in round 2).
+        constexpr bool ROWS4 = UPW == 2 && S == 1 && OW == 16 && !SRCG;
+        int raddr[ROWS4 ? 4 : 1][3];
+        if constexpr (ROWS4) {
+            const int g = p[0] / PER_CHUNK, oy = (p[0] % PER_CHUNK) / OW, ox = n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int iy = oy - 1 + r, ix = ox - 1 + dx;
+                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    raddr[r][dx] = (ok ? L.x_off + ((g * H + iy) * W + ix) * PIN : L.zp_off) + 4 * qb;
+                }
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             int frag[UPW][4];
@@ -186,6 +208,28 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
                 for (int t = 0; t < UPW; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[t][e] = bias[e];
+                if constexpr (ROWS4) {
+                    v4i wprev = (v4i){0, 0, 0, 0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int rr[3];
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) rr[dx] = *reinterpret_cast<const int*>(lds + raddr[r][dx] + 4 * qi);
+                        const int lo = perm(rr[1], rr[0], 0x05010400u), hi = perm(rr[1], rr[0], 0x07030602u);  // bytes (tap0, tap1, tap2, 0) per channel
+                        const int tr[4] = {perm(rr[2], lo, 0x0c040100u), perm(rr[2], lo, 0x0c050302u), perm(rr[2], hi, 0x0c060100u), perm(rr[2], hi, 0x0c070302u)};
+                        v4i w = wprev;
+                        if (r < 3) {  // input row r is window row r of the upper output row ...
+                            w = dwc[qi * 8 + r];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[0][e] = dot4(tr[e], w[e], acc[0][e]);
+                        }
+                        if (r > 0) {  // ... and window row r - 1 of the lower one
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[1][e] = dot4(tr[e], wprev[e], acc[1][e]);
+                        }
+                        wprev = w;
+                    }
+                } else {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const v4i w = dwc[qi * 8 + dy];
@@ -207,6 +251,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
                         acc[t][2] = dot4(perm(r[2], hi, 0x0c060100u), w[2], acc[t][2]);
                         acc[t][3] = dot4(perm(r[2], hi, 0x0c070302u), w[3], acc[t][3]);
                     }
+                }
                 }
                 const v4i m = dwc[qi * 8 + 4], c01 = dwc[qi * 8 + 5], c23 = dwc[qi * 8 + 6];
                 const int e1 = reinterpret_cast<const int*>(dwc + qi * 8 + 7)[0];
@@ -251,8 +296,11 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
                     // with the ADD: value + 128 = index of the second table (any sign: full rounding)
                     int v = med3(ADD ? rq(acc[t][e], m[e], c1[e], sh[e]) : rq_hi(acc[t][e], m[e], cc[e], e1, e), pw_lo, pw_hi);
                     if constexpr (ADD) {
+                        // the ADD's own rescale: its clamp starts at the zero point (fused ReLU6; the packer checks it), so the sign term of the
+                        // rounding shift is not needed and the result is the high dword of one 64-bit multiply-add, shifted (rq_hi's form with
+                        // wave-uniform constants): 4 instructions instead of 7
                         const int sa = lut[(res >> (8 * e)) & 0xff], sb = lut[256 + v];
-                        v = med3(rq(sa + sb, L.add_m, L.add_c1, L.add_e), L.add_lo, L.add_hi);
+                        v = med3((int)(((long)(sa + sb) * (long)add_m + add_c) >> 32) >> add_e1, L.add_lo, L.add_hi);
                     }
                     qv[e] = v;
                 }
@@ -263,9 +311,47 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
     __syncthreads();
 }
 
+// MEAN + FULLY_CONNECTED + head for the workgroup's chunks.  (As a real function call it costs a stack copy of the arguments: 1168 B of
+// scratch per lane — it stays inlined.)
+__device__ __forceinline__ void tail_head(const Tail8Args& a, unsigned char* lds, int chunk0) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // keeps this part's index arithmetic from being hoisted to the top of the kernel and held in registers across
+                                   // the blocks, which run at the 128-register cap of a 16-wave workgroup (it was what spilled)
+    // ---- MEAN over the positions of the last map: one thread per (chunk slot, channel) ---------------------------------------
+    const Tail8Layer& L = a.L[a.n_layers - 1];
+    const int pitch = a.C + 4;
+    for (int i = tid; i < kTailG * a.C; i += kTailThreads) {
+        const int g = i / a.C, c = i - g * a.C;
+        const int8_t* src = reinterpret_cast<const int8_t*>(lds + L.y_off + g * a.P * pitch + c);
+        int s = 0;
+        for (int k = 0; k < a.P; ++k) s += src[k * pitch];
+        s -= a.mean_zp_in * a.P;
+        reinterpret_cast<int8_t*>(lds + a.mean_off)[i] = (int8_t)clampi(mbqm(s, a.mean_mult, a.mean_shift) + a.mean_zp_out, -128, 127);
+    }
+    __syncthreads();
+    // ---- FULLY_CONNECTED + head: one thread per (chunk slot, class) ----------------------------------------------------------
+    for (int i = tid; i < kTailG * a.NC; i += kTailThreads) {
+        const int g = i / a.NC, j = i - g * a.NC;
+        const int chunk = chunk0 + g;
+        if (chunk >= a.B) continue;
+        const int* xr = reinterpret_cast<const int*>(lds + a.mean_off + g * a.C);
+        const int* wr = a.cst + a.g_fcw + j * (a.C / 4);
+        int acc = a.cst[a.g_fcb + j];
+        for (int k = 0; k < a.C / 4; ++k) acc = dot4(xr[k], wr[k], acc);
+        const int qv = clampi(mbqm(acc, a.cst[a.g_fcm + j], a.cst[a.g_fcs + j]) + a.fc_zp_out, a.fc_lo, a.fc_hi);
+        const size_t o = (size_t)chunk * a.NC + j;
+        if (a.logits) a.logits[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
+        if (a.g_hlut >= 0) {
+            const int ov = reinterpret_cast<const int8_t*>(a.cst + a.g_hlut)[qv + 128];
+            a.scores[o] = (float)(ov - a.head_zp_out) * a.s_head;
+        } else {
+            a.scores[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kTailThreads) void i8_tail_kernel(Tail8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
     const int ngroups = (a.B + kTailG - 1) / kTailG;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int chunk0 = grp * kTailG;
@@ -276,37 +362,7 @@ __global__ __launch_bounds__(kTailThreads) void i8_tail_kernel(Tail8Args a) {
             else if (L.Cin == 128) tail_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0);
             else tail_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0);
         }
-        // ---- MEAN over the positions of the last map: one thread per (chunk slot, channel) ---------------------------------------
-        const Tail8Layer& L = a.L[a.n_layers - 1];
-        const int pitch = a.C + 4;
-        for (int i = tid; i < kTailG * a.C; i += kTailThreads) {
-            const int g = i / a.C, c = i - g * a.C;
-            const int8_t* src = reinterpret_cast<const int8_t*>(lds + L.y_off + g * a.P * pitch + c);
-            int s = 0;
-            for (int k = 0; k < a.P; ++k) s += src[k * pitch];
-            s -= a.mean_zp_in * a.P;
-            reinterpret_cast<int8_t*>(lds + a.mean_off)[i] = (int8_t)clampi(mbqm(s, a.mean_mult, a.mean_shift) + a.mean_zp_out, -128, 127);
-        }
-        __syncthreads();
-        // ---- FULLY_CONNECTED + head: one thread per (chunk slot, class) ----------------------------------------------------------
-        for (int i = tid; i < kTailG * a.NC; i += kTailThreads) {
-            const int g = i / a.NC, j = i - g * a.NC;
-            const int chunk = chunk0 + g;
-            if (chunk >= a.B) continue;
-            const int* xr = reinterpret_cast<const int*>(lds + a.mean_off + g * a.C);
-            const int* wr = a.cst + a.g_fcw + j * (a.C / 4);
-            int acc = a.cst[a.g_fcb + j];
-            for (int k = 0; k < a.C / 4; ++k) acc = dot4(xr[k], wr[k], acc);
-            const int qv = clampi(mbqm(acc, a.cst[a.g_fcm + j], a.cst[a.g_fcs + j]) + a.fc_zp_out, a.fc_lo, a.fc_hi);
-            const size_t o = (size_t)chunk * a.NC + j;
-            if (a.logits) a.logits[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
-            if (a.g_hlut >= 0) {
-                const int ov = reinterpret_cast<const int8_t*>(a.cst + a.g_hlut)[qv + 128];
-                a.scores[o] = (float)(ov - a.head_zp_out) * a.s_head;
-            } else {
-                a.scores[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
-            }
-        }
+        tail_head(a, lds, chunk0);
         __syncthreads();  // the next group overwrites the maps
     }
 }
@@ -363,6 +419,13 @@ bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a) {
         const int tiles = kTailG * L.OH * L.OW / 16;
         if (tiles < kTailWaves && (kTailWaves % tiles || (L.Cout / 16) % (kTailWaves / tiles))) return false;
         if ((L.g_w | L.g_dwc | L.g_pwc) & 3 || (L.has_add && (L.g_lut & 3))) return false;
+        // offsets into the constant block start at 0 (tail_const_words bounds them from above: a stale or hostile blob must not make the
+        // kernel read in front of the block), and every clamp whose result indexes a table or is stored as a byte is an int8 range
+        // (+ 128 where the pointwise value of a residual block is kept as the index of the second ADD table)
+        if (L.g_w < 0 || L.g_dwc < 0 || L.g_pwc < 0 || (L.has_add && L.g_lut < 0)) return false;
+        const int off = L.has_add ? 128 : 0;
+        if (L.dw_lo < -128 || L.dw_hi > 127 || L.dw_lo > L.dw_hi || L.pw_lo < -128 + off || L.pw_hi > 127 + off || L.pw_lo > L.pw_hi) return false;
+        if (L.has_add && (L.add_lo < -128 || L.add_hi > 127 || L.add_lo > L.add_hi)) return false;
         std::vector<Span> used;
         L.x_off = cur_off;
         if (cur_off >= 0) used.push_back({cur_off, cur_off + kTailG * L.H * L.W * (L.Cin + 4)});
@@ -384,6 +447,8 @@ bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a) {
     a.mean_zp_in = h[0]; a.mean_mult = h[1]; a.mean_shift = h[2]; a.mean_zp_out = h[3];
     a.fc_zp_out = h[4]; a.fc_lo = h[5]; a.fc_hi = h[6]; a.g_fcw = h[7]; a.g_fcb = h[8]; a.g_fcm = h[9]; a.g_fcs = h[10]; a.g_hlut = h[11];
     a.head_zp_fc = h[12]; a.head_zp_out = h[13]; a.P = h[14]; a.C = h[15];
+    if (a.g_fcw < 0 || a.g_fcb < 0 || a.g_fcm < 0 || a.g_fcs < 0 || a.g_hlut < -1 || (a.g_fcw & 3)) return false;
+    if (a.fc_lo < -128 || a.fc_hi > 127 || a.fc_lo > a.fc_hi) return false;  // (the classifier byte + 128 indexes the head's table)
     const Tail8Layer& last = a.L[n_layers - 1];
     if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 4 || a.NC < 1 || kTailG * a.NC > kTailThreads * 4) return false;
     a.lds_bytes = lds_need;

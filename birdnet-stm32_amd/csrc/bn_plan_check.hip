@@ -72,6 +72,12 @@ struct Checker {
         return true;
     }
 
+    // clamp bounds of a value that is used as a table index (value + 128 into 256 entries): must be int8 bounds
+    bool clamp8(int lo, int hi, const char* what) {
+        if (lo < -128 || hi > 127 || lo > hi) return bad("%s: clamp [%d, %d] is not an int8 range (the clamped value indexes a 256-entry table)", what, lo, hi);
+        return true;
+    }
+
     bool conv_geom(int H, int W, int sh, int sw, int OH, int OW, int pt, int pl) {
         if (sh < 1 || sw < 1 || sh > 2 || sw > 2) return bad("stride %dx%d (1 or 2 expected)", sh, sw);
         if (OH != (H + sh - 1) / sh || OW != (W + sw - 1) / sw) return bad("output %dx%d does not follow from input %dx%d at stride %dx%d (SAME)", OH, OW, H, W, sh, sw);
@@ -111,6 +117,8 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                 c.dims({p[0], p[1], p[2], p[3]}, "raw frontend") && c.slot(o.in0, 4LL * p[0], "waveform") && c.slot(o.out, 4LL * p[2] * p[1], "output") &&
                     c.tensor(0, 64LL * p[2], "filterbank") && c.tensor(1, 4LL * p[2], "bias") && (p[5] == 0 || c.tensor(2, 4LL * p[2], "magnitude parameters"));
                 if (c.ok && p[4] < 0) c.bad("negative left padding");
+                if (c.ok && p[9]) c.clamp8(p[7], p[8], "raw frontend");
+                if (c.ok && p[1] % 4) c.bad("raw frontend width %d is not a multiple of 4 (the kernel stores dwords of one filter)", p[1]);
                 break;
             case BN_OP_F32_STEM:
             case BN_OP_F32_DW: {  // H W C sh sw act OH OW pt pl
@@ -179,6 +187,7 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                 c.dims({p[0], p[1], p[2]}, "mel") && c.slot(o.in0, 1LL * p[0] * p[1], "input") && c.slot(o.out, 1LL * p[2] * p[0], "output") &&
                     c.tensor(0, 1LL * p[2] * p[1], "weights") && c.tensor(1, 4LL * p[2], "bias") && c.tensor(2, 4LL * p[2], "multipliers") &&
                     c.tensor(3, 4LL * p[2], "shifts") && (!p[6] || c.tensor(4, 256LL * p[2], "table"));
+                if (c.ok && p[6]) c.clamp8(p[4], p[5], "mel");  // the clamped value + 128 indexes the 256-entry table
                 break;
             case BN_OP_I8_STEM:
             case BN_OP_I8_DW: {  // H W C sh sw - OH OW pt pl ...
@@ -200,6 +209,7 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                 c.dims({p[0], p[1]}, "fully connected") && c.slot(o.in0, 1LL * p[0], "input") && c.slot(o.out, 1LL * p[1], "output") &&
                     c.tensor(0, up(p[0], 4) * p[1], "weights") && c.tensor(1, 4LL * p[1], "bias") && c.tensor(2, 4LL * p[1], "multipliers") &&
                     c.tensor(3, 4LL * p[1], "shifts") && (!p[5] || c.tensor(4, 256, "table"));
+                if (c.ok && p[5]) c.clamp8(p[3], p[4], "fully connected");
                 break;
             case BN_OP_I8_SCALE:  // P C zp_x zp_gate mult shift zp_out act_min act_max
                 c.dims({p[0], p[1]}, "scale") && c.slot(o.in0, 1LL * p[0] * p[1], "input") && c.slot(o.in1, 1LL * p[1], "gate") && c.slot(o.out, 1LL * p[0] * p[1], "output");
@@ -215,6 +225,8 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                     c.tensor(0, 16LL * p[2], "filterbank") && c.tensor(1, 4LL * p[2], "bias") && c.tensor(2, 4LL * p[2], "multipliers") &&
                     c.tensor(3, 4LL * p[2], "shifts") && (!p[9] || c.tensor(4, 256LL * p[2], "table"));
                 if (c.ok && p[4] < 0) c.bad("negative left padding");
+                if (c.ok && p[9]) c.clamp8(p[7], p[8], "raw frontend");
+                if (c.ok && p[1] % 4) c.bad("raw frontend width %d is not a multiple of 4 (the kernel stores dwords of one filter)", p[1]);
                 break;
             case BN_OP_I8_HEAD:  // C zp_fc zp_out has_lut
                 c.dims({p[0]}, "head") && c.slot(o.in0, 1LL * p[0], "input") && c.slot(o.out, 4LL * p[0], "scores") && (!p[3] || c.tensor(0, 256, "table"));
@@ -238,6 +250,8 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                 // the transposed form is the mel mixer: a plain 1x1 over the frames of one chunk, no residual; only it takes a table or float32 input
                 if (c.ok && p[30] && (p[29] || p[18] || p[0] != 1 || p[6] != 1 || p[33] != 1)) c.bad("transposed output on a block that is not a mel mixer");
                 if (c.ok && !p[30] && (p[34] || p[36])) c.bad("table / fused QUANTIZE on a block without transposed output");
+                if (c.ok && p[34]) c.clamp8(p[16], p[17], "mel mixer");
+                if (c.ok && p[18]) c.clamp8(p[16], p[17], "block with ADD") && c.clamp8(p[27], p[28], "ADD");  // both index the 256-entry rescale tables
                 if (c.ok && p[35] && o.t[9] >= 0) {  // constant block of the strip kernel (bn_i8_strip.hip: kPWC + NW * nPWC words)
                     const int nw = p[3] == p[4] ? i8_strip_waves(p[2], p[14], p[3], p[7], p[18] != 0) : 0;
                     if (nw) {

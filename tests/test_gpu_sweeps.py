@@ -704,3 +704,33 @@ def test_c_abi_refuses_bad_calls_with_an_error_code(torch_mod):
     torch.cuda.synchronize()
     assert torch.equal(scores[:8], want)
     runner.close()
+
+
+def test_hostile_tail_descriptor_falls_back_to_the_block_kernels(torch_mod):
+    """A fused-tail descriptor with a NEGATIVE constant-block offset or a clamp outside int8 (a stale or hostile blob; the size check bounds
+    offsets from above only) must not reach i8_tail_kernel: tail_plan refuses it at load and the per-block operators run instead — same
+    scores, bit for bit."""
+    import copy
+
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models.runners import HipRunner, lower_model_file
+
+    plan = lower_model_file(TFLITE_PATH)
+    ti = next(i for i, o in enumerate(plan.ops) if o.kind == pk.I8_TAIL)
+    S = np.random.default_rng(3).random((8, 257, 256, 1), dtype=np.float32) ** 3
+    good = HipRunner(plan, max_batch=8)
+    want = good.predict(S)
+    assert good.profile_collect() is not None
+    good.close()
+    for word, value in ((21, -4), (13, -300), (19, 400), (24 * 6 + 7, -8)):  # g_dwc of block 0, pw_lo of block 0, add_hi of block 0, g_fcw of the head
+        bad = copy.deepcopy(plan)
+        desc = bad.tensors[bad.ops[ti].t[1]].copy()
+        desc.reshape(-1)[word] = value
+        bad.tensors[bad.ops[ti].t[1]] = desc
+        r = HipRunner(bad, max_batch=8)
+        r.profile(True)
+        got = r.predict(S)
+        kinds = {q["kind"] for q in r.profile_collect() if q["launches"]}
+        r.close()
+        assert "i8_tail" not in kinds, f"descriptor word {word} = {value} was accepted by the fused kernel"
+        assert np.array_equal(got, want)

@@ -407,6 +407,14 @@ def test_blob_check_accepts_every_lowered_plan_and_refuses_damaged_ones():
     bad = copy.deepcopy(i8)
     bad.ops[oi].p[34] = 1  # per-channel table on a block whose kernel has none
     refused(bad, "table")
+    # 6c) a clamp that is not an int8 range on a value that indexes a 256-entry table (residual ADD tables, the mel mixer's PWL table)
+    bad = copy.deepcopy(i8)
+    bad.ops[oj].p[28] = 300
+    refused(bad, "not an int8 range")
+    bad = copy.deepcopy(i8)
+    om = next(i for i, o in enumerate(bad.ops) if o.kind == pk.I8_DWPW and o.p[34])
+    bad.ops[om].p[16] = -129
+    refused(bad, "not an int8 range")
     # 7) truncated blob, bad magic
     blob = i8.to_blob()
     for cut in (10, 63, 200, len(blob) // 2):
