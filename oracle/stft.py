@@ -49,16 +49,34 @@ def cabs_numpy_simd(z: np.ndarray) -> np.ndarray:
     return (np.sqrt(t) * larger).astype(np.float32)
 
 
-def stft_magnitude(y: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
-    """``abs(librosa.stft(y, n_fft, hop, win_length=n_fft, window='hann'))`` -> float32 ``[1+n_fft//2, 1+len(y)//hop]``."""
+def hann_symmetric(n: int) -> np.ndarray:
+    """Symmetric Hann window ``0.5 (1 - cos(2 pi k / (n - 1)))`` in float64 (the reference FIRMWARE's window, firmware/Src/audio_stft.c)."""
+    k = np.arange(n, dtype=np.float64)
+    return 0.5 * (1.0 - np.cos(2.0 * np.pi * k / (n - 1)))
+
+
+def stft_magnitude(y: np.ndarray, n_fft: int, hop: int, center: bool = True, window: str = "hann_periodic", n_frames: int | None = None) -> np.ndarray:
+    """``abs(librosa.stft(y, n_fft, hop, win_length=n_fft, window='hann'))`` -> float32 ``[1+n_fft//2, 1+len(y)//hop]``.
+
+    The defaults are librosa's (and the evaluate path's).  ``center=False`` / ``window='hann_symmetric'`` / ``n_frames`` select the framing
+    of the reference's firmware STFT (frame t = samples ``[t*hop, t*hop + n_fft)`` of the signal, zero-extended at the end, symmetric Hann):
+    the SAME function evaluated with that framing is pinned against the reference's own ``audio_stft.c`` compiled in place
+    (tests/test_oracle_pinning.py), so everything in it but the two framing switches is reference-checked code."""
     y = np.asarray(y, dtype=np.float32)
     if hop <= 0:
         raise ValueError("hop must be positive")
-    pad = n_fft // 2
-    yp = np.concatenate([np.zeros(pad, np.float32), y, np.zeros(pad, np.float32)])
-    n_frames = 1 + len(y) // hop
+    win = {"hann_periodic": hann_periodic, "hann_symmetric": hann_symmetric}[window](n_fft)
+    if center:
+        pad = n_fft // 2
+        yp = np.concatenate([np.zeros(pad, np.float32), y, np.zeros(pad, np.float32)])
+        if n_frames is None:
+            n_frames = 1 + len(y) // hop
+    else:
+        if n_frames is None:
+            n_frames = 1 + max(len(y) - n_fft, 0) // hop
+        yp = np.concatenate([y, np.zeros(max(0, hop * (n_frames - 1) + n_fft - len(y)), np.float32)])
     idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
-    frames = yp[idx].astype(np.float64) * hann_periodic(n_fft)[None, :]
+    frames = yp[idx].astype(np.float64) * win[None, :]
     spec = np.fft.rfft(frames, axis=1).astype(np.complex64)  # stored as complex64 like librosa
     return np.abs(spec).T.astype(np.float32, copy=False)
 

@@ -70,6 +70,42 @@ json.dump(out, sys.stdout)
 """
 
 
+_REPORT_CASES = {
+    "full": dict(metrics={"roc-auc": 0.9123456789, "cmAP": 0.5, "mAP": 0.123456749, "f1": 1.0, "precision": 0.3333333333, "recall": 2 / 3,
+                          "total_chunks": 28, "ap_per_class": [0.1, 0.2], "latency_mean_ms": 1.23456789, "latency_p99_ms": 3, "note": "x", "flag": True,
+                          "nested": {"a": 0.1234567891}},
+                 classes=["alpha", "beta", "gamma"], model_path="checkpoints/m.tflite",
+                 species_data=[{"class": "alpha", "ap": 0.25, "ci_lower": 0.1, "ci_upper": 0.4, "n_positive": 3, "n_total": 9}],
+                 config={"sample_rate": 24000, "class_names": ["alpha", "beta", "gamma"], "alpha": 1.0}),
+    "bare": dict(metrics={"roc-auc": 0.0, "total_chunks": 0}, classes=[], model_path="m.keras", species_data=None, config=None),
+    "no_chunks_key": dict(metrics={"f1": 0.7071067811865476}, classes=["a"], model_path="x", species_data=[], config={}),
+}
+
+_REPORT_SCRIPT = r"""
+import io, json, os, sys, tempfile, contextlib
+sys.path.insert(0, %r)
+from birdnet_stm32.evaluation.reporting import save_benchmark_json
+cases = json.loads(%r)
+out = {}
+for name, c in cases.items():
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "sub", "report.json")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        save_benchmark_json(c["metrics"], c["classes"], c["model_path"], path, species_data=c["species_data"], config=c["config"])
+    out[name] = {"file": open(path).read(), "stdout": buf.getvalue().replace(path, "<out>")}
+json.dump(out, sys.stdout)
+"""
+
+
+def reference_reporting() -> None:
+    """``save_benchmark_json`` of the reference (evaluation/reporting.py:192-236) on three metric dicts: the text of the file it writes."""
+    res = subprocess.run([sys.executable, "-c", _REPORT_SCRIPT % (REF, json.dumps(_REPORT_CASES))], capture_output=True, text=True, check=True, cwd="/tmp")
+    with open(os.path.join(HERE, "reference_reporting.json"), "w") as fh:
+        json.dump({"cases": _REPORT_CASES, "reference": json.loads(res.stdout)}, fh, indent=1)
+    print("wrote reference_reporting.json")
+
+
 def reference_fixtures() -> None:
     shipped = os.path.join(REF, "checkpoints", "birdnet_stm32n6_100_model_config.json")
     code = _REF_SCRIPT % (REF, shipped)
@@ -119,6 +155,7 @@ def oracle_fixtures() -> None:
 if __name__ == "__main__":
     if os.path.isdir(REF):
         reference_fixtures()
+        reference_reporting()
     else:
         print("no /root/reference here: keeping the committed reference_* fixtures")
     oracle_fixtures()

@@ -228,13 +228,39 @@ def test_firmware_stft_is_a_different_framing():
     x = fixture_signals(22050)["noise"]
     hop, W = 258, 256
     got = fw.stft_magnitude(x, hop, W)
-    win = 0.5 * (1 - np.cos(2 * np.pi * np.arange(512) / 511))
-    idx = np.arange(512)[None, :] + hop * np.arange(W)[:, None]
-    xp = np.concatenate([x, np.zeros(512, np.float32)])
-    own = np.abs(np.fft.rfft(xp[idx] * win, axis=1)).T
+    # the ORACLE'S function with the firmware's framing (no centre padding, symmetric Hann, W frames) against the reference's C: everything
+    # in oracle.stft.stft_magnitude except its two framing switches is thereby reference-checked (the firmware FFT is float32: 5e-6)
+    own = stft.stft_magnitude(x, 512, hop, center=False, window="hann_symmetric", n_frames=W)
+    assert own.shape == got.shape == (257, W)
     assert np.abs(got - own).max() < 5e-6 * own.max() + 1e-5
+    for name, sig in fixture_signals(24000).items():  # the other fixture signals, at the metric's rate
+        g2, o2 = fw.stft_magnitude(sig, 281, W), stft.stft_magnitude(sig, 512, 281, center=False, window="hann_symmetric", n_frames=W)
+        assert np.abs(g2 - o2).max() < 5e-6 * o2.max() + 1e-5, name
     ev = stft.stft_magnitude(x, 512, hop)[:, :W]
     assert cosine(got, ev) < 0.95
+
+
+def test_stft_framing_cross_checked_with_scipy_short_time_fft():
+    """The evaluate path's framing (librosa defaults: centre padding with zeros, periodic Hann, frame t centred on sample t * hop) written
+    by an independent third party: ``scipy.signal.ShortTimeFFT`` puts its slice p on sample p * hop, extends the signal with zeros and takes
+    the window as given.  A CROSS-CHECK of ``oracle.stft.stft_magnitude``'s framing (frame count, alignment, padding), not a pin of
+    librosa's numerics: librosa itself cannot be imported here."""
+    from scipy.signal import ShortTimeFFT, get_window
+
+    from oracle import stft
+
+    for sr, hop in ((24000, 281), (22050, 258)):
+        for name, x in fixture_signals(sr).items():
+            win = get_window("hann", 512, fftbins=True)  # what librosa passes to its FFT
+            assert np.abs(win - stft.hann_periodic(512)).max() < 1e-15
+            sft = ShortTimeFFT(win, hop=hop, fs=sr, fft_mode="onesided", mfft=512, scale_to=None)
+            n_frames = 1 + len(x) // hop
+            Z = sft.stft(x.astype(np.float64), p0=0, p1=n_frames)  # slices 0 .. n_frames - 1: centred on 0, hop, 2 hop, ...
+            ours = stft.stft_magnitude(x, 512, hop)
+            assert Z.shape == ours.shape == (257, n_frames)
+            ref = np.abs(Z)
+            assert np.abs(ref - ours).max() <= 2e-7 * ref.max() + 1e-9, (sr, name)
+
 
 
 def test_mel_against_reference_firmware():
@@ -390,3 +416,20 @@ def test_numpy_cabs_restatement_is_pinned_to_the_installed_numpy():
     assert bad.size == 0, f"{bad.size} of {n} differ, first {z[bad[0]]}: {got[bad[0]]} vs {want[bad[0]]}"
     exact = np.sqrt(z.real.astype(np.float64) ** 2 + z.imag.astype(np.float64) ** 2).astype(np.float32)
     assert 0.2 < (want != exact).mean() < 0.5
+
+
+def test_benchmark_json_report_is_pinned_to_the_reference(tmp_path, capsys):
+    """``cli/evaluate.py: save_benchmark_json`` writes, byte for byte, the file the reference's ``evaluation/reporting.py:192-236`` writes for
+    the same metric dicts (tests/golden/reference_reporting.json: generated by importing the reference, tests/golden/make_golden.py), and
+    prints the same line."""
+    import json
+
+    from birdnet_stm32.cli.evaluate import save_benchmark_json
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_reporting.json")))
+    assert set(gold["cases"]) == set(gold["reference"]) and len(gold["cases"]) >= 3
+    for name, c in gold["cases"].items():
+        out = tmp_path / name / "sub" / "report.json"
+        save_benchmark_json(c["metrics"], c["classes"], c["model_path"], str(out), config=c["config"], species_data=c["species_data"])
+        assert out.read_text() == gold["reference"][name]["file"], name
+        assert capsys.readouterr().out.replace(str(out), "<out>") == gold["reference"][name]["stdout"], name
