@@ -207,6 +207,8 @@ EXPORT_TOPOLOGIES = {
     # raw frontend (QUANTIZE of the waveform -> [PAD] -> RESHAPE -> CONV_2D 1x16 strided VALID): BASELINE configs[4]'s frontend with PCEN, and a
     # geometry whose chunk is shorter than stride * (W - 1) + 16 samples (symmetric zero padding in front of the filterbank)
     "raw_pcen_ir_se": dict(audio_frontend="raw", mag_scale="pcen", chunk_duration=2, alpha=0.5),
+    # the same at the metric's chunk length: 3 s @ 24 kHz = 72000 samples, stride 282, no PAD (the reference's T < 65536 guard lifted)
+    "raw_pcen_ir_se_3s": dict(audio_frontend="raw", mag_scale="pcen", chunk_duration=3, alpha=0.5, raw_length_limit=None),
     "raw_pad_nomag_ds": dict(audio_frontend="raw", mag_scale="none", sample_rate=6000, chunk_duration=0.5, spec_width=128, num_mels=32,
                              use_se=False, use_inverted_residual=False),
 }

@@ -483,17 +483,25 @@ def test_cli_evaluate_benchmark_latency(torch_mod, tmp_path):
     assert rep["num_files"] == 16 and rep["metrics"]["total_chunks"] == 16 and rep["metrics"]["latency_p95_ms"] > 0
 
 
-def test_f32_raw_frontend_config5_topology(torch_mod):
-    """BASELINE configs[4]: raw-waveform learned filterbank + PCEN + alpha=1.5 DS-CNN with SE / inverted residuals, seeded weights.
-    The raw frontend follows the reference's deployment geometry 24 kHz x 2 s (T = 48000 < 65536, stride 188; SURVEY finding 11)."""
+@pytest.mark.parametrize("seconds", [2, 3])
+def test_f32_raw_frontend_config5_topology(torch_mod, seconds):
+    """BASELINE configs[4]: raw-waveform learned filterbank + PCEN + alpha=1.5 DS-CNN with SE / inverted residuals, seeded weights, per
+    layer against the float64 oracle.  2 s: the reference's deployment geometry 24 kHz x 2 s (T = 48000 < 65536, stride 188; SURVEY
+    finding 11).  3 s: the METRIC's chunk length (T = 72000, stride ceil(72000 / 256) = 282, pad_total = max(0, 282 * 255 + 16 - 72000) = 0:
+    reference models/frontend.py:147-155) with the reference's STM32N6 length guard lifted (``raw_length_limit=None``, models/dscnn.py:144-151)."""
     from birdnet_stm32.models import build_model
     from birdnet_stm32.models._lower_f32 import lower_f32
     from birdnet_stm32.models.runners import HipRunner
     from oracle import float_graph
 
-    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
-                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
-    x = synth_chunks(3)[:, :48000]
+    T = 24000 * seconds
+    if seconds == 3:
+        with pytest.raises(ValueError, match="STM32N6 constraint"):  # the reference's guard, kept by default
+            build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=100, audio_frontend="raw")
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=seconds, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42,
+                       **({"raw_length_limit": None} if seconds == 3 else {}))
+    x = synth_chunks(3)[:, :T]
     x = (x / (np.abs(x).max(axis=1, keepdims=True) + 1e-6)).astype(np.float32)[..., None]  # host prep of evaluation/metrics.py:62-69
     ref_scores, ref_logits, acts = float_graph.forward(spec, x, np.float64, return_all=True, return_logits=True)
     runner = HipRunner(lower_f32(spec, keep_all=True), max_batch=4)
@@ -509,7 +517,7 @@ def test_f32_raw_frontend_config5_topology(torch_mod):
         assert 1.0 - cosine(got[b], ref_scores[b]) < 1e-5
     assert np.abs(got - ref_scores).max() < 1e-4
     with pytest.raises(ValueError, match="expected input of shape"):
-        runner.predict(np.zeros((1, 72000, 1), np.float32))
+        runner.predict(np.zeros((1, 72000 if seconds == 2 else 48000, 1), np.float32))
     runner.close()
 
 

@@ -299,9 +299,10 @@ def test_f32_dw_stream_matches_baseline_kernel(torch_mod):
 
 
 # -------------------------------------------------------------------------------- configs[4] at its full batch
-def test_config5_full_batch_properties(torch_mod):
+@pytest.mark.parametrize("seconds", [2, 3])
+def test_config5_full_batch_properties(torch_mod, seconds):
     """BASELINE configs[4] (raw learned-filterbank frontend + PCEN + alpha 1.5 DS-CNN with SE / inverted residuals, seeded weights,
-    24 kHz x 2 s) at B = 1024: a chunk's scores do not depend on its batch neighbours, position or batch slicing (== the same chunks
+    24 kHz x 2 s as the reference's raw frontend builds, and x 3 s — the metric's chunk — with its length guard lifted) at B = 1024: a chunk's scores do not depend on its batch neighbours, position or batch slicing (== the same chunks
     through a 96-chunk workspace, where the per-layer parity test against the oracle runs), repeated runs are bit-identical, softmax rows
     sum to one; and the first chunks agree with the float64 oracle."""
     torch = torch_mod
@@ -310,9 +311,10 @@ def test_config5_full_batch_properties(torch_mod):
     from birdnet_stm32.models.runners import HipRunner
     from oracle import float_graph
 
-    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
-                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
-    base = torch.from_numpy(synth_chunks(64)[:, :48000].copy()).cuda()
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=seconds, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42,
+                       **({"raw_length_limit": None} if seconds == 3 else {}))
+    base = torch.from_numpy(synth_chunks(64)[:, : 24000 * seconds].copy()).cuda()
     B = 1024
     idx = torch.randint(0, 64, (B,), generator=torch.Generator().manual_seed(3)).cuda()
     audio = base[idx].contiguous()
@@ -722,7 +724,7 @@ def test_hostile_tail_descriptor_falls_back_to_the_block_kernels(torch_mod):
     want = good.predict(S)
     assert good.profile_collect() is not None
     good.close()
-    for word, value in ((21, -4), (13, -300), (19, 400), (24 * 6 + 7, -8)):  # g_dwc of block 0, pw_lo of block 0, add_hi of block 0, g_fcw of the head
+    for word, value in ((21, -4), (13, -300), (24 + 19, 400), (24 * 6 + 7, -8)):  # g_dwc / pw_lo of block 0, add_hi of block 1 (the first with an ADD), g_fcw of the head
         bad = copy.deepcopy(plan)
         desc = bad.tensors[bad.ops[ti].t[1]].copy()
         desc.reshape(-1)[word] = value
