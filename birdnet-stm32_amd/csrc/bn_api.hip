@@ -181,6 +181,10 @@ bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
     g.list += b0 * (size_t)g.cap;
     g.count += b0;
     g.dirty += b0;
+    g.audio = m->guard_audio;  // (already offset to the launch group's first chunk by bn_infer_audio)
+    g.T = m->guard_T;
+    g.hop = m->guard_hop;
+    g.tabs = m->ctx->tables;
     return g;
 }
 
@@ -855,14 +859,14 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
     if (m->spec_tiled_ok && h.dtype == BN_DTYPE_I8) {
         // exactness pass of the audio path: per chunk W bounds, W / 16 tile records, a list of flagged elements, counters
         const size_t W = h.spec_width, n_tiles = (W + 15) / 16, t64 = (W + 63) / 64;
-        const int cap = 1024;
+        const int cap = 1 << 20;  // a chunk's count beyond this = one of its mel-mixer workgroups gave up (more in doubt than it keeps)
         size_t off = 0;
         auto take = [&](size_t bytes) {
             const size_t o = off;
             off += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_eps = take(mb * W * 4), o_rec = take(mb * n_tiles * bn::kGuardRec * 4), o_list = take(mb * cap * 4), o_cnt = take(mb * 4),
+        const size_t o_eps = take(mb * W * 4), o_rec = take(mb * n_tiles * bn::kGuardRec * 4), o_list = take(16), o_cnt = take(mb * 4),
                      o_dirty = take(mb * 4), o_work = take(mb * t64 * 4), o_nw = take(4), o_hard = take(2 * mb * 4), o_nh = take(8);
         if (hipMalloc(&m->d_guard, off) != hipSuccess) return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu exactness-pass bytes failed", off));
         m->workspace_bytes += off;

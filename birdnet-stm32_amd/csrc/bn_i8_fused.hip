@@ -23,6 +23,7 @@
 #include "bn_kernels.h"
 #include "bn_requant.h"
 #include "bn_quant_in.h"
+#include "bn_exact_dft.h"
 
 namespace bn {
 namespace {
@@ -492,7 +493,8 @@ constexpr int kMelFlagCap = 1022;  // flagged elements a workgroup keeps in LDS 
 template <bool QIN, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 4, 8))) void i8_mel_mfma_kernel(DwPw8Args a) {
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-    __shared__ int flag_n, flag_base, flags[MODE == 1 ? kMelFlagCap : 1];
+    __shared__ int flag_n, flags[MODE == 1 ? kMelFlagCap : 1];
+    __shared__ std::conditional_t<MODE == 1, ExactTabsW, int> xtabs_s;  // float64 twiddles + window for the elements this workgroup re-evaluates itself
     v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);
     const int Kp = a.Cin, W = a.W, M = a.Cout;
     const int S16 = (Kp >> 4) + 1;  // row stride in 16-byte units (one unit of padding: conflict-free 16-byte reads along rows)
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             // half-width of the band around a rounding boundary inside which the reference's byte may differ (bn_quant_in.h)
             float dband[4] = {0.f, 0.f, 0.f, 0.f}, crel = 0.f;
             if (MODE == 1) {
-                crel = kGuardRel * (qi.y_rng * qi.y_scale * 1.000001f);
+                crel = kBandRel * (qi.y_rng * qi.y_scale * 1.000001f);
                 const float4 e = *reinterpret_cast<const float4*>(a.qguard.eps + (size_t)chunk * W + t0 + 16 * wv + 4 * ft);
                 const float dsc = qi.y_rng * qi.y_scale * 1.000001f;
                 // (a bound of 0 = the frame is exact: zeros, or a chunk recomputed as a whole in float64 — nothing to list)
@@ -606,12 +608,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         }
     }
     __syncthreads();
-    if (MODE == 1) {
-        // hand the flagged elements to the chunk's list; a workgroup that flagged more than it could keep makes the chunk's count
-        // exceed the list's capacity, which sends stft_fix_kernel over the whole chunk
-        if (tid == 0) {
-            const int n = flag_n;
-            flag_base = n ? atomicAdd(a.qguard.count + chunk, n <= kMelFlagCap ? n : a.qguard.cap + 1) : 0;
+    if constexpr (MODE == 1) {
+        // The elements in doubt are settled HERE, before the tile is multiplied: a 16-lane row per element re-evaluates it the reference's way
+        // (float64 DFT over the frame's 512 samples, complex64, numpy's |.|: bn_exact_dft.h), the byte in the tile and the value in the
+        // spectrogram are replaced.  About 11 elements per workgroup (6.5e-4 of its 16 448): one round of 16.  (As a separate kernel over
+        // per-chunk lists this cost 0.09 ms per 4096 chunks for the pass itself plus a second run of the mixer over every block with a changed
+        // byte; here the sample reads overlap the other workgroups' spectrogram reads.)  A workgroup that flags more than it can keep — no
+        // sane audio does — makes the chunk's count exceed the list's capacity: stft_fix_kernel then takes the whole chunk in float64.
+        const int nf = flag_n;
+        if (tid == 0 && nf) atomicAdd(a.qguard.count + chunk, nf > kMelFlagCap ? a.qguard.cap + 1 : nf);  // (statistics; beyond `cap`: given up)
+        if (nf > 0 && nf <= kMelFlagCap) {
+            ExactTabsW& xt = reinterpret_cast<ExactTabsW&>(xtabs_s);
+            stage_tabs(xt, a.qguard.tabs);
+            __syncthreads();
+            int8_t* tile = reinterpret_cast<int8_t*>(lds_raw);
+            const int stride = S16 * 16;
+            QuantIn qi;
+            qi.set(a.qminmax + 2 * chunk, a.qscale, a.qzp);
+            const float* x = a.qguard.audio + (size_t)chunk * a.qguard.T;
+            float* Sc = const_cast<float*>(a.qx) + (size_t)chunk * a.qF * W;
+            const LdsWindow lw{xt.hann};
+            const int grp = tid >> 4, gl = tid & 15;
+            for (int i0 = 0; i0 < nf; i0 += 16) {
+                const bool act = i0 + grp < nf;
+                const int e = act ? flags[i0 + grp] : 0;
+                const int t = e >> 16, f = e & 0xffff;
+                const float ex = exact_mag_row(xt, lw, x, a.qguard.T, a.qguard.hop, t, f);
+                if (act && gl == 0) {
+                    tile[(t - t0) * stride + f] = (int8_t)qi.q(ex);
+                    Sc[(size_t)(t / 16) * a.qF * 16 + (size_t)f * 16 + (t % 16)] = ex;  // (tile-major; keeps bn_debug_input_bytes' view consistent)
+                }
+            }
+            __syncthreads();
         }
     }
     const int lane = tid & 63, wv = tid >> 6;  // wave wv: mel bins 16 wv .. 16 wv + 15
@@ -645,13 +673,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             packed |= (qv & 0xff) << (8 * e);
         }
         *reinterpret_cast<int*>(yrow + 16 * g) = packed;
-    }
-    if (MODE == 1) {
-        __syncthreads();  // flag_base
-        const int n = min(flag_n, kMelFlagCap), base = flag_base;
-        int* list = a.qguard.list + (size_t)chunk * a.qguard.cap;
-        for (int i = tid; i < n; i += 256)
-            if (base + i < a.qguard.cap) list[base + i] = flags[i];
     }
     }
 }

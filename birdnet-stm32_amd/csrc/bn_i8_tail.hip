@@ -99,15 +99,16 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
     constexpr int NGRP = TILES >= kTailWaves ? 1 : kTailWaves / TILES;  // few tiles: split them over groups of output channels
     constexpr int NT_PER = NTILES / NGRP;
     constexpr int PT = S == 1 ? 1 : 0, PL = PT;  // TF SAME padding of a 3x3 window on even maps: 1 / 1 at stride 1, 0 / 1 at stride 2
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));  // everything derived from the thread id is recomputed per block: hoisted to the top of the kernel (64-bit
-                                   // staging pointers, tap bases) it stayed live across all blocks and two registers spilled at the 128 cap
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
 
     // ---- stage the block's constants: pointwise weights, depthwise / pointwise constants, ADD tables, zero-point row ----------
     {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // the staging copies' 64-bit pointers (constant block + 16 tid, + 112 tid) are recomputed per block: hoisted to
+                                       // the top of the kernel they stayed live across all blocks and two registers spilled at the 128-register cap
         const v4i* g = reinterpret_cast<const v4i*>(a.cst);
         v4i* dst = reinterpret_cast<v4i*>(lds + L.w_off);
 #pragma unroll

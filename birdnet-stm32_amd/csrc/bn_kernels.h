@@ -66,8 +66,8 @@ constexpr int kGuardBudget = 48;  // float64 re-evaluations stft_minmax_exact_ke
 struct StftGuard {
     float* eps;    // [B][W] per-frame bound on |S' - S|
     int* rec;      // [B][ceil(W / 16)][kGuardRec]
-    int* list;     // [B][cap] flagged elements (frame << 16 | bin)
-    int* count;    // [B]
+    int* list;     // (unused since the mel mixer re-evaluates its own elements)
+    int* count;    // [B] elements found in doubt; > cap: a workgroup of the mixer gave up on the chunk
     int cap;
     int* dirty;    // [B] bit per 64-frame block whose quantised bytes changed
     int* work;     // [B * ceil(W / 64)] dirty (chunk, block) pairs
@@ -75,6 +75,9 @@ struct StftGuard {
     int* hard;     // [2][hard_cap] chunks recomputed as whole float64 spectrograms: behind the min / max pass, behind the fix pass
     int* n_hard;   // [2]
     int hard_cap;
+    const float* audio;  // [B][T] the chunks' samples, their geometry and the float64 tables: the mel mixer re-evaluates the elements it finds
+    int T, hop;          // in doubt itself (set per call by bn_infer_audio)
+    StftTables tabs;
 };
 
 // ---- STFT ------------------------------------------------------------------------------

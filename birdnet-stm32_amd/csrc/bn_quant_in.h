@@ -93,8 +93,11 @@ constexpr float kGuardL2 = 48.0f * kGuardU, kGuardPeak = 8.0f * kGuardU, kGuardR
 __device__ __forceinline__ float guard_hi(float s, float eps_f) { return __builtin_fmaf(s, kGuardRel, s) + eps_f; }
 __device__ __forceinline__ float guard_lo(float s, float eps_f) { return __builtin_fmaf(-s, kGuardRel, s) - eps_f; }
 
-// The quantiser input v = value(S') moves by at most eps / (rng * scale) when S' moves by eps, plus 3 roundings of relative size u
-// on either evaluation (|v| <= 256: 2 * 4.6e-5) and one rounding of v + 0.5 in the test itself (1.5e-5).
-constexpr float kQuantSlack = 1.25e-4f;
+// From the bound on S to the band around a rounding boundary: the quantiser's argument v = value(S') moves by at most
+// eps(S') / (range * scale) when S' moves by eps(S'); both evaluations of value() carry three roundings of relative size u each
+// (6 u v together) and the test's own v + 0.5 one more (u (v + 1)).  With v <= S' / (range * scale) the v-proportional part rides on the
+// S'-proportional term of the bound (kBandRel), what is left is a constant of a few u (kQuantSlack).
+constexpr float kBandRel = kGuardRel + 8.0f * kGuardU;
+constexpr float kQuantSlack = 4.0f * kGuardU;
 
 }  // namespace bn

@@ -10,12 +10,12 @@
 //                                          chunk's extrema (elements within the bound of the tile's largest / smallest value)
 //   K2  stft_minmax_exact_kernel           the candidates that can still be the chunk's max / min re-evaluated in float64
 //                                          (512-term DFT per element, a wave per element) -> the EXACT float32 min / max
-//   K3  i8_mel_mfma_kernel<QIN, flagging>  quantises S' with the exact min / max and lists every element whose byte could differ
-//                                          for some S within [S' - eps, S' + eps] (the quantiser is monotone: test the distance
-//                                          of its argument to the next rounding boundary)
-//   K4  stft_fix_kernel                    listed elements in float64 -> exact S patched into the spectrogram; a changed byte
-//                                          marks its (chunk, 64-frame block) dirty
-//   K5  i8_mel_mfma_kernel<QIN, worklist>  the mel mixer again for the dirty blocks only.
+//   K3  i8_mel_mfma_kernel<QIN, flagging>  quantises S' with the exact min / max, finds every element whose byte could differ for
+//                                          some S within [S' - eps, S' + eps] (the quantiser is monotone: test the distance of its
+//                                          argument to the next rounding boundary) and re-evaluates those elements in float64 ITSELF
+//                                          (512-term DFT by a 16-lane row, bn_exact_dft.h) before the tile is multiplied
+//   K4  stft_fix_kernel + K5  i8_mel_mfma_kernel<QIN, worklist>   only for chunks in which a workgroup of K3 found more elements in
+//                                          doubt than it keeps (none for sane audio): whole chunk in float64, its blocks once more.
 //
 // Elements that are not listed have the same byte for every S the bound allows, listed ones are exact: the bytes equal the
 // oracle's (oracle/stft.py + oracle/int8_graph.py) as long as the float64 DFT here and numpy's float64 FFT round to the same
@@ -25,6 +25,7 @@
 // bn_infer_audio's INT8 route whenever the guarded fast path does not apply (debug plans, layout / kernel A-B options).
 #include "bn_kernels.h"
 #include "bn_quant_in.h"
+#include "bn_exact_dft.h"
 
 #pragma clang fp contract(off)
 
@@ -36,76 +37,6 @@ constexpr int kFT = 16;  // frames per tile (= stft512_mag_kernel's workgroup)
 
 __device__ __forceinline__ size_t spec_offset(int W, bool tile_major, int k, int t) {
     return tile_major ? (size_t)(t / kFT) * 257 * kFT + (size_t)k * kFT + (t % kFT) : (size_t)k * W + t;
-}
-
-// float64 sums over the 16 lanes of a DPP row (quad swaps, rotations by 4 and 8): no LDS traffic
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-    const long bits = __builtin_bit_cast(long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
-    return __builtin_bit_cast(double, ((long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ double row16_sum_d(double v) {
-    v += dpp_d<0xB1>(v);
-    v += dpp_d<0x4E>(v);
-    v += dpp_d<0x124>(v);
-    v += dpp_d<0x128>(v);
-    return v;
-}
-
-// LDS copy of the twiddles as (cos, sin) pairs: ONE 16-byte gather per term.  Entry e sits at slot e + (e >> 4): a lane group walks the
-// table with stride k, and without the skew every k that is a multiple of 16 would put its 16 lanes on one bank.
-struct ExactTabs {
-    double2 cs[512 + 32];
-};
-__device__ __forceinline__ int cs_slot(int e) { return e + (e >> 4); }
-__device__ __forceinline__ void stage_tabs(ExactTabs& tl, const StftTables& tb) {
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) tl.cs[cs_slot(i)] = make_double2(tb.cs64[i], tb.cs64[(i + 384) & 511]);  // sin(a) = cos(a - pi/2); sin(0) = 0 exactly
-}
-// the window values of a lane's 16 sample pairs n = (lane & 15) + 16 i (hann[512 - n] = hann[n]): fetched once, kept in registers
-struct LaneWindow {
-    double w[16];
-    __device__ __forceinline__ void load(const StftTables& tb) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = tb.hann64[(threadIdx.x & 15) + 16 * i];
-    }
-};
-
-// |X_k| of frame t the way the reference evaluates it: float64 window product, float64 DFT, complex64, numpy's |.|.
-// A GROUP of 16 lanes (one DPP row) evaluates one element; the four groups of a wave work on four elements at once.  Samples
-// n and 512 - n share their cosine and have opposite sines (and the same window value), so a lane takes 16 such pairs:
-//   re = sum_n (xw[n] + xw[512 - n]) cos(2 pi k n / 512),   im = -sum_n (xw[n] - xw[512 - n]) sin(2 pi k n / 512),   n = 1..255,
-// with xw[0] + (-1)^k xw[256] riding on n = 0 (cos = 1, sin = 0).  Tree sum inside the row; every lane of the group returns the value.
-__device__ __forceinline__ float exact_mag_row(const ExactTabs& tl, const LaneWindow& lw, const float* __restrict__ x, int T, int hop, int t, int k) {
-    const int gl = threadIdx.x & 15;
-    // range-checked raw buffer loads over exactly this chunk: samples before / behind it read as 0 (librosa's centre padding) with no
-    // branch around the load, so all 32 loads of a lane are in flight together (as conditional loads they ran one round trip at a time:
-    // 20 us per element)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
-    const int base = (t * hop - 256) * 4;  // byte offset of the frame's first sample (negative = out of range as unsigned)
-    float xa[16], xb[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int n = gl + 16 * i;
-        xa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * n, 0, 0));
-        xb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * (n == 0 ? 256 : 512 - n), 0, 0));
-    }
-    double re = 0.0, im = 0.0;
-    int idx = k * gl;  // k n mod 512, n = gl + 16 i
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const double va = (double)xa[i] * lw.w[i];
-        double vb = (double)xb[i] * ((i == 0 && gl == 0) ? 1.0 : lw.w[i]);  // n = 0 pairs with n = 256: hann[256] = 1
-        if (i == 0 && gl == 0 && (k & 1)) vb = -vb;
-        const double2 c = tl.cs[cs_slot(idx & 511)];
-        re = fma(va + vb, c.x, re);
-        im = fma(va - vb, c.y, im);
-        idx += 16 * k;
-    }
-    re = row16_sum_d(re);
-    im = row16_sum_d(im);
-    return numpy_cabsf((float)re, (float)im);
 }
 
 // ------------------------------------------------------------------------------------------------ whole spectrogram in float64
@@ -339,52 +270,19 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K4: listed elements in float64
-__global__ __launch_bounds__(256) void stft_fix_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
-                                                       float* __restrict__ spec, int tile_major, StftGuard g,
-                                                       const float* __restrict__ minmax, float qscale, int qzp) {
-    __shared__ ExactTabs tl;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = g.count[b];
-    if (n == 0) return;
+// ------------------------------------------------------------------------------------------------ K4: chunks the mel mixer gave up on
+// The mel mixer (i8_mel_mfma_kernel<QIN, 1>) re-evaluates the elements it finds in doubt itself.  A workgroup of it that finds more than
+// it can keep (> 1022 of its 16 448: no sane audio does) raises the chunk's count beyond `cap`: that chunk is recomputed as a whole float64
+// spectrogram (stft512_f64_list_kernel on the second list) and all its blocks go through the mixer again.
+__global__ __launch_bounds__(256) void stft_fix_kernel(StftGuard g, int B, int W) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || g.count[b] <= g.cap) return;
     const int tiles64 = (W + 63) / 64;
-    if (n > g.cap) {
-        // more flagged elements than the chunk's list holds: the whole chunk in float64 (stft512_f64_list_kernel on the second list),
-        // every block of it through the mel mixer again
-        if (tid == 0) {
-            g.hard[g.hard_cap + atomicAdd(g.n_hard + 1, 1)] = b;
-            const int all = tiles64 >= 32 ? -1 : (1 << tiles64) - 1;
-            const int old = atomicOr(g.dirty + b, all);
-            for (int i = 0; i < tiles64; ++i)
-                if (!(old >> i & 1)) g.work[atomicAdd(g.n_work, 1)] = b * tiles64 + i;
-        }
-        return;
-    }
-    stage_tabs(tl, tb);
-    LaneWindow lw;
-    lw.load(tb);
-    const float* x = audio + (size_t)b * T;
-    float* S = spec + (size_t)b * 257 * W;
-    QuantIn qi;
-    qi.set(minmax + 2 * b, qscale, qzp);
-    const int* list = g.list + (size_t)b * g.cap;
-    __syncthreads();
-    const int grp = tid >> 4, gl = tid & 15;  // 16 groups of 16 lanes: 16 elements at a time
-    for (int i0 = 0; i0 < n; i0 += 16) {
-        const bool act = i0 + grp < n;
-        const int e = act ? list[i0 + grp] : 0;
-        const int t = e >> 16, k = e & 0xffff;
-        const size_t off = spec_offset(W, tile_major != 0, k, t);
-        const float old = act ? S[off] : 0.0f;
-        const float ex = exact_mag_row(tl, lw, x, T, hop, t, k);
-        if (act && gl == 0) {
-            S[off] = ex;
-            if (qi.q(old) != qi.q(ex)) {
-                const int bit = 1 << (t / 64);
-                if (!(atomicOr(g.dirty + b, bit) & bit)) g.work[atomicAdd(g.n_work, 1)] = b * tiles64 + t / 64;
-            }
-        }
-    }
+    g.hard[g.hard_cap + atomicAdd(g.n_hard + 1, 1)] = b;
+    const int all = tiles64 >= 32 ? -1 : (1 << tiles64) - 1;
+    const int old = atomicOr(g.dirty + b, all);
+    for (int i = 0; i < tiles64; ++i)
+        if (!(old >> i & 1)) g.work[atomicAdd(g.n_work, 1)] = b * tiles64 + i;
 }
 
 // test hook: the bytes QUANTIZE makes of the spectrogram as it lies in the workspace, [B][257][W] frequency-major
@@ -424,7 +322,9 @@ void launch_stft_minmax_exact(const StftTables& tb, const float* audio, int B, i
 
 void launch_stft_fix(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, bool tile_major, const StftGuard& g,
                      const float* minmax, float qscale, int qzp, hipStream_t s) {
-    hipLaunchKernelGGL(stft_fix_kernel, dim3(B), dim3(256), 0, s, tb, audio, T, hop, W, spec, tile_major ? 1 : 0, g, minmax, qscale, qzp);
+    (void)qscale;
+    (void)qzp;
+    hipLaunchKernelGGL(stft_fix_kernel, dim3((B + 255) / 256), dim3(256), 0, s, g, B, W);
     // (minmax is exact already: the atomics of this pass find the same values)
     hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(128), dim3(256), 0, s, tb, audio, T, hop, W, spec, const_cast<float*>(minmax), tile_major ? 1 : 0,
                        g.hard + g.hard_cap, g.n_hard + 1, (float*)nullptr);
