@@ -178,7 +178,6 @@ bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
     const size_t W = m->hdr.spec_width;
     g.eps += b0 * W;
     g.rec += b0 * ((W + 15) / 16) * bn::kGuardRec;
-    g.list += b0 * (size_t)g.cap;
     g.count += b0;
     g.dirty += b0;
     g.audio = m->guard_audio;  // (already offset to the launch group's first chunk by bn_infer_audio)

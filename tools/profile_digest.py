@@ -100,6 +100,22 @@ def main():
         mean = lambda v: sum(v) / max(len(v), 1)  # noqa: E731
         traffic.append({"kernel": key[0], "grid_threads": int(key[1]), "read_bytes": int(2 * mean(f) * 1024), "write_bytes": int(mean(w) * 1024)})
     open(re.sub(r"_digest\.md$|\.md$", "", out) + "_traffic.json", "w").write(json.dumps(traffic, indent=1) + "\n")
+    # machine-readable SQ counters per launch, read back by bench.py for roofline.valu_issue_frac / lds_wait
+    s2 = pmc(sq2_dir) if sq2_dir else {}
+    sqrows = []
+    mean = lambda v: sum(v) / max(len(v), 1)  # noqa: E731
+    for key in sorted(sq):
+        c, d = sq[key], s2.get(key, {})
+        waves = mean(c.get("SQ_WAVES", [1])) or 1
+        wc = mean(d.get("SQ_WAVE_CYCLES", [0])) or 0
+        row = {"kernel": key[0], "grid_threads": int(key[1]), "waves": int(waves), "valu_insts": int(mean(c.get("SQ_INSTS_VALU", [0]))),
+               "valu_insts_per_wave": round(mean(c.get("SQ_INSTS_VALU", [0])) / waves, 1), "mfma_insts_per_wave": round(mean(c.get("SQ_INSTS_MFMA", [0])) / waves, 1),
+               "lds_conflict_cycles_per_wave": round(mean(c.get("SQ_LDS_BANK_CONFLICT", [0])) / waves, 1)}
+        if wc:
+            row.update({"parked_frac": round(mean(d.get("SQ_WAIT_ANY", [0])) / wc, 3), "issue_stalled_frac": round(mean(d.get("SQ_WAIT_INST_ANY", [0])) / wc, 3),
+                        "issuing_frac": round(mean(d.get("SQ_ACTIVE_INST_ANY", [0])) / wc, 3), "lds_insts_per_wave": round(mean(d.get("SQ_INSTS_LDS", [0])) / waves, 1)})
+        sqrows.append(row)
+    open(re.sub(r"_digest\.md$|\.md$", "", out) + "_sq.json", "w").write(json.dumps(sqrows, indent=1) + "\n")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
