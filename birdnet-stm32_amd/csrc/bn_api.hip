@@ -683,7 +683,7 @@ int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
     HIP_TRY(hipMemcpy(c->d_tw512, t512.data(), t512.size() * sizeof(float4), hipMemcpyHostToDevice));
     // float64 tables of the exactness pass: cos(2 pi j / 512) with the symmetries exact (cs[128] = 0, cs[j] = -cs[256 - j], ...),
     // the reference's periodic Hann window 0.5 - 0.5 cos(2 pi n / 512) from it
-    std::vector<double> f64tab(1024);
+    std::vector<double> f64tab(2048);
     for (int j = 0; j < 512; ++j) {
         const int a2 = j <= 256 ? j : 512 - j;                 // cos is even about pi
         const int a3 = a2 <= 128 ? a2 : 256 - a2;              // and odd about pi / 2
@@ -692,9 +692,13 @@ int bn_ctx_create(int device, int max_batch, bn_ctx** out) {
         if (a3 == 128) f64tab[512 + j] = 0.0;
     }
     for (int n = 0; n < 512; ++n) f64tab[n] = 0.5 - 0.5 * f64tab[512 + n];
+    for (int j = 0; j < 512; ++j) {  // (cos, sin) pairs: sin(a) = cos(a - pi / 2)
+        f64tab[1024 + 2 * j] = f64tab[512 + j];
+        f64tab[1024 + 2 * j + 1] = f64tab[512 + ((j + 384) & 511)];
+    }
     HIP_TRY(hipMalloc(&c->d_f64tab, f64tab.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(c->d_f64tab, f64tab.data(), f64tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    c->tables = bn::StftTables{c->d_window, c->d_tw256, c->d_tw512, c->d_f64tab, c->d_f64tab + 512};
+    c->tables = bn::StftTables{c->d_window, c->d_tw256, c->d_tw512, c->d_f64tab, c->d_f64tab + 512, reinterpret_cast<const double2*>(c->d_f64tab + 1024)};
     // bn_ingest_resample's per-workgroup peak scratch (one float per >= 1024 resampled samples): sized here for windows that
     // yield max_batch 3 s chunks at 24 kHz (72 blocks per chunk) with headroom, so that the ingest call itself does not allocate
     // (no hidden device sync on that path); a call that needs more still grows it, once.

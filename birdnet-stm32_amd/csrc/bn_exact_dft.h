@@ -62,8 +62,21 @@ struct LdsWindow {  // the same values read from ExactTabsW::hann at each use
 // n and 512 - n share their cosine and have opposite sines (and the same window value), so a lane takes 16 such pairs:
 //   re = sum_n (xw[n] + xw[512 - n]) cos(2 pi k n / 512),   im = -sum_n (xw[n] - xw[512 - n]) sin(2 pi k n / 512),   n = 1..255,
 // with xw[0] + (-1)^k xw[256] riding on n = 0 (cos = 1, sin = 0).  Tree sum inside the row; every lane of the group returns the value.
-template <class Window>
-__device__ __forceinline__ float exact_mag_row(const ExactTabs& tl, const Window& lw, const float* __restrict__ x, int T, int hop, int t, int k) {
+// twiddles straight from the (cos, sin) table in global memory (8 KB, L1 / L2 resident) and the window derived from them
+// (0.5 - 0.5 cos has one rounding, like the host's table): for callers that re-evaluate a dozen elements and would spend more on
+// staging 12 KB into LDS behind a barrier than on the gathers
+struct GlobalTabs {
+    const double2* cs2;
+};
+__device__ __forceinline__ double2 twiddle(const ExactTabs& tl, int e) { return tl.cs[cs_slot(e)]; }
+__device__ __forceinline__ double2 twiddle(const GlobalTabs& tl, int e) { return tl.cs2[e]; }
+struct GlobalWindow {
+    const double2* cs2;
+    __device__ __forceinline__ double at(int i) const { return fma(-0.5, cs2[(threadIdx.x & 15) + 16 * i].x, 0.5); }
+};
+
+template <class Tabs, class Window>
+__device__ __forceinline__ float exact_mag_row(const Tabs& tl, const Window& lw, const float* __restrict__ x, int T, int hop, int t, int k) {
 #pragma clang fp contract(off)
     const int gl = threadIdx.x & 15;
     // range-checked raw buffer loads over exactly this chunk: samples before / behind it read as 0 (librosa's centre padding) with no
@@ -86,7 +99,7 @@ __device__ __forceinline__ float exact_mag_row(const ExactTabs& tl, const Window
         const double va = (double)xa[i] * w;
         double vb = (double)xb[i] * ((i == 0 && gl == 0) ? 1.0 : w);  // n = 0 pairs with n = 256: hann[256] = 1
         if (i == 0 && gl == 0 && (k & 1)) vb = -vb;
-        const double2 c = tl.cs[cs_slot(idx & 511)];
+        const double2 c = twiddle(tl, idx & 511);
         re = fma(va + vb, c.x, re);
         im = fma(va - vb, c.y, im);
         idx += 16 * k;

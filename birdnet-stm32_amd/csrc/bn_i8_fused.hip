@@ -618,6 +618,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         const int nf = flag_n;
         if (tid == 0 && nf) atomicAdd(a.qguard.count + chunk, nf > kMelFlagCap ? a.qguard.cap + 1 : nf);  // (statistics; beyond `cap`: given up)
         if (nf > 0 && nf <= kMelFlagCap) {
+            // (twiddles and window staged into LDS, 12 KB behind one barrier: gathered straight from the table in L1 / L2 the kernel took 0.41 instead of 0.36 ms)
             ExactTabsW& xt = reinterpret_cast<ExactTabsW&>(xtabs_s);
             stage_tabs(xt, a.qguard.tabs);
             __syncthreads();

@@ -57,6 +57,7 @@ struct StftTables {
     const float4* tw512;    // [16] per-lane split-pass base: (-sin a_j, -cos a_j, -cos a_j, sin a_j), a_j = 2 pi j / 512
     const double* hann64;   // [512] 0.5 - 0.5 cos(2 pi n / 512): the reference's float64 window (bn_stft_exact.hip)
     const double* cs64;     // [512] cos(2 pi j / 512) with exact symmetries (sin by index shift)
+    const double2* cs2;     // [512] (cos, sin)(2 pi j / 512): the same values as pairs
 };
 
 // Exactness pass of the INT8 audio path (bn_stft_exact.hip explains the five kernels).
