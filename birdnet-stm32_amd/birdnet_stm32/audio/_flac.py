@@ -3,7 +3,10 @@
 The reference reads FLAC (like every other container) through libsndfile (reference: birdnet_stm32/audio/io.py:90,114-116);
 ``soundfile`` is not on the MI355X image.  ``read_flac_window`` returns the samples the way ``soundfile.read(dtype='float32',
 always_2d=True)`` does — integers scaled by ``2^-(bits-1)`` — plus the raw integers for the device ingest, which uploads PCM as
-int16 / int32 and does the arithmetic on the GPU.  The decoded audio is checked against the stream's MD5 when the file carries one.
+int16 / int32 and does the arithmetic on the GPU.  Whenever a WHOLE stream is decoded (``decode_flac`` from frame 0 to the end: what the
+length pass of ``load_audio_window`` / ``read_pcm_window`` does once per file that does not state its length, and any caller that asks for
+everything) the audio is checked against the stream's MD5 when the file carries one; a window read of a longer file is covered by the
+per-frame CRC-16 only, like libsndfile's.
 """
 
 from __future__ import annotations
@@ -28,6 +31,7 @@ def _load():
                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]
         lib.bn_flac_decode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         lib.bn_flac_decode.restype = ctypes.c_int64
+        lib.bn_flac_md5.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
         _lib = lib
     return _lib
 
@@ -48,10 +52,13 @@ def flac_info(raw: bytes) -> tuple[int, int, int, int]:
 def decode_flac(raw: bytes, first: int = 0, count: int | None = None, verify_md5: bool = True) -> tuple[np.ndarray, int, int]:
     """Decode frames ``[first, first + count)``: ``(int32 [n, channels], sample rate, bits per sample)``."""
     sr, ch, bps, total = flac_info(raw)
+    # no more frames than the bytes can hold: a frame is at least 11 bytes and carries at most 65 535 samples per channel (a forged
+    # STREAMINFO total or an absurd `count` must not size the output buffer)
+    ceiling = (len(raw) // 11 + 1) * 65535
     if count is not None:
-        want = count
+        want = min(int(count), ceiling)
     elif total:
-        want = max(total - first, 0)
+        want = min(max(total - first, 0), ceiling)
     else:  # the stream does not state its length (total = 0): count by decoding once without storing — no bound follows from the file size
         want = _load().bn_flac_decode(raw, len(raw), int(first), (1 << 62), None)  # (a constant subframe holds 65 535 samples in a few bytes)
         if want < 0:
@@ -61,7 +68,8 @@ def decode_flac(raw: bytes, first: int = 0, count: int | None = None, verify_md5
     if n < 0:
         raise ValueError(_ERRORS.get(int(n), f"FLAC error {n}"))
     out = out[:n]
-    if verify_md5 and first == 0 and total and n == total:
+    whole = first == 0 and (n == total if total else count is None)
+    if verify_md5 and whole:
         md5 = _stream_md5(raw)
         if md5 != b"\x00" * 16:
             width = (bps + 7) // 8
@@ -72,15 +80,12 @@ def decode_flac(raw: bytes, first: int = 0, count: int | None = None, verify_md5
 
 
 def _stream_md5(raw: bytes) -> bytes:
-    pos = raw.find(b"fLaC") + 4
-    while True:
-        last, kind = raw[pos] >> 7, raw[pos] & 0x7F
-        length = int.from_bytes(raw[pos + 1 : pos + 4], "big")
-        if kind == 0:
-            return raw[pos + 4 + 18 : pos + 4 + 34]
-        pos += 4 + length
-        if last:
-            return b"\x00" * 16
+    """STREAMINFO's MD5 as the C parser locates it (behind an ID3v2 tag, at the marker it accepted — not the first ``fLaC`` byte pattern)."""
+    out = ctypes.create_string_buffer(16)
+    rc = _load().bn_flac_md5(raw, len(raw), out)
+    if rc:
+        raise ValueError(_ERRORS.get(rc, f"FLAC error {rc}"))
+    return out.raw
 
 
 def read_flac_window(raw: bytes, first: int, count: int) -> tuple[np.ndarray, np.ndarray, int, int]:

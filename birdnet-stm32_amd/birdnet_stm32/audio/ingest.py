@@ -93,7 +93,7 @@ def read_pcm_window(path: str, max_duration: float | None = 30, chunk_duration: 
                 raw = fh.read()
             sr0, ch, bps, total = _flac.flac_info(raw)
             if total == 0:
-                total = int(_flac.decode_flac(raw, verify_md5=False)[0].shape[0])
+                total = int(_flac.decode_flac(raw)[0].shape[0])  # (the whole stream: checked against its MD5)
             first, count = _window_frames(total, sr0, max_duration, chunk_duration, random_offset)
             if count <= 0:
                 return None

@@ -128,7 +128,7 @@ def _read_window(path: str, max_duration, chunk_duration: float, random_offset: 
             raw = fh.read()
         sr0, _ch, _bps, total = _flac.flac_info(raw)
         if total == 0:  # length not recorded in STREAMINFO: decode once to learn it
-            total = int(_flac.decode_flac(raw, verify_md5=False)[0].shape[0])
+            total = int(_flac.decode_flac(raw)[0].shape[0])  # (the whole stream: checked against its MD5)
         reader = lambda first, count: _flac.read_flac_window(raw, first, count)[0]  # noqa: E731
     else:
         import soundfile as sf  # not installed on the MI355X image: such files count as unreadable

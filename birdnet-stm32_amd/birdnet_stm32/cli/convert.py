@@ -52,7 +52,7 @@ def main(argv=None):
         raise SystemExit("--quantization dynamic needs the TensorFlow converter; this build implements 'ptq'.")
     if args.export_onnx:
         raise SystemExit("--export_onnx needs tf2onnx; not part of this build.")
-    from birdnet_stm32.conversion.quantize import representative_data_gen, requantize_like
+    from birdnet_stm32.conversion.quantize import TopologyMismatch, representative_data_gen, requantize_like
     from birdnet_stm32.conversion.validate import validate_models
     from birdnet_stm32.data.dataset import load_file_paths_from_directory
     from birdnet_stm32.models._keras_loader import load_keras_archive
@@ -105,12 +105,17 @@ def main(argv=None):
         args.output_path = os.path.splitext(args.checkpoint_path)[0] + "_quantized.tflite"
     os.makedirs(os.path.dirname(args.output_path) or ".", exist_ok=True)
     new = None
+    template_is_default = os.path.abspath(args.template) == os.path.abspath(_DEFAULT_TEMPLATE)
     if args.template.lower() != "none":
         try:
             new = requantize_like(load_tflite(args.template), spec, rep, per_tensor=args.per_tensor)
             with open(args.template, "rb") as fh:
                 raw = patch_tflite(fh.read(), new)
-        except (ValueError, NotImplementedError) as e:
+        except TopologyMismatch as e:
+            # only this, and only for the DEFAULT template: a template the user named must fit (another graph form would be a different
+            # artefact under the same exit code), and any other failure (a patch size mismatch, an unsupported operator) is a bug to see
+            if not template_is_default:
+                raise
             print(f"Template {os.path.basename(args.template)} does not fit this model ({e}); writing the graph from the model itself.")
             new = None
     if new is None:

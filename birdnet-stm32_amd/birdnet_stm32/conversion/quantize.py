@@ -257,29 +257,34 @@ def _backbone_kernels(spec: ns.NetSpec):
             bn = nxt[0] if len(nxt) == 1 and nxt[0].kind == ns.BN else None
             k, b = fold_bn(ly.weights["kernel"], bn)
             if "bias" in ly.weights:
-                raise NotImplementedError(f"{ly.name}: convolution with its own bias")
+                raise TopologyMismatch(f"{ly.name}: convolution with its own bias")
             out.append((ly.name, ly.kind, k, b))
         elif ly.kind == ns.DENSE:
             if "bias" not in ly.weights or ly is not spec.layers[-1]:
-                raise NotImplementedError(f"{ly.name}: only the classifier Dense is quantised (squeeze-excite Dense layers have no INT8 kernels)")
+                raise TopologyMismatch(f"{ly.name}: a Dense layer that is not the classifier (squeeze-excite): not the template's layer family")
             out.append((ly.name, ly.kind, ly.weights["kernel"].astype(np.float32), ly.weights["bias"].astype(np.float32)))
         elif ly.kind not in _PLAIN_KINDS:
-            raise NotImplementedError(f"{ly.name}: layer kind {ly.kind!r} has no INT8 kernels (squeeze-excite / attention pooling)")
+            raise TopologyMismatch(f"{ly.name}: layer kind {ly.kind!r} (squeeze-excite / attention pooling) is not in the template's layer family")
     return out
+
+
+class TopologyMismatch(ValueError):
+    """The float model is not the template's topology (another layer list, kernel shape or layer family): the template cannot describe it.
+    Distinct from every other failure of :func:`requantize_like` so that a caller may fall back to the template-free exporter on THIS only."""
 
 
 def requantize_like(template: TfliteModel, spec: ns.NetSpec, rep_data_gen, per_tensor: bool = False) -> TfliteModel:
     """Quantise the float model ``spec`` into a new INT8 graph with the operator structure of ``template`` (module docstring)."""
     fa = spec.frontend.attrs
     if fa["mode"] != "hybrid":
-        raise NotImplementedError("own PTQ covers the hybrid-frontend DS-CNN family")
+        raise TopologyMismatch("the template graph has the hybrid frontend, the float model does not")
     T = template.tensors
     conv_ops = [op for op in template.ops if op.name in ("CONV_2D", "DEPTHWISE_CONV_2D", "FULLY_CONNECTED")]
     # the backbone starts at the first 3x3 CONV_2D (the stem); everything before it is the frozen frontend
     first = next(k for k, op in enumerate(conv_ops) if op.name == "CONV_2D" and T[op.inputs[1]].shape[1:3] == (3, 3))
     kernels = _backbone_kernels(spec)
     if len(kernels) != len(conv_ops) - first:
-        raise ValueError(f"template has {len(conv_ops) - first} backbone convolutions, the float model {len(kernels)}: not the same topology")
+        raise TopologyMismatch(f"template has {len(conv_ops) - first} backbone convolutions, the float model {len(kernels)}: not the same topology")
 
     consts: dict[int, np.ndarray] = {t.index: (_dequant(t) if t.is_quantized else np.asarray(t.data)) for t in T if t.data is not None}
     float_wb: dict[int, tuple[np.ndarray, np.ndarray]] = {}  # operator index -> (kernel in TFLite layout, bias), real-valued
@@ -292,9 +297,9 @@ def requantize_like(template: TfliteModel, spec: ns.NetSpec, rep_data_gen, per_t
         elif op.name == "FULLY_CONNECTED" and kind == ns.DENSE:
             w = k.T
         else:
-            raise ValueError(f"operator {op.index} ({op.name}) does not line up with layer {name} ({kind})")
+            raise TopologyMismatch(f"operator {op.index} ({op.name}) does not line up with layer {name} ({kind})")
         if tuple(w.shape) != tuple(want):
-            raise ValueError(f"layer {name}: kernel {w.shape} vs template {want}")
+            raise TopologyMismatch(f"layer {name}: kernel {w.shape} vs template {want}")
         float_wb[op.index] = (w.astype(np.float32), b.astype(np.float32))
         consts[op.inputs[1]], consts[op.inputs[2]] = float_wb[op.index]
     for op in conv_ops[:first]:  # frontend: constants of the template, real-valued

@@ -96,6 +96,8 @@ struct bn_model {
     std::vector<uint8_t> rq_right;       // per operator: all requantisation multipliers >= 0 and shifts < 0
     std::vector<bn::Tail8Args> tails;    // per operator: arguments of the fused tail kernel (BN_OP_I8_TAIL operators only)
     std::vector<uint8_t> tail_ok;        // per operator: BN_OP_I8_TAIL whose maps fit the kernel's LDS plan
+    std::vector<uint8_t> out_valid;      // per operator: it wrote its output slot in the last forward call (not when a fused kernel covered it)
+    std::vector<uint8_t> slot_valid;     // per slot: some operator wrote it in the last forward call
     bool has_tail = false;               // the plan holds a usable fused tail operator
     bool spec_tiled_ok = false;          // the plan's first operator reads the spectrogram through i8_mel_mfma_kernel<QIN>: bn_infer_audio
                                          // may hand it the tile-major layout the STFT writes fastest
@@ -168,9 +170,12 @@ struct ProfScope {
     ~ProfScope() { end(); }
 };
 
-// A fused kernel runs its head operator and the partner(s) the packer tagged as ONE launch: only when both belong to the same entry path
-// (a partner of the other path would be skipped by the operator loop on its own, or run without its head: separate launches then).
-inline bool same_path(const OpRec& head, const OpRec& partner) { return head.p[BN_OP_PATH] == partner.p[BN_OP_PATH]; }
+// A fused kernel runs its head operator and the partner(s) the packer tagged as ONE launch: only when the partner runs wherever the head
+// does — it belongs to both entry paths (the usual case: one head per path in front of a shared block) or to the head's own.  A partner of
+// the OTHER path would not run at all in this mode: separate launches then.
+inline bool same_path(const OpRec& head, const OpRec& partner) {
+    return partner.p[BN_OP_PATH] == BN_PATH_BOTH || partner.p[BN_OP_PATH] == head.p[BN_OP_PATH];
+}
 
 // The exactness pass's buffers for the chunks from b0 on (the work list is shared: one launch group at a time uses it).
 bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
@@ -266,6 +271,9 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         a.rq_right = m->rq_right[di];
         return a;
     };
+    m->out_valid.resize(m->ops.size());
+    for (size_t oi = op_begin; oi < op_end; ++oi) m->out_valid[oi] = 0;
+    if (op_begin == 0) m->slot_valid.assign(m->d_slots.size(), 0);
     for (size_t oi = op_begin; oi < op_end; ++oi) {
         const OpRec& o = m->ops[oi];
         const int* p = o.p;
@@ -274,6 +282,17 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
+        m->out_valid[oi] = 1;  // (a fused kernel that keeps this operator's map on chip clears it again and marks the partner it wrote)
+        auto mark_slot = [&](int sid, int v) {
+            if (sid >= 0 && (size_t)sid < m->slot_valid.size()) m->slot_valid[sid] = (uint8_t)v;
+        };
+        mark_slot(o.out, 1);
+        auto fused_into = [&](size_t partner) {
+            m->out_valid[oi] = 0;
+            mark_slot(o.out, 0);
+            m->out_valid[partner] = 1;
+            mark_slot(m->ops[partner].out, 1);
+        };
         char* in0 = slot_ptr(o.in0);
         char* in1 = slot_ptr(o.in1);
         char* out = slot_ptr(o.out);
@@ -322,6 +341,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                                 q[8], q[9], q[5], &st, gap_target(oi + 2), s)) {
                             pwdw_head_done = oi + 1;
                             pwdw_done = oi + 2;
+                            fused_into(oi + 2);
                             gap_for = cand_for;
                             gap_R = cand_R;
                             break;
@@ -365,6 +385,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                         bn::launch_f32_pwdw(a, (const float*)m->tensor(d.t[0]), (const float*)m->tensor(d.t[1]), (float*)slot_ptr(d.out), q[3], q[6], q[7], q[8],
                                             q[9], q[5], nullptr, gap_target(oi + 1), s)) {
                         pwdw_done = oi + 1;
+                        fused_into(oi + 1);
                         gap_for = cand_for;
                         gap_R = cand_R;
                         break;
@@ -392,6 +413,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                         const bn::DwPwArgs da = dwpw_args(d);
                         if (p[2] == 16 && p[3] == 32 && bn::f32_front2_supported(f, da) && bn::launch_f32_front2(f, da, s)) {
                             front2_done = oi + (size_t)p[BN_OP_FRONT2_DIST];
+                            fused_into(front2_done);
                             break;
                         }
                     }
@@ -470,6 +492,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                             bn::launch_i8_pwdw(a, g, (const int8_t*)m->tensor(d.t[0]), (const int32_t*)m->tensor(d.t[1]), (const int32_t*)m->tensor(d.t[2]),
                                                (const int32_t*)m->tensor(d.t[3]), (int8_t*)slot_ptr(d.out), s)) {
                             pwdw_done = oi + 1;
+                            fused_into(oi + 1);
                             break;
                         }
                     }
@@ -562,6 +585,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                                              (const int32_t*)m->tensor(f2.t[3]), f2.p[5] ? (const int8_t*)m->tensor(f2.t[4]) : nullptr, s);
                         segate_done[0] = oi + 1;
                         segate_done[1] = oi + 2;
+                        fused_into(oi + 2);
                         break;
                     }
                 }
@@ -586,6 +610,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                         if (!a2.has_dw && !a2.transposed && bn::i8_pw_wave_takes(a2)) {
                             bn::launch_i8_dwpw(a2, s);
                             scale_done = oi + 1;
+                            fused_into(oi + 1);
                             break;
                         }
                     }
@@ -1242,6 +1267,12 @@ int bn_debug_op_output(bn_model* m, int op_index, int B, void* d_dst, size_t dst
     if (op_index < 0 || op_index >= (int)m->ops.size()) return fail(BN_ERR_ARG, "op_index %d out of range", op_index);
     const int sid = m->ops[op_index].out;
     if (sid < 0) return fail(BN_ERR_ARG, "operator %d writes a caller buffer, not a workspace slot", op_index);
+    // valid: the operator ran, or its twin of the other entry path wrote the same slot (plans keep one operator per path for the first stages)
+    bool valid = (size_t)op_index < m->out_valid.size() && m->out_valid[op_index];
+    if (!valid && (size_t)sid < m->slot_valid.size() && m->slot_valid[sid]) valid = true;
+    if (d_dst && !valid)
+        return fail(BN_ERR_UNSUPPORTED, "operator %d did not write its output in the last forward call: a fused kernel keeps that map on chip under the "
+                                        "current options", op_index);
     const size_t per = m->slots[sid].bytes_per_chunk;
     if (bytes_per_chunk) *bytes_per_chunk = per;
     if (!d_dst) return BN_OK;

@@ -1154,13 +1154,7 @@ bool launch_f32_pwdw(const DwPwArgs& e, const float* dw_w, const float* dw_b, fl
     const int nj = (e.Cin + 15) / 16, ncw = pwdw_ncw(e.W, e.Cout);
 #define BN_PWDW(NJV, SV, NCWV)                                                                                                              \
     if (nj == NJV && dsh == SV && ncw == NCWV) {                                                                                            \
-        static size_t allowed = 0;                                                                                                          \
-        if (smem > allowed) {                                                                                                               \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(f32_pwdw_kernel<NJV, SV, NCWV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)smem) != hipSuccess)                                                                               \
-                return false;                                                                                                               \
-            allowed = smem;                                                                                                                 \
-        }                                                                                                                                   \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(f32_pwdw_kernel<NJV, SV, NCWV>), smem)) return false;                            \
         hipLaunchKernelGGL((f32_pwdw_kernel<NJV, SV, NCWV>), dim3(blocks), dim3(stem ? 512 : 640), smem, s, a);  /* stem mode: no loader waves */                             \
         return true;                                                                                                                        \
     }
@@ -1206,12 +1200,7 @@ bool f32_front2_supported(const F32FrontStripArgs& f, const DwPwArgs& d) {
 
 bool launch_f32_front2(const F32FrontStripArgs& f, const DwPwArgs& d, hipStream_t s) {
     const size_t smem = ((size_t)(f.H0 + 4) * (f.W0 + 8) + 2 * (f.OW + 2) * 36) * 4 + (size_t)(f.OW / 16) * 256 * 16;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(f32_front2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return false;
-        raised = true;
-    }
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(f32_front2_kernel), 150 * 1024)) return false;
     F32Front2Args A{f, d.dw_w, d.dw_b, d.pw_w, d.pw_b, d.y, d.dw_act, d.pw_act};
     hipLaunchKernelGGL(f32_front2_kernel, dim3((unsigned)f.B), dim3(192 * (f.OW / 16)), smem, s, A);
     return true;

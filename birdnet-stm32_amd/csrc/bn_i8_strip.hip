@@ -445,13 +445,7 @@ void launch_strip(const Strip8Args& a, hipStream_t s) {
     const long per_chunk = (long)(W8 ? 1 : a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
     const long blocks = NW == 1 ? (a.B * per_chunk + SPB - 1) / SPB : ((a.B + SPB - 1) / SPB) * per_chunk;
     auto kern = i8_strip_kernel<CW, NW, COUT, S, ADD, W8>;
-    if (smem > 65536) {
-        static bool raised = false;  // one attribute call per instantiation
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            raised = true;
-        }
-    }
+    if (smem > 65536) (void)ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem);  // (a refusal shows as the launch's error)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW * SPB), smem, s, a);
 }
 

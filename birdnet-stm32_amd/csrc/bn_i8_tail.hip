@@ -476,12 +476,7 @@ long tail_const_words(const Tail8Args& a) {
 }
 
 bool launch_i8_tail(Tail8Args a, hipStream_t s) {
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(i8_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return false;
-        raised = true;
-    }
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(i8_tail_kernel), 160 * 1024)) return false;
     const int ngroups = (a.B + kTailG - 1) / kTailG;
     int cus = 256;
     const int grid = ngroups < cus ? ngroups : cus;  // one workgroup per CU (its LDS), each walks over its share of the chunk groups

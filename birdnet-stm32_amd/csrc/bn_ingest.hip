@@ -498,15 +498,12 @@ static void launch_resample_kernels(const ResampleArgs& a, int fmt, int n_files,
         return;
     }
     if (smem > 64 * 1024) {  // unusual ratios (96 kHz -> 22.05 kHz = 147/640, 11.025 -> 32 kHz = 1280/441): the whole polyphase filter needs up to ~110 KB
-        static size_t allowed[4] = {64 * 1024, 64 * 1024, 64 * 1024, 64 * 1024};  // per sample format: what the kernel may use so far
         const int f = fmt < 0 || fmt > 3 ? 3 : fmt;
-        if (smem > allowed[f]) {
-            const void* kernels[4] = {reinterpret_cast<const void*>(ingest_resample_kernel<0>), reinterpret_cast<const void*>(ingest_resample_kernel<1>),
-                                      reinterpret_cast<const void*>(ingest_resample_kernel<2>), reinterpret_cast<const void*>(ingest_resample_kernel<3>)};
-            // exactly what this launch needs (the kernel's static LDS comes on top; asking for the CU's whole 160 KB is refused)
-            if (hipFuncSetAttribute(kernels[f], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess) allowed[f] = smem;
-            else (void)hipGetLastError();  // the launch below reports the failure
-        }
+        const void* kernels[4] = {reinterpret_cast<const void*>(ingest_resample_kernel<0>), reinterpret_cast<const void*>(ingest_resample_kernel<1>),
+                                  reinterpret_cast<const void*>(ingest_resample_kernel<2>), reinterpret_cast<const void*>(ingest_resample_kernel<3>)};
+        // exactly what this launch needs (the kernel's static LDS comes on top; asking for the CU's whole 160 KB is refused); a refusal
+        // shows as the error of the launch below
+        (void)ensure_dynamic_lds(kernels[f], smem);
     }
     switch (fmt) {
         case 0: hipLaunchKernelGGL(ingest_resample_kernel<0>, grid, dim3(256), smem, s, a); break;

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bn_blob.h"
@@ -36,6 +39,25 @@ struct Options {
     int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
 };
 extern Options g_opt;
+
+// A kernel that needs more than the default 64 KB of dynamic LDS has its limit raised with hipFuncSetAttribute — per DEVICE (the attribute
+// belongs to the current device's copy of the function; bn_ctx_create takes a device index) and only when the request grows.  false: the
+// runtime refused (the caller falls back or reports the launch error).
+inline bool ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> allowed;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = allowed[{kernel, dev}];
+    if (bytes <= have) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    have = bytes;
+    return true;
+}
 
 // Load-time validation of a packed plan (bn_plan_check.hip): every operator's geometry against the slot and tensor sizes.
 bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const std::vector<TensorRec>& tensors,

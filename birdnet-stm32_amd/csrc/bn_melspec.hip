@@ -151,12 +151,9 @@ size_t melspec_finish_lds_bytes(int M, int W, int Wout, int mode, int mag, int n
 bool launch_melspec_finish(const float* mel, float* out, const float* dct, int B, int M, int W, int Wout, int mode, int mag,
                            int n_mfcc, double pcen_b, hipStream_t s) {
     const size_t smem = melspec_finish_lds_bytes(M, W, Wout, mode, mag, n_mfcc);
-    static bool raised = false;
-    if (smem + 64 > 64 * 1024 && !raised) {  // the static reduction scratch counts against the same limit
-        if (hipFuncSetAttribute((const void*)melspec_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
-            return false;
-        raised = true;
-    }
+    if (smem + 64 > 64 * 1024 &&  // the static reduction scratch counts against the same limit
+        !ensure_dynamic_lds((const void*)melspec_finish_kernel, 160 * 1024 - 64))
+        return false;
     FinishArgs a{mel, out, dct, M, W, Wout, mode, mag, n_mfcc, pcen_b};
     hipLaunchKernelGGL(melspec_finish_kernel, dim3(B), dim3(256), smem, s, a);
     return true;

@@ -6,7 +6,8 @@
  * Written from the format specification (RFC 9639): STREAMINFO, frame headers (fixed and variable block size, UTF-8 coded numbers,
  * CRC-8), CONSTANT / VERBATIM / FIXED / LPC subframes, Rice and Rice2 residuals with escape partitions, wasted bits, the three stereo
  * decorrelation modes, CRC-16 per frame.  Output: interleaved int32 samples at the stream's own bit depth (the caller scales by
- * 2^-(bps-1) like libsndfile).  The decoded audio's MD5 (STREAMINFO) is checked by the Python wrapper.
+ * 2^-(bps-1) like libsndfile).  The decoded audio's MD5 (STREAMINFO, bn_flac_md5) is checked by the Python wrapper whenever it decodes a
+ * whole stream (audio/_flac.py: decode_flac); a frame whose bit depth differs from STREAMINFO's is refused.
  */
 #include <stddef.h>
 #include <stdint.h>
@@ -76,6 +77,7 @@ typedef struct {
     int sample_rate, channels, bps, min_block, max_block;
     int64_t total;
     size_t first_frame; /* byte offset of the first audio frame */
+    uint8_t md5[16];    /* MD5 of the decoded audio as the encoder wrote it (all zero: none) */
 } StreamInfo;
 
 static int parse_header(const uint8_t* d, size_t n, StreamInfo* si) {
@@ -102,6 +104,7 @@ static int parse_header(const uint8_t* d, size_t n, StreamInfo* si) {
             si->channels = ((s[12] >> 1) & 7) + 1;
             si->bps = (((s[12] & 1) << 4) | (s[13] >> 4)) + 1;
             si->total = ((int64_t)(s[13] & 0x0f) << 32) | ((int64_t)s[14] << 24) | ((int64_t)s[15] << 16) | ((int64_t)s[16] << 8) | s[17];
+            memcpy(si->md5, s + 18, 16);
             have = 1;
         }
         pos += len;
@@ -144,6 +147,7 @@ static int decode_subframe(BitReader* b, int32_t* s, int blocksize, int bps) {
     const int type = (int)br_read(b, 6);
     int wasted = 0;
     if (br_read(b, 1)) wasted = (int)br_unary(b) + 1;
+    if (wasted > 31) return BN_FLAC_ERR_FORMAT; /* (a shift by 32 of the 32-bit sample would be undefined) */
     bps -= wasted;
     if (bps < 1 || bps > 33) return BN_FLAC_ERR_FORMAT;
     if (bps > 32) return BN_FLAC_ERR_UNSUPPORTED; /* 32-bit side channels */
@@ -202,6 +206,16 @@ int bn_flac_info(const uint8_t* data, size_t n, int* sample_rate, int* channels,
     return 0;
 }
 
+/* The 16 bytes of STREAMINFO's MD5 (all zero = the encoder did not write one) as THIS parser locates them: behind an ID3v2 tag and at
+ * the stream marker the header parser accepted, not at the first "fLaC" byte pattern in the file. */
+int bn_flac_md5(const uint8_t* data, size_t n, uint8_t* md5_out) {
+    StreamInfo si;
+    int rc = parse_header(data, n, &si);
+    if (rc) return rc;
+    memcpy(md5_out, si.md5, 16);
+    return 0;
+}
+
 /* Decode frames [first, first + max_frames) (inter-channel sample frames) into out[frames][channels]; returns the number of frames
  * written or a negative error.  A stream whose STREAMINFO holds total = 0 (unknown) is decoded to its end.  out == NULL: nothing is stored,
  * the frames are only counted (the length of a stream that does not state it: frames carry no byte length, they have to be decoded). */
@@ -245,7 +259,8 @@ int64_t bn_flac_decode(const uint8_t* data, size_t n, int64_t first, int64_t max
         if (blocksize <= 0 || blocksize > 65535 || b.eof) { rc = BN_FLAC_ERR_FORMAT; break; }
         if (crc8(data + pos, hdr_end - pos) != want8) { rc = BN_FLAC_ERR_CRC; break; }
         int bps = ss_code ? kBps[ss_code] : si.bps;
-        if (bps == 0) { rc = BN_FLAC_ERR_FORMAT; break; }
+        /* the wrapper scales every sample by STREAMINFO's 2^-(bps-1): a frame that states another depth would be mis-scaled silently */
+        if (bps == 0 || bps != si.bps) { rc = BN_FLAC_ERR_FORMAT; break; }
         const int nch = ca < 8 ? ca + 1 : 2;
         if (nch != ch || ca > 10) { rc = BN_FLAC_ERR_FORMAT; break; }
         for (int c = 0; c < nch && !rc; ++c) {

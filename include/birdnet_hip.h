@@ -226,7 +226,9 @@ BN_API int bn_mel_spectrogram(bn_ctx* ctx, const float* d_audio, int B, int T, i
 
 /* Test hook: number of plan operators' outputs and a copy of one of them.
  * `op_index` in [0, n_ops); the element type/shape is what the packer recorded.
- * Valid until the next forward call. */
+ * Valid until the next forward call.  BN_ERR_UNSUPPORTED when the operator's output was not written by that call: a fused kernel
+ * kept the map on chip under the current options (front block pairs, expand + depthwise pairs, squeeze-excite gates, the blocks the
+ * fused tail covers); bn_set_option switches the fusion off for a per-layer look. */
 BN_API int bn_debug_op_output(bn_model* model, int op_index, int B, void* d_dst, size_t dst_bytes,
                        size_t* bytes_per_chunk, void* stream);
 
@@ -251,7 +253,8 @@ BN_API int bn_debug_requant(bn_ctx* ctx, const int32_t* d_x, const int32_t* d_mu
  * operator of bn_forward / bn_infer_audio is bracketed by an event pair (index n_ops = the STFT
  * stage of bn_infer_audio).  bn_profile_collect waits for the recorded events, adds the elapsed
  * milliseconds and launch counts per operator into total_ms[n] / launches[n] (n >= n_ops + 1)
- * and forgets them. */
+ * and forgets them.  INT8 plans from audio have two more entries, n_ops + 1 (exact min / max of the spectrogram) and n_ops + 2 (whole-chunk
+ * float64 fallback + second run of the mel mixer): with n >= n_ops + 3 they are reported on their own, else under the STFT stage. */
 BN_API int bn_profile_enable(bn_model* model, int enable);
 /* Restrict the event pairs to ONE operator (op_index in [0, n_ops]; -1 = every operator again).  A pair per operator costs
  * ~6 % of a 1.5 ms step; bracketing only the kernel under study keeps the timed region undisturbed. */

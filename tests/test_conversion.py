@@ -153,6 +153,24 @@ def test_requantised_graph_round_trips_through_a_tflite_file(ptq, tmp_path):
         patch_tflite(b"\x00" * 64, new)
 
 
+def test_template_mismatch_is_its_own_exception():
+    """``requantize_like`` signals "this is not the template's topology" with ``TopologyMismatch`` — the only failure on which the convert CLI
+    switches to the template-free exporter (and only for its default template); every other failure keeps its own type and propagates."""
+    from birdnet_stm32.conversion.quantize import TopologyMismatch, requantize_like
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._keras_loader import load_keras_archive
+    from birdnet_stm32.models._tflite_reader import load_tflite
+
+    template = load_tflite(TFLITE_PATH)
+    other = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=3, embeddings_size=256, num_classes=10, randomize_bn=True, seed=7)
+    with pytest.raises(TopologyMismatch):
+        requantize_like(template, other, lambda: iter(()))
+    assert issubclass(TopologyMismatch, ValueError)
+    with pytest.raises(ValueError, match="representative dataset is empty") as e:  # the right topology, no calibration data: NOT a mismatch
+        requantize_like(template, load_keras_archive(KERAS_PATH), lambda: iter(()))
+    assert not isinstance(e.value, TopologyMismatch)
+
+
 @pytest.mark.gpu
 def test_cli_convert_end_to_end(tmp_path):
     """`python -m birdnet_stm32 convert` on the shipped checkpoint with WAV calibration data: writes a .tflite, validates it on the

@@ -454,6 +454,29 @@ def test_flac_decoder_matches_the_encoded_samples(tmp_path):
         _flac.decode_flac(bytes(good))
     with pytest.raises(ValueError, match="malformed"):
         _flac.flac_info(b"RIFF" + bytes(40))
+    # the MD5 is located by the C parser: an ID3v2 tag that happens to contain the bytes "fLaC" does not mislead it, and a stream that does
+    # not state its length is checked too once it has been decoded to the end (the length pass of the loaders)
+    tagged = fw.encode(x, sr, bps, frames, id3=True)
+    assert tagged[:3] == b"ID3"
+    body = bytearray(tagged)
+    body[10:14] = b"fLaC"  # inside the tag's payload
+    assert np.array_equal(_flac.decode_flac(bytes(body))[0], x)
+    unknown = bytearray(fw.encode(x, sr, bps, frames, total_known=False))
+    assert np.array_equal(_flac.decode_flac(bytes(unknown))[0], x)
+    unknown[8 + 18 + 4] ^= 0xFF
+    with pytest.raises(ValueError, match="MD5"):
+        _flac.decode_flac(bytes(unknown))
+    # a frame header that states another bit depth than STREAMINFO is refused (the samples would be mis-scaled silently)
+    other = bytearray(fw.encode(x, sr, bps, frames))
+    ff = other.index(b"\xff\xf8", 8 + 34)
+    other[ff + 3] = (other[ff + 3] & 0xF1) | ((1 if bps != 8 else 4) << 1)  # sample-size code of the first frame: 8 bits (16 for an 8-bit stream)
+    with pytest.raises(ValueError, match="malformed|checksum"):
+        _flac.decode_flac(bytes(other))
+    # a forged STREAMINFO total cannot size the output beyond what the bytes can hold
+    forged = bytearray(fw.encode(x, sr, bps, frames, with_md5=False))
+    forged[8 + 4 + 13] |= 0x0F
+    forged[8 + 4 + 14 : 8 + 4 + 18] = b"\xff\xff\xff\xff"
+    assert _flac.decode_flac(bytes(forged), verify_md5=False)[0].shape[0] == x.shape[0]
     # the loader: same audio as .flac and as .wav gives the same chunks (mono mean, resampling, peak normalisation, chunking)
     from birdnet_stm32.audio.io import save_wav
 
