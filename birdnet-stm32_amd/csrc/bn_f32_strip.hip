@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
 // (each lane streaming its own rows from memory one step ahead) was bound by memory latency, 3150 cycles per wave and row, and
 // finalised every element three times.
 template <bool STAGED>
-__global__ __launch_bounds__(STAGED ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4))) void f32_front_strip_kernel(F32FrontStripArgs a) {
+__global__ __launch_bounds__(STAGED ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(STAGED ? 4 : 3))) void f32_front_strip_kernel(F32FrontStripArgs a) {  // (the per-wave A/B form spilled 4 registers at four waves)
     extern __shared__ __attribute__((aligned(16))) float fe_tile[];  // STAGED: [2 TH + 4][W0 + 8], rows sr0 - 1 .., zero outside the map
     __shared__ float rowc[64][12];          // per input row: wsum, then the ten magnitude-scaling rows (finalising mode)
     __shared__ v4f dw_lds[9][4];            // depthwise taps [tap][quad]

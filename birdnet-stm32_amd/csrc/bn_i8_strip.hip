@@ -109,7 +109,10 @@ __device__ __forceinline__ RawRow<QL> load_row(__amdgpu_buffer_rsrc_t rsrc, cons
 // W8: maps 8 columns wide (stage 4).  The 16 positions of a wave are 2 row blocks x 8 columns: lanes n < 8 walk the upper half of
 // the rows, lanes n >= 8 the lower half, each half streaming its own input rows (row offsets and row padding become per-lane).
 template <int CW, int NW, int COUT, int S, bool ADD, bool W8 = false>
-__global__ __launch_bounds__(64 * NW * (ADD ? 8 / NW : (NW == 1 ? 4 : 1))) __attribute__((amdgpu_waves_per_eu(CW == 32 ? 4 : 2)))
+// (registers: four waves per SIMD for the shipped shapes; the stride-1 blocks without an ADD that keep 64 output channels per wave and
+// the 8-column variants — shapes only other topologies reach — spilled 6-26 registers at that cap and are built for three)
+__global__ __launch_bounds__(64 * NW * (ADD ? 8 / NW : (NW == 1 ? 4 : 1)))
+__attribute__((amdgpu_waves_per_eu(CW == 32 ? (((S == 1 && !ADD && COUT / NW >= 64) || W8) ? 3 : 4) : 2)))
 void i8_strip_kernel(Strip8Args a) {
     constexpr int CIN = CW * NW, CL = CW / 4, QL = CL / 4;
     constexpr int CWO = COUT / NW, NT = CWO / 16, COL = CWO / 4;  // output channels per wave / tiles per wave / per lane
