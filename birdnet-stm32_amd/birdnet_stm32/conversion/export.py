@@ -23,7 +23,10 @@ Operator vocabulary of the emitted graphs (all int8 between QUANTIZE and DEQUANT
   (softmax; the TFLite converter would keep the softmax in int8 — a deliberate difference: the float softmax is exact on the
   dequantised logits and needs no fixed-point exponential).
 
-Not emitted (``NotImplementedError``): precomputed frontends (their graphs start at the stem: nothing to quantise in front), attention pooling.
+* attention pooling (reference models/blocks.py:136-159): RESHAPE -> FULLY_CONNECTED (C -> 1 per position) -> SOFTMAX over the positions (int8) ->
+  MUL -> SUM.
+
+Not emitted (``NotImplementedError``): precomputed frontends (their graphs start at the stem: nothing to quantise in front).
 """
 
 from __future__ import annotations
@@ -280,6 +283,27 @@ def netspec_to_graph(spec: ns.NetSpec, frontend_norm: bool | None = None):
                     final = g.act(ly.name, oshape, quantized=False)
                     g.op("SOFTMAX", [deq], final, {"beta": 1.0})
                 model_out = final
+        elif ly.kind == ns.ATTNPOOL:
+            # attention pooling (reference models/blocks.py:136-159): Dense(1, no bias) over the channels of every position -> softmax over the
+            # positions -> weighted sum.  As the converter writes it: RESHAPE [1, P, C] -> FULLY_CONNECTED (keep_num_dims) -> RESHAPE [1, P] ->
+            # SOFTMAX (int8, 1 / 256) -> RESHAPE [1, P, 1] -> MUL (broadcast over the channels) -> SUM over the positions
+            _, H, Wd, C = shape[src]
+            P = H * Wd
+            flat = g.act(ly.name + "/flat", (1, P, C))
+            g.op("RESHAPE", [val[src], g.const(ly.name + "/flat_shape", np.array([1, P, C], np.int32), np.int32, False)], flat)
+            score = g.conv("FULLY_CONNECTED", flat, ly.name + "/score", np.asarray(ly.weights["score"], np.float32).reshape(1, C), np.zeros(1, np.float32), (1, P, 1),
+                           {"activation": "none", "keep_num_dims": True})
+            row = g.act(ly.name + "/score_row", (1, P))
+            g.op("RESHAPE", [score, g.const(ly.name + "/row_shape", np.array([1, P], np.int32), np.int32, False)], row)
+            attn = g.act(ly.name + "/softmax", (1, P))
+            g.op("SOFTMAX", [row], attn, {"beta": 1.0})
+            col = g.act(ly.name + "/attn", (1, P, 1))
+            g.op("RESHAPE", [attn, g.const(ly.name + "/col_shape", np.array([1, P, 1], np.int32), np.int32, False)], col)
+            wmap = g.act(ly.name + "/weighted", (1, P, C))
+            g.op("MUL", [flat, col], wmap, {"activation": "none"})
+            o = g.act(ly.name, (1, C))
+            g.op("SUM", [wmap, g.const(ly.name + "/axis", np.array([1], np.int32), np.int32, False)], o, {"keep_dims": False})
+            val[ly.name], shape[ly.name] = o, (1, C)
         elif ly.kind == ns.MUL:
             o = g.act(ly.name, shape[ly.inputs[0]])
             g.op("MUL", [val[ly.inputs[0]], val[ly.inputs[1]]], o, {"activation": "none"})
@@ -287,7 +311,7 @@ def netspec_to_graph(spec: ns.NetSpec, frontend_norm: bool | None = None):
         elif ly.kind == ns.BN:
             raise NotImplementedError(f"{ly.name}: BatchNorm that does not follow a convolution")
         else:
-            raise NotImplementedError(f"{ly.name}: layer kind {ly.kind!r} has no INT8 export (attention pooling, nested frontends)")
+            raise NotImplementedError(f"{ly.name}: layer kind {ly.kind!r} has no INT8 export (nested frontends)")
     model = TfliteModel(3, "birdnet_stm32.conversion.export (own PTQ, no TensorFlow)", g.tensors, g.ops, [x_in], [model_out])
     return model, g.consts, g.float_wb
 

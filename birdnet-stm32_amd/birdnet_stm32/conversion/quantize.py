@@ -197,6 +197,9 @@ def run_float(model: TfliteModel, consts: dict[int, np.ndarray], x: np.ndarray) 
         elif n == "SOFTMAX":
             z = (env[i[0]] - env[i[0]].max(axis=-1, keepdims=True)) * op.options.get("beta", 1.0)
             y = np.exp(z) / np.exp(z).sum(axis=-1, keepdims=True)
+        elif n == "SUM":
+            axes = tuple(int(a) % env[i[0]].ndim for a in np.atleast_1d(env[i[1]]))
+            y = env[i[0]].sum(axis=axes, keepdims=bool(op.options.get("keep_dims")))
         else:
             raise NotImplementedError(f"operator {n} in float calibration")
         env[op.outputs[0]] = y.astype(np.float32) if y.dtype.kind == "f" else y
@@ -358,12 +361,13 @@ def quantize_graph(template: TfliteModel, consts: dict[int, np.ndarray], float_w
     new = copy.deepcopy(template)
     N = new.tensors
     act_q: dict[int, tuple[float, int]] = {}
-    logistic_out = {op.outputs[0] for op in template.ops if op.name == "LOGISTIC"}
+    logistic_out = {op.outputs[0] for op in template.ops if op.name in ("LOGISTIC", "SOFTMAX")}  # fixed output parameters 1 / 256, -128
     float_io = {template.inputs[0], template.outputs[0]}
+    fixed_roots = {find(ti) for ti in logistic_out if ti in parent}  # tensors tied to such an output by data movement (RESHAPE behind SOFTMAX) share it
     for ti in lo:
         if ti in float_io or not T[ti].is_quantized:
             continue
-        s, z = (1.0 / 256.0, -128) if ti in logistic_out else choose_activation_params(glo[find(ti)], ghi[find(ti)])
+        s, z = (1.0 / 256.0, -128) if (ti in logistic_out or find(ti) in fixed_roots) else choose_activation_params(glo[find(ti)], ghi[find(ti)])
         act_q[ti] = (s, z)
         N[ti].scale = np.asarray([s], np.float32)
         N[ti].zero_point = np.asarray([z], np.int64)

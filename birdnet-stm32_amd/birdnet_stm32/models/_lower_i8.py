@@ -390,9 +390,10 @@ def tail_constants(blocks: list[dict], head: dict):
     return np.concatenate(sections).astype(np.int32), np.asarray(desc, np.int32)
 
 
-def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
+def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str = "fixed") -> pk.Plan:
     """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse; ``fuse=False`` keeps the
-    baseline one-kernel-per-operator plan instead of the fused matrix-core blocks."""
+    baseline one-kernel-per-operator plan instead of the fused matrix-core blocks.  ``softmax_form`` picks the arithmetic of an int8
+    SOFTMAX (attention pooling): ``'fixed'`` = TFLite's reference kernel, ``'lut'`` = its optimized kernel (oracle/int8_graph.py has both)."""
     from birdnet_stm32.models._lower_f32 import pick_tile
 
     g = _Graph(model)
@@ -768,6 +769,42 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True) -> pk.Plan:
                       name=f"t{out_t}", out_shape=(H, Wd, Cout), out_dtype="int8")
             val[out_t], shape[out_t] = v, (H, Wd, Cout)
             i += 1
+        elif op.name == "RESHAPE" and len(shape[src]) == 3 and i + 6 < len(ops) and [o.name for o in ops[i + 1 : i + 7]] == ["FULLY_CONNECTED", "RESHAPE", "SOFTMAX", "RESHAPE", "MUL", "SUM"]:
+            # attention pooling (reference models/blocks.py:136-159) as the exporter writes it: RESHAPE [P, C] -> FULLY_CONNECTED C -> 1 per
+            # position -> RESHAPE -> SOFTMAX over the positions -> RESHAPE -> MUL (broadcast over the channels) -> SUM over the positions:
+            # ONE operator (i8_attnpool_kernel); the softmax is table-driven (models/_quant.py: softmax_tables)
+            H, Wd, C = shape[src]
+            P = H * Wd
+            fc, r2, sm, r3, mul, sm_sum = ops[i + 1 : i + 7]
+            flat = op.outputs[0]
+            _expect(fc.inputs[0] == flat and r2.inputs[0] == fc.outputs[0] and sm.inputs[0] == r2.outputs[0] and r3.inputs[0] == sm.outputs[0]
+                    and set(mul.inputs) == {flat, r3.outputs[0]} and sm_sum.inputs[0] == mul.outputs[0], "attention pooling operator chain")
+            _expect(g.consumers.get(flat, []) == sorted([fc.index, mul.index]) and C % 4 == 0 and P * C <= 60 * 1024, "attention pooling geometry")
+            _expect([int(a) % 3 for a in np.atleast_1d(g.const(sm_sum.inputs[1]))] == [1] and not sm_sum.options.get("keep_dims"), "SUM over the positions")
+            wt_ = t[fc.inputs[1]]
+            _expect(tuple(wt_.shape) == (1, C) and bool(fc.options.get("keep_num_dims")) and fc.options["activation"] == "none", "score layer C -> 1")
+            s_x, z_x = g.q(src)
+            _expect(g.q(flat) == (s_x, z_x), "RESHAPE keeps the quantisation")
+            s_s, z_s = g.q(fc.outputs[0])
+            mu, sh = qz.channel_multipliers(s_x, wt_.scale, s_s, 1)
+            w = wt_.data.astype(np.int64).reshape(C)
+            b = (g.const(fc.inputs[2]).astype(np.int64).reshape(-1)[0] if len(fc.inputs) > 2 and fc.inputs[2] >= 0 else 0) - z_x * int(w.sum())
+            _expect_acc_range(wt_.data.reshape(1, C), np.asarray([b], np.int64), 1, f"attention score operator #{fc.index}", mu, sh)
+            s_a, z_a = g.q(sm.outputs[0])
+            _expect((round(1.0 / s_a), z_a) == (256, -128) and g.q(r2.outputs[0]) == (s_s, z_s) and g.q(r3.outputs[0]) == (s_a, z_a), "softmax quantisation")
+            beta = float(sm.options.get("beta", 1.0))
+            s_m, z_m = g.q(mul.outputs[0])
+            m_mu, m_sh = qz.quantize_multiplier(float(np.float32(s_x)) * float(np.float32(s_a)) / float(np.float32(s_m)))
+            m_lo, m_hi = qz.activation_bounds(mul.options["activation"], s_m, z_m)
+            s_o, z_o = g.q(sm_sum.outputs[0])
+            o_mu, o_sh = qz.quantize_multiplier(float(np.float32(s_m)) / float(np.float32(s_o)))
+            form = {"fixed": 0, "lut": 1}[softmax_form]
+            v = pb.value(C)
+            pb.op(pk.I8_ATTNPOOL, val[src], v, p=[P, C, int(b), int(mu[0]), int(sh[0]), z_s, form, z_x, z_a, m_mu, m_sh, z_m, m_lo, m_hi, o_mu, o_sh, z_o],
+                  t=[pb.tensor(w.astype(np.int8), np.int8), pb.tensor(qz.softmax_tables(s_s, beta, softmax_form), np.int32)],
+                  name=f"t{sm_sum.outputs[0]}", out_shape=(C,), out_dtype="int8")
+            val[sm_sum.outputs[0]], shape[sm_sum.outputs[0]] = v, (C,)
+            i += 7
         elif op.name == "MEAN":
             H, Wd, C = shape[src]
             axes = sorted(int(a) % 4 for a in np.atleast_1d(g.const(op.inputs[1])))

@@ -181,3 +181,42 @@ def div_table(s1: float, z1: int, s2: float, z2: int, so: float, zo: int, act: s
     quotient = _high_mul(x1 << headroom, inv)
     y = requantize(quotient, mo, sho - bits - headroom) + int(zo)
     return np.clip(y, amin, amax).astype(np.int8)
+
+
+# -- int8 SOFTMAX as tables (attention pooling; reference models/blocks.py:136-159) -------------------------------------------------
+def _exp_q5_to_q31(a: np.ndarray) -> np.ndarray:
+    """gemmlowp ``exp_on_negative_values`` for FixedPoint<int32, 5>: a <= 0 as Q5.26 raw -> exp(a) as Q0.31 raw (fixedpoint.h: the
+    argument modulo 1/4 through a fourth-order polynomial around -1/8, the multiples of 1/4 through constants exp(-2^k), k = -2 .. 4)."""
+    a = np.asarray(a, np.int64)
+    quarter = 1 << 24
+    a_mod = (a & (quarter - 1)) - quarter
+    x = (a_mod << 5) + (1 << 28)
+    x2 = _high_mul(x, x)
+    x3, x4 = _high_mul(x2, x), _high_mul(x2, x2)
+    poly = _round_shift(_high_mul(_round_shift(x4, 2) + x3, 715827883) + x2, 1)
+    result = 1895147668 + _high_mul(np.full(a.shape, 1895147668, np.int64), x + poly)
+    rem = a_mod - a
+    for bit, mult in ((24, 1672461947), (25, 1302514674), (26, 790015084), (27, 290630308), (28, 39332535), (29, 720401), (30, 242)):
+        result = np.where((rem >> bit) & 1 == 1, _high_mul(result, mult), result)
+    return np.where(a == 0, _I32_MAX, result)
+
+
+def softmax_tables(s_in: float, beta: float, form: str) -> np.ndarray:
+    """What the device needs of an int8 SOFTMAX (output 1 / 256, -128), indexed by d = max - x in 0 .. 255.
+
+    ``form='fixed'`` (TFLite's reference kernel): int32 ``[2][256]`` — exp(-beta s d) as Q0.31 raw (-1: below diff_min, the output is
+    -128 and the term does not enter the sum) and the same value rescaled to the accumulator's Q12.19.  ``form='lut'`` (TFLite's optimized
+    kernel): float32 ``[256]`` exp(-beta s d), viewed as int32 bits."""
+    d = np.arange(256, dtype=np.int64)
+    if form == "lut":
+        return np.exp((np.float32(-float(np.float32(s_in)) * float(beta)) * d.astype(np.float32)).astype(np.float32)).astype(np.float32).view(np.int32)
+    if form != "fixed":
+        raise ValueError("softmax form must be 'fixed' or 'lut'")
+    real = min(float(beta) * float(np.float32(s_in)) * (1 << 26), (1 << 31) - 1.0)
+    mult, shift = quantize_multiplier(real)
+    if shift < 0:
+        raise NotImplementedError("softmax input multiplier below one")
+    diff_min = -int(np.floor(31.0 * (1 << 26) / (1 << shift)))
+    live = -d >= diff_min
+    e = _exp_q5_to_q31(_high_mul(np.where(live, -d, 0) << shift, mult))
+    return np.stack([np.where(live, e, -1), np.where(live, _round_shift(e, 12), 0)]).astype(np.int32)

@@ -39,6 +39,7 @@ BUILTIN_NAMES = {
     42: "DIV",
     45: "STRIDED_SLICE",
     77: "SHAPE",
+    74: "SUM",
     82: "REDUCE_MAX",
     83: "PACK",
     94: "FILL",
@@ -209,7 +210,7 @@ def _decode_options(name: str, t: _Table | None) -> dict:
         return {"activation": act(0)}
     if name == "FULLY_CONNECTED":
         return {"activation": act(0), "keep_num_dims": bool(t.scalar(2, "b", 0))}
-    if name in ("MEAN", "REDUCE_MAX"):
+    if name in ("MEAN", "REDUCE_MAX", "SUM"):
         return {"keep_dims": bool(t.scalar(0, "b", 0))}
     if name == "CONCATENATION":
         return {"axis": t.scalar(0, "i", 0), "activation": act(1)}

@@ -27,11 +27,11 @@ _ACT_OF = {v: k for k, v in _ACTIVATIONS.items()}
 
 # BuiltinOptions union tags of the schema (checked against the shipped file for the operators it holds)
 _OPTIONS_TYPE = {"CONV_2D": 1, "DEPTHWISE_CONV_2D": 2, "FULLY_CONNECTED": 8, "SOFTMAX": 9, "CONCATENATION": 10, "ADD": 11, "RESHAPE": 17,
-                 "MUL": 21, "PAD": 22, "TRANSPOSE": 0, "MEAN": 27, "REDUCE_MAX": 27, "DIV": 29, "STRIDED_SLICE": 32, "SHAPE": 55, "PACK": 59}
+                 "MUL": 21, "PAD": 22, "TRANSPOSE": 0, "MEAN": 27, "REDUCE_MAX": 27, "SUM": 27, "DIV": 29, "STRIDED_SLICE": 32, "SHAPE": 55, "PACK": 59}
 # operator versions the converter writes for int8 graphs (read off the shipped file where present)
 _VERSION = {"QUANTIZE": 1, "TRANSPOSE": 2, "STRIDED_SLICE": 2, "SHAPE": 1, "PACK": 1, "FILL": 3, "CONCATENATION": 2, "CONV_2D": 3,
             "DEPTHWISE_CONV_2D": 3, "ADD": 2, "MEAN": 2, "FULLY_CONNECTED": 4, "LOGISTIC": 2, "DEQUANTIZE": 2, "MUL": 2, "SOFTMAX": 1,
-            "REDUCE_MAX": 2, "DIV": 2, "RESHAPE": 1, "PAD": 2}
+            "REDUCE_MAX": 2, "DIV": 2, "RESHAPE": 1, "PAD": 2, "SUM": 2}
 
 
 class _Builder:
@@ -139,7 +139,7 @@ def _options(b: _Builder, op) -> tuple[int, int]:
         return tag, b.table([act()])
     if n == "FULLY_CONNECTED":
         return tag, b.table([act(), None, ("s", "b", int(bool(o.get("keep_num_dims"))))])
-    if n in ("MEAN", "REDUCE_MAX"):
+    if n in ("MEAN", "REDUCE_MAX", "SUM"):
         return tag, b.table([("s", "b", int(bool(o.get("keep_dims"))))])
     if n == "CONCATENATION":
         return tag, b.table([("s", "i", o["axis"]), act()])

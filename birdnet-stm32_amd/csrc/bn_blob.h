@@ -193,4 +193,5 @@ enum BnOpKind : int32_t {
     // p: T W M stride pad_left q_zp zp_out act_min act_max has_lut   f: q_scale
     // t: weights [M][16] int8, bias (zero point of the input folded), multipliers, shifts, table [M][256] (has_lut)
     BN_OP_I8_RAWFE = 33,
+    BN_OP_I8_ATTNPOOL = 34,  // attention pooling of an exported graph: score FC + int8 SOFTMAX over the positions + MUL + SUM (bn_i8.hip)
 };

@@ -543,6 +543,95 @@ __global__ __launch_bounds__(256) void i8_maxnorm_kernel(const int8_t* __restric
     }
 }
 
+// Attention pooling of an exported INT8 graph (reference models/blocks.py:136-159; conversion/export.py writes it as RESHAPE ->
+// FULLY_CONNECTED C -> 1 per position -> SOFTMAX over the positions -> MUL -> SUM): one workgroup per chunk, the [P][C] map in LDS.
+//   scores s[p] = requantised dot product of the position's channels with the score vector        (thread per position, v_dot4)
+//   a[p]        = int8 SOFTMAX of s over the positions, output 1 / 256, -128 — table-driven, in either of TFLite's two published forms:
+//                 form 0 (reference kernel, gemmlowp fixed point): table[0][d] = exp(-beta s d) as Q0.31, table[1][d] the same in the
+//                 accumulator's Q12.19, d = max - s; reciprocal of the sum by gemmlowp's Newton-Raphson division (three steps on the
+//                 half denominator), output RoundingDivideByPOT(SRDHM(1 / sum, exp), bits + 31 - 8) - 128;
+//                 form 1 (optimized kernel, float32 table): sum in float32 in position order, prob = exp / (sum / 256) rounded half away.
+//   out[c]      = requantised sum over p of the int8 MUL (x[p][c] - zx) (a[p] + 128)                (thread per channel)
+// Integer steps use the literal gemmlowp definitions (srdhm_ref / rdivpot_ref): exactness over speed, the operator is ~1e5 operations per chunk.
+struct AttnPool8Args {
+    const int8_t* x;      // [B][P][C]
+    int8_t* y;            // [B][C]
+    const int8_t* w;      // [C] score vector
+    const int32_t* table; // softmax tables (form 0: int32 [2][256]; form 1: float32 [256])
+    int P, C, fc_bias, fc_mult, fc_shift, fc_zo, form, zx, za, mul_mult, mul_shift, mul_zo, mul_lo, mul_hi, sum_mult, sum_shift, sum_zo;
+};
+
+__device__ __forceinline__ int32_t sat_shl(int32_t x, int e) {  // gemmlowp SaturatingRoundingMultiplyByPOT<e>, e > 0
+    const long v = (long)x << e;
+    return v > 2147483647L ? 2147483647 : (v < -2147483648L ? (int32_t)-2147483648L : (int32_t)v);
+}
+// 1 / (1 + f) for f in [0, 1) as Q0.31 (gemmlowp one_over_one_plus_x_for_x_in_0_1)
+__device__ __forceinline__ int32_t one_over_one_plus(int32_t f) {
+    const int32_t half_den = (int32_t)(((long)f + 2147483647L + 1) / 2);  // RoundingHalfSum(f, One()); the sum is >= 0
+    int32_t est = 1515870810 + srdhm_ref(half_den, -1010580540);          // 48/17 - 32/17 d  (Q2.29)
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int32_t err = (1 << 29) - srdhm_ref(half_den, est);
+        est = est + sat_shl(srdhm_ref(est, err), 2);
+    }
+    return sat_shl(est, 1);
+}
+
+__global__ __launch_bounds__(256) void i8_attnpool_kernel(AttnPool8Args a) {
+    extern __shared__ __attribute__((aligned(16))) int8_t apx[];  // [P][C] map, then P score bytes, P attention bytes
+    __shared__ int sh_max, sh_over, sh_inv;
+    __shared__ float sh_finv;
+    const int tid = threadIdx.x, P = a.P, C = a.C;
+    const int8_t* src = a.x + (size_t)blockIdx.x * P * C;
+    int8_t* sc = apx + (size_t)P * C;
+    int8_t* at = sc + P;
+    for (int i = tid; i < P * C / 4; i += 256) reinterpret_cast<int*>(apx)[i] = reinterpret_cast<const int*>(src)[i];
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) {
+        int acc = a.fc_bias;  // bias - zx * sum(w) folded by the packer
+        for (int k = 0; k < C / 4; ++k) acc = __builtin_amdgcn_sdot4(reinterpret_cast<const int*>(apx + (size_t)p * C)[k], reinterpret_cast<const int*>(a.w)[k], acc, false);
+        sc[p] = (int8_t)clampi(mbqm_ref(acc, a.fc_mult, a.fc_shift) + a.fc_zo, -128, 127);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int mx = -128;
+        for (int p = 0; p < P; ++p) mx = max(mx, (int)sc[p]);
+        sh_max = mx;
+        if (a.form == 0) {
+            int total = 0;
+            for (int p = 0; p < P; ++p) total += a.table[256 + mx - sc[p]];
+            const int lz = __clz(total);               // total >= 2^19: the maximum contributes exp(0) = 1.0
+            sh_over = 12 - lz;
+            sh_inv = one_over_one_plus((int32_t)(((uint32_t)total << lz) - 0x80000000u));
+        } else {
+            float total = 0.0f;
+            for (int p = 0; p < P; ++p) total = __fadd_rn(total, __int_as_float(a.table[mx - sc[p]]));
+            sh_finv = __fdiv_rn(1.0f, __fmul_rn(total, 1.0f / 256.0f));
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) {
+        const int d = sh_max - sc[p];
+        int q;
+        if (a.form == 0) {
+            const int e = a.table[d];
+            q = e < 0 ? -128 : clampi(rdivpot_ref(srdhm_ref(sh_inv, e), sh_over + 31 - 8) - 128, -128, 127);
+        } else {
+            q = clampi((int)roundf(__fmul_rn(__int_as_float(a.table[d]), sh_finv)) - 128, -128, 127);
+        }
+        at[p] = (int8_t)q;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        int total = 0;
+        for (int p = 0; p < P; ++p) {
+            const int v = clampi(mbqm_ref(((int)apx[(size_t)p * C + c] - a.zx) * ((int)at[p] - a.za), a.mul_mult, a.mul_shift) + a.mul_zo, a.mul_lo, a.mul_hi);
+            total += v - a.mul_zo;
+        }
+        a.y[(size_t)blockIdx.x * C + c] = (int8_t)clampi(mbqm_ref(total, a.sum_mult, a.sum_shift) + a.sum_zo, -128, 127);
+    }
+}
+
 // DEQUANTIZE -> float32 SOFTMAX over the classes of a chunk: one wave per chunk (scores), logits = the dequantised input
 __global__ __launch_bounds__(64) void i8_head_softmax_kernel(const int8_t* __restrict__ x, float* __restrict__ scores, float* __restrict__ logits,
                                                              int C, int zp_fc, float s_fc, float beta) {
@@ -648,6 +737,14 @@ void launch_i8_rawfe(const float* x, int8_t* y, int B, int T, int W, int M, int 
 
 void launch_i8_maxnorm(const int8_t* x, int8_t* y, int B, int C, int W, const int8_t* den_tab, const int8_t* div_tab, const int8_t* lut, hipStream_t s) {
     hipLaunchKernelGGL(i8_maxnorm_kernel, dim3(B), dim3(256), 0, s, x, y, C, W, den_tab, div_tab, lut);
+}
+
+bool launch_i8_attnpool(const int8_t* x, int8_t* y, int B, const int* p, const int8_t* w, const int32_t* table, hipStream_t s) {
+    AttnPool8Args a{x, y, w, table, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15], p[16]};
+    const size_t smem = (size_t)a.P * a.C + 2 * (size_t)a.P + 16;
+    if (a.C % 4 || smem > 64 * 1024) return false;
+    hipLaunchKernelGGL(i8_attnpool_kernel, dim3(B), dim3(256), smem, s, a);
+    return true;
 }
 
 void launch_i8_head_softmax(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, float s_fc, float beta, hipStream_t s) {

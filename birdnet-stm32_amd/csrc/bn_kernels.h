@@ -255,6 +255,9 @@ void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int 
 void launch_i8_rawfe(const float* x, int8_t* y, int B, int T, int W, int M, int stride, int pad_left, float q_scale, int q_zp, int zp_out, int amin,
                      int amax, const int8_t* w, const int32_t* bias, const int32_t* mult, const int32_t* shift, const int8_t* lut, hipStream_t s);
 void launch_i8_maxnorm(const int8_t* x, int8_t* y, int B, int C, int W, const int8_t* den_tab, const int8_t* div_tab, const int8_t* lut, hipStream_t s);
+// attention pooling of an exported graph: p = the operator's parameters (P C fc_bias fc_mult fc_shift fc_zo form zx za mul_mult mul_shift mul_zo mul_lo
+// mul_hi sum_mult sum_shift sum_zo), w the score vector, table the softmax tables (models/_quant.py: softmax_tables); false = geometry not taken
+bool launch_i8_attnpool(const int8_t* x, int8_t* y, int B, const int* p, const int8_t* w, const int32_t* table, hipStream_t s);
 void launch_i8_head_softmax(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, float s_fc, float beta, hipStream_t s);
 void launch_i8_head(const int8_t* x, float* scores, float* logits, int B, int C, int zp_fc, int zp_out, float s_fc,
                     float s_out, const int8_t* lut, hipStream_t s);

@@ -228,6 +228,13 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                 if (c.ok && p[9]) c.clamp8(p[7], p[8], "raw frontend");
                 if (c.ok && p[1] % 4) c.bad("raw frontend width %d is not a multiple of 4 (the kernel stores dwords of one filter)", p[1]);
                 break;
+            case BN_OP_I8_ATTNPOOL:  // P C fc_bias fc_mult fc_shift fc_zo form zx za mul_mult mul_shift mul_zo mul_lo mul_hi sum_mult sum_shift sum_zo
+                c.dims({p[0], p[1]}, "attention pooling") && c.slot(o.in0, 1LL * p[0] * p[1], "input map") && c.slot(o.out, 1LL * p[1], "output") &&
+                    c.tensor(0, 1LL * p[1], "score vector") && c.tensor(1, p[6] == 0 ? 2048 : 1024, "softmax tables");
+                if (c.ok && (p[1] % 4 || 1LL * p[0] * p[1] + 2LL * p[0] + 16 > 64 * 1024)) c.bad("attention pooling map %d x %d does not fit the kernel", p[0], p[1]);
+                if (c.ok && (p[6] < 0 || p[6] > 1)) c.bad("softmax form %d", p[6]);
+                if (c.ok) c.clamp8(p[12], p[13], "attention pooling MUL");
+                break;
             case BN_OP_I8_HEAD:  // C zp_fc zp_out has_lut
                 c.dims({p[0]}, "head") && c.slot(o.in0, 1LL * p[0], "input") && c.slot(o.out, 4LL * p[0], "scores") && (!p[3] || c.tensor(0, 256, "table"));
                 if (c.ok && p[0] != (int)h.num_classes) c.bad("classifier width %d, header says %u classes", p[0], h.num_classes);

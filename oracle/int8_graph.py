@@ -143,6 +143,76 @@ def get_reciprocal(x):
     return one_over_one_plus_x_for_x_in_0_1(shifted), 31 - lz
 
 
+def exp_on_interval_between_negative_one_quarter_and_0_excl(a):
+    """gemmlowp fixedpoint.h, FixedPoint<int32, 0>: exp(a) for a in [-1/4, 0) as Q0.31 raw — a fourth-order Taylor polynomial around -1/8."""
+    a = np.asarray(a, dtype=np.int64)
+    constant_term, one_third = 1895147668, 715827883        # exp(-1/8), 1/3
+    x = a + (1 << 28)                                       # + 1/8
+    x2 = srdhm(x, x)
+    x3 = srdhm(x2, x)
+    x4 = srdhm(x2, x2)
+    x4_over_4 = rounding_divide_by_pot(x4, 2)
+    poly = rounding_divide_by_pot(srdhm(x4_over_4 + x3, one_third) + x2, 1)
+    return constant_term + srdhm(constant_term, x + poly)     # exp(-1/8) (1 + x + x^2/2 + x^3/6 + x^4/24)
+
+
+def exp_on_negative_values_q5(a):
+    """gemmlowp ``exp_on_negative_values`` for FixedPoint<int32, 5> (Q5.26 raw, a <= 0) -> Q0.31 raw: the argument modulo 1/4 through the
+    polynomial above, the multiples of 1/4 through a barrel shifter of constants exp(-2^k), k = -2 .. 4."""
+    a = np.asarray(a, dtype=np.int64)
+    frac = 26
+    quarter = 1 << (frac - 2)
+    a_mod = (a & (quarter - 1)) - quarter
+    result = exp_on_interval_between_negative_one_quarter_and_0_excl(a_mod << 5)   # Rescale<0>: exact (|a_mod| < 2^24)
+    remainder = a_mod - a
+    for exponent, mult in ((-2, 1672461947), (-1, 1302514674), (0, 790015084), (1, 290630308), (2, 39332535), (3, 720401), (4, 242)):
+        hit = (remainder & (1 << (frac + exponent))) != 0
+        result = np.where(hit, srdhm(result, mult), result)
+    return np.where(a == 0, INT32_MAX, result)
+
+
+def softmax_fixed_params(s_in: float, beta: float) -> tuple[int, int, int]:
+    """TFLite ``PreprocessSoftmaxScaling`` + ``CalculateInputRadius`` for 5 integer bits: (input multiplier, left shift, diff_min)."""
+    real = min(float(beta) * float(np.float32(s_in)) * (1 << (31 - 5)), (1 << 31) - 1.0)
+    mult, shift = quantize_multiplier(real)
+    if shift < 0:
+        raise ValueError("softmax input multiplier below one")
+    radius = int(np.floor(1.0 * ((1 << 5) - 1) * (1 << (31 - 5)) / (1 << shift)))
+    return mult, shift, -radius
+
+
+def softmax_int8_fixed(x, s_in: float, beta: float = 1.0):
+    """int8 SOFTMAX over the last axis as TFLite's REFERENCE kernel computes it (softmax.h: gemmlowp fixed point; output scale 1 / 256,
+    zero point -128).  Restated from the published source, **parity unpinned**."""
+    x = np.asarray(x, dtype=np.int64)
+    mult, shift, diff_min = softmax_fixed_params(s_in, beta)
+    diff = x - x.max(axis=-1, keepdims=True)
+    live = diff >= diff_min
+    e = exp_on_negative_values_q5(srdhm(np.where(live, diff, 0) << shift, mult))
+    total = np.where(live, rounding_divide_by_pot(e, 12), 0).sum(axis=-1, keepdims=True)       # FixedPoint<int32, 12>
+    lz = count_leading_zeros32(total)
+    over = 12 - lz
+    inv = one_over_one_plus_x_for_x_in_0_1(((total << lz) & 0xFFFFFFFF) - (1 << 31))
+    y = rounding_divide_by_pot(srdhm(inv, e), over + 31 - 8) - 128
+    return np.where(live, np.clip(y, -128, 127), -128).astype(np.int8)
+
+
+def softmax_int8_lut(x, s_in: float, beta: float = 1.0, s_out: float = 1.0 / 256.0, zp_out: int = -128):
+    """int8 SOFTMAX over the last axis as TFLite's OPTIMIZED kernel computes it (optimized_ops::Softmax with SoftmaxParams::table, a
+    float32 table of exp(-scale beta d), d = max - x; the sum runs over the row in index order).  Restated from the published source,
+    **parity unpinned**; numpy's float32 exp stands in for libm's expf."""
+    x = np.asarray(x, dtype=np.int64)
+    table = np.exp((np.float32(-float(np.float32(s_in)) * float(beta)) * np.arange(256, dtype=np.float32)).astype(np.float32)).astype(np.float32)
+    d = x.max(axis=-1, keepdims=True) - x
+    e = table[d]
+    total = np.zeros(e.shape[:-1] + (1,), np.float32)
+    for j in range(e.shape[-1]):                      # sequential float32 accumulation, like the kernel's loop
+        total = (total + e[..., j : j + 1]).astype(np.float32)
+    inv = (np.float32(1.0) / (total * np.float32(s_out)).astype(np.float32)).astype(np.float32)
+    y = round_half_away((e * inv).astype(np.float32)).astype(np.int64) + zp_out
+    return np.clip(y, -128, 127).astype(np.int8)
+
+
 def activation_range(act: str, scale: float, zp: int, qmin=-128, qmax=127) -> tuple[int, int]:
     """``CalculateActivationRangeQuantized`` for int8 outputs."""
     s = np.float32(scale)
@@ -183,7 +253,15 @@ def _same(size, k, s):
 class Int8Interpreter:
     """Executes a decoded ``TfliteModel`` on float32 batches, like ``TFLiteRunner.predict``."""
 
-    def __init__(self, model):
+    def __init__(self, model, softmax_form: str = "fixed"):
+        """``softmax_form``: which published form an int8 SOFTMAX takes — ``'fixed'`` TFLite's reference kernel (gemmlowp fixed point),
+        ``'lut'`` its optimized kernel (float32 exponent table).  Nothing here can tell which one the reference's interpreter runs."""
+        if softmax_form not in ("fixed", "lut"):
+            raise ValueError("softmax_form must be 'fixed' or 'lut'")
+        self.softmax_form = softmax_form
+        self._init(model)
+
+    def _init(self, model):
         self.model = model
         self._prep: dict[int, dict] = {}
 
@@ -277,6 +355,17 @@ class Int8Interpreter:
         total = x.sum(axis=axes, keepdims=bool(op.options.get("keep_dims"))) - zp_in * n
         y = mbqm(total, mult, shift) + zp_out
         return np.clip(y, -128, 127).astype(np.int8)
+
+    def _sum(self, op, env):
+        """int8 SUM over an axis: int32 sum of (q - zp_in), one MultiplyByQuantizedMultiplier by s_in / s_out (the integer form of reduce.h,
+        as for MEAN without the division by the count)."""
+        x = self._value(env, op.inputs[0]).astype(np.int64)
+        axes = tuple(int(a) % x.ndim for a in np.atleast_1d(self._value(env, op.inputs[1])))
+        s_in, zp_in = self._q(op.inputs[0])
+        s_out, zp_out = self._q(op.outputs[0])
+        mult, shift = quantize_multiplier(float(np.float32(s_in)) / float(np.float32(s_out)))
+        total = (x - zp_in).sum(axis=axes, keepdims=bool(op.options.get("keep_dims")))
+        return np.clip(mbqm(total, mult, shift) + zp_out, -128, 127).astype(np.int8)
 
     def _fully_connected(self, op, env):
         x = self._value(env, op.inputs[0]).astype(np.int64)
@@ -430,13 +519,21 @@ class Int8Interpreter:
                 y = self._reduce_max(op, env)
             elif n == "DIV":
                 y = self._div(op, env)
-            elif n == "SOFTMAX":  # float32 softmax behind DEQUANTIZE (the form this build's exporter writes): exp(beta (x - max)) / sum
+            elif n == "SOFTMAX":
                 xin = self._value(env, op.inputs[0])
-                if xin.dtype != np.float32:
-                    raise ValueError("int8 SOFTMAX is not restated; the exporter of this build dequantises first")
-                z = (xin - xin.max(axis=-1, keepdims=True)) * np.float32(op.options.get("beta", 1.0))
-                e = np.exp(z, dtype=np.float32)
-                y = (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+                beta = float(op.options.get("beta", 1.0))
+                if xin.dtype == np.float32:  # float32 softmax behind DEQUANTIZE (the classifier head this build's exporter writes): exp(beta (x - max)) / sum
+                    z = (xin - xin.max(axis=-1, keepdims=True)) * np.float32(beta)
+                    e = np.exp(z, dtype=np.float32)
+                    y = (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+                else:  # int8 (attention pooling): one of the two published kernels
+                    s_i, _ = self._q(op.inputs[0])
+                    s_o, z_o = self._q(op.outputs[0])
+                    if (round(1.0 / s_o), z_o) != (256, -128):
+                        raise ValueError("int8 SOFTMAX output must be 1/256, -128")
+                    y = softmax_int8_fixed(xin, s_i, beta) if self.softmax_form == "fixed" else softmax_int8_lut(xin, s_i, beta, s_o, z_o)
+            elif n == "SUM":
+                y = self._sum(op, env)
             else:
                 raise ValueError(f"operator {n} not handled by the oracle")
             env[op.outputs[0]] = y

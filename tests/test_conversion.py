@@ -227,6 +227,9 @@ EXPORT_TOPOLOGIES = {
     "raw_pcen_ir_se": dict(audio_frontend="raw", mag_scale="pcen", chunk_duration=2, alpha=0.5),
     # the same at the metric's chunk length: 3 s @ 24 kHz = 72000 samples, stride 282, no PAD (the reference's T < 65536 guard lifted)
     "raw_pcen_ir_se_3s": dict(audio_frontend="raw", mag_scale="pcen", chunk_duration=3, alpha=0.5, raw_length_limit=None),
+    # attention pooling instead of the global average (reference models/blocks.py:136-159): RESHAPE -> FULLY_CONNECTED C -> 1 -> int8 SOFTMAX over
+    # the positions -> MUL -> SUM, sigmoid head
+    "ds_attnpool_sigmoid": dict(use_inverted_residual=False, use_se=False, use_attention_pooling=True, class_activation="sigmoid", alpha=0.5),
     "raw_pad_nomag_ds": dict(audio_frontend="raw", mag_scale="none", sample_rate=6000, chunk_duration=0.5, spec_width=128, num_mels=32,
                              use_se=False, use_inverted_residual=False),
 }
@@ -266,7 +269,12 @@ def test_exported_int8_graph_tracks_the_float_model(name):
     assert raw[4:8] == b"TFL3" and model.ops[0].name == "QUANTIZE" and model.tensors[model.inputs[0]].dtype == np.float32
     names = {op.name for op in model.ops}
     assert names <= {"QUANTIZE", "TRANSPOSE", "CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "MUL", "MEAN", "FULLY_CONNECTED", "LOGISTIC", "DEQUANTIZE", "SOFTMAX",
-                     "REDUCE_MAX", "DIV", "RESHAPE", "PAD"}
+                     "REDUCE_MAX", "DIV", "RESHAPE", "PAD", "SUM"}
+    if EXPORT_TOPOLOGIES[name].get("use_attention_pooling"):
+        assert [op.name for op in model.ops][-10:-3] == ["RESHAPE", "FULLY_CONNECTED", "RESHAPE", "SOFTMAX", "RESHAPE", "MUL", "SUM"]
+        sm = next(op for op in model.ops if op.name == "SOFTMAX")
+        assert model.tensors[sm.outputs[0]].dtype == np.int8 and model.tensors[sm.outputs[0]].scale[0] == pytest.approx(1 / 256) and model.tensors[sm.outputs[0]].zero_point[0] == -128
+        assert np.array_equal(Int8Interpreter(model, softmax_form="lut").invoke(x).argmax(1), Int8Interpreter(model).invoke(x).argmax(1))
     if EXPORT_TOPOLOGIES[name].get("frontend_norm"):
         assert {"REDUCE_MAX", "DIV"} <= names
         div = next(op for op in model.ops if op.name == "DIV")
@@ -293,6 +301,34 @@ def test_exported_int8_graph_tracks_the_float_model(name):
         assert cosine(got[b], ref[b]) > 0.98, (name, b, cosine(got[b], ref[b]))
     if spec.layers[-1].attrs["activation"] == "softmax":
         assert np.allclose(got.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_int8_softmax_restatements():
+    """The int8 SOFTMAX of attention pooling in TFLite's two published forms — the reference kernel (gemmlowp fixed point: exp_on_negative_values,
+    Newton-Raphson reciprocal) and the optimized kernel (float32 exponent table): each within one output step of the real softmax, the two
+    within one step of each other (they differ on ~1e-4 of the outputs, which is why the form is a switch), the product's tables
+    (models/_quant.py: softmax_tables) equal to the oracle's arithmetic, and the fixed-point exponential accurate to 3e-7.
+    PARITY UNPINNED: restated from the published kernels (softmax.h, fixedpoint.h), no reference vectors exist."""
+    from birdnet_stm32.models import _quant as qz
+    from oracle import int8_graph as ig
+
+    rng = np.random.default_rng(0)
+    a = -rng.integers(0, 31 << 26, 20000)
+    assert np.abs(ig.exp_on_negative_values_q5(a) / 2.0**31 - np.exp(a / 2.0**26)).max() < 3e-7
+    assert np.array_equal(ig.exp_on_negative_values_q5(a), qz._exp_q5_to_q31(a))
+    for s_in in (0.004, 0.02, 0.1, 0.3, 1.0):
+        x = rng.integers(-128, 128, (3000, 32))
+        x[:10] = x[:10, :1]  # rows of equal scores
+        f = np.exp((x - x.max(-1, keepdims=True)) * np.float64(np.float32(s_in)))
+        want = np.clip(np.round(f / f.sum(-1, keepdims=True) * 256) - 128, -128, 127)
+        fixed, lut = ig.softmax_int8_fixed(x, s_in), ig.softmax_int8_lut(x, s_in)
+        assert np.abs(fixed - want).max() <= 1 and np.abs(lut - want).max() <= 1 and np.abs(fixed.astype(int) - lut).max() <= 1
+        tab = qz.softmax_tables(s_in, 1.0, "fixed")
+        d = x.max(-1, keepdims=True) - x
+        mult, shift, diff_min = ig.softmax_fixed_params(s_in, 1.0)
+        assert np.array_equal(tab[0][d] >= 0, -d >= diff_min)
+        assert np.array_equal(np.where(tab[0][d] >= 0, tab[0][d], 0), np.where(-d >= diff_min, ig.exp_on_negative_values_q5(ig.srdhm(np.where(-d >= diff_min, -d, 0) << shift, mult)), 0))
+        assert np.array_equal(qz.softmax_tables(s_in, 1.0, "lut").view(np.float32), np.exp((np.float32(-np.float32(s_in)) * np.arange(256, dtype=np.float32)).astype(np.float32)))
 
 
 def test_int8_div_and_reduce_max_restatements():
@@ -359,8 +395,8 @@ def test_exporter_refuses_what_it_cannot_express():
     args = dict(num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=10)
     with pytest.raises(NotImplementedError, match="hybrid and raw frontends"):
         netspec_to_graph(build_model("dscnn", audio_frontend="librosa", **args))
-    with pytest.raises(NotImplementedError, match="attention pooling"):
-        netspec_to_graph(build_model("dscnn", use_attention_pooling=True, **args), frontend_norm=False)
+    graph, _, _ = netspec_to_graph(build_model("dscnn", use_attention_pooling=True, **args), frontend_norm=False)  # (exported since round 3)
+    assert "SOFTMAX" in {op.name for op in graph.ops} and "SUM" in {op.name for op in graph.ops}
 
 
 def test_tflite_writer_round_trips_the_shipped_file():
@@ -398,8 +434,13 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
 
     spec, model, _, x = _export(EXPORT_TOPOLOGIES[name])
     x = np.concatenate([x, np.zeros_like(x[:1])])  # a silent chunk: with the max normalisation its denominator is the epsilon alone
-    ref, env = Int8Interpreter(model).invoke(x, return_all=True)
     B = x.shape[0]
+    if EXPORT_TOPOLOGIES[name].get("use_attention_pooling"):  # the other published form of the int8 SOFTMAX (float32 exponent table), oracle and device
+        want = Int8Interpreter(model, softmax_form="lut").invoke(x)
+        r2 = HipRunner(lower_i8(model, softmax_form="lut"), max_batch=B)
+        assert np.array_equal(r2.predict(x), want)
+        r2.close()
+    ref, env = Int8Interpreter(model).invoke(x, return_all=True)
     for fuse in (True, False):
         runner = HipRunner(lower_i8(model, keep_all=True, fuse=fuse), max_batch=B)
         got = runner.predict(x)
@@ -417,7 +458,7 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
             bad = int((a != r).sum())
             assert bad == 0, f"{name} fuse={fuse}: tensor {op.name} (plan op {oi}, kind {op.kind}): {bad} of {a.size} values differ"
             checked += 1
-        assert checked >= 14  # (the plain depthwise-separable topology has the fewest operators)
+        assert checked >= 12  # (the plain depthwise-separable topologies have the fewest operators)
         softmax = spec.layers[-1].attrs["activation"] == "softmax"
         assert np.allclose(got, ref, atol=1e-6) if softmax else np.array_equal(got, ref)
         runner.close()
