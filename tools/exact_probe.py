@@ -1,3 +1,8 @@
+"""INT8 from audio against the oracle for the three settings of option stft_exact (2: float32 STFT + float64 pass over the elements in doubt, the
+default; 1: every bin in float64; 0: round 2's plain float32 STFT): flipped input bytes, score equality, counters of the exactness pass, time per call.
+
+    python tools/exact_probe.py [chunks] [plain]      # `plain`: without the pathological chunks (pure tone, DC, zero tail, impulse)
+"""
 import os, sys, time
 import numpy as np, torch
 REPO="/root/repo" if os.path.isdir("/root/repo/tests") else os.environ.get("GRAFT_REPO_ROOT",".")

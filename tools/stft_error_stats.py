@@ -1,50 +1,63 @@
-"""|S' - S| of the float32 STFT kernel against the float64 oracle, in units of the bound the exactness pass assumes
-(csrc/bn_quant_in.h: kStftGuard * ||frame||_2), for several signal families; and bn_stft_mag_exact == oracle bit for bit.
+"""|S' - S| of the float32 STFT kernel (stft512_mag_kernel) against the float64 oracle over 16 signal families, binned by S' / ||x||_2, and the
+largest error in units of candidate bounds  u (a ||x_t||_2 + b max_k S'_tk + c S')  — how the constants of csrc/bn_quant_in.h (48, 8, 14: the first
+combination listed) were chosen: 4 x what covers the largest error seen.  Run on the GPU box:
 
     python tools/stft_error_stats.py [chunks per family]
 """
-import os
-import sys
-
-import numpy as np
-import torch
-
+import os, sys
+import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "birdnet-stm32_amd")]
-from oracle import stft  # noqa: E402
-
-from birdnet_stm32 import _hip  # noqa: E402
-from birdnet_stm32.models.runners import stft_device  # noqa: E402
-
+from oracle import stft
+from birdnet_stm32 import _hip
+from birdnet_stm32.models.runners import stft_device
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T, W, sr = 72000, 256, 24000
-rng = np.random.default_rng(5)
+rng = np.random.default_rng(11)
 t = np.arange(T) / sr
 fam = {}
 fam["tone+noise"] = np.stack([0.3 * rng.standard_normal(T) + np.sin(2 * np.pi * (500 + 37 * b) * t) for b in range(N)])
-fam["pure tone"] = np.stack([np.sin(2 * np.pi * (440.0 + 13.7 * b) * t) for b in range(N)])
+fam["pure tone"] = np.stack([np.sin(2 * np.pi * (440.0 + 113.7 * b) * t) for b in range(N)])
+fam["bin-centred"] = np.stack([np.sin(2 * np.pi * (46.875 * (3 + 7 * b)) * t) for b in range(N)])
+fam["two tones"] = np.stack([np.sin(2 * np.pi * (1000.0 + 50 * b) * t) + 0.5 * np.sin(2 * np.pi * (3000.0 + 77.7 * b) * t) for b in range(N)])
 fam["noise"] = rng.standard_normal((N, T))
-fam["dc+step"] = np.concatenate([np.ones((N // 2, T)), np.repeat((np.arange(T) > T // 3)[None, :], N - N // 2, 0)]).astype(np.float64)
-fam["impulses"] = (rng.random((N, T)) < 1e-3).astype(np.float64)
-fam["zero tail"] = np.stack([np.where(np.arange(T) < 5000 + 997 * b, rng.standard_normal(T), 0.0) for b in range(N)])
-fam["square"] = np.sign(np.sin(2 * np.pi * 1000.0 * t))[None, :].repeat(N, 0) + 0.0
-fam["quiet"] = 1e-4 * fam["tone+noise"]
+fam["chirp"] = np.stack([np.sin(2 * np.pi * (500 * t + (3500 + 100 * b) / 6 * t * t)) for b in range(N)])
+fam["dc"] = np.ones((N, T))
+fam["square"] = np.stack([np.sign(np.sin(2 * np.pi * (300.0 + 91 * b) * t)) for b in range(N)])
+fam["impulses"] = (rng.random((N, T)) < 2e-3) * rng.standard_normal((N, T))
+fam["harmonics"] = np.stack([sum(np.sin(2 * np.pi * (110.0 + 7 * b) * h * t) / h for h in range(1, 40)) + 0.01 * rng.standard_normal(T) for b in range(N)])
+fam["clipped"] = np.clip(3 * fam["tone+noise"], -1, 1)
+fam["low tone"] = np.stack([np.sin(2 * np.pi * (5.0 + 3 * b) * t) for b in range(N)])
+fam["nyquist"] = np.stack([np.sin(2 * np.pi * (11990.0 - 13 * b) * t) for b in range(N)])
+fam["onset"] = np.stack([np.where(t > 0.5 + 0.07 * b, np.sin(2 * np.pi * 3000 * t), 0.0) for b in range(N)])
+fam["tone>>noise"] = np.stack([1e-4 * rng.standard_normal(T) + np.sin(2 * np.pi * (700 + 37 * b) * t) for b in range(N)])
+fam["am"] = np.stack([(1 + 0.9 * np.sin(2 * np.pi * 7 * t)) * np.sin(2 * np.pi * (2000 + 10 * b) * t) for b in range(N)])
 ctx = _hip.Context(0, N)
-guard = 2.0**-15 * 1.01
+u = 2.0**-24
+edges = [0, 0.25, 0.5, 1, 2, 4, 8, 16, 64]
+tot = np.zeros(len(edges) - 1)
+combos = [(48, 8, 14), (48, 20, 0), (48, 7, 14), (40, 8, 16), (48, 6, 16), (32, 10, 14), (48, 8, 12), (56, 6, 14), (64, 4, 14), (48, 5, 14), (64, 6, 12)]
+worst = np.zeros(len(combos))
 for name, x in fam.items():
-    x = (x / max(np.abs(x).max(), 1e-30) if name != "quiet" else x).astype(np.float32)
+    x = (x / max(np.abs(x).max(), 1e-30)).astype(np.float32)
     d = torch.from_numpy(x).cuda()
-    S_ref = np.stack([stft.stft_magnitude(a, 512, T // W)[:, :W] for a in x])
-    S32 = stft_device(ctx, d, normalize=False).cpu().numpy()
-    S64 = stft_device(ctx, d, normalize=False, exact=True).cpu().numpy()
-    N64 = stft_device(ctx, d, normalize=True, exact=True).cpu().numpy()
-    N_ref = np.stack([stft.minmax_normalize(s) for s in S_ref])
-    # per-frame bound
+    S_ref = np.stack([stft.stft_magnitude(a, 512, T // W)[:, :W] for a in x]).astype(np.float64)
+    S32 = stft_device(ctx, d, normalize=False).cpu().numpy().astype(np.float64)
     xp = np.pad(x, ((0, 0), (256, 256)))
     idx = np.arange(512)[None, :] + (T // W) * np.arange(W)[:, None]
-    l2 = np.sqrt((xp[:, idx].astype(np.float64) ** 2).sum(-1))  # [N, W]
-    bound = guard * l2[:, None, :]
-    err = np.abs(S32.astype(np.float64) - S_ref)
-    ratio = np.where(bound > 0, err / np.maximum(bound, 1e-300), np.where(err > 0, np.inf, 0.0))
-    print(f"{name:12s} max |S'-S| / bound = {ratio.max():.4f}   rms ratio {np.sqrt((ratio**2).mean()):.5f}   exact kernel: "
-          f"{int((S64 != S_ref).sum())} of {S_ref.size} magnitudes differ, {int((N64 != N_ref).sum())} normalised values differ", flush=True)
+    l2 = np.sqrt((xp[:, idx].astype(np.float64) ** 2).sum(-1))[:, None, :] + 1e-300
+    err = np.abs(S32 - S_ref) / (u * l2)
+    rel = S32 / l2
+    P = (S32.max(axis=1, keepdims=True) / l2)
+    for ci, (a, b1, b2) in enumerate(combos):
+        worst[ci] = max(worst[ci], (err / (a + b1 * P + b2 * rel)).max())
+    row = []
+    for i in range(len(edges) - 1):
+        m = (rel >= edges[i]) & (rel < edges[i + 1])
+        v = err[m].max() if m.any() else 0.0
+        tot[i] = max(tot[i], v)
+        row.append(f"{v:7.1f}")
+    print(f"{name:12s} max err/(u||x||2) by S'/||x||2 in {edges}: " + " ".join(row) + f"   rms {np.sqrt((err**2).mean()):.2f}", flush=True)
+for c, w in zip(combos, worst):
+    print("combo", c, "max err / bound =", round(float(w), 3))
+print("overall      " + " ".join(f"{v:7.1f}" for v in tot))
