@@ -50,7 +50,7 @@ const OptName kOptions[] = {
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
-    {"stft_exact", &bn::Options::stft_exact},
+    {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap},
     {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
@@ -185,10 +185,17 @@ bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
     g.rec += b0 * ((W + 15) / 16) * bn::kGuardRec;
     g.count += b0;
     g.dirty += b0;
+    // every launch group has its own lists and counters (a batch beyond kMaxGridBatch runs the STFT stage of all groups before the plan of the first)
+    const size_t group = b0 / kMaxGridBatch;
+    g.work += b0 * ((W + 63) / 64);
+    g.n_work += group;
+    g.hard += b0;
+    g.n_hard += 2 * group;
     g.audio = m->guard_audio;  // (already offset to the launch group's first chunk by bn_infer_audio)
     g.T = m->guard_T;
     g.hop = m->guard_hop;
     g.tabs = m->ctx->tables;
+    g.flag_cap = bn::g_opt.stft_flagcap;
     return g;
 }
 
@@ -899,7 +906,8 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             return o;
         };
         const size_t o_eps = take(mb * W * 4), o_rec = take(mb * n_tiles * bn::kGuardRec * 4), o_list = take(16), o_cnt = take(mb * 4),
-                     o_dirty = take(mb * 4), o_work = take(mb * t64 * 4), o_nw = take(4), o_hard = take(2 * mb * 4), o_nh = take(8);
+                     o_dirty = take(mb * 4), o_work = take(mb * t64 * 4), o_nw = take(4 * (mb / kMaxGridBatch + 1)), o_hard = take(2 * mb * 4),
+                     o_nh = take(8 * (mb / kMaxGridBatch + 1));
         if (hipMalloc(&m->d_guard, off) != hipSuccess) return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu exactness-pass bytes failed", off));
         m->workspace_bytes += off;
         char* g = m->d_guard;

@@ -504,13 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     for (int item = MODE == 2 ? blockIdx.x : 0; item < n_items; item += MODE == 2 ? gridDim.x : 1) {
     const int bid = MODE == 2 ? a.qguard.work[item] : xcd_tile(blockIdx.x, gridDim.x);
     const int chunk = bid / tiles_x, t0 = (bid - chunk * tiles_x) << 6;
-    if (MODE == 1 && tid == 0) {
-        flag_n = 0;
-        if (blockIdx.x == 0) {  // counters of the passes behind this one
-            *a.qguard.n_work = 0;
-            a.qguard.n_hard[1] = 0;
-        }
-    }
+    if (MODE == 1 && tid == 0) flag_n = 0;
     if (MODE != 0) __syncthreads();  // (MODE 2: the previous item's tile has been consumed)
     if constexpr (!QIN) {
         const v4i* src = reinterpret_cast<const v4i*>(a.x + ((size_t)chunk * W + t0) * Kp);
@@ -616,8 +610,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         // byte; here the sample reads overlap the other workgroups' spectrogram reads.)  A workgroup that flags more than it can keep — no
         // sane audio does — makes the chunk's count exceed the list's capacity: stft_fix_kernel then takes the whole chunk in float64.
         const int nf = flag_n;
-        if (tid == 0 && nf) atomicAdd(a.qguard.count + chunk, nf > kMelFlagCap ? a.qguard.cap + 1 : nf);  // (statistics; beyond `cap`: given up)
-        if (nf > 0 && nf <= kMelFlagCap) {
+        const int keep = min(max(a.qguard.flag_cap, 0), kMelFlagCap);
+        if (tid == 0 && nf) {
+            atomicAdd(a.qguard.count + chunk, nf > keep ? a.qguard.cap + 1 : nf);  // (statistics; beyond `cap`: given up)
+            if (nf > keep) {
+                // more in doubt than this workgroup keeps (no sane audio): the chunk goes to stft512_f64_list_kernel as a whole and ALL its blocks
+                // through the mixer again (the first of the chunk's workgroups to get here lists it)
+                const int all = tiles_x >= 32 ? -1 : (1 << tiles_x) - 1;
+                if (atomicOr(a.qguard.dirty + chunk, all) == 0) {
+                    a.qguard.hard[a.qguard.hard_cap + atomicAdd(a.qguard.n_hard + 1, 1)] = chunk;
+                    for (int i = 0; i < tiles_x; ++i) a.qguard.work[atomicAdd(a.qguard.n_work, 1)] = chunk * tiles_x + i;
+                }
+            }
+        }
+        if (nf > 0 && nf <= keep) {
             // (twiddles and window staged into LDS, 12 KB behind one barrier: gathered straight from the table in L1 / L2 the kernel took 0.41 instead of 0.36 ms)
             ExactTabsW& xt = reinterpret_cast<ExactTabsW&>(xtabs_s);
             stage_tabs(xt, a.qguard.tabs);

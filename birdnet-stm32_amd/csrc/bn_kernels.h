@@ -35,6 +35,7 @@ struct Options {
     int stft_exact = 2;        // INT8 plans from audio: 2 = float32 STFT + float64 pass over the doubtful elements (bit-exact input bytes,
                                // bn_stft_exact.hip; plans / options the guarded kernels do not cover take 1), 1 = every bin as a float64
                                // DFT (same bytes, ~10 x slower), 0 = plain float32 STFT (round 2: ~3e-6 of the input bytes off by one)
+    int stft_flagcap = 1022;   // elements in doubt a workgroup of the INT8 mel mixer re-evaluates itself before it hands the chunk over (tests lower it)
     int ingest_blk = 0;        // outputs per workgroup of the resampler (0: auto)
     int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
 };
@@ -101,6 +102,7 @@ struct StftGuard {
     const float* audio;  // [B][T] the chunks' samples, their geometry and the float64 tables: the mel mixer re-evaluates the elements it finds
     int T, hop;          // in doubt itself (set per call by bn_infer_audio)
     StftTables tabs;
+    int flag_cap;        // elements in doubt a workgroup of the mel mixer keeps (<= its LDS list; option stft_flagcap: tests lower it to reach the give-up path)
 };
 
 // ---- STFT ------------------------------------------------------------------------------

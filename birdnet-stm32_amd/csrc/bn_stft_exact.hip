@@ -14,8 +14,9 @@
 //                                          some S within [S' - eps, S' + eps] (the quantiser is monotone: test the distance of its
 //                                          argument to the next rounding boundary) and re-evaluates those elements in float64 ITSELF
 //                                          (512-term DFT by a 16-lane row, bn_exact_dft.h) before the tile is multiplied
-//   K4  stft_fix_kernel + K5  i8_mel_mfma_kernel<QIN, worklist>   only for chunks in which a workgroup of K3 found more elements in
-//                                          doubt than it keeps (none for sane audio): whole chunk in float64, its blocks once more.
+//   K4  stft512_f64_list_kernel + K5  i8_mel_mfma_kernel<QIN, worklist>   only for chunks in which a workgroup of K3 found more elements
+//                                          in doubt than it keeps (none for sane audio; K3 lists them): whole chunk in float64, its blocks
+//                                          through the mixer once more.
 //
 // Elements that are not listed have the same byte for every S the bound allows, listed ones are exact: the bytes equal the
 // oracle's (oracle/stft.py + oracle/int8_graph.py) as long as the float64 DFT here and numpy's float64 FFT round to the same
@@ -177,9 +178,13 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
     float* S = spec + (size_t)b * 257 * W;
     const float* eps = g.eps + (size_t)b * W;
     const int* rec = g.rec + (size_t)b * n_tiles * kGuardRec;
-    if (lane == 0) {  // (stft_fix_kernel / the first operator's flagging start from clean counters)
+    if (lane == 0) {  // (the first operator's flagging starts from clean counters)
         g.count[b] = 0;
         g.dirty[b] = 0;
+        if (b == 0) {
+            *g.n_work = 0;
+            g.n_hard[1] = 0;
+        }
     }
     float L = 0.0f, U = __uint_as_float(0x7f800000u);
     int n_max = 0, n_min = 0;  // lane = tile
@@ -270,21 +275,6 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K4: chunks the mel mixer gave up on
-// The mel mixer (i8_mel_mfma_kernel<QIN, 1>) re-evaluates the elements it finds in doubt itself.  A workgroup of it that finds more than
-// it can keep (> 1022 of its 16 448: no sane audio does) raises the chunk's count beyond `cap`: that chunk is recomputed as a whole float64
-// spectrogram (stft512_f64_list_kernel on the second list) and all its blocks go through the mixer again.
-__global__ __launch_bounds__(256) void stft_fix_kernel(StftGuard g, int B, int W) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B || g.count[b] <= g.cap) return;
-    const int tiles64 = (W + 63) / 64;
-    g.hard[g.hard_cap + atomicAdd(g.n_hard + 1, 1)] = b;
-    const int all = tiles64 >= 32 ? -1 : (1 << tiles64) - 1;
-    const int old = atomicOr(g.dirty + b, all);
-    for (int i = 0; i < tiles64; ++i)
-        if (!(old >> i & 1)) g.work[atomicAdd(g.n_work, 1)] = b * tiles64 + i;
-}
-
 // test hook: the bytes QUANTIZE makes of the spectrogram as it lies in the workspace, [B][257][W] frequency-major
 __global__ void spec_bytes_kernel(const float* __restrict__ spec, const float* __restrict__ minmax, int W, int tile_major, float qscale, int qzp,
                                   int8_t* __restrict__ out) {
@@ -324,7 +314,9 @@ void launch_stft_fix(const StftTables& tb, const float* audio, int B, int T, int
                      const float* minmax, float qscale, int qzp, hipStream_t s) {
     (void)qscale;
     (void)qzp;
-    hipLaunchKernelGGL(stft_fix_kernel, dim3((B + 255) / 256), dim3(256), 0, s, g, B, W);
+    (void)B;
+    // chunks a workgroup of the mel mixer gave up on (it listed them itself): whole float64 spectrograms; the caller then runs the mixer's
+    // work-list form over their blocks
     // (minmax is exact already: the atomics of this pass find the same values)
     hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(128), dim3(256), 0, s, tb, audio, T, hop, W, spec, const_cast<float*>(minmax), tile_major ? 1 : 0,
                        g.hard + g.hard_cap, g.n_hard + 1, (float*)nullptr);
