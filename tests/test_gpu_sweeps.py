@@ -583,6 +583,11 @@ def test_batches_beyond_one_launch_group(torch_mod):
         big = load_model_runner(path, max_batch=B)
         got = big.infer_audio_device(audio)
         assert torch.equal(got, ref[idx]), os.path.basename(path)
+        if path == TFLITE_PATH:  # the exactness pass's give-up route in both launch groups (their lists and counters are separate)
+            from birdnet_stm32 import _hip
+
+            with _hip.options(stft_flagcap=2):
+                assert torch.equal(big.infer_audio_device(audio), ref[idx])
         spec = big.stft_device(audio).reshape(B, -1)
         assert torch.equal(big.predict_device(spec), ref_spec_scores[idx]), os.path.basename(path)
         del spec, got
