@@ -512,6 +512,26 @@ def self_launch(args, argv: list[str]) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its communicator comes up; rank 0's stdout must carry the JSON line and nothing else.
+    While active, file descriptor 1 points at stderr (the library writes with C stdio, so ``sys.stdout`` redirection would not catch it)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)  # C stdio buffers of the libraries that printed
+        except Exception:  # noqa: BLE001
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def collective_block(torch, dist, device, rows: int, n_classes: int, reps: int = 5) -> dict:
     """What RCCL saw: backend, ranks, library version, and the all-gather of ``[rows, n_classes]`` float32 per rank on its own
     (one warm-up, then ``reps`` timed calls between device synchronisations + barriers; MAX over ranks is not taken: rank 0's clock)."""
@@ -568,7 +588,11 @@ def main() -> None:
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            probe = torch.zeros(8, device=device)
+            dist.all_reduce(probe)  # the communicator (and its banner) comes up with the first collective
+            torch.cuda.synchronize(device)
 
     use_dist = world > 1 or args.collective
     if use_dist:
