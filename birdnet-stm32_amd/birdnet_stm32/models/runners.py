@@ -223,7 +223,7 @@ class HipRunner:
                 op = self.plan.ops[i]
                 rows.append({"op": i, "kind": pk.KIND_NAMES[op.kind], "name": op.name, "ms": ms[i], "launches": int(cnt[i]), "p": list(op.p)})
             else:
-                kind, name = (("stft512", "stft"), ("stft_minmax_exact", "exact min/max"), ("stft_fix", "float64 pass + redo"))[i - len(self.plan.ops)]
+                kind, name = (("stft512", "stft"), ("stft_minmax_exact", "exact min/max"), ("stft512_f64_list", "float64 pass + redo"))[i - len(self.plan.ops)]
                 rows.append({"op": i, "kind": kind, "name": name, "ms": ms[i], "launches": int(cnt[i]), "p": []})
         return rows
 

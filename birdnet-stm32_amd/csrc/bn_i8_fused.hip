@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         // spectrogram are replaced.  About 11 elements per workgroup (6.5e-4 of its 16 448): one round of 16.  (As a separate kernel over
         // per-chunk lists this cost 0.09 ms per 4096 chunks for the pass itself plus a second run of the mixer over every block with a changed
         // byte; here the sample reads overlap the other workgroups' spectrogram reads.)  A workgroup that flags more than it can keep — no
-        // sane audio does — makes the chunk's count exceed the list's capacity: stft_fix_kernel then takes the whole chunk in float64.
+        // sane audio does — puts the chunk on the give-up list: stft512_f64_list_kernel then takes the whole chunk in float64 and mode 2 redoes its blocks.
         const int nf = flag_n;
         const int keep = min(max(a.qguard.flag_cap, 0), kMelFlagCap);
         if (tid == 0 && nf) {
