@@ -529,16 +529,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             const int ft = lane & 3, fr = lane >> 2;
             const float* Sb = a.qx + (size_t)chunk * a.qF * W + (size_t)(t0 / 16 + wv) * a.qF * 16 + 4 * ft;
             // half-width of the band around a rounding boundary inside which the reference's byte may differ (bn_quant_in.h)
-            float dband[4] = {0.f, 0.f, 0.f, 0.f}, crel = 0.f;
+            float dband[4] = {0.f, 0.f, 0.f, 0.f}, crel = 0.f, inv_step = 0.f;
             if (MODE == 1) {
+                inv_step = (float)(1.0 / ((double)qi.rng * (double)qi.scale));
                 crel = kBandRel * (qi.y_rng * qi.y_scale * 1.000001f);
                 const float4 e = *reinterpret_cast<const float4*>(a.qguard.eps + (size_t)chunk * W + t0 + 16 * wv + 4 * ft);
                 const float dsc = qi.y_rng * qi.y_scale * 1.000001f;
                 // (a bound of 0 = the frame is exact: zeros, or a chunk recomputed as a whole in float64 — nothing to list)
-                dband[0] = e.x > 0.0f ? 0.5f - (e.x * dsc + kQuantSlack) : 0.75f;
-                dband[1] = e.y > 0.0f ? 0.5f - (e.y * dsc + kQuantSlack) : 0.75f;
-                dband[2] = e.z > 0.0f ? 0.5f - (e.z * dsc + kQuantSlack) : 0.75f;
-                dband[3] = e.w > 0.0f ? 0.5f - (e.w * dsc + kQuantSlack) : 0.75f;
+                const float slack = (renorm && a.qzp == -128) ? kQuantSlackFolded : kQuantSlack;
+                dband[0] = e.x > 0.0f ? 0.5f - (e.x * dsc + slack) : 0.75f;
+                dband[1] = e.y > 0.0f ? 0.5f - (e.y * dsc + slack) : 0.75f;
+                dband[2] = e.z > 0.0f ? 0.5f - (e.z * dsc + slack) : 0.75f;
+                dband[3] = e.w > 0.0f ? 0.5f - (e.w * dsc + slack) : 0.75f;
             }
             // renormalisation and the zero-point fast path are wave-uniform: picked once, outside the per-element code
             auto run = [&](auto RN, auto FAST) {
@@ -556,6 +558,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                         const int f = f0 + 16 * i + fr;
                         if (f0 + 16 * i >= Kp) break;
                         const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                        if constexpr (MODE == 1 && RN.value && FAST.value) {
+                            // Guarded form: every byte that is not provably the reference's is re-evaluated from the exact S below, so the
+                            // bytes kept here only have to be right OUTSIDE the band — one multiply-add by RN(1 / (range scale)) with the zero
+                            // point folded in stands for the two divisions (its error, u v + 128 u, is part of the band: bn_quant_in.h), and
+                            // the four tests of a load share one branch.
+                            float s[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float x = __builtin_fmaf(e[k] - qi.mn, inv_step, -128.0f);
+                                int r;
+                                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+                                const int q = min(max(r, -128), 127);
+                                tile[(16 * wv + 4 * ft + k) * stride + f] = (int8_t)(f < a.qF ? q : a.qfill);
+                                s[k] = __builtin_fmaf(e[k], crel, fabsf(__builtin_amdgcn_fractf(x + 0.5f) - 0.5f)) - dband[k];
+                            }
+                            if (fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])) >= 0.0f && f < a.qF) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (s[k] >= 0.0f) {
+                                        const int sl = atomicAdd(&flag_n, 1);
+                                        if (sl < kMelFlagCap) flags[sl] = ((t0 + 16 * wv + 4 * ft + k) << 16) | f;
+                                    }
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float x = e[k];

@@ -99,5 +99,10 @@ __device__ __forceinline__ float guard_lo(float s, float eps_f) { return __built
 // S'-proportional term of the bound (kBandRel), what is left is a constant of a few u (kQuantSlack).
 constexpr float kBandRel = kGuardRel + 8.0f * kGuardU;
 constexpr float kQuantSlack = 4.0f * kGuardU;
+// The guarded mixer (i8_mel_mfma_kernel<QIN, 1>) evaluates v - 128 = fma(S' - min, RN(1 / (range scale)), -128) instead of the two divisions:
+// against the reference's chain on the same S' that is u v for the rounded reciprocal (the chain's own two division roundings are
+// already in the 6 u v above) and one rounding of a number of magnitude <= 128, the test's v - 128 + 0.5 another: 257 u, taken as 320 u
+// (1.9e-5 of a quantisation step: 8 % more elements in doubt than with 4 u).
+constexpr float kQuantSlackFolded = 320.0f * kGuardU;
 
 }  // namespace bn
