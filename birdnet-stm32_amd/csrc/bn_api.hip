@@ -99,6 +99,7 @@ struct bn_model {
     std::vector<uint8_t> out_valid;      // per operator: it wrote its output slot in the last forward call (not when a fused kernel covered it)
     std::vector<uint8_t> slot_valid;     // per slot: some operator wrote it in the last forward call
     bool has_tail = false;               // the plan holds a usable fused tail operator
+    bool guard_form_ok = false;          // ... and its QUANTIZE has zero point -128 (the only form the guarded mixer is built for)
     bool spec_tiled_ok = false;          // the plan's first operator reads the spectrogram through i8_mel_mfma_kernel<QIN>: bn_infer_audio
                                          // may hand it the tile-major layout the STFT writes fastest
     bool spec_tiled_now = false;         // set by bn_infer_audio around its bn_forward call
@@ -841,7 +842,10 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
     // INT8 blocks: can every requantisation of the operator take the branch-free right-shift form?
     m->rq_right.assign(h.n_ops, 0);
     for (const OpRec& o : m->ops)
-        if (o.in0 == BN_SLOT_INPUT) m->spec_tiled_ok = o.kind == BN_OP_I8_DWPW && o.p[36] && o.p[30] && o.p[1] % 64 == 0;
+        if (o.in0 == BN_SLOT_INPUT) {
+            m->spec_tiled_ok = o.kind == BN_OP_I8_DWPW && o.p[36] && o.p[30] && o.p[1] % 64 == 0;
+            m->guard_form_ok = m->spec_tiled_ok && o.p[37] == -128;
+        }
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         auto all_right = [&](int t_mult, int t_shift) {
@@ -895,8 +899,8 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu spectrogram workspace bytes failed", bytes));
         m->workspace_bytes += bytes;
     }
-    if (m->spec_tiled_ok && h.dtype == BN_DTYPE_I8) {
-        // exactness pass of the audio path: per chunk W bounds, W / 16 tile records, a list of flagged elements, counters
+    if (m->guard_form_ok && h.dtype == BN_DTYPE_I8) {
+        // exactness pass of the audio path (plans with another zero point take the float64 STFT for every bin): per chunk W bounds, W / 16 tile records, a list of flagged elements, counters
         const size_t W = h.spec_width, n_tiles = (W + 15) / 16, t64 = (W + 63) / 64;
         const int cap = 1 << 20;  // a chunk's count beyond this = one of its mel-mixer workgroups gave up (more in doubt than it keeps)
         size_t off = 0;

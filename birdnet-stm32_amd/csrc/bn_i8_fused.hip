@@ -536,13 +536,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 const float4 e = *reinterpret_cast<const float4*>(a.qguard.eps + (size_t)chunk * W + t0 + 16 * wv + 4 * ft);
                 const float dsc = qi.y_rng * qi.y_scale * 1.000001f;
                 // (a bound of 0 = the frame is exact: zeros, or a chunk recomputed as a whole in float64 — nothing to list)
-                const float slack = (renorm && a.qzp == -128) ? kQuantSlackFolded : kQuantSlack;
+                const float slack = kQuantSlackFolded;
                 dband[0] = e.x > 0.0f ? 0.5f - (e.x * dsc + slack) : 0.75f;
                 dband[1] = e.y > 0.0f ? 0.5f - (e.y * dsc + slack) : 0.75f;
                 dband[2] = e.z > 0.0f ? 0.5f - (e.z * dsc + slack) : 0.75f;
                 dband[3] = e.w > 0.0f ? 0.5f - (e.w * dsc + slack) : 0.75f;
             }
             // renormalisation and the zero-point fast path are wave-uniform: picked once, outside the per-element code
+            int8_t* trow[4];  // the lane's four frames of the tile, at its frequency row
+#pragma unroll
+            for (int k = 0; k < 4; ++k) trow[k] = tile + (16 * wv + 4 * ft + k) * stride + fr;
             auto run = [&](auto RN, auto FAST) {
                 constexpr int kBatch = 20;  // Kp <= 320 (257 bins padded to 320): every load of the wave's block is issued before the first use
                 for (int f0 = 0; f0 < Kp; f0 += 16 * kBatch) {
@@ -562,24 +565,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                             // Guarded form: every byte that is not provably the reference's is re-evaluated from the exact S below, so the
                             // bytes kept here only have to be right OUTSIDE the band — one multiply-add by RN(1 / (range scale)) with the zero
                             // point folded in stands for the two divisions (its error, u v + 128 u, is part of the band: bn_quant_in.h), and
-                            // the four tests of a load share one branch.
+                            // the four tests of a load share one branch.  Rows past the last frequency get the FILL byte behind the loop.
                             float s[4];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 const float x = __builtin_fmaf(e[k] - qi.mn, inv_step, -128.0f);
-                                int r;
-                                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-                                const int q = min(max(r, -128), 127);
-                                tile[(16 * wv + 4 * ft + k) * stride + f] = (int8_t)(f < a.qF ? q : a.qfill);
-                                s[k] = __builtin_fmaf(e[k], crel, fabsf(__builtin_amdgcn_fractf(x + 0.5f) - 0.5f)) - dband[k];
+                                const float xr = __builtin_rintf(x);  // (nearest-even instead of half-away: they differ on ties only, and a tie is in doubt)
+                                trow[k][f0 + 16 * i] = (int8_t)min(max((int)xr, -128), 127);
+                                s[k] = __builtin_fmaf(e[k], crel, fabsf(x - xr)) - dband[k];  // |x - round(x)| >= 1/2 - band: within the band of a boundary
                             }
-                            if (fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])) >= 0.0f && f < a.qF) {
+                            if (fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])) >= 0.0f) {
+                                if (f < a.qF) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k)
-                                    if (s[k] >= 0.0f) {
-                                        const int sl = atomicAdd(&flag_n, 1);
-                                        if (sl < kMelFlagCap) flags[sl] = ((t0 + 16 * wv + 4 * ft + k) << 16) | f;
-                                    }
+                                    for (int k = 0; k < 4; ++k)
+                                        if (s[k] >= 0.0f) {
+                                            const int sl = atomicAdd(&flag_n, 1);
+                                            if (sl < kMelFlagCap) flags[sl] = ((t0 + 16 * wv + 4 * ft + k) << 16) | f;
+                                        }
+                                }
                             }
                             continue;
                         }
@@ -604,7 +607,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             };
             using T = std::true_type;
             using F = std::false_type;
-            if (a.qzp == -128) {
+            if constexpr (MODE == 1) {
+                run(T{}, T{});  // the guarded form exists for renormalised input with zero point -128 only (bn_api.hip: guard_form_ok)
+                for (int f = fr + ((a.qF - fr + 15) & ~15); f < Kp; f += 16) {  // padded frequency rows: the graph's FILL constant (same lane, same
+#pragma unroll                                                                 // addresses as the stores above: LDS keeps a wave's order)
+                    for (int k = 0; k < 4; ++k) trow[k][f - fr] = (int8_t)a.qfill;
+                }
+            } else if (a.qzp == -128) {
                 if (renorm) run(T{}, T{}); else run(F{}, T{});
             } else {
                 if (renorm) run(T{}, F{}); else run(F{}, F{});
