@@ -44,7 +44,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 if os.environ.get("OPS"):
     for q in rows:
-        print(f'{q["kind"]:12s} {q["name"]:28s} {q["ms"]:.3f}')
+        print(f'{q["kind"]:12s} {q["name"]:28s} {q["ms"]:.3f} {q["p"][:16]}')
 top = sorted(rows, key=lambda q: -q["ms"])[:6]
 print(json.dumps({"workload": f"{fe} frontend + alpha={alpha} IR/SE DS-CNN, {2 if fe == 'raw' else 3} s @ 24 kHz, seeded weights" + (" (BASELINE configs[4])" if (alpha, fe) == (1.5, "raw") else ""), "batch": B, "ms_per_step": round(dt * 1e3, 3),
                   "chunks_per_s": round(B / dt, 1), "plan_ops": len(r.plan.ops), 
