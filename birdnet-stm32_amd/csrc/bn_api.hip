@@ -46,7 +46,7 @@ struct OptName {
 };
 const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
-    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"front_tpw", &bn::Options::front_tpw},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},

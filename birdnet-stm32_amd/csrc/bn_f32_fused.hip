@@ -769,6 +769,7 @@ void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s) {
     const int wave_variant = g_opt.wave_dwpw;
     const int strip_variant = g_opt.f32_strip;  // (tests switch it inside one process through bn_set_option)
     if (strip_variant && f32_strip_supported(a)) return launch_f32_strip(a, s);
+    if (g_opt.f32_pw_ws && !a.has_dw && launch_f32_pw_ws(a, s)) return;
     if (wave_variant && a.has_dw && a.NB == 1 && a.Cin <= 64 && a.Cout <= 64 && 64 % (a.Cin / 4) == 0 && !a.gate) {
         switch (ct_total) {
             case 1: launch_wave<1>(a, s); return;

@@ -21,6 +21,7 @@ struct Options {
     int f32_front_staged = 1;  // LDS-staged form of the float32 front strip kernel
     int i8_pwdw = 0;           // 1: expand 1x1 + depthwise 3x3 of exported inverted-residual graphs as one kernel (i8_pwdw_kernel; bit-identical, but
                                // measured 1.5-1.8 x SLOWER than the two kernels: off by default)
+    int f32_pw_ws = 1;         // plain 1x1 convolutions with Cin > 128 through the persistent producer / consumer kernel (bn_f32_pw.hip)
     int f32_tile_slice = 0;    // > 0: cap on the 16-column tiles per workgroup slice of the f32 tile kernel (0: the default cap of 16)
     int f32_pwdw = 2;          // expand 1x1 + depthwise 3x3 of inverted-residual blocks as one kernel (the expanded map stays in LDS); 2: it also
                                // hands the squeeze-excite gate behind it per-row-block channel sums (1: the gate pools the map itself, bit-identical to 0)
@@ -185,6 +186,8 @@ void launch_f32_front(const float* fe, float* y, int B, int H0, int W0, int C, i
 void launch_f32_gap_dense(const float* x, float* scores, float* logits, int B, int P, int Cin, int Cout, int act, const float* w,
                           const float* bias, hipStream_t s);
 void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s);
+// persistent two-role kernel for plain 1x1 convolutions with Cin > 128 (bn_f32_pw.hip); false: not its shape
+bool launch_f32_pw_ws(const DwPwArgs& a, hipStream_t s);
 // row-streaming strip kernel for the wide early blocks (bn_f32_strip.hip); launch_f32_dwpw picks it when supported
 struct F32FrontStripArgs {
     const float* fe;      // [B][H0][W0]: frontend map, or raw mel energies when minmax != null
