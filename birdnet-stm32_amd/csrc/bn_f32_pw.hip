@@ -37,6 +37,11 @@ __device__ __forceinline__ float act1(float v, int act) {
     return v;
 }
 
+// The workgroup's barrier orders LDS traffic only (tiles, accumulators): global loads and stores stay in flight across it.  __syncthreads()
+// is a workgroup-scope fence as well: for the waves that store it put `s_waitcnt vmcnt(0)` in front of every barrier — the epilogue waves
+// arrived late by a store round trip at the first barrier behind each tile and the matrix waves waited for them (5.5 us per tile).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kKC = 128;            // contraction channels per slice
 constexpr int kS4 = kKC / 4 + 1;    // row stride of an activation buffer in float4 (one of padding: conflict-free fragment reads)
 constexpr int kABuf = 64 * kS4;     // one activation buffer, in float4
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
         const int et = tid - 384;
         constexpr int EP2 = 64 * Q4 / 128;
         f32x4 rp[RES ? EP2 : 1];
-        __syncthreads();
+        lds_barrier();
         for (int ti = 0; ti < my_tiles; ++ti) {
             const int base = (tile_p0(ti) * N + n_base) * 4;
             if constexpr (RES) {
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
                     rp[i] = buf_load4(rs_r, base + (p * N + 4 * c4) * 4, 0);
                 }
             }
-            for (int s = 0; s < S; ++s) __syncthreads();
+            for (int s = 0; s < S; ++s) lds_barrier();
 #pragma unroll
             for (int i = 0; i < EP2; ++i) {
                 const int item = et + 128 * i, p = item / Q4, c4 = item - p * Q4;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
                 buf_store4(rs_y, base + (p * N + 4 * c4) * 4, 0, o);
             }
         }
-        if (G & 1) __syncthreads();
+        if (G & 1) lds_barrier();
         return;
     }
 
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
             step_of(0, 0, 1, t1, s1);
             fill_issue(S1{}, 1 < G, t1, s1);
         }
-        __syncthreads();
+        lds_barrier();
         int ti = 0, s = 0;
         auto step = [&](auto CUR, auto NXT, int g) __attribute__((always_inline)) {  // set CUR held slice g (free now), NXT holds slice g + 1
             int t1, s1, t2, s2;
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
             gate_issue(g + 1 < G, t1, s1);  // (first: the commit below then waits for these loads only, not for the slice behind them)
             fill_issue(CUR, g + 2 < G, t2, s2);
             fill_commit(NXT, g + 1);
-            __syncthreads();
+            lds_barrier();
             ti = t1;
             s = s1;
         };
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
         jn = jn + 1 == KS ? 0 : jn + 1;
     }
     f32x4 acc[4][CT];
-    __syncthreads();
+    lds_barrier();
     int s = 0;
     for (int g = 0; g < G; ++g) {
         if (s == 0) {
@@ -251,10 +256,10 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) otile[(16 * gg + 4 * q + reg) * SO + (wave * CT + c) * 16 + r] = acc[gg][c][reg];
         }
-        __syncthreads();
+        lds_barrier();
         s = s + 1 == S ? 0 : s + 1;
     }
-    if (G & 1) __syncthreads();  // (the producers' steps come in pairs)
+    if (G & 1) lds_barrier();  // (the producers' steps come in pairs)
 }
 
 template <int CT, bool GATE, bool RES>

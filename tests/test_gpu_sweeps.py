@@ -490,6 +490,45 @@ def test_f32_pwdw_fused_kernel_matches_the_two_kernels(torch_mod, alpha):
     runner.close()
 
 
+# --------------------------------------------------------------------------------------- float32: plain 1x1 convolutions, three-role persistent kernel
+@pytest.mark.parametrize("alpha", [1.5, 1.0])
+def test_f32_pw_ws_kernel_matches_the_tile_kernel(torch_mod, alpha):
+    """``f32_pw_ws_kernel`` (bn_f32_pw.hip: plain 1x1 convolutions with Cin > 128 — the projections with squeeze-excite gate and residual,
+    the expansions of the late stages, the embedding convolution) against ``f32_dwpw_kernel<.., false>`` (option ``f32_pw_ws`` = 0): the
+    same k order, bias, residual, activation — scores and logits BIT FOR BIT; batch sizes that leave a partial 64-position tile (one chunk
+    = 32 positions in stage 4), an odd number of steps per workgroup, one and several tiles per workgroup; repeated launches."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_f32 import lower_f32
+    from birdnet_stm32.models.runners import HipRunner
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=alpha, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+    B = 600  # stage 3: 1200 tiles over 256 workgroups (4-5 tiles each), stage 4: 300 tiles (1-2 each)
+    runner = HipRunner(lower_f32(spec), max_batch=B)
+    from birdnet_stm32.models import _pack as pk
+
+    wide = [o for o in runner.plan.ops if o.kind == pk.F32_DWPW and o.p[2] > 128 and o.p[2] % 64 == 0 and o.p[10] % 128 in (0, 64)]
+    assert len(wide) >= 6, len(wide)  # (the shapes the kernel takes: Cin > 128, Cout a multiple of 192 or 128)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((B, 48000)).astype(np.float32)
+    x /= np.abs(x).max(axis=1, keepdims=True) + 1e-6
+    xd = torch.from_numpy(x).cuda()
+    with _hip.options(f32_pw_ws=0):
+        base_s, base_l = (t.clone() for t in runner.predict_device(xd, return_logits=True))
+        runner.profile(True)
+        runner.predict_device(xd[:8])
+        t0 = sum(r["ms"] for r in runner.profile_collect())
+        runner.profile(False)
+    assert t0 > 0
+    for rep in range(3):
+        for nb in (B, 1, 3, 64, 65, 257, 511):
+            s, l = runner.predict_device(xd[:nb], return_logits=True)
+            assert torch.equal(s, base_s[:nb]) and torch.equal(l, base_l[:nb]), f"batch {nb}, launch {rep}"
+    runner.close()
+
+
 # --------------------------------------------------------------------------------------- INT8: row-streaming depthwise kernel
 def test_i8_dw_stream_kernel_matches_the_baseline_kernel(torch_mod):
     """``i8_dw_stream_kernel`` (stand-alone depthwise 3x3 of exported inverted-residual graphs, stride 1 and 2, channel counts that
