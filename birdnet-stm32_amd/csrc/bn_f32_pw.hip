@@ -31,12 +31,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float act1(float v, int act) {
-    if (act == 1) return fmaxf(v, 0.0f);
-    if (act == 2) return fminf(fmaxf(v, 0.0f), 6.0f);
-    return v;
-}
-
 // The workgroup's barrier orders LDS traffic only (tiles, accumulators): global loads and stores stay in flight across it.  __syncthreads()
 // is a workgroup-scope fence as well: for the waves that store it put `s_waitcnt vmcnt(0)` in front of every barrier — the epilogue waves
 // arrived late by a store round trip at the first barrier behind each tile and the matrix waves waited for them (5.5 us per tile).
@@ -92,6 +86,9 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
     auto tile_p0 = [&](int ti) __attribute__((always_inline)) { return ((int)blockIdx.x + ti * (int)gridDim.x) * 64; };
     const int n_bar = G + (G & 1);  // barriers behind the first one: the loaders' steps come in pairs
 
+    // The matrix waves need one issue slot per 32 cycles; the loader / epilogue wave that shares their SIMD is the younger one and loses every
+    // arbitration at equal priority (measured: ~25 cycles per instruction in the epilogue).  Static priority for waves 4-7.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(2);
     if (wave >= 6) {
         // ------------------------------------------------------------------ waves 6-7: epilogue ------------------------------------
         // Per tile: request the residual at the tile's first step, sit out the tile's S barriers, then bias + residual + activation and
@@ -101,6 +98,8 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
         const int et = tid - 384;
         constexpr int EP2 = 64 * Q4 / 128;
         f32x4 rp[RES ? EP2 : 1];
+        const bool clamp = a.act != 0;                                           // act 1: max(v, 0); act 2: min(max(v, 0), 6)
+        const float hi = a.act == 2 ? 6.0f : __builtin_inff();
         lds_barrier();
         for (int ti = 0; ti < my_tiles; ++ti) {
             const int base = (tile_p0(ti) * N + n_base) * 4;
@@ -112,16 +111,30 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
                 }
             }
             for (int s = 0; s < S; ++s) lds_barrier();
+            // four rows at a time: their eight LDS reads in flight together; the activation's bounds are picked once (a per-element
+            // `switch` on the run-time activation cost 260 scalar branches per tile)
+            constexpr int GRP = 4;
+            static_assert(EP2 % GRP == 0, "items per epilogue thread");
 #pragma unroll
-            for (int i = 0; i < EP2; ++i) {
-                const int item = et + 128 * i, p = item / Q4, c4 = item - p * Q4;
-                f32x4 o = *reinterpret_cast<const f32x4*>(otile + p * SO + 4 * c4) + *reinterpret_cast<const f32x4*>(bias_l + 4 * c4);
-                if constexpr (RES) o += rp[i];
-                o[0] = act1(o[0], a.act);
-                o[1] = act1(o[1], a.act);
-                o[2] = act1(o[2], a.act);
-                o[3] = act1(o[3], a.act);
-                buf_store4(rs_y, base + (p * N + 4 * c4) * 4, 0, o);
+            for (int i0 = 0; i0 < EP2; i0 += GRP) {
+                f32x4 t[GRP], b[GRP];
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int item = et + 128 * (i0 + i), p = item / Q4, c4 = item - p * Q4;
+                    t[i] = *reinterpret_cast<const f32x4*>(otile + p * SO + 4 * c4);
+                    b[i] = *reinterpret_cast<const f32x4*>(bias_l + 4 * c4);
+                }
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int item = et + 128 * (i0 + i), p = item / Q4, c4 = item - p * Q4;
+                    f32x4 o = t[i] + b[i];
+                    if constexpr (RES) o += rp[i0 + i];
+                    if (clamp) {  // (wave-uniform)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], 0.0f), hi);
+                    }
+                    buf_store4(rs_y, base + (p * N + 4 * c4) * 4, 0, o);
+                }
             }
         }
         if (G & 1) lds_barrier();
