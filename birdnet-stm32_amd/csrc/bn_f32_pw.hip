@@ -58,10 +58,13 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, int voff, 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff, 0);
 }
 
-template <int CT, bool GATE, bool RES>
+// NS = columns per workgroup (column slice), CT = 16-column tiles per matrix wave: the four matrix waves are WN = NS / (16 CT) across the columns
+// times WM = 4 / WN down the rows, RG = 4 / WM row groups of 16 positions each (NS = 192, 128: 4 x 1 waves, all 64 rows; NS = 96: 2 x 2).
+template <int NS, int CT, bool GATE, bool RES>
 __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    constexpr int NS = 4 * CT * 16, SO = NS + 4, Q4 = NS / 4;
+    constexpr int SO = NS + 4, Q4 = NS / 4, WN = NS / (16 * CT), WM = 4 / WN, RG = 4 / WM;
+    static_assert(WN * CT * 16 == NS && WM * WN == 4 && RG * WM == 4, "four matrix waves cover 64 rows x NS columns");
     f32x4* abuf = reinterpret_cast<f32x4*>(lds_raw);  // [2][64][kS4]
     float* otile = lds_raw + 2 * kABuf * 4;            // [64][SO]: the accumulators of the tile that has just been multiplied
     float* bias_l = otile + 64 * SO;                   // [NS]: this column slice's bias
@@ -215,7 +218,8 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
 
     // ---------------------------------------------------------------------- consumers ---------------------------------------------
     const int lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int n_ct = N >> 4, ct0 = blockIdx.y * (4 * CT) + wave * CT, KS = K >> 4;
+    const int wn = wave % WN, wm = wave / WN, row0 = wm * RG * 16;
+    const int n_ct = N >> 4, ct0 = blockIdx.y * (NS / 16) + wn * CT, KS = K >> 4;
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.w);
     f32x4 bq[4][CT];
     int jn = 0;  // next k-step of the (cyclic) weight stream to request
@@ -225,32 +229,32 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
         for (int c = 0; c < CT; ++c) bq[u][c] = wp[((size_t)jn * n_ct + ct0 + c) * 64 + lane];
         jn = jn + 1 == KS ? 0 : jn + 1;
     }
-    f32x4 acc[4][CT];
+    f32x4 acc[RG][CT];
     lds_barrier();
     int s = 0;
     for (int g = 0; g < G; ++g) {
         if (s == 0) {
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg)
+            for (int gg = 0; gg < RG; ++gg)
 #pragma unroll
                 for (int c = 0; c < CT; ++c) acc[gg][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         const int k0 = s * kKC, ksteps = ((K - k0) < kKC ? (K - k0) : kKC) >> 4;  // 8, or 4 in a last slice of 64 channels
         const f32x4* tile = abuf + (g & 1) * kABuf;
-        f32x4 af[4], afn[4];
+        f32x4 af[RG], afn[RG];
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) af[gg] = tile[(16 * gg + r) * kS4 + q];
+        for (int gg = 0; gg < RG; ++gg) af[gg] = tile[(row0 + 16 * gg + r) * kS4 + q];
         for (int j = 0; j < ksteps; j += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int gg = 0; gg < 4; ++gg) afn[gg] = tile[(16 * gg + r) * kS4 + ((4 * (j + u + 1) + q) & 31)  /* behind the last k-step: a harmless wrap, the value is dropped */];
+                for (int gg = 0; gg < RG; ++gg) afn[gg] = tile[(row0 + 16 * gg + r) * kS4 + ((4 * (j + u + 1) + q) & 31)  /* behind the last k-step: a harmless wrap, the value is dropped */];
                 __builtin_amdgcn_sched_barrier(0);  // keep the four LDS reads AHEAD of the 48 matrix instructions (the scheduler sinks them to the block's end,
                                                     // where every k-step then waits out the LDS latency: 0.219 -> ? ms on configs[4]'s 384 -> 192 projection)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg)
+                    for (int gg = 0; gg < RG; ++gg)
 #pragma unroll
                         for (int c = 0; c < CT; ++c)
                             acc[gg][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gg][e], bq[u][c][e], acc[gg][c], 0, 0, 0);
@@ -258,16 +262,16 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
                 for (int c = 0; c < CT; ++c) bq[u][c] = wp[((size_t)jn * n_ct + ct0 + c) * 64 + lane];
                 jn = jn + 1 == KS ? 0 : jn + 1;
 #pragma unroll
-                for (int gg = 0; gg < 4; ++gg) af[gg] = afn[gg];
+                for (int gg = 0; gg < RG; ++gg) af[gg] = afn[gg];
             }
         }
         if (s == S - 1) {
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg)
+            for (int gg = 0; gg < RG; ++gg)
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) otile[(16 * gg + 4 * q + reg) * SO + (wave * CT + c) * 16 + r] = acc[gg][c][reg];
+                    for (int reg = 0; reg < 4; ++reg) otile[(row0 + 16 * gg + 4 * q + reg) * SO + (wn * CT + c) * 16 + r] = acc[gg][c][reg];
         }
         lds_barrier();
         s = s + 1 == S ? 0 : s + 1;
@@ -275,21 +279,20 @@ __global__ __launch_bounds__(512) void f32_pw_ws_kernel(PwArgs a) {
     if (G & 1) lds_barrier();  // (the producers' steps come in pairs)
 }
 
-template <int CT, bool GATE, bool RES>
+template <int NS, int CT, bool GATE, bool RES>
 bool launch_one(const PwArgs& a, int slices, hipStream_t s) {
-    constexpr int NS = 4 * CT * 16;
     const size_t smem = (size_t)2 * kABuf * 16 + (size_t)64 * (NS + 4) * sizeof(float) + NS * sizeof(float);
-    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&f32_pw_ws_kernel<CT, GATE, RES>), smem)) return false;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&f32_pw_ws_kernel<NS, CT, GATE, RES>), smem)) return false;
     int per_slice = 256 / slices;  // one persistent workgroup per CU
     if (per_slice < 1) per_slice = 1;
     if (per_slice > a.n_tiles) per_slice = a.n_tiles;
-    hipLaunchKernelGGL((f32_pw_ws_kernel<CT, GATE, RES>), dim3(per_slice, slices), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((f32_pw_ws_kernel<NS, CT, GATE, RES>), dim3(per_slice, slices), dim3(512), smem, s, a);
     return true;
 }
-template <int CT>
+template <int NS, int CT>
 bool launch_ct(const PwArgs& a, int slices, hipStream_t s) {
-    if (a.gate) return a.res ? launch_one<CT, true, true>(a, slices, s) : launch_one<CT, true, false>(a, slices, s);
-    return a.res ? launch_one<CT, false, true>(a, slices, s) : launch_one<CT, false, false>(a, slices, s);
+    if (a.gate) return a.res ? launch_one<NS, CT, true, true>(a, slices, s) : launch_one<NS, CT, true, false>(a, slices, s);
+    return a.res ? launch_one<NS, CT, false, true>(a, slices, s) : launch_one<NS, CT, false, false>(a, slices, s);
 }
 
 }  // namespace
@@ -304,8 +307,9 @@ bool launch_f32_pw_ws(const DwPwArgs& d, hipStream_t s) {
     int hw_shift = 0;
     while ((1 << hw_shift) < HW) ++hw_shift;
     PwArgs a{d.x, d.pw_w, d.pw_b, d.gate, d.res, d.y, (int)P, K, N, hw_shift, d.pw_act, (int)((P + 63) / 64), d.B};
-    if (N % 192 == 0) return launch_ct<3>(a, N / 192, s);
-    if (N % 128 == 0) return launch_ct<2>(a, N / 128, s);  // (four column tiles per consumer wave do not fit 256 registers)
+    if (N % 192 == 0) return launch_ct<192, 3>(a, N / 192, s);
+    if (N % 128 == 0) return launch_ct<128, 2>(a, N / 128, s);  // (four column tiles per consumer wave do not fit 256 registers)
+    if (N % 96 == 0) return launch_ct<96, 3>(a, N / 96, s);     // (2 x 2 matrix waves of 32 rows x 48 columns)
     return false;
 }
 
