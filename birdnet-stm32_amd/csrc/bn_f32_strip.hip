@@ -56,7 +56,7 @@ __device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t rs, v4f r, int vo
 struct Row4 { v4f t[3]; };  // the three taps (columns j = 0..2) of one input row, one channel quad
 
 template <int NW, int COUT, int S, bool RES>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 2 && COUT == 32) ? 4 : 3))) void f32_strip_kernel(DwPwArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((NW == 2 && COUT == 32) || NW == 8) ? 4 : 3))) void f32_strip_kernel(DwPwArgs a) {
     constexpr int CIN = 16 * NW, CWO = COUT / NW, NT = CWO / 16;
     static_assert(NT == 1 || NT == 2, "16 or 32 output channels per wave");
     static_assert(!RES || (CIN == COUT && S == 1), "the residual is the block input");
@@ -142,10 +142,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
         buf[w][lane] = acc;
         // LDS only: the prefetched global loads stay in flight across the barrier
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        v4f o[NT];
+        if constexpr (NW >= 8 && NT == 1) {
+            // eight waves per strip: the other waves' fragments two at a time (the eight of them at once are 32 registers: with them the kernel
+            // needs ~145 and ONE workgroup of eight waves fits a CU; at <= 128 two fit, and this kernel is bound by the per-row latency chain)
+            o[0] = pb[0];
+            v4f fc = buf[0][lane], fn = buf[1][lane];
+#pragma unroll
+            for (int ks = 0; ks < NW; ++ks) {
+                const v4f fu = fc;
+                fc = fn;
+                if (ks + 2 < NW) fn = buf[ks + 2][lane];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mfma_acc(o[0], pa[0][ks][g], fu[g]);
+            }
+        } else {
         v4f f[NW];
 #pragma unroll
         for (int ks = 0; ks < NW; ++ks) f[ks] = buf[ks][lane];
-        v4f o[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             o[t] = pb[t];
@@ -153,6 +167,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((NW == 
             for (int ks = 0; ks < NW; ++ks)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) mfma_acc(o[t], pa[t][ks][g], f[ks][g]);
+        }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
