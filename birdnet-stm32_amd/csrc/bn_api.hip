@@ -1366,7 +1366,7 @@ int bn_get_option(const char* name, int* value) {
 
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
-           "f32_pw_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
+           "f32_pw_kernel\nf32_pw_ws_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
            "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_attnpool_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }
