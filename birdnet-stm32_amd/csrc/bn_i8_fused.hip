@@ -535,12 +535,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 crel = kBandRel * (qi.y_rng * qi.y_scale * 1.000001f);
                 const float4 e = *reinterpret_cast<const float4*>(a.qguard.eps + (size_t)chunk * W + t0 + 16 * wv + 4 * ft);
                 const float dsc = qi.y_rng * qi.y_scale * 1.000001f;
-                // (a bound of 0 = the frame is exact: zeros, or a chunk recomputed as a whole in float64 — nothing to list)
+                // A bound of 0 = the frame's values are exact (zeros, or a chunk recomputed as a whole in float64).  Its band is NOT empty: the
+                // kept bytes come from the folded multiply-add, whose own error (kQuantSlackFolded + the S'-proportional term) can cross a
+                // rounding boundary — those elements are listed like any other and get the exact chain (found by tools/exact_soak.py: with
+                // "nothing to list" for exact frames 304 of 245 812 whole-float64 chunks ended with different scores).
                 const float slack = kQuantSlackFolded;
-                dband[0] = e.x > 0.0f ? 0.5f - (e.x * dsc + slack) : 0.75f;
-                dband[1] = e.y > 0.0f ? 0.5f - (e.y * dsc + slack) : 0.75f;
-                dband[2] = e.z > 0.0f ? 0.5f - (e.z * dsc + slack) : 0.75f;
-                dband[3] = e.w > 0.0f ? 0.5f - (e.w * dsc + slack) : 0.75f;
+                dband[0] = 0.5f - (e.x * dsc + slack);
+                dband[1] = 0.5f - (e.y * dsc + slack);
+                dband[2] = 0.5f - (e.z * dsc + slack);
+                dband[3] = 0.5f - (e.w * dsc + slack);
             }
             // renormalisation and the zero-point fast path are wave-uniform: picked once, outside the per-element code
             int8_t* trow[4];  // the lane's four frames of the tile, at its frequency row
