@@ -239,7 +239,9 @@ BN_API int bn_debug_op_output(bn_model* model, int op_index, int B, void* d_dst,
  * one addend (same preconditions, shift >= -22), zero point subtracted again.  (Reference: the int8 kernels inside
  * tf.lite.Interpreter.invoke, birdnet_stm32/models/runners.py:93.) */
 /* Test hook: the int8 bytes the graph's QUANTIZE (op #0) made of the spectrograms of the last bn_infer_audio call on an INT8 plan,
- * d_out [B, 257, W] frequency-major (the production plan never stores them: QUANTIZE is fused into the mel mixer's load). */
+ * d_out [B, 257, W] frequency-major (the production plan never stores them: QUANTIZE is fused into the mel mixer's load).  It is a VIEW:
+ * the bytes are recomputed from the spectrogram the call left behind with the graph's exact QUANTIZE chain, not read back from the mixer's
+ * tile — tests that check the bytes check the scores (or the pre-sigmoid bytes) as well, which is what the network consumed. */
 BN_API int bn_debug_input_bytes(bn_model* model, int B, int8_t* d_out, void* stream);
 /* Test hook (synchronises the device): counters of the exactness pass of the last bn_infer_audio call on an INT8 plan (first launch group) —
  * out[0] elements listed as in doubt (sum over the B chunks), out[1] the largest count of one chunk, out[2] (chunk, 64-frame block) pairs
