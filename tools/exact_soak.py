@@ -2,7 +2,7 @@
 elements in doubt) against the all-float64 STFT (stft_exact = 1, itself checked against the oracle by tests/test_gpu_sweeps.py) on many batches of
 random signals from a dozen families with random parameters — generated on the device, so the CPU oracle's speed does not limit the count.
 
-    python tools/exact_soak.py [batches] [chunks per batch]      # prints one summary line; exit code 1 on any differing byte
+    python tools/exact_soak.py [batches] [chunks per batch] [seed]      # prints one summary line; exit code 1 on any differing byte or score
 """
 import os
 import sys
@@ -21,7 +21,8 @@ n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 T, sr = 72000, 24000
 dev = torch.device("cuda")
-g = torch.Generator(device=dev).manual_seed(1234)
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1234
+g = torch.Generator(device=dev).manual_seed(seed)
 t = torch.arange(T, device=dev, dtype=torch.float64) / sr
 
 
@@ -79,6 +80,6 @@ for i in range(n_batches):
     whole += st["whole_minmax"] + st["whole_fix"]
     if d:
         print(f"batch {i} (family {i % 12}): {d} bytes differ", flush=True)
-print(f"exactness soak: {total} chunks of 12 signal families, {bad_bytes} differing input bytes, {bad_scores} chunks with differing scores; "
+print(f"exactness soak (seed {seed}): {total} chunks of 12 signal families, {bad_bytes} differing input bytes, {bad_scores} chunks with differing scores; "
       f"{listed / (total * 257 * 256):.2e} of the elements re-evaluated in float64, {whole} chunks as whole float64 spectrograms")
 sys.exit(1 if bad_bytes or bad_scores else 0)
