@@ -1,4 +1,4 @@
-// bn_f32_pw.hip — plain float32 1x1 convolutions of the wide layers (Cin >= 192) as a persistent kernel with two roles
+// bn_f32_pw.hip — plain float32 1x1 convolutions of the wide layers (Cin > 128) as a persistent kernel in three roles
 //
 //   y[p][n] = act( sum_k (x[p][k] * gate[chunk(p)][k]) * W[k][n] + b[n] [+ res[p][n]] )
 //
@@ -11,17 +11,21 @@
 // resident workgroups per CU do not overlap their phases (staggered starts and raised priority for the memory phases changed nothing).
 // Here the overlap is by construction.  One 512-thread workgroup per CU walks over 64-position tiles:
 //
-//   * waves 4-7 (PRODUCERS) keep the next 128-channel slice of the activations in flight while the current one is multiplied: loads (and
-//     the gate) into registers right behind the barrier, written into the other half of a double-buffered LDS tile before the next
-//     barrier; they also run the epilogue of the PREVIOUS tile (bias, residual prefetched one slice earlier, activation, whole-row
-//     stores) while the consumers already multiply the next one;
-//   * waves 0-3 (CONSUMERS, one per SIMD) do nothing but matrix instructions: 64 rows x CT column tiles each, A fragments from LDS one
-//     k-step ahead, B fragments (weights in fragment order, L2) FOUR k-steps ahead in a rotating register set that runs on across slices
-//     and tiles (the weight stream is cyclic), accumulators dumped into a separate LDS tile behind a tile's last slice;
-//   * one workgroup barrier per slice is the only synchronisation: the producers' slice g + 1 and the consumers' slice g meet there.
+//   * waves 0-3 (MATRIX waves, one per SIMD) do nothing but matrix instructions: 64 rows x CT column tiles each (or 2 x 2 waves of 32 rows x
+//     48 columns for 96 columns), A fragments from LDS one k-step ahead, B fragments (weights in fragment order, L2) FOUR k-steps ahead in a
+//     rotating register set that runs on across slices and tiles (the weight stream is cyclic), accumulators dumped into a separate LDS
+//     tile behind a tile's last slice;
+//   * waves 4-5 (LOADERS) keep the next TWO 128-channel slices of the activations in flight while the current one is multiplied: range-checked
+//     buffer loads in straight-line steps (what does not apply to a step is requested behind the buffer's end), the gate requested at the
+//     start of the step and applied on the way into the other half of a double-buffered LDS tile;
+//   * waves 6-7 (EPILOGUE) request a tile's residual at its first step and, behind its last barrier, add bias and residual, clamp and store
+//     whole rows while the matrix waves already multiply the next tile;
+//   * one LDS-only barrier per slice is the only synchronisation; waves 4-7 run at raised priority (beside a wave that streams matrix
+//     instructions the other wave of the SIMD otherwise loses every issue arbitration).
 //
+// Why three roles, which barrier, why no branch in a loader step: DESIGN.md §4 (kernel table) lists what each cost when it was missing.
 // Same arithmetic in the same order as the tile kernel (v_mfma_f32_16x16x4_f32 chains over k in ascending order, bias, residual,
-// activation): results are bit-identical to it (tests/test_gpu_sweeps.py).
+// activation): results are bit-identical to it (tests/test_gpu_sweeps.py: test_f32_pw_ws_kernel_matches_the_tile_kernel).
 #include <type_traits>
 
 #include "bn_kernels.h"
