@@ -872,7 +872,9 @@ void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s)
     // rows per wave: as tall as possible while the launch still fills the chip a few times over
     int th = a.OH;
     if (a.OW != 8) {
-        while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 16384) th = (th + 1) / 2;
+        // two rounds of resident waves (4 per SIMD x 1024 SIMDs) are enough to fill the chip; halving the rows beyond that only adds prologues
+        // (stage2_ds1 at 4096 chunks: 8 rows per wave 2.079 ms per step, 16 rows 2.058 — tools/ab_option.py i8_strip_th)
+        while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) * nw < 8192) th = (th + 1) / 2;
         if (const int v = g_opt.i8_strip_th; v >= 1) th = v < a.OH ? v : a.OH;  // tests: force the rows per wave
     }  // 8-wide maps: the whole (even) height, half per lane group
     a.TH = th;
@@ -906,7 +908,7 @@ bool i8_front_strip_supported(int H0, int W0, int C, int N, int OH, int OW) {
 
 void launch_i8_front_strip(FrontStrip8Args a, hipStream_t s) {
     int th = a.OH;
-    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 16384) th = (th + 1) / 2;
+    while (th > 4 && (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th) < 8192) th = (th + 1) / 2;
     if (const int v = g_opt.i8_strip_th; v >= 1) th = v < a.OH ? v : a.OH;
     a.TH = th;
     const long waves = (long)a.B * (a.OW / 16) * ((a.OH + th - 1) / th);
