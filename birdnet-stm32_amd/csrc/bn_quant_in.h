@@ -84,7 +84,7 @@ __device__ __forceinline__ float numpy_cabsf(float re, float im) {
 // The constants are 4 x what tools/stft_error_stats.py needs to cover the largest error it finds over 16 signal families
 // (tones on and between bins, two tones, chirps, AM, harmonics, noise, impulses, DC, square, clipped, onsets, near-DC and
 // near-Nyquist tones; 2.5e7 elements: largest |S' - S| / eps = 0.25; tools/guard_margin.py on the device, 20 families with random parameters,
-// 4.3e10 elements: 0.34 — profiles/r03_guard_margin.md).  It is an EMPIRICAL bound with that margin, not a
+// 2.2e11 elements: 0.343 — profiles/r03_guard_margin.md).  It is an EMPIRICAL bound with that margin, not a
 // worst-case one: the worst case over all rounding patterns (every one of ~65 roundings per path aligned over 512 samples)
 // is ~1000 u ||x||_2 and would put 5e-3 of all elements in doubt instead of 6e-4.  bn_set_option("stft_exact", 1) computes
 // every bin in float64 for callers who want no bound at all.
