@@ -5,7 +5,7 @@
 
 * kernel-trace --stats: calls, total / average duration per kernel (product kernels only);
 * SQ passes: instruction mix per wave; with the second pass (<sq2_dir>) the wave-cycle breakdown (parked in s_waitcnt / barrier,
-  issue-stalled, issuing) and the matrix-pipe busy share: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES);
+  issue-stalled, issuing) and the matrix-pipe busy share: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), both in cycles;
 * with <bench_json> (the JSON line of the same bench.py command): each operator's 1x1-convolution OP/s as a fraction of the
   dense matrix-core peak (5 POP/s int8, 157.3 TFLOP/s float32), from its HIP-event time;
 
@@ -73,8 +73,10 @@ def main():
             wc = mean(c.get("SQ_WAVE_CYCLES", [0])) or 1
             busy_cu = mean(c.get("SQ_BUSY_CU_CYCLES", [0]))
             mfma_busy = mean(a.get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))
-            # SQ_BUSY_CU_CYCLES counts quad-cycles per CU, SQ_VALU_MFMA_BUSY_CYCLES cycles per SIMD (MI355X_MICROARCH.md: units of SQ counters)
-            pipe = 100 * mfma_busy / max(16 * busy_cu, 1)
+            # SQ_VALU_MFMA_BUSY_CYCLES = cycles, summed over the SIMDs (N_mfma x 32 for v_mfma_f32_16x16x4_f32: checked on f32_pw_ws_kernel, 9.437e6
+            # instructions -> 3.020e8); SQ_BUSY_CU_CYCLES = plain cycles per CU summed over the CUs (kernel time x clock x CUs), NOT quad-cycles —
+            # the round-2 / early round-3 digests divided by 16 and under-reported this column four-fold
+            pipe = 100 * mfma_busy / max(4 * busy_cu, 1)
             lines.append(f"| {key[0]} | {key[1]} | {4 * wc / waves:.0f} | {100 * mean(c.get('SQ_WAIT_ANY', [0])) / wc:.0f} | "
                          f"{100 * mean(c.get('SQ_WAIT_INST_ANY', [0])) / wc:.0f} | {100 * mean(c.get('SQ_ACTIVE_INST_ANY', [0])) / wc:.0f} | "
                          f"{mean(c.get('SQ_INSTS_LDS', [0])) / waves:.0f} | {pipe:.1f} |")
