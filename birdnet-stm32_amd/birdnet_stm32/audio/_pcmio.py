@@ -1,0 +1,98 @@
+"""ctypes binding of the threaded file reader in ``lib/libbn_host.so`` (``csrc/host/bn_pcmio.c``, C ABI ``include/bn_host.h``).
+
+The reference reads its test files one at a time through libsndfile (reference: birdnet_stm32/audio/io.py:89-117, called per file
+from evaluation/metrics.py:117-125).  The device pipeline of ``evaluate`` needs only the container layout on the host — the samples
+travel to the GPU as they lie in the file — so this module offers exactly two bulk operations, both running on a pool of POSIX
+threads outside the GIL: ``probe_wavs`` (header walks of many files) and ``read_windows`` (``pread`` of many byte ranges straight into
+one page-locked slab).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "lib", "libbn_host.so")
+_lib = None
+
+IO_OK, IO_OPEN, IO_NOT_WAVE, IO_NO_CHUNK, IO_SHORT = 0, -1, -2, -3, -4
+
+# every symbol include/bn_host.h declares
+EXPORTS = ("bn_wav_probe", "bn_wav_probe_many", "bn_file_read_many", "bn_copy_many", "bn_flac_info", "bn_flac_md5", "bn_flac_decode")
+
+LAYOUT_DTYPE = np.dtype([("status", "<i4"), ("format_tag", "<i4"), ("channels", "<i4"), ("sample_rate", "<i4"), ("bits", "<i4"),
+                         ("reserved", "<i4"), ("data_offset", "<i8"), ("data_bytes", "<i8")])
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: run `make -C birdnet-stm32_amd/csrc` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise RuntimeError(f"{_LIB_PATH} does not export {name}")
+        vp, i64p = ctypes.c_void_p, ctypes.c_void_p
+        lib.bn_wav_probe.argtypes = [ctypes.c_char_p, vp]
+        lib.bn_wav_probe_many.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, vp, ctypes.c_int]
+        lib.bn_file_read_many.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, i64p, i64p, vp, i64p, vp, ctypes.c_int]
+        lib.bn_copy_many.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, i64p, vp, i64p, ctypes.c_int]
+        _lib = lib
+    return _lib
+
+
+def default_threads() -> int:
+    """Reader threads: the process's CPU share, at most 16 (one GPU's share of a host), at least 2."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 2
+    return max(2, min(16, n))
+
+
+def _path_array(paths):
+    arr = (ctypes.c_char_p * len(paths))()
+    arr[:] = [os.fsencode(p) for p in paths]
+    return arr
+
+
+def probe_wavs(paths: list[str], n_threads: int | None = None) -> np.ndarray:
+    """Structured array (``LAYOUT_DTYPE``) with the RIFF/WAVE layout of every path; ``status`` != 0 marks what is not a WAV file."""
+    out = np.zeros(len(paths), LAYOUT_DTYPE)
+    if paths:
+        _load().bn_wav_probe_many(_path_array(paths), len(paths), out.ctypes.data, int(n_threads or default_threads()))
+    return out
+
+
+def read_windows(paths: list[str], file_off: np.ndarray, nbytes: np.ndarray, base_ptr: int, dst_off: np.ndarray,
+                 n_threads: int | None = None) -> np.ndarray:
+    """``nbytes[i]`` bytes from offset ``file_off[i]`` of ``paths[i]`` into ``base_ptr + dst_off[i]``; returns the per-file status.
+
+    The caller owns the destination (a page-locked slab), guarantees ``dst_off[i] + nbytes[i]`` stays inside it and that ranges
+    do not overlap.
+    """
+    n = len(paths)
+    status = np.zeros(n, np.int32)
+    if n:
+        fo = np.ascontiguousarray(file_off, np.int64)
+        nb = np.ascontiguousarray(nbytes, np.int64)
+        do = np.ascontiguousarray(dst_off, np.int64)
+        if not (fo.shape == nb.shape == do.shape == (n,)):
+            raise ValueError("file_off, nbytes and dst_off need one entry per path")
+        _load().bn_file_read_many(_path_array(paths), n, fo.ctypes.data, nb.ctypes.data, ctypes.c_void_p(int(base_ptr)), do.ctypes.data,
+                                  status.ctypes.data, int(n_threads or default_threads()))
+    return status
+
+
+def copy_into(arrays: list[np.ndarray], base_ptr: int, dst_off: np.ndarray, n_threads: int | None = None) -> None:
+    """``memcpy`` every (contiguous) array's bytes to ``base_ptr + dst_off[i]`` on the pool."""
+    n = len(arrays)
+    if not n:
+        return
+    srcs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+    nb = np.array([a.nbytes for a in arrays], np.int64)
+    do = np.ascontiguousarray(dst_off, np.int64)
+    _load().bn_copy_many(srcs, n, nb.ctypes.data, ctypes.c_void_p(int(base_ptr)), do.ctypes.data, int(n_threads or default_threads()))

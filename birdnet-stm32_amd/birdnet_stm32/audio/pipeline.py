@@ -1,0 +1,554 @@
+"""Files -> chunk scores as a three-stage pipeline: reader pool -> pinned slab -> H2D on a copy stream -> ingest + inference.
+
+What the reference does for every test file, one after another on one thread (reference: birdnet_stm32/evaluation/metrics.py:117-141:
+``load_audio_file`` -> spectrograms -> ``predict`` in batches of ``batch_size``; audio/io.py:63-130,177-213), runs here as three
+stages that overlap:
+
+1. **read** (host threads, ``csrc/host/bn_pcmio.c``): the RIFF headers of all files are walked once (``bn_wav_probe_many``); per
+   *group* of files the read windows — the first ``max_duration`` seconds, as they lie in the file — are ``pread`` straight into a
+   ring of page-locked slabs (``bn_file_read_many``; no intermediate ``bytes`` objects, no ``np.concatenate``).  Windows that share
+   (sample format, channels, native rate) lie back to back, which is the layout ``bn_ingest_resample`` takes.  Every offset table of
+   the group (window offsets, resampled offsets, chunk starts / valid lengths / owners) is written into ONE pinned table.
+2. **H2D** (copy stream): one ``non_blocking`` copy of the slab and one of the table per group into a ring of two device slabs, so
+   the copy of group g+1 runs under the kernels of group g.
+3. **compute** (the caller's stream): ``bn_ingest_resample`` per sub-group, one ``bn_ingest_chunks``, ``bn_infer_audio`` in slices
+   of the runner's ``max_batch`` into a preallocated score tensor.
+
+Nothing synchronises the host inside the loop except the ring hand-overs (events).  The chunk scores of all files stay on the GPU;
+the caller pools them (``bn_pool_scores``) once at the end.
+
+There is no CPU fallback: the module needs ``libbirdnet_hip.so`` and a GPU.  Files that are not plain PCM / float32 WAV (FLAC,
+8-bit, float64, containers only ``soundfile`` reads) are decoded on the host by ``audio.ingest.read_pcm_window`` inside the read
+stage and copied into the slab; their arithmetic still happens on the device.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import queue
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from math import gcd
+
+import numpy as np
+
+from birdnet_stm32 import _hip
+from birdnet_stm32.audio import _pcmio
+from birdnet_stm32.audio import io as _io
+from birdnet_stm32.audio.ingest import PCM_F32, PCM_S16, PCM_S24, PCM_S32, _BYTES, polyphase_filter, read_pcm_window
+
+_RAW_FORMATS = {(1, 16): PCM_S16, (1, 24): PCM_S24, (1, 32): PCM_S32, (3, 32): PCM_F32}
+_ALIGN = 256
+MAX_WINDOWS_PER_GROUP = 65535  # bn_ingest_resample's limit per launch
+
+
+def window_counts(total_frames: np.ndarray, sr0: np.ndarray, max_duration) -> np.ndarray:
+    """Frames of the read window of ``load_audio_window`` (reference io.py:95-111 with ``random_offset=False``), vectorised; the
+    same float64 operations as ``audio.ingest._window_frames`` so the counts agree exactly."""
+    total = np.asarray(total_frames, np.int64)
+    sr = np.asarray(sr0, np.int64)
+    ok = (total > 0) & (sr > 0)
+    safe_sr = np.where(ok, sr, 1).astype(np.float64)
+    duration = total.astype(np.float64) / safe_sr
+    want = np.minimum(float(max_duration), duration) if max_duration and max_duration > 0 else duration
+    count = np.minimum(total.astype(np.float64), want * safe_sr).astype(np.int64)
+    return np.where(ok, count, 0)
+
+
+def resampled_lengths(frames: np.ndarray, sr0: np.ndarray, sample_rate: int) -> np.ndarray:
+    """``len(resample_poly(x, up, down))`` = ceil(n * up / down) per window (identity at the target rate)."""
+    frames = np.asarray(frames, np.int64)
+    sr0 = np.asarray(sr0, np.int64)
+    g = np.gcd(np.where(sr0 > 0, sr0, 1), int(sample_rate))
+    up, down = int(sample_rate) // g, np.where(sr0 > 0, sr0, 1) // g
+    n = frames * up
+    return np.where(sr0 == sample_rate, frames, n // down + (n % down != 0))
+
+
+def chunk_counts(n_out: np.ndarray, sample_rate: int, chunk_duration: float, chunk_overlap: float) -> np.ndarray:
+    """``estimate_num_chunks`` (reference io.py:33-60) for an array of waveform lengths."""
+    size = int(sample_rate * chunk_duration)
+    step = _io._step(sample_rate, chunk_duration, chunk_overlap)
+    n = np.asarray(n_out, np.int64)
+    rest = np.maximum(n - size, 0)
+    many = 1 + rest // step + (rest % step != 0)
+    return np.where((n <= 0) | (size <= 0), 0, np.where(n <= size, 1, many)).astype(np.int64)
+
+
+def chunk_table_arrays(n_out: np.ndarray, sample_rate: int, chunk_duration: float, chunk_overlap: float):
+    """Vectorised ``audio.ingest.chunk_table``: ``(start within its window, valid samples, window index, chunks per window, size)``."""
+    size = int(sample_rate * chunk_duration)
+    step = _io._step(sample_rate, chunk_duration, chunk_overlap)
+    n = np.asarray(n_out, np.int64)
+    counts = chunk_counts(n, sample_rate, chunk_duration, chunk_overlap)
+    total = int(counts.sum())
+    owner = np.repeat(np.arange(n.shape[0], dtype=np.int64), counts)
+    first = np.cumsum(counts) - counts
+    j = np.arange(total, dtype=np.int64) - first[owner]
+    n_own = n[owner]
+    start = j * step
+    tail = (j == counts[owner] - 1) & (n_own > size) & ((n_own - size) % step != 0)  # the uncovered end: one more chunk at len - size
+    start = np.where(tail, n_own - size, start)
+    valid = np.where(n_own <= size, n_own, size).astype(np.int32)
+    return start, valid, owner.astype(np.int32), counts, size
+
+
+@dataclass
+class FileTable:
+    """Per-file facts the pipeline plans with (arrays over the rank's file list)."""
+
+    paths: list[str]
+    kind: np.ndarray        # 0: plain WAV payload read by the C pool; 1: decoded on the host in the read stage; -1: unreadable / empty
+    fmt: np.ndarray
+    channels: np.ndarray
+    sr0: np.ndarray
+    frames: np.ndarray      # frames of the read window
+    file_off: np.ndarray    # byte offset of the window in the file (kind 0)
+    nbytes: np.ndarray      # bytes of the window in the slab
+    n_out: np.ndarray       # samples after resampling
+    n_chunks: np.ndarray
+    decoded: dict = field(default_factory=dict)  # kind 1 windows that had to be decoded to learn their length
+
+
+def plan_files(paths: list[str], sample_rate: int, chunk_duration: float, chunk_overlap: float, max_duration=60,
+               n_threads: int | None = None) -> FileTable:
+    """Probe every file's container (threads, headers only) and derive window, resampled and chunk sizes.
+
+    Plain WAV: exact, from the header.  FLAC: from STREAMINFO (the first 64 KB of the file); a stream that does not state its length,
+    and every other container, is decoded now (``read_pcm_window``) and kept until its group is staged."""
+    n = len(paths)
+    lay = _pcmio.probe_wavs(paths, n_threads)
+    kind = np.full(n, -1, np.int32)
+    fmt = np.zeros(n, np.int32)
+    ch = lay["channels"].astype(np.int64)
+    sr0 = lay["sample_rate"].astype(np.int64)
+    bits = lay["bits"].astype(np.int64)
+    frames = np.zeros(n, np.int64)
+    file_off = np.zeros(n, np.int64)
+    is_wav_name = np.array([p.lower().endswith(".wav") for p in paths], bool) if n else np.zeros(0, bool)
+    raw_fmt = np.full(n, -1, np.int32)
+    for (code, b), f in _RAW_FORMATS.items():
+        raw_fmt[(lay["format_tag"] == code) & (bits == b)] = f
+    raw = is_wav_name & (lay["status"] == 0) & (raw_fmt >= 0) & (ch >= 1) & (sr0 > 0)
+    frame_bytes = np.where(raw, (bits // 8) * ch, 1)
+    total = np.where(raw, lay["data_bytes"] // frame_bytes, 0)
+    cnt = window_counts(total, np.where(raw, sr0, 0), max_duration)
+    raw &= cnt > 0
+    kind[raw] = 0
+    fmt[raw] = raw_fmt[raw]
+    frames[raw] = cnt[raw]
+    file_off[raw] = lay["data_offset"][raw]
+    decoded: dict[int, object] = {}
+    rest = [i for i in range(n) if not raw[i] and not (is_wav_name[i] and lay["status"][i] == 0 and cnt[i] <= 0 and raw_fmt[i] >= 0)]
+    if rest:
+        def slow(i):
+            p = paths[i]
+            if p.lower().endswith(".flac"):
+                try:
+                    from birdnet_stm32.audio import _flac
+
+                    with open(p, "rb") as fh:
+                        head = fh.read(65536)
+                    fsr, fch, bps, ftotal = _flac.flac_info(head)
+                    if ftotal > 0 and 1 <= fch and fsr > 0:
+                        c = int(window_counts(np.array([ftotal]), np.array([fsr]), max_duration)[0])
+                        return (PCM_S16 if bps == 16 else PCM_S32, fch, fsr, c, None) if c > 0 else None
+                except Exception:
+                    pass
+            w = read_pcm_window(p, max_duration, chunk_duration, False)
+            if w is None or w.frames <= 0:
+                return None
+            return (w.fmt, w.channels, w.sample_rate, w.frames, w)
+
+        with ThreadPoolExecutor(max_workers=n_threads or _pcmio.default_threads()) as pool:
+            for i, r in zip(rest, pool.map(slow, rest)):
+                if r is None:
+                    continue
+                kind[i], fmt[i], ch[i], sr0[i], frames[i] = 1, r[0], r[1], r[2], r[3]
+                if r[4] is not None:
+                    decoded[i] = r[4]
+    good = kind >= 0
+    ch = np.where(good, ch, 0)
+    sr0 = np.where(good, sr0, 0)
+    bps = np.array([_BYTES[int(f)] for f in fmt], np.int64) if n else np.zeros(0, np.int64)
+    nbytes = np.where(good, frames * ch * bps, 0)
+    n_out = np.where(good, resampled_lengths(frames, sr0, sample_rate), 0)
+    n_chunks = chunk_counts(n_out, sample_rate, chunk_duration, chunk_overlap)
+    return FileTable(list(paths), kind, fmt, ch, sr0, frames, file_off, nbytes, n_out, n_chunks, decoded)
+
+
+def cut_groups(nbytes: np.ndarray, n_chunks: np.ndarray, slab_bytes: int, group_chunks: int) -> list[tuple[int, int]]:
+    """Greedy contiguous groups of files: at most ``group_chunks`` chunks, ``slab_bytes`` bytes (with per-sub-group alignment slack)
+    and ``MAX_WINDOWS_PER_GROUP`` files each; a single file larger than either limit forms its own group."""
+    n = int(nbytes.shape[0])
+    cb = np.concatenate([[0], np.cumsum(nbytes + _ALIGN)])
+    cc = np.concatenate([[0], np.cumsum(n_chunks)])
+    groups, a = [], 0
+    while a < n:
+        b = int(min(np.searchsorted(cb, cb[a] + slab_bytes, side="right") - 1, np.searchsorted(cc, cc[a] + group_chunks, side="right") - 1,
+                    a + MAX_WINDOWS_PER_GROUP))
+        b = max(b, a + 1)
+        groups.append((a, b))
+        a = b
+    return groups
+
+
+@dataclass
+class GroupLayout:
+    """Where one group's windows lie in its slab and what its offset table holds (pure host data; see ``layout_group``)."""
+
+    lo: int
+    hi: int
+    files: np.ndarray         # file indices (table order) that made it into the group, in file order
+    counts: np.ndarray        # chunks per file of [lo, hi) (0 for files that dropped out)
+    subs: list                # per sub-group: (slab byte offset, fmt, channels, sr0, first window, n windows, in_off word offset, max_in, max_out)
+    n_windows: int
+    n_chunks: int
+    total_out: int            # resampled samples of all windows
+    used: int                 # slab bytes
+    tab_len: int              # table words (int64)
+    off_out: int              # word offsets of the tables: resampled offsets [n_windows + 1],
+    off_src: int              # chunk source positions [n_chunks] (int64),
+    off_valid: int            # chunk valid lengths [n_chunks] (int32, two per word),
+    off_owner: int            # chunk window indices [n_chunks] (int32)
+
+
+def layout_group(tab: FileTable, lo: int, hi: int, base_ptr: int, capacity: int, table: np.ndarray, sample_rate: int, chunk_duration: float,
+                 chunk_overlap: float, max_duration=60, n_threads: int | None = None) -> GroupLayout:
+    """Read the windows of files ``[lo, hi)`` into the slab at ``base_ptr`` and write the group's offset tables into ``table``.
+
+    Windows are ordered by (format, channels, native rate) — each such *sub-group* is one ``bn_ingest_resample`` launch and lies
+    back to back from a 256-byte aligned start — and keep file order inside a sub-group.  The chunk table is in FILE order, so the
+    score rows of one file are contiguous and files follow the caller's order.  A file that fails now (it was readable when probed)
+    drops out and the group is laid out again without it.  Host only: no GPU call in here.
+    """
+    alive = np.arange(lo, hi)[tab.kind[lo:hi] >= 0]
+    while True:  # (repeats only when a file failed between probing and reading)
+        key = (tab.fmt[alive].astype(np.int64) << 40) | (tab.channels[alive] << 32) | tab.sr0[alive]
+        order = np.argsort(key, kind="stable")       # window w of the group = file alive[order[w]]
+        wfile = alive[order]
+        wkey = key[order]
+        bounds = np.flatnonzero(np.concatenate([[True], wkey[1:] != wkey[:-1], [True]])) if wfile.size else np.array([0])
+        nb = tab.nbytes[wfile]
+        dst = np.zeros(wfile.shape[0], np.int64)
+        subs_meta, pos = [], 0
+        for s in range(len(bounds) - 1):
+            w0, w1 = int(bounds[s]), int(bounds[s + 1])
+            pos = -(-pos // _ALIGN) * _ALIGN
+            csum = np.cumsum(nb[w0:w1])
+            dst[w0:w1] = pos + csum - nb[w0:w1]
+            subs_meta.append((pos, w0, w1))
+            pos += int(csum[-1])
+        used = pos
+        if used > capacity:
+            raise RuntimeError(f"evaluate pipeline: a group of {used} bytes outgrew its slab of {capacity}")
+        raw_w = np.flatnonzero(tab.kind[wfile] == 0)
+        status = _pcmio.read_windows([tab.paths[i] for i in wfile[raw_w]], tab.file_off[wfile[raw_w]], nb[raw_w], base_ptr, dst[raw_w], n_threads)
+        failed = set(wfile[raw_w][status != 0].tolist())
+        host_w = np.flatnonzero(tab.kind[wfile] == 1)
+        if host_w.size:
+            def decode(w):
+                i = int(wfile[w])
+                win = tab.decoded.pop(i, None) or read_pcm_window(tab.paths[i], max_duration, chunk_duration, False)
+                if win is None or win.fmt != tab.fmt[i] or win.channels != tab.channels[i] or win.sample_rate != tab.sr0[i] or win.payload.nbytes != nb[w]:
+                    return None
+                return np.ascontiguousarray(win.payload)
+
+            with ThreadPoolExecutor(max_workers=n_threads or _pcmio.default_threads()) as pool:
+                payloads = list(pool.map(decode, host_w))
+            good = [j for j, p in enumerate(payloads) if p is not None]
+            failed |= {int(wfile[host_w[j]]) for j, p in enumerate(payloads) if p is None}
+            if good:
+                _pcmio.copy_into([payloads[j] for j in good], base_ptr, dst[host_w[good]], n_threads)
+        if not failed:
+            break
+        alive = np.array([i for i in alive if i not in failed], np.int64)
+    n_windows = int(wfile.shape[0])
+    n_chunks = int(tab.n_chunks[wfile].sum())
+    half = -(-n_chunks // 2)
+    need = (n_windows + len(subs_meta)) + (n_windows + 1) + n_chunks + 2 * half
+    if need > table.shape[0]:
+        raise RuntimeError(f"evaluate pipeline: a group's table of {need} words outgrew its buffer of {table.shape[0]}")
+    n_out = tab.n_out[wfile]
+    out_off = np.zeros(n_windows + 1, np.int64)
+    np.cumsum(n_out, out=out_off[1:])
+    cur = 0
+    subs = []
+    for pos, w0, w1 in subs_meta:
+        fr = tab.frames[wfile[w0:w1]]
+        table[cur] = 0
+        np.cumsum(fr, out=table[cur + 1 : cur + 1 + (w1 - w0)])
+        f0 = int(wfile[w0])
+        subs.append((pos, int(tab.fmt[f0]), int(tab.channels[f0]), int(tab.sr0[f0]), w0, w1 - w0, cur, int(fr.max()), int(n_out[w0:w1].max())))
+        cur += w1 - w0 + 1
+    off_out = cur
+    table[cur : cur + n_windows + 1] = out_off
+    cur += n_windows + 1
+    # chunk table in FILE order (the rows of one file contiguous, files in the caller's order)
+    win_of_file = np.empty(n_windows, np.int64)
+    win_of_file[order] = np.arange(n_windows)   # alive[j] is window win_of_file[j]
+    start, valid, owner_f, counts_f, _ = chunk_table_arrays(tab.n_out[alive], sample_rate, chunk_duration, chunk_overlap)
+    owner_w = win_of_file[owner_f]
+    off_src = cur
+    table[cur : cur + n_chunks] = start + out_off[owner_w]
+    cur += n_chunks
+    off_valid = cur
+    table[cur : cur + half].view(np.int32)[:n_chunks] = valid
+    cur += half
+    off_owner = cur
+    table[cur : cur + half].view(np.int32)[:n_chunks] = owner_w.astype(np.int32)
+    cur += half
+    counts = np.zeros(hi - lo, np.int64)
+    counts[alive - lo] = counts_f
+    return GroupLayout(lo, hi, alive, counts, subs, n_windows, n_chunks, int(out_off[-1]), used, cur, off_out, off_src, off_valid, off_owner)
+
+
+@dataclass
+class _Staged:
+    """One group on its way to the GPU."""
+
+    lay: GroupLayout
+    slot: int                 # index into the device slab ring
+    copied: object            # event: H2D of slab + table done
+    h2d_events: tuple         # (start, stop) on the copy stream
+    read_s: float
+
+
+class EvaluatePipeline:
+    """Runs files of one rank through read -> H2D -> ingest + inference; see the module docstring.
+
+    ``run(paths)`` returns ``(scores [N, C] CUDA float32 with the chunks in file order, chunks per file, stats)``.
+    """
+
+    def __init__(self, runner, sample_rate: int, chunk_duration: float, chunk_overlap: float = 0.0, max_duration=60,
+                 slab_bytes: int = 256 << 20, group_chunks: int | None = None, readers: int | None = None, pinned_slabs: int = 3):
+        import torch
+
+        self.torch = torch
+        self.runner = runner
+        self.ctx = runner.ctx
+        self.dev = runner.device
+        self.sr, self.cd, self.ov, self.max_duration = int(sample_rate), float(chunk_duration), float(chunk_overlap), max_duration
+        self.slab_bytes = int(slab_bytes)
+        self.group_chunks = int(group_chunks or max(runner.max_batch, 1024))
+        self.readers = int(readers or _pcmio.default_threads())
+        self.n_pinned = max(2, int(pinned_slabs))
+        self.size = int(self.sr * self.cd)
+        self._taps: dict[tuple[int, int], object] = {}
+        self._pinned: list = []
+        self._pinned_free: list = []   # per pinned slab: the event of the last H2D that read it
+        self._dslab: list = []
+        self._dslab_free: list = []    # per device slab: the event behind the last kernels that read it
+        self._mono = self._chunks = self._peak = None
+        self._tab_pinned: list = []
+        self._tab_dev: list = []
+        self.copy_stream = None
+        self._slot_ready = [threading.Semaphore(1), threading.Semaphore(1)]
+        self._stop = threading.Event()
+
+    # -- buffers (grow only) ------------------------------------------------------------------------------------------------
+    def _ensure_slabs(self, need: int, tab_words: int) -> None:
+        torch = self.torch
+        cap = max(self.slab_bytes, need)
+        if not self._pinned or self._pinned[0].numel() < cap:
+            self._pinned = [torch.empty(cap, dtype=torch.uint8, pin_memory=True) for _ in range(self.n_pinned)]
+            self._pinned_free = [None] * self.n_pinned
+            self._dslab = [torch.empty(cap, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            self._dslab_free = [None, None]
+        if not self._tab_pinned or self._tab_pinned[0].numel() < tab_words:
+            words = max(tab_words, 1 << 16)
+            self._tab_pinned = [torch.empty(words, dtype=torch.int64, pin_memory=True) for _ in range(self.n_pinned)]
+            self._tab_dev = [torch.empty(words, dtype=torch.int64, device=self.dev) for _ in range(2)]
+
+    def _filter(self, sr0: int):
+        """(device taps or None, up, down, taps per phase, leading outputs to drop) for one native rate."""
+        if sr0 == self.sr:
+            return None, 1, 1, 0, 0
+        g = gcd(sr0, self.sr)
+        up, down = self.sr // g, sr0 // g
+        key = (up, down)
+        if key not in self._taps:
+            taps, per_phase, pre = polyphase_filter(up, down)
+            self._taps[key] = (self.torch.from_numpy(taps).to(self.dev), per_phase, pre)
+        d, per_phase, pre = self._taps[key]
+        return d, up, down, per_phase, pre
+
+    # -- stage 1 + 2: producer thread ----------------------------------------------------------------------------------------------
+    def _stage_group(self, tab: FileTable, lo: int, hi: int, seq: int) -> _Staged:
+        torch = self.torch
+        t0 = time.perf_counter()
+        k = seq % self.n_pinned
+        prev = self._pinned_free[k]
+        if prev is not None:
+            prev.synchronize()  # the H2D that last read this pinned slab has finished
+        pinned = self._pinned[k]  # (sized for the largest group before the producer started: run())
+        lay = layout_group(tab, lo, hi, pinned.data_ptr(), pinned.numel(), self._tab_pinned[k].numpy(), self.sr, self.cd, self.ov,
+                           self.max_duration, self.readers)
+        read_s = time.perf_counter() - t0
+        # ---- H2D on the copy stream ----
+        slot = seq % 2
+        while not self._slot_ready[slot].acquire(timeout=0.1):  # the consumer has launched the group that used this device slab
+            if self._stop.is_set():
+                raise RuntimeError("evaluate pipeline stopped")
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.copy_stream):
+            free = self._dslab_free[slot]
+            if free is not None:
+                self.copy_stream.wait_event(free)  # the kernels that read this device slab / table have run
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(self.copy_stream)
+            if lay.used:
+                self._dslab[slot][: lay.used].copy_(pinned[: lay.used], non_blocking=True)
+            self._tab_dev[slot][: lay.tab_len].copy_(self._tab_pinned[k][: lay.tab_len], non_blocking=True)
+            e1.record(self.copy_stream)
+        self._pinned_free[k] = e1
+        return _Staged(lay, slot, e1, (e0, e1), read_s)
+
+    # -- stage 3: consumer (caller's thread and stream) -----------------------------------------------------------------------
+    def _compute_group(self, st: _Staged, scores, row0: int, batch: int, lat_events: list | None, stats: dict) -> None:
+        torch = self.torch
+        lib = self.ctx.lib
+        cur = torch.cuda.current_stream(self.dev)
+        g = st.lay
+        cur.wait_event(st.copied)
+        stream = ctypes.c_void_p(cur.cuda_stream)
+        if self._mono is None or self._mono.numel() < max(g.total_out, 1):
+            self._mono = torch.empty(max(g.total_out, 1) * 5 // 4 + 1024, dtype=torch.float32, device=self.dev)
+        if self._peak is None or self._peak.numel() < max(g.n_windows, 1):
+            self._peak = torch.empty(max(g.n_windows, 1) * 5 // 4 + 64, dtype=torch.float32, device=self.dev)
+        if self._chunks is None or self._chunks.shape[0] < g.n_chunks:
+            self._chunks = None
+            self._chunks = torch.empty((max(g.n_chunks, self.group_chunks), self.size), dtype=torch.float32, device=self.dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record(cur)
+        if g.n_windows:
+            self._peak[: g.n_windows].zero_()
+        slab = self._dslab[st.slot].data_ptr()
+        tab = self._tab_dev[st.slot].data_ptr()
+        for pos, fmt, ch, sr0, w0, nw, in_off, max_in, max_out in g.subs:
+            d_taps, up, down, per_phase, pre = self._filter(sr0)
+            _hip.check(lib.bn_ingest_resample(self.ctx.handle, slab + pos, fmt, ch, tab + 8 * in_off, tab + 8 * (g.off_out + w0), nw, max_in, max_out,
+                                              d_taps.data_ptr() if d_taps is not None else None, up, down, per_phase, pre,
+                                              self._mono.data_ptr(), self._peak.data_ptr() + 4 * w0, stream))
+        if g.n_chunks:
+            _hip.check(lib.bn_ingest_chunks(self.ctx.handle, self._mono.data_ptr(), self._peak.data_ptr(), tab + 8 * g.off_src, tab + 8 * g.off_valid,
+                                            tab + 8 * g.off_owner, g.n_chunks, self.size, self._chunks.data_ptr(), stream))
+        done = torch.cuda.Event()
+        done.record(cur)
+        self._dslab_free[st.slot] = done  # slab and table may be overwritten once these launches have run
+        self._slot_ready[st.slot].release()
+        ev[1].record(cur)
+        n = g.n_chunks
+        if n:
+            if lat_events is None:
+                self.runner.infer_audio_device(self._chunks[:n], out=scores[row0 : row0 + n])
+            else:
+                for b0 in range(0, n, batch):
+                    nb = min(batch, n - b0)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(cur)
+                    self.runner.infer_audio_device(self._chunks[b0 : b0 + nb], out=scores[row0 + b0 : row0 + b0 + nb])
+                    b.record(cur)
+                    lat_events.append((a, b, nb))
+        ev[2].record(cur)
+        stats["_events"].append((st.h2d_events, ev, g.used + 8 * g.tab_len))
+
+    def run(self, paths: list[str], batch_size: int | None = None, measure_latency: bool = False):
+        """Score every chunk of ``paths``: ``(scores [N, C] CUDA, chunks per file (list), stats dict, per-chunk latencies in ms)``.
+
+        ``batch_size`` only matters with ``measure_latency``: inference then runs in slices of that many chunks, each bracketed by
+        events on the launch stream (the reference's accounting: time of one ``predict`` / its batch size, replicated per chunk,
+        evaluation/metrics.py:130-136) — without a host synchronisation per slice.  Otherwise slices are the runner's ``max_batch``.
+        """
+        torch = self.torch
+        t_start = time.perf_counter()
+        stats: dict = {"_events": []}
+        with torch.cuda.device(self.dev):
+            if self.copy_stream is None:
+                self.copy_stream = torch.cuda.Stream(device=self.dev)
+            tab = plan_files(paths, self.sr, self.cd, self.ov, self.max_duration, self.readers)
+            stats["probe_s"] = time.perf_counter() - t_start
+            groups = cut_groups(tab.nbytes, tab.n_chunks, self.slab_bytes, self.group_chunks)
+            planned = int(tab.n_chunks.sum())
+            # size the rings for the largest group once, before the producer starts (nothing is reallocated while copies are in flight)
+            cb = np.concatenate([[0], np.cumsum(tab.nbytes + _ALIGN)])
+            cc = np.concatenate([[0], np.cumsum(tab.n_chunks)])
+            need_bytes = max((int(cb[b] - cb[a]) for a, b in groups), default=0)
+            need_words = max((3 * (b - a) + 2 * int(cc[b] - cc[a]) + 16 for a, b in groups), default=16)
+            self._ensure_slabs(need_bytes, need_words)
+            self._slot_ready = [threading.Semaphore(1), threading.Semaphore(1)]
+            self._dslab_free = [None, None]
+            self._pinned_free = [None] * self.n_pinned
+            self._stop.clear()
+            scores = torch.empty((max(planned, 1), self.runner.num_classes), dtype=torch.float32, device=self.dev)
+            q: queue.Queue = queue.Queue(maxsize=max(1, self.n_pinned - 1))
+            stop = self._stop
+
+            def producer():
+                try:
+                    torch.cuda.set_device(self.dev)
+                    for seq, (lo, hi) in enumerate(groups):
+                        if stop.is_set():
+                            break
+                        q.put(self._stage_group(tab, lo, hi, seq))
+                    q.put(None)
+                except BaseException as exc:  # noqa: BLE001 - handed to the consumer
+                    q.put(exc)
+
+            th = threading.Thread(target=producer, name="bn-evaluate-reader", daemon=True)
+            th.start()
+            counts = np.zeros(len(paths), np.int64)
+            lat_events: list | None = [] if measure_latency else None
+            row = 0
+            read_s = 0.0
+            try:
+                while True:
+                    g = q.get()
+                    if g is None:
+                        break
+                    if isinstance(g, BaseException):
+                        raise g
+                    self._compute_group(g, scores, row, int(batch_size or self.runner.max_batch), lat_events, stats)
+                    counts[g.lay.lo : g.lay.hi] = g.lay.counts
+                    row += g.lay.n_chunks
+                    read_s += g.read_s
+            finally:
+                stop.set()
+                while th.is_alive():  # let a blocked producer finish its put()
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        th.join(timeout=0.05)
+            torch.cuda.current_stream(self.dev).synchronize()
+            h2d_ms = ingest_ms = infer_ms = 0.0
+            moved = 0
+            for (c0, c1), ev, nbytes in stats.pop("_events"):
+                h2d_ms += c0.elapsed_time(c1)
+                ingest_ms += ev[0].elapsed_time(ev[1])
+                infer_ms += ev[1].elapsed_time(ev[2])
+                moved += nbytes
+            lat: list[float] = []
+            if lat_events:
+                for a, b, nb in lat_events:
+                    lat.extend([a.elapsed_time(b) / nb] * nb)
+        stats.update(files=len(paths), readable=int((tab.kind >= 0).sum()), chunks=row, groups=len(groups), read_s=read_s, h2d_s=h2d_ms / 1e3,
+                     h2d_bytes=moved, h2d_gbps=(moved / 1e9) / (h2d_ms / 1e3) if h2d_ms > 0 else 0.0, ingest_s=ingest_ms / 1e3,
+                     infer_s=infer_ms / 1e3, wall_s=time.perf_counter() - t_start, readers=self.readers, slab_bytes=self.slab_bytes,
+                     group_chunks=self.group_chunks)
+        return scores[:row], counts.tolist(), stats, lat
+
+
+def balanced_bounds(weights, world: int) -> list[int]:
+    """Contiguous blocks of the file list with (nearly) equal total weight: ``bounds[r] .. bounds[r+1]`` belongs to rank r.
+
+    ``weights[i]`` = chunks of file i (plus a twentieth of a chunk for the host's per-file work, so that runs of unreadable files
+    still spread).  Deterministic: every rank derives the same bounds from the same headers."""
+    w = np.asarray(weights, np.float64) + 0.05
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [int(np.searchsorted(c, c[-1] * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, len(w)
+    for r in range(1, world + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return cuts

@@ -30,7 +30,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--model_config", type=str, default="", help="Path to model config JSON")
     p.add_argument("--data_path_test", type=str, required=True, help="Path to test dataset root")
     p.add_argument("--max_files", type=int, default=-1, help="Max test files per class")
-    p.add_argument("--batch_size", type=int, default=16, help="Batch size for chunk inference")
+    p.add_argument("--batch_size", type=int, default=16,
+                   help="Batch size for chunk inference. On the GPU pipeline throughput runs use --max_batch slices; --batch_size is the "
+                        "slice size of the latency samples taken with --benchmark_latency (per-chunk latency = slice time / slice chunks)")
     p.add_argument("--overlap", type=float, default=0.0, help="Chunk overlap (seconds)")
     p.add_argument("--pooling", type=str, default="avg", choices=["avg", "max", "lme"])
     p.add_argument("--save_csv", type=str, default="", help="Optional path to save predictions CSV")
@@ -47,7 +49,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--report_html", type=str, default="")
     p.add_argument("--profile_memory", action="store_true", default=False, help="Report peak memory (RSS) during inference")
     p.add_argument("--device", type=int, default=0, help="MI355X index")
-    p.add_argument("--max_batch", type=int, default=1024, help="Workspace size in chunks")
+    p.add_argument("--max_batch", type=int, default=4096, help="Workspace size in chunks = inference slice of the device pipeline")
     return p
 
 

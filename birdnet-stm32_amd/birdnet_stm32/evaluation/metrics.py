@@ -11,11 +11,12 @@ Two execution modes:
 
 * any object with ``predict(x_batch)`` (the reference's duck-typed runner, e.g. the tests' ``FakeRunner``):
   the reference loop, one file at a time, batches never crossing files (reference :117-141);
-* a :class:`HipRunner` on a hybrid-frontend model: the *device pipeline* — the PCM of a group of files is
-  uploaded as it lies in the files; decode, mono mix, resampling, peak normalisation and chunking
-  (``bn_ingest_resample`` / ``bn_ingest_chunks``), STFT + frontend + network (``bn_infer_audio``, batches of
-  ``batch_size`` chunks crossing file boundaries — the reference never batches across files, SURVEY.md
-  finding 10) and file-level pooling (``bn_pool_scores``) all run on the GPU; one pooled row per file returns.
+* a :class:`HipRunner`: the *device pipeline* (``audio/pipeline.py``) — a reader pool ``pread``s the PCM of groups of files, as it
+  lies in the files, into pinned slabs; the H2D copy of one group runs on a copy stream under the kernels of the previous one;
+  decode, mono mix, resampling, peak normalisation and chunking (``bn_ingest_resample`` / ``bn_ingest_chunks``), STFT + frontend +
+  network (``bn_infer_audio``, slices of the runner's ``max_batch`` chunks crossing file boundaries — the reference never batches
+  across files, SURVEY.md finding 10) and file-level pooling (``bn_pool_scores``) all run on the GPU; one pooled row per file
+  returns.  ``batch_size`` is then only the granularity of the latency samples (``measure_latency``).
 """
 
 from __future__ import annotations
@@ -92,31 +93,23 @@ def _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scal
         yield path, chunk_scores.shape[0], pool_scores(chunk_scores, method=pooling, beta=beta), lat
 
 
-def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, beta, files_per_group=64):
-    """Device pipeline: ingest, inference and pooling of ``files_per_group`` files at a time on the GPU.
-
-    Per group: the PCM payloads are uploaded as they lie in the files, ``bn_ingest_resample`` + ``bn_ingest_chunks``
-    produce the chunk matrix, ``bn_infer_audio`` scores it in batches of ``batch_size`` chunks (batches cross file
-    boundaries), ``bn_pool_scores`` reduces it to one row per file; only that row travels back to the host.
-
-    Under ``torch.distributed`` (one process per GPU, ``WORLD_SIZE`` > 1) the files are dealt to the ranks in contiguous
-    blocks (``evaluation/sharding.py: score_files_sharded``): every rank scores the chunks of its files, the chunk scores
-    meet in ONE all-gather (RCCL over xGMI) and every rank pools all files from the gathered tensor, so ``evaluate``
-    returns the same metrics on every rank.  The latency list then covers this rank's batches only.
-    """
+def _score_files_device_serial(runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, beta, files_per_group=64):
+    """The device pipeline of rounds 1-3, kept as the A/B partner of :func:`_score_files_device` (``evaluate(..., pipelined=False)``,
+    ``tools/evaluate_bench.py --serial``): groups of ``files_per_group`` files are read, uploaded, ingested, scored in slices of
+    ``batch_size`` and pooled one after another, the host waiting for every step."""
     import torch
 
     from birdnet_stm32.audio.ingest import load_audio_files_device, pool_scores_device
-    from birdnet_stm32.evaluation.sharding import score_files_sharded, world_info
 
     sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
     todo = [p for p in files if _label_of(p) in classes]
     lat: list[float] = []
-
-    def score_group(group):
-        chunks, counts = load_audio_files_device(runner.ctx, group, sample_rate=sr, max_duration=60, chunk_duration=cd,
-                                                 chunk_overlap=overlap)
+    for g0 in range(0, len(todo), files_per_group):
+        group = todo[g0 : g0 + files_per_group]
+        chunks, counts = load_audio_files_device(runner.ctx, group, sample_rate=sr, max_duration=60, chunk_duration=cd, chunk_overlap=overlap)
         n = chunks.shape[0]
+        if n == 0:
+            continue
         scores = torch.empty((n, runner.num_classes), dtype=torch.float32, device=chunks.device)
         for b0 in range(0, n, batch_size):
             nb = min(batch_size, n - b0)
@@ -125,46 +118,83 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
             if measure_latency:
                 torch.cuda.synchronize(chunks.device)
                 lat.extend([(time.perf_counter() - t0) * 1000.0 / nb] * nb)
-        return scores, counts
-
-    if world_info()[1] > 1:
-        def score_block(lo, hi):
-            parts, counts = [], []
-            for g0 in range(lo, hi, files_per_group):
-                s, c = score_group(todo[g0 : min(g0 + files_per_group, hi)])
-                parts.append(s)
-                counts += c
-            return (torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]), counts
-
-        scores, counts = score_files_sharded(len(todo), score_block, runner.num_classes, device=runner.device)
-        if scores.shape[0] == 0:
-            return
-        pooled = pool_scores_device(runner.ctx, scores.contiguous(), counts, pooling, beta).cpu().numpy()
-        for path, c, row in zip(todo, counts, pooled):
-            if c:
-                yield path, c, row, lat
-        return
-
-    for g0 in range(0, len(todo), files_per_group):
-        group = todo[g0 : g0 + files_per_group]
-        scores, counts = score_group(group)
-        if scores.shape[0] == 0:
-            continue
         pooled = pool_scores_device(runner.ctx, scores, counts, pooling, beta).cpu().numpy()
         for path, c, row in zip(group, counts, pooled):
             if c:
                 yield path, c, row, lat
 
 
+def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, beta, stats: dict | None = None,
+                        pipeline_options: dict | None = None):
+    """Device pipeline: read -> H2D -> ingest + inference as overlapping stages (``audio/pipeline.py``), pooling at the end.
+
+    The host walks the headers of all files once, a reader pool ``pread``s the PCM of a group of files straight into a ring of
+    pinned slabs, one ``non_blocking`` copy per group runs on a copy stream under the kernels of the previous group
+    (``bn_ingest_resample`` + ``bn_ingest_chunks`` + ``bn_infer_audio`` in slices of the runner's ``max_batch`` chunks, crossing
+    file boundaries — the reference never batches across files, SURVEY.md finding 10), the chunk scores of all files stay on the
+    GPU and ONE ``bn_pool_scores`` launch reduces them to a row per file; only those rows travel back.
+
+    ``batch_size`` (the reference CLI's ``--batch_size``, default 16) is the latency-sample granularity only: with
+    ``measure_latency`` inference runs in slices of ``batch_size`` chunks, each bracketed by events on the launch stream (time of
+    one slice / its chunks, replicated per chunk: the reference's accounting, :130-136, without a host synchronisation per slice);
+    without it slices are ``max_batch`` chunks.
+
+    Under ``torch.distributed`` (one process per GPU, ``WORLD_SIZE`` > 1) the files are dealt to the ranks in contiguous blocks of
+    equal CHUNK count (every rank probes all headers and derives the same bounds: ``audio.pipeline.balanced_bounds``), every rank
+    scores the chunks of its files, the chunk scores meet in ONE all-gather (RCCL over xGMI; ``evaluation/sharding.py``) and every
+    rank pools all files from the gathered tensor, so ``evaluate`` returns the same metrics on every rank.  The latency list then
+    covers this rank's slices only.
+    """
+    import torch
+
+    from birdnet_stm32.audio.ingest import pool_scores_device
+    from birdnet_stm32.audio.pipeline import EvaluatePipeline, balanced_bounds, plan_files
+    from birdnet_stm32.evaluation.sharding import score_files_sharded, world_info
+
+    sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
+    todo = [p for p in files if _label_of(p) in classes]
+    lat: list[float] = []
+    if not todo:
+        return
+    pipe = EvaluatePipeline(runner, sr, cd, overlap, max_duration=60, **(pipeline_options or {}))
+    if world_info()[1] > 1:
+        weights = plan_files(todo, sr, cd, overlap, 60, pipe.readers).n_chunks  # headers only; the same on every rank
+        bounds = balanced_bounds(weights, world_info()[1])
+
+        def score_block(lo, hi):
+            s, c, st, l = pipe.run(todo[lo:hi], batch_size, measure_latency)
+            lat.extend(l)
+            if stats is not None:
+                stats.update(st)
+            return s, c
+
+        scores, counts = score_files_sharded(len(todo), score_block, runner.num_classes, device=runner.device, bounds=bounds)
+    else:
+        scores, counts, st, l = pipe.run(todo, batch_size, measure_latency)
+        lat.extend(l)
+        if stats is not None:
+            stats.update(st)
+    if scores.shape[0] == 0:
+        return
+    t0 = time.perf_counter()
+    pooled = pool_scores_device(runner.ctx, scores.contiguous(), counts, pooling, beta).cpu().numpy()
+    if stats is not None:
+        stats["pool_s"] = time.perf_counter() - t0
+    for path, c, row in zip(todo, counts, pooled):
+        if c:
+            yield path, c, row, lat
+
+
 def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pooling: str = "average", batch_size: int = 64,
              overlap: float = 0.0, mep_beta: float = 10.0, measure_latency: bool = False, profile_memory: bool = False,
-             spectrogram_fn=None, device_pipeline: bool | None = None):
+             spectrogram_fn=None, device_pipeline: bool | None = None, pipelined: bool = True, stats: dict | None = None,
+             pipeline_options: dict | None = None):
     """Run inference per chunk, pool to file level and compute metrics (reference :75-207).
 
-    Returns ``(metrics, per_file, y_true [N, C], y_scores [N, C])``.
+    Returns ``(metrics, per_file, y_true [N, C], y_scores [N, C])``.  ``stats`` (a dict) receives the device pipeline's per-stage
+    times (read / H2D / ingest / inference / pooling / metrics; ``tools/evaluate_bench.py``); ``pipelined=False`` selects the serial
+    device pipeline of earlier rounds (A/B); ``pipeline_options`` are keyword arguments of ``audio.pipeline.EvaluatePipeline``.
     """
-    from sklearn.metrics import average_precision_score, roc_auc_score
-
     frontend = normalize_frontend_name(cfg["audio_frontend"])
     mag_scale = cfg.get("mag_scale", "none")
     n_fft = int(cfg["fft_length"])
@@ -179,17 +209,24 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
     if device_pipeline:
         if pooling.lower() not in ("avg", "mean", "average", "max", "lme", "log_mean_exp", "log_mean_exponential"):
             raise ValueError(f"Unsupported pooling method: {pooling}")
-        stream = _score_files_device(model_runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, mep_beta)
+        if pipelined:
+            stream = _score_files_device(model_runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, mep_beta, stats,
+                                         pipeline_options)
+        else:
+            stream = _score_files_device_serial(model_runner, files, classes, cfg, overlap, batch_size, measure_latency, pooling, mep_beta)
     else:
         stream = _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scale, n_fft, overlap, batch_size,
                                         measure_latency, spectrogram_fn, pooling, mep_beta)
 
     y_true, y_scores, per_file, lat = [], [], [], []
     total_chunks = 0
+    index_of = {}
+    for i, name in enumerate(classes):
+        index_of.setdefault(name, i)  # (list.index: the first occurrence)
     for path, n_chunks, pooled, lat in stream:
         label = _label_of(path)
         target = np.zeros(n_cls, np.float32)
-        target[classes.index(label)] = 1.0
+        target[index_of[label]] = 1.0
         total_chunks += n_chunks
         y_true.append(target)
         y_scores.append(pooled)
@@ -217,29 +254,30 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
 
     yt = np.asarray(y_true, np.float32)
     ys = np.asarray(y_scores, np.float32)
+    t_metrics = time.perf_counter()
+    # ROC-AUC (micro), per-class AP, micro AP: the reference's three scikit-learn calls (:155-190), computed from shared sorts
+    # (evaluation/_ranking.py: bit-identical to the library, tests/test_host_logic.py); with the device pipeline the sorts run on the GPU
+    from birdnet_stm32.evaluation._ranking import ranking_metrics
+
     metrics: dict = {}
+    rank_dev = getattr(model_runner, "device", None) if device_pipeline else None
     try:
-        metrics["roc-auc"] = float(roc_auc_score(yt, ys, average="micro"))
+        ranked = ranking_metrics(yt, ys, device=rank_dev)
     except Exception:
-        metrics["roc-auc"] = float("nan")
+        ranked = {"roc-auc": float("nan"), "ap_per_class": [float("nan")] * n_cls, "mAP": float("nan")}
+    metrics["roc-auc"] = ranked["roc-auc"]
     hit = (ys >= 0.5).astype(np.float32)
     tp, fp, fn = float((yt * hit).sum()), float(((1 - yt) * hit).sum()), float((yt * (1 - hit)).sum())
     precision, recall = tp / (tp + fp + 1e-12), tp / (tp + fn + 1e-12)
     metrics["f1"] = float(2 * precision * recall / (precision + recall)) if precision + recall > 0 else 0.0
     metrics["precision"], metrics["recall"] = float(precision), float(recall)
-    aps = []
-    for c in range(n_cls):
-        try:
-            aps.append(average_precision_score(yt[:, c], ys[:, c]))
-        except Exception:
-            aps.append(np.nan)
+    aps = ranked["ap_per_class"]
     good = [a for a in aps if not (a is None or (isinstance(a, float) and math.isnan(a)))]
     metrics["ap_per_class"] = aps
     metrics["cmAP"] = float(np.mean(good)) if good else float("nan")
-    try:
-        metrics["mAP"] = float(average_precision_score(yt, ys, average="micro"))
-    except Exception:
-        metrics["mAP"] = float("nan")
+    metrics["mAP"] = ranked["mAP"]
+    if stats is not None:
+        stats["metrics_s"] = time.perf_counter() - t_metrics
     if measure_latency and lat:
         arr = np.asarray(lat)
         metrics["latency_mean_ms"] = float(arr.mean())

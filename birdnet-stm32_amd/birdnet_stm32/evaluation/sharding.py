@@ -124,19 +124,30 @@ def all_gather_ragged(local, group=None):
     return torch.cat([gathered[r * longest : r * longest + counts[r]] for r in range(world)], dim=0), counts
 
 
-def score_files_sharded(n_files: int, score_files_fn, width: int, device=None, group=None):
+def score_files_sharded(n_files: int, score_files_fn, width: int, device=None, group=None, bounds=None):
     """File-level sharding for ``evaluate``: rank r scores the files of its contiguous block, the chunk scores of all
     files meet in one (ragged) all-gather.
 
     ``score_files_fn(lo, hi) -> (scores [n_chunks, width], chunks per file [hi - lo])`` scores files ``[lo, hi)``.
     Returns ``(scores of all chunks in file order [N, width], chunks per file for all n_files)`` on every rank; pooling
     happens on the gathered tensor (the file -> chunk map stays on the host).
+
+    ``bounds`` (``world + 1`` non-decreasing file indices from 0 to ``n_files``, the same list on every rank) replaces the
+    equal-count blocks: ``evaluate`` passes blocks of equal CHUNK count (``audio.pipeline.balanced_bounds`` over the probed
+    headers), so that a dataset of mixed file lengths does not leave ranks idle.
     """
     import torch
     import torch.distributed as dist
 
     rank, world = world_info(group)
-    lo, hi = shard_bounds(n_files, rank, world)
+    if bounds is not None:
+        bounds = [int(b) for b in bounds]
+        if len(bounds) != world + 1 or bounds[0] != 0 or bounds[-1] != n_files or any(a > b for a, b in zip(bounds, bounds[1:])):
+            raise ValueError(f"bounds {bounds} do not partition {n_files} files over {world} ranks")
+        block = lambda r: (bounds[r], bounds[r + 1])  # noqa: E731
+    else:
+        block = lambda r: shard_bounds(n_files, r, world)  # noqa: E731
+    lo, hi = block(rank)
     if hi > lo:
         scores, per_file = score_files_fn(lo, hi)
     else:
@@ -146,7 +157,7 @@ def score_files_sharded(n_files: int, score_files_fn, width: int, device=None, g
     if _local_only(world):
         return scores, list(per_file)
     all_scores, _ = all_gather_ragged(scores, group=group)
-    longest = -(-n_files // world)
+    longest = max(1, max(block(r)[1] - block(r)[0] for r in range(world)))
     mine = torch.zeros(longest, dtype=torch.int64, device=scores.device)
     if per_file:
         mine[: hi - lo] = torch.tensor(per_file, dtype=torch.int64, device=scores.device)
@@ -155,6 +166,6 @@ def score_files_sharded(n_files: int, score_files_fn, width: int, device=None, g
     every = every.cpu().tolist()
     counts: list[int] = []
     for r in range(world):
-        a, b = shard_bounds(n_files, r, world)
+        a, b = block(r)
         counts += every[r * longest : r * longest + (b - a)]
     return all_scores, counts

@@ -55,6 +55,10 @@ def score_files(a, b):
 
 sc, cnt = sharding.score_files_sharded(40, score_files, 100, device=dev)
 assert cnt == per_file and torch.equal(sc, direct[: starts[-1]])
+from birdnet_stm32.audio.pipeline import balanced_bounds  # noqa: E402
+
+sc, cnt = sharding.score_files_sharded(40, score_files, 100, device=dev, bounds=balanced_bounds(per_file, world))
+assert cnt == per_file and torch.equal(sc, direct[: starts[-1]])
 torch.cuda.synchronize()
 if rank == 0:
     ver = torch.cuda.nccl.version()

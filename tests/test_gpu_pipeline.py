@@ -1,0 +1,131 @@
+"""The pipelined ``evaluate`` on the GPU (birdnet_stm32/audio/pipeline.py): reader pool -> pinned slabs -> copy stream -> ingest +
+inference, against the serial device pipeline of rounds 1-3 and the reference-style per-file loop.
+
+Reference flow being replaced: birdnet_stm32/evaluation/metrics.py:117-153 (per file: load, spectrograms, predict in batches, pool).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(__file__))
+from conftest import CONFIG_PATH, KERAS_PATH, TFLITE_PATH  # noqa: E402
+from test_pipeline_host import dataset  # noqa: E402,F401  (the mixed-format fixture: formats, rates, channels, broken files, FLAC)
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch
+
+
+def _cfg():
+    from birdnet_stm32.training.config import ModelConfig
+
+    cfg = ModelConfig.load(CONFIG_PATH).to_dict()
+    cfg.update(sample_rate=24000, hop_length=281)
+    return cfg
+
+
+def _labelled(paths, tmp_path, classes):
+    """Hard-link / copy the fixture's files into <class>/ directories (evaluate takes the label from the directory name)."""
+    import shutil
+
+    out = []
+    for i, p in enumerate(paths):
+        d = tmp_path / classes[i % 5]
+        d.mkdir(exist_ok=True)
+        q = d / f"{i:03d}_{os.path.basename(p)}"
+        if os.path.isfile(p):
+            shutil.copy(p, q)
+        out.append(str(q))
+    return out
+
+
+@pytest.mark.parametrize("model_path", [TFLITE_PATH, KERAS_PATH])
+def test_pipelined_evaluate_equals_the_serial_device_pipeline(torch_mod, dataset, tmp_path, model_path):  # noqa: F811
+    """Same kernels, same chunk order -> the pooled scores of every file are identical, whatever the grouping (several small slabs,
+    one slab, inference slices of 7 chunks in latency mode), and the skipped files are the same."""
+    import warnings
+
+    from birdnet_stm32.evaluation.metrics import evaluate
+    from birdnet_stm32.models.runners import load_model_runner
+
+    cfg = _cfg()
+    classes = cfg["class_names"]
+    files = _labelled(dataset, tmp_path, classes)
+    runner = load_model_runner(model_path, max_batch=64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)  # "n files were empty or could not be decoded"
+        m0, pf0, yt0, ys0 = evaluate(runner, files, classes, cfg, pooling="lme", batch_size=16, pipelined=False)
+        variants = [dict(slab_bytes=6 << 20, group_chunks=40, readers=3), dict(slab_bytes=256 << 20, group_chunks=100000), dict(pinned_slabs=2, group_chunks=24)]
+        for opts in variants:
+            st: dict = {}
+            m1, pf1, yt1, ys1 = evaluate(runner, files, classes, cfg, pooling="lme", batch_size=16, stats=st, pipeline_options=opts)
+            assert [p["file"] for p in pf1] == [p["file"] for p in pf0]
+            assert np.array_equal(yt1, yt0) and np.array_equal(ys1, ys0), opts
+            assert st["chunks"] >= len(pf1)
+            assert st["h2d_bytes"] > 0 and st["groups"] >= 1 and st["read_s"] > 0
+        assert st["groups"] > 3  # the last variant really ran as several groups
+        m2, pf2, _, ys2 = evaluate(runner, files, classes, cfg, pooling="lme", batch_size=7, measure_latency=True,
+                                   pipeline_options=dict(group_chunks=50))
+    assert np.array_equal(ys2, ys0)
+    assert m2["total_chunks"] == st["chunks"] and m2["latency_mean_ms"] > 0 and m2["latency_p99_ms"] >= m2["latency_median_ms"] > 0
+    runner.close()
+
+
+def test_pipelined_evaluate_equals_the_reference_loop_on_wavs(torch_mod, tmp_path):
+    """Per-file loop (host ingest, bn_stft_mag_exact, predict) vs the pipeline on PCM16 / float WAVs at three rates: mean pooling is
+    ``array_equal`` (INT8: both routes quantise the reference's bytes)."""
+    from birdnet_stm32.audio.io import save_wav
+    from birdnet_stm32.evaluation.metrics import evaluate
+    from birdnet_stm32.models.runners import load_model_runner
+
+    from conftest import synth_chunks
+
+    cfg = _cfg()
+    classes = cfg["class_names"]
+    x = synth_chunks(12)
+    files = []
+    for i in range(12):
+        d = tmp_path / classes[i % 3]
+        d.mkdir(exist_ok=True)
+        n = 72000 if i % 4 else 72000 * 2 + 30000
+        wav = np.concatenate([x[i], x[(i + 1) % 12], x[(i + 2) % 12]])[:n]
+        save_wav(wav, str(d / f"f{i}.wav"), 24000, subtype="FLOAT" if i % 2 else "PCM_16")
+        files.append(str(d / f"f{i}.wav"))
+    runner = load_model_runner(TFLITE_PATH, max_batch=16)
+    _, pf_dev, _, ys_dev = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=5, pipeline_options=dict(group_chunks=9))
+    _, pf_ref, _, ys_ref = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=5, device_pipeline=False)
+    assert [p["file"] for p in pf_dev] == [p["file"] for p in pf_ref] == files
+    assert np.array_equal(ys_dev, ys_ref)
+    runner.close()
+
+
+def test_pipeline_run_reports_counts_for_unreadable_files(torch_mod, dataset):  # noqa: F811
+    from birdnet_stm32.audio.io import load_audio_file
+    from birdnet_stm32.audio.pipeline import EvaluatePipeline
+    from birdnet_stm32.models.runners import load_model_runner
+
+    runner = load_model_runner(TFLITE_PATH, max_batch=32)
+    pipe = EvaluatePipeline(runner, 24000, 3.0, 0.0, group_chunks=30, slab_bytes=8 << 20)
+    scores, counts, st, lat = pipe.run(list(dataset))
+    want = [len(load_audio_file(p, 24000, 60, 3.0, 0.0)) for p in dataset]
+    assert counts == want and scores.shape == (sum(want), 100) and lat == []
+    assert st["files"] == len(dataset) and st["readable"] == sum(1 for w in want if w) and st["chunks"] == sum(want)
+    # a second run on the same object reuses its rings and gives the same scores
+    scores2, counts2, _, _ = pipe.run(list(dataset))
+    assert counts2 == counts and torch_mod.equal(scores, scores2)
+    # empty input
+    s0, c0, st0, _ = pipe.run([])
+    assert s0.shape[0] == 0 and c0 == [] and st0["chunks"] == 0
+    runner.close()

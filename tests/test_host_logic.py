@@ -492,3 +492,48 @@ def test_flac_decoder_matches_the_encoded_samples(tmp_path):
     assert ya.size > 0 and np.array_equal(ya, yb)
     ca, cb = load_audio_file(str(tmp_path / "a.flac"), 24000, chunk_duration=0.1), load_audio_file(str(tmp_path / "a.wav"), 24000, chunk_duration=0.1)
     assert len(ca) == len(cb) > 1 and np.array_equal(np.asarray(ca), np.asarray(cb))
+
+
+# ------------------------------------------------------------------------------- ranking metrics (evaluation/_ranking.py)
+def test_ranking_metrics_are_bit_identical_to_scikit_learn():
+    """evaluate()'s ROC-AUC (micro), per-class AP and micro AP come from shared sorts instead of 102 library calls (reference:
+    birdnet_stm32/evaluation/metrics.py:155-190 calls sklearn): same numbers, bit for bit, on continuous scores, heavy ties (the INT8
+    model's 1/256 steps), classes without positives, a class that is all positives, two files only."""
+    import warnings
+
+    from sklearn.metrics import average_precision_score, roc_auc_score
+
+    from birdnet_stm32.evaluation._ranking import ranking_metrics
+
+    rng = np.random.default_rng(11)
+    cases = []
+    for n, c, ties in ((300, 7, False), (513, 12, True), (2, 3, False), (64, 100, True), (1000, 5, False)):
+        ys = rng.random((n, c)).astype(np.float32)
+        if ties:
+            ys = (np.floor(ys * 256) / 256).astype(np.float32)
+        yt = np.zeros((n, c), np.float32)
+        yt[np.arange(n), rng.integers(0, max(1, c - 2), n)] = 1.0  # the last classes have no positives
+        cases.append((yt, ys))
+    yt, ys = cases[0]
+    yt = yt.copy()
+    yt[:, 1] = 1.0  # a class every file belongs to (multi-label y_true is still a 0/1 indicator)
+    cases.append((yt, ys))
+    cases.append((np.zeros((10, 4), np.float32), rng.random((10, 4)).astype(np.float32)))  # no positives at all: ROC-AUC undefined
+    for yt, ys in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = ranking_metrics(yt, ys)
+            try:
+                want_auc = float(roc_auc_score(yt, ys, average="micro"))
+            except Exception:
+                want_auc = float("nan")
+            want_ap = [float(average_precision_score(yt[:, k], ys[:, k])) for k in range(yt.shape[1])]
+            want_map = float(average_precision_score(yt, ys, average="micro"))
+        assert got["ap_per_class"] == want_ap
+        assert got["mAP"] == want_map
+        assert got["roc-auc"] == want_auc or (np.isnan(got["roc-auc"]) and np.isnan(want_auc))
+    # non-finite scores: the library raises, evaluate reports NaN
+    bad = cases[0][1].copy()
+    bad[3, 2] = np.nan
+    got = ranking_metrics(cases[0][0], bad)
+    assert np.isnan(got["roc-auc"]) and np.isnan(got["mAP"]) and all(np.isnan(a) for a in got["ap_per_class"])

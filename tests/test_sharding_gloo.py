@@ -86,6 +86,24 @@ assert torch.equal(scores[:, 0], torch.repeat_interleave(torch.arange(5, dtype=t
 # fewer files than ranks: the rank without files still joins both collectives
 scores, counts = score_files_sharded(1, lambda lo, hi: (torch.ones(2, C), [2]), C)
 assert counts == [2] and scores.shape == (2, C)
+# blocks of equal CHUNK count instead of equal file count (evaluate's dealing): 2 long files + 8 short ones
+from birdnet_stm32.audio.pipeline import balanced_bounds
+per = [20, 20, 1, 1, 1, 1, 1, 1, 1, 1]
+bounds = balanced_bounds(per, world)
+assert bounds == [0, 2, 10] if world == 2 else True
+seen_blocks = []
+def score_files2(lo, hi):
+    seen_blocks.append((lo, hi))
+    rows = [torch.full((per[f], C), float(f)) for f in range(lo, hi)]
+    return torch.cat(rows), per[lo:hi]
+scores, counts = score_files_sharded(10, score_files2, C, bounds=bounds)
+assert seen_blocks == [(bounds[rank], bounds[rank + 1])]
+assert counts == per and torch.equal(scores[:, 0], torch.repeat_interleave(torch.arange(10, dtype=torch.float32), torch.tensor(per)))
+try:
+    score_files_sharded(10, score_files2, C, bounds=[0, 11, 10])
+    raise SystemExit("expected ValueError")
+except ValueError as e:
+    assert "do not partition" in str(e)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
