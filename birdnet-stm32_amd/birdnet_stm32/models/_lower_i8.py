@@ -946,13 +946,13 @@ def _tag_pwdw_pairs(pb: pk.PlanBuilder) -> None:
 def _tag_scale_pairs(pb: pk.PlanBuilder) -> None:
     """Squeeze-excite MUL followed by the projection 1x1 convolution (reference models/blocks.py:27-46,104-118): when that
     convolution is the only reader of the scaled map the pair is tagged, and the library applies the gate while the convolution
-    loads its input (``i8_pw_wave_kernel``) instead of writing the scaled map out and reading it back."""
+    loads its input (``i8_pw_wave_kernel`` up to 256 channels, ``i8_pw_lds_kernel`` for 384 and 768) instead of writing the scaled map out and reading it back."""
     ops = pb.plan.ops
     for i in range(len(ops) - 1):
         a, b = ops[i], ops[i + 1]
         if a.kind != pk.I8_SCALE or b.kind != pk.I8_DWPW or b.p[29] or b.p[30] or b.p[34] or b.p[36] or b.in0 != a.out:
             continue
-        if b.p[2] != a.p[1] or b.p[0] * b.p[1] != a.p[0] or b.p[2] > 256 or (b.p[3], b.p[4]) != (1, 1):
+        if b.p[2] != a.p[1] or b.p[0] * b.p[1] != a.p[0] or b.p[2] > 768 or (b.p[3], b.p[4]) != (1, 1):
             continue
         readers = [k for k, o in enumerate(ops) if k != i + 1 and a.out in (o.in0, o.in1)]
         if readers or b.in1 == a.out:

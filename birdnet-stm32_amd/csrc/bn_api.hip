@@ -46,7 +46,7 @@ struct OptName {
 };
 const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
-    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"front_tpw", &bn::Options::front_tpw},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
@@ -865,7 +865,14 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             const int* p = o.p;
             bool ok = all_right(o.t[6], o.t[7]) && (!p[29] || all_right(o.t[2], o.t[3]));
             if (p[18]) ok = ok && p[20] >= 0 && p[21] < 0 && p[22] >= 0 && p[23] < 0 && p[24] >= 0 && p[25] < 0;  // ADD: m1 s1 m2 s2 mo so
-            m->rq_right[oi] = ok;
+            // bit 1: every pointwise shift lies in [-20, -1] — the 64-bit addend of the one-multiply-add requantisation (i8_pw_lds_kernel) cannot overflow
+            bool narrow = ok && o.t[7] >= 0;
+            if (narrow) {
+                const TensorRec& ts = m->tensors[o.t[7]];
+                const int32_t* ps = (const int32_t*)(base + ts.offset);
+                for (size_t i = 0; i < ts.nbytes / 4; ++i) narrow = narrow && ps[i] >= -20;
+            }
+            m->rq_right[oi] = (ok ? 1 : 0) | (narrow ? 2 : 0);
         } else if (o.kind == BN_OP_I8_DW || o.kind == BN_OP_I8_STEM) {
             m->rq_right[oi] = all_right(o.t[2], o.t[3]);
         } else if (o.kind == BN_OP_I8_FRONT) {
@@ -1367,7 +1374,7 @@ int bn_get_option(const char* name, int* value) {
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_pw_ws_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_attnpool_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_pw_lds_kernel\ni8_attnpool_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }
 

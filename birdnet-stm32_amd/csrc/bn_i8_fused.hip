@@ -790,6 +790,9 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     }
     const int P = a.OH * a.OW;
     const bool g_right = a.g_mult >= 0 && a.g_shift < 0;  // (uniform) the gate's MUL requantises with a plain right shift: branch-free form
+    const bool g_fast = a.gate && a.g_zx == -128 && a.g_zg == -128 && a.g_mult >= 0 && a.g_shift <= -1 && a.g_shift >= -20;
+    const int ge = g_fast ? -a.g_shift : 1, gsh = ge - 1;
+    const long long gC = (1ll << 30) + (((1ll << (ge - 1)) + (long long)a.g_zo * (1ll << ge)) << 31);
     for (; grp < n_groups; grp += stride) {
     fetch(grp + stride, bnx);
     const long pos = grp * 16 + r;
@@ -806,10 +809,21 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     int packed = 0;
+                    if (g_fast) {
+                        // both zero points -128: (x + 128)(g + 128) >= 0, no sign term, and the requantisation with the output zero point folded in
+                        // is the high dword of one multiply-add (bn_i8_pw.hip) — 5 instead of 12 instructions per byte
+                        const unsigned xu = (unsigned)bfr[s][d] ^ 0x80808080u, gu = (unsigned)gv[d] ^ 0x80808080u;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int xv = (int)(int8_t)(bfr[s][d] >> (8 * e)) - a.g_zx, g = (int)(int8_t)(gv[d] >> (8 * e)) - a.g_zg;
-                        packed |= (clampi(mbqm_u(xv * g, a.g_mult, a.g_shift, g_right) + a.g_zo, a.g_amin, a.g_amax) & 0xff) << (8 * e);
+                        for (int e = 0; e < 4; ++e) {
+                            const int p = (int)((xu >> (8 * e)) & 0xff) * (int)((gu >> (8 * e)) & 0xff);
+                            packed |= (clampi((int)(((long long)p * a.g_mult + gC) >> 32) >> gsh, a.g_amin, a.g_amax) & 0xff) << (8 * e);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int xv = (int)(int8_t)(bfr[s][d] >> (8 * e)) - a.g_zx, g = (int)(int8_t)(gv[d] >> (8 * e)) - a.g_zg;
+                            packed |= (clampi(mbqm_u(xv * g, a.g_mult, a.g_shift, g_right) + a.g_zo, a.g_amin, a.g_amax) & 0xff) << (8 * e);
+                        }
                     }
                     o[d] = packed;
                 }
@@ -945,7 +959,7 @@ bool i8_mel_mfma_supported(const DwPw8Args& a) {
 
 bool i8_dwpw_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 16 == 0 && Cin >= 4; }
 
-bool i8_pw_wave_takes(const DwPw8Args& a) { return i8_pw_wave_supported(a); }
+bool i8_pw_wave_takes(const DwPw8Args& a) { return i8_pw_lds_supported(a) || i8_pw_wave_supported(a); }
 
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
     const bool mel_kernel = !g_opt.i8_mel_generic;
@@ -962,6 +976,7 @@ void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
             hipLaunchKernelGGL((i8_mel_mfma_kernel<false, 0>), dim3(nb), dim3(256), lds, s, a);
         return;
     }
+    if (i8_pw_lds_supported(a)) return launch_i8_pw_lds(a, s);
     if (i8_pw_wave_supported(a)) return launch_i8_pw_wave(a, s);
     // (a gate is only ever set by the caller after i8_pw_wave_takes() said yes)
     const int ct_total = a.Cout / 16;

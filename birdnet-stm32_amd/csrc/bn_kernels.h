@@ -30,6 +30,8 @@ struct Options {
     int wave_dwpw = 1;         // wave-autonomous variant of the small float32 fused block
     int i8_strip = 1;          // INT8 strip kernels (0: generic fused block everywhere)
     int i8_strip_th = 0;       // force the rows per wave of the INT8 strip kernels (0: auto)
+    int i8_pw_lds = 1;         // dense 1x1 convolutions (Cin 192 / 384 / 768) of exported INT8 graphs through i8_pw_lds_kernel (bn_i8_pw.hip): weights of a
+                               // slice of output channels resident in LDS, squeeze-excite MUL applied on load (0: tile kernel + i8_scale)
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
     int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
@@ -307,6 +309,8 @@ bool i8_dwpw_supported(int Cin, int Cout);
 bool i8_pwdw_supported(const DwPw8Args& expand, const I8ConvGeom& dw);
 bool launch_i8_pwdw(const DwPw8Args& expand, const I8ConvGeom& dw, const int8_t* dw_w, const int32_t* dw_b, const int32_t* dw_mult, const int32_t* dw_shift,
                     int8_t* y, hipStream_t s);
+bool i8_pw_lds_supported(const DwPw8Args& a);   // bn_i8_pw.hip
+void launch_i8_pw_lds(const DwPw8Args& a, hipStream_t s);
 bool i8_pw_wave_takes(const DwPw8Args& a);  // the wave-level 1x1 convolution kernel (the only one that applies DwPw8Args::gate) runs this operator
 bool i8_mel_mfma_supported(const DwPw8Args& a);
 // Wave-autonomous strip kernel for the same block at Cin, Cout in {32, 64} (bn_i8_strip.hip); `cst` is the constant block

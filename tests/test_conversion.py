@@ -471,6 +471,8 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
     with _hip.options(i8_pwdw=1):  # expand + depthwise of inverted-residual blocks as one kernel (off by default: measured slower), same integers
         assert np.array_equal(prod.predict(x), got)
         assert np.array_equal(prod.predict(x[:3]), got[:3])
+    with _hip.options(i8_pw_lds=0):  # the dense late 1x1 convolutions (Cin 192 / 384 / 768) through the tile kernel + a separate MUL: same integers
+        assert np.array_equal(prod.predict(x), got)
     prod.close()
 
 
@@ -516,3 +518,39 @@ def test_exported_graphs_of_other_geometries_match_the_oracle_on_the_gpu(name):
         p = prod.predict(x[:nb])
         assert np.allclose(p, ref[:nb], atol=1e-6) if softmax else np.array_equal(p, ref[:nb])
     prod.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [37, 300])
+def test_dense_int8_pointwise_kernel_equals_the_tile_kernel_at_batch(batch):
+    """i8_pw_lds_kernel (csrc/bn_i8_pw.hip: the 192 / 384 / 768-channel 1x1 convolutions of the alpha = 1.5 inverted-residual net, the
+    squeeze-excite MUL applied on load, residual ADD) against the tile kernel + separate MUL (option i8_pw_lds = 0; those are held to
+    the INT8 oracle per tensor above) on batches that need several strides of the persistent walkers, odd batch sizes, repeated
+    launches; and per tensor against the oracle on the first chunks (debug plan: no gate fusion, the kernel's plain forms)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models._lower_i8 import lower_i8
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle.int8_graph import Int8Interpreter
+
+    spec, model, _, x0 = _export(EXPORT_TOPOLOGIES["alpha1.5_pcen"])
+    rng = np.random.default_rng(batch)
+    x = (rng.random((batch, 257, 256, 1), dtype=np.float32) ** 3).astype(np.float32)
+    x[: x0.shape[0]] = x0
+    x[-1] = 0.0
+    prod = HipRunner(lower_i8(model), max_batch=batch)
+    kinds = [op.kind for op in prod.plan.ops]
+    got = prod.predict(x)
+    for _ in range(3):
+        assert np.array_equal(prod.predict(x), got)
+    with _hip.options(i8_pw_lds=0):
+        ref = prod.predict(x)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(prod.predict(x[:5]), got[:5])
+    prod.close()
+    want = Int8Interpreter(model).invoke(x[:3])
+    assert np.allclose(got[:3], want, atol=1e-6)
+    assert len(kinds) > 20
