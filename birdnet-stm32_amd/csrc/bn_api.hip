@@ -48,7 +48,7 @@ const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
     {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
-    {"i8_strip_th", &bn::Options::i8_strip_th},   {"i8_tail", &bn::Options::i8_tail},
+    {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
     {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap},
     {"ingest_blk", &bn::Options::ingest_blk},
@@ -116,6 +116,8 @@ struct bn_model {
     float* d_smax = nullptr;             // [max_batch] per-sample maxima of the frontend
     float* d_gap_part = nullptr;         // [max_batch][gap_part_elems] channel sums per row block from f32_pwdw_kernel for the squeeze-excite gate behind it
     size_t gap_part_elems = 0;
+    int32_t* d_pool8 = nullptr;          // [max_batch][pool8_C] int32 channel sums from i8_dw_stream_kernel for the squeeze-excite gate behind it (zero between uses)
+    size_t pool8_C = 0;
     size_t workspace_bytes = 0;
     // per-operator HIP-event timing (bn_profile_*): one (start, stop) pair per launch group
     bool profiling = false;
@@ -217,6 +219,9 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
     };
     const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
     if (op_end > m->ops.size()) op_end = m->ops.size();
+    // the pooling scratch is zero between uses (i8_segate_kernel clears what it reads); cleared here as well, so that a call that failed half-way
+    // cannot leave sums behind for the next one
+    if (m->d_pool8 && op_begin == 0 && bn::g_opt.i8_dw_pool) HIP_TRY(hipMemsetAsync(m->d_pool8, 0, (size_t)B * m->pool8_C * sizeof(int32_t), s));
     size_t gap_for = (size_t)-1;      // squeeze-excite gate whose pooling comes as row-block sums from the fused kernel in front of it
     int gap_R = 0, cand_R = 0;
     size_t cand_for = (size_t)-1;     // (candidate: becomes gap_for once the fused kernel has been launched)
@@ -255,6 +260,18 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         return a;
     };
     size_t segate_done[2] = {(size_t)-1, (size_t)-1};  // the two dense layers of a squeeze-excite gate that ran inside the pooling kernel
+    size_t pool8_for = (size_t)-1;  // MEAN operator whose channel sums the depthwise kernel in front of it has already put into d_pool8
+    // does the MEAN operator `mi` run as i8_segate_kernel (MEAN -> FC -> FC in one launch)?
+    auto segate_fused = [&](size_t mi) {
+        if (mi + 2 >= op_end) return false;
+        const OpRec& o = m->ops[mi];
+        const OpRec& f1 = m->ops[mi + 1];
+        const OpRec& f2 = m->ops[mi + 2];
+        const int* p = o.p;
+        return o.kind == BN_OP_I8_MEAN && p[BN_OP_TAIL_TAG] == BN_SEGATE_HEAD && bn::g_opt.i8_strip && same_path(o, f1) && same_path(o, f2) &&
+               f1.kind == BN_OP_I8_FC && f2.kind == BN_OP_I8_FC && f1.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED && f2.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED &&
+               f1.in0 == o.out && f2.in0 == f1.out && f1.p[0] == p[1] && f2.p[0] == f1.p[1] && f2.p[1] == p[1] && p[1] % 4 == 0 && f2.out != o.in0;
+    };
     size_t scale_done = (size_t)-1;  // 1x1 convolution that already ran with the squeeze-excite MUL in front of it applied on load
     auto dwpw8_args = [&](const OpRec& d, size_t di) {
         bn::DwPw8Args a{};
@@ -467,10 +484,19 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
             case BN_OP_I8_DW: {
                 bn::I8ConvGeom g{p[0], p[1], p[2], p[3], p[4], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13]};
                 g.rq_right = m->rq_right[oi];
-                if (o.kind == BN_OP_I8_DW &&  // row-streaming form (three loads per input row instead of nine per output) where the shape allows
-                    bn::launch_i8_dw_stream((const int8_t*)in0, (int8_t*)out, B, g, (const int8_t*)m->tensor(o.t[0]), (const int32_t*)m->tensor(o.t[1]),
-                                            (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]), s))
-                    break;
+                if (o.kind == BN_OP_I8_DW) {  // row-streaming form (three loads per input row instead of nine per output) where the shape allows
+                    // ... which also adds up what it stores when the squeeze-excite gate's MEAN is the next operator (integer sums: bit-identical)
+                    int32_t* pool = nullptr;
+                    if (bn::g_opt.i8_dw_pool && m->d_pool8 && oi + 1 < op_end && segate_fused(oi + 1)) {
+                        const OpRec& mo = m->ops[oi + 1];
+                        if (same_path(o, mo) && mo.in0 == o.out && mo.p[1] == p[2] && mo.p[0] == p[6] * p[7] && (size_t)p[2] <= m->pool8_C) pool = m->d_pool8;
+                    }
+                    if (bn::launch_i8_dw_stream((const int8_t*)in0, (int8_t*)out, B, g, (const int8_t*)m->tensor(o.t[0]), (const int32_t*)m->tensor(o.t[1]),
+                                                (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]), s, pool)) {
+                        if (pool) pool8_for = oi + 1;
+                        break;
+                    }
+                }
                 if (o.kind == BN_OP_I8_STEM &&
                     bn::launch_i8_stem_stream((const int8_t*)in0, (int8_t*)out, B, g, (const int8_t*)m->tensor(o.t[0]), (const int32_t*)m->tensor(o.t[1]),
                                               (const int32_t*)m->tensor(o.t[2]), (const int32_t*)m->tensor(o.t[3]), s))
@@ -580,22 +606,19 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 break;
             }
             case BN_OP_I8_MEAN:
-                if (p[BN_OP_TAIL_TAG] == BN_SEGATE_HEAD && bn::g_opt.i8_strip && oi + 2 < op_end) {
+                if (segate_fused(oi)) {
                     const OpRec& f1 = m->ops[oi + 1];
                     const OpRec& f2 = m->ops[oi + 2];
-                    if (same_path(o, f1) && same_path(o, f2) &&
-                        f1.kind == BN_OP_I8_FC && f2.kind == BN_OP_I8_FC && f1.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED && f2.p[BN_OP_TAIL_TAG] == BN_SEGATE_COVERED &&
-                        f1.in0 == o.out && f2.in0 == f1.out && f1.p[0] == p[1] && f2.p[0] == f1.p[1] && f2.p[1] == p[1] && p[1] % 4 == 0 && f2.out != o.in0) {
-                        bn::launch_i8_segate((const int8_t*)in0, (int8_t*)slot_ptr(f2.out), B, p[0], p[1], p[2], p[3], p[4], p[5], f1.p[1], f1.p[2], f1.p[3], f1.p[4],
-                                             (const int8_t*)m->tensor(f1.t[0]), (const int32_t*)m->tensor(f1.t[1]), (const int32_t*)m->tensor(f1.t[2]),
-                                             (const int32_t*)m->tensor(f1.t[3]), f1.p[5] ? (const int8_t*)m->tensor(f1.t[4]) : nullptr, f2.p[2], f2.p[3], f2.p[4],
-                                             (const int8_t*)m->tensor(f2.t[0]), (const int32_t*)m->tensor(f2.t[1]), (const int32_t*)m->tensor(f2.t[2]),
-                                             (const int32_t*)m->tensor(f2.t[3]), f2.p[5] ? (const int8_t*)m->tensor(f2.t[4]) : nullptr, s);
-                        segate_done[0] = oi + 1;
-                        segate_done[1] = oi + 2;
-                        fused_into(oi + 2);
-                        break;
-                    }
+                    bn::launch_i8_segate((const int8_t*)in0, (int8_t*)slot_ptr(f2.out), B, p[0], p[1], p[2], p[3], p[4], p[5], f1.p[1], f1.p[2], f1.p[3], f1.p[4],
+                                         (const int8_t*)m->tensor(f1.t[0]), (const int32_t*)m->tensor(f1.t[1]), (const int32_t*)m->tensor(f1.t[2]),
+                                         (const int32_t*)m->tensor(f1.t[3]), f1.p[5] ? (const int8_t*)m->tensor(f1.t[4]) : nullptr, f2.p[2], f2.p[3], f2.p[4],
+                                         (const int8_t*)m->tensor(f2.t[0]), (const int32_t*)m->tensor(f2.t[1]), (const int32_t*)m->tensor(f2.t[2]),
+                                         (const int32_t*)m->tensor(f2.t[3]), f2.p[5] ? (const int8_t*)m->tensor(f2.t[4]) : nullptr, s,
+                                         oi == pool8_for ? m->d_pool8 : nullptr);
+                    segate_done[0] = oi + 1;
+                    segate_done[1] = oi + 2;
+                    fused_into(oi + 2);
+                    break;
                 }
                 bn::launch_i8_mean((const int8_t*)in0, (int8_t*)out, B, p[0], p[1], p[2], p[3], p[4], p[5], s);
                 break;
@@ -945,6 +968,15 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             const size_t need = (size_t)((q[7] + ncol - 1) / ncol) * (size_t)((q[6] + 3) / 4) * (size_t)q[2];
             if (need > m->gap_part_elems) m->gap_part_elems = need;
         }
+    for (size_t i = 0; i + 1 < m->ops.size(); ++i)  // INT8 depthwise stage -> MEAN of a squeeze-excite gate: channel sums taken on the way out
+        if (m->ops[i].kind == BN_OP_I8_DW && m->ops[i + 1].kind == BN_OP_I8_MEAN && m->ops[i + 1].in0 == m->ops[i].out && m->ops[i + 1].p[1] == m->ops[i].p[2])
+            if ((size_t)m->ops[i].p[2] > m->pool8_C) m->pool8_C = (size_t)m->ops[i].p[2];
+    if (m->pool8_C) {
+        if (hipMalloc(&m->d_pool8, mb * m->pool8_C * sizeof(int32_t)) != hipSuccess)
+            return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of pooling scratch failed"));
+        if (hipMemset(m->d_pool8, 0, mb * m->pool8_C * sizeof(int32_t)) != hipSuccess) return cleanup_fail(fail(BN_ERR_DEVICE, "clearing the pooling scratch failed"));
+        m->workspace_bytes += mb * m->pool8_C * sizeof(int32_t);
+    }
     if (m->gap_part_elems) {
         if (hipMalloc(&m->d_gap_part, mb * m->gap_part_elems * sizeof(float)) != hipSuccess)
             return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of pooling scratch failed"));
@@ -964,6 +996,7 @@ void bn_model_free(bn_model* m) {
     (void)hipFree(m->d_guard);
     (void)hipFree(m->d_smax);
     (void)hipFree(m->d_gap_part);
+    (void)hipFree(m->d_pool8);
     for (auto& r : m->ev_used) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);

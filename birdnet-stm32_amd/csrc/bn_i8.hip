@@ -352,6 +352,7 @@ struct SeGate8Args {
     const int8_t* w1; const int32_t* b1; const int32_t* m1; const int32_t* s1; const int8_t* lut1;
     int Kp2, zo2, amin2, amax2;
     const int8_t* w2; const int32_t* b2; const int32_t* m2; const int32_t* s2; const int8_t* lut2;
+    int32_t* sums;  // [B][C] channel sums of x taken by the kernel that wrote it (read and zeroed here), or null
 };
 
 // dot product of an int8 vector in LDS with a weight row in memory, `nd` dwords: sixteen weight dwords requested before the first is
@@ -378,42 +379,59 @@ __global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
     int8_t* hidden = pooled + a.Kp1;
     for (int i = tid; i < (a.Kp1 + a.Kp2) / 4; i += 256) se_vec[i] = 0;
     __syncthreads();
-    const int32_t* row0 = reinterpret_cast<const int32_t*>(a.x + (size_t)b * P * C);
-    for (int q0 = 0; q0 < cq; q0 += 256) {  // channel quads beyond 256 go round again
-        const int nq = cq - q0 < 256 ? cq - q0 : 256;
-        const int slices = 256 / nq;
-        const int q = tid % nq, sl = tid / nq;
-        int acc[4] = {0, 0, 0, 0};
-        if (sl < slices) {
-            const int32_t* row = row0 + q0 + q;
-            for (int i0 = sl; i0 < P; i0 += 8 * slices) {
-                int32_t v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * slices;
-                    v[u] = i < P ? row[(size_t)i * cq] : 0;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += (int32_t)(int8_t)(v[u] >> (8 * e));
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part[tid][e] = acc[e];
-        __syncthreads();
-        if (tid < nq) {
+    if (a.sums) {
+        // the depthwise kernel in front added the map up while it stored it (i8_dw_stream_kernel): only the requantisation is left
+        int32_t* srow = a.sums + (size_t)b * C;
+        for (int q4 = tid; q4 < cq; q4 += 256) {
             uint32_t packed = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int s4 = 0;
-                for (int k = 0; k < slices; ++k) s4 += part[k * nq + tid][e];
+                const int s4 = srow[4 * q4 + e];
+                srow[4 * q4 + e] = 0;  // ready for the next stage that pools into this buffer
                 const int32_t qv = clampi(mbqm(s4 - a.zp_in * P, a.mean_mult, a.mean_shift) + a.mean_zp, -128, 127);
                 packed |= ((uint32_t)(uint8_t)(int8_t)qv) << (8 * e);
             }
-            se_vec[q0 + tid] = (int32_t)packed;
+            se_vec[q4] = (int32_t)packed;
         }
         __syncthreads();
+    } else {
+        const int32_t* row0 = reinterpret_cast<const int32_t*>(a.x + (size_t)b * P * C);
+        for (int q0 = 0; q0 < cq; q0 += 256) {  // channel quads beyond 256 go round again
+            const int nq = cq - q0 < 256 ? cq - q0 : 256;
+            const int slices = 256 / nq;
+            const int q = tid % nq, sl = tid / nq;
+            int acc[4] = {0, 0, 0, 0};
+            if (sl < slices) {
+                const int32_t* row = row0 + q0 + q;
+                for (int i0 = sl; i0 < P; i0 += 8 * slices) {
+                    int32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * slices;
+                        v[u] = i < P ? row[(size_t)i * cq] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] += (int32_t)(int8_t)(v[u] >> (8 * e));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[tid][e] = acc[e];
+            __syncthreads();
+            if (tid < nq) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int s4 = 0;
+                    for (int k = 0; k < slices; ++k) s4 += part[k * nq + tid][e];
+                    const int32_t qv = clampi(mbqm(s4 - a.zp_in * P, a.mean_mult, a.mean_shift) + a.mean_zp, -128, 127);
+                    packed |= ((uint32_t)(uint8_t)(int8_t)qv) << (8 * e);
+                }
+                se_vec[q0 + tid] = (int32_t)packed;
+            }
+            __syncthreads();
+        }
     }
     for (int n = tid; n < a.R; n += 256) {
         const int32_t* wr = reinterpret_cast<const int32_t*>(a.w1 + (size_t)n * a.Kp1);
@@ -717,9 +735,9 @@ void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_o
 
 void launch_i8_segate(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, int mean_mult, int mean_shift, int mean_zp, int R, int zo1, int amin1,
                       int amax1, const int8_t* w1, const int32_t* b1, const int32_t* m1, const int32_t* s1, const int8_t* lut1, int zo2, int amin2,
-                      int amax2, const int8_t* w2, const int32_t* b2, const int32_t* m2, const int32_t* s2, const int8_t* lut2, hipStream_t s) {
+                      int amax2, const int8_t* w2, const int32_t* b2, const int32_t* m2, const int32_t* s2, const int8_t* lut2, hipStream_t s, int32_t* sums) {
     const int Kp1 = (C + 3) & ~3, Kp2 = (R + 3) & ~3;
-    SeGate8Args a{x, y, P, C, zp_in, mean_mult, mean_shift, mean_zp, R, Kp1, zo1, amin1, amax1, w1, b1, m1, s1, lut1, Kp2, zo2, amin2, amax2, w2, b2, m2, s2, lut2};
+    SeGate8Args a{x, y, P, C, zp_in, mean_mult, mean_shift, mean_zp, R, Kp1, zo1, amin1, amax1, w1, b1, m1, s1, lut1, Kp2, zo2, amin2, amax2, w2, b2, m2, s2, lut2, sums};
     hipLaunchKernelGGL(i8_segate_kernel, dim3(B), dim3(256), (size_t)(Kp1 + Kp2), s, a);
 }
 

@@ -619,6 +619,7 @@ struct DwStream8Args {
     const int8_t* x; int8_t* y;
     const int8_t* w; const int32_t* bias; const int32_t* mult; const int32_t* shift;   // [3][3][C], [C], [C], [C]
     int B, H, W, C, OH, OW, TH, pt, pl, zp_in, zp_out, amin, amax, CQ, rq_right;
+    int32_t* pool;  // [B][C] or null: += sum of the stored bytes per channel (the squeeze-excite MEAN behind the stage; i8_dw_stream_kernel only)
 };
 
 template <int S>
@@ -679,6 +680,7 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
     const int rows_needed = S * (nrows - 1) + 3;
 
     int raw[2][3], T[3][4];
+    int psum[4] = {0, 0, 0, 0};  // what this lane stored, per channel (pool != null)
     auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
     auto issue = [&](int slot, int rr) {
         if (row_ok(rr)) {
@@ -708,6 +710,7 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             acc = dot4(T[i1][e], wr[1][e], acc);
             acc = dot4(T[i2][e], wr[2][e], acc);
             qv[e] = med3(mbqm_u(acc, mult[e], shift[e], a.rq_right != 0) + a.zp_out, a.amin, a.amax);
+            psum[e] += qv[e];
         }
         const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         __builtin_amdgcn_raw_buffer_store_b32(word, rs_out, voff_out, oh * a.OW * a.C, 0);
@@ -732,6 +735,15 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
                 issue(rs & 1, S * k + rs + 2);
             }
             emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
+        }
+    }
+    if (a.pool) {
+        // squeeze-excite pooling on the way out: integer sums, so the order (lanes, waves, atomics) does not matter — bit-identical to MEAN over the map
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int v = live ? psum[e] : 0;
+            for (int off = CQ; off < 64; off <<= 1) v += __shfl_xor(v, off);
+            if (n == 0) atomicAdd(a.pool + (size_t)chunk * a.C + c0 + e, v);
         }
     }
 }
@@ -1134,13 +1146,13 @@ bool launch_i8_pwdw(const DwPw8Args& e, const I8ConvGeom& d, const int8_t* dw_w,
 }
 
 bool launch_i8_dw_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias, const int32_t* mult,
-                         const int32_t* shift, hipStream_t s) {
+                         const int32_t* shift, hipStream_t s, int32_t* pool) {
     if (!g_opt.i8_strip || g.sh != g.sw || (g.sh != 1 && g.sh != 2) || g.C % 4 || (long)g.H * g.W * g.C >= 0x7fff0000L ||
         (long)g.OH * g.OW * g.C >= 0x7fff0000L)
         return false;
     int cq = 16;
     while ((g.C / 4) % cq) cq >>= 1;
-    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq, g.rq_right};
+    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq, g.rq_right, pool};
     const int ncol = 64 / cq;
     const long per_row_block = (long)B * (g.C / (4 * cq)) * ((g.OW + ncol - 1) / ncol);
     int th = g.OH;
@@ -1161,7 +1173,7 @@ bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& 
     if (!g_opt.i8_strip || (g.sh != 1 && g.sh != 2) || g.sw < 1 || g.sw > 2 || g.C % 4 || (long)g.OH * g.OW * g.C >= 0x7fff0000L) return false;
     int cq = 16;
     while ((g.C / 4) % cq) cq >>= 1;
-    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq, g.rq_right};
+    DwStream8Args a{x, y, w, bias, mult, shift, B, g.H, g.W, g.C, g.OH, g.OW, 0, g.pt, g.pl, g.zp_in, g.zp_out, g.amin, g.amax, cq, g.rq_right, nullptr};
     const int ncol = 64 / cq;
     const long per_row_block = (long)B * (g.C / (4 * cq)) * ((g.OW + ncol - 1) / ncol);
     int th = g.OH;

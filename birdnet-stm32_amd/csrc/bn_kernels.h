@@ -30,6 +30,8 @@ struct Options {
     int wave_dwpw = 1;         // wave-autonomous variant of the small float32 fused block
     int i8_strip = 1;          // INT8 strip kernels (0: generic fused block everywhere)
     int i8_strip_th = 0;       // force the rows per wave of the INT8 strip kernels (0: auto)
+    int i8_dw_pool = 1;        // the row-streaming depthwise kernel of exported graphs adds up what it stores for the squeeze-excite MEAN behind it
+                               // (integer sums, order-free: bit-identical); 0: i8_segate_kernel reads the whole map again
     int i8_pw_lds = 1;         // dense 1x1 convolutions (Cin 192 / 384 / 768) of exported INT8 graphs through i8_pw_lds_kernel (bn_i8_pw.hip): weights of a
                                // slice of output channels resident in LDS, squeeze-excite MUL applied on load (0: tile kernel + i8_scale)
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
@@ -238,7 +240,7 @@ void launch_i8_dw(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const 
                   const int32_t* mult, const int32_t* shift, hipStream_t s);
 // the same as a row-streaming kernel (bn_i8_strip.hip); false = shape not taken, use launch_i8_dw
 bool launch_i8_dw_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias, const int32_t* mult,
-                         const int32_t* shift, hipStream_t s);
+                         const int32_t* shift, hipStream_t s, int32_t* pool = nullptr);  // pool: [B][C] int32, += the sum of every output byte (zeroed by the caller)
 bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g, const int8_t* w, const int32_t* bias, const int32_t* mult,
                            const int32_t* shift, hipStream_t s);  // the single-channel 3x3 stem in the same form
 struct I8AddParams {
@@ -255,7 +257,7 @@ void launch_i8_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, int zp_o
 // MEAN -> FULLY_CONNECTED -> FULLY_CONNECTED (optional tables behind each) of a squeeze-excite gate as one kernel per chunk (C % 4 == 0)
 void launch_i8_segate(const int8_t* x, int8_t* y, int B, int P, int C, int zp_in, int mean_mult, int mean_shift, int mean_zp, int R, int zo1, int amin1,
                       int amax1, const int8_t* w1, const int32_t* b1, const int32_t* m1, const int32_t* s1, const int8_t* lut1, int zo2, int amin2,
-                      int amax2, const int8_t* w2, const int32_t* b2, const int32_t* m2, const int32_t* s2, const int8_t* lut2, hipStream_t s);
+                      int amax2, const int8_t* w2, const int32_t* b2, const int32_t* m2, const int32_t* s2, const int8_t* lut2, hipStream_t s, int32_t* sums = nullptr);  // sums: [B][C] channel sums of x already taken (read, then zeroed for the next user); null: the kernel pools x itself
 void launch_i8_scale(const int8_t* x, const int8_t* gate, int8_t* y, int B, int P, int C, int zx, int zg, int mult, int shift, int zo,
                      int amin, int amax, hipStream_t s);
 // per-chunk max -> denominator byte -> DIV table row [-> per-channel table]: [C][W] int8 -> [C][W] int8 (W a multiple of 4)

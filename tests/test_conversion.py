@@ -471,6 +471,8 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
     with _hip.options(i8_pwdw=1):  # expand + depthwise of inverted-residual blocks as one kernel (off by default: measured slower), same integers
         assert np.array_equal(prod.predict(x), got)
         assert np.array_equal(prod.predict(x[:3]), got[:3])
+    with _hip.options(i8_dw_pool=0):  # the squeeze-excite MEAN reads the depthwise map itself instead of taking the sums the depthwise kernel added up
+        assert np.array_equal(prod.predict(x), got)
     with _hip.options(i8_pw_lds=0):  # the dense late 1x1 convolutions (Cin 192 / 384 / 768) through the tile kernel + a separate MUL: same integers
         assert np.array_equal(prod.predict(x), got)
     prod.close()
