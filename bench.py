@@ -291,14 +291,37 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+def host_peaks() -> dict:
+    """What the host could do at best, for scale beside ``cpu_baseline.gops``: cores x max clock x int8 multiply-add lanes per cycle (two
+    512-bit VNNI pipes = 256 ops per cycle and core with avx512_vnni, 128 with avx_vnni only, 64 with AVX2's vpmaddubsw) — an upper bound from
+    the flags and the clock the kernel reports, not a measurement."""
+    flags, mhz = "", 0.0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags") and not flags:
+                flags = line
+            if line.startswith("cpu MHz"):
+                mhz = max(mhz, float(line.split(":")[1]))
+        try:
+            mhz = max(mhz, float(open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq").read()) / 1e3)
+        except OSError:
+            pass
+    except OSError:
+        pass
+    per_cycle = 256 if " avx512_vnni" in flags else 128 if " avx_vnni" in flags else 64 if " avx2" in flags else 16
+    cores = physical_cores()
+    return {"cores": cores, "max_mhz": round(mhz, 1), "int8_ops_per_cycle_per_core": per_cycle,
+            "theoretical_int8_peak_gops": round(cores * mhz * 1e6 * per_cycle / 1e9, 1), "isa": "avx512_vnni" if per_cycle == 256 else "avx_vnni" if per_cycle == 128 else "avx2" if per_cycle == 64 else "scalar"}
+
+
 def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
     """Time the CPU restatement of the reference path (``oracle/``) on this host, on a bounded sample.
 
     float32: the plain-C + OpenMP port (``oracle/c/oracle_cpu.c``) on all host threads when it has been built, otherwise the
     numpy oracle on one thread.  INT8: the C + OpenMP port of the TFLite int8 reference kernels (``oracle/c/oracle_i8.c``) when
     built, otherwise the numpy interpreter on one thread.  ``gops`` is the arithmetic rate that throughput amounts to
-    (53.08 MOP + 3.35 MFLOP of STFT per chunk) — a plain port, not a tuned CPU library: the ratio to the GPU
-    number says nothing about either.
+    (53.08 MOP + 3.35 MFLOP of STFT per chunk), ``host`` the machine's theoretical int8 peak beside it.  A port, not
+    a tuned CPU library and not the reference's TFLite: a reported baseline, never a target.
     """
     import contextlib
 
@@ -336,13 +359,22 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
         return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": physical_cores(), "threads": threads, "kind": "port", "gops": gops(done / dt),
                 "sample": f"{done} synthetic 3 s @ 24 kHz chunks, {what}, {threads} threads, {dt:.1f} s"}
 
-    if dtype == "f32" and os.path.isfile(cport.CPU_LIB):
-        path = cport.CpuFloatPath(load_keras_archive(ckpt + ".keras"))
-        return timed(path, path.threads, "plain-C + OpenMP port of the float path (oracle/c/oracle_cpu.c)")
-    if dtype == "i8" and os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB):
-        path = cport.CpuInt8Path(load_tflite(ckpt + ".tflite"))
-        return timed(lambda x: path.invoke(path.spectrogram(x, HOP, W)), path.threads,
-                     "plain-C + OpenMP port of the TFLite int8 reference kernels (oracle/c/oracle_i8.c under the numpy interpreter's graph walk) + C STFT")
+    # the C ports are rebuilt -march=native on THIS host first (oracle/Makefile: native; a few seconds): on AVX-512 / VNNI hosts the INT8 port then
+    # runs its vpdpbusd / sixteen-lane requantisation paths (bit-identical to the numpy interpreter: tests/test_oracle_pinning.py)
+    native = cport.build_native()
+    if dtype == "f32" and (native or os.path.isfile(cport.CPU_LIB)):
+        path = cport.CpuFloatPath(load_keras_archive(ckpt + ".keras"), native=native)
+        out = timed(path, path.threads, "plain-C + OpenMP port of the float path (oracle/c/oracle_cpu.c" + (", -march=native)" if native else ")"))
+        out["host"] = host_peaks()
+        return out
+    if dtype == "i8" and (native or (os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB))):
+        path = cport.CpuInt8Path(load_tflite(ckpt + ".tflite"), native=native)
+        out = timed(lambda x: path.invoke(path.spectrogram(x, HOP, W)), path.threads,
+                    "C + OpenMP port of the TFLite int8 reference kernels (oracle/c/oracle_i8.c under the numpy interpreter's graph walk"
+                    + (", -march=native" + (", AVX-512 VNNI paths" if path.vectorised else "") if native else "") + ") + C STFT")
+        out["host"] = host_peaks()
+        out["int8_vector_paths"] = bool(path.vectorised)
+        return out
 
     if dtype == "f32":
         spec = load_keras_archive(ckpt + ".keras")
@@ -409,6 +441,58 @@ def quick_rate(torch, dtype: str, batch: int, device, local_rank: int, steps: in
     out["workload"] = ("birdnet_stm32n6_100 float32 DS-CNN" if dtype == "f32" else "birdnet_stm32n6_100 INT8 DS-CNN") + ", hybrid+pwl frontend"
     out["roofline"] = roof
     return out
+
+
+def hard_inputs(torch, device, local_rank: int, headline: float, batch: int = 4096, steps: int = 5) -> dict:
+    """Throughput of the headline path (INT8 from audio, ``batch`` chunks per step) per SIGNAL FAMILY (tools/signal_families.py: the twelve
+    families of tools/exact_soak.py, random parameters and levels per chunk), with the share of each family's chunks on every route of the
+    exactness pass (csrc/bn_stft_exact.hip): elements re-evaluated one by one inside the mel mixer, chunks recomputed as whole float64
+    spectrograms (noise-free and flat inputs: the guard's bound is useless there).  The benchmark's own input is family 0."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from signal_families import FAMILIES, family_batch
+
+    from birdnet_stm32.models.runners import load_model_runner
+
+    runner = load_model_runner(os.path.join(PKG, "checkpoints", "birdnet_stm32n6_100.tflite"), device=local_rank, max_batch=batch)
+    g = torch.Generator(device=device).manual_seed(1234)
+    scores = torch.empty((batch, runner.num_classes), dtype=torch.float32, device=device)
+    rows = []
+    for kind, name in enumerate(FAMILIES):
+        x = family_batch(torch, kind, batch, g, device)
+        for _ in range(2):
+            runner.infer_audio_device(x, hop=HOP, out=scores)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.infer_audio_device(x, hop=HOP, out=scores)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        st = runner.guard_stats(batch)
+        rows.append({"family": name, "chunks_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 4), "vs_headline": round(batch / dt / headline, 3),
+                     "elements_reevaluated_frac": round(st["listed"] / (batch * 257.0 * 256.0), 7),
+                     "whole_float64_chunks_frac": round((st["whole_minmax"] + st["whole_fix"]) / batch, 4),
+                     "scores_finite": bool(torch.isfinite(scores).all().item())})
+        del x
+    runner.close()
+    worst = min(rows, key=lambda r: r["chunks_per_s"])
+    return {"batch": batch, "steps": steps, "worst_family": worst["family"], "worst_vs_headline": worst["vs_headline"], "families": rows,
+            "note": "same kernels and options as the headline; only the input family changes (random frequencies, phases, levels over four decades)"}
+
+
+def evaluate_leg(n_files: int = 1024) -> dict:
+    """``evaluate`` end to end (files on tmpfs -> metrics) as a child process running tools/evaluate_bench.py on ``n_files`` synthetic 30 s stereo
+    PCM16 WAVs: reader pool -> pinned slabs -> H2D on a copy stream -> ingest + inference -> pooling -> metrics (reference flow:
+    birdnet_stm32/evaluation/metrics.py:117-153).  PCIe is this path's roof; the JSON carries both bounds and the per-stage split."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "evaluate_bench.py"), "--files", str(n_files), "--repeats", "3"],
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    d = json.loads(lines[-1])
+    keep = ("files", "seconds", "channels", "native_rate", "dataset_gb", "value", "unit", "files_per_s", "pinned_copy_gbps", "h2d_gbps", "h2d_frac_of_pinned_copy",
+            "pcm_bytes_per_chunk", "pcie_bound_chunks_per_s", "kernel_bound_chunks_per_s", "frac_of_min_bound", "best_warm_run", "cold_run")
+    return {"workload": "python -m birdnet_stm32 evaluate's function on synthetic WAV files on tmpfs, INT8 shipped checkpoint (tools/evaluate_bench.py)",
+            **{k: d[k] for k in keep if k in d}}
 
 
 C4_PW_MAC, C4_MMAC = 191_889_408, 200.8  # SURVEY.md §8d: configs[4] pointwise multiply-accumulates / all MACs per chunk
@@ -561,6 +645,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (default 4096 i8, 1024 f32)")
     ap.add_argument("--collective", action="store_true", help="initialise RCCL even on one GPU and run the all-gather inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the main measurement (other configurations, hard inputs, evaluate end to end)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -700,11 +785,17 @@ def main() -> None:
         if coll is not None:
             coll["in_timed_region"] = True
             out["collective"] = coll
-        if world == 1 and not args.batch:  # the other single-GPU BASELINE configurations, for reference (not the reported value)
+        if world == 1 and not args.batch and not args.no_extras:  # the other single-GPU BASELINE configurations, for reference (not the reported value)
             runner.close()
             runner = None
             del pool
             torch.cuda.empty_cache()
+            if args.dtype == "i8":
+                try:  # what the headline costs on inputs the benchmark's own generator never produces
+                    out["hard_inputs"] = hard_inputs(torch, device, local_rank, out["value"])
+                except Exception as e:  # noqa: BLE001
+                    out["hard_inputs"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
             other = "i8" if args.dtype == "f32" else "f32"
             out["also_measured"] = quick_rate(torch, other, 4096 if other == "i8" else 1024, device, local_rank)
             for key, kw in (("also_measured_configs4", {}), ("also_measured_configs4_3s", {"seconds": 3}), ("also_measured_configs4_int8", {"int8": True})):
@@ -720,6 +811,11 @@ def main() -> None:
                                          note="probe behind the measurement; `--collective` puts the all-gather inside the timed region")
             except Exception as e:  # noqa: BLE001
                 out["collective"] = {"backend": None, "ranks_seen": 1, "error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.batch and not args.no_extras and not use_dist:
+            try:
+                out["also_measured_evaluate"] = evaluate_leg()
+            except Exception as e:  # noqa: BLE001
+                out["also_measured_evaluate"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.dtype)
         print(json.dumps(out))

@@ -35,82 +35,110 @@ namespace bn {
 namespace {
 
 constexpr int kFT = 16;  // frames per tile (= stft512_mag_kernel's workgroup)
+constexpr int kListGrid = 768;  // workgroups of the list kernel (three per CU by LDS; they walk the list and leave at once when it is empty)
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void wave_lds_sync() { wave_sync(); }  // a wave's LDS writes visible to its own lanes: wave-level, no workgroup barrier
 
 __device__ __forceinline__ size_t spec_offset(int W, bool tile_major, int k, int t) {
     return tile_major ? (size_t)(t / kFT) * 257 * kFT + (size_t)k * kFT + (t % kFT) : (size_t)k * W + t;
 }
 
 // ------------------------------------------------------------------------------------------------ whole spectrogram in float64
+// A 512-point real transform per frame as ONE 256-point complex float64 FFT (z[n] = xw[2n] + i xw[2n+1], four radix-4 Stockham passes
+// through LDS, one butterfly per lane and pass) plus the split pass X[k] = E[k] + W^k O[k].  A WAVE owns a frame — its ping / pong
+// buffers are its own, so the passes meet at wave-level barriers only — and the four waves of a workgroup share the 16 frames of a
+// tile.  Round 3 evaluated every bin as a 255-term float64 DFT (67 MFLOP per chunk, LDS-bound at 7.7 us per chunk); the FFT needs 2.6
+// MFLOP.  Both agree with numpy's float64 FFT to ~1e-16 of the frame's norm, i.e. they round to the same complex64 except for elements
+// that sit that close to a rounding boundary (the argument of bn_stft_exact.hip's header applies unchanged); the window product is
+// rounded to float64 before it enters the transform, as in the reference (fp contraction is off for this file).
 struct F64Lds {
-    double cs[512];
-    double xw[512];
-    double2 sd[256];  // n = 1..255: (xw[n] + xw[512 - n], xw[n] - xw[512 - n])
-    double red[4];
+    double cs[512];          // cos(2 pi e / 512); sin(2 pi e / 512) = cs[(e + 384) & 511]
+    double2 buf[4][2][256];  // per wave: ping / pong
     float red_min[4], red_max[4];
 };
 
-// The 16 frames of tile (b, tile) with every bin a float64 DFT; 256 threads, thread k = bin k.  cs must be staged.
+__device__ __forceinline__ double2 cmul_tw(const double2 v, const double c, const double sn) {  // v * (c - i sn)
+    return make_double2(v.x * c + v.y * sn, v.y * c - v.x * sn);
+}
+
+// The 16 frames of tile (b, tile); 256 threads.  cs must be staged (the caller's loop; the barrier at the top orders it).
 __device__ __forceinline__ void f64_tile(F64Lds& L, const StftTables& tb, const float* __restrict__ audio, int T, int hop, int W,
                                          float* __restrict__ spec, float* minmax, bool tile_major, int b, int tile) {
-    const int tid = threadIdx.x, t0 = tile * kFT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t0 = tile * kFT;
     const float* x = audio + (size_t)b * T;
     float* out = spec + (size_t)b * 257 * W;
     float lmin = __uint_as_float(0x7f800000u), lmax = 0.0f;
-    for (int ff = 0; ff < kFT && t0 + ff < W; ++ff) {
+    __syncthreads();  // cs staged; the previous tile's reduction scratch read
+    double2* A = L.buf[wave][0];
+    double2* Bf = L.buf[wave][1];
+    for (int ff = wave; ff < kFT && t0 + ff < W; ff += 4) {
         const int t = t0 + ff;
         const long base = (long)t * hop - 256;
-        __syncthreads();  // previous frame done with xw / sd (and cs staged)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = tid + 256 * h;
-            const long pos = base + n;
-            const float xv = (pos >= 0 && pos < T) ? x[pos] : 0.0f;
-            L.xw[n] = (double)xv * tb.hann64[n];
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            const long p0 = base + 2 * n;
+            const float x0 = (p0 >= 0 && p0 < T) ? x[p0] : 0.0f;
+            const float x1 = (p0 + 1 >= 0 && p0 + 1 < T) ? x[p0 + 1] : 0.0f;
+            A[n] = make_double2((double)x0 * tb.hann64[2 * n], (double)x1 * tb.hann64[2 * n + 1]);
         }
-        __syncthreads();
-        double alt;  // this thread's term of the Nyquist bin sum_n (-1)^n xw[n]
-        if (tid == 0) {
-            alt = L.xw[0] + L.xw[256];
-        } else {
-            const double p = L.xw[tid], q = L.xw[512 - tid];
-            L.sd[tid] = make_double2(p + q, p - q);
-            alt = (tid & 1) ? -(p + q) : (p + q);
-        }
-        __syncthreads();
-        // bin k = tid: re = xw[0] + (-1)^k xw[256] + sum_n s_n cos(2 pi k n / 512), im = -sum_n d_n sin(2 pi k n / 512)
-        double re = 0.0, im = 0.0;
-        for (int n = 1; n < 256; ++n) {
-            const int idx = (tid * n) & 511;
-            const double2 v = L.sd[n];
-            re = fma(v.x, L.cs[idx], re);
-            im = fma(v.y, L.cs[(idx + 384) & 511], im);
-        }
-        re += (tid & 1) ? (L.xw[0] - L.xw[256]) : (L.xw[0] + L.xw[256]);
-        const float m = numpy_cabsf((float)re, (float)im);
-        out[spec_offset(W, tile_major, tid, t)] = m;
-        lmin = fminf(lmin, m);
-        lmax = fmaxf(lmax, m);
-        // Nyquist bin
+        wave_lds_sync();
+        double2* src = A;
+        double2* dst = Bf;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) alt += __shfl_xor(alt, off);
-        if ((tid & 63) == 0) L.red[tid >> 6] = alt;
-        __syncthreads();
-        if (tid == 0) {
-            const float ny = numpy_cabsf((float)((L.red[0] + L.red[1]) + (L.red[2] + L.red[3])), 0.0f);
-            out[spec_offset(W, tile_major, 256, t)] = ny;
-            lmin = fminf(lmin, ny);
-            lmax = fmaxf(lmax, ny);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int Ns = 1 << (2 * pass);
+            const int jm = lane & (Ns - 1);
+            const int e1 = jm * (128 >> (2 * pass));  // 512 jm / (4 Ns)
+            double2 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
+            if (pass) {
+                v1 = cmul_tw(v1, L.cs[e1], L.cs[(e1 + 384) & 511]);
+                v2 = cmul_tw(v2, L.cs[2 * e1], L.cs[(2 * e1 + 384) & 511]);
+                v3 = cmul_tw(v3, L.cs[3 * e1], L.cs[(3 * e1 + 384) & 511]);
+            }
+            const double2 a0 = make_double2(v0.x + v2.x, v0.y + v2.y), a1 = make_double2(v0.x - v2.x, v0.y - v2.y);
+            const double2 a2 = make_double2(v1.x + v3.x, v1.y + v3.y), d13 = make_double2(v1.x - v3.x, v1.y - v3.y);
+            const double2 a3 = make_double2(d13.y, -d13.x);  // -i (v1 - v3)
+            const int j0 = ((lane - jm) << 2) + jm;
+            dst[j0] = make_double2(a0.x + a2.x, a0.y + a2.y);
+            dst[j0 + Ns] = make_double2(a1.x + a3.x, a1.y + a3.y);
+            dst[j0 + 2 * Ns] = make_double2(a0.x - a2.x, a0.y - a2.y);
+            dst[j0 + 3 * Ns] = make_double2(a1.x - a3.x, a1.y - a3.y);
+            wave_lds_sync();
+            double2* tmp = src;
+            src = dst;
+            dst = tmp;
         }
+        // four passes: the transform is back in A (= src).  Split pass: E = (Z_k + conj Z_-k) / 2, O = (Z_k - conj Z_-k) / (2 i), X_k = E + W^k O
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = lane + 64 * i;
+            if (i == 4 && lane != 0) break;
+            const double2 zk = src[k & 255], zm = src[(256 - k) & 255];
+            const double2 E = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+            const double2 D = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+            const double2 O = make_double2(D.y, -D.x);
+            const double2 WO = cmul_tw(O, L.cs[k], L.cs[(k + 384) & 511]);
+            const float m = numpy_cabsf((float)(E.x + WO.x), (float)(E.y + WO.y));
+            out[spec_offset(W, tile_major, k, t)] = m;
+            lmin = fminf(lmin, m);
+            lmax = fmaxf(lmax, m);
+        }
+        wave_lds_sync();  // the next frame overwrites A
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         lmin = fminf(lmin, __shfl_xor(lmin, off));
         lmax = fmaxf(lmax, __shfl_xor(lmax, off));
     }
-    __syncthreads();
-    if ((tid & 63) == 0) {
-        L.red_min[tid >> 6] = lmin;
-        L.red_max[tid >> 6] = lmax;
+    if (lane == 0) {
+        L.red_min[wave] = lmin;
+        L.red_max[wave] = lmax;
     }
     __syncthreads();
     if (tid == 0) {
@@ -154,11 +182,6 @@ __global__ __launch_bounds__(256) void stft512_f64_list_kernel(StftTables tb, co
 // are re-evaluated in float64 four at a time.  A chunk with more than kGuardBudget of them (or an overflowing record: flat spectra,
 // pure stationary tones, signals far below the bound) goes to stft512_f64_list_kernel as a whole.
 constexpr int kK2Thr = 192;  // candidate threads a wave keeps
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
                                                                 float* __restrict__ spec, int tile_major, StftGuard g, int n_tiles,
                                                                 float* __restrict__ minmax, int B) {
@@ -306,7 +329,7 @@ void launch_stft_minmax_exact(const StftTables& tb, const float* audio, int B, i
     hipLaunchKernelGGL(stft_minmax_exact_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tb, audio, T, hop, W, spec, tile_major ? 1 : 0, g,
                        (W + kFT - 1) / kFT, minmax, B);  // (the caller keeps W <= 1024: one lane per tile record)
     // chunks the wave gave up on (none for ordinary audio: the 256 workgroups read the count and leave)
-    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(128), dim3(256), 0, s, tb, audio, T, hop, W, spec, minmax, tile_major ? 1 : 0, g.hard, g.n_hard,
+    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(kListGrid), dim3(256), 0, s, tb, audio, T, hop, W, spec, minmax, tile_major ? 1 : 0, g.hard, g.n_hard,
                        g.eps);
 }
 
@@ -318,7 +341,7 @@ void launch_stft_fix(const StftTables& tb, const float* audio, int B, int T, int
     // chunks a workgroup of the mel mixer gave up on (it listed them itself): whole float64 spectrograms; the caller then runs the mixer's
     // work-list form over their blocks
     // (minmax is exact already: the atomics of this pass find the same values)
-    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(128), dim3(256), 0, s, tb, audio, T, hop, W, spec, const_cast<float*>(minmax), tile_major ? 1 : 0,
+    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(kListGrid), dim3(256), 0, s, tb, audio, T, hop, W, spec, const_cast<float*>(minmax), tile_major ? 1 : 0,
                        g.hard + g.hard_cap, g.n_hard + 1, (float*)nullptr);
 }
 

@@ -6,12 +6,29 @@
  * birdnet_stm32/models/runners.py:51-95): MultiplyByQuantizedMultiplier = RoundingDivideByPOT(SaturatingRoundingDoublingHighMul(
  * x << left, M0), right) (kernels/internal/common.h), CONV_2D / DEPTHWISE_CONV_2D per-channel (reference_integer_ops/conv.h,
  * depthwise_conv.h: padded taps are skipped, i.e. contribute (zp - zp) = 0), ADD with left shift 20 (reference_integer_ops/add.h),
- * MEAN with the folded multiplier (reduce.h), FULLY_CONNECTED per-channel.  Parallelism: OpenMP over chunks / rows. */
+ * MEAN with the folded multiplier (reduce.h), FULLY_CONNECTED per-channel.  Parallelism: OpenMP over chunks / rows.
+ *
+ * Two builds of this one file (oracle/Makefile): the portable one (-march=x86-64-v3: the scalar loops below, what the CPU tests load) and
+ * `make native` (-march=native on the box the baseline is timed on).  With AVX-512 + VNNI the native build takes the vector paths:
+ * 1x1 convolutions as u8 x s8 dot products (vpdpbusd: (x ^ 0x80) is x + 128 as an unsigned byte, the 128 and the input zero point are
+ * folded into the bias as (128 + zp) * sum(w)), sixteen output channels per accumulator register, weights re-packed [K/4][N/16][16][4];
+ * everything else sixteen channels per register in int32; MultiplyByQuantizedMultiplier on sixteen lanes with the literal definitions
+ * (64-bit products, sign-dependent nudge, truncating division, remainder / threshold rounding shift).  Same integers either way:
+ * tests/test_oracle_pinning.py holds BOTH builds against oracle/int8_graph.py on every tensor of the shipped graph. */
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+#if defined(__AVX512F__) && defined(__AVX512BW__) && defined(__AVX512VNNI__)
+#include <immintrin.h>
+#define OI_VEC 1
+#else
+#define OI_VEC 0
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+int oi_vectorised(void) { return OI_VEC; }  /* 1: this build takes the AVX-512 / VNNI paths */
 
 int oi_max_threads(void) {
 #ifdef _OPENMP
@@ -39,10 +56,120 @@ static inline int32_t mbqm(int32_t x, int32_t mult, int shift) {
 }
 static inline int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+
+#if OI_VEC
+/* MultiplyByQuantizedMultiplier on sixteen int32 lanes, the definitions above lane by lane */
+static inline __m512i srdhm_half(__m512i p) { /* eight 64-bit products -> (p + nudge) / 2^31, C truncation */
+    const __mmask8 neg = _mm512_cmplt_epi64_mask(p, _mm512_setzero_si512());
+    const __m512i t = _mm512_add_epi64(p, _mm512_mask_blend_epi64(neg, _mm512_set1_epi64(1ll << 30), _mm512_set1_epi64(1ll - (1ll << 30))));
+    const __mmask8 tneg = _mm512_cmplt_epi64_mask(t, _mm512_setzero_si512());
+    return _mm512_srai_epi64(_mm512_mask_add_epi64(t, tneg, t, _mm512_set1_epi64((1ll << 31) - 1)), 31);
+}
+static inline __m512i mbqm16(__m512i x, __m512i mult, __m512i shift) {
+    const __m512i zero = _mm512_setzero_si512(), one = _mm512_set1_epi32(1);
+    const __m512i left = _mm512_max_epi32(shift, zero), right = _mm512_max_epi32(_mm512_sub_epi32(zero, shift), zero);
+    const __m512i xl = _mm512_sllv_epi32(x, left); /* x * (1 << left), int32 wrap-around */
+    const __m512i re = srdhm_half(_mm512_mul_epi32(xl, mult));
+    const __m512i ro = srdhm_half(_mm512_mul_epi32(_mm512_srli_epi64(xl, 32), _mm512_srli_epi64(mult, 32)));
+    __m512i v = _mm512_mask_blend_epi32(0xAAAA, re, _mm512_slli_epi64(ro, 32));
+    const __mmask16 sat = _mm512_cmpeq_epi32_mask(xl, _mm512_set1_epi32(INT32_MIN)) & _mm512_cmpeq_epi32_mask(mult, _mm512_set1_epi32(INT32_MIN));
+    v = _mm512_mask_blend_epi32(sat, v, _mm512_set1_epi32(INT32_MAX));
+    const __m512i mask = _mm512_sub_epi32(_mm512_sllv_epi32(one, right), one);
+    const __m512i rem = _mm512_and_si512(v, mask);
+    const __m512i thr = _mm512_add_epi32(_mm512_srli_epi32(mask, 1), _mm512_srli_epi32(v, 31));
+    return _mm512_mask_add_epi32(_mm512_srav_epi32(v, right), _mm512_cmpgt_epi32_mask(rem, thr), _mm512_srav_epi32(v, right), one);
+}
+static inline void store16_i8(int8_t* dst, __m512i v, int zp, int lo, int hi, __mmask16 live) {
+    v = _mm512_min_epi32(_mm512_max_epi32(_mm512_add_epi32(v, _mm512_set1_epi32(zp)), _mm512_set1_epi32(lo)), _mm512_set1_epi32(hi));
+    _mm_mask_storeu_epi8(dst, live, _mm512_cvtepi32_epi8(v));
+}
+static inline __mmask16 live16(int n0, int N) { return N - n0 >= 16 ? (__mmask16)0xFFFF : (__mmask16)((1u << (N - n0)) - 1u); }
+
+/* 1x1 convolution, stride 1: P positions x Cin -> Cout */
+static void conv1x1_vnni(const int8_t* x, int8_t* y, long P, int Cin, int Cout, const int8_t* w, const int32_t* bias, int zp_in, int zp_out,
+                         const int32_t* mult, const int32_t* shift, int amin, int amax) {
+    const int K4 = (Cin + 3) / 4, N16 = (Cout + 15) / 16;
+    int8_t* wp = (int8_t*)aligned_alloc(64, (size_t)K4 * N16 * 64);
+    int32_t* cst = (int32_t*)aligned_alloc(64, (size_t)N16 * 16 * 3 * 4);
+    memset(wp, 0, (size_t)K4 * N16 * 64);
+    for (int n = 0; n < N16 * 16; ++n) {
+        int32_t ws = 0;
+        if (n < Cout)
+            for (int c = 0; c < Cin; ++c) {
+                wp[((size_t)(c / 4) * N16 + n / 16) * 64 + (n % 16) * 4 + c % 4] = w[(size_t)n * Cin + c];
+                ws += w[(size_t)n * Cin + c];
+            }
+        cst[n] = n < Cout ? (bias ? bias[n] : 0) - (128 + zp_in) * ws : 0;
+        cst[N16 * 16 + n] = n < Cout ? mult[n] : 0;
+        cst[2 * N16 * 16 + n] = n < Cout ? shift[n] : 0;
+    }
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < P; ++p) {
+        uint32_t xu[K4];
+        uint8_t tmp[4 * K4];
+        memset(tmp, 0, sizeof tmp);
+        memcpy(tmp, x + p * Cin, Cin);
+        memcpy(xu, tmp, sizeof tmp);
+        for (int k = 0; k < K4; ++k) xu[k] ^= 0x80808080u; /* (padding bytes meet zero weights) */
+        for (int nb = 0; nb < N16; ++nb) {
+            __m512i acc = _mm512_load_si512(cst + 16 * nb);
+            for (int k = 0; k < K4; ++k)
+                acc = _mm512_dpbusd_epi32(acc, _mm512_set1_epi32((int)xu[k]), _mm512_load_si512(wp + ((size_t)k * N16 + nb) * 64));
+            store16_i8(y + p * Cout + 16 * nb, mbqm16(acc, _mm512_load_si512(cst + N16 * 16 + 16 * nb), _mm512_load_si512(cst + 2 * N16 * 16 + 16 * nb)),
+                       zp_out, amin, amax, live16(16 * nb, Cout));
+        }
+    }
+    free(wp);
+    free(cst);
+}
+#endif
+
 /* x [B][H][W][Cin], w [Cout][kh][kw][Cin], y [B][OH][OW][Cout] */
 void oi_conv(const int8_t* x, int8_t* y, int B, int H, int W, int Cin, int kh, int kw, int Cout, int sh, int sw, int OH, int OW,
              int pt, int pl, const int8_t* w, const int32_t* bias, int zp_in, int zp_out, const int32_t* mult, const int32_t* shift,
              int amin, int amax) {
+#if OI_VEC
+    if (kh == 1 && kw == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && OH == H && OW == W) {
+        conv1x1_vnni(x, y, (long)B * H * W, Cin, Cout, w, bias, zp_in, zp_out, mult, shift, amin, amax);
+        return;
+    }
+    {   /* any other convolution (the 3x3 stem): sixteen output channels per register, one broadcast input value per multiply-add */
+        const int N16 = (Cout + 15) / 16, taps = kh * kw * Cin;
+        int32_t* wp = (int32_t*)aligned_alloc(64, (size_t)taps * N16 * 64);
+        int32_t* cst = (int32_t*)aligned_alloc(64, (size_t)N16 * 16 * 3 * 4);
+        for (int n = 0; n < N16 * 16; ++n) {
+            for (int t = 0; t < taps; ++t) wp[((size_t)t * N16 + n / 16) * 16 + n % 16] = n < Cout ? w[(size_t)n * taps + t] : 0;
+            cst[n] = n < Cout && bias ? bias[n] : 0;
+            cst[N16 * 16 + n] = n < Cout ? mult[n] : 0;
+            cst[2 * N16 * 16 + n] = n < Cout ? shift[n] : 0;
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int oh = 0; oh < OH; ++oh)
+                for (int ow = 0; ow < OW; ++ow)
+                    for (int nb = 0; nb < N16; ++nb) {
+                        __m512i acc = _mm512_load_si512(cst + 16 * nb);
+                        for (int i = 0; i < kh; ++i) {
+                            const int ih = oh * sh - pt + i;
+                            if (ih < 0 || ih >= H) continue;
+                            for (int j = 0; j < kw; ++j) {
+                                const int iw = ow * sw - pl + j;
+                                if (iw < 0 || iw >= W) continue;
+                                const int8_t* xi = x + (((size_t)b * H + ih) * W + iw) * Cin;
+                                for (int c = 0; c < Cin; ++c)
+                                    acc = _mm512_add_epi32(acc, _mm512_mullo_epi32(_mm512_set1_epi32((int32_t)xi[c] - zp_in),
+                                                                                   _mm512_load_si512(wp + ((size_t)((i * kw + j) * Cin + c) * N16 + nb) * 16)));
+                            }
+                        }
+                        store16_i8(y + (((size_t)b * OH + oh) * OW + ow) * Cout + 16 * nb,
+                                   mbqm16(acc, _mm512_load_si512(cst + N16 * 16 + 16 * nb), _mm512_load_si512(cst + 2 * N16 * 16 + 16 * nb)), zp_out, amin, amax,
+                                   live16(16 * nb, Cout));
+                    }
+        free(wp);
+        free(cst);
+        return;
+    }
+#endif
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int oh = 0; oh < OH; ++oh)
@@ -72,6 +199,31 @@ void oi_conv(const int8_t* x, int8_t* y, int B, int H, int W, int Cin, int kh, i
 void oi_dwconv(const int8_t* x, int8_t* y, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int OH, int OW, int pt, int pl,
                const int8_t* w, const int32_t* bias, int zp_in, int zp_out, const int32_t* mult, const int32_t* shift, int amin,
                int amax) {
+#if OI_VEC
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int oh = 0; oh < OH; ++oh)
+            for (int ow = 0; ow < OW; ++ow)
+                for (int c0 = 0; c0 < C; c0 += 16) {
+                    const __mmask16 live = live16(c0, C);
+                    __m512i acc = bias ? _mm512_maskz_loadu_epi32(live, bias + c0) : _mm512_setzero_si512();
+                    for (int i = 0; i < kh; ++i) {
+                        const int ih = oh * sh - pt + i;
+                        if (ih < 0 || ih >= H) continue;
+                        for (int j = 0; j < kw; ++j) {
+                            const int iw = ow * sw - pl + j;
+                            if (iw < 0 || iw >= W) continue;
+                            const __m512i xv = _mm512_sub_epi32(_mm512_cvtepi8_epi32(_mm_maskz_loadu_epi8(live, x + (((size_t)b * H + ih) * W + iw) * C + c0)),
+                                                                _mm512_set1_epi32(zp_in));
+                            const __m512i wv = _mm512_cvtepi8_epi32(_mm_maskz_loadu_epi8(live, w + ((size_t)i * kw + j) * C + c0));
+                            acc = _mm512_add_epi32(acc, _mm512_mullo_epi32(xv, wv));
+                        }
+                    }
+                    store16_i8(y + (((size_t)b * OH + oh) * OW + ow) * C + c0,
+                               mbqm16(acc, _mm512_maskz_loadu_epi32(live, mult + c0), _mm512_maskz_loadu_epi32(live, shift + c0)), zp_out, amin, amax, live);
+                }
+    return;
+#endif
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int oh = 0; oh < OH; ++oh)
@@ -96,6 +248,19 @@ void oi_dwconv(const int8_t* x, int8_t* y, int B, int H, int W, int C, int kh, i
 /* element-wise ADD; b is broadcast with period nb (nb == n: same shape) */
 void oi_add(const int8_t* a, const int8_t* b, int8_t* y, long n, long nb, int z1, int m1, int s1, int z2, int m2, int s2, int mo, int so,
             int zo, int amin, int amax) {
+#if OI_VEC
+    if (nb == n) {
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < n; i += 16) {
+            const __mmask16 live = n - i >= 16 ? (__mmask16)0xFFFF : (__mmask16)((1u << (n - i)) - 1u);
+            const __m512i av = _mm512_slli_epi32(_mm512_sub_epi32(_mm512_cvtepi8_epi32(_mm_maskz_loadu_epi8(live, a + i)), _mm512_set1_epi32(z1)), 20);
+            const __m512i bv = _mm512_slli_epi32(_mm512_sub_epi32(_mm512_cvtepi8_epi32(_mm_maskz_loadu_epi8(live, b + i)), _mm512_set1_epi32(z2)), 20);
+            const __m512i sa = mbqm16(av, _mm512_set1_epi32(m1), _mm512_set1_epi32(s1)), sb = mbqm16(bv, _mm512_set1_epi32(m2), _mm512_set1_epi32(s2));
+            store16_i8(y + i, mbqm16(_mm512_add_epi32(sa, sb), _mm512_set1_epi32(mo), _mm512_set1_epi32(so)), zo, amin, amax, live);
+        }
+        return;
+    }
+#endif
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < n; ++i) {
         const int32_t sa = mbqm(((int32_t)a[i] - z1) * (1 << 20), m1, s1);

@@ -15,6 +15,18 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CPU_LIB = os.path.join(_HERE, "_build", "liboracle_cpu.so")
 I8_LIB = os.path.join(_HERE, "_build", "liboracle_i8.so")
+NATIVE_DIR = os.path.join(_HERE, "_build", "native")  # `make -C oracle native`: the same sources built -march=native on the host they are timed on
+
+
+def build_native() -> bool:
+    """Build the -march=native variants of the two C ports on THIS host (bench.py's cpu_baseline leg; seconds).  False if gcc / make fail."""
+    import subprocess
+
+    try:
+        subprocess.run(["make", "-C", _HERE, "native"], check=True, capture_output=True, timeout=300)
+    except Exception:  # noqa: BLE001
+        return False
+    return os.path.isfile(os.path.join(NATIVE_DIR, "liboracle_i8.so")) and os.path.isfile(os.path.join(NATIVE_DIR, "liboracle_cpu.so"))
 FW_LIB = os.path.join(_HERE, "_ref", "libfw_ref.so")
 
 _f = ctypes.POINTER(ctypes.c_float)
@@ -27,8 +39,8 @@ def _p(a: np.ndarray):
 class CpuFloatPath:
     """audio -> scores for a NetSpec of plain DS blocks (the shipped checkpoint), in C with OpenMP."""
 
-    def __init__(self, spec):
-        self.lib = ctypes.CDLL(CPU_LIB)
+    def __init__(self, spec, native: bool = False):
+        self.lib = ctypes.CDLL(os.path.join(NATIVE_DIR, "liboracle_cpu.so") if native else CPU_LIB)
         self.lib.oc_max_threads.restype = ctypes.c_int
         self.threads = int(self.lib.oc_max_threads())
         self.spec = spec
@@ -139,13 +151,15 @@ class CpuInt8Path:
     and activation ranges come from the numpy interpreter's own preparation code, so both paths share one definition;
     tests check that their tensors are identical.  ``spectrogram()`` is the C STFT of the float port."""
 
-    def __init__(self, model):
+    def __init__(self, model, native: bool = False):
         from oracle import int8_graph as ig
 
         self.ig = ig
-        self.lib = ctypes.CDLL(I8_LIB)
+        self.native = bool(native)
+        self.lib = ctypes.CDLL(os.path.join(NATIVE_DIR, "liboracle_i8.so") if native else I8_LIB)
         self.lib.oi_max_threads.restype = ctypes.c_int
         self.threads = int(self.lib.oi_max_threads())
+        self.vectorised = bool(self.lib.oi_vectorised())  # the AVX-512 / VNNI paths of oracle_i8.c are compiled in
         outer = self
 
         class _Interp(ig.Int8Interpreter):
@@ -248,10 +262,9 @@ class CpuInt8Path:
     def invoke(self, x, return_all: bool = False):
         return self.interp.invoke(x, return_all=return_all)
 
-    @staticmethod
-    def spectrogram(audio: np.ndarray, hop: int, width: int) -> np.ndarray:
+    def spectrogram(self, audio: np.ndarray, hop: int, width: int) -> np.ndarray:
         """Normalised |STFT| [B, 257, width, 1] through the float port's C STFT (OpenMP over chunks)."""
-        lib = ctypes.CDLL(CPU_LIB)
+        lib = ctypes.CDLL(os.path.join(NATIVE_DIR, "liboracle_cpu.so") if getattr(self, "native", False) else CPU_LIB)
         x = np.ascontiguousarray(audio, np.float32)
         S = np.empty((x.shape[0], 257, width), np.float32)
         lib.oc_stft_norm(_p(x), x.shape[0], x.shape[1], hop, width, _p(S))

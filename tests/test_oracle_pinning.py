@@ -336,8 +336,11 @@ def test_ingest_window_and_chunks_equal_host_io(tmp_path):
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_c_int8_port_is_identical_to_the_numpy_interpreter():
-    """oracle/c/oracle_i8.c (the INT8 CPU baseline) against oracle/int8_graph.py: every tensor of the shipped graph, bit for bit."""
+@pytest.mark.parametrize("native", [False, True])
+def test_c_int8_port_is_identical_to_the_numpy_interpreter(native):
+    """oracle/c/oracle_i8.c (the INT8 CPU baseline) against oracle/int8_graph.py: every tensor of the shipped graph, bit for bit — the
+    portable build (scalar loops) and the -march=native build of the same file (on AVX-512 / VNNI hosts: vpdpbusd 1x1 convolutions,
+    sixteen-lane MultiplyByQuantizedMultiplier), which is the one bench.py times."""
     from birdnet_stm32.models._tflite_reader import load_tflite
     from oracle import cport, stft
     from oracle.int8_graph import Int8Interpreter
@@ -346,11 +349,13 @@ def test_c_int8_port_is_identical_to_the_numpy_interpreter():
 
     if not (os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB)):
         pytest.skip("oracle C libraries not built (python -c 'import __graft_entry__ as g; g.build()')")
+    if native and not cport.build_native():
+        pytest.skip("no native build of the oracle's C port on this host")
     model = load_tflite(TFLITE_PATH)
     x = synth_chunks(3)
     S = np.stack([stft.hybrid_spectrogram(a) for a in x])[..., None]
     ref, env = Int8Interpreter(model).invoke(S, return_all=True)
-    port = cport.CpuInt8Path(model)
+    port = cport.CpuInt8Path(model, native=native)
     got, env_c = port.invoke(S, return_all=True)
     assert np.array_equal(got, ref)
     for k, v in env.items():

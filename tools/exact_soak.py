@@ -23,43 +23,12 @@ T, sr = 72000, 24000
 dev = torch.device("cuda")
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1234
 g = torch.Generator(device=dev).manual_seed(seed)
-t = torch.arange(T, device=dev, dtype=torch.float64) / sr
-
-
-def rnd(*shape, lo=0.0, hi=1.0):
-    return lo + (hi - lo) * torch.rand(shape, generator=g, device=dev, dtype=torch.float64)
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from signal_families import family_batch  # noqa: E402
 
 
 def batch(kind: int):
-    f = rnd(B, 1, lo=60.0, hi=11500.0)
-    tone = torch.sin(2 * np.pi * f * t[None, :] + rnd(B, 1, hi=6.28))
-    noise = torch.randn((B, T), generator=g, device=dev, dtype=torch.float64)
-    if kind == 0:
-        x = rnd(B, 1, hi=1.0) * noise + tone
-    elif kind == 1:
-        x = tone + rnd(B, 1) * torch.sin(2 * np.pi * rnd(B, 1, lo=60.0, hi=11500.0) * t[None, :])
-    elif kind == 2:
-        x = noise
-    elif kind == 3:
-        x = torch.sin(2 * np.pi * (f * t[None, :] + rnd(B, 1, lo=-1500.0, hi=1500.0) * t[None, :] ** 2))
-    elif kind == 4:
-        x = (1 + 0.9 * torch.sin(2 * np.pi * rnd(B, 1, lo=1.0, hi=40.0) * t[None, :])) * tone + 0.01 * noise
-    elif kind == 5:
-        x = torch.clamp(3 * (0.3 * noise + tone), -1, 1)
-    elif kind == 6:
-        x = sum(torch.sin(2 * np.pi * (rnd(B, 1, lo=80.0, hi=400.0)) * h * t[None, :]) / h for h in range(1, 12)) + 0.02 * noise
-    elif kind == 7:
-        x = torch.where(t[None, :] > rnd(B, 1, hi=2.5), 0.2 * noise + tone, torch.zeros_like(tone))  # onset behind digital silence
-    elif kind == 8:
-        x = (torch.rand((B, T), generator=g, device=dev) < 2e-3).double() * noise + 1e-3 * noise
-    elif kind == 9:
-        x = 1e-4 * noise + tone  # almost noise-free
-    elif kind == 10:
-        x = torch.cumsum(noise, dim=1) / 50.0  # brown noise: strong low frequencies
-    else:
-        x = 0.05 * noise + torch.sign(tone)
-    x = x * 10.0 ** rnd(B, 1, lo=-4.0, hi=0.0)  # any level: the normalisation is scale-free
-    return x.to(torch.float32).contiguous()
+    return family_batch(torch, kind, B, g, dev)
 
 
 runner = load_model_runner(TFLITE_PATH, max_batch=B)
