@@ -390,10 +390,15 @@ def tail_constants(blocks: list[dict], head: dict):
     return np.concatenate(sections).astype(np.int32), np.asarray(desc, np.int32)
 
 
-def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str = "fixed") -> pk.Plan:
+def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str = "fixed", mean_form: str = "int") -> pk.Plan:
     """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse; ``fuse=False`` keeps the
     baseline one-kernel-per-operator plan instead of the fused matrix-core blocks.  ``softmax_form`` picks the arithmetic of an int8
-    SOFTMAX (attention pooling): ``'fixed'`` = TFLite's reference kernel, ``'lut'`` = its optimized kernel (oracle/int8_graph.py has both)."""
+    SOFTMAX (attention pooling): ``'fixed'`` = TFLite's reference kernel, ``'lut'`` = its optimized kernel (oracle/int8_graph.py has both).
+    ``mean_form`` picks the arithmetic of int8 MEAN: ``'int'`` = the integer form with the count folded into the multiplier (reduce.h),
+    ``'float'`` = TFLite's float-arithmetic ``QuantizedMeanOrSum`` (the two differ by one step on ~4 % of the pooled bytes of the shipped
+    graph; every MEAN kernel of the device evaluates either, csrc/bn_requant.h: mean_q)."""
+    if mean_form not in ("int", "float"):
+        raise ValueError("mean_form must be 'int' or 'float'")
     from birdnet_stm32.models._lower_f32 import pick_tile
 
     g = _Graph(model)
@@ -811,7 +816,7 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str
             _expect(axes == [1, 2], "MEAN over the spatial axes")
             s_i, z_i = g.q(src)
             s_o, z_o = g.q(op.outputs[0])
-            mu, sh = qz.mean_multiplier(s_i, s_o, H * Wd)
+            mu, sh = qz.mean_multiplier(s_i, s_o, H * Wd) if mean_form == "int" else qz.mean_float_params(s_i, s_o)
             v = pb.value(C)
             tail_head.update(mean_op=len(plan.ops), mean_src=val[src], P=H * Wd, C=C, mean_zp_in=z_i, mean_mult=mu, mean_shift=sh, mean_zp_out=z_o)
             pb.op(pk.I8_MEAN, val[src], v, p=[H * Wd, C, z_i, mu, sh, z_o], name=f"t{op.outputs[0]}", out_shape=(C,), out_dtype="int8")

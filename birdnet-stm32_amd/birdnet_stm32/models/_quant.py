@@ -129,6 +129,16 @@ def mean_multiplier(s_in: float, s_out: float, n: int) -> tuple[int, int]:
     return int((mult << fold) // n), shift - fold
 
 
+MEAN_FLOAT_FORM = 0x7FFFFF00  # csrc/bn_requant.h: kMeanFloatForm — `shift` value that selects the float-arithmetic MEAN on the device
+
+
+def mean_float_params(s_in: float, s_out: float) -> tuple[int, int]:
+    """(float32 bits of s_in / s_out, MEAN_FLOAT_FORM): the (mult, shift) pair that makes the device's MEAN evaluate TFLite's float-arithmetic
+    ``QuantizedMeanOrSum`` — round(sum / n * scale - zp_in * scale) + zp_out in float32 — instead of the integer form of ``mean_multiplier``."""
+    scale = np.float32(np.float32(s_in) / np.float32(s_out))
+    return int(np.frombuffer(scale.tobytes(), np.int32)[0]), MEAN_FLOAT_FORM
+
+
 def logistic_table(s_in: float, z_in: int, s_out: float, z_out: int) -> np.ndarray:
     """int8 -> int8 sigmoid table indexed by ``q + 128`` (float32 evaluation, like LUTPopulate)."""
     q = np.arange(-128, 128, dtype=np.int32)

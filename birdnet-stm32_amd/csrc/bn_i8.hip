@@ -301,8 +301,7 @@ __global__ __launch_bounds__(256) void i8_mean_kernel(const int8_t* __restrict__
             const int8_t* p = x + (size_t)b * P * C + c;
             int32_t s = 0;
             for (int i = 0; i < P; ++i) s += p[(size_t)i * C];
-            s -= zp_in * P;
-            y[(size_t)b * C + c] = (int8_t)clampi(mbqm(s, mult, shift) + zp_out, -128, 127);
+            y[(size_t)b * C + c] = (int8_t)mean_q(s, P, zp_in, mult, shift, zp_out);
         }
         return;
     }
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(256) void i8_mean_kernel(const int8_t* __restrict__
         uint32_t packed = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int32_t qv = clampi(mbqm(s4[e] - zp_in * P, mult, shift) + zp_out, -128, 127);
+            const int32_t qv = mean_q(s4[e], P, zp_in, mult, shift, zp_out);
             packed |= ((uint32_t)(uint8_t)(int8_t)qv) << (8 * e);
         }
         *reinterpret_cast<uint32_t*>(y + (size_t)b * C + 4 * tid) = packed;
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
             for (int e = 0; e < 4; ++e) {
                 const int s4 = srow[4 * q4 + e];
                 srow[4 * q4 + e] = 0;  // ready for the next stage that pools into this buffer
-                const int32_t qv = clampi(mbqm(s4 - a.zp_in * P, a.mean_mult, a.mean_shift) + a.mean_zp, -128, 127);
+                const int32_t qv = mean_q(s4, P, a.zp_in, a.mean_mult, a.mean_shift, a.mean_zp);
                 packed |= ((uint32_t)(uint8_t)(int8_t)qv) << (8 * e);
             }
             se_vec[q4] = (int32_t)packed;
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
                 for (int e = 0; e < 4; ++e) {
                     int s4 = 0;
                     for (int k = 0; k < slices; ++k) s4 += part[k * nq + tid][e];
-                    const int32_t qv = clampi(mbqm(s4 - a.zp_in * P, a.mean_mult, a.mean_shift) + a.mean_zp, -128, 127);
+                    const int32_t qv = mean_q(s4, P, a.zp_in, a.mean_mult, a.mean_shift, a.mean_zp);
                     packed |= ((uint32_t)(uint8_t)(int8_t)qv) << (8 * e);
                 }
                 se_vec[q0 + tid] = (int32_t)packed;

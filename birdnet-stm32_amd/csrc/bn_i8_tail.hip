@@ -326,8 +326,7 @@ __device__ __forceinline__ void tail_head(const Tail8Args& a, unsigned char* lds
         const int8_t* src = reinterpret_cast<const int8_t*>(lds + L.y_off + g * a.P * pitch + c);
         int s = 0;
         for (int k = 0; k < a.P; ++k) s += src[k * pitch];
-        s -= a.mean_zp_in * a.P;
-        reinterpret_cast<int8_t*>(lds + a.mean_off)[i] = (int8_t)clampi(mbqm(s, a.mean_mult, a.mean_shift) + a.mean_zp_out, -128, 127);
+        reinterpret_cast<int8_t*>(lds + a.mean_off)[i] = (int8_t)mean_q(s, a.P, a.mean_zp_in, a.mean_mult, a.mean_shift, a.mean_zp_out);
     }
     __syncthreads();
     // ---- FULLY_CONNECTED + head: one thread per (chunk slot, class) ----------------------------------------------------------

@@ -63,4 +63,24 @@ __device__ __forceinline__ int32_t mbqm_u(int32_t x, int32_t mult, int shift, bo
 
 __device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// int8 MEAN of `raw_sum` = sum of the P raw bytes of a channel.  Two published forms (oracle/int8_graph.py has both behind mean_form):
+//   integer (default): MultiplyByQuantizedMultiplier(raw_sum - zp_in P, mult, shift) with 1 / P folded into the multiplier (reduce.h);
+//   float (shift == kMeanFloatForm, mult = the float32 bits of s_in / s_out): TFLite's float-arithmetic QuantizedMeanOrSum —
+//       round(raw_sum / P * scale + (-zp_in * scale)) in float32, every operation rounded on its own (no fused multiply-add).
+// The lowering pass picks the form (models/_lower_i8.py: lower_i8(mean_form=...)); ~4 % of the pooled bytes of the shipped graph differ by
+// one step between the two (tests/test_oracle_pinning.py counts them), so a deployment that must match a given interpreter picks its form.
+constexpr int32_t kMeanFloatForm = 0x7fffff00;
+__device__ __forceinline__ int32_t mean_q(int32_t raw_sum, int32_t P, int32_t zp_in, int32_t mult, int32_t shift, int32_t zp_out) {
+#pragma clang fp contract(off)
+    if (shift == kMeanFloatForm) {
+        const float scale = __int_as_float(mult);
+        const float bias = (float)(-zp_in) * scale;
+        const float mean = (float)raw_sum / (float)P;
+        const float t = mean * scale;
+        const float r = roundf(t + bias) + (float)zp_out;
+        return (int32_t)fminf(fmaxf(r, -128.0f), 127.0f);
+    }
+    return clampi(mbqm(raw_sum - zp_in * P, mult, shift) + zp_out, -128, 127);
+}
+
 }  // namespace bn

@@ -151,7 +151,7 @@ class CpuInt8Path:
     and activation ranges come from the numpy interpreter's own preparation code, so both paths share one definition;
     tests check that their tensors are identical.  ``spectrogram()`` is the C STFT of the float port."""
 
-    def __init__(self, model, native: bool = False):
+    def __init__(self, model, native: bool = False, **interp_kwargs):
         from oracle import int8_graph as ig
 
         self.ig = ig
@@ -222,7 +222,7 @@ class CpuInt8Path:
             def _mean(self, op, env):
                 x = self._value(env, op.inputs[0])
                 axes = sorted(int(a) % x.ndim for a in np.atleast_1d(self._value(env, op.inputs[1])))
-                if x.ndim != 4 or axes != [1, 2]:
+                if x.ndim != 4 or axes != [1, 2] or self.mean_form != "int":  # (the C kernel is the integer form)
                     return super()._mean(op, env)
                 x = np.ascontiguousarray(x, np.int8)
                 B, H, W, C = x.shape
@@ -257,7 +257,7 @@ class CpuInt8Path:
                                 _i32(p["shift"]), lo, hi)
                 return y
 
-        self.interp = _Interp(model)
+        self.interp = _Interp(model, **interp_kwargs)
 
     def invoke(self, x, return_all: bool = False):
         return self.interp.invoke(x, return_all=return_all)

@@ -156,19 +156,52 @@ def exp_on_interval_between_negative_one_quarter_and_0_excl(a):
     return constant_term + srdhm(constant_term, x + poly)     # exp(-1/8) (1 + x + x^2/2 + x^3/6 + x^4/24)
 
 
-def exp_on_negative_values_q5(a):
-    """gemmlowp ``exp_on_negative_values`` for FixedPoint<int32, 5> (Q5.26 raw, a <= 0) -> Q0.31 raw: the argument modulo 1/4 through the
-    polynomial above, the multiples of 1/4 through a barrel shifter of constants exp(-2^k), k = -2 .. 4."""
+def exp_on_negative_values(a, integer_bits: int):
+    """gemmlowp ``exp_on_negative_values`` for FixedPoint<int32, integer_bits> (a <= 0) -> Q0.31 raw: the argument modulo 1/4 through the
+    polynomial above, the multiples of 1/4 through a barrel shifter of constants exp(-2^k), k = -2 .. integer_bits - 1."""
     a = np.asarray(a, dtype=np.int64)
-    frac = 26
+    frac = 31 - integer_bits
     quarter = 1 << (frac - 2)
     a_mod = (a & (quarter - 1)) - quarter
-    result = exp_on_interval_between_negative_one_quarter_and_0_excl(a_mod << 5)   # Rescale<0>: exact (|a_mod| < 2^24)
+    result = exp_on_interval_between_negative_one_quarter_and_0_excl(a_mod << integer_bits)   # Rescale<0>: exact (|a_mod| < 2^(frac - 2))
     remainder = a_mod - a
     for exponent, mult in ((-2, 1672461947), (-1, 1302514674), (0, 790015084), (1, 290630308), (2, 39332535), (3, 720401), (4, 242)):
+        if exponent >= integer_bits:
+            break
         hit = (remainder & (1 << (frac + exponent))) != 0
         result = np.where(hit, srdhm(result, mult), result)
     return np.where(a == 0, INT32_MAX, result)
+
+
+def exp_on_negative_values_q5(a):
+    """... for FixedPoint<int32, 5> (the int8 SOFTMAX's scaled differences)."""
+    return exp_on_negative_values(a, 5)
+
+
+def logistic_fixed_q4(a):
+    """gemmlowp ``logistic`` for FixedPoint<int32, 4> raw -> Q0.31 raw: 1 / (1 + exp(-|a|)) through ``exp_on_negative_values`` and the
+    Newton-Raphson reciprocal, mirrored for negative arguments (One() - result), exactly 1/2 at zero."""
+    a = np.asarray(a, dtype=np.int64)
+    pos = one_over_one_plus_x_for_x_in_0_1(exp_on_negative_values(-np.abs(a), 4))
+    return np.where(a == 0, 1 << 30, np.where(a > 0, pos, INT32_MAX - pos))
+
+
+def logistic_int8_fixed(x, s_in: float, zp_in: int):
+    """int8 LOGISTIC as TFLite's fixed-point kernels compute it (reference_integer_ops/logistic.h, registered as
+    ``Register_LOGISTIC_FIXED_POINT_OPT`` and the form TFLite-Micro runs; output 1 / 256, -128): the input rescaled to Q4.27 by a
+    quantised multiplier of ``s_in 2^27``, saturation outside the input radius, gemmlowp's ``logistic``, RoundingDivideByPOT by 23.
+    The interpreter's DEFAULT int8 LOGISTIC is the float32 table of ``Int8Interpreter.logistic_lut``.  Restated from the published
+    source, **parity unpinned**."""
+    x = np.asarray(x, dtype=np.int64) - int(zp_in)
+    mult, left = quantize_multiplier(float(np.float32(s_in)) * float(1 << (31 - 4)))
+    if left < 0:
+        raise ValueError("LOGISTIC input multiplier below one")
+    radius = int(np.floor(1.0 * ((1 << 4) - 1) * (1 << (31 - 4)) / (1 << left)))
+    inside = (x > -radius) & (x < radius)
+    q4 = mbqm(np.where(inside, x, 0), mult, left)
+    y = rounding_divide_by_pot(logistic_fixed_q4(q4), 31 - 8) - 128
+    y = np.clip(y, -128, 127)
+    return np.where(x <= -radius, -128, np.where(x >= radius, 127, y)).astype(np.int8)
 
 
 def softmax_fixed_params(s_in: float, beta: float) -> tuple[int, int, int]:
@@ -213,6 +246,18 @@ def softmax_int8_lut(x, s_in: float, beta: float = 1.0, s_out: float = 1.0 / 256
     return np.clip(y, -128, 127).astype(np.int8)
 
 
+def mean_int8_float(x, axes, keep_dims: bool, n: int, s_in: float, zp_in: int, s_out: float, zp_out: int):
+    """int8 MEAN as TFLite's float-arithmetic ``QuantizedMeanOrSum`` computes it (reduce.h, ``compute_sum = false``): the int32 sum of the raw
+    bytes, then in float32 ``mean = sum / n``, ``scale = s_in / s_out``, ``bias = -zp_in * scale``, ``round(mean * scale + bias) + zp_out``
+    (TfLiteRound: half away from zero), clamped to int8.  Restated from the published source, **parity unpinned**."""
+    total = np.asarray(x, dtype=np.int64).sum(axis=axes, keepdims=keep_dims)
+    scale = np.float32(np.float32(s_in) / np.float32(s_out))
+    bias = np.float32(np.float32(-zp_in) * scale)
+    mean = (total.astype(np.float32) / np.float32(n)).astype(np.float32)
+    y = round_half_away((mean * scale + bias).astype(np.float32)).astype(np.int64) + int(zp_out)
+    return np.clip(y, -128, 127).astype(np.int8)
+
+
 def activation_range(act: str, scale: float, zp: int, qmin=-128, qmax=127) -> tuple[int, int]:
     """``CalculateActivationRangeQuantized`` for int8 outputs."""
     s = np.float32(scale)
@@ -253,12 +298,22 @@ def _same(size, k, s):
 class Int8Interpreter:
     """Executes a decoded ``TfliteModel`` on float32 batches, like ``TFLiteRunner.predict``."""
 
-    def __init__(self, model, softmax_form: str = "fixed"):
+    def __init__(self, model, softmax_form: str = "fixed", mean_form: str = "int", logistic_form: str = "lut"):
         """``softmax_form``: which published form an int8 SOFTMAX takes — ``'fixed'`` TFLite's reference kernel (gemmlowp fixed point),
-        ``'lut'`` its optimized kernel (float32 exponent table).  Nothing here can tell which one the reference's interpreter runs."""
+        ``'lut'`` its optimized kernel (float32 exponent table).  Nothing here can tell which one the reference's interpreter runs.
+
+        ``mean_form``: int8 MEAN — ``'int'`` the integer form with the count folded into the multiplier (reduce.h; the default here and
+        what the device runs), ``'float'`` the float-arithmetic ``QuantizedMeanOrSum`` (sum in int32, ``round(sum / n * (s_in / s_out) -
+        zp_in s_in / s_out) + zp_out`` in float32).  ``logistic_form``: int8 LOGISTIC — ``'lut'`` the float32 table of the
+        builtin kernel (default), ``'fixed'`` gemmlowp fixed point (``logistic_int8_fixed``).  tests/test_oracle_pinning.py counts the
+        bytes and top-1 labels that depend on the choice for the shipped checkpoint."""
         if softmax_form not in ("fixed", "lut"):
             raise ValueError("softmax_form must be 'fixed' or 'lut'")
-        self.softmax_form = softmax_form
+        if mean_form not in ("int", "float"):
+            raise ValueError("mean_form must be 'int' or 'float'")
+        if logistic_form not in ("lut", "fixed"):
+            raise ValueError("logistic_form must be 'lut' or 'fixed'")
+        self.softmax_form, self.mean_form, self.logistic_form = softmax_form, mean_form, logistic_form
         self._init(model)
 
     def _init(self, model):
@@ -348,6 +403,8 @@ class Int8Interpreter:
         s_in, zp_in = self._q(op.inputs[0])
         s_out, zp_out = self._q(op.outputs[0])
         n = int(np.prod([x.shape[a] for a in axes]))
+        if self.mean_form == "float":
+            return mean_int8_float(x, axes, bool(op.options.get("keep_dims")), n, s_in, zp_in, s_out, zp_out)
         mult, shift = quantize_multiplier(float(np.float32(s_in)) / float(np.float32(s_out)))
         fold = min(n.bit_length() - 1, 32, 31 + shift)  # 63 - clz(n), clamped as in reduce.h
         mult = int((mult << fold) // n)
@@ -459,11 +516,12 @@ class Int8Interpreter:
         return x[tuple(sl)]
 
     # -- graph walk ---------------------------------------------------------------
-    def invoke(self, x: np.ndarray, return_all: bool = False):
-        """float32 batch in -> float32 ``[B, C]`` out; optionally every intermediate tensor."""
+    def invoke(self, x: np.ndarray, return_all: bool = False, resume: tuple[dict, int] | None = None):
+        """float32 batch in -> float32 ``[B, C]`` out; optionally every intermediate tensor.  ``resume = (env, first_op)`` continues from the
+        tensors of an earlier run at operator ``first_op`` (tests re-run the graph's tail under another form of MEAN / LOGISTIC)."""
         m = self.model
-        env: dict[int, np.ndarray] = {m.inputs[0]: np.asarray(x, dtype=np.float32)}
-        for op in m.ops:
+        env: dict[int, np.ndarray] = {m.inputs[0]: np.asarray(x, dtype=np.float32)} if resume is None else dict(resume[0])
+        for op in m.ops[resume[1] if resume else 0:]:
             n = op.name
             if n == "QUANTIZE":
                 s, zp = self._q(op.outputs[0])
@@ -511,8 +569,15 @@ class Int8Interpreter:
             elif n == "FULLY_CONNECTED":
                 y = self._fully_connected(op, env)
             elif n == "LOGISTIC":
-                lut = self.logistic_lut(op)
-                y = lut[self._value(env, op.inputs[0]).astype(np.int32) + 128]
+                if self.logistic_form == "fixed":
+                    s_i, z_i = self._q(op.inputs[0])
+                    s_o, z_o = self._q(op.outputs[0])
+                    if (round(1.0 / s_o), z_o) != (256, -128):
+                        raise ValueError("fixed-point int8 LOGISTIC writes 1/256, -128")
+                    y = logistic_int8_fixed(self._value(env, op.inputs[0]), s_i, z_i)
+                else:
+                    lut = self.logistic_lut(op)
+                    y = lut[self._value(env, op.inputs[0]).astype(np.int32) + 128]
             elif n == "MUL":
                 y = self._mul(op, env)
             elif n == "REDUCE_MAX":

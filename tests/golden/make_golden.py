@@ -148,8 +148,68 @@ def oracle_fixtures() -> None:
             out[key + "/i8_fc"] = env[128][0].astype(np.int8)
             out[key + "/i8_probs"] = q_probs[0].astype(np.float32)
             out[key + "/i8_sums"] = np.array([int(env[t].astype(np.int64).sum()) for t in (83, 96, 97, 102, 110, 121, 126, 127)], np.int64)
+            # every int8 tensor of the graph: (tensor index, sum, position-weighted checksum) — a GPU test holds each plan operator's output to these
+            out[key + "/i8_tensors"] = tensor_checksums(env)
+    out.update(config4_fixtures())
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
     print("wrote oracle_vectors.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
+def tensor_checksums(env) -> np.ndarray:
+    """``[n, 3]`` int64 rows (tensor index, sum of the bytes, sum of (i mod 65521 + 1) * byte) over the int8 tensors of an interpreter run."""
+    rows = []
+    for t in sorted(env):
+        v = np.asarray(env[t])
+        if v.dtype != np.int8:
+            continue
+        flat = v.astype(np.int64).reshape(-1)
+        rows.append((int(t), int(flat.sum()), int(((np.arange(flat.size, dtype=np.int64) % 65521 + 1) * flat).sum())))
+    return np.array(rows, np.int64)
+
+
+C4_SECONDS, C4_CHUNKS = 2, 3
+
+
+def config4_model():
+    """BASELINE configs[4]'s topology as bench.py builds it (raw frontend + PCEN + alpha = 1.5 DS-CNN with squeeze-excite / inverted residuals,
+    seeded weights, the reference's 2 s deployment geometry) and its INT8 export (own PTQ, seeded calibration)."""
+    from birdnet_stm32.conversion.export import convert_netspec_to_int8
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._tflite_writer import write_tflite
+
+    T4 = 24000 * C4_SECONDS
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=C4_SECONDS, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+    rng = np.random.default_rng(0)
+    cal = [rng.standard_normal((1, T4, 1)).astype(np.float32) for _ in range(8)]
+    cal = [c / (np.abs(c).max() + 1e-6) for c in cal]
+    raw = write_tflite(convert_netspec_to_int8(spec, lambda: ([c] for c in cal)))
+    return spec, raw
+
+
+def config4_inputs() -> np.ndarray:
+    """``[C4_CHUNKS, T, 1]`` model inputs of the raw frontend: peak-normalised noise + tone, seeded."""
+    T4 = 24000 * C4_SECONDS
+    rng = np.random.default_rng(11)
+    t = np.arange(T4) / 24000.0
+    x = np.stack([0.3 * rng.standard_normal(T4) + np.sin(2 * np.pi * (700 + 900 * b) * t) for b in range(C4_CHUNKS)])
+    return (x / (np.abs(x).max(axis=1, keepdims=True) + 1e-6)).astype(np.float32)[..., None]
+
+
+def config4_fixtures() -> dict:
+    import hashlib
+
+    from oracle import float_graph
+    from oracle.int8_graph import Int8Interpreter
+
+    from birdnet_stm32.models._tflite_reader import parse_tflite
+
+    spec, raw = config4_model()
+    x = config4_inputs()
+    probs, logits = float_graph.forward(spec, x, np.float64, return_logits=True)
+    q_probs, env = Int8Interpreter(parse_tflite(raw)).invoke(x, return_all=True)
+    return {"c4/tflite_sha256": np.frombuffer(hashlib.sha256(raw).digest(), np.uint8).copy(), "c4/f32_logits": logits.astype(np.float32),
+            "c4/f32_probs": probs.astype(np.float32), "c4/i8_probs": q_probs.astype(np.float32), "c4/i8_tensors": tensor_checksums(env)}
 
 
 if __name__ == "__main__":
