@@ -46,11 +46,13 @@ def normalize(S: np.ndarray) -> np.ndarray:
 
 
 def spectrograms_from_chunks(chunks: np.ndarray, n_fft: int = 512, spec_width: int = 256, normalize_out: bool = True,
-                             exact: bool = True) -> np.ndarray:
+                             exact: bool = False) -> np.ndarray:
     """``[B, T]`` float32 chunks -> ``[B, n_fft//2+1, spec_width]`` float32, one GPU launch group.
 
-    ``exact`` (default): ``bn_stft_mag_exact`` — librosa's float64 arithmetic value for value, so that an INT8 runner behind this
-    host-side call quantises the bytes the reference quantises; ``exact=False`` is the float32 FFT (2e-6 of the peak, ten times faster)."""
+    Default: the float32 FFT (within 2e-6 of the peak of the reference's values) — what float32 models, PTQ calibration and
+    ``get_spectrogram_from_audio`` need.  ``exact=True``: ``bn_stft_mag_exact`` — librosa's float64 arithmetic value for value (a float64
+    FFT, about five times slower), so that an INT8 runner behind this host-side call quantises the bytes the reference quantises;
+    ``evaluate``'s per-file loop passes it for INT8 runners only."""
     import torch
 
     from birdnet_stm32.models.runners import stft_device

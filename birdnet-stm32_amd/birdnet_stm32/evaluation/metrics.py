@@ -34,7 +34,7 @@ from birdnet_stm32.models.frontend import normalize_frontend_name
 
 
 def make_chunks_for_file(path: str, cfg: dict, frontend: str, mag_scale: str, n_fft: int, chunk_overlap: float,
-                         spectrogram_fn=None) -> list[np.ndarray]:
+                         spectrogram_fn=None, exact_spectrogram: bool = False) -> list[np.ndarray]:
     """Model-ready inputs for one file: a list of per-chunk float32 arrays (reference :18-72).
 
     ``spectrogram_fn(chunks [N,T], n_fft, spec_width) -> [N, F, W]`` replaces the GPU STFT (tests inject the
@@ -48,8 +48,13 @@ def make_chunks_for_file(path: str, cfg: dict, frontend: str, mag_scale: str, n_
         return []
     if frontend == "hybrid":
         if spectrogram_fn is None:
-            from birdnet_stm32.audio.spectrogram import spectrograms_from_chunks as spectrogram_fn
-        specs = np.asarray(spectrogram_fn(np.asarray(chunks, np.float32), n_fft, width), np.float32)
+            from birdnet_stm32.audio.spectrogram import spectrograms_from_chunks
+
+            # an INT8 runner quantises these values: it gets the reference's float64 arithmetic; float32 models take the float32 FFT
+            specs = spectrograms_from_chunks(np.asarray(chunks, np.float32), n_fft, width, exact=exact_spectrogram)
+        else:
+            specs = spectrogram_fn(np.asarray(chunks, np.float32), n_fft, width)
+        specs = np.asarray(specs, np.float32)
         bins = n_fft // 2 + 1
         return [s[:bins, :width, None] for s in specs]
     if frontend == "raw":
@@ -76,10 +81,11 @@ def _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scal
                            spectrogram_fn, pooling, beta):
     """The reference loop: per file, batches of at most ``batch_size`` chunks, never across files."""
     lat: list[float] = []
+    exact = getattr(model_runner, "dtype", None) == "i8"
     for path in files:
         if _label_of(path) not in classes:
             continue
-        chunks = make_chunks_for_file(path, cfg, frontend, mag_scale, n_fft, overlap, spectrogram_fn=spectrogram_fn)
+        chunks = make_chunks_for_file(path, cfg, frontend, mag_scale, n_fft, overlap, spectrogram_fn=spectrogram_fn, exact_spectrogram=exact)
         if not chunks:
             continue
         preds = []

@@ -784,7 +784,10 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str
             flat = op.outputs[0]
             _expect(fc.inputs[0] == flat and r2.inputs[0] == fc.outputs[0] and sm.inputs[0] == r2.outputs[0] and r3.inputs[0] == sm.outputs[0]
                     and set(mul.inputs) == {flat, r3.outputs[0]} and sm_sum.inputs[0] == mul.outputs[0], "attention pooling operator chain")
-            _expect(g.consumers.get(flat, []) == sorted([fc.index, mul.index]) and C % 4 == 0 and P * C <= 60 * 1024, "attention pooling geometry")
+            # the kernel keeps the map, the scores and the softmax bytes in LDS (P C + 2 P + 16 bytes of dynamic LDS beside 16 static ones) and sums
+            # up to P exponentials of at most 2^19 in an int32: P <= 4096 (TFLite's kAccumulationIntegerBits = 12 has the same ceiling)
+            _expect(g.consumers.get(flat, []) == sorted([fc.index, mul.index]) and C % 4 == 0 and P <= 4096 and P * C + 2 * P + 32 <= 64 * 1024,
+                    "attention pooling geometry")
             _expect([int(a) % 3 for a in np.atleast_1d(g.const(sm_sum.inputs[1]))] == [1] and not sm_sum.options.get("keep_dims"), "SUM over the positions")
             wt_ = t[fc.inputs[1]]
             _expect(tuple(wt_.shape) == (1, C) and bool(fc.options.get("keep_num_dims")) and fc.options["activation"] == "none", "score layer C -> 1")

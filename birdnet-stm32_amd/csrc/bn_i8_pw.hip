@@ -1,4 +1,4 @@
-// bn_i8_pw.hip — dense INT8 1x1 convolutions (Cin a multiple of 64, 192..768: the expand / project / embedding convolutions of the late
+// bn_i8_pw.hip — dense INT8 1x1 convolutions (Cin = 192, 384, 512 or 768: the expand / project / embedding convolutions of the late
 // stages of exported inverted-residual graphs, reference birdnet_stm32/models/blocks.py:49-133 behind the converter) on the int8 matrix
 // cores, with the squeeze-excite MUL (blocks.py:27-46) applied while the projection loads its input.
 //
@@ -232,7 +232,7 @@ bool i8_pw_lds_supported(const DwPw8Args& a) {
     if (!g_opt.i8_pw_lds || !g_opt.i8_strip) return false;
     const long n_pos = (long)a.B * a.OH * a.OW;
     if (a.has_dw || a.transposed || a.lut || a.qx || a.sh != 1 || a.sw != 1 || a.H != a.OH || a.W != a.OW) return false;
-    if (a.Cin != 192 && a.Cin != 384 && a.Cin != 768) return false;
+    if (a.Cin != 192 && a.Cin != 384 && a.Cin != 512 && a.Cin != 768) return false;
     if (n_pos % 16 || n_pos * a.Cin >= 0x7fff0000L || n_pos * a.Cout >= 0x7fff0000L) return false;
     if (a.gate) {
         if (((long)a.OH * a.OW) % 16) return false;  // a group of 16 positions must lie inside one chunk
@@ -281,6 +281,10 @@ void launch_i8_pw_lds(const DwPw8Args& a, hipStream_t s) {
     } while (0)
     if (a.Cin == 192) BN_PWL_N(3);
     else if (a.Cin == 384) BN_PWL_N(6);
+    else if (a.Cin == 512) {  // (192-channel slices of 512 inputs do not fit)
+        if (g.ns == 128) BN_PWL_AG(8, 8);
+        else BN_PWL_AG(8, 4);
+    }
     else BN_PWL_AG(12, 4);  // (768 input channels: only 64-channel slices fit)
 #undef BN_PWL_N
 #undef BN_PWL_AG

@@ -231,7 +231,8 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
             case BN_OP_I8_ATTNPOOL:  // P C fc_bias fc_mult fc_shift fc_zo form zx za mul_mult mul_shift mul_zo mul_lo mul_hi sum_mult sum_shift sum_zo
                 c.dims({p[0], p[1]}, "attention pooling") && c.slot(o.in0, 1LL * p[0] * p[1], "input map") && c.slot(o.out, 1LL * p[1], "output") &&
                     c.tensor(0, 1LL * p[1], "score vector") && c.tensor(1, p[6] == 0 ? 2048 : 1024, "softmax tables");
-                if (c.ok && (p[1] % 4 || 1LL * p[0] * p[1] + 2LL * p[0] + 16 > 64 * 1024)) c.bad("attention pooling map %d x %d does not fit the kernel", p[0], p[1]);
+                if (c.ok && (p[1] % 4 || p[0] > 4096 || 1LL * p[0] * p[1] + 2LL * p[0] + 32 > 64 * 1024))  // (P <= 4096: the int32 sum of the exponentials)
+                    c.bad("attention pooling map %d x %d does not fit the kernel", p[0], p[1]);
                 if (c.ok && (p[6] < 0 || p[6] > 1)) c.bad("softmax form %d", p[6]);
                 if (c.ok) c.clamp8(p[12], p[13], "attention pooling MUL");
                 break;

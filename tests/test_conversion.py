@@ -371,7 +371,7 @@ def test_squeeze_excite_scale_is_paired_with_its_projection():
     _, model, _, _ = _export(EXPORT_TOPOLOGIES["ir_se_softmax"])
     plan = lower_i8(model)
     heads = [i for i, o in enumerate(plan.ops) if o.kind == pk.I8_SCALE and o.p[pk.TAIL_TAG] == pk.SCALE_HEAD]
-    assert len(heads) >= 8 and len(heads) == sum(o.kind == pk.I8_SCALE and o.p[1] <= 256 for o in plan.ops)  # (the kernel takes up to 256 input channels)
+    assert len(heads) >= 8 and len(heads) == sum(o.kind == pk.I8_SCALE and o.p[1] <= 768 for o in plan.ops)  # (the kernels take up to 768 input channels)
     for i in heads:
         a, b = plan.ops[i], plan.ops[i + 1]
         assert b.kind == pk.I8_DWPW and b.p[pk.TAIL_TAG] == pk.SCALE_COVERED and b.p[29] == 0 and b.in0 == a.out
