@@ -886,16 +886,17 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
         };
         if (o.kind == BN_OP_I8_DWPW) {
             const int* p = o.p;
-            bool ok = all_right(o.t[6], o.t[7]) && (!p[29] || all_right(o.t[2], o.t[3]));
+            const bool pw_ok = all_right(o.t[6], o.t[7]);  // (bit 2: the pointwise stage alone, whatever the ADD behind it looks like)
+            bool ok = pw_ok && (!p[29] || all_right(o.t[2], o.t[3]));
             if (p[18]) ok = ok && p[20] >= 0 && p[21] < 0 && p[22] >= 0 && p[23] < 0 && p[24] >= 0 && p[25] < 0;  // ADD: m1 s1 m2 s2 mo so
             // bit 1: every pointwise shift lies in [-20, -1] — the 64-bit addend of the one-multiply-add requantisation (i8_pw_lds_kernel) cannot overflow
-            bool narrow = ok && o.t[7] >= 0;
+            bool narrow = pw_ok && o.t[7] >= 0;
             if (narrow) {
                 const TensorRec& ts = m->tensors[o.t[7]];
                 const int32_t* ps = (const int32_t*)(base + ts.offset);
                 for (size_t i = 0; i < ts.nbytes / 4; ++i) narrow = narrow && ps[i] >= -20;
             }
-            m->rq_right[oi] = (ok ? 1 : 0) | (narrow ? 2 : 0);
+            m->rq_right[oi] = (ok ? 1 : 0) | (narrow ? 2 : 0) | (pw_ok ? 4 : 0);
         } else if (o.kind == BN_OP_I8_DW || o.kind == BN_OP_I8_STEM) {
             m->rq_right[oi] = all_right(o.t[2], o.t[3]);
         } else if (o.kind == BN_OP_I8_FRONT) {

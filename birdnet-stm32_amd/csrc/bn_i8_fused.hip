@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void i8_dwpw_kernel(DwPw8Args a) {
     v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);  // activation tile [64][kcp/16 + 1] x 16 bytes
     const int K = a.Cin, N = a.Cout;
     const int tid = threadIdx.x;
-    const bool rq = a.rq_right != 0;  // uniform: every requantisation of this operator is a pure right shift
+    const bool rq = (a.rq_right & 1) != 0;  // uniform: every requantisation of this operator is a pure right shift
 
     if (tid < 64) {
         const int tiles_x = a.OW / a.TW, tiles_y = a.OH / a.TH;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
     __shared__ __attribute__((aligned(16))) int stem_t[TS * TS][C / 4];       // 4 channels per dword
     __shared__ __attribute__((aligned(16))) int tile[64 * (NS + 4)];          // A tile [64][64 + 16 bytes], later int32 accumulators
     const int tid = threadIdx.x;
-    const bool rq = a.rq_right != 0;
+    const bool rq = (a.rq_right & 1) != 0;
     int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int tiles_x = a.OW / 8, tiles_y = a.OH / 8;
     const int tx0 = (bid % tiles_x) * 8;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     // lane (n = r, q): accumulator register reg of row group g = frame t0 + 16 g + 4 q + reg of mel bin 16 wv + r
     const int mel = 16 * wv + r;
     const int b = a.pw_b[mel], m = a.pw_mult[mel], sh = a.pw_shift[mel];
-    const bool rq = a.rq_right != 0;
+    const bool rq = (a.rq_right & 1) != 0;
     int8_t* yrow = a.y + ((size_t)chunk * M + mel) * W + t0 + 4 * q;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     __shared__ int add_lut[2][256];
     const int tid = threadIdx.x;
     const int K = a.Cin, N = a.Cout;
-    const bool rq = a.rq_right != 0;
+    const bool rq = (a.rq_right & 1) != 0;
     for (int i = tid; i < N / 4; i += 256) {
         cst[3 * i + 0] = *reinterpret_cast<const v4i*>(a.pw_b + 4 * i);
         cst[3 * i + 1] = *reinterpret_cast<const v4i*>(a.pw_mult + 4 * i);

@@ -32,9 +32,9 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int kPwLdsThreads = 512;
+constexpr int kPwLdsThreads = 1024;  // one workgroup of sixteen waves per CU: the slice's weights are staged once per CU, not twice
 constexpr int kPwLdsWaves = kPwLdsThreads / 64;
-constexpr size_t kPwLdsBudget = 78 * 1024;  // weights + constants of a slice: two workgroups (+ 2 KB of ADD tables each) fit a CU's 160 KB
+constexpr size_t kPwLdsBudget = 154 * 1024;  // weights + constants of a slice (+ 2 KB of ADD tables) inside a CU's 160 KB
 
 struct PwLdsGeom {
     long n_pos;     // B * OH * OW
@@ -43,8 +43,8 @@ struct PwLdsGeom {
     int walkers;    // position walkers = gridDim.x / n_slices
 };
 
-template <bool ADD, bool GATE, int KS, int NCT>  // K = 64 KS input channels, slices of 16 NCT output channels
-__global__ __launch_bounds__(kPwLdsThreads, 4) void i8_pw_lds_kernel(DwPw8Args a, PwLdsGeom g) {
+template <bool ADD, bool GATE, int KS, int NCT, bool HI>  // K = 64 KS input channels, slices of 16 NCT output channels; HI: sign-free requantisation
+__global__ __launch_bounds__(kPwLdsThreads) void i8_pw_lds_kernel(DwPw8Args a, PwLdsGeom g) {
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
     __shared__ int add_lut[2][256];
     constexpr int K = 64 * KS, ns = 16 * NCT, cpl = 4 * NCT;
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(kPwLdsThreads, 4) void i8_pw_lds_kernel(DwPw8Args a
     v4i bfr[KS];
     fetch(grp, bfr);  // the first group's bytes travel while the weights are staged
     // sign-free requantisation (ReLU6 outputs: the clamp starts at the zero point, a negative value ends at the lower bound either way):
-    // clamp(hi32(acc m + C) >> (e - 1)),  C = 2^30 + (2^(e-1) + zp 2^e) 2^31 — three instructions per output instead of eight
-    const bool hi = (a.rq_right & 2) && a.pw_amin >= a.pw_zp_out;
+    // clamp(hi32(acc m + C) >> (e - 1)),  C = 2^30 + (2^(e-1) + zp 2^e) 2^31 — three instructions per output instead of eight (HI: the launcher
+    // checked that every shift lies in [-20, -1] and that the clamp starts at the zero point)
     {
         const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);  // packer's fragment order [K/64][N/16][64 lanes]
         const int n_ct_all = N >> 4;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kPwLdsThreads, 4) void i8_pw_lds_kernel(DwPw8Args a
             const v4i bb = *reinterpret_cast<const v4i*>(a.pw_b + ch), mm = *reinterpret_cast<const v4i*>(a.pw_mult + ch);
             v4i ss = *reinterpret_cast<const v4i*>(a.pw_shift + ch);
             v4i clo = (v4i){0, 0, 0, 0}, chi = (v4i){0, 0, 0, 0};
-            if (hi) {
+            if constexpr (HI) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ex = -ss[e];  // 1 .. 20 (checked at load)
@@ -121,7 +121,6 @@ __global__ __launch_bounds__(kPwLdsThreads, 4) void i8_pw_lds_kernel(DwPw8Args a
         }
     }
     __syncthreads();
-    const bool rq = (a.rq_right & 1) != 0;
     // the gate's constants: C = 2^30 + (2^(e-1) + zo 2^e) 2^31, shift e - 1 (uniform: the MUL is quantised per tensor)
     const int ge = GATE ? -a.g_shift : 1, gsh = ge - 1;
     const long long gC = (1ll << 30) + (((1ll << (ge - 1)) + (long long)a.g_zo * (1ll << ge)) << 31);
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(kPwLdsThreads, 4) void i8_pw_lds_kernel(DwPw8Args a
                 const int cidx = q * NCT + ct0 + u;
                 const v4i m = cst[5 * cidx + 1], sh = cst[5 * cidx + 2];
                 v4i clo = (v4i){0, 0, 0, 0}, chi = (v4i){0, 0, 0, 0};
-                if (hi) {
+                if constexpr (HI) {
                     clo = cst[5 * cidx + 3];
                     chi = cst[5 * cidx + 4];
                 }
@@ -198,16 +197,16 @@ __global__ __launch_bounds__(kPwLdsThreads, 4) void i8_pw_lds_kernel(DwPw8Args a
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int qv;
-                    if (hi) {
+                    if constexpr (HI) {
                         const long long C = (long long)(((unsigned long long)(unsigned)chi[e] << 32) | (unsigned)clo[e]);
                         qv = clampi((int)(((long long)acc[ct0 + u][e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
-                    } else {
-                        qv = clampi(mbqm_u(acc[ct0 + u][e], m[e], sh[e], rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                    } else {  // every multiplier >= 0 and every shift < 0 (checked at load): the branch-free signed form
+                        qv = clampi(mbqm_right(acc[ct0 + u][e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
                     }
                     if (ADD) {
                         const int sa = add_lut[0][(rv4[u] >> (8 * e)) & 0xff];
                         const int sb = add_lut[1][qv & 0xff];
-                        qv = clampi(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);
+                        qv = clampi(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);  // (uniform parameters: the form is chosen once)
                     }
                     packed |= (qv & 0xff) << (8 * e);
                 }
@@ -219,17 +218,18 @@ __global__ __launch_bounds__(kPwLdsThreads, 4) void i8_pw_lds_kernel(DwPw8Args a
     }
 }
 
-// slice width: 192 output channels where Cout allows and the slice's weights fit two workgroups per CU, else 128, else 64
+// slice width: 192 output channels where Cout and the register budget allow, else 128, else 64
 int pick_slice(int K, int N) {
+    const int widest = K <= 384 ? 192 : K <= 512 ? 128 : 64;  // registers: 4 K / 64 for the activations + ns / 4 accumulators per lane, 128 in all
     for (int ns : {192, 128, 64})
-        if (N % ns == 0 && (size_t)ns * (K + 20) <= kPwLdsBudget) return ns;
+        if (ns <= widest && N % ns == 0 && (size_t)ns * (K + 20) <= kPwLdsBudget) return ns;
     return 0;
 }
 
 }  // namespace
 
 bool i8_pw_lds_supported(const DwPw8Args& a) {
-    if (!g_opt.i8_pw_lds || !g_opt.i8_strip) return false;
+    if (!g_opt.i8_pw_lds || !g_opt.i8_strip || !(a.rq_right & 4)) return false;  // (pointwise multipliers >= 0, right shifts only: the kernel's two requantisation forms)
     const long n_pos = (long)a.B * a.OH * a.OW;
     if (a.has_dw || a.transposed || a.lut || a.qx || a.sh != 1 || a.sw != 1 || a.H != a.OH || a.W != a.OW) return false;
     if (a.Cin != 192 && a.Cin != 384 && a.Cin != 512 && a.Cin != 768) return false;
@@ -249,19 +249,25 @@ void launch_i8_pw_lds(const DwPw8Args& a, hipStream_t s) {
     g.n_pos = (long)a.B * a.OH * a.OW;
     g.ns = pick_slice(a.Cin, a.Cout);
     g.n_slices = a.Cout / g.ns;
-    // persistent: two workgroups per CU; walkers in multiples of the eight XCDs, no more than there are groups of 16 positions per wave
+    // persistent: one workgroup per CU; walkers in multiples of the eight XCDs, no more than there are groups of 16 positions per wave
     const long groups = g.n_pos / 16;
-    long walkers = (2 * 256) / g.n_slices / 8 * 8;
+    long walkers = 256 / g.n_slices / 8 * 8;
     if (walkers < 8) walkers = 8;
     const long need = ((groups + kPwLdsWaves - 1) / kPwLdsWaves + 7) / 8 * 8;
     if (walkers > need) walkers = need;
     g.walkers = (int)walkers;
     const unsigned blocks = (unsigned)(walkers * g.n_slices);
     const size_t smem = (size_t)g.ns * (a.Cin + 20);
-#define BN_PWL(ADDV, GATEV, KSV, NCTV)                                                                                     \
-    do {                                                                                                                   \
-        if (smem > 64 * 1024) ensure_dynamic_lds((const void*)i8_pw_lds_kernel<ADDV, GATEV, KSV, NCTV>, smem);             \
-        hipLaunchKernelGGL((i8_pw_lds_kernel<ADDV, GATEV, KSV, NCTV>), dim3(blocks), dim3(kPwLdsThreads), smem, s, a, g); \
+    const bool hi = (a.rq_right & 2) && a.pw_amin >= a.pw_zp_out;
+#define BN_PWL1(ADDV, GATEV, KSV, NCTV, HIV)                                                                                    \
+    do {                                                                                                                        \
+        if (smem > 64 * 1024) ensure_dynamic_lds((const void*)i8_pw_lds_kernel<ADDV, GATEV, KSV, NCTV, HIV>, smem);             \
+        hipLaunchKernelGGL((i8_pw_lds_kernel<ADDV, GATEV, KSV, NCTV, HIV>), dim3(blocks), dim3(kPwLdsThreads), smem, s, a, g); \
+    } while (0)
+#define BN_PWL(ADDV, GATEV, KSV, NCTV)                   \
+    do {                                                 \
+        if (hi) BN_PWL1(ADDV, GATEV, KSV, NCTV, true);   \
+        else BN_PWL1(ADDV, GATEV, KSV, NCTV, false);     \
     } while (0)
 #define BN_PWL_AG(KSV, NCTV)                                \
     do {                                                    \
@@ -281,14 +287,15 @@ void launch_i8_pw_lds(const DwPw8Args& a, hipStream_t s) {
     } while (0)
     if (a.Cin == 192) BN_PWL_N(3);
     else if (a.Cin == 384) BN_PWL_N(6);
-    else if (a.Cin == 512) {  // (192-channel slices of 512 inputs do not fit)
+    else if (a.Cin == 512) {
         if (g.ns == 128) BN_PWL_AG(8, 8);
         else BN_PWL_AG(8, 4);
     }
-    else BN_PWL_AG(12, 4);  // (768 input channels: only 64-channel slices fit)
+    else BN_PWL_AG(12, 4);
 #undef BN_PWL_N
 #undef BN_PWL_AG
 #undef BN_PWL
+#undef BN_PWL1
 }
 
 }  // namespace bn

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             int acc = dot4_first(T[i0][e], wr[0][e], bias[e]);
             acc = dot4(T[i1][e], wr[1][e], acc);
             acc = dot4(T[i2][e], wr[2][e], acc);
-            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], a.rq_right != 0) + a.zp_out, a.amin, a.amax);
+            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], (a.rq_right & 1) != 0) + a.zp_out, a.amin, a.amax);
             psum[e] += qv[e];
         }
         const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, in
             int acc = dot4_first(T[i0], wr[0][e], bias[e]);
             acc = dot4(T[i1], wr[1][e], acc);
             acc = dot4(T[i2], wr[2][e], acc);
-            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], a.rq_right != 0) + a.zp_out, a.amin, a.amax);
+            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], (a.rq_right & 1) != 0) + a.zp_out, a.amin, a.amax);
         }
         const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         __builtin_amdgcn_raw_buffer_store_b32(word, rs_out, voff_out, oh * a.OW * a.C, 0);
