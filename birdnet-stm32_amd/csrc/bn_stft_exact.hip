@@ -35,7 +35,7 @@ namespace bn {
 namespace {
 
 constexpr int kFT = 16;  // frames per tile (= stft512_mag_kernel's workgroup)
-constexpr int kListGrid = 768;  // workgroups of the list kernel (three per CU by LDS; they walk the list and leave at once when it is empty)
+
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -58,7 +58,7 @@ __device__ __forceinline__ size_t spec_offset(int W, bool tile_major, int k, int
 // rounded to float64 before it enters the transform, as in the reference (fp contraction is off for this file).
 struct F64Lds {
     double cs[512];          // cos(2 pi e / 512); sin(2 pi e / 512) = cs[(e + 384) & 511]
-    double2 buf[4][2][256];  // per wave: ping / pong
+    double2 buf[4][2][320];  // per wave: ping / pong (256 elements, one gap per four: fslot)
     float red_min[4], red_max[4];
 };
 
@@ -66,8 +66,34 @@ __device__ __forceinline__ double2 cmul_tw(const double2 v, const double c, cons
     return make_double2(v.x * c + v.y * sn, v.y * c - v.x * sn);
 }
 
+// element i of a wave's 256-point buffer sits at slot i + (i >> 2) (one 16-byte gap per four): the radix-4 passes write with strides of 4 and 16
+// elements, which without the skew put the eight lanes of a ds_write_b128 group on a quarter of the banks (4-way conflicts in passes 0 and 1)
+__device__ __forceinline__ int fslot(int i) { return i + (i >> 2); }
+
 // The 16 frames of tile (b, tile); 256 threads.  cs must be staged (the caller's loop; the barrier at the top orders it).
-__device__ __forceinline__ void f64_tile(F64Lds& L, const StftTables& tb, const float* __restrict__ audio, int T, int hop, int W,
+// everything that depends on the lane only, loaded once per workgroup and kept in registers across tiles and frames: the window values of the
+// lane's 8 samples, the twiddles of its butterfly in passes 1-3 and of its 4 (+1) bins in the split pass
+struct F64Regs {
+    double2 win[4], tw[3][3], tws[5];
+    __device__ __forceinline__ void load(const F64Lds& L, const StftTables& tb) {  // after cs is staged and a barrier
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            win[i] = make_double2(tb.hann64[2 * n], tb.hann64[2 * n + 1]);
+            tws[i] = make_double2(L.cs[n], L.cs[(n + 384) & 511]);
+        }
+        tws[4] = make_double2(L.cs[256], L.cs[(256 + 384) & 511]);
+#pragma unroll
+        for (int pass = 1; pass < 4; ++pass) {
+            const int e1 = (lane & ((1 << (2 * pass)) - 1)) * (128 >> (2 * pass));  // 512 (j mod Ns) / (4 Ns)
+#pragma unroll
+            for (int r = 1; r < 4; ++r) tw[pass - 1][r - 1] = make_double2(L.cs[r * e1], L.cs[(r * e1 + 384) & 511]);
+        }
+    }
+};
+
+__device__ __forceinline__ void f64_tile(F64Lds& L, const F64Regs& R, const float* __restrict__ audio, int T, int hop, int W,
                                          float* __restrict__ spec, float* minmax, bool tile_major, int b, int tile) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t0 = tile * kFT;
     const float* x = audio + (size_t)b * T;
@@ -76,6 +102,9 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const StftTables& tb, const 
     __syncthreads();  // cs staged; the previous tile's reduction scratch read
     double2* A = L.buf[wave][0];
     double2* Bf = L.buf[wave][1];
+    const double2 (&win)[4] = R.win;
+    const double2 (&tw)[3][3] = R.tw;
+    const double2 (&tws)[5] = R.tws;
     for (int ff = wave; ff < kFT && t0 + ff < W; ff += 4) {
         const int t = t0 + ff;
         const long base = (long)t * hop - 256;
@@ -85,7 +114,7 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const StftTables& tb, const 
             const long p0 = base + 2 * n;
             const float x0 = (p0 >= 0 && p0 < T) ? x[p0] : 0.0f;
             const float x1 = (p0 + 1 >= 0 && p0 + 1 < T) ? x[p0 + 1] : 0.0f;
-            A[n] = make_double2((double)x0 * tb.hann64[2 * n], (double)x1 * tb.hann64[2 * n + 1]);
+            A[fslot(n)] = make_double2((double)x0 * win[i].x, (double)x1 * win[i].y);
         }
         wave_lds_sync();
         double2* src = A;
@@ -94,21 +123,20 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const StftTables& tb, const 
         for (int pass = 0; pass < 4; ++pass) {
             const int Ns = 1 << (2 * pass);
             const int jm = lane & (Ns - 1);
-            const int e1 = jm * (128 >> (2 * pass));  // 512 jm / (4 Ns)
-            double2 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
+            double2 v0 = src[fslot(lane)], v1 = src[fslot(lane + 64)], v2 = src[fslot(lane + 128)], v3 = src[fslot(lane + 192)];
             if (pass) {
-                v1 = cmul_tw(v1, L.cs[e1], L.cs[(e1 + 384) & 511]);
-                v2 = cmul_tw(v2, L.cs[2 * e1], L.cs[(2 * e1 + 384) & 511]);
-                v3 = cmul_tw(v3, L.cs[3 * e1], L.cs[(3 * e1 + 384) & 511]);
+                v1 = cmul_tw(v1, tw[pass - 1][0].x, tw[pass - 1][0].y);
+                v2 = cmul_tw(v2, tw[pass - 1][1].x, tw[pass - 1][1].y);
+                v3 = cmul_tw(v3, tw[pass - 1][2].x, tw[pass - 1][2].y);
             }
             const double2 a0 = make_double2(v0.x + v2.x, v0.y + v2.y), a1 = make_double2(v0.x - v2.x, v0.y - v2.y);
             const double2 a2 = make_double2(v1.x + v3.x, v1.y + v3.y), d13 = make_double2(v1.x - v3.x, v1.y - v3.y);
             const double2 a3 = make_double2(d13.y, -d13.x);  // -i (v1 - v3)
             const int j0 = ((lane - jm) << 2) + jm;
-            dst[j0] = make_double2(a0.x + a2.x, a0.y + a2.y);
-            dst[j0 + Ns] = make_double2(a1.x + a3.x, a1.y + a3.y);
-            dst[j0 + 2 * Ns] = make_double2(a0.x - a2.x, a0.y - a2.y);
-            dst[j0 + 3 * Ns] = make_double2(a1.x - a3.x, a1.y - a3.y);
+            dst[fslot(j0)] = make_double2(a0.x + a2.x, a0.y + a2.y);
+            dst[fslot(j0 + Ns)] = make_double2(a1.x + a3.x, a1.y + a3.y);
+            dst[fslot(j0 + 2 * Ns)] = make_double2(a0.x - a2.x, a0.y - a2.y);
+            dst[fslot(j0 + 3 * Ns)] = make_double2(a1.x - a3.x, a1.y - a3.y);
             wave_lds_sync();
             double2* tmp = src;
             src = dst;
@@ -119,11 +147,11 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const StftTables& tb, const 
         for (int i = 0; i < 5; ++i) {
             const int k = lane + 64 * i;
             if (i == 4 && lane != 0) break;
-            const double2 zk = src[k & 255], zm = src[(256 - k) & 255];
+            const double2 zk = src[fslot(k & 255)], zm = src[fslot((256 - k) & 255)];
             const double2 E = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
             const double2 D = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
             const double2 O = make_double2(D.y, -D.x);
-            const double2 WO = cmul_tw(O, L.cs[k], L.cs[(k + 384) & 511]);
+            const double2 WO = cmul_tw(O, tws[i].x, tws[i].y);
             const float m = numpy_cabsf((float)(E.x + WO.x), (float)(E.y + WO.y));
             out[spec_offset(W, tile_major, k, t)] = m;
             lmin = fminf(lmin, m);
@@ -153,7 +181,10 @@ __global__ __launch_bounds__(256) void stft512_f64_kernel(StftTables tb, const f
                                                           float* __restrict__ spec, float* minmax, int tile_major) {
     __shared__ F64Lds L;
     for (int i = threadIdx.x; i < 512; i += 256) L.cs[i] = tb.cs64[i];
-    f64_tile(L, tb, audio, T, hop, W, spec, minmax, tile_major != 0, blockIdx.y, blockIdx.x);
+    __syncthreads();
+    F64Regs R;
+    R.load(L, tb);
+    f64_tile(L, R, audio, T, hop, W, spec, minmax, tile_major != 0, blockIdx.y, blockIdx.x);
 }
 
 // The chunks of a list (those the guarded pass gives up on: flat spectra, pure tones, signals far below the error bound — more
@@ -165,9 +196,12 @@ __global__ __launch_bounds__(256) void stft512_f64_list_kernel(StftTables tb, co
     const int n_tiles = (W + kFT - 1) / kFT, n = *n_list * n_tiles;
     if ((int)blockIdx.x >= n) return;
     for (int i = threadIdx.x; i < 512; i += 256) L.cs[i] = tb.cs64[i];
+    __syncthreads();
+    F64Regs R;
+    R.load(L, tb);
     for (int w = blockIdx.x; w < n; w += gridDim.x) {
         const int b = list[w / n_tiles], tile = w % n_tiles;
-        f64_tile(L, tb, audio, T, hop, W, spec, minmax, tile_major != 0, b, tile);
+        f64_tile(L, R, audio, T, hop, W, spec, minmax, tile_major != 0, b, tile);
         if (eps && threadIdx.x < kFT && tile * kFT + threadIdx.x < W) eps[(size_t)b * W + tile * kFT + threadIdx.x] = 0.0f;
     }
 }
@@ -313,6 +347,20 @@ __global__ void spec_bytes_kernel(const float* __restrict__ spec, const float* _
 
 }  // namespace
 
+// workgroups of the list kernel: exactly what the device keeps resident (registers and LDS allow two or three per CU) — the kernel strides over
+// its work list by gridDim.x, so a grid that needs a second scheduling round would leave the first round's workgroups idle for half the time
+static int list_grid() {
+    static int grid = 0;
+    if (!grid) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stft512_f64_list_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        grid = per_cu * prop.multiProcessorCount;
+    }
+    return grid;
+}
+
 void launch_stft512_f64(const StftTables& tb, const float* audio, int B, int T, int hop, int W, float* spec, float* minmax, hipStream_t s,
                         bool tile_major) {
     const int n_tiles = (W + kFT - 1) / kFT;
@@ -329,7 +377,7 @@ void launch_stft_minmax_exact(const StftTables& tb, const float* audio, int B, i
     hipLaunchKernelGGL(stft_minmax_exact_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tb, audio, T, hop, W, spec, tile_major ? 1 : 0, g,
                        (W + kFT - 1) / kFT, minmax, B);  // (the caller keeps W <= 1024: one lane per tile record)
     // chunks the wave gave up on (none for ordinary audio: the 256 workgroups read the count and leave)
-    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(kListGrid), dim3(256), 0, s, tb, audio, T, hop, W, spec, minmax, tile_major ? 1 : 0, g.hard, g.n_hard,
+    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(list_grid()), dim3(256), 0, s, tb, audio, T, hop, W, spec, minmax, tile_major ? 1 : 0, g.hard, g.n_hard,
                        g.eps);
 }
 
@@ -341,7 +389,7 @@ void launch_stft_fix(const StftTables& tb, const float* audio, int B, int T, int
     // chunks a workgroup of the mel mixer gave up on (it listed them itself): whole float64 spectrograms; the caller then runs the mixer's
     // work-list form over their blocks
     // (minmax is exact already: the atomics of this pass find the same values)
-    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(kListGrid), dim3(256), 0, s, tb, audio, T, hop, W, spec, const_cast<float*>(minmax), tile_major ? 1 : 0,
+    hipLaunchKernelGGL(stft512_f64_list_kernel, dim3(list_grid()), dim3(256), 0, s, tb, audio, T, hop, W, spec, const_cast<float*>(minmax), tile_major ? 1 : 0,
                        g.hard + g.hard_cap, g.n_hard + 1, (float*)nullptr);
 }
 
