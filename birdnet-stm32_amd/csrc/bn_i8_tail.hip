@@ -39,6 +39,18 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
+// BN_TAIL_STAMPS (tools/tail_stamps.py builds lib/libbirdnet_hip_stamps.so with it; never defined in the production library): every wave
+// of the first workgroups records, per block, when it entered, finished staging, left the staging barrier, how long its depthwise and
+// pointwise phases took, and when it left the end barrier (s_memrealtime: 100 MHz) — the attribution of the kernel's parked cycles.
+#ifdef BN_TAIL_STAMPS
+__device__ long long* g_tail_stamps = nullptr;   // [workgroup < 8][group < 4][block < 8][wave 16][6]
+constexpr int kStampWg = 8, kStampGrp = 4;
+__device__ __forceinline__ long long now_ticks() { return (long long)__builtin_amdgcn_s_memrealtime(); }
+#define BN_STAMP(var) const long long var = now_ticks()
+#else
+#define BN_STAMP(var) do {} while (0)
+#endif
+
 __device__ __forceinline__ int perm(int s0, int s1, uint32_t sel) { return (int)__builtin_amdgcn_perm((uint32_t)s0, (uint32_t)s1, sel); }
 __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 __device__ __forceinline__ int med3(int v, int lo, int hi) {
@@ -90,7 +102,8 @@ __device__ __forceinline__ int pq_base(int kq) {
 // The geometry is a template parameter (H x W input map, stride S): positions turn into shifts and the padding tests into
 // comparisons with constants; tail_plan() only accepts the four shapes instantiated below.
 template <int CIN, int COUT, int S, int H, int W, bool ADD, bool SRCG>
-__device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args& a, unsigned char* lds, int chunk0) {
+__device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args& a, unsigned char* lds, int chunk0, int stamp_slot = -1) {
+    BN_STAMP(st0);
     constexpr int KS = CIN / 64;        // k-steps of v_mfma_i32_16x16x64_i8
     constexpr int NTILES = COUT / 16;
     constexpr int PIN = CIN + 4, POUT = COUT + 4;
@@ -130,7 +143,12 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
         if (ADD && tid < 128) reinterpret_cast<v4i*>(lds + L.lut_off)[tid] = g[L.g_lut / 4 + tid];
         if (!SRCG && tid < PIN / 4) reinterpret_cast<int*>(lds + L.zp_off)[tid] = (L.zp_in & 0xff) * 0x01010101;
     }
+    BN_STAMP(st1);
     __syncthreads();
+    BN_STAMP(st2);
+#ifdef BN_TAIL_STAMPS
+    long long t_dw = 0, t_pw = 0;
+#endif
 
     const int zp4 = (L.zp_in & 0xff) * 0x01010101;
     const int qb = pq_base<CIN>(kq);
@@ -179,6 +197,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
             const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * H * W * CIN : 0), 0, SRCG ? H * W * CIN : 0, 0x00020000);
 
         // ---- depthwise 3x3 for all CIN channels of this lane's position(s) -> B fragments -------------------------------------
+        BN_STAMP(sa);
         v4i bf[UPW][KS];
         // Two tiles of a wave at stride 1 on a 16-wide map are two vertically adjacent output rows of one chunk (u0 is even, a chunk has
         // an even number of rows): they share two of their three input rows.  Four rows of taps are read and byte-transposed once for
@@ -271,6 +290,10 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 
         // ---- pointwise 1x1 on the matrix cores, requantise, [ADD], store into the next map ------------------------------------
         // accumulator rows 4 kq .. 4 kq + 3 of tile nt = output channels 16 nt + 4 kq ..; the tiles of a wave share the channel group
+#ifdef BN_TAIL_STAMPS
+        asm volatile("" :: "v"(bf[0][0]) : "memory");  // (the stamp sits behind the depthwise results, not in front of them)
+#endif
+        BN_STAMP(sb);
         for (int tt = 0; tt < NT_PER; ++tt) {
             const int nt = grp[0] * NT_PER + tt;
             const v4i* pc4 = pwc + nt * 20;
@@ -308,8 +331,22 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
                 *reinterpret_cast<int*>(lds + yrow + 16 * nt) = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
             }
         }
+#ifdef BN_TAIL_STAMPS
+        asm volatile("" ::: "memory");
+        const long long sc = now_ticks();
+        t_dw += sb - sa;
+        t_pw += sc - sb;
+#endif
     }
+    BN_STAMP(st4);
     __syncthreads();
+#ifdef BN_TAIL_STAMPS
+    if (stamp_slot >= 0 && g_tail_stamps && (threadIdx.x & 63) == 0) {
+        long long* o = g_tail_stamps + ((size_t)stamp_slot * kTailWaves + (threadIdx.x >> 6)) * 6;
+        const long long st5 = now_ticks();
+        o[0] = st1 - st0; o[1] = st2 - st1; o[2] = t_dw; o[3] = t_pw; o[4] = st5 - st4; o[5] = st5 - st0;
+    }
+#endif
 }
 
 // MEAN + FULLY_CONNECTED + head for the workgroup's chunks.  (As a real function call it costs a stack copy of the arguments: 1168 B of
@@ -318,8 +355,23 @@ __device__ __forceinline__ void tail_head(const Tail8Args& a, unsigned char* lds
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // keeps this part's index arithmetic from being hoisted to the top of the kernel and held in registers across
                                    // the blocks, which run at the 128-register cap of a 16-wave workgroup (it was what spilled)
-    // ---- MEAN over the positions of the last map: one thread per (chunk slot, channel) ---------------------------------------
+    // The classifier matrix (NC x C bytes: 25.6 KB) comes into LDS for the four chunks of the group: as 64 dependent dword loads per
+    // (chunk, class) thread, 256 bytes apart between neighbouring threads, the head took 15 % of a group's time with 60 % of the threads idle.
+    // Requested here (coalesced 16-byte loads, one round trip for the whole workgroup), written behind the MEAN; it overlays the last
+    // block's pointwise weights, which nobody reads any more (the block's end barrier is behind us).  Rows of C / 4 + 1 dwords: thread j
+    // walks row j, so neighbouring threads sit on neighbouring banks.
     const Tail8Layer& L = a.L[a.n_layers - 1];
+    const int c16 = a.C / 16, n_w16 = a.NC * c16, pitchw = a.C / 4 + 1;
+    v4i wreg[4];
+    if (a.fcw_off >= 0) {
+        const v4i* gw = reinterpret_cast<const v4i*>(a.cst + a.g_fcw);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * kTailThreads;
+            wreg[u] = i < n_w16 ? gw[i] : (v4i){0, 0, 0, 0};
+        }
+    }
+    // ---- MEAN over the positions of the last map: one thread per (chunk slot, channel) ---------------------------------------
     const int pitch = a.C + 4;
     for (int i = tid; i < kTailG * a.C; i += kTailThreads) {
         const int g = i / a.C, c = i - g * a.C;
@@ -328,6 +380,17 @@ __device__ __forceinline__ void tail_head(const Tail8Args& a, unsigned char* lds
         for (int k = 0; k < a.P; ++k) s += src[k * pitch];
         reinterpret_cast<int8_t*>(lds + a.mean_off)[i] = (int8_t)mean_q(s, a.P, a.mean_zp_in, a.mean_mult, a.mean_shift, a.mean_zp_out);
     }
+    if (a.fcw_off >= 0) {
+        int* wl = reinterpret_cast<int*>(lds + a.fcw_off);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * kTailThreads;
+            if (i < n_w16) {
+                int* d = wl + (i / c16) * pitchw + 4 * (i % c16);
+                d[0] = wreg[u].x; d[1] = wreg[u].y; d[2] = wreg[u].z; d[3] = wreg[u].w;
+            }
+        }
+    }
     __syncthreads();
     // ---- FULLY_CONNECTED + head: one thread per (chunk slot, class) ----------------------------------------------------------
     for (int i = tid; i < kTailG * a.NC; i += kTailThreads) {
@@ -335,7 +398,7 @@ __device__ __forceinline__ void tail_head(const Tail8Args& a, unsigned char* lds
         const int chunk = chunk0 + g;
         if (chunk >= a.B) continue;
         const int* xr = reinterpret_cast<const int*>(lds + a.mean_off + g * a.C);
-        const int* wr = a.cst + a.g_fcw + j * (a.C / 4);
+        const int* wr = a.fcw_off >= 0 ? reinterpret_cast<const int*>(lds + a.fcw_off) + j * pitchw : a.cst + a.g_fcw + j * (a.C / 4);
         int acc = a.cst[a.g_fcb + j];
         for (int k = 0; k < a.C / 4; ++k) acc = dot4(xr[k], wr[k], acc);
         const int qv = clampi(mbqm(acc, a.cst[a.g_fcm + j], a.cst[a.g_fcs + j]) + a.fc_zp_out, a.fc_lo, a.fc_hi);
@@ -357,10 +420,15 @@ __global__ __launch_bounds__(kTailThreads) void i8_tail_kernel(Tail8Args a) {
         const int chunk0 = grp * kTailG;
         for (int li = 0; li < a.n_layers; ++li) {
             const Tail8Layer& L = a.L[li];
-            if (L.Cin == 64) tail_block<64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0);
-            else if (L.Cin == 128 && L.Cout == 128) tail_block<128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0);
-            else if (L.Cin == 128) tail_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0);
-            else tail_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0);
+            int slot = -1;
+#ifdef BN_TAIL_STAMPS
+            const int gi = (grp - (int)blockIdx.x) / (int)gridDim.x;
+            if ((int)blockIdx.x < kStampWg && gi < kStampGrp && li < 8) slot = ((int)blockIdx.x * kStampGrp + gi) * 8 + li;
+#endif
+            if (L.Cin == 64) tail_block<64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0, slot);
+            else if (L.Cin == 128 && L.Cout == 128) tail_block<128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0, slot);
+            else if (L.Cin == 128) tail_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0, slot);
+            else tail_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0, slot);
         }
         tail_head(a, lds, chunk0);
         __syncthreads();  // the next group overwrites the maps
@@ -451,6 +519,9 @@ bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a) {
     if (a.fc_lo < -128 || a.fc_hi > 127 || a.fc_lo > a.fc_hi) return false;  // (the classifier byte + 128 indexes the head's table)
     const Tail8Layer& last = a.L[n_layers - 1];
     if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 4 || a.NC < 1 || kTailG * a.NC > kTailThreads * 4) return false;
+    // the head's LDS copy of the classifier matrix overlays the last block's pointwise weights (4 x 1024 threads x 16 bytes are staged at most)
+    const int fc_bytes = a.NC * (a.C / 4 + 1) * 4;
+    a.fcw_off = (a.C % 16 == 0 && fc_bytes <= last.Cin * last.Cout && a.NC * (a.C / 16) <= 4 * kTailThreads) ? last.w_off : -1;
     a.lds_bytes = lds_need;
     return true;
 }
@@ -474,7 +545,15 @@ long tail_const_words(const Tail8Args& a) {
     return need;
 }
 
+#ifdef BN_TAIL_STAMPS
+// debug export of the stamps build only: where the kernel writes its stamps ([8][4][8][16][6] int64, zeroed by the caller)
+extern "C" __attribute__((visibility("default"))) int bn_debug_tail_stamps(long long* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamps), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
+}
+#endif
+
 bool launch_i8_tail(Tail8Args a, hipStream_t s) {
+    if (!g_opt.i8_tail_fclds) a.fcw_off = -1;
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(i8_tail_kernel), 160 * 1024)) return false;
     const int ngroups = (a.B + kTailG - 1) / kTailG;
     int cus = 256;

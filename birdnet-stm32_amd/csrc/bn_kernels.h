@@ -34,6 +34,7 @@ struct Options {
                                // (integer sums, order-free: bit-identical); 0: i8_segate_kernel reads the whole map again
     int i8_pw_lds = 1;         // dense 1x1 convolutions (Cin 192 / 384 / 768) of exported INT8 graphs through i8_pw_lds_kernel (bn_i8_pw.hip): weights of a
                                // slice of output channels resident in LDS, squeeze-excite MUL applied on load (0: tile kernel + i8_scale)
+    int i8_tail_fclds = 1;     // the fused tail's head reads the classifier matrix from an LDS copy (0: from memory, 64 dependent loads per thread)
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
     int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
@@ -359,6 +360,7 @@ struct Tail8Args {
     int fc_zp_out, fc_lo, fc_hi, g_fcw, g_fcb, g_fcm, g_fcs, g_hlut, head_zp_fc, head_zp_out;
     float s_fc, s_head;
     int lds_bytes;
+    int fcw_off;          // LDS copy of the classifier matrix for the head, rows of C / 4 + 1 dwords (-1: read it from memory); overlays the last block's weights
     Tail8Layer L[8];
 };
 bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a);  // a.NC must be set; false = not a topology / size the kernel takes
