@@ -111,6 +111,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
     constexpr int TILES = kTailG * PER_CHUNK / 16;
     constexpr int NGRP = TILES >= kTailWaves ? 1 : kTailWaves / TILES;  // few tiles: split them over groups of output channels
     constexpr int NT_PER = NTILES / NGRP;
+    constexpr int kSkewBit = CIN == 64 ? 2 : 4;  // the bit of a quad's index that tells lane group kq from kq ^ 1 (pq_base)
     constexpr int PT = S == 1 ? 1 : 0, PL = PT;  // TF SAME padding of a 3x3 window on even maps: 1 / 1 at stride 1, 0 / 1 at stride 2
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -129,7 +130,9 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
             if (i * kTailThreads + tid < CIN * COUT / 16) dst[i * kTailThreads + tid] = g[L.g_w / 4 + i * kTailThreads + tid];
         if (tid < CIN / 4) {   // per channel quad: three weight rows, bias, then the requantisation constants in rq_hi form (8 x 16 bytes)
             const v4i* q = g + L.g_dwc / 4 + tid * 7;
-            v4i* d = reinterpret_cast<v4i*>(lds + L.dwc_off) + tid * 8;
+            // (one more 16-byte slot of skew per lane group's run of quads: the lanes of kq and kq ^ 1 share a ds_read_b128 group and their
+            // quads lie a multiple of 256 bytes apart — without it every read of these constants is a 2-way bank conflict)
+            v4i* d = reinterpret_cast<v4i*>(lds + L.dwc_off) + tid * 8 + (tid >> kSkewBit);
             d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3];
             stage_rq(d + 4, q[4], q[5], q[6]);
         }
@@ -152,7 +155,7 @@ __device__ __forceinline__ void tail_block(const Tail8Layer& L, const Tail8Args&
 
     const int zp4 = (L.zp_in & 0xff) * 0x01010101;
     const int qb = pq_base<CIN>(kq);
-    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.dwc_off) + qb * 8;
+    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.dwc_off) + qb * 8 + (qb >> kSkewBit);
     const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.pwc_off) + kq * 5;
     const int* lut = reinterpret_cast<const int*>(lds + L.lut_off);
     const v4i* wl = reinterpret_cast<const v4i*>(lds + L.w_off) + lane;
@@ -499,7 +502,7 @@ bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a) {
         if (cur_off >= 0) used.push_back({cur_off, cur_off + kTailG * L.H * L.W * (L.Cin + 4)});
         L.y_off = first_fit(used, kTailG * L.OH * L.OW * (L.Cout + 4), CAP);
         L.w_off = first_fit(used, L.Cin * L.Cout, CAP);
-        L.dwc_off = first_fit(used, L.Cin * 32, CAP);   // staged in rq_hi form: 8 x 16 bytes per channel quad,
+        L.dwc_off = first_fit(used, L.Cin * 32 + 64, CAP);   // staged in rq_hi form: 8 x 16 bytes per channel quad (+ up to four slots of skew),
         L.pwc_off = first_fit(used, L.Cout * 20, CAP);  // 5 x 16 bytes per four output channels
         L.lut_off = L.has_add ? first_fit(used, 2048, CAP) : 0;
         L.zp_off = first_fit(used, L.Cin + 16, CAP);
