@@ -59,6 +59,39 @@ from birdnet_stm32.audio.pipeline import balanced_bounds  # noqa: E402
 
 sc, cnt = sharding.score_files_sharded(40, score_files, 100, device=dev, bounds=balanced_bounds(per_file, world))
 assert cnt == per_file and torch.equal(sc, direct[: starts[-1]])
+# evaluate() itself through its sharded branch (chunk-balanced file blocks, pipeline per rank, ragged all-gather over RCCL, pooling of all files on every
+# rank) against the same call without a process group in the picture
+import tempfile  # noqa: E402
+
+from birdnet_stm32.audio.io import save_wav  # noqa: E402
+from birdnet_stm32.evaluation.metrics import evaluate  # noqa: E402
+from birdnet_stm32.training.config import ModelConfig  # noqa: E402
+from conftest import CONFIG_PATH  # noqa: E402
+
+cfg = ModelConfig.load(CONFIG_PATH).to_dict()
+cfg.update(sample_rate=24000, hop_length=281)
+classes = cfg["class_names"]
+root = tempfile.mkdtemp() if rank == 0 else None
+box = [root]
+dist.broadcast_object_list(box, src=0)
+root = box[0]
+wav = synth_chunks(12, seed=3)
+files = []
+for i in range(12):
+    d = os.path.join(root, classes[i % 3])
+    os.makedirs(d, exist_ok=True)
+    p = os.path.join(d, f"f{i}.wav")
+    if rank == 0:
+        save_wav(np.concatenate([wav[i]] * (1 + i % 4))[: 72000 * (1 + i % 4) - 5000 * (i % 2)], p, 24000)
+    files.append(p)
+dist.barrier()
+sharding.COLLECTIVE_AT_WORLD_1 = False
+_, pf_a, _, ys_a = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=8) if world == 1 else (None, None, None, None)
+sharding.COLLECTIVE_AT_WORLD_1 = True
+_, pf_b, _, ys_b = evaluate(runner, files, classes, cfg, pooling="avg", batch_size=8)
+assert len(pf_b) == 12
+if world == 1:
+    assert [p["file"] for p in pf_a] == [p["file"] for p in pf_b] and np.array_equal(ys_a, ys_b), "sharded evaluate differs from the single-process one"
 torch.cuda.synchronize()
 if rank == 0:
     ver = torch.cuda.nccl.version()
