@@ -102,20 +102,24 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const F64Regs& R, const floa
     __syncthreads();  // cs staged; the previous tile's reduction scratch read
     double2* A = L.buf[wave][0];
     double2* Bf = L.buf[wave][1];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
     const double2 (&win)[4] = R.win;
     const double2 (&tw)[3][3] = R.tw;
     const double2 (&tws)[5] = R.tws;
     for (int ff = wave; ff < kFT && t0 + ff < W; ff += 4) {
         const int t = t0 + ff;
         const long base = (long)t * hop - 256;
+        // range-checked raw buffer loads over exactly this chunk: samples before / behind it read as 0 (librosa's centre padding), no selects,
+        // all eight loads of the lane in flight together
+        float xs[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = lane + 64 * i;
-            const long p0 = base + 2 * n;
-            const float x0 = (p0 >= 0 && p0 < T) ? x[p0] : 0.0f;
-            const float x1 = (p0 + 1 >= 0 && p0 + 1 < T) ? x[p0 + 1] : 0.0f;
-            A[fslot(n)] = make_double2((double)x0 * win[i].x, (double)x1 * win[i].y);
+            const int off = (int)((base + 2 * (lane + 64 * i)) * 4);
+            xs[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+            xs[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[fslot(lane + 64 * i)] = make_double2((double)xs[i][0] * win[i].x, (double)xs[i][1] * win[i].y);
         wave_lds_sync();
         double2* src = A;
         double2* dst = Bf;
@@ -177,7 +181,7 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const F64Regs& R, const floa
     }
 }
 
-__global__ __launch_bounds__(256) void stft512_f64_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
+__global__ __launch_bounds__(256, 3) void stft512_f64_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
                                                           float* __restrict__ spec, float* minmax, int tile_major) {
     __shared__ F64Lds L;
     for (int i = threadIdx.x; i < 512; i += 256) L.cs[i] = tb.cs64[i];
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void stft512_f64_kernel(StftTables tb, const f
 
 // The chunks of a list (those the guarded pass gives up on: flat spectra, pure tones, signals far below the error bound — more
 // elements in doubt than is worth recomputing one by one) as whole float64 spectrograms; their frames' bounds become 0 = exact.
-__global__ __launch_bounds__(256) void stft512_f64_list_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
+__global__ __launch_bounds__(256, 3) void stft512_f64_list_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
                                                                float* __restrict__ spec, float* minmax, int tile_major, const int* __restrict__ list,
                                                                const int* __restrict__ n_list, float* __restrict__ eps) {
     __shared__ F64Lds L;
