@@ -166,12 +166,12 @@ __global__ __launch_bounds__(256) void f32_rawfe_kernel(const float* __restrict_
     if (t >= W) return;
     const float* xin = x + (size_t)b * T;
     const int s0 = t * stride - pad_left;
+    // range-checked raw buffer loads over this chunk: samples of the symmetric zero pad (before / behind the waveform) read as 0, no branch
+    // around any of the sixteen loads
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, T * 4, 0x00020000);
     float v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int g = s0 + k;
-        v[k] = (g >= 0 && g < T) ? xin[g] : 0.0f;
-    }
+    for (int k = 0; k < 16; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (s0 + k) * 4, 0, 0));
     float* o = out + (size_t)b * M * W + t;
     for (int m = 0; m < M; ++m) {
         const float4* wr = reinterpret_cast<const float4*>(fbt + 16 * m);

@@ -881,14 +881,19 @@ __global__ __launch_bounds__(640) void f32_pwdw_kernel(F32PwDwArgs a) {
         v4f sbias[NJS];
         const bool stem = STEM_OK && a.fe != nullptr;
         const ActBounds st_bounds = act_bounds(a.stem_act);
-        const float* fmap = stem ? a.fe + (size_t)chunk * a.H0 * a.W0 : nullptr;
+        // taps through a range-checked raw buffer over this chunk's map: a tap outside it (SAME padding, rows the strip does not need, lane
+        // group 3) gets an offset behind the buffer's end and reads as 0 — no branch around the load, all six in flight (as conditional
+        // loads `ok ? fmap[i] : 0` they ran one round trip at a time)
+        const __amdgpu_buffer_rsrc_t rs_fe = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(stem ? a.fe + (size_t)chunk * a.H0 * a.W0 : a.pw_b), 0, stem ? a.H0 * a.W0 * 4 : 0, 0x00020000);
         auto taps = [&](float (&v)[2][3], int k) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const int ih = (h_lo + k) * a.ssh - a.spt + i, iw = (32 * pp + 16 * u + n) * a.ssw - a.spl + kq;
-                    v[u][i] = (row_ok(k) && kq < 3 && ih >= 0 && ih < a.H0 && iw >= 0 && iw < a.W0) ? fmap[ih * a.W0 + iw] : 0.0f;
+                    const bool ok = row_ok(k) && kq < 3 && ih >= 0 && ih < a.H0 && iw >= 0 && iw < a.W0;
+                    v[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_fe, ok ? (ih * a.W0 + iw) * 4 : 0x7ffffff0, 0, 0));
                 }
         };
         if (stem) {

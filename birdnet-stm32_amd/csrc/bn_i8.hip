@@ -309,14 +309,13 @@ __global__ __launch_bounds__(256) void i8_mean_kernel(const int8_t* __restrict__
     const int q = tid % cq, sl = tid / cq;
     int acc[4] = {0, 0, 0, 0};
     if (sl < slices) {
-        const int32_t* row = reinterpret_cast<const int32_t*>(x + (size_t)b * P * C) + q;
-        for (int i0 = sl; i0 < P; i0 += 8 * slices) {  // eight loads in flight per thread: one workgroup per chunk has to cover the latency itself
+        // range-checked raw buffer loads over this chunk's map: a position beyond P lies behind the buffer and reads as 0 (adds nothing) — no
+        // branch around the loads, so the eight really are in flight together (one workgroup per chunk has to cover the latency itself)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x) + (size_t)b * P * C, 0, P * C, 0x00020000);
+        for (int i0 = sl; i0 < P; i0 += 8 * slices) {
             int32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * slices;
-                v[u] = i < P ? row[(size_t)i * cq] : 0;
-            }
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, ((i0 + u * slices) * cq + q) * 4, 0, 0);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -394,21 +393,17 @@ __global__ __launch_bounds__(256) void i8_segate_kernel(SeGate8Args a) {
         }
         __syncthreads();
     } else {
-        const int32_t* row0 = reinterpret_cast<const int32_t*>(a.x + (size_t)b * P * C);
         for (int q0 = 0; q0 < cq; q0 += 256) {  // channel quads beyond 256 go round again
             const int nq = cq - q0 < 256 ? cq - q0 : 256;
             const int slices = 256 / nq;
             const int q = tid % nq, sl = tid / nq;
             int acc[4] = {0, 0, 0, 0};
             if (sl < slices) {
-                const int32_t* row = row0 + q0 + q;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x) + (size_t)b * P * C, 0, P * C, 0x00020000);
                 for (int i0 = sl; i0 < P; i0 += 8 * slices) {
                     int32_t v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = i0 + u * slices;
-                        v[u] = i < P ? row[(size_t)i * cq] : 0;
-                    }
+                    for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, ((i0 + u * slices) * cq + q0 + q) * 4, 0, 0);
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
 #pragma unroll
