@@ -46,7 +46,7 @@ struct OptName {
 };
 const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
-    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"front_tpw", &bn::Options::front_tpw},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"i8_pw_forms", &bn::Options::i8_pw_forms}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
@@ -898,7 +898,14 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             }
             m->rq_right[oi] = (ok ? 1 : 0) | (narrow ? 2 : 0) | (pw_ok ? 4 : 0);
         } else if (o.kind == BN_OP_I8_DW || o.kind == BN_OP_I8_STEM) {
-            m->rq_right[oi] = all_right(o.t[2], o.t[3]);
+            // bit 0: multipliers >= 0, right shifts; bit 1: every shift >= -20 (the 64-bit addend of the one-multiply-add form cannot overflow)
+            bool narrow = o.t[3] >= 0;
+            if (narrow) {
+                const TensorRec& ts = m->tensors[o.t[3]];
+                const int32_t* ps = (const int32_t*)(base + ts.offset);
+                for (size_t i = 0; i < ts.nbytes / 4; ++i) narrow = narrow && ps[i] >= -20;
+            }
+            m->rq_right[oi] = (all_right(o.t[2], o.t[3]) ? 1 : 0) | (narrow ? 2 : 0);
         } else if (o.kind == BN_OP_I8_FRONT) {
             m->rq_right[oi] = all_right(o.t[2], o.t[3]) && all_right(o.t[6], o.t[7]) && all_right(o.t[10], o.t[11]);
         }

@@ -37,6 +37,12 @@ __device__ __forceinline__ int32_t sx8(int32_t v, int byte) { return (int32_t)(i
 __device__ __forceinline__ int32_t lane_byte(int32_t w, int e) { return w & (0xff << (8 * e)); }
 __device__ __forceinline__ int32_t dot4(int32_t a, int32_t b, int32_t c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 
+// the low bytes of four values as one dword (three v_perm_b32)
+__device__ __forceinline__ int pack4(const int (&q)[4]) {
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[1], (uint32_t)q[0], 0x0c0c0400u), hi = __builtin_amdgcn_perm((uint32_t)q[3], (uint32_t)q[2], 0x0c0c0400u);
+    return (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 // 4 x 4 byte transpose: rows r0..r3 hold four channels of one tap each; c[e] gets channel e of the four taps.
 // v_perm_b32 picks bytes out of the 8-byte value {s0 (bytes 4-7), s1 (bytes 0-3)}.
 __device__ __forceinline__ void transpose4x4(int r0, int r1, int r2, int r3, int c[4]) {
@@ -729,19 +735,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 // meet zero weights), the weight fragments the packer already writes for the tile kernel are the A operand, so the accumulators of
 // lane (r, q) are the four CONSECUTIVE output channels 16 ct + 4 q .. of position r: requantise, [ADD], one dword store per tile.
 // Per-channel constants are staged in LDS once per workgroup.
-template <bool ADD, int NCT, int KS>  // NCT > 0: the tile / k-step counts are compile-time constants and the weight fragments live in registers
+// MODE picks the requantisation forms at compile time (the launcher checks the conditions; all three are bit-identical where they apply):
+//   0  any multiplier / shift, any gate (runtime-uniform choices);
+//   1  linear layers (projections): every multiplier >= 0 and every shift < 0 — mbqm_right; the ADD's output rescale likewise; a gate, if
+//      present, has both zero points -128 and a right shift 1..20 (one multiply-add per byte);
+//   2  ReLU layers (expansions; no ADD): the clamp starts at the zero point and every shift lies in [-20, -1] — the sign-free
+//      clamp(hi32(acc m + C) >> (e - 1)) of i8_pw_lds_kernel, three instructions per output; gate as in 1.
+template <bool ADD, int NCT, int KS, int MODE>  // NCT > 0: the tile / k-step counts are compile-time constants and the weight fragments live in registers
 __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos, int lds_w16) {
     constexpr bool AREG = NCT > 0;
+    constexpr int CW = MODE == 2 ? 5 : 3;  // v4i per channel quad: bias, multiplier, shift [, addend low, addend high]
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-    v4i* cst = reinterpret_cast<v4i*>(lds_raw);  // [Cout / 4][bias, multiplier, shift]
+    v4i* cst = reinterpret_cast<v4i*>(lds_raw);  // [Cout / 4][CW]
     __shared__ int add_lut[2][256];
     const int tid = threadIdx.x;
     const int K = a.Cin, N = a.Cout;
     const bool rq = (a.rq_right & 1) != 0;
     for (int i = tid; i < N / 4; i += 256) {
-        cst[3 * i + 0] = *reinterpret_cast<const v4i*>(a.pw_b + 4 * i);
-        cst[3 * i + 1] = *reinterpret_cast<const v4i*>(a.pw_mult + 4 * i);
-        cst[3 * i + 2] = *reinterpret_cast<const v4i*>(a.pw_shift + 4 * i);
+        cst[CW * i + 0] = *reinterpret_cast<const v4i*>(a.pw_b + 4 * i);
+        cst[CW * i + 1] = *reinterpret_cast<const v4i*>(a.pw_mult + 4 * i);
+        v4i ss = *reinterpret_cast<const v4i*>(a.pw_shift + 4 * i);
+        if constexpr (MODE == 2) {
+            v4i clo, chi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ex = -ss[e];  // 1 .. 20 (checked at load)
+                const long long C = (1ll << 30) + (((1ll << (ex - 1)) + (long long)a.pw_zp_out * (1ll << ex)) << 31);
+                clo[e] = (int)(unsigned)(C & 0xffffffffll);
+                chi[e] = (int)(C >> 32);
+                ss[e] = ex - 1;
+            }
+            cst[CW * i + 3] = clo;
+            cst[CW * i + 4] = chi;
+        }
+        cst[CW * i + 2] = ss;
     }
     if (ADD) {
         const int v = (int)(int8_t)tid;
@@ -750,7 +777,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     }
     // layers with more fragments than registers: the whole weight matrix (fragment order, up to 48 KB) is staged in LDS once per
     // workgroup when the launcher made room for it — a 16-byte LDS read per tile and k-step instead of a trip to L1 / L2
-    v4i* wl = cst + 3 * (N / 4);
+    v4i* wl = cst + CW * (N / 4);
     const bool w_in_lds = !AREG && lds_w16 > 0;
     if (w_in_lds)
         for (int i = tid; i < lds_w16; i += 256) wl[i] = reinterpret_cast<const v4i*>(a.pw_w)[i];
@@ -790,7 +817,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     }
     const int P = a.OH * a.OW;
     const bool g_right = a.g_mult >= 0 && a.g_shift < 0;  // (uniform) the gate's MUL requantises with a plain right shift: branch-free form
-    const bool g_fast = a.gate && a.g_zx == -128 && a.g_zg == -128 && a.g_mult >= 0 && a.g_shift <= -1 && a.g_shift >= -20;
+    const bool g_fast = MODE != 0 || (a.gate && a.g_zx == -128 && a.g_zg == -128 && a.g_mult >= 0 && a.g_shift <= -1 && a.g_shift >= -20);
     const int ge = g_fast ? -a.g_shift : 1, gsh = ge - 1;
     const long long gC = (1ll << 30) + (((1ll << (ge - 1)) + (long long)a.g_zo * (1ll << ge)) << 31);
     for (; grp < n_groups; grp += stride) {
@@ -809,16 +836,18 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     int packed = 0;
-                    if (g_fast) {
+                    if (MODE != 0 || g_fast) {
                         // both zero points -128: (x + 128)(g + 128) >= 0, no sign term, and the requantisation with the output zero point folded in
                         // is the high dword of one multiply-add (bn_i8_pw.hip) — 5 instead of 12 instructions per byte
                         const unsigned xu = (unsigned)bfr[s][d] ^ 0x80808080u, gu = (unsigned)gv[d] ^ 0x80808080u;
+                        int gq[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int p = (int)((xu >> (8 * e)) & 0xff) * (int)((gu >> (8 * e)) & 0xff);
-                            packed |= (clampi((int)(((long long)p * a.g_mult + gC) >> 32) >> gsh, a.g_amin, a.g_amax) & 0xff) << (8 * e);
+                            gq[e] = clampi((int)(((long long)p * a.g_mult + gC) >> 32) >> gsh, a.g_amin, a.g_amax);
                         }
-                    } else {
+                        packed = pack4(gq);
+                    } else if constexpr (MODE == 0) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int xv = (int)(int8_t)(bfr[s][d] >> (8 * e)) - a.g_zx, g = (int)(int8_t)(gv[d] >> (8 * e)) - a.g_zg;
@@ -847,7 +876,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
             if (ct >= n_ct) break;
             const int ch = ch_r + 4 * ct;
             const int cidx = ((cpl * q) >> 2) + ct;  // constants of the lane's four channels (N / 4) q + 4 ct ..
-            v4i acc = cst[cidx * 3 + 0];
+            v4i acc = cst[cidx * CW + 0];
             if constexpr (AREG) {
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[ct * KS + s_], bfr[s_], acc, 0, 0, 0);
@@ -857,21 +886,45 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
                 for (int s = 0; s < 4; ++s)
                     if (s < ksteps) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wsrc[((size_t)s * n_ct + (ch >> 4)) * 64 + q * 16 + (ch & 15)], bfr[s], acc, 0, 0, 0);
             }
-            const v4i m = cst[cidx * 3 + 1], sh = cst[cidx * 3 + 2];
+            const v4i m = cst[cidx * CW + 1], sh = cst[cidx * CW + 2];
             int rv = 0;
             if (ADD) rv = *reinterpret_cast<const int*>(rrow + 4 * ct);
-            int packed = 0;
+            if constexpr (MODE == 0) {
+                int packed = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int qv = clampi(mbqm_u(acc[e], m[e], sh[e], rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
-                if (ADD) {
-                    const int sa = add_lut[0][(rv >> (8 * e)) & 0xff];
-                    const int sb = add_lut[1][qv & 0xff];
-                    qv = clampi(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);
+                for (int e = 0; e < 4; ++e) {
+                    int qv = clampi(mbqm_u(acc[e], m[e], sh[e], rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                    if (ADD) {
+                        const int sa = add_lut[0][(rv >> (8 * e)) & 0xff];
+                        const int sb = add_lut[1][qv & 0xff];
+                        qv = clampi(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);
+                    }
+                    packed |= (qv & 0xff) << (8 * e);
                 }
-                packed |= (qv & 0xff) << (8 * e);
+                outw[u] = packed;
+            } else {
+                int qv[4];
+                if constexpr (MODE == 2) {
+                    const v4i clo = cst[cidx * CW + 3], chi = cst[cidx * CW + 4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const long long C = (long long)(((unsigned long long)(unsigned)chi[e] << 32) | (unsigned)clo[e]);
+                        qv[e] = clampi((int)(((long long)acc[e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qv[e] = clampi(mbqm_right(acc[e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                }
+                if (ADD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int sa = add_lut[0][(rv >> (8 * e)) & 0xff];
+                        const int sb = add_lut[1][qv[e] & 0xff];
+                        qv[e] = clampi(mbqm_right(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);
+                    }
+                }
+                outw[u] = pack4(qv);
             }
-            outw[u] = packed;
             if constexpr (AREG) asm volatile("" : "+v"(outw[u]) :: "memory");  // one tile at a time: the unrolled tiles must not all be in flight (288 registers)
         }
         const int left = n_ct - ct0;
@@ -901,24 +954,39 @@ void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {
     const long cap = (long)256 * ((a.Cout / 16) * ((a.Cin + 63) / 64) > 6 ? 6 : 16);  // persistent; fewer workgroups where each stages the weights
     const unsigned blocks = (unsigned)(wanted < cap ? wanted : cap);
     const int nct = a.Cout / 16, ks = (a.Cin + 63) / 64;
-    const size_t smem = (size_t)a.Cout * 12;
     size_t w_bytes = (size_t)ks * 64 * a.Cout;  // the fragment-ordered weight matrix
     if (w_bytes > 48 * 1024) w_bytes = 0;
-#define BN_PWW(ADDV, NCTV, KSV) hipLaunchKernelGGL((i8_pw_wave_kernel<ADDV, NCTV, KSV>), dim3(blocks), dim3(256), smem + (NCTV ? 0 : w_bytes), s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16))
-#define BN_PWW2(NCTV, KSV)                    \
-    if (nct == NCTV && ks == KSV) {           \
-        if (a.add.enabled) BN_PWW(true, NCTV, KSV); \
-        else BN_PWW(false, NCTV, KSV);        \
-        return;                               \
+    // requantisation forms (see the kernel's MODE): a gate must have the one-multiply-add form for modes 1 and 2
+    const bool gate_fast = !a.gate || (a.g_zx == -128 && a.g_zg == -128 && a.g_mult >= 0 && a.g_shift <= -1 && a.g_shift >= -20);
+    const bool add_right = !a.add.enabled || (a.add.mo >= 0 && a.add.so < 0);
+    int mode = 0;
+    if (g_opt.i8_pw_forms && (a.rq_right & 4) && gate_fast && add_right) {
+        mode = 1;
+        if ((a.rq_right & 2) && a.pw_amin >= a.pw_zp_out && !a.add.enabled) mode = 2;
     }
+    const size_t smem = (size_t)a.Cout * (mode == 2 ? 20 : 12);
+#define BN_PWW(ADDV, NCTV, KSV, MODEV) \
+    hipLaunchKernelGGL((i8_pw_wave_kernel<ADDV, NCTV, KSV, MODEV>), dim3(blocks), dim3(256), smem + (NCTV ? 0 : w_bytes), s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16))
+#define BN_PWW1(NCTV, KSV)                                   \
+    {                                                        \
+        if (a.add.enabled) {                                 \
+            if (mode == 1) BN_PWW(true, NCTV, KSV, 1);       \
+            else BN_PWW(true, NCTV, KSV, 0);                 \
+        } else if (mode == 2) BN_PWW(false, NCTV, KSV, 2);   \
+        else if (mode == 1) BN_PWW(false, NCTV, KSV, 1);     \
+        else BN_PWW(false, NCTV, KSV, 0);                    \
+        return;                                              \
+    }
+#define BN_PWW2(NCTV, KSV) \
+    if (nct == NCTV && ks == KSV) BN_PWW1(NCTV, KSV)
     BN_PWW2(3, 1)
     BN_PWW2(6, 1)
     BN_PWW2(3, 2)
     BN_PWW2(2, 1)
     BN_PWW2(4, 1)
 #undef BN_PWW2
-    if (a.add.enabled) BN_PWW(true, 0, 0);
-    else BN_PWW(false, 0, 0);
+    BN_PWW1(0, 0)
+#undef BN_PWW1
 #undef BN_PWW
 }
 

@@ -622,7 +622,22 @@ struct DwStream8Args {
     int32_t* pool;  // [B][C] or null: += sum of the stored bytes per channel (the squeeze-excite MEAN behind the stage; i8_dw_stream_kernel only)
 };
 
-template <int S>
+// HI (the launcher checked: multipliers >= 0, shifts in [-20, -1], clamp starting at the zero point — ReLU behind the stage): the sign-free
+// requantisation clamp(hi32(acc m + C) >> (e - 1)), C = 2^30 + (2^(e-1) + zp 2^e) 2^31 (bn_i8_pw.hip), one multiply-add + shift + clamp per output
+struct RqHi {
+    long long c[4];
+    int sh[4];
+};
+__device__ __forceinline__ void rq_hi_setup(RqHi& r, const int (&shift)[4], int zp_out) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ex = -shift[e];
+        r.c[e] = (1ll << 30) + (((1ll << (ex - 1)) + (long long)zp_out * (1ll << ex)) << 31);
+        r.sh[e] = ex - 1;
+    }
+}
+
+template <int S, bool HI>
 __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -647,19 +662,33 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
 
     // weights as bytes (tap0, tap1, tap2, 0) per window row and channel; bias with the input zero point folded in
     int wr[3][4], bias[4], mult[4], shift[4];
+    {
+        // nine dword loads (four channels of a tap each) + four 16-byte loads, all in flight together; byte transposes per window row
+        int wq[9];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        int sum = 0;
+        for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const int*>(a.w + t * a.C + c0);
+        const v4i b4 = *reinterpret_cast<const v4i*>(a.bias + c0), m4 = *reinterpret_cast<const v4i*>(a.mult + c0), s4 = *reinterpret_cast<const v4i*>(a.shift + c0);
+        int sum[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int k0 = a.w[(i * 3 + 0) * a.C + c0 + e], k1 = a.w[(i * 3 + 1) * a.C + c0 + e], k2 = a.w[(i * 3 + 2) * a.C + c0 + e];
-            wr[i][e] = (k0 & 0xff) | ((k1 & 0xff) << 8) | ((k2 & 0xff) << 16);
-            sum += k0 + k1 + k2;
+            const int r0 = wq[3 * i], r1 = wq[3 * i + 1], r2 = wq[3 * i + 2];
+            const int lo = perm(r1, r0, 0x05010400u), hi = perm(r1, r0, 0x07030602u);
+            wr[i][0] = perm(r2, lo, 0x0c040100u);
+            wr[i][1] = perm(r2, lo, 0x0c050302u);
+            wr[i][2] = perm(r2, hi, 0x0c060100u);
+            wr[i][3] = perm(r2, hi, 0x0c070302u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] = dot4(wr[i][e], 0x00010101, sum[e]);
         }
-        bias[e] = a.bias[c0 + e] - a.zp_in * sum;
-        mult[e] = a.mult[c0 + e];
-        shift[e] = a.shift[c0 + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bias[e] = b4[e] - a.zp_in * sum[e];
+            mult[e] = m4[e];
+            shift[e] = s4[e];
+        }
     }
+    RqHi rqh;
+    if constexpr (HI) rq_hi_setup(rqh, shift, a.zp_out);
     const int zp4 = (a.zp_in & 0xff) * 0x01010101, zprow = (a.zp_in & 0xff) * 0x00010101;
     const int in_chunk_bytes = a.H * a.W * a.C;
     const int row_bytes = a.W * a.C;
@@ -679,7 +708,8 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
     const int ir0 = oh0 * S - a.pt;
     const int rows_needed = S * (nrows - 1) + 3;
 
-    int raw[2][3], T[3][4];
+    constexpr int D = 6;  // input rows requested ahead (slot = row % D: static under the six-row unrolling): the walk is bound by load latency, not issue
+    int raw[D][3], T[3][4];
     int psum[4] = {0, 0, 0, 0};  // what this lane stored, per channel (pool != null)
     auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
     auto issue = [&](int slot, int rr) {
@@ -709,19 +739,20 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             int acc = dot4_first(T[i0][e], wr[0][e], bias[e]);
             acc = dot4(T[i1][e], wr[1][e], acc);
             acc = dot4(T[i2][e], wr[2][e], acc);
-            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], (a.rq_right & 1) != 0) + a.zp_out, a.amin, a.amax);
+            if constexpr (HI) qv[e] = med3((int)(((long long)acc * mult[e] + rqh.c[e]) >> 32) >> rqh.sh[e], a.amin, a.amax);
+            else qv[e] = med3(mbqm_u(acc, mult[e], shift[e], (a.rq_right & 1) != 0) + a.zp_out, a.amin, a.amax);
             psum[e] += qv[e];
         }
         const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         __builtin_amdgcn_raw_buffer_store_b32(word, rs_out, voff_out, oh * a.OW * a.C, 0);
     };
     constexpr int P = 3 - S;
-    issue(0, 0);
-    issue(1, 1);
+#pragma unroll
+    for (int rr = 0; rr < D; ++rr) issue(rr, rr);
 #pragma unroll
     for (int rr = 0; rr < P; ++rr) {
-        consume(rr & 1, rr, rr % 3);
-        issue(rr & 1, rr + 2);
+        consume(rr % D, rr, rr % 3);
+        issue(rr % D, rr + D);
     }
     constexpr int U = 6 / S;
     for (int k = 0; k < nrows; k += U) {
@@ -730,9 +761,9 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             if (k + u >= nrows) break;
 #pragma unroll
             for (int s2 = 0; s2 < S; ++s2) {
-                const int rs = P + S * u + s2;
-                consume(rs & 1, S * k + rs, rs % 3);
-                issue(rs & 1, S * k + rs + 2);
+                const int rs = P + S * u + s2;  // (S k is a multiple of six: the slot of row S k + rs is rs % D)
+                consume(rs % D, S * k + rs, rs % 3);
+                issue(rs % D, S * k + rs + D);
             }
             emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
         }
@@ -751,7 +782,7 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
 // The stem of exported graphs (3x3 convolution of the single-channel map, any stride, C output channels) in the same row-streaming
 // form: lane = (column, channel quad), the three window bytes of an input row packed into ONE dword that serves all four channels
 // of the lane (three v_dot4_i32_i8 per output instead of nine sign-extend + multiply-add triples), three byte loads per input row.
-template <int S>
+template <int S, bool HI>
 __global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, int SW) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -787,6 +818,8 @@ __global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, in
         mult[e] = a.mult[c0 + e];
         shift[e] = a.shift[c0 + e];
     }
+    RqHi rqh;
+    if constexpr (HI) rq_hi_setup(rqh, shift, a.zp_out);
     const int zp = a.zp_in & 0xff, zprow = zp * 0x00010101;
     const __amdgpu_buffer_rsrc_t rs_in =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x) + (size_t)chunk * a.H * a.W, 0, a.H * a.W, 0x00020000);
@@ -803,7 +836,8 @@ __global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, in
     const int voff_out = live ? ow * a.C + c0 : 0x7fff0000;
     const int ir0 = oh0 * S - a.pt;
     const int rows_needed = S * (nrows - 1) + 3;
-    int raw[2][3], T[3];
+    constexpr int D = 6;
+    int raw[D][3], T[3];
     auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
     auto issue = [&](int slot, int rr) {
         if (row_ok(rr)) {
@@ -827,18 +861,19 @@ __global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, in
             int acc = dot4_first(T[i0], wr[0][e], bias[e]);
             acc = dot4(T[i1], wr[1][e], acc);
             acc = dot4(T[i2], wr[2][e], acc);
-            qv[e] = med3(mbqm_u(acc, mult[e], shift[e], (a.rq_right & 1) != 0) + a.zp_out, a.amin, a.amax);
+            if constexpr (HI) qv[e] = med3((int)(((long long)acc * mult[e] + rqh.c[e]) >> 32) >> rqh.sh[e], a.amin, a.amax);
+            else qv[e] = med3(mbqm_u(acc, mult[e], shift[e], (a.rq_right & 1) != 0) + a.zp_out, a.amin, a.amax);
         }
         const int word = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
         __builtin_amdgcn_raw_buffer_store_b32(word, rs_out, voff_out, oh * a.OW * a.C, 0);
     };
     constexpr int P = 3 - S;
-    issue(0, 0);
-    issue(1, 1);
+#pragma unroll
+    for (int rr = 0; rr < D; ++rr) issue(rr, rr);
 #pragma unroll
     for (int rr = 0; rr < P; ++rr) {
-        consume(rr & 1, rr, rr % 3);
-        issue(rr & 1, rr + 2);
+        consume(rr % D, rr, rr % 3);
+        issue(rr % D, rr + D);
     }
     constexpr int U = 6 / S;
     for (int k = 0; k < nrows; k += U) {
@@ -847,9 +882,9 @@ __global__ __launch_bounds__(256) void i8_stem_stream_kernel(DwStream8Args a, in
             if (k + u >= nrows) break;
 #pragma unroll
             for (int s2 = 0; s2 < S; ++s2) {
-                const int rs = P + S * u + s2;
-                consume(rs & 1, S * k + rs, rs % 3);
-                issue(rs & 1, S * k + rs + 2);
+                const int rs = P + S * u + s2;  // (S k is a multiple of six: the slot of row S k + rs is rs % D)
+                consume(rs % D, S * k + rs, rs % 3);
+                issue(rs % D, S * k + rs + D);
             }
             emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
         }
@@ -1156,15 +1191,20 @@ bool launch_i8_dw_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& g,
     const int ncol = 64 / cq;
     const long per_row_block = (long)B * (g.C / (4 * cq)) * ((g.OW + ncol - 1) / ncol);
     int th = g.OH;
-    while (th > 16) th = (th + 1) / 2;
+    while (th > 32) th = (th + 1) / 2;  // (a wave's prologue — weights, constants, the first rows — is paid once per th rows)
     while (th > 4 && per_row_block * ((g.OH + th - 1) / th) < 8192) th = (th + 1) / 2;
     if (const int v = g_opt.i8_strip_th; v >= 1) th = v < g.OH ? v : g.OH;
     a.TH = th;
     const long waves = per_row_block * ((g.OH + th - 1) / th);
-    if (g.sh == 1)
-        hipLaunchKernelGGL(i8_dw_stream_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(i8_dw_stream_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    const bool hi = g_opt.i8_pw_forms && (g.rq_right & 3) == 3 && g.amin >= g.zp_out;  // (bit 1: every shift in [-20, -1])
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (g.sh == 1) {
+        if (hi) hipLaunchKernelGGL((i8_dw_stream_kernel<1, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((i8_dw_stream_kernel<1, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (hi) hipLaunchKernelGGL((i8_dw_stream_kernel<2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((i8_dw_stream_kernel<2, false>), grid, dim3(256), 0, s, a);
+    }
     return true;
 }
 
@@ -1182,10 +1222,15 @@ bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& 
     if (const int v = g_opt.i8_strip_th; v >= 1) th = v < g.OH ? v : g.OH;
     a.TH = th;
     const long waves = per_row_block * ((g.OH + th - 1) / th);
-    if (g.sh == 1)
-        hipLaunchKernelGGL(i8_stem_stream_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, g.sw);
-    else
-        hipLaunchKernelGGL(i8_stem_stream_kernel<2>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, g.sw);
+    const bool hi = g_opt.i8_pw_forms && (g.rq_right & 3) == 3 && g.amin >= g.zp_out;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (g.sh == 1) {
+        if (hi) hipLaunchKernelGGL((i8_stem_stream_kernel<1, true>), grid, dim3(256), 0, s, a, g.sw);
+        else hipLaunchKernelGGL((i8_stem_stream_kernel<1, false>), grid, dim3(256), 0, s, a, g.sw);
+    } else {
+        if (hi) hipLaunchKernelGGL((i8_stem_stream_kernel<2, true>), grid, dim3(256), 0, s, a, g.sw);
+        else hipLaunchKernelGGL((i8_stem_stream_kernel<2, false>), grid, dim3(256), 0, s, a, g.sw);
+    }
     return true;
 }
 

@@ -34,6 +34,8 @@ struct Options {
                                // (integer sums, order-free: bit-identical); 0: i8_segate_kernel reads the whole map again
     int i8_pw_lds = 1;         // dense 1x1 convolutions (Cin 192 / 384 / 768) of exported INT8 graphs through i8_pw_lds_kernel (bn_i8_pw.hip): weights of a
                                // slice of output channels resident in LDS, squeeze-excite MUL applied on load (0: tile kernel + i8_scale)
+    int i8_pw_forms = 1;       // i8_pw_wave_kernel / i8_dw_stream_kernel pick their requantisation form at compile time where the operator's constants allow
+                               // (sign-free one-multiply-add form behind ReLU, branch-free right-shift form elsewhere); 0: the runtime-uniform general code
     int i8_tail_fclds = 1;     // the fused tail's head reads the classifier matrix from an LDS copy (0: from memory, 64 dependent loads per thread)
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
