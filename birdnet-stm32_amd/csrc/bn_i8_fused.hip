@@ -37,12 +37,6 @@ __device__ __forceinline__ int32_t sx8(int32_t v, int byte) { return (int32_t)(i
 __device__ __forceinline__ int32_t lane_byte(int32_t w, int e) { return w & (0xff << (8 * e)); }
 __device__ __forceinline__ int32_t dot4(int32_t a, int32_t b, int32_t c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 
-// the low bytes of four values as one dword (three v_perm_b32)
-__device__ __forceinline__ int pack4(const int (&q)[4]) {
-    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[1], (uint32_t)q[0], 0x0c0c0400u), hi = __builtin_amdgcn_perm((uint32_t)q[3], (uint32_t)q[2], 0x0c0c0400u);
-    return (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
-}
-
 // 4 x 4 byte transpose: rows r0..r3 hold four channels of one tap each; c[e] gets channel e of the four taps.
 // v_perm_b32 picks bytes out of the 8-byte value {s0 (bytes 4-7), s1 (bytes 0-3)}.
 __device__ __forceinline__ void transpose4x4(int r0, int r1, int r2, int r3, int c[4]) {
@@ -789,19 +783,23 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);  // [Kp/64][N/16][64 lanes] x 16 bytes
     // a wave walks over groups of 16 positions (the constants above are staged once per workgroup, not once per 64 positions); the
     // activations of the next group are requested before the current one is multiplied
-    const long n_groups = n_pos / 16, stride = (long)gridDim.x * 4;
-    auto fetch = [&](long grp, v4i (&dst)[4]) {
+    // (each wave owns a CONTIGUOUS run of groups: it stays inside one chunk for P / 16 groups, so the squeeze-excite gate bytes are loaded once per
+    // chunk and wave, not once per group)
+    // (32-bit arithmetic throughout: the launcher checked n_pos * Cin and n_pos * Cout < 2^31)
+    const int n_groups = (int)(n_pos / 16), n_walkers = (int)gridDim.x * 4, per_wave = (n_groups + n_walkers - 1) / n_walkers;
+    auto fetch = [&](int grp, v4i (&dst)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int koff = 64 * s + 16 * q;
             dst[s] = (v4i){0, 0, 0, 0};
             if (grp < n_groups && s < ksteps && koff < K)
-                dst[s] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((grp * 16 + r) * K) + koff, 0, 0));
+                dst[s] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (grp * 16 + r) * K + koff, 0, 0));
         }
     };
-    long grp = (long)blockIdx.x * 4 + wave;
+    int grp = ((int)blockIdx.x * 4 + wave) * per_wave;
+    const int g_end = grp + per_wave < n_groups ? grp + per_wave : n_groups;
     v4i bfr[4], bnx[4];
-    fetch(grp, bfr);
+    fetch(grp < g_end ? grp : n_groups, bfr);
     // AREG (at most six weight fragments: the wide early layers, 24 -> 48, 48 -> 96, 96 -> 48): the A operands live in registers for the
     // whole walk — the counters showed the waves 61 % of their time waiting on memory with a fragment fetch in front of every tile
     v4i areg[AREG ? NCT * KS : 1];
@@ -820,18 +818,59 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     const bool g_fast = MODE != 0 || (a.gate && a.g_zx == -128 && a.g_zg == -128 && a.g_mult >= 0 && a.g_shift <= -1 && a.g_shift >= -20);
     const int ge = g_fast ? -a.g_shift : 1, gsh = ge - 1;
     const long long gC = (1ll << 30) + (((1ll << (ge - 1)) + (long long)a.g_zo * (1ll << ge)) << 31);
-    for (; grp < n_groups; grp += stride) {
-    fetch(grp + stride, bnx);
-    const long pos = grp * 16 + r;
+    // the gate bytes and the residual of a group travel with its activations, one group ahead (the walk is bound by load latency: a load at
+    // the point of use costs a round trip per group); out-of-range requests (past the last group, k past Cin) read zeros
+    const int cpl = N >> 2;                         // channels per lane
+    constexpr int RN = AREG ? NCT : 4;              // residual dwords requested ahead: all tiles (register variants) or the first block of four
+    const __amdgpu_buffer_rsrc_t rs_g =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.gate ? a.gate : a.x), 0, a.gate ? (int)(n_pos / P * K) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(ADD ? a.res : a.x), 0, ADD ? (int)(n_pos * N) : 0, 0x00020000);
+    auto fetch_gate = [&](int chunk, v4i (&dst)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int koff = 64 * s + 16 * q;
+            dst[s] = (v4i){0, 0, 0, 0};
+            if (s < ksteps) dst[s] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_g, koff < K ? chunk * K + koff : 0x7ffffff0, 0, 0));
+        }
+    };
+    auto fetch_res = [&](int g_, int (&dst)[RN]) {
+        const int base = (g_ < n_groups ? g_ * 16 + r : (int)n_pos) * N + cpl * q;
+#pragma unroll
+        for (int u = 0; u < RN; ++u) {
+            dst[u] = 0;
+            if (ADD && u < n_ct) dst[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_res, base + 4 * u, 0, 0);
+        }
+    };
+    v4i gfr[4];
+    int rcur[RN], rnx[RN];
+    // the chunk of the walk's first group (one division per wave), then counted: gpc groups per chunk
+    const int gpc = P >> 4;
+    int gchunk = a.gate && grp < g_end ? grp / gpc : 0, g_left = 0;  // groups left with the gate bytes in gfr
+    if (a.gate && grp < g_end) {
+        fetch_gate(gchunk, gfr);
+        g_left = (gchunk + 1) * gpc - grp;
+    }
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(n_pos * N), 0x00020000);
+    fetch_res(grp < g_end ? grp : n_groups, rcur);
+    for (; grp < g_end; ++grp) {
+    const int nxt = grp + 1 < g_end ? grp + 1 : n_groups;
+    fetch(nxt, bnx);
+    fetch_res(nxt, rnx);
+    const int pos = grp * 16 + r;
     if (a.gate) {
+        if (g_left == 0) {  // (wave-uniform)
+            fetch_gate(++gchunk, gfr);
+            g_left = gpc;
+        }
+        --g_left;
         // squeeze-excite MUL on the way in: the 16 bytes of every k-step times the chunk's gate bytes, requantised exactly as
         // i8_scale_kernel does (the scaled map is never written); a group of 16 positions lies inside one chunk (P % 16 == 0)
-        const int8_t* gb = a.gate + (grp * 16 / P) * K;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int koff = 64 * s + 16 * q;
             if (s < ksteps && koff < K) {
-                const v4i gv = *reinterpret_cast<const v4i*>(gb + koff);
+                const v4i gv = gfr[s];
                 v4i o;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -844,7 +883,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int p = (int)((xu >> (8 * e)) & 0xff) * (int)((gu >> (8 * e)) & 0xff);
-                            gq[e] = clampi((int)(((long long)p * a.g_mult + gC) >> 32) >> gsh, a.g_amin, a.g_amax);
+                            gq[e] = med3i((int)(((long long)p * a.g_mult + gC) >> 32) >> gsh, a.g_amin, a.g_amax);
                         }
                         packed = pack4(gq);
                     } else if constexpr (MODE == 0) {
@@ -863,11 +902,22 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     // Tile ct computes the channels (N / 4) (i >> 2) + 4 ct + (i & 3) in its rows i (the A fragment of row i is fetched from wherever
     // the packer put that channel), so lane (r, q) ends up with the N / 4 CONSECUTIVE channels (N / 4) q .. of its position: the four
     // lanes of a position write one contiguous run of N bytes, in 16-byte pieces where the tile count allows.
-    const int cpl = N >> 2;                         // channels per lane
-    int8_t* yrow = a.y + pos * N + cpl * q;
-    const int8_t* rrow = ADD ? a.res + pos * N + cpl * q : nullptr;
+    const int y_base = pos * N + cpl * q, res_base = y_base;
     const int ch_r = cpl * (r >> 2) + (r & 3);      // + 4 ct: the channel of this lane's A row
+    int rmid[4] = {0, 0, 0, 0};                     // (tile-loop variant) residual dwords of the block after the current one
+#pragma unroll AREG ? 2 : 1
     for (int ct0 = 0; ct0 < n_ct; ct0 += 4) {
+        int rblk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (AREG) rblk[u] = ct0 + u < NCT ? rcur[ct0 + u < NCT ? ct0 + u : 0] : 0;
+            else rblk[u] = ct0 == 0 ? rcur[u] : rmid[u];
+        }
+        if constexpr (ADD && !AREG) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ct0 + 4 + u < n_ct) rmid[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_res, res_base + 4 * (ct0 + 4 + u), 0, 0);
+        }
         int outw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -887,8 +937,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
                     if (s < ksteps) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wsrc[((size_t)s * n_ct + (ch >> 4)) * 64 + q * 16 + (ch & 15)], bfr[s], acc, 0, 0, 0);
             }
             const v4i m = cst[cidx * CW + 1], sh = cst[cidx * CW + 2];
-            int rv = 0;
-            if (ADD) rv = *reinterpret_cast<const int*>(rrow + 4 * ct);
+            const int rv = rblk[u];
             if constexpr (MODE == 0) {
                 int packed = 0;
 #pragma unroll
@@ -909,18 +958,18 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const long long C = (long long)(((unsigned long long)(unsigned)chi[e] << 32) | (unsigned)clo[e]);
-                        qv[e] = clampi((int)(((long long)acc[e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
+                        qv[e] = med3i((int)(((long long)acc[e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) qv[e] = clampi(mbqm_right(acc[e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                    for (int e = 0; e < 4; ++e) qv[e] = med3i(mbqm_right(acc[e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
                 }
                 if (ADD) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int sa = add_lut[0][(rv >> (8 * e)) & 0xff];
                         const int sb = add_lut[1][qv[e] & 0xff];
-                        qv[e] = clampi(mbqm_right(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);
+                        qv[e] = med3i(mbqm_right(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);
                     }
                 }
                 outw[u] = pack4(qv);
@@ -929,15 +978,17 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
         }
         const int left = n_ct - ct0;
         if (left >= 4 && (cpl & 15) == 0) {
-            *reinterpret_cast<v4i*>(yrow + 4 * ct0) = (v4i){outw[0], outw[1], outw[2], outw[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(int)))) int, (v4i){outw[0], outw[1], outw[2], outw[3]}), rs_y, y_base + 4 * ct0, 0, 0);
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (u < left) *reinterpret_cast<int*>(yrow + 4 * (ct0 + u)) = outw[u];
+                if (u < left) __builtin_amdgcn_raw_buffer_store_b32(outw[u], rs_y, y_base + 4 * (ct0 + u), 0, 0);
         }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) bfr[s] = bnx[s];
+#pragma unroll
+    for (int u = 0; u < RN; ++u) rcur[u] = rnx[u];
     }
 }
 
@@ -945,7 +996,7 @@ bool i8_pw_wave_supported(const DwPw8Args& a) {
     const long n_pos = (long)a.B * a.OH * a.OW;
     if (a.gate && (a.Cin % 16 || ((long)a.OH * a.OW) % 16)) return false;  // gate rows are read 16 bytes at a time, a group stays inside a chunk
     return g_opt.i8_strip && !a.has_dw && !a.transposed && !a.lut && !a.qx && a.sh == 1 && a.sw == 1 && a.H == a.OH && a.W == a.OW && a.Cin <= 256 &&
-           a.Cin % 4 == 0 && a.Cout % 16 == 0 && n_pos % 16 == 0 && n_pos * a.Cin < 0x7fff0000L;
+           a.Cin % 4 == 0 && a.Cout % 16 == 0 && n_pos % 16 == 0 && n_pos * a.Cin < 0x7fff0000L && n_pos * a.Cout < 0x7fff0000L;
 }
 
 void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {

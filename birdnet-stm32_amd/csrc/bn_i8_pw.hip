@@ -155,14 +155,13 @@ __global__ __launch_bounds__(kPwLdsThreads) void i8_pw_lds_kernel(DwPw8Args a, P
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const unsigned xu = (unsigned)b[d] ^ 0x80808080u, gu = (unsigned)gv[d] ^ 0x80808080u;  // byte + 128 = byte - zero point
-                        int packed = 0;
+                        int gq[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int p = (int)((xu >> (8 * e)) & 0xff) * (int)((gu >> (8 * e)) & 0xff);
-                            const int t = (int)(((long long)p * a.g_mult + gC) >> 32) >> gsh;
-                            packed |= (clampi(t, a.g_amin, a.g_amax) & 0xff) << (8 * e);
+                            gq[e] = med3i((int)(((long long)p * a.g_mult + gC) >> 32) >> gsh, a.g_amin, a.g_amax);
                         }
-                        b[d] = packed;
+                        b[d] = pack4(gq);
                         __builtin_amdgcn_sched_barrier(0);  // (one dword at a time: the sixteen requantisations in parallel cost 40 more registers)
                     }
                 }
@@ -193,24 +192,22 @@ __global__ __launch_bounds__(kPwLdsThreads) void i8_pw_lds_kernel(DwPw8Args a, P
                     clo = cst[5 * cidx + 3];
                     chi = cst[5 * cidx + 4];
                 }
-                int packed = 0;
+                int qv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int qv;
                     if constexpr (HI) {
                         const long long C = (long long)(((unsigned long long)(unsigned)chi[e] << 32) | (unsigned)clo[e]);
-                        qv = clampi((int)(((long long)acc[ct0 + u][e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
+                        qv[e] = med3i((int)(((long long)acc[ct0 + u][e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
                     } else {  // every multiplier >= 0 and every shift < 0 (checked at load): the branch-free signed form
-                        qv = clampi(mbqm_right(acc[ct0 + u][e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+                        qv[e] = med3i(mbqm_right(acc[ct0 + u][e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
                     }
                     if (ADD) {
                         const int sa = add_lut[0][(rv4[u] >> (8 * e)) & 0xff];
-                        const int sb = add_lut[1][qv & 0xff];
-                        qv = clampi(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);  // (uniform parameters: the form is chosen once)
+                        const int sb = add_lut[1][qv[e] & 0xff];
+                        qv[e] = med3i(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);  // (uniform parameters: the form is chosen once)
                     }
-                    packed |= (qv & 0xff) << (8 * e);
                 }
-                outw[u] = packed;
+                outw[u] = pack4(qv);
             }
             *reinterpret_cast<v4i*>(yrow + 4 * ct0) = outw;  // (cpl = 4 NCT is a multiple of 16: NCT % 4 == 0)
             __builtin_amdgcn_sched_barrier(0);

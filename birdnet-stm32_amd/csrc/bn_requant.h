@@ -63,6 +63,19 @@ __device__ __forceinline__ int32_t mbqm_u(int32_t x, int32_t mult, int shift, bo
 
 __device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// clamp as ONE instruction; lo <= hi.  (The compiler cannot prove lo <= hi for run-time bounds and emits compare + select + min.)
+__device__ __forceinline__ int med3i(int v, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+// the low bytes of four values as one dword (three v_perm_b32)
+__device__ __forceinline__ int pack4(const int (&q)[4]) {
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[1], (uint32_t)q[0], 0x0c0c0400u), hi = __builtin_amdgcn_perm((uint32_t)q[3], (uint32_t)q[2], 0x0c0c0400u);
+    return (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+
 // int8 MEAN of `raw_sum` = sum of the P raw bytes of a channel.  Two published forms (oracle/int8_graph.py has both behind mean_form):
 //   integer (default): MultiplyByQuantizedMultiplier(raw_sum - zp_in P, mult, shift) with 1 / P folded into the multiplier (reduce.h);
 //   float (shift == kMeanFloatForm, mult = the float32 bits of s_in / s_out): TFLite's float-arithmetic QuantizedMeanOrSum —
