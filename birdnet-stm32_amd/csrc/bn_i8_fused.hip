@@ -772,14 +772,25 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     // layers with more fragments than registers: the whole weight matrix (fragment order, up to 48 KB) is staged in LDS once per
     // workgroup when the launcher made room for it — a 16-byte LDS read per tile and k-step instead of a trip to L1 / L2
     v4i* wl = cst + CW * (N / 4);
+    // ... in CONSUMPTION order: entry (ct KS + s) 64 + lane is the A fragment lane (row rr, k quarter qq) feeds to tile ct in k-step s — the
+    // walk reads them with one running address, no index arithmetic per matrix instruction
     const bool w_in_lds = !AREG && lds_w16 > 0;
-    if (w_in_lds)
-        for (int i = tid; i < lds_w16; i += 256) wl[i] = reinterpret_cast<const v4i*>(a.pw_w)[i];
+    if (w_in_lds) {
+        const v4i* wsrc = reinterpret_cast<const v4i*>(a.pw_w);
+        const int n_ct_all = N >> 4, cpl0 = N >> 2;
+        for (int i = tid; i < lds_w16; i += 256) {
+            const int ln = i & 63, f = i >> 6, s_ = f % KS, ct = f / KS;
+            const int rr = ln & 15, qq = ln >> 4;
+            const int ch = cpl0 * (rr >> 2) + (rr & 3) + 4 * ct;
+            wl[i] = wsrc[((size_t)s_ * n_ct_all + (ch >> 4)) * 64 + qq * 16 + (ch & 15)];
+        }
+    }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x), 0, (int)(n_pos * K), 0x00020000);
-    const int ksteps = AREG ? KS : (K + 63) >> 6, n_ct = AREG ? NCT : N >> 4;
+    constexpr int ksteps = KS;
+    const int n_ct = AREG ? NCT : N >> 4;
     const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);  // [Kp/64][N/16][64 lanes] x 16 bytes
     // a wave walks over groups of 16 positions (the constants above are staged once per workgroup, not once per 64 positions); the
     // activations of the next group are requested before the current one is multiplied
@@ -931,10 +942,14 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
 #pragma unroll
                 for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[ct * KS + s_], bfr[s_], acc, 0, 0, 0);
             } else {
-                const v4i* wsrc = w_in_lds ? wl : wp;
+                if (w_in_lds) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s < ksteps) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wsrc[((size_t)s * n_ct + (ch >> 4)) * 64 + q * 16 + (ch & 15)], bfr[s], acc, 0, 0, 0);
+                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wl[(ct * KS + s) * 64 + lane], bfr[s], acc, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wp[((size_t)s * n_ct + (ch >> 4)) * 64 + q * 16 + (ch & 15)], bfr[s], acc, 0, 0, 0);
+                }
             }
             const v4i m = cst[cidx * CW + 1], sh = cst[cidx * CW + 2];
             const int rv = rblk[u];
@@ -1036,7 +1051,11 @@ void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {
     BN_PWW2(2, 1)
     BN_PWW2(4, 1)
 #undef BN_PWW2
-    BN_PWW1(0, 0)
+    // more fragments than registers: tile loop over the LDS copy, k-steps still a compile-time constant (Cin <= 256)
+    if (ks == 1) BN_PWW1(0, 1)
+    if (ks == 2) BN_PWW1(0, 2)
+    if (ks == 3) BN_PWW1(0, 3)
+    BN_PWW1(0, 4)
 #undef BN_PWW1
 #undef BN_PWW
 }
