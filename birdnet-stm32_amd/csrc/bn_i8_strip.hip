@@ -660,9 +660,11 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
     const bool live = ow < a.OW;
     const int c0 = 4 * (g * CQ + cq);
 
-    // weights as bytes (tap0, tap1, tap2, 0) per window row and channel; bias with the input zero point folded in
+    // weights as bytes (tap0, tap1, tap2, 0) per window row and channel; bias with the input zero point folded in (filled by load_constants()
+    // BEHIND the first row requests: the wave's first rows and its constants travel together — one round trip of prologue instead of two)
     int wr[3][4], bias[4], mult[4], shift[4];
-    {
+    RqHi rqh;
+    auto load_constants = [&]() {
         // nine dword loads (four channels of a tap each) + four 16-byte loads, all in flight together; byte transposes per window row
         int wq[9];
 #pragma unroll
@@ -686,9 +688,8 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             mult[e] = m4[e];
             shift[e] = s4[e];
         }
-    }
-    RqHi rqh;
-    if constexpr (HI) rq_hi_setup(rqh, shift, a.zp_out);
+        if constexpr (HI) rq_hi_setup(rqh, shift, a.zp_out);
+    };
     const int zp4 = (a.zp_in & 0xff) * 0x01010101, zprow = (a.zp_in & 0xff) * 0x00010101;
     const int in_chunk_bytes = a.H * a.W * a.C;
     const int row_bytes = a.W * a.C;
@@ -749,6 +750,7 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
     constexpr int P = 3 - S;
 #pragma unroll
     for (int rr = 0; rr < D; ++rr) issue(rr, rr);
+    load_constants();
 #pragma unroll
     for (int rr = 0; rr < P; ++rr) {
         consume(rr % D, rr, rr % 3);
