@@ -766,7 +766,8 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str
                 zero = pb.tensor(np.zeros(4, np.int32), np.int32)
                 pp = [H, Wd, Cin, 1, 1, 0, H, Wd, 0, 0, 0, 0, 0, 0, Cout, z_o, a_lo, a_hi, *add_p, 0, 0, *tile, 0, 0]
                 pb.op(pk.I8_DWPW, val[src], v, p=pp, in1=res_val,
-                      t=[zero, zero, zero, zero, pb.tensor(pack_i8_fragments(w), np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32)],
+                      t=[zero, zero, zero, zero, pb.tensor(pack_i8_fragments(w), np.int8), pb.tensor(b, np.int32), pb.tensor(mu, np.int32), pb.tensor(sh, np.int32),
+                         -1, -1, pb.tensor(add_table(add_p, z_o), np.int8) if add_p[0] else -1],  # the whole ADD as a 64 KB table (i8_pw_wave / i8_pw_lds kernels)
                       name=f"t{out_t}", out_shape=(H, Wd, Cout), out_dtype="int8")
             else:
                 pb.op(pk.I8_PW, val[src], v, p=[H * Wd, Cin, Cout, z_o, a_lo, a_hi, *add_p], in1=res_val,

@@ -46,7 +46,7 @@ struct OptName {
 };
 const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
-    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"i8_pw_forms", &bn::Options::i8_pw_forms}, {"front_tpw", &bn::Options::front_tpw},
+    {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"i8_pw_forms", &bn::Options::i8_pw_forms}, {"i8_add_tab", &bn::Options::i8_add_tab}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
@@ -294,6 +294,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         a.add = bn::I8AddParams{q[18], q[19], q[20], q[21], q[22], q[23], q[24], q[25], q[26], q[27], q[28]};
         a.has_dw = q[29]; a.transposed = q[30]; a.TH = q[31]; a.TW = q[32]; a.NB = q[33];
         a.rq_right = m->rq_right[di];
+        a.add_tab = (q[18] && !q[29] && d.t[10] >= 0) ? (const int8_t*)m->tensor(d.t[10]) : nullptr;
         return a;
     };
     m->out_valid.resize(m->ops.size());

@@ -735,17 +735,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 //      present, has both zero points -128 and a right shift 1..20 (one multiply-add per byte);
 //   2  ReLU layers (expansions; no ADD): the clamp starts at the zero point and every shift lies in [-20, -1] — the sign-free
 //      clamp(hi32(acc m + C) >> (e - 1)) of i8_pw_lds_kernel, three instructions per output; gate as in 1.
-template <bool ADD, int NCT, int KS, int MODE>  // NCT > 0: the tile / k-step counts are compile-time constants and the weight fragments live in registers
-__global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos, int lds_w16) {
+// TAB (projections with a residual ADD, MODE 1): the whole ADD is ONE lookup in the packer's 64 KB table [residual byte][own value + 128] held in LDS
+// (a v_perm for the index + a byte read instead of two rescale lookups and a third requantisation: 46 -> ~9 issue cycles per output).  The table
+// fills a CU's LDS budget for one workgroup, so that one has sixteen waves (1024 threads).
+template <bool ADD, int NCT, int KS, int MODE, bool TAB>  // NCT > 0: the tile / k-step counts are compile-time constants and the weight fragments live in registers
+__global__ __launch_bounds__(TAB ? 1024 : 256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos, int lds_w16) {
     constexpr bool AREG = NCT > 0;
     constexpr int CW = MODE == 2 ? 5 : 3;  // v4i per channel quad: bias, multiplier, shift [, addend low, addend high]
+    constexpr int NTH = TAB ? 1024 : 256, NWV = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-    v4i* cst = reinterpret_cast<v4i*>(lds_raw);  // [Cout / 4][CW]
+    const unsigned char* add_tab = reinterpret_cast<const unsigned char*>(lds_raw);  // (TAB) first 64 KB
+    v4i* cst = reinterpret_cast<v4i*>(lds_raw + (TAB ? 16384 : 0));  // [Cout / 4][CW]
     __shared__ int add_lut[2][256];
     const int tid = threadIdx.x;
     const int K = a.Cin, N = a.Cout;
     const bool rq = (a.rq_right & 1) != 0;
-    for (int i = tid; i < N / 4; i += 256) {
+    if constexpr (TAB) {
+        const v4i* tsrc = reinterpret_cast<const v4i*>(a.add_tab);
+        v4i* tdst = reinterpret_cast<v4i*>(lds_raw);
+        v4i tv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tv[k] = tsrc[tid + NTH * k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tdst[tid + NTH * k] = tv[k];
+    }
+    for (int i = tid; i < N / 4; i += NTH) {
         cst[CW * i + 0] = *reinterpret_cast<const v4i*>(a.pw_b + 4 * i);
         cst[CW * i + 1] = *reinterpret_cast<const v4i*>(a.pw_mult + 4 * i);
         v4i ss = *reinterpret_cast<const v4i*>(a.pw_shift + 4 * i);
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
         }
         cst[CW * i + 2] = ss;
     }
-    if (ADD) {
+    if (ADD && !TAB && tid < 256) {
         const int v = (int)(int8_t)tid;
         add_lut[0][tid] = mbqm((v - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);
         add_lut[1][tid] = mbqm((v - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);
@@ -778,7 +792,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     if (w_in_lds) {
         const v4i* wsrc = reinterpret_cast<const v4i*>(a.pw_w);
         const int n_ct_all = N >> 4, cpl0 = N >> 2;
-        for (int i = tid; i < lds_w16; i += 256) {
+        for (int i = tid; i < lds_w16; i += NTH) {
             const int ln = i & 63, f = i >> 6, s_ = f % KS, ct = f / KS;
             const int rr = ln & 15, qq = ln >> 4;
             const int ch = cpl0 * (rr >> 2) + (rr & 3) + 4 * ct;
@@ -797,7 +811,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
     // (each wave owns a CONTIGUOUS run of groups: it stays inside one chunk for P / 16 groups, so the squeeze-excite gate bytes are loaded once per
     // chunk and wave, not once per group)
     // (32-bit arithmetic throughout: the launcher checked n_pos * Cin and n_pos * Cout < 2^31)
-    const int n_groups = (int)(n_pos / 16), n_walkers = (int)gridDim.x * 4, per_wave = (n_groups + n_walkers - 1) / n_walkers;
+    const int n_groups = (int)(n_pos / 16), n_walkers = (int)gridDim.x * NWV, per_wave = (n_groups + n_walkers - 1) / n_walkers;
     auto fetch = [&](int grp, v4i (&dst)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -807,7 +821,7 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
                 dst[s] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (grp * 16 + r) * K + koff, 0, 0));
         }
     };
-    int grp = ((int)blockIdx.x * 4 + wave) * per_wave;
+    int grp = ((int)blockIdx.x * NWV + wave) * per_wave;
     const int g_end = grp + per_wave < n_groups ? grp + per_wave : n_groups;
     v4i bfr[4], bnx[4];
     fetch(grp < g_end ? grp : n_groups, bfr);
@@ -975,11 +989,18 @@ __global__ __launch_bounds__(256) void i8_pw_wave_kernel(DwPw8Args a, long n_pos
                         const long long C = (long long)(((unsigned long long)(unsigned)chi[e] << 32) | (unsigned)clo[e]);
                         qv[e] = med3i((int)(((long long)acc[e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
                     }
+                } else if constexpr (TAB) {
+                    // own value + 128 (the table's column), then the ADD as one byte read
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int own = med3i(mbqm_right(acc[e], m[e], sh[e]) + (a.pw_zp_out + 128), a.pw_amin + 128, a.pw_amax + 128);
+                        qv[e] = add_tab[__builtin_amdgcn_perm((unsigned)rv, (unsigned)own, 0x0c0c0400u + (e << 8))];
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) qv[e] = med3i(mbqm_right(acc[e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
                 }
-                if (ADD) {
+                if (ADD && !TAB) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int sa = add_lut[0][(rv >> (8 * e)) & 0xff];
@@ -1024,6 +1045,7 @@ void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {
     if (w_bytes > 48 * 1024) w_bytes = 0;
     // requantisation forms (see the kernel's MODE): a gate must have the one-multiply-add form for modes 1 and 2
     const bool gate_fast = !a.gate || (a.g_zx == -128 && a.g_zg == -128 && a.g_mult >= 0 && a.g_shift <= -1 && a.g_shift >= -20);
+    bool tab = false;  // (set below)
     const bool add_right = !a.add.enabled || (a.add.mo >= 0 && a.add.so < 0);
     int mode = 0;
     if (g_opt.i8_pw_forms && (a.rq_right & 4) && gate_fast && add_right) {
@@ -1031,12 +1053,23 @@ void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {
         if ((a.rq_right & 2) && a.pw_amin >= a.pw_zp_out && !a.add.enabled) mode = 2;
     }
     const size_t smem = (size_t)a.Cout * (mode == 2 ? 20 : 12);
+    // the ADD as a 64 KB table in LDS: one sixteen-wave workgroup per CU
+    tab = mode == 1 && a.add.enabled && a.add_tab && g_opt.i8_add_tab;
+    const long wanted_t = (n_pos / 16 + 15) / 16;
+    const unsigned blocks_t = (unsigned)(wanted_t < 256 ? wanted_t : 256);
 #define BN_PWW(ADDV, NCTV, KSV, MODEV) \
-    hipLaunchKernelGGL((i8_pw_wave_kernel<ADDV, NCTV, KSV, MODEV>), dim3(blocks), dim3(256), smem + (NCTV ? 0 : w_bytes), s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16))
+    hipLaunchKernelGGL((i8_pw_wave_kernel<ADDV, NCTV, KSV, MODEV, false>), dim3(blocks), dim3(256), smem + (NCTV ? 0 : w_bytes), s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16))
+#define BN_PWWT(NCTV, KSV)                                                                                                                   \
+    {                                                                                                                                        \
+        const size_t sm = 65536 + smem + (NCTV ? 0 : w_bytes);                                                                               \
+        ensure_dynamic_lds(reinterpret_cast<const void*>(i8_pw_wave_kernel<true, NCTV, KSV, 1, true>), sm);                                  \
+        hipLaunchKernelGGL((i8_pw_wave_kernel<true, NCTV, KSV, 1, true>), dim3(blocks_t), dim3(1024), sm, s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16)); \
+    }
 #define BN_PWW1(NCTV, KSV)                                   \
     {                                                        \
         if (a.add.enabled) {                                 \
-            if (mode == 1) BN_PWW(true, NCTV, KSV, 1);       \
+            if (tab) BN_PWWT(NCTV, KSV)                      \
+            else if (mode == 1) BN_PWW(true, NCTV, KSV, 1);  \
             else BN_PWW(true, NCTV, KSV, 0);                 \
         } else if (mode == 2) BN_PWW(false, NCTV, KSV, 2);   \
         else if (mode == 1) BN_PWW(false, NCTV, KSV, 1);     \
@@ -1057,6 +1090,7 @@ void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {
     if (ks == 3) BN_PWW1(0, 3)
     BN_PWW1(0, 4)
 #undef BN_PWW1
+#undef BN_PWWT
 #undef BN_PWW
 }
 

@@ -41,6 +41,7 @@ struct PwLdsGeom {
     int ns;         // output channels per slice (multiple of 16)
     int n_slices;
     int walkers;    // position walkers = gridDim.x / n_slices
+    int tab;        // the ADD as one lookup in the 64 KB table (DwPw8Args::add_tab), staged behind the constants
 };
 
 template <bool ADD, bool GATE, int KS, int NCT, bool HI>  // K = 64 KS input channels, slices of 16 NCT output channels; HI: sign-free requantisation
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(kPwLdsThreads) void i8_pw_lds_kernel(DwPw8Args a, P
     const int n0 = slice * ns;
     v4i* wl = reinterpret_cast<v4i*>(lds_raw);       // [KS][NCT][64 lanes]
     v4i* cst = wl + (size_t)KS * NCT * 64;           // [4 lane quarters][NCT][bias, multiplier, shift | addend low, addend high]
+    const unsigned char* tabl = reinterpret_cast<const unsigned char*>(lds_raw) + (size_t)ns * (K + 20);  // (g.tab) the ADD table behind them
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x), 0, (int)(g.n_pos * K), 0x00020000);
@@ -114,7 +116,16 @@ __global__ __launch_bounds__(kPwLdsThreads) void i8_pw_lds_kernel(DwPw8Args a, P
             cst[5 * i + 3] = clo;
             cst[5 * i + 4] = chi;
         }
-        if (ADD && tid < 256) {
+        if (ADD && g.tab) {
+            const v4i* tsrc = reinterpret_cast<const v4i*>(a.add_tab);
+            v4i* tdst = reinterpret_cast<v4i*>(lds_raw) + (size_t)ns * (K + 20) / 16;
+            v4i tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tv[k] = tsrc[tid + kPwLdsThreads * k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tdst[tid + kPwLdsThreads * k] = tv[k];
+        }
+        if (ADD && !g.tab && tid < 256) {
             const int v = (int)(int8_t)tid;
             add_lut[0][tid] = mbqm((v - a.add.z1) * (1 << 20), a.add.m1, a.add.s1);
             add_lut[1][tid] = mbqm((v - a.pw_zp_out) * (1 << 20), a.add.m2, a.add.s2);
@@ -198,10 +209,13 @@ __global__ __launch_bounds__(kPwLdsThreads) void i8_pw_lds_kernel(DwPw8Args a, P
                     if constexpr (HI) {
                         const long long C = (long long)(((unsigned long long)(unsigned)chi[e] << 32) | (unsigned)clo[e]);
                         qv[e] = med3i((int)(((long long)acc[ct0 + u][e] * m[e] + C) >> 32) >> sh[e], a.pw_amin, a.pw_amax);
+                    } else if (ADD && g.tab) {  // (uniform) own value + 128 = the table's column; the ADD is one byte read
+                        const int own = med3i(mbqm_right(acc[ct0 + u][e], m[e], sh[e]) + (a.pw_zp_out + 128), a.pw_amin + 128, a.pw_amax + 128);
+                        qv[e] = tabl[__builtin_amdgcn_perm((unsigned)rv4[u], (unsigned)own, 0x0c0c0400u + (e << 8))];
                     } else {  // every multiplier >= 0 and every shift < 0 (checked at load): the branch-free signed form
                         qv[e] = med3i(mbqm_right(acc[ct0 + u][e], m[e], sh[e]) + a.pw_zp_out, a.pw_amin, a.pw_amax);
                     }
-                    if (ADD) {
+                    if (ADD && !g.tab) {
                         const int sa = add_lut[0][(rv4[u] >> (8 * e)) & 0xff];
                         const int sb = add_lut[1][qv[e] & 0xff];
                         qv[e] = med3i(mbqm(sa + sb, a.add.mo, a.add.so) + a.add.zo, a.add.amin, a.add.amax);  // (uniform parameters: the form is chosen once)
@@ -254,7 +268,8 @@ void launch_i8_pw_lds(const DwPw8Args& a, hipStream_t s) {
     if (walkers > need) walkers = need;
     g.walkers = (int)walkers;
     const unsigned blocks = (unsigned)(walkers * g.n_slices);
-    const size_t smem = (size_t)g.ns * (a.Cin + 20);
+    g.tab = a.add.enabled && a.add_tab && g_opt.i8_add_tab && (a.rq_right & 4) && (size_t)g.ns * (a.Cin + 20) + 65536 <= kPwLdsBudget ? 1 : 0;
+    const size_t smem = (size_t)g.ns * (a.Cin + 20) + (g.tab ? 65536 : 0);
     const bool hi = (a.rq_right & 2) && a.pw_amin >= a.pw_zp_out;
 #define BN_PWL1(ADDV, GATEV, KSV, NCTV, HIV)                                                                                    \
     do {                                                                                                                        \

@@ -36,6 +36,8 @@ struct Options {
                                // slice of output channels resident in LDS, squeeze-excite MUL applied on load (0: tile kernel + i8_scale)
     int i8_pw_forms = 1;       // i8_pw_wave_kernel / i8_dw_stream_kernel pick their requantisation form at compile time where the operator's constants allow
                                // (sign-free one-multiply-add form behind ReLU, branch-free right-shift form elsewhere); 0: the runtime-uniform general code
+    int i8_add_tab = 1;        // projections with a residual ADD (i8_pw_wave / i8_pw_lds kernels): the ADD as one lookup in a 64 KB table in LDS
+                               // (1024-thread workgroups, one per CU); 0: two 256-entry rescale tables + the output requantisation on the vector ALU
     int i8_tail_fclds = 1;     // the fused tail's head reads the classifier matrix from an LDS copy (0: from memory, 64 dependent loads per thread)
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
@@ -309,6 +311,8 @@ struct DwPw8Args {
     // plain 1x1 convolution behind a squeeze-excite MUL (i8_pw_wave_kernel only): x is the UNSCALED map, the gate is applied on load
     const int8_t* gate;    // [B][Cin] or null
     int g_zx, g_zg, g_mult, g_shift, g_zo, g_amin, g_amax;
+    // plain 1x1 convolution + ADD: the whole ADD as a table [256 residual byte patterns][own value + 128] (packer: add_table) or null
+    const int8_t* add_tab;
 };
 bool i8_dwpw_supported(int Cin, int Cout);
 bool i8_pwdw_supported(const DwPw8Args& expand, const I8ConvGeom& dw);

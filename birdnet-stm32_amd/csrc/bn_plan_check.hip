@@ -254,6 +254,7 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                     c.conv_geom(p[0], p[1], p[3], p[4], p[6], p[7], p[8], p[9]) && c.tensor(0, 9LL * p[2], "depthwise weights") && c.tensor(1, 4LL * p[2], "depthwise bias") &&
                         c.tensor(2, 4LL * p[2], "depthwise multipliers") && c.tensor(3, 4LL * p[2], "depthwise shifts");
                 if (c.ok && !p[29] && (p[0] != p[6] || p[1] != p[7])) c.bad("plain 1x1 convolution must keep the map size");
+                if (c.ok && !p[29] && p[18] && o.t[10] >= 0) c.tensor(10, 65536, "ADD table");
                 if (c.ok && (p[31] < 1 || p[32] < 1 || p[33] < 1)) c.bad("tile %dx%dx%d", p[31], p[32], p[33]);
                 // the transposed form is the mel mixer: a plain 1x1 over the frames of one chunk, no residual; only it takes a table or float32 input
                 if (c.ok && p[30] && (p[29] || p[18] || p[0] != 1 || p[6] != 1 || p[33] != 1)) c.bad("transposed output on a block that is not a mel mixer");

@@ -475,6 +475,8 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
         assert np.array_equal(prod.predict(x), got)
     with _hip.options(i8_pw_lds=0):  # the dense late 1x1 convolutions (Cin 192 / 384 / 768) through the tile kernel + a separate MUL: same integers
         assert np.array_equal(prod.predict(x), got)
+    with _hip.options(i8_add_tab=0):  # residual ADD behind a projection on the vector ALU instead of the 64 KB table in LDS
+        assert np.array_equal(prod.predict(x), got)
     with _hip.options(i8_pw_forms=0):  # general requantisation code instead of the compile-time forms of i8_pw_wave_kernel / i8_dw_stream_kernel
         assert np.array_equal(prod.predict(x), got)
     prod.close()
