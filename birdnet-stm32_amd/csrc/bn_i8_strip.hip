@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
     const int sr0 = 2 * oh0;                        // first stem row of the strip (depthwise: stride 2, no top padding)
     const int rows_needed = 2 * (nrows - 1) + 3;
 
-    v2i raw[2];
+    constexpr int FD = 6;  // input rows requested ahead (slot = row % FD, static under the six-row unrolling below)
+    v2i raw[FD];
     TRow<1> T[3];
 
     // stem row sr0 + srel: lane (n, kq) reads input row sr - 1 + kq (the stem's top padding is row -1)
@@ -589,19 +590,19 @@ __global__ __launch_bounds__(256) void i8_front_strip_kernel(FrontStrip8Args a) 
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out, oh * a.OW * 32, 0);
     };
 
-    issue(0, 0);
-    issue(1, 1);
+#pragma unroll
+    for (int rr = 0; rr < FD; ++rr) issue(rr, rr);
     stem_row(0, 0, 0);
-    issue(0, 2);
+    issue(0, FD);
     for (int k = 0; k < nrows; k += 3) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             if (k + u >= nrows) break;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int rs = 1 + 2 * u + s;  // static part of the relative stem row (k is a multiple of 3 output rows)
-                stem_row(rs & 1, 2 * k + rs, rs % 3);
-                issue(rs & 1, 2 * k + rs + 2);
+                const int rs = 1 + 2 * u + s;  // static part of the relative stem row (k is a multiple of 3 output rows = 6 stem rows)
+                stem_row(rs % FD, 2 * k + rs, rs % 3);
+                issue(rs % FD, 2 * k + rs + FD);
             }
             emit((2 * u) % 3, (2 * u + 1) % 3, (2 * u + 2) % 3, oh0 + k + u);
         }
