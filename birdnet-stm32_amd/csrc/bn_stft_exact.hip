@@ -59,6 +59,7 @@ __device__ __forceinline__ size_t spec_offset(int W, bool tile_major, int k, int
 struct F64Lds {
     double cs[512];          // cos(2 pi e / 512); sin(2 pi e / 512) = cs[(e + 384) & 511]
     double2 buf[4][2][320];  // per wave: ping / pong (256 elements, one gap per four: fslot)
+    double2 win[256];        // window values of sample pairs (2 n, 2 n + 1): read per frame (in registers they cost the third workgroup per CU)
     float red_min[4], red_max[4];
 };
 
@@ -74,13 +75,12 @@ __device__ __forceinline__ int fslot(int i) { return i + (i >> 2); }
 // everything that depends on the lane only, loaded once per workgroup and kept in registers across tiles and frames: the window values of the
 // lane's 8 samples, the twiddles of its butterfly in passes 1-3 and of its 4 (+1) bins in the split pass
 struct F64Regs {
-    double2 win[4], tw[3][3], tws[5];
+    double2 tw[3][3], tws[5];
     __device__ __forceinline__ void load(const F64Lds& L, const StftTables& tb) {  // after cs is staged and a barrier
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = lane + 64 * i;
-            win[i] = make_double2(tb.hann64[2 * n], tb.hann64[2 * n + 1]);
             tws[i] = make_double2(L.cs[n], L.cs[(n + 384) & 511]);
         }
         tws[4] = make_double2(L.cs[256], L.cs[(256 + 384) & 511]);
@@ -103,23 +103,36 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const F64Regs& R, const floa
     double2* A = L.buf[wave][0];
     double2* Bf = L.buf[wave][1];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
-    const double2 (&win)[4] = R.win;
     const double2 (&tw)[3][3] = R.tw;
     const double2 (&tws)[5] = R.tws;
-    for (int ff = wave; ff < kFT && t0 + ff < W; ff += 4) {
-        const int t = t0 + ff;
-        const long base = (long)t * hop - 256;
+    // A wave takes FOUR CONSECUTIVE frames of the tile (4 wave .. 4 wave + 3): in the tile-major layout their magnitudes of one bin are 16 contiguous
+    // bytes, written as one dwordx4 per bin when the four are done (a scalar store per frame and bin was 64 four-byte pieces per instruction).
+    // The samples of the next frame are requested before the current one is transformed (the walk was a load round trip + a transform per frame).
+    auto request = [&](int t, float (&xs)[4][2]) {
         // range-checked raw buffer loads over exactly this chunk: samples before / behind it read as 0 (librosa's centre padding), no selects,
-        // all eight loads of the lane in flight together
-        float xs[4][2];
+        // all eight loads of the lane in flight together; a frame past the spectrogram's end requests nothing real (offsets behind the buffer)
+        const long base = (long)t * hop - 256;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int off = (int)((base + 2 * (lane + 64 * i)) * 4);
+            const int off = t < W ? (int)((base + 2 * (lane + 64 * i)) * 4) : 0x7ffffff0;
             xs[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
-            xs[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
+            xs[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off < 0x7ffffff0 ? off + 4 : off, 0, 0));
         }
+    };
+    float xs[4][2], xn[4][2];
+    float mag[5][4];
+    const int f_lo = t0 + 4 * wave;
+    request(f_lo, xs);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) A[fslot(lane + 64 * i)] = make_double2((double)xs[i][0] * win[i].x, (double)xs[i][1] * win[i].y);
+    for (int fi = 0; fi < 4; ++fi) {
+        const int t = f_lo + fi;
+        if (fi < 3) request(t + 1, xn);
+        if (t < W) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double2 wv = L.win[lane + 64 * i];
+            A[fslot(lane + 64 * i)] = make_double2((double)xs[i][0] * wv.x, (double)xs[i][1] * wv.y);
+        }
         wave_lds_sync();
         double2* src = A;
         double2* dst = Bf;
@@ -157,11 +170,34 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const F64Regs& R, const floa
             const double2 O = make_double2(D.y, -D.x);
             const double2 WO = cmul_tw(O, tws[i].x, tws[i].y);
             const float m = numpy_cabsf((float)(E.x + WO.x), (float)(E.y + WO.y));
-            out[spec_offset(W, tile_major, k, t)] = m;
+            mag[i][fi] = m;
             lmin = fminf(lmin, m);
             lmax = fmaxf(lmax, m);
         }
         wave_lds_sync();  // the next frame overwrites A
+        }
+        if (fi < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xs[i][0] = xn[i][0];
+                xs[i][1] = xn[i][1];
+            }
+        }
+    }
+    if (f_lo < W) {
+        const bool four = tile_major && f_lo + 3 < W;  // (W is a multiple of 4 in every shipped geometry; the scalar path covers the rest)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = lane + 64 * i;
+            if (i == 4 && lane != 0) break;
+            if (four) {
+                *reinterpret_cast<float4*>(out + spec_offset(W, true, k, f_lo)) = make_float4(mag[i][0], mag[i][1], mag[i][2], mag[i][3]);
+            } else {
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi)
+                    if (f_lo + fi < W) out[spec_offset(W, tile_major, k, f_lo + fi)] = mag[i][fi];
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -185,6 +221,7 @@ __global__ __launch_bounds__(256, 3) void stft512_f64_kernel(StftTables tb, cons
                                                           float* __restrict__ spec, float* minmax, int tile_major) {
     __shared__ F64Lds L;
     for (int i = threadIdx.x; i < 512; i += 256) L.cs[i] = tb.cs64[i];
+    L.win[threadIdx.x] = make_double2(tb.hann64[2 * threadIdx.x], tb.hann64[2 * threadIdx.x + 1]);
     __syncthreads();
     F64Regs R;
     R.load(L, tb);
@@ -200,6 +237,7 @@ __global__ __launch_bounds__(256, 3) void stft512_f64_list_kernel(StftTables tb,
     const int n_tiles = (W + kFT - 1) / kFT, n = *n_list * n_tiles;
     if ((int)blockIdx.x >= n) return;
     for (int i = threadIdx.x; i < 512; i += 256) L.cs[i] = tb.cs64[i];
+    L.win[threadIdx.x] = make_double2(tb.hann64[2 * threadIdx.x], tb.hann64[2 * threadIdx.x + 1]);
     __syncthreads();
     F64Regs R;
     R.load(L, tb);
