@@ -179,15 +179,18 @@ def plan_files(paths: list[str], sample_rate: int, chunk_duration: float, chunk_
     return FileTable(list(paths), kind, fmt, ch, sr0, frames, file_off, nbytes, n_out, n_chunks, decoded)
 
 
-def cut_groups(nbytes: np.ndarray, n_chunks: np.ndarray, slab_bytes: int, group_chunks: int) -> list[tuple[int, int]]:
+def cut_groups(nbytes: np.ndarray, n_chunks: np.ndarray, slab_bytes: int, group_chunks: int, ramp: tuple = (8, 4, 2)) -> list[tuple[int, int]]:
     """Greedy contiguous groups of files: at most ``group_chunks`` chunks, ``slab_bytes`` bytes (with per-sub-group alignment slack)
-    and ``MAX_WINDOWS_PER_GROUP`` files each; a single file larger than either limit forms its own group."""
+    and ``MAX_WINDOWS_PER_GROUP`` files each; a single file larger than either limit forms its own group.  The first ``len(ramp)``
+    groups are cut at ``slab_bytes / ramp[i]``: the copy stream has nothing to do until the first slab is read, so the pipeline starts
+    on a small one (a full 256 MB slab costs ~4.5 ms of reading before the first byte crosses the bus)."""
     n = int(nbytes.shape[0])
     cb = np.concatenate([[0], np.cumsum(nbytes + _ALIGN)])
     cc = np.concatenate([[0], np.cumsum(n_chunks)])
     groups, a = [], 0
     while a < n:
-        b = int(min(np.searchsorted(cb, cb[a] + slab_bytes, side="right") - 1, np.searchsorted(cc, cc[a] + group_chunks, side="right") - 1,
+        div = ramp[len(groups)] if len(groups) < len(ramp) else 1
+        b = int(min(np.searchsorted(cb, cb[a] + slab_bytes // div, side="right") - 1, np.searchsorted(cc, cc[a] + group_chunks, side="right") - 1,
                     a + MAX_WINDOWS_PER_GROUP))
         b = max(b, a + 1)
         groups.append((a, b))
@@ -323,7 +326,8 @@ class EvaluatePipeline:
     """
 
     def __init__(self, runner, sample_rate: int, chunk_duration: float, chunk_overlap: float = 0.0, max_duration=60,
-                 slab_bytes: int = 256 << 20, group_chunks: int | None = None, readers: int | None = None, pinned_slabs: int = 3):
+                 slab_bytes: int = 256 << 20, group_chunks: int | None = None, readers: int | None = None, pinned_slabs: int = 3,
+                 ramp: tuple = (8, 4, 2)):
         import torch
 
         self.torch = torch
@@ -332,6 +336,7 @@ class EvaluatePipeline:
         self.dev = runner.device
         self.sr, self.cd, self.ov, self.max_duration = int(sample_rate), float(chunk_duration), float(chunk_overlap), max_duration
         self.slab_bytes = int(slab_bytes)
+        self.ramp = tuple(ramp)  # first groups cut at slab_bytes / ramp[i] (cut_groups)
         self.group_chunks = int(group_chunks or max(runner.max_batch, 1024))
         self.readers = int(readers or _pcmio.default_threads())
         self.n_pinned = max(2, int(pinned_slabs))
@@ -470,7 +475,7 @@ class EvaluatePipeline:
                 self.copy_stream = torch.cuda.Stream(device=self.dev)
             tab = plan_files(paths, self.sr, self.cd, self.ov, self.max_duration, self.readers)
             stats["probe_s"] = time.perf_counter() - t_start
-            groups = cut_groups(tab.nbytes, tab.n_chunks, self.slab_bytes, self.group_chunks)
+            groups = cut_groups(tab.nbytes, tab.n_chunks, self.slab_bytes, self.group_chunks, self.ramp)
             planned = int(tab.n_chunks.sum())
             # size the rings for the largest group once, before the producer starts (nothing is reallocated while copies are in flight)
             cb = np.concatenate([[0], np.cumsum(tab.nbytes + _ALIGN)])

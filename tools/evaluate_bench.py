@@ -112,6 +112,7 @@ def main(argv=None) -> int:
     ap.add_argument("--serial_files", type=int, default=512)
     ap.add_argument("--max_batch", type=int, default=4096)
     ap.add_argument("--slab_mb", type=int, default=256)
+    ap.add_argument("--no_ramp", action="store_true", help="every group a full slab (A/B of the small first groups)")
     ap.add_argument("--readers", type=int, default=0)
     ap.add_argument("--batch_size", type=int, default=16)
     ap.add_argument("--latency", action="store_true", help="one more run with measure_latency (slices of --batch_size)")
@@ -148,6 +149,8 @@ def main(argv=None) -> int:
         log(f"pinned H2D copy: {rate:.1f} GB/s")
         runner = load_model_runner(ckpt + (".tflite" if args.dtype == "i8" else ".keras"), max_batch=args.max_batch)
         opts = {"slab_bytes": args.slab_mb << 20}
+        if args.no_ramp:
+            opts["ramp"] = ()
         if args.readers:
             opts["readers"] = args.readers
         runs = []
