@@ -40,14 +40,53 @@ __device__ __forceinline__ v2f mul_neg_i(v2f a) {  // a * (-i) = (a.y, -a.x)
     return t;
 }
 
+// a + (-i) b = (a.x + b.y, a.y - b.x) and a - (-i) b = (a.x - b.y, a.y + b.x) as ONE packed add each: the swap of b's halves goes into op_sel, the sign into
+// neg_hi / neg_lo (the compiler built (b.y, -b.x) with a v_xor and moves first: ~65 + 100 of the STFT kernel's 794 vector instructions).  Same roundings:
+// x - y and x + (-y) are the same IEEE operation.
+__device__ __forceinline__ v2f add_neg_i(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f sub_neg_i(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// complex a * b and a * b + c with the rotation (-b.y, b.x) of the second product folded into op_sel / neg_lo — the same two roundings per component as
+// cmulr (t = a.x b, then fma(a.y, rot b, t)), without building rot b
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f cmul_add(v2f a, v2f b, v2f c) {  // fma(a.y, rot b, fma(a.x, b, c))
+    v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a + conj b and a - conj b
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // forward 4-point DFT, natural order in and out
 __device__ __forceinline__ void fft4(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {
     const v2f s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = x1 - x3;
-    const v2f r = mul_neg_i(d13);
     x0 = s02 + s13;
     x2 = s02 - s13;
-    x1 = d02 + r;
-    x3 = d02 - r;
+    x1 = add_neg_i(d02, d13);
+    x3 = sub_neg_i(d02, d13);
 }
 
 #define BN_TW(c, s) (v2f){c, s}, (v2f){-(s), c}
@@ -216,8 +255,7 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
             const v4f wl = reinterpret_cast<const v4f*>(tb.tw256)[j];
             v2f p[16];
             p[1] = (v2f){wl.x, wl.y};
-#define BN_ROT(z) ((v2f){-(z).y, (z).x})
-#define BN_CM(u, v) cmulr(u, v, BN_ROT(v))
+#define BN_CM(u, v) cmul(u, v)
             p[2] = BN_CM(p[1], p[1]);
             p[3] = BN_CM(p[2], p[1]);
             p[4] = BN_CM(p[2], p[2]);
@@ -230,7 +268,6 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
 #pragma unroll
             for (int k1 = 1; k1 < 16; ++k1) a[fidx(k1)] = BN_CM(a[fidx(k1)], p[k1]);
 #undef BN_CM
-#undef BN_ROT
         }
         // 16 x 16 transpose through LDS, real parts first: a[n].x may be overwritten as soon as every x of the frame has been written
 #pragma unroll
@@ -270,13 +307,10 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
         for (int k2 = 0; k2 < 16; ++k2) {
             const int k = j + 16 * k2;
             const v2f z = a[fidx(k2)];
-            v2f pc = partner[k2];
-            pc.y = -pc.y;  // conj
-            const v2f e = z + pc, o = z - pc;
+            const v2f pc = partner[k2];
+            const v2f e = add_conj(z, pc), o = sub_conj(z, pc);
             const v2f tk = __builtin_elementwise_fma(tq, (v2f){kSin16[k2], kSin16[k2]}, tp * (v2f){kCos16[k2], kCos16[k2]});  // -i W512^k
-            v2f tkr = BN_SWAP(tk);
-            tkr.x = -tkr.x;  // its rotation (-t.y, t.x)
-            const v2f xr = __builtin_elementwise_fma(BN_YY(o), tkr, __builtin_elementwise_fma(BN_XX(o), tk, e));
+            const v2f xr = cmul_add(o, tk, e);  // o.y (-tk.y, tk.x) + (o.x tk + e)
             const v2f sq = xr * xr;
             const float m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
             mag[k][f] = m;
