@@ -343,6 +343,45 @@ def test_config5_full_batch_properties(torch_mod, seconds):
     small.close()
 
 
+def test_config5_int8_full_batch_properties(torch_mod):
+    """BASELINE configs[4] through this build's INT8 exporter (raw frontend, 2 s @ 24 kHz — the bench line's ``also_measured_configs4_int8``) at
+    B = 1024, where the persistent pointwise kernels walk long runs of groups per wave (the per-tensor parity against the INT8 oracle runs at small
+    batches in tests/test_conversion.py): repeated runs are bit-identical, a chunk's scores do not depend on its batch position, neighbours or the
+    workspace size, and every kernel-selection switch of the exported-graph path reproduces the same bytes at this size."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.conversion.export import convert_netspec_to_int8
+    from birdnet_stm32.models import build_model
+    from birdnet_stm32.models._lower_i8 import lower_i8
+    from birdnet_stm32.models._tflite_reader import parse_tflite
+    from birdnet_stm32.models._tflite_writer import write_tflite
+    from birdnet_stm32.models.runners import HipRunner
+
+    spec = build_model("dscnn", num_mels=64, spec_width=256, sample_rate=24000, chunk_duration=2, embeddings_size=256, num_classes=100,
+                       audio_frontend="raw", mag_scale="pcen", alpha=1.5, use_se=True, use_inverted_residual=True, randomize_bn=True, seed=42)
+    rng = np.random.default_rng(0)
+    cal = [rng.standard_normal((1, 48000, 1)).astype(np.float32) for _ in range(8)]
+    cal = [c / (np.abs(c).max() + 1e-6) for c in cal]
+    model = parse_tflite(write_tflite(convert_netspec_to_int8(spec, lambda: ([c] for c in cal))))
+    base = torch.from_numpy(synth_chunks(64)[:, :48000].copy()).cuda()
+    base = base / base.abs().amax(dim=1, keepdim=True)
+    B = 1024
+    idx = torch.randint(0, 64, (B,), generator=torch.Generator().manual_seed(5)).cuda()
+    audio = base[idx].contiguous()
+    big = HipRunner(lower_i8(model), max_batch=B)
+    s1 = big.infer_audio_device(audio).clone()
+    assert torch.equal(s1, big.infer_audio_device(audio)), "run-to-run determinism"
+    assert torch.isfinite(s1).all() and float((s1.sum(dim=1) - 1).abs().max()) < 1e-5
+    small = HipRunner(lower_i8(model), max_batch=96)
+    ref64 = small.infer_audio_device(base)
+    assert torch.equal(s1, ref64[idx]), "a chunk's scores depend on its batch position / neighbours"
+    small.close()
+    for opts in (dict(i8_add_tab=0), dict(i8_pw_forms=0), dict(i8_pw_lds=0), dict(i8_dw_pool=0), dict(i8_pw_forms=0, i8_add_tab=0, i8_pw_lds=0)):
+        with _hip.options(**opts):
+            assert torch.equal(big.infer_audio_device(audio), s1), opts
+    big.close()
+
+
 # ------------------------------------------------------------------------------------------ fused INT8 tail
 def test_i8_fused_tail_matches_per_block_kernels_and_oracle(torch_mod):
     """The back half of the INT8 graph as one kernel (i8_tail_kernel: stage 3-4 + MEAN + FULLY_CONNECTED + head, maps in LDS) against
