@@ -75,7 +75,7 @@ __device__ __forceinline__ int fslot(int i) { return i + (i >> 2); }
 // everything that depends on the lane only, loaded once per workgroup and kept in registers across tiles and frames: the window values of the
 // lane's 8 samples, the twiddles of its butterfly in passes 1-3 and of its 4 (+1) bins in the split pass
 struct F64Regs {
-    double2 tw[3][3], tws[5];
+    double2 tw[3][3], tws[4];
     __device__ __forceinline__ void load(const F64Lds& L, const StftTables& tb) {  // after cs is staged and a barrier
         const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -83,7 +83,6 @@ struct F64Regs {
             const int n = lane + 64 * i;
             tws[i] = make_double2(L.cs[n], L.cs[(n + 384) & 511]);
         }
-        tws[4] = make_double2(L.cs[256], L.cs[(256 + 384) & 511]);
 #pragma unroll
         for (int pass = 1; pass < 4; ++pass) {
             const int e1 = (lane & ((1 << (2 * pass)) - 1)) * (128 >> (2 * pass));  // 512 (j mod Ns) / (4 Ns)
@@ -104,7 +103,7 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const F64Regs& R, const floa
     double2* Bf = L.buf[wave][1];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
     const double2 (&tw)[3][3] = R.tw;
-    const double2 (&tws)[5] = R.tws;
+    const double2 (&tws)[4] = R.tws;
     // A wave takes FOUR CONSECUTIVE frames of the tile (4 wave .. 4 wave + 3): in the tile-major layout their magnitudes of one bin are 16 contiguous
     // bytes, written as one dwordx4 per bin when the four are done (a scalar store per frame and bin was 64 four-byte pieces per instruction).
     // The samples of the next frame are requested before the current one is transformed (the walk was a load round trip + a transform per frame).
@@ -160,19 +159,28 @@ __device__ __forceinline__ void f64_tile(F64Lds& L, const F64Regs& R, const floa
             dst = tmp;
         }
         // four passes: the transform is back in A (= src).  Split pass: E = (Z_k + conj Z_-k) / 2, O = (Z_k - conj Z_-k) / (2 i), X_k = E + W^k O
+        // (the halves are taken once, on the sum: scaling by 1/2 is exact and commutes with every rounding, so 2 E + W (2 O) halved is bit for bit
+        // E + W O.  The Nyquist bin X[256] = Re Z[0] - Im Z[0] comes out of lane 0's k = 0 step: as a fifth step it cost every lane a masked pass.)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int k = lane + 64 * i;
-            if (i == 4 && lane != 0) break;
-            const double2 zk = src[fslot(k & 255)], zm = src[fslot((256 - k) & 255)];
-            const double2 E = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-            const double2 D = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
-            const double2 O = make_double2(D.y, -D.x);
-            const double2 WO = cmul_tw(O, tws[i].x, tws[i].y);
-            const float m = numpy_cabsf((float)(E.x + WO.x), (float)(E.y + WO.y));
+            const double2 zk = src[fslot(k)], zm = src[fslot((256 - k) & 255)];
+            const double2 S2 = make_double2(zk.x + zm.x, zk.y - zm.y);   // 2 E
+            const double2 D2 = make_double2(zk.x - zm.x, zk.y + zm.y);
+            const double2 O2 = make_double2(D2.y, -D2.x);                // 2 O
+            const double2 WO = cmul_tw(O2, tws[i].x, tws[i].y);
+            const float m = numpy_cabsf((float)(0.5 * (S2.x + WO.x)), (float)(0.5 * (S2.y + WO.y)));
             mag[i][fi] = m;
             lmin = fminf(lmin, m);
             lmax = fmaxf(lmax, m);
+            if (i == 0) {  // (only lane 0's value is stored and enters the reduction)
+                const float ny = fabsf((float)(zk.x - zk.y));
+                mag[4][fi] = ny;
+                if (lane == 0) {
+                    lmin = fminf(lmin, ny);
+                    lmax = fmaxf(lmax, ny);
+                }
+            }
         }
         wave_lds_sync();  // the next frame overwrites A
         }
