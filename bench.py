@@ -775,7 +775,7 @@ def main() -> None:
                 "path": "audio in HBM -> STFT -> mel+PWL -> DS-CNN -> scores in HBM" + gather_note,
                 "distinct_input_batches_per_gpu": n_distinct,
                 "int8_input_bytes": ("float32 STFT + float64 pass over every element whose byte the float32 error could change, inside the timed region: the reference's "
-                                     "bytes on every input checked (0 differing bytes on 3e6 soaked chunks, profiles/r03_exact_soak.txt; again on 2.5e5 chunks of 12 families with this round's kernels, profiles/r04_exact_soak.txt). The guard's error bound is "
+                                     "bytes on every input checked (0 differing bytes on 3e6 soaked chunks, profiles/r03_exact_soak.txt; again on 1.4e6 chunks of 12 families with round 4's kernels, profiles/r04_exact_soak.txt). The guard's error bound is "
                                      "EMPIRICAL (4 x the largest error seen; largest observed |S' - S| / eps = 0.343 over 2.2e11 elements), not a worst-case proof; "
                                      "bn_set_option('stft_exact', 1) computes every bin in float64 and needs no bound") if args.dtype == "i8" else None,
             },
