@@ -696,17 +696,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (v4i){0, 0, 0, 0};
     const int ksteps = Kp >> 6;
-    v4i bf = wp[((size_t)0 * n_ct + wv) * 64 + lane];
-    for (int s = 0; s < ksteps; ++s) {
-        v4i bnext = bf;
-        if (s + 1 < ksteps) bnext = wp[((size_t)(s + 1) * n_ct + wv) * 64 + lane];
+    // every k-step's B fragment (the wave's 16 mel bins) and the per-bin constants requested TOGETHER up front: fetched one step ahead inside the loop they
+    // were five dependent L2 round trips per workgroup (four matrix instructions per k-step hide ~64 of a round trip's ~700 cycles).  Not before the
+    // barrier above: 23 more live registers across the float64 settle spilled.
+    constexpr int kPreK = 5;  // k-steps kept in registers (Kp <= 320: the 257-bin spectrogram padded to 320)
+    v4i bpre[kPreK];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16[(16 * g + r) * S16 + 4 * s + q], bf, acc[g], 0, 0, 0);
-        bf = bnext;
+    for (int s = 0; s < kPreK; ++s) bpre[s] = wp[((size_t)(s < ksteps ? s : 0) * n_ct + wv) * 64 + lane];
+    const int cpre[3] = {a.pw_b[16 * wv + r], a.pw_mult[16 * wv + r], a.pw_shift[16 * wv + r]};
+    if (ksteps <= kPreK) {
+#pragma unroll
+        for (int s = 0; s < kPreK; ++s) {
+            if (s < ksteps) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16[(16 * g + r) * S16 + 4 * s + q], bpre[s], acc[g], 0, 0, 0);
+            }
+        }
+    } else {
+        v4i bf = wp[((size_t)0 * n_ct + wv) * 64 + lane];
+        for (int s = 0; s < ksteps; ++s) {
+            v4i bnext = bf;
+            if (s + 1 < ksteps) bnext = wp[((size_t)(s + 1) * n_ct + wv) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16[(16 * g + r) * S16 + 4 * s + q], bf, acc[g], 0, 0, 0);
+            bf = bnext;
+        }
     }
     // lane (n = r, q): accumulator register reg of row group g = frame t0 + 16 g + 4 q + reg of mel bin 16 wv + r
     const int mel = 16 * wv + r;
-    const int b = a.pw_b[mel], m = a.pw_mult[mel], sh = a.pw_shift[mel];
+    const int b = cpre[0], m = cpre[1], sh = cpre[2];
     const bool rq = (a.rq_right & 1) != 0;
     int8_t* yrow = a.y + ((size_t)chunk * M + mel) * W + t0 + 4 * q;
 #pragma unroll
