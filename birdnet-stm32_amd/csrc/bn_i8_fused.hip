@@ -490,8 +490,25 @@ __global__ __launch_bounds__(256) void i8_front_kernel(Front8Args a) {
 // boundary: 4 instructions per element); 2 = run only the (chunk, block) pairs of the work list (the blocks whose bytes the
 // float64 pass changed), nothing is listed.
 constexpr int kMelFlagCap = 1022;  // flagged elements a workgroup keeps in LDS before it hands them to the chunk's list
+// BN_TAIL_STAMPS (the measurement build lib/libbirdnet_hip_stamps.so, tools/mel_stamps.py; never defined in the production library): the waves of
+// kMelStampWg workgroups from the MIDDLE of the guarded mixer's grid record when they started, had quantised their block, left the barrier behind the
+// tile, finished the float64 settle, the matrix phase and the epilogue (s_memrealtime, 10 ns ticks).
+#ifdef BN_TAIL_STAMPS
+__device__ long long* g_mel_stamps = nullptr;   // [kMelStampWg][4 waves][8]
+constexpr int kMelStampWg = 1024;
+#define BN_MSTAMP(i) do { if (MODE == 1 && mstamp) mst[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BN_MSTAMP(i) do {} while (0)
+#endif
+
 template <bool QIN, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 4, 8))) void i8_mel_mfma_kernel(DwPw8Args a) {
+#ifdef BN_TAIL_STAMPS
+    long long mst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int mslot = (int)blockIdx.x - (int)gridDim.x / 2;
+    const bool mstamp = MODE == 1 && g_mel_stamps && mslot >= 0 && mslot < kMelStampWg;
+#endif
+    BN_MSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
     __shared__ int flag_n, flags[MODE == 1 ? kMelFlagCap : 1];
     __shared__ std::conditional_t<MODE == 1, ExactTabsW, int> xtabs_s;  // float64 twiddles + window for the elements this workgroup re-evaluates itself
@@ -640,7 +657,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         }
         }
     }
+    BN_MSTAMP(1);
     __syncthreads();
+    BN_MSTAMP(2);
     if constexpr (MODE == 1) {
         // The elements in doubt are settled HERE, before the tile is multiplied: a 16-lane row per element re-evaluates it the reference's way
         // (float64 DFT over the frame's 512 samples, complex64, numpy's |.|: bn_exact_dft.h), the byte in the tile and the value in the
@@ -688,6 +707,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             __syncthreads();
         }
     }
+    BN_MSTAMP(3);
     const int lane = tid & 63, wv = tid >> 6;  // wave wv: mel bins 16 wv .. 16 wv + 15
     const int r = lane & 15, q = lane >> 4;
     const v4i* wp = reinterpret_cast<const v4i*>(a.pw_w);  // [Kp/64][M/16][64 lanes] x 16 bytes
@@ -722,22 +742,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             bf = bnext;
         }
     }
+#ifdef BN_TAIL_STAMPS
+    asm volatile("" :: "v"(acc[0]), "v"(acc[3]) : "memory");  // (the stamp sits behind the matrix results)
+#endif
+    BN_MSTAMP(4);
     // lane (n = r, q): accumulator register reg of row group g = frame t0 + 16 g + 4 q + reg of mel bin 16 wv + r
     const int mel = 16 * wv + r;
     const int b = cpre[0], m = cpre[1], sh = cpre[2];
     const bool rq = (a.rq_right & 1) != 0;
     int8_t* yrow = a.y + ((size_t)chunk * M + mel) * W + t0 + 4 * q;
+    // all sixteen values first, then all sixteen table reads in flight together (with the lookup inside the loop — a branch around a load per value —
+    // the gathers went out one round trip at a time: 4.3 of a wave's 19 us, tools/mel_stamps.py)
+    int qv[4][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        int packed = 0;
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int qv = clampi(mbqm_u(acc[g][e] + b, m, sh, rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
-            if (a.lut) qv = a.lut[mel * 256 + qv + 128];
-            packed |= (qv & 0xff) << (8 * e);
-        }
-        *reinterpret_cast<int*>(yrow + 16 * g) = packed;
+        for (int e = 0; e < 4; ++e) qv[g][e] = clampi(mbqm_u(acc[g][e] + b, m, sh, rq) + a.pw_zp_out, a.pw_amin, a.pw_amax);
+    if (a.lut) {  // (uniform)
+        const int8_t* lrow = a.lut + mel * 256 + 128;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[g][e] = lrow[qv[g][e]];
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<int*>(yrow + 16 * g) = pack4(qv[g]);
+    BN_MSTAMP(5);
+#ifdef BN_TAIL_STAMPS
+    if (mstamp && (tid & 63) == 0) {
+        long long* o = g_mel_stamps + ((size_t)mslot * 4 + (tid >> 6)) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = mst[i];
+        o[6] = flag_n;
+    }
+#endif
     }
 }
 
@@ -1190,3 +1227,10 @@ void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
 }
 
 }  // namespace bn
+
+#ifdef BN_TAIL_STAMPS
+// debug export of the stamps build only: where the guarded mel mixer writes its stamps ([1024][4][8] int64, zeroed by the caller)
+extern "C" __attribute__((visibility("default"))) int bn_debug_mel_stamps(long long* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(bn::g_mel_stamps), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
+}
+#endif
