@@ -638,8 +638,25 @@ __device__ __forceinline__ void rq_hi_setup(RqHi& r, const int (&shift)[4], int 
     }
 }
 
+// BN_TAIL_STAMPS (measurement build only, tools/dw_stamps.py): waves from the middle of the grid of the launch with (C, H) = g_dw_sel record when
+// they started, had their constants and first rows, finished the row walk and the pooling atomics (s_memrealtime, 10 ns ticks)
+#ifdef BN_TAIL_STAMPS
+__device__ long long* g_dw_stamps = nullptr;   // [kDwStampWaves][6]
+__device__ int g_dw_sel[2] = {0, 0};
+constexpr int kDwStampWaves = 4096;
+#define BN_DSTAMP(i) do { if (dstamp) dst_[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BN_DSTAMP(i) do {} while (0)
+#endif
+
 template <int S, bool HI>
 __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
+#ifdef BN_TAIL_STAMPS
+    long long dst_[4] = {0, 0, 0, 0};
+    const long dslot = ((long)blockIdx.x - (long)gridDim.x / 2) * 4 + (threadIdx.x >> 6);
+    const bool dstamp = g_dw_stamps && a.C == g_dw_sel[0] && a.H == g_dw_sel[1] && dslot >= 0 && dslot < kDwStampWaves;
+#endif
+    BN_DSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int CQ = a.CQ, NCOL = 64 / CQ;
@@ -752,6 +769,10 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
 #pragma unroll
     for (int rr = 0; rr < D; ++rr) issue(rr, rr);
     load_constants();
+#ifdef BN_TAIL_STAMPS
+    asm volatile("" :: "v"(wr[0][0]), "v"(bias[3]) : "memory");  // (the stamp sits behind the constants' arrival)
+#endif
+    BN_DSTAMP(1);
 #pragma unroll
     for (int rr = 0; rr < P; ++rr) {
         consume(rr % D, rr, rr % 3);
@@ -771,6 +792,7 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             emit((S * u) % 3, (S * u + 1) % 3, (S * u + 2) % 3, oh0 + k + u);
         }
     }
+    BN_DSTAMP(2);
     if (a.pool) {
         // squeeze-excite pooling on the way out: integer sums, so the order (lanes, waves, atomics) does not matter — bit-identical to MEAN over the map
 #pragma unroll
@@ -780,6 +802,15 @@ __global__ __launch_bounds__(256) void i8_dw_stream_kernel(DwStream8Args a) {
             if (n == 0) atomicAdd(a.pool + (size_t)chunk * a.C + c0 + e, v);
         }
     }
+    BN_DSTAMP(3);
+#ifdef BN_TAIL_STAMPS
+    if (dstamp && lane == 0) {
+        long long* o = g_dw_stamps + dslot * 6;
+        for (int i = 0; i < 4; ++i) o[i] = dst_[i];
+        o[4] = nrows;
+        o[5] = S;
+    }
+#endif
 }
 
 // The stem of exported graphs (3x3 convolution of the single-channel map, any stride, C output channels) in the same row-streaming
@@ -1238,3 +1269,12 @@ bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& 
 }
 
 }  // namespace bn
+
+#ifdef BN_TAIL_STAMPS
+// debug export of the stamps build only: stamps of the row-streaming depthwise launch with (C, H) ([4096][6] int64, zeroed by the caller)
+extern "C" __attribute__((visibility("default"))) int bn_debug_dw_stamps(long long* d_buf, int C, int H) {
+    const int sel[2] = {C, H};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bn::g_dw_sel), sel, sizeof sel) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(bn::g_dw_stamps), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
+}
+#endif
