@@ -1117,8 +1117,9 @@ void launch_i8_pw_wave(const DwPw8Args& a, hipStream_t s) {
 #define BN_PWWT(NCTV, KSV)                                                                                                                   \
     {                                                                                                                                        \
         const size_t sm = 65536 + smem + (NCTV ? 0 : w_bytes);                                                                               \
-        ensure_dynamic_lds(reinterpret_cast<const void*>(i8_pw_wave_kernel<true, NCTV, KSV, 1, true>), sm);                                  \
-        hipLaunchKernelGGL((i8_pw_wave_kernel<true, NCTV, KSV, 1, true>), dim3(blocks_t), dim3(1024), sm, s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16)); \
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(i8_pw_wave_kernel<true, NCTV, KSV, 1, true>), sm))                              \
+            hipLaunchKernelGGL((i8_pw_wave_kernel<true, NCTV, KSV, 1, true>), dim3(blocks_t), dim3(1024), sm, s, a, n_pos, NCTV ? 0 : (int)(w_bytes / 16)); \
+        else BN_PWW(true, NCTV, KSV, 1); /* (the runtime refused the LDS size: the two-table form) */                                        \
     }
 #define BN_PWW1(NCTV, KSV)                                   \
     {                                                        \
