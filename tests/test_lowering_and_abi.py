@@ -588,6 +588,40 @@ def _emulate_front_strip(cst, fe, p):
     return y.astype(np.int8)
 
 
+def test_add_table_is_the_oracles_add_on_every_byte_pair():
+    """``_lower_i8.add_table`` (the 64 KB table the strip / pointwise kernels look the residual ADD up in) against the oracle's int8 ADD (TFLite's
+    left-shift-20 form, oracle/int8_graph.py) on all 65 536 (residual byte, own byte) pairs, for random scales / zero points / activations and
+    for both operand orders; and the 1x1-convolution + ADD operators of an exported inverted-residual plan carry the table."""
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models import _quant as qz
+    from birdnet_stm32.models._lower_i8 import add_table, lower_i8
+    from oracle.int8_graph import activation_range, mbqm, quantize_multiplier
+
+    rng = np.random.default_rng(11)
+    res = np.arange(256).astype(np.uint8).view(np.int8).astype(np.int64)   # row index = the residual's BYTE PATTERN
+    own = np.arange(256, dtype=np.int64) - 128                             # column index = own value + 128
+    for trial in range(12):
+        s1, s2, so = (float(np.float32(v)) for v in rng.uniform(0.004, 0.2, 3))
+        z1, z2, zo = (int(v) for v in rng.integers(-128, 127, 3))
+        act = ["none", "relu", "relu6"][trial % 3]
+        twice_max = 2.0 * max(s1, s2)
+        m1, m2, mo = quantize_multiplier(s1 / twice_max), quantize_multiplier(s2 / twice_max), quantize_multiplier(twice_max / ((1 << 20) * so))
+        lo, hi = activation_range(act, so, zo)
+        want = np.clip(mbqm((mbqm((res - z1) << 20, *m1))[:, None] + (mbqm((own - z2) << 20, *m2))[None, :], *mo) + zo, lo, hi).astype(np.int8)
+        ap = qz.AddParams(s1, z1, s2, z2, so, zo, act)                     # residual = first operand
+        got = add_table([1, ap.z1, ap.m1, ap.sh1, ap.m2, ap.sh2, ap.mo, ap.sho, ap.zo, ap.amin, ap.amax], z2)
+        assert got.shape == (256, 256) and got.dtype == np.int8 and np.array_equal(got, want), trial
+        ap = qz.AddParams(s2, z2, s1, z1, so, zo, act)                     # residual = second operand: the packer swaps the roles, not the arithmetic
+        got = add_table([1, ap.z2, ap.m2, ap.sh2, ap.m1, ap.sh1, ap.mo, ap.sho, ap.zo, ap.amin, ap.amax], z2)
+        assert np.array_equal(got, want), trial
+    from test_conversion import EXPORT_TOPOLOGIES, _export
+
+    _, model, _, _ = _export(next(v for k, v in EXPORT_TOPOLOGIES.items() if "ir" in k))
+    plan = lower_i8(model)
+    with_add = [o for o in plan.ops if o.kind == pk.I8_DWPW and o.p[18] and not o.p[29]]
+    assert with_add and all(o.t[10] >= 0 and plan.tensors[o.t[10]].nbytes == 65536 for o in with_add)
+
+
 def test_front_strip_constant_block_reproduces_the_oracle():
     """The INT8 front block (stem on the matrix cores + depthwise + pointwise) restated from the strip kernel's constant
     block: bit-identical to the oracle's tensor after the first pointwise convolution."""

@@ -251,6 +251,27 @@ def test_read_windows_and_copy_into_fill_exact_ranges(tmp_path):
     assert np.array_equal(dst[10:343], blobs[4]) and dst[500] == blobs[0][0] and dst[:10].sum() == 0
 
 
+def test_cut_groups_limits_and_ramp():
+    """Groups are contiguous, respect the slab / chunk limits, and the first three are cut at 1/8, 1/4, 1/2 of a slab (the copy stream starts on a
+    small slab); ``ramp=()`` gives full slabs from the start; a file larger than a limit is a group of its own."""
+    rng = np.random.default_rng(3)
+    nbytes = rng.integers(1 << 20, 3 << 20, 400).astype(np.int64)
+    n_chunks = rng.integers(1, 12, 400).astype(np.int64)
+    slab = 64 << 20
+    for ramp in ((8, 4, 2), ()):
+        groups = pl.cut_groups(nbytes, n_chunks, slab, 4096, ramp)
+        assert groups[0][0] == 0 and groups[-1][1] == 400 and all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+        for i, (a, b) in enumerate(groups):
+            lim = slab // (ramp[i] if i < len(ramp) else 1)
+            assert b - a == 1 or int((nbytes[a:b] + 256).sum()) <= lim + 256 * (b - a), (i, a, b)
+        if ramp:
+            sizes = [int(nbytes[a:b].sum()) for a, b in groups[:4]]
+            assert sizes[0] < sizes[1] < sizes[2] < sizes[3]
+    big = np.array([1 << 20, 200 << 20, 1 << 20], np.int64)
+    assert pl.cut_groups(big, np.array([1, 900, 1], np.int64), slab, 4096, ()) == [(0, 1), (1, 2), (2, 3)]
+    assert [b - a for a, b in pl.cut_groups(np.full(10, 1 << 10, np.int64), np.full(10, 5, np.int64), slab, 12, ())] == [2, 2, 2, 2, 2]
+
+
 def test_balanced_bounds_are_contiguous_and_even():
     rng = np.random.default_rng(2)
     w = rng.integers(0, 21, 1000)
