@@ -390,6 +390,159 @@ def tail_constants(blocks: list[dict], head: dict):
     return np.concatenate(sections).astype(np.int32), np.asarray(desc, np.int32)
 
 
+TAIL2_LAYER_WORDS = 32
+TAIL2_DW_KINDS = 5   # v4i per (channel tile, lane group) of the depthwise constants: bias, multiplier, C01, C23, packed shifts
+TAIL2_DW_KINDS_FIRST = 8   # ... + three border biases in the first block (taps from memory, zero-filled outside the map)
+TAIL2_PW_KINDS = 5
+
+
+def _rq_hi_consts(rq):
+    """(multiplier, c1, e) per channel -> the operands of the sign-free one-multiply-add form ``((x m + C) >> 32) >> (e - 1)`` with
+    ``C = (c1 << 31) + 2^30``: multiplier, C low dword, C high dword, e - 1 (csrc/bn_i8_tail2.hip: rq_hi)."""
+    m, c1, e = (np.asarray(v, np.int64) for v in rq)
+    c = (c1 << 31) + (1 << 30)
+    return m.astype(np.int32), (c & 0xFFFFFFFF).astype(np.uint32).view(np.int32), (c >> 32).astype(np.int32), (e - 1).astype(np.int32)
+
+
+def tail2_layer_section(b: dict, rq_dw, rq_pw, first: bool) -> np.ndarray:
+    """Constants of one block of ``i8_tail2_kernel`` (csrc/bn_i8_tail2.hip) as ONE run of int32 words, in the order the kernel keeps
+    them in LDS:
+
+    * pointwise A fragments ``[nt][ks][lane][16 bytes]``: byte ``4 j + r`` of lane (m, g) = ``W[16 nt + m][16 (4 ks + j) + 4 g + r]`` —
+      the contraction order in which the depthwise stage leaves its results in registers (dword j of k-step ks = channel tile
+      ``4 ks + j``, lane group g holds its channels ``4 g ..``);
+    * depthwise A fragments ``[ct][dy][lane][16 bytes]``: the 3x3 weights of channel tile ct as a block-diagonal 16 x 64 matrix per
+      window row dy: lane (m, g), byte c' = ``wd[dy][g][16 ct + m]`` where c' = m and g < 3, else 0 (contraction index = 16 g + c':
+      window column g, channel c' of the tile);
+    * depthwise constants ``[ct][kind][g][4]`` for channel ``16 ct + 4 g + r``: folded bias, multiplier, (C low, C high) of r = 0, 1,
+      of r = 2, 3, packed shifts - 1, then the bias for positions whose window leaves the map on the right / at the bottom / both when
+      the taps outside read 0 instead of the zero point (first block: taps from memory, range-checked loads);
+    * pointwise constants ``[nt][kind][g][4]``: the same five kinds, or (bias, multiplier, c1, e, 0) with the ADD (signed form)."""
+    wd, w2 = np.asarray(b["wd"], np.int8), np.asarray(b["w2"], np.int8)
+    C, N = b["C"], b["N"]
+    KS, NCT, NT = C // 64, C // 16, N // 16
+    lane = np.arange(64)
+    m_, g_ = lane & 15, lane >> 4
+    frag = np.zeros((NT, KS, 64, 16), np.int8)
+    for nt in range(NT):
+        for ks in range(KS):
+            for j in range(4):
+                for r in range(4):
+                    frag[nt, ks, :, 4 * j + r] = w2[16 * nt + m_, 16 * (4 * ks + j) + 4 * g_ + r]
+    dwa = np.zeros((NCT, 3, 64, 16), np.int8)
+    for ct in range(NCT):
+        for dy in range(3):
+            for ln in range(64):
+                if g_[ln] < 3:
+                    dwa[ct, dy, ln, m_[ln]] = wd[dy, g_[ln], 16 * ct + m_[ln]]
+    ch = 16 * np.arange(NCT)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :]  # [ct][g][r]
+    m, clo, chi, e1 = _rq_hi_consts(rq_dw)
+    dwc = np.zeros((NCT, TAIL2_DW_KINDS_FIRST if first else TAIL2_DW_KINDS, 4, 4), np.int32)
+    bdw = np.asarray(b["bdw"], np.int64)
+    dwc[:, 0] = bdw[ch]
+    dwc[:, 1] = m[ch]
+    dwc[:, 2] = np.stack([clo[ch][..., 0], chi[ch][..., 0], clo[ch][..., 1], chi[ch][..., 1]], axis=-1)
+    dwc[:, 3] = np.stack([clo[ch][..., 2], chi[ch][..., 2], clo[ch][..., 3], chi[ch][..., 3]], axis=-1)
+    e1c = e1[ch].astype(np.int64)
+    dwc[:, 4, :, 0] = (e1c[..., 0] | (e1c[..., 1] << 8) | (e1c[..., 2] << 16) | (e1c[..., 3] << 24)).astype(np.int32)
+    if first:  # a tap outside the map contributes (0 - zp) w instead of 0: take it back through the bias
+        wd64 = wd.astype(np.int64)
+        right, bottom = wd64[:, 2, :].sum(axis=0), wd64[2, :, :].sum(axis=0)
+        corner = right + bottom - wd64[2, 2, :]
+        for k, lost in ((5, right), (6, bottom), (7, corner)):
+            dwc[:, k] = (bdw + b["z_in"] * lost)[ch]
+    cho = 16 * np.arange(NT)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :]  # [nt][g][r]
+    pwc = np.zeros((NT, TAIL2_PW_KINDS, 4, 4), np.int32)
+    pwc[:, 0] = np.asarray(b["b2"], np.int32)[cho]
+    if b["add"][0]:
+        for k in range(3):
+            pwc[:, 1 + k] = rq_pw[k][cho]
+    else:
+        m, clo, chi, e1 = _rq_hi_consts(rq_pw)
+        pwc[:, 1] = m[cho]
+        pwc[:, 2] = np.stack([clo[cho][..., 0], chi[cho][..., 0], clo[cho][..., 1], chi[cho][..., 1]], axis=-1)
+        pwc[:, 3] = np.stack([clo[cho][..., 2], chi[cho][..., 2], clo[cho][..., 3], chi[cho][..., 3]], axis=-1)
+        e1c = e1[cho].astype(np.int64)
+        pwc[:, 4, :, 0] = (e1c[..., 0] | (e1c[..., 1] << 8) | (e1c[..., 2] << 16) | (e1c[..., 3] << 24)).astype(np.int32)
+    return np.concatenate([frag.view(np.int32).reshape(-1), dwa.view(np.int32).reshape(-1), dwc.reshape(-1), pwc.reshape(-1)]).astype(np.int32)
+
+
+def tail2_constants(blocks: list[dict], head: dict):
+    """Constant block and descriptor table of ``i8_tail2_kernel`` (csrc/bn_i8_tail2.hip: the fused tail with the depthwise stage on the
+    matrix cores), or ``None`` when a block cannot take its forms (the plan then keeps ``i8_tail_kernel`` only).
+
+    On top of ``tail_constants``' conditions the ADD must have the shape TFLite's converter gives a residual block: the block's own
+    value is the input with the LARGER scale (multiplier 2^30, shift 0: its rescale is exactly ``(v - z) << 19``) and the residual's
+    zero point is -128 (its rescale ``RoundingDivideByPOT(SRDHM((b + 128) << 20, m), e)`` of a non-negative number is one unsigned
+    multiply-add: ``(((b + 128) << 24) m + R 2^24) >> 32 >> (3 + e)`` with ``R = 2^10 + 2^(10 + e)``) — both checked here on all 256 bytes.
+
+    Descriptor words per block (32): H W Cin Cout S OH OW pt pl has_add zp_in dw_lo dw_hi pw_lo pw_hi add_m add_c1 add_e add_lo add_hi
+    res_m res_c_lo res_c_hi res_k g_cst 0...; with the ADD the pointwise stage produces its value MINUS its zero point (clamp bounds
+    shifted accordingly).  Head words as in ``tail_constants``."""
+    sections, desc = [], []
+    pos = 0
+
+    def put(arr):
+        nonlocal pos
+        a = np.ascontiguousarray(np.asarray(arr, np.int32).reshape(-1))
+        a = np.concatenate([a, np.zeros((-a.size) % 4, np.int32)])
+        off = pos
+        sections.append(a)
+        pos += a.size
+        return off
+
+    for i, b in enumerate(blocks):
+        C, N = b["C"], b["N"]
+        if C not in (64, 128, 256) or N % 64 or b["sh"] != b["sw"] or b["sh"] not in (1, 2) or (b["OH"] * b["OW"]) % 16 or b["OW"] not in (8, 16):
+            return None
+        wd64, w264 = np.asarray(b["wd"], np.int64), np.asarray(b["w2"], np.int64)
+        lo_dw = np.minimum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(b["bdw"], np.int64)
+        hi_dw = np.maximum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(b["bdw"], np.int64)
+        lo_pw = np.minimum(-128 * w264, 127 * w264).sum(axis=1) + np.asarray(b["b2"], np.int64)
+        hi_pw = np.maximum(-128 * w264, 127 * w264).sum(axis=1) + np.asarray(b["b2"], np.int64)
+        if i == 0:  # zero-filled taps: the corrected biases widen the range by at most 128 * sum |w| of the taps left out, already inside lo / hi
+            if b["z_in"] != -128:
+                return None
+        add = b["add"]
+        rq_dw = _strip_requant(b["mu"], b["sh_dw"], b["z_dw"], lo_dw, hi_dw)
+        rq_pw = _strip_requant(b["mu2"], b["sh2"], 0 if add[0] else b["z_pw"], lo_pw, hi_pw)
+        if rq_dw is None or rq_pw is None or b["dw_lo"] < b["z_dw"] or (not add[0] and b["pw_lo"] < b["z_pw"]):
+            return None
+        if (rq_dw[2] > 32).any() or (not add[0] and (rq_pw[2] > 32).any()):
+            return None
+        add_m, add_c1, add_e, add_lo, add_hi, res_m, res_c, res_k = 0, 0, 1, 0, 0, 0, 0, 0
+        pw_lo, pw_hi = b["pw_lo"], b["pw_hi"]
+        if add[0]:
+            _, z1, m1, s1, m2, s2, mo, so, zo, amin, amax = (int(v) for v in add)
+            if mo < 0 or so >= 0 or -so > STRIP_MAX_SHIFT or amin < zo or z1 != -128 or m1 < 0 or s1 > 0 or -s1 > 16 or m2 != 1 << 30 or s2 != 0:
+                return None
+            e1 = -s1
+            R = (1 << 10) + ((1 << (e1 + 10)) if e1 >= 1 else 0)
+            x = np.arange(256, dtype=np.int64)
+            want = qz.requantize(x << 20, m1, s1)
+            got = ((((x << 24) * m1 + (R << 24)) >> 32) >> (3 + e1))
+            own = np.arange(-128, 128, dtype=np.int64) - b["z_pw"]
+            if not np.array_equal(want, got) or not np.array_equal(qz.requantize(own << 20, m2, s2), own << 19) or np.abs(want).max() >= 2**29:
+                return None
+            res_m, res_c, res_k = m1, R << 24, 3 + e1
+            add_m, add_e = mo, -so
+            add_c1 = (1 << (add_e - 1)) + (zo << add_e)
+            add_lo, add_hi = amin, amax
+            pw_lo, pw_hi = pw_lo - b["z_pw"], pw_hi - b["z_pw"]
+        g_cst = put(tail2_layer_section(b, rq_dw, rq_pw, first=(i == 0)))
+        row = [b["H"], b["W"], C, N, b["sh"], b["OH"], b["OW"], b["pt"], b["pl"], int(bool(add[0])), b["z_in"], b["dw_lo"], b["dw_hi"],
+               pw_lo, pw_hi, add_m, add_c1, add_e, add_lo, add_hi, res_m, res_c & 0xFFFFFFFF, res_c >> 32, res_k, g_cst]
+        desc += [int(np.int64(v).astype(np.uint32).view(np.int32)) if v > 0x7FFFFFFF else int(v) for v in row] + [0] * (TAIL2_LAYER_WORDS - len(row))
+    h = head
+    if h["C"] != 256 or h["C"] != blocks[-1]["N"] or h["P"] != blocks[-1]["OH"] * blocks[-1]["OW"] or TAIL_G * h["NC"] > 1024:
+        return None
+    desc += [h["mean_zp_in"], h["mean_mult"], h["mean_shift"], h["mean_zp_out"], h["fc_zp_out"], h["fc_lo"], h["fc_hi"],
+             put(np.ascontiguousarray(np.asarray(h["fc_w"], np.int8)).view(np.int32)), put(h["fc_b"]), put(h["fc_m"]), put(h["fc_s"]),
+             put(np.asarray(h["lut"], np.int8).view(np.int32)) if h["lut"] is not None else -1, h["zp_fc"], h["zp_head"], h["P"], h["C"]]
+    assert len(desc) == TAIL2_LAYER_WORDS * len(blocks) + TAIL_HEAD_WORDS
+    return np.concatenate(sections).astype(np.int32), np.asarray(desc, np.int32)
+
+
 def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str = "fixed", mean_form: str = "int") -> pk.Plan:
     """Build the INT8 plan for a decoded ``TfliteModel``.  ``keep_all`` disables slot reuse; ``fuse=False`` keeps the
     baseline one-kernel-per-operator plan instead of the fused matrix-core blocks.  ``softmax_form`` picks the arithmetic of an int8
@@ -996,6 +1149,7 @@ def _add_tail_op(pb, plan, blocks: list[dict], head: dict) -> None:
     if packed is None:
         return
     cst, desc = packed
+    packed2 = tail2_constants(chain, head)  # the same blocks for i8_tail2_kernel (depthwise stage on the matrix cores), when they take its forms
     first = chain[0]
     dw_macs = sum(b["macs"][0] for b in chain)
     pw_macs = sum(b["macs"][1] for b in chain)
@@ -1004,4 +1158,5 @@ def _add_tail_op(pb, plan, blocks: list[dict], head: dict) -> None:
     pb.op(pk.I8_TAIL, first["src"], pk.SLOT_SCORES,
           p=[first["H"] * first["W"] * first["C"], pw_macs, dw_macs, head["P"] * head["C"] + head["C"] * head["NC"], head["NC"], len(chain),
              first["H"], first["W"], first["C"], head["P"], head["C"], *([0] * (pk.TAIL_TAG - 11)), pk.TAIL_OP],
-          t=[pb.tensor(cst, np.int32), pb.tensor(desc, np.int32)], f=[head["s_fc"], head["s_head"]], name="tail", out_shape=(head["NC"],))
+          t=[pb.tensor(cst, np.int32), pb.tensor(desc, np.int32)] + ([pb.tensor(packed2[0], np.int32), pb.tensor(packed2[1], np.int32)] if packed2 is not None else []),
+          f=[head["s_fc"], head["s_head"]], name="tail", out_shape=(head["NC"],))

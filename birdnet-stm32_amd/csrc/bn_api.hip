@@ -48,7 +48,7 @@ const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
     {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"i8_pw_forms", &bn::Options::i8_pw_forms}, {"i8_add_tab", &bn::Options::i8_add_tab}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
-    {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail},
+    {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail}, {"i8_tail_mfdw", &bn::Options::i8_tail_mfdw},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
     {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap},
     {"ingest_blk", &bn::Options::ingest_blk},
@@ -96,6 +96,8 @@ struct bn_model {
     std::vector<uint8_t> rq_right;       // per operator: all requantisation multipliers >= 0 and shifts < 0
     std::vector<bn::Tail8Args> tails;    // per operator: arguments of the fused tail kernel (BN_OP_I8_TAIL operators only)
     std::vector<uint8_t> tail_ok;        // per operator: BN_OP_I8_TAIL whose maps fit the kernel's LDS plan
+    std::vector<bn::Tail2Args> tails2;   // per operator: the same for i8_tail2_kernel (depthwise stage on the matrix cores), when the plan carries its constants
+    std::vector<uint8_t> tail2_ok;
     std::vector<uint8_t> out_valid;      // per operator: it wrote its output slot in the last forward call (not when a fused kernel covered it)
     std::vector<uint8_t> slot_valid;     // per slot: some operator wrote it in the last forward call
     bool has_tail = false;               // the plan holds a usable fused tail operator
@@ -597,6 +599,16 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 break;
             }
             case BN_OP_I8_TAIL: {
+                if (bn::g_opt.i8_tail_mfdw && m->tail2_ok[oi]) {
+                    bn::Tail2Args t2 = m->tails2[oi];
+                    t2.x = (const int8_t*)in0;
+                    t2.scores = d_scores;
+                    t2.logits = d_logits;
+                    t2.cst = (const int32_t*)m->tensor(o.t[2]);
+                    t2.B = B;
+                    if (!bn::launch_i8_tail2(t2, s)) return fail(BN_ERR_DEVICE, "could not raise the LDS limit of the fused tail kernel");
+                    break;
+                }
                 bn::Tail8Args ta = m->tails[oi];
                 ta.x = (const int8_t*)in0;
                 ta.scores = d_scores;
@@ -848,6 +860,8 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
     // fused tail operators: build the kernel arguments and the LDS plan from the descriptor table
     m->tails.resize(h.n_ops);
     m->tail_ok.assign(h.n_ops, 0);
+    m->tails2.resize(h.n_ops);
+    m->tail2_ok.assign(h.n_ops, 0);
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         if (o.kind != BN_OP_I8_TAIL) continue;
@@ -862,6 +876,18 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
                         ta.L[0].H == o.p[6] && ta.L[0].W == o.p[7] && ta.L[0].Cin == o.p[8] && bn::tail_const_words(ta) * 4 <= (long)tc.nbytes;
         m->tail_ok[oi] = ok;
         m->has_tail = m->has_tail || ok;
+        // the second form's constants (t[2], t[3]) are optional; it only ever runs where the first form could (same coverage, same fallback)
+        if (ok && o.t[2] >= 0 && o.t[3] >= 0 && (size_t)o.t[2] < m->tensors.size() && (size_t)o.t[3] < m->tensors.size()) {
+            bn::Tail2Args& t2 = m->tails2[oi];
+            t2 = bn::Tail2Args{};
+            t2.NC = o.p[4];
+            t2.s_fc = o.f[0];
+            t2.s_head = o.f[1];
+            const TensorRec& td2 = m->tensors[o.t[3]];
+            const TensorRec& tc2 = m->tensors[o.t[2]];
+            m->tail2_ok[oi] = (td2.nbytes & 3) == 0 && bn::tail2_plan((const int32_t*)(base + td2.offset), (int)(td2.nbytes / 4), o.p[5], t2) &&
+                              t2.L[0].H == o.p[6] && t2.L[0].W == o.p[7] && t2.L[0].Cin == o.p[8] && bn::tail2_const_words(t2) * 4 <= (long)tc2.nbytes;
+        }
     }
     // INT8 blocks: can every requantisation of the operator take the branch-free right-shift form?
     m->rq_right.assign(h.n_ops, 0);
@@ -1416,7 +1442,7 @@ int bn_get_option(const char* name, int* value) {
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_pw_ws_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_pw_lds_kernel\ni8_attnpool_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_tail2_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_pw_lds_kernel\ni8_attnpool_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }
 

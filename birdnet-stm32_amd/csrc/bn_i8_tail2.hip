@@ -1,0 +1,301 @@
+// bn_i8_tail2.hip — the back half of the INT8 graph as ONE kernel, second form: the DEPTHWISE stage runs on the matrix cores too.
+//
+//   DEPTHWISE_CONV_2D 3x3 (ReLU6) -> CONV_2D 1x1 [-> TFLite ADD with the block input]        (x n_layers)
+//   -> MEAN -> FULLY_CONNECTED -> LOGISTIC / DEQUANTIZE
+//
+// Same operators, same integer results as bn_i8_tail.hip (reference: SURVEY.md Appendix B ops #36-#55; models/dscnn.py:28-84,
+// 209-261 of the reference).  What changes is which pipe does the depthwise multiply-accumulates.
+//
+// Why.  profiles/r04_i8_b4096_digest.md: i8_tail_kernel issues 33.6 k vector instructions per wave against 640 matrix instructions;
+// its vector ALU is busy 59 % of the launch, its matrix pipe 4.7 %.  Per depthwise output the vector form needs a tap read per
+// channel quad and window position, 1.5 byte permutes, 0.75 dot products, then the requantisation: ~12 instructions.  Here a
+// 3 x 3 window row over a tile of 16 channels x 16 positions is ONE v_mfma_i32_16x16x64_i8:
+//
+//   A (16 x 64, weights)      row m = channel m of the tile, contraction index k = 16 g + c': window column g (g = 3: zero), channel c';
+//                             A[m][16 g + c'] = w[dy][g][channel m] where c' = m, else 0  — block-diagonal, one byte in sixteen is used
+//   B (64 x 16, activations)  column n = position n of the tile; lane (n, g) holds the 16 channels of the tile at input position
+//                             (row + dy, column n + g - 1): ONE ds_read_b128 from the NHWC map in LDS, no transposition
+//   D (16 x 16)               lane (n, g) holds channels 4 g .. 4 g + 3 at position n: four requantisations, one dword of NHWC bytes
+//
+// and a window is three of them (dy = 0, 1, 2) into one accumulator whose start value is the folded bias.  The matrix pipe does 16 x
+// the useful work and does not care (it was idle); the vector ALU is left with the requantisation alone: 3.75 instructions per
+// depthwise output.  A wave's depthwise results for the channel tiles 4 ks .. 4 ks + 3 ARE its B fragment of the pointwise
+// convolution's k-step ks (the packer orders the contraction index of the pointwise weights accordingly), as in the first form.
+//
+// Geometry: a workgroup of 8 waves (up to 256 registers per lane) owns kTailG = 4 chunks; a wave owns UPW consecutive tiles of 16
+// positions (four rows of a 16-wide map of one chunk; one tile = two rows of an 8-wide map) so that the A operands and the
+// per-channel constants it reads from LDS serve four tiles and vertically adjacent tiles share their input rows (six B reads per
+// channel tile for four tiles).  Maps live in LDS with a pitch of C + 16 bytes (16-byte reads 144 / 272 bytes apart are
+// conflict-free) and are updated IN PLACE: all depthwise results of a block sit in registers before a barrier, then the pointwise
+// results overwrite the input map — which frees the LDS the expanded depthwise weights need (3 KB per channel tile).
+//
+// The residual ADD is arithmetic here (no table reads: the LDS array is the busiest shared unit once the depthwise taps come as
+// 16-byte reads): the block's own value enters with multiplier 2^30 / shift 0 (it has the larger scale: (v - z) << 19 exactly), the
+// residual byte's rescale is one unsigned 64-bit multiply-add and a shift (tail2_constants in models/_lower_i8.py proves both forms on
+// all 256 bytes), the sum's rescale is the sign-free form the other stages use.
+//
+// The first block streams its taps from global memory (range-checked 16-byte buffer loads: a tap outside the map reads 0; what the
+// folded bias assumed for it — the zero point — is taken back through per-border variants of the bias).
+#include "bn_tail_common.h"
+
+namespace bn {
+namespace {
+
+__device__ __forceinline__ long upair(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
+
+template <int N>
+__device__ __forceinline__ void copy16(v4i* __restrict__ dst, const v4i* __restrict__ src, int tid) {
+    // N sixteen-byte pieces by kTail2Threads threads: all requests of a batch first, then the LDS writes
+    constexpr int FULL = N / kTail2Threads, REM = N % kTail2Threads, BATCH = 8;
+#pragma unroll
+    for (int b0 = 0; b0 < FULL; b0 += BATCH) {
+        v4i tmp[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i)
+            if (b0 + i < FULL) tmp[i] = src[(b0 + i) * kTail2Threads + tid];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i)
+            if (b0 + i < FULL) dst[(b0 + i) * kTail2Threads + tid] = tmp[i];
+    }
+    if (REM && tid < REM) dst[FULL * kTail2Threads + tid] = src[FULL * kTail2Threads + tid];
+}
+
+// One block for the kTailG chunks of the workgroup; maps are [chunk][position][C + 16 bytes], input and output at the same place.
+template <int CIN, int COUT, int S, int H, int W, bool ADD, bool SRCG>
+__device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args& a, unsigned char* lds, int chunk0) {
+    constexpr int KS = CIN / 64, NCT = CIN / 16, NT = COUT / 16;
+    constexpr int PIN = CIN + 16, POUT = COUT + 16;
+    constexpr int OH = H / S, OW = W / S, PER_CHUNK = OH * OW;
+    constexpr int TILES = kTailG * PER_CHUNK / 16;
+    static_assert(TILES % kTail2Waves == 0, "tiles per wave");
+    constexpr int UPW = TILES / kTail2Waves;
+    constexpr int TR = 16 / OW;                    // output rows of a tile
+    constexpr int NR = (UPW - 1) * TR * S + 3;     // input rows a wave reads per channel tile
+    constexpr int PT = S == 1 ? 1 : 0, PL = PT;    // TF SAME padding of a 3x3 window on even maps: 1 / 1 at stride 1, 0 / 1 at stride 2
+    constexpr int DWK = SRCG ? 8 : 5;              // v4i per (channel tile, lane group) of depthwise constants
+    constexpr int W_BYTES = CIN * COUT, DWA_BYTES = NCT * 3 * 1024, DWC_BYTES = NCT * DWK * 64, PWC_BYTES = NT * 5 * 64;
+    static_assert(PER_CHUNK % (16 * UPW) == 0, "a wave's tiles lie in one chunk");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---- stage the block's constants (one contiguous run) and the zero-point row --------------------------------------------------
+    copy16<(W_BYTES + DWA_BYTES + DWC_BYTES + PWC_BYTES) / 16>(reinterpret_cast<v4i*>(lds + L.cst_off), reinterpret_cast<const v4i*>(a.cst + L.g_cst), tid);
+    if (!SRCG && tid < PIN / 4) reinterpret_cast<int*>(lds + L.zp_off)[tid] = (L.zp_in & 0xff) * 0x01010101;
+    __syncthreads();
+
+    const v4i* wl = reinterpret_cast<const v4i*>(lds + L.cst_off) + lane;
+    const v4i* dwa = reinterpret_cast<const v4i*>(lds + L.cst_off + W_BYTES) + lane;
+    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.cst_off + W_BYTES + DWA_BYTES) + g;
+    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.cst_off + W_BYTES + DWA_BYTES + DWC_BYTES) + g;
+    const int dw_lo = L.dw_lo, dw_hi = L.dw_hi, pw_lo = L.pw_lo, pw_hi = L.pw_hi;
+
+    // ---- where this wave's tiles are --------------------------------------------------------------------------------------------
+    const int tile0 = wave * UPW;
+    const int gch = (tile0 * 16) / PER_CHUNK;                 // chunk slot of the wave's tiles
+    const int oy0 = ((tile0 * 16) % PER_CHUNK) / OW;          // first output row
+    const int lr = OW == 8 ? n >> 3 : 0, ox = OW == 8 ? n & 7 : n;
+    int chunk = chunk0 + gch;
+    if (chunk >= a.B) chunk = a.B - 1;                         // ragged last group: the spare slots repeat the last chunk
+    int raddr[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int iy = (oy0 + lr) * S - PT + r, ix = ox * S - PL + g;
+        const bool ok = g < 3 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        if constexpr (SRCG) raddr[r] = ok ? (iy * W + ix) * CIN : 0x40000000;   // (past the buffer: the load returns 0)
+        else raddr[r] = ok ? L.x_off + ((gch * H + iy) * W + ix) * PIN : L.zp_off;
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * H * W * CIN : 0), 0, SRCG ? H * W * CIN : 0, 0x00020000);
+    int bkind[UPW];   // first block: which bias a tile's lanes start from (0 inside, 5 right border, 6 bottom, 7 both)
+#pragma unroll
+    for (int t = 0; t < UPW; ++t) {
+        const bool right = ox == OW - 1, bottom = oy0 + t * TR + lr == OH - 1;
+        bkind[t] = SRCG ? (right ? (bottom ? 7 : 5) : (bottom ? 6 : 0)) * 4 : 0;
+    }
+
+    // ---- depthwise 3x3 on the matrix cores: all CIN channels of this wave's positions -> B fragments of the pointwise stage -------
+    v4i bf[UPW][KS];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        v4i af[3], brow[NR];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) af[dy] = dwa[(ct * 3 + dy) * 64];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if constexpr (SRCG) brow[r] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, raddr[r] + 16 * ct, 0, 0));
+            else brow[r] = *reinterpret_cast<const v4i*>(lds + raddr[r] + 16 * ct);
+        }
+        const v4i* dc = dwc + ct * DWK * 4;
+        const v4i m = dc[4], c01 = dc[8], c23 = dc[12];
+        const int e1 = reinterpret_cast<const int*>(dc + 16)[0];
+        const long cc[4] = {pair(c01.x, c01.y), pair(c01.z, c01.w), pair(c23.x, c23.y), pair(c23.z, c23.w)};
+        v4i acc[UPW];
+#pragma unroll
+        for (int t = 0; t < UPW; ++t) acc[t] = SRCG ? dc[bkind[t]] : dc[0];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int t = 0; t < UPW; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[dy], brow[t * TR * S + dy], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < UPW; ++t) {
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[e] = med3(rq_hi(acc[t][e], m[e], cc[e], e1, e), dw_lo, dw_hi);
+            bf[t][ct >> 2][ct & 3] = pack4(qv);
+        }
+    }
+    if (!SRCG) __syncthreads();   // every wave has read its taps: the map may be overwritten
+
+    // ---- pointwise 1x1 on the matrix cores, requantise, [ADD], store into the map -------------------------------------------------
+    const int add_m = L.add_m, add_e1 = L.add_e - 1;
+    const long add_c = rq64(L.add_c1);
+    const uint32_t res_m = (uint32_t)L.res_m;
+    const long res_c = upair((uint32_t)L.res_c_lo, (uint32_t)L.res_c_hi);
+    const int res_k = L.res_k;
+    const int pbase = tile0 * 16 + n;
+#pragma unroll 2
+    for (int nt = 0; nt < NT; ++nt) {
+        const v4i* pc = pwc + nt * 20;
+        v4i acc[UPW];
+#pragma unroll
+        for (int t = 0; t < UPW; ++t) acc[t] = pc[0];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v4i af = wl[(nt * KS + ks) * 64];
+#pragma unroll
+            for (int t = 0; t < UPW; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[t][ks], acc[t], 0, 0, 0);
+        }
+        const v4i m = pc[4], c1 = pc[8], sh = pc[12];  // ADD: (multiplier, c1, shift); else (multiplier, C01, C23) + packed shifts
+        const int e1 = ADD ? 0 : reinterpret_cast<const int*>(pc + 16)[0];
+        const long cc[4] = {pair(c1.x, c1.y), pair(c1.z, c1.w), pair(sh.x, sh.y), pair(sh.z, sh.w)};
+#pragma unroll
+        for (int t = 0; t < UPW; ++t) {
+            const int p = pbase + 16 * t;
+            int xr = 0;
+            if constexpr (ADD) xr = *reinterpret_cast<const int*>(lds + L.x_off + p * PIN + 4 * g + 16 * nt) ^ (int)0x80808080u;  // residual bytes + 128
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (ADD) {
+                    const int v = med3(rq(acc[t][e], m[e], c1[e], sh[e]), pw_lo, pw_hi);                 // the block's own value minus its zero point
+                    const uint32_t xt = (uint32_t)perm(0, xr, ((uint32_t)e << 24) | 0x000c0c0cu);            // (b + 128) << 24
+                    const int f = (int)((uint32_t)(((unsigned long)xt * (unsigned long)res_m + (unsigned long)res_c) >> 32) >> res_k);
+                    const int total = (v << 19) + f;
+                    qv[e] = med3((int)(((long)total * (long)add_m + add_c) >> 32) >> add_e1, L.add_lo, L.add_hi);
+                } else {
+                    qv[e] = med3(rq_hi(acc[t][e], m[e], cc[e], e1, e), pw_lo, pw_hi);
+                }
+            }
+            *reinterpret_cast<int*>(lds + L.y_off + p * POUT + 4 * g + 16 * nt) = pack4(qv);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int ngroups = (a.B + kTailG - 1) / kTailG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int chunk0 = grp * kTailG;
+        for (int li = 0; li < a.n_layers; ++li) {
+            const Tail2Layer& L = a.L[li];
+            if (L.Cin == 64) tail2_block<64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0);
+            else if (L.Cin == 128 && L.Cout == 128) tail2_block<128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0);
+            else if (L.Cin == 128) tail2_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0);
+            else tail2_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0);
+        }
+        tail_head<kTail2Threads, 16>(a, lds, chunk0);
+        __syncthreads();  // the next group overwrites the maps
+    }
+}
+
+int tail2_cst_bytes(const Tail2Layer& L, bool first) {
+    return L.Cin * L.Cout + (L.Cin / 16) * 3 * 1024 + (L.Cin / 16) * (first ? 8 : 5) * 64 + (L.Cout / 16) * 5 * 64;
+}
+
+}  // namespace
+
+// Kernel arguments and LDS plan from the packer's descriptor table (32 words per block + 16 head words).  Per block the map sits at
+// LDS offset 0 (input and output in place), then the zero-point row, then the block's constants; the pooled vector of the head lies
+// behind the last block's constants.  false = not a topology / size the kernel takes (the plan keeps i8_tail_kernel).
+bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
+    constexpr int LW = kTail2LayerWords, HW = 16, CAP = 160 * 1024;
+    if (n_layers < 1 || n_layers > 8 || n_words != LW * n_layers + HW) return false;
+    a.n_layers = n_layers;
+    int lds_need = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const int32_t* d = desc + LW * i;
+        Tail2Layer& L = a.L[i];
+        L.H = d[0]; L.W = d[1]; L.Cin = d[2]; L.Cout = d[3]; L.S = d[4]; L.OH = d[5]; L.OW = d[6]; L.pt = d[7]; L.pl = d[8]; L.has_add = d[9];
+        L.zp_in = d[10]; L.dw_lo = d[11]; L.dw_hi = d[12]; L.pw_lo = d[13]; L.pw_hi = d[14];
+        L.add_m = d[15]; L.add_c1 = d[16]; L.add_e = d[17]; L.add_lo = d[18]; L.add_hi = d[19];
+        L.res_m = d[20]; L.res_c_lo = d[21]; L.res_c_hi = d[22]; L.res_k = d[23]; L.g_cst = d[24];
+        const bool first = i == 0;
+        auto is = [&](int cin, int cout, int st, int hh, int ww, int add) {
+            return L.Cin == cin && L.Cout == cout && L.S == st && L.H == hh && L.W == ww && L.has_add == add && L.pt == (st == 1) && L.pl == (st == 1) &&
+                   L.OH == hh / st && L.OW == ww / st;
+        };
+        // the four instantiations of tail2_block
+        if (!((first && is(64, 128, 2, 16, 32, 0)) || (!first && (is(128, 128, 1, 8, 16, 1) || is(128, 256, 2, 8, 16, 0) || is(256, 256, 1, 4, 8, 1))))) return false;
+        if (i > 0 && (L.H != a.L[i - 1].OH || L.W != a.L[i - 1].OW || L.Cin != a.L[i - 1].Cout)) return false;
+        if (L.g_cst < 0 || (L.g_cst & 3)) return false;
+        if (first && L.zp_in != -128) return false;   // (zero-filled taps + border biases assume it; the packer checks the same)
+        // every clamp whose result is stored as a byte is an int8 range; with the ADD the pointwise value is kept minus its zero point
+        if (L.dw_lo < -128 || L.dw_hi > 127 || L.dw_lo > L.dw_hi || L.pw_lo > L.pw_hi) return false;
+        if (!L.has_add && (L.pw_lo < -128 || L.pw_hi > 127)) return false;
+        if (L.has_add && (L.pw_lo < -255 || L.pw_hi > 255 || L.add_lo < -128 || L.add_hi > 127 || L.add_lo > L.add_hi || L.add_e < 1 || L.add_e > 22 || L.add_m < 0 ||
+                          L.res_m < 0 || L.res_k < 3 || L.res_k > 19))
+            return false;
+        const int in_bytes = first ? 0 : kTailG * L.H * L.W * (L.Cin + 16), out_bytes = kTailG * L.OH * L.OW * (L.Cout + 16);
+        L.x_off = first ? -1 : 0;
+        L.y_off = 0;
+        L.zp_off = in_bytes > out_bytes ? in_bytes : out_bytes;
+        L.cst_off = L.zp_off + ((L.Cin + 16 + 15) & ~15);
+        int end = L.cst_off + tail2_cst_bytes(L, first);
+        if (i == n_layers - 1) {
+            a.mean_off = end;
+            end += kTailG * L.Cout;
+        }
+        if (end > CAP) return false;
+        lds_need = end > lds_need ? end : lds_need;
+    }
+    const int32_t* h = desc + LW * n_layers;
+    a.mean_zp_in = h[0]; a.mean_mult = h[1]; a.mean_shift = h[2]; a.mean_zp_out = h[3];
+    a.fc_zp_out = h[4]; a.fc_lo = h[5]; a.fc_hi = h[6]; a.g_fcw = h[7]; a.g_fcb = h[8]; a.g_fcm = h[9]; a.g_fcs = h[10]; a.g_hlut = h[11];
+    a.head_zp_fc = h[12]; a.head_zp_out = h[13]; a.P = h[14]; a.C = h[15];
+    if (a.g_fcw < 0 || a.g_fcb < 0 || a.g_fcm < 0 || a.g_fcs < 0 || a.g_hlut < -1 || (a.g_fcw & 3)) return false;
+    if (a.fc_lo < -128 || a.fc_hi > 127 || a.fc_lo > a.fc_hi) return false;
+    const Tail2Layer& last = a.L[n_layers - 1];
+    if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 4 || a.NC < 1 || kTailG * a.NC > kTail2Threads * 4) return false;
+    // the head's LDS copy of the classifier matrix overlays the last block's constants (nobody reads them behind its end barrier)
+    const int fc_bytes = a.NC * (a.C / 4 + 1) * 4;
+    a.fcw_off = (a.C % 16 == 0 && fc_bytes <= tail2_cst_bytes(last, n_layers == 1) && a.NC * (a.C / 16) <= 4096) ? last.cst_off : -1;
+    a.lds_bytes = lds_need;
+    return true;
+}
+
+long tail2_const_words(const Tail2Args& a) {
+    long need = 0;
+    auto upto = [&](long off, long words) { need = off + words > need ? off + words : need; };
+    for (int i = 0; i < a.n_layers; ++i) upto(a.L[i].g_cst, tail2_cst_bytes(a.L[i], i == 0) / 4);
+    upto(a.g_fcw, (long)a.NC * a.C / 4);
+    upto(a.g_fcb, a.NC);
+    upto(a.g_fcm, a.NC);
+    upto(a.g_fcs, a.NC);
+    if (a.g_hlut >= 0) upto(a.g_hlut, 64);
+    return need;
+}
+
+bool launch_i8_tail2(Tail2Args a, hipStream_t s) {
+    if (!g_opt.i8_tail_fclds) a.fcw_off = -1;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(i8_tail2_kernel), 160 * 1024)) return false;
+    const int ngroups = (a.B + kTailG - 1) / kTailG;
+    const int grid = ngroups < 256 ? ngroups : 256;  // one workgroup per CU (its LDS), each walks over its share of the chunk groups
+    hipLaunchKernelGGL(i8_tail2_kernel, dim3(grid), dim3(kTail2Threads), (size_t)a.lds_bytes, s, a);
+    return true;
+}
+
+}  // namespace bn

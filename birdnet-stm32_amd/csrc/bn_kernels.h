@@ -40,6 +40,7 @@ struct Options {
                                // (1024-thread workgroups, one per CU); 0: two 256-entry rescale tables + the output requantisation on the vector ALU
     int i8_tail_fclds = 1;     // the fused tail's head reads the classifier matrix from an LDS copy (0: from memory, 64 dependent loads per thread)
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
+    int i8_tail_mfdw = 1;      // ... with the depthwise stage on the matrix cores (i8_tail2_kernel) where the plan carries its constants; 0: i8_tail_kernel
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
     int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
     int stft_exact = 2;        // INT8 plans from audio: 2 = float32 STFT + float64 pass over the doubtful elements (bit-exact input bytes,
@@ -372,6 +373,35 @@ struct Tail8Args {
 bool tail_plan(const int32_t* desc, int n_words, int n_layers, Tail8Args& a);  // a.NC must be set; false = not a topology / size the kernel takes
 long tail_const_words(const Tail8Args& a);
 bool launch_i8_tail(Tail8Args a, hipStream_t s);
+
+// The same back half with the DEPTHWISE stage on the matrix cores too (bn_i8_tail2.hip): 8 waves per workgroup, maps in place.
+constexpr int kTail2Waves = 8;
+constexpr int kTail2Threads = 64 * kTail2Waves;
+constexpr int kTail2LayerWords = 32;   // models/_lower_i8.py: TAIL2_LAYER_WORDS
+struct Tail2Layer {
+    int H, W, Cin, Cout, S, OH, OW, pt, pl, has_add;
+    int zp_in, dw_lo, dw_hi, pw_lo, pw_hi;        // clamp bounds (pointwise with the ADD: minus the block's own zero point)
+    int add_m, add_c1, add_e, add_lo, add_hi;     // output rescale of the ADD (zero point folded into c1) and its clamp
+    int res_m, res_c_lo, res_c_hi, res_k;         // rescale of the residual byte: (((b + 128) << 24) res_m + res_c) >> 32 >> res_k
+    int g_cst;                                    // word offset of the block's constants (one run: pointwise A | depthwise A | depthwise | pointwise constants)
+    int x_off, y_off, cst_off, zp_off;            // LDS byte offsets (x_off < 0: the input map is in global memory)
+};
+struct Tail2Args {
+    const int8_t* x;
+    float* scores;
+    float* logits;
+    const int32_t* cst;   // constant block (models/_lower_i8.py: tail2_constants)
+    int B, n_layers, NC, P, C;
+    int mean_zp_in, mean_mult, mean_shift, mean_zp_out, mean_off;
+    int fc_zp_out, fc_lo, fc_hi, g_fcw, g_fcb, g_fcm, g_fcs, g_hlut, head_zp_fc, head_zp_out;
+    float s_fc, s_head;
+    int lds_bytes;
+    int fcw_off;
+    Tail2Layer L[8];
+};
+bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a);  // a.NC must be set
+long tail2_const_words(const Tail2Args& a);
+bool launch_i8_tail2(Tail2Args a, hipStream_t s);
 
 // INT8 stem 3x3 + depthwise 3x3 stride 2 + pointwise in one kernel (bn_i8_fused.hip)
 struct I8FrontParams {

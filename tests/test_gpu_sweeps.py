@@ -415,11 +415,20 @@ def test_i8_fused_tail_matches_per_block_kernels_and_oracle(torch_mod):
     rows = {r["kind"]: r["launches"] for r in runner.profile_collect() if r["launches"]}
     runner.profile(False)
     assert rows.get("i8_tail") == 1 and "i8_mean" not in rows
+    # both forms of the fused kernel: depthwise stage on the matrix cores (i8_tail2_kernel, the default where the plan carries its
+    # constants) and on the vector ALU (i8_tail_kernel)
+    assert tail[0].t[2] >= 0 and tail[0].t[3] >= 0, "the shipped graph must take the matrix-core depthwise form"
+    with _hip.options(i8_tail_mfdw=0):
+        for nb in (261, 1, 3, 37):
+            s, l = runner.predict_device(x[:nb], return_logits=True)
+            assert torch.equal(s, base_s[:nb]) and torch.equal(l, base_l[:nb]), f"vector-ALU form, batch {nb}"
     audio = torch.from_numpy(synth_chunks(70, seed=9)).cuda()
     a1 = runner.infer_audio_device(audio).clone()
     with _hip.options(i8_tail=0):
         a0 = runner.infer_audio_device(audio)
     assert torch.equal(a0, a1)
+    with _hip.options(i8_tail_mfdw=0):
+        assert torch.equal(runner.infer_audio_device(audio), a1)
     runner.close()
 
 
