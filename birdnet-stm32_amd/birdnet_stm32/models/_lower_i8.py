@@ -405,8 +405,9 @@ def _rq_hi_consts(rq):
 
 
 def tail2_layer_section(b: dict, rq_dw, rq_pw, first: bool) -> np.ndarray:
-    """Constants of one block of ``i8_tail2_kernel`` (csrc/bn_i8_tail2.hip) as ONE run of int32 words, in the order the kernel keeps
-    them in LDS:
+    """Constants of one block of ``i8_tail2_kernel`` (csrc/bn_i8_tail2.hip) as ONE run of int32 words: the depthwise part (depthwise A
+    fragments, depthwise constants) followed by the pointwise part (pointwise A fragments, pointwise constants) — the kernel stages the
+    two parts at different times.  The pieces:
 
     * pointwise A fragments ``[nt][ks][lane][16 bytes]``: byte ``4 j + r`` of lane (m, g) = ``W[16 nt + m][16 (4 ks + j) + 4 g + r]`` —
       the contraction order in which the depthwise stage leaves its results in registers (dword j of k-step ks = channel tile
@@ -464,7 +465,7 @@ def tail2_layer_section(b: dict, rq_dw, rq_pw, first: bool) -> np.ndarray:
         pwc[:, 3] = np.stack([clo[cho][..., 2], chi[cho][..., 2], clo[cho][..., 3], chi[cho][..., 3]], axis=-1)
         e1c = e1[cho].astype(np.int64)
         pwc[:, 4, :, 0] = (e1c[..., 0] | (e1c[..., 1] << 8) | (e1c[..., 2] << 16) | (e1c[..., 3] << 24)).astype(np.int32)
-    return np.concatenate([frag.view(np.int32).reshape(-1), dwa.view(np.int32).reshape(-1), dwc.reshape(-1), pwc.reshape(-1)]).astype(np.int32)
+    return np.concatenate([dwa.view(np.int32).reshape(-1), dwc.reshape(-1), frag.view(np.int32).reshape(-1), pwc.reshape(-1)]).astype(np.int32)
 
 
 def tail2_constants(blocks: list[dict], head: dict):

@@ -34,6 +34,11 @@
 // residual byte's rescale is one unsigned 64-bit multiply-add and a shift (tail2_constants in models/_lower_i8.py proves both forms on
 // all 256 bytes), the sum's rescale is the sign-free form the other stages use.
 //
+// Constants never make a wave wait for memory: a block's depthwise part (expanded weights + constants) is requested while the PREVIOUS
+// block's pointwise phase runs and written to LDS behind it, its pointwise part (weights + constants) is requested before the block's
+// own depthwise phase and written behind that — two barriers per block, none of them behind a load (tail2_plan places the parts so that
+// nothing live is overwritten).
+//
 // The first block streams its taps from global memory (range-checked 16-byte buffer loads: a tap outside the map reads 0; what the
 // folded bias assumed for it — the zero point — is taken back through per-border variants of the bias).
 #include "bn_tail_common.h"
@@ -41,28 +46,50 @@
 namespace bn {
 namespace {
 
+// BN_TAIL_STAMPS (the measurement build `make stamps`, never the production library): per block and wave, when it entered, had issued its
+// staging copies, left the staging barrier, finished the depthwise phase, left the middle barrier, finished the pointwise phase, left the end
+// barrier (s_memrealtime: 100 MHz) — tools/tail2_stamps.py.
+#ifdef BN_TAIL_STAMPS
+__device__ long long* g_tail2_stamps = nullptr;   // [workgroup < 8][group < 4][block < 8][wave 8][8]
+// (only the stamps right behind a barrier are taken — 0, 4, 6: a stamp in the middle of a phase needs a scheduling fence and changes what it measures;
+// the stamped launch is within 2 % of the production one)
+#define BN_T2STAMP(i) do { if ((i) == 0 || (i) == 4 || (i) == 6) st[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BN_T2STAMP(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ long upair(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
 
-template <int N>
-__device__ __forceinline__ void copy16(v4i* __restrict__ dst, const v4i* __restrict__ src, int tid) {
-    // N sixteen-byte pieces by kTail2Threads threads: all requests of a batch first, then the LDS writes
-    constexpr int FULL = N / kTail2Threads, REM = N % kTail2Threads, BATCH = 8;
+// Constant parts travel global -> registers -> LDS in two halves so that the round trip hides behind a compute phase: part_load issues
+// range-checked 16-byte buffer loads (pieces past the part read 0 and are never stored), part_store writes them.
+template <int MAXP>
+__device__ __forceinline__ void part_load(v4i (&r)[MAXP], const int32_t* src, int n16, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(src), 0, n16 * 16, 0x00020000);
 #pragma unroll
-    for (int b0 = 0; b0 < FULL; b0 += BATCH) {
-        v4i tmp[BATCH];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i)
-            if (b0 + i < FULL) tmp[i] = src[(b0 + i) * kTail2Threads + tid];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i)
-            if (b0 + i < FULL) dst[(b0 + i) * kTail2Threads + tid] = tmp[i];
-    }
-    if (REM && tid < REM) dst[FULL * kTail2Threads + tid] = src[FULL * kTail2Threads + tid];
+    for (int i = 0; i < MAXP; ++i) r[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * kTail2Threads + tid) * 16, 0, 0));
 }
+template <int MAXP>
+__device__ __forceinline__ void part_store(const v4i (&r)[MAXP], unsigned char* dst, int n16, int tid) {
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+        if (i * kTail2Threads + tid < n16) reinterpret_cast<v4i*>(dst)[i * kTail2Threads + tid] = r[i];
+}
+constexpr int kTail2MaxDw16 = 7 * kTail2Threads;   // sixteen-byte pieces of the largest depthwise part a block may prefetch (256 channels: 3392)
+
+// what a block stages for its successor while its own pointwise phase runs
+struct Tail2Next {
+    const int32_t* g;   // the successor's depthwise part in the constant block (null: nothing follows)
+    int n16, dw_off;    // its size in 16-byte pieces, its place in LDS
+    int zp_off, zp_n4, zp4;  // the successor's zero-point row: place, dwords (0: none), value
+};
 
 // One block for the kTailG chunks of the workgroup; maps are [chunk][position][C + 16 bytes], input and output at the same place.
 template <int CIN, int COUT, int S, int H, int W, bool ADD, bool SRCG>
-__device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args& a, unsigned char* lds, int chunk0) {
+__device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args& a, unsigned char* lds, int chunk0, const Tail2Next& nx, int stamp_slot = -1) {
+#ifdef BN_TAIL_STAMPS
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    BN_T2STAMP(0);
     constexpr int KS = CIN / 64, NCT = CIN / 16, NT = COUT / 16;
     constexpr int PIN = CIN + 16, POUT = COUT + 16;
     constexpr int OH = H / S, OW = W / S, PER_CHUNK = OH * OW;
@@ -74,6 +101,7 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     constexpr int PT = S == 1 ? 1 : 0, PL = PT;    // TF SAME padding of a 3x3 window on even maps: 1 / 1 at stride 1, 0 / 1 at stride 2
     constexpr int DWK = SRCG ? 8 : 5;              // v4i per (channel tile, lane group) of depthwise constants
     constexpr int W_BYTES = CIN * COUT, DWA_BYTES = NCT * 3 * 1024, DWC_BYTES = NCT * DWK * 64, PWC_BYTES = NT * 5 * 64;
+    constexpr int PW16 = (W_BYTES + PWC_BYTES) / 16, PWP = (PW16 + kTail2Threads - 1) / kTail2Threads;
     static_assert(PER_CHUNK % (16 * UPW) == 0, "a wave's tiles lie in one chunk");
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -81,15 +109,16 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
 
-    // ---- stage the block's constants (one contiguous run) and the zero-point row --------------------------------------------------
-    copy16<(W_BYTES + DWA_BYTES + DWC_BYTES + PWC_BYTES) / 16>(reinterpret_cast<v4i*>(lds + L.cst_off), reinterpret_cast<const v4i*>(a.cst + L.g_cst), tid);
-    if (!SRCG && tid < PIN / 4) reinterpret_cast<int*>(lds + L.zp_off)[tid] = (L.zp_in & 0xff) * 0x01010101;
-    __syncthreads();
+    // ---- request the block's pointwise part (its depthwise part and zero-point row are in LDS already) ------------------------------
+    v4i pwr[PWP];
+    part_load(pwr, a.cst + L.g_cst + (DWA_BYTES + DWC_BYTES) / 4, PW16, tid);
+    BN_T2STAMP(1);
+    BN_T2STAMP(2);
 
-    const v4i* wl = reinterpret_cast<const v4i*>(lds + L.cst_off) + lane;
-    const v4i* dwa = reinterpret_cast<const v4i*>(lds + L.cst_off + W_BYTES) + lane;
-    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.cst_off + W_BYTES + DWA_BYTES) + g;
-    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.cst_off + W_BYTES + DWA_BYTES + DWC_BYTES) + g;
+    const v4i* wl = reinterpret_cast<const v4i*>(lds + L.pw_off) + lane;
+    const v4i* dwa = reinterpret_cast<const v4i*>(lds + L.dw_off) + lane;
+    const v4i* dwc = reinterpret_cast<const v4i*>(lds + L.dw_off + DWA_BYTES) + g;
+    const v4i* pwc = reinterpret_cast<const v4i*>(lds + L.pw_off + W_BYTES) + g;
     const int dw_lo = L.dw_lo, dw_hi = L.dw_hi, pw_lo = L.pw_lo, pw_hi = L.pw_hi;
 
     // ---- where this wave's tiles are --------------------------------------------------------------------------------------------
@@ -117,37 +146,76 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     }
 
     // ---- depthwise 3x3 on the matrix cores: all CIN channels of this wave's positions -> B fragments of the pointwise stage -------
+    // (taps from memory: the rows of two channel tiles are in flight ahead of the one in use — the tiles' round trips overlap)
+    constexpr int AHEAD = 2;
+    v4i grow[SRCG ? NCT : 1][SRCG ? NR : 1];
+    if constexpr (SRCG) {
+#pragma unroll
+        for (int ct = 0; ct < AHEAD && ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) grow[ct][r] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, raddr[r] + 16 * ct, 0, 0));
+    }
+    // Software pipeline over the channel tiles, written out (left to itself the scheduler merges all iterations of this loop and runs out of
+    // registers): iteration ct requests the operands of tile ct + 1, issues the matrix instructions of tile ct and requantises tile ct - 1.
     v4i bf[UPW][KS];
+    constexpr int NB0 = SRCG ? UPW : 1;   // start values (the folded bias): one per tile where the border decides which, else one for all
+    v4i af[2][3], brow[2][NR], acc[2][UPW], b0[2][NB0], rqm[2], rq01[2], rq23[2];
+    int rqe[2];
+    auto request = [&](int ct) {   // operands of channel tile ct: A fragments, input rows, start values
+        const int b = ct & 1;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        v4i af[3], brow[NR];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) af[dy] = dwa[(ct * 3 + dy) * 64];
+        for (int dy = 0; dy < 3; ++dy) af[b][dy] = dwa[(ct * 3 + dy) * 64];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            if constexpr (SRCG) brow[r] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, raddr[r] + 16 * ct, 0, 0));
-            else brow[r] = *reinterpret_cast<const v4i*>(lds + raddr[r] + 16 * ct);
+            if constexpr (SRCG) {
+                brow[b][r] = grow[ct][r];
+                if (ct + AHEAD < NCT) grow[ct + AHEAD][r] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, raddr[r] + 16 * (ct + AHEAD), 0, 0));
+            } else {
+                brow[b][r] = *reinterpret_cast<const v4i*>(lds + raddr[r] + 16 * ct);
+            }
         }
         const v4i* dc = dwc + ct * DWK * 4;
-        const v4i m = dc[4], c01 = dc[8], c23 = dc[12];
-        const int e1 = reinterpret_cast<const int*>(dc + 16)[0];
-        const long cc[4] = {pair(c01.x, c01.y), pair(c01.z, c01.w), pair(c23.x, c23.y), pair(c23.z, c23.w)};
-        v4i acc[UPW];
 #pragma unroll
-        for (int t = 0; t < UPW; ++t) acc[t] = SRCG ? dc[bkind[t]] : dc[0];
+        for (int t = 0; t < NB0; ++t) b0[b][t] = SRCG ? dc[bkind[t]] : dc[0];
+    };
+    auto request_rq = [&](int ct) {   // its requantisation constants (needed one iteration later than the rest)
+        const int b = ct & 1;
+        const v4i* dc = dwc + ct * DWK * 4;
+        rqm[b] = dc[4]; rq01[b] = dc[8]; rq23[b] = dc[12];
+        rqe[b] = reinterpret_cast<const int*>(dc + 16)[0];
+    };
+    request(0);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+    for (int ct = 0; ct <= NCT; ++ct) {
+        if (ct + 1 < NCT) request(ct + 1);
+        if (ct < NCT) {
+            const int b = ct & 1;
+            request_rq(ct);
 #pragma unroll
-            for (int t = 0; t < UPW; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[dy], brow[t * TR * S + dy], acc[t], 0, 0, 0);
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int t = 0; t < UPW; ++t) {
-            int qv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qv[e] = med3(rq_hi(acc[t][e], m[e], cc[e], e1, e), dw_lo, dw_hi);
-            bf[t][ct >> 2][ct & 3] = pack4(qv);
+                for (int t = 0; t < UPW; ++t)
+                    acc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[b][dy], brow[b][t * TR * S + dy], dy ? acc[b][t] : b0[b][SRCG ? t : 0], 0, 0, 0);
         }
+        if (ct > 0) {
+            const int pt = ct - 1, b = pt & 1, c = b;
+            const long cc[4] = {pair(rq01[c].x, rq01[c].y), pair(rq01[c].z, rq01[c].w), pair(rq23[c].x, rq23[c].y), pair(rq23[c].z, rq23[c].w)};
+#pragma unroll
+            for (int t = 0; t < UPW; ++t) {
+                int qv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qv[e] = med3(rq_hi(acc[b][t][e], rqm[c][e], cc[e], rqe[c], e), dw_lo, dw_hi);
+                bf[t][pt >> 2][pt & 3] = pack4(qv);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (!SRCG) __syncthreads();   // every wave has read its taps: the map may be overwritten
+    BN_T2STAMP(3);
+    part_store(pwr, lds + L.pw_off, PW16, tid);
+    __syncthreads();   // the pointwise part is in place, and every wave has read its taps: the map may be overwritten
+    BN_T2STAMP(4);
+    v4i dwr[kTail2MaxDw16 / kTail2Threads];
+    if (nx.g) part_load(dwr, nx.g, nx.n16, tid);
 
     // ---- pointwise 1x1 on the matrix cores, requantise, [ADD], store into the map -------------------------------------------------
     const int add_m = L.add_m, add_e1 = L.add_e - 1;
@@ -192,40 +260,99 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
             *reinterpret_cast<int*>(lds + L.y_off + p * POUT + 4 * g + 16 * nt) = pack4(qv);
         }
     }
+    BN_T2STAMP(5);
+    if (nx.g) {
+        part_store(dwr, lds + nx.dw_off, nx.n16, tid);
+        if (tid < nx.zp_n4) reinterpret_cast<int*>(lds + nx.zp_off)[tid] = nx.zp4;
+    }
     __syncthreads();
+    BN_T2STAMP(6);
+#ifdef BN_TAIL_STAMPS
+    if (stamp_slot >= 0 && g_tail2_stamps && (threadIdx.x & 63) == 0) {
+        long long* o = g_tail2_stamps + ((size_t)stamp_slot * kTail2Waves + (threadIdx.x >> 6)) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = st[i];
+    }
+#endif
 }
+
+__device__ __forceinline__ int tail2_dw_bytes(const Tail2Layer& L, bool first) { return (L.Cin / 16) * (3 * 1024 + (first ? 8 : 5) * 64); }
 
 __global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int ngroups = (a.B + kTailG - 1) / kTailG;
+    {   // the first block's depthwise part, once; afterwards every block finds its own staged by its predecessor
+        v4i r0[kTail2MaxDw16 / kTail2Threads];
+        const int n16 = tail2_dw_bytes(a.L[0], true) / 16;
+        part_load(r0, a.cst + a.L[0].g_cst, n16, (int)threadIdx.x);
+        part_store(r0, lds + a.L[0].dw_off, n16, (int)threadIdx.x);
+        __syncthreads();
+    }
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int chunk0 = grp * kTailG;
+        const bool more = grp + (int)gridDim.x < ngroups;
         for (int li = 0; li < a.n_layers; ++li) {
             const Tail2Layer& L = a.L[li];
-            if (L.Cin == 64) tail2_block<64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0);
-            else if (L.Cin == 128 && L.Cout == 128) tail2_block<128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0);
-            else if (L.Cin == 128) tail2_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0);
-            else tail2_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0);
+            const bool last = li == a.n_layers - 1;
+            const Tail2Layer& N = a.L[last ? 0 : li + 1];
+            Tail2Next nx;
+            nx.g = last && !more ? nullptr : a.cst + N.g_cst;
+            nx.n16 = tail2_dw_bytes(N, last) / 16;
+            nx.dw_off = N.dw_off;
+            nx.zp_off = N.zp_off;
+            nx.zp_n4 = last ? 0 : (N.Cin + 16) / 4;   // (the first block reads its taps from memory: no zero-point row)
+            nx.zp4 = (N.zp_in & 0xff) * 0x01010101;
+            int slot = -1;
+#ifdef BN_TAIL_STAMPS
+            const int gi = (grp - (int)blockIdx.x) / (int)gridDim.x;
+            if ((int)blockIdx.x < 8 && gi < 4 && li < 8 && g_tail2_stamps) slot = ((int)blockIdx.x * 4 + gi) * 8 + li;
+#endif
+            if (L.Cin == 64) tail2_block<64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0, nx, slot);
+            else if (L.Cin == 128 && L.Cout == 128) tail2_block<128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0, nx, slot);
+            else if (L.Cin == 128) tail2_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0, nx, slot);
+            else tail2_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0, nx, slot);
         }
         tail_head<kTail2Threads, 16>(a, lds, chunk0);
         __syncthreads();  // the next group overwrites the maps
     }
 }
 
-int tail2_cst_bytes(const Tail2Layer& L, bool first) {
-    return L.Cin * L.Cout + (L.Cin / 16) * 3 * 1024 + (L.Cin / 16) * (first ? 8 : 5) * 64 + (L.Cout / 16) * 5 * 64;
+int tail2_dw_part(const Tail2Layer& L, bool first) { return (L.Cin / 16) * (3 * 1024 + (first ? 8 : 5) * 64); }
+int tail2_pw_part(const Tail2Layer& L) { return L.Cin * L.Cout + (L.Cout / 16) * 5 * 64; }
+
+struct Span2 {
+    int b, e;
+};
+int first_fit2(const std::vector<Span2>& used, int bytes, int cap) {
+    bytes = (bytes + 15) & ~15;
+    int pos = 0;
+    for (;;) {
+        bool moved = false;
+        for (const Span2& s : used)
+            if (pos < s.e && pos + bytes > s.b) {
+                pos = (s.e + 15) & ~15;
+                moved = true;
+            }
+        if (!moved) break;
+    }
+    return pos + bytes > cap ? -1 : pos;
 }
+bool overlap2(int b0, int e0, int b1, int e1) { return b0 < e1 && b1 < e0; }
 
 }  // namespace
 
-// Kernel arguments and LDS plan from the packer's descriptor table (32 words per block + 16 head words).  Per block the map sits at
-// LDS offset 0 (input and output in place), then the zero-point row, then the block's constants; the pooled vector of the head lies
-// behind the last block's constants.  false = not a topology / size the kernel takes (the plan keeps i8_tail_kernel).
+// Kernel arguments and LDS plan from the packer's descriptor table (32 words per block + 16 head words).  A block's map sits at LDS
+// offset 0 (input and output in place).  Its depthwise part and zero-point row are written while the PREVIOUS block's pointwise phase
+// runs: they avoid that block's output map (= this block's input) and pointwise part; its pointwise part is written while its own
+// depthwise phase runs: it avoids the map, the zero-point row and the depthwise part.  The first block's depthwise part is written behind
+// the last block of the previous group and stays through the head: it avoids the last map, the last pointwise part, the pooled vector and
+// the head's copy of the classifier matrix.  false = not a topology / size the kernel takes (the plan keeps i8_tail_kernel).
 bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
     constexpr int LW = kTail2LayerWords, HW = 16, CAP = 160 * 1024;
     if (n_layers < 1 || n_layers > 8 || n_words != LW * n_layers + HW) return false;
     a.n_layers = n_layers;
     int lds_need = 0;
+    Span2 prev_pw{0, 0};
+    auto grow = [&](int end) { lds_need = end > lds_need ? end : lds_need; };
     for (int i = 0; i < n_layers; ++i) {
         const int32_t* d = desc + LW * i;
         Tail2Layer& L = a.L[i];
@@ -249,18 +376,28 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
         if (L.has_add && (L.pw_lo < -255 || L.pw_hi > 255 || L.add_lo < -128 || L.add_hi > 127 || L.add_lo > L.add_hi || L.add_e < 1 || L.add_e > 22 || L.add_m < 0 ||
                           L.res_m < 0 || L.res_k < 3 || L.res_k > 19))
             return false;
+        if (tail2_dw_part(L, first) / 16 > kTail2MaxDw16) return false;
         const int in_bytes = first ? 0 : kTailG * L.H * L.W * (L.Cin + 16), out_bytes = kTailG * L.OH * L.OW * (L.Cout + 16);
+        const Span2 map{0, in_bytes > out_bytes ? in_bytes : out_bytes};
         L.x_off = first ? -1 : 0;
         L.y_off = 0;
-        L.zp_off = in_bytes > out_bytes ? in_bytes : out_bytes;
-        L.cst_off = L.zp_off + ((L.Cin + 16 + 15) & ~15);
-        int end = L.cst_off + tail2_cst_bytes(L, first);
-        if (i == n_layers - 1) {
-            a.mean_off = end;
-            end += kTailG * L.Cout;
+        std::vector<Span2> used{map};
+        if (prev_pw.e > prev_pw.b) used.push_back(prev_pw);
+        L.zp_off = 0;
+        if (!first) {
+            L.zp_off = first_fit2(used, L.Cin + 16, CAP);
+            if (L.zp_off < 0) return false;
+            used.push_back({L.zp_off, L.zp_off + L.Cin + 16});
         }
-        if (end > CAP) return false;
-        lds_need = end > lds_need ? end : lds_need;
+        L.dw_off = first_fit2(used, tail2_dw_part(L, first), CAP);
+        if (L.dw_off < 0) return false;
+        const Span2 dw{L.dw_off, L.dw_off + tail2_dw_part(L, first)};
+        used = {map, dw};
+        if (!first) used.push_back({L.zp_off, L.zp_off + L.Cin + 16});
+        L.pw_off = first_fit2(used, tail2_pw_part(L), CAP);
+        if (L.pw_off < 0) return false;
+        prev_pw = {L.pw_off, L.pw_off + tail2_pw_part(L)};
+        grow(map.e); grow(dw.e); grow(prev_pw.e);
     }
     const int32_t* h = desc + LW * n_layers;
     a.mean_zp_in = h[0]; a.mean_mult = h[1]; a.mean_shift = h[2]; a.mean_zp_out = h[3];
@@ -270,12 +407,35 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
     if (a.fc_lo < -128 || a.fc_hi > 127 || a.fc_lo > a.fc_hi) return false;
     const Tail2Layer& last = a.L[n_layers - 1];
     if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 4 || a.NC < 1 || kTailG * a.NC > kTail2Threads * 4) return false;
-    // the head's LDS copy of the classifier matrix overlays the last block's constants (nobody reads them behind its end barrier)
+    // the first block's depthwise part of the NEXT group is written behind the last block's pointwise phase and lies there through the head
+    const Span2 dw0{a.L[0].dw_off, a.L[0].dw_off + tail2_dw_part(a.L[0], true)};
+    const Span2 map_last{0, kTailG * last.OH * last.OW * (last.Cout + 16)};
+    if (overlap2(dw0.b, dw0.e, map_last.b, map_last.e) || overlap2(dw0.b, dw0.e, prev_pw.b, prev_pw.e)) return false;
+    std::vector<Span2> used{map_last, dw0};
+    a.mean_off = first_fit2(used, kTailG * last.Cout, CAP);
+    if (a.mean_off < 0) return false;
+    used.push_back({a.mean_off, a.mean_off + kTailG * last.Cout});
+    grow(a.mean_off + kTailG * last.Cout);
+    // the head's LDS copy of the classifier matrix (nobody reads the last block's parts behind its end barrier)
     const int fc_bytes = a.NC * (a.C / 4 + 1) * 4;
-    a.fcw_off = (a.C % 16 == 0 && fc_bytes <= tail2_cst_bytes(last, n_layers == 1) && a.NC * (a.C / 16) <= 4096) ? last.cst_off : -1;
+    a.fcw_off = -1;
+    if (a.C % 16 == 0 && a.NC * (a.C / 16) <= 4096) {
+        a.fcw_off = first_fit2(used, fc_bytes, CAP);
+        if (a.fcw_off >= 0) grow(a.fcw_off + fc_bytes);
+    }
     a.lds_bytes = lds_need;
     return true;
 }
+
+namespace {
+int tail2_cst_bytes(const Tail2Layer& L, bool first) { return tail2_dw_part(L, first) + tail2_pw_part(L); }
+}  // namespace
+
+#ifdef BN_TAIL_STAMPS
+extern "C" __attribute__((visibility("default"))) int bn_debug_tail2_stamps(long long* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tail2_stamps), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
+}
+#endif
 
 long tail2_const_words(const Tail2Args& a) {
     long need = 0;

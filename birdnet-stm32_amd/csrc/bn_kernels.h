@@ -383,8 +383,8 @@ struct Tail2Layer {
     int zp_in, dw_lo, dw_hi, pw_lo, pw_hi;        // clamp bounds (pointwise with the ADD: minus the block's own zero point)
     int add_m, add_c1, add_e, add_lo, add_hi;     // output rescale of the ADD (zero point folded into c1) and its clamp
     int res_m, res_c_lo, res_c_hi, res_k;         // rescale of the residual byte: (((b + 128) << 24) res_m + res_c) >> 32 >> res_k
-    int g_cst;                                    // word offset of the block's constants (one run: pointwise A | depthwise A | depthwise | pointwise constants)
-    int x_off, y_off, cst_off, zp_off;            // LDS byte offsets (x_off < 0: the input map is in global memory)
+    int g_cst;                                    // word offset of the block's constants: depthwise part (A fragments | constants), then pointwise part (A fragments | constants)
+    int x_off, y_off, dw_off, pw_off, zp_off;     // LDS byte offsets (x_off < 0: the input map is in global memory)
 };
 struct Tail2Args {
     const int8_t* x;
