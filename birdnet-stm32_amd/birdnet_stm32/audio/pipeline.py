@@ -552,8 +552,14 @@ def balanced_bounds(weights, world: int) -> list[int]:
     still spread).  Deterministic: every rank derives the same bounds from the same headers."""
     w = np.asarray(weights, np.float64) + 0.05
     c = np.concatenate([[0.0], np.cumsum(w)])
-    cuts = [int(np.searchsorted(c, c[-1] * r / world, side="left")) for r in range(world + 1)]
-    cuts[0], cuts[-1] = 0, len(w)
+    cuts = [0] * (world + 1)
+    for r in range(1, world):
+        target = c[-1] * r / world
+        i = int(np.searchsorted(c, target, side="left"))  # first prefix at or above the target ...
+        if i > 0 and i < len(c) and target - c[i - 1] < c[i] - target:
+            i -= 1                                          # ... unless the prefix in front of it is nearer (a long file at the cut goes to the later rank)
+        cuts[r] = min(i, len(w))
+    cuts[-1] = len(w)
     for r in range(1, world + 1):
         cuts[r] = max(cuts[r], cuts[r - 1])
     return cuts

@@ -418,9 +418,18 @@ def tail2_layer_section(b: dict, rq_dw, rq_pw, first: bool) -> np.ndarray:
     * depthwise constants ``[ct][kind][g][4]`` for channel ``16 ct + 4 g + r``: folded bias, multiplier, (C low, C high) of r = 0, 1,
       of r = 2, 3, packed shifts - 1, then the bias for positions whose window leaves the map on the right / at the bottom / both when
       the taps outside read 0 instead of the zero point (first block: taps from memory, range-checked loads);
-    * pointwise constants ``[nt][kind][g][4]``: the same five kinds, or (bias, multiplier, c1, e, 0) with the ADD (signed form)."""
-    wd, w2 = np.asarray(b["wd"], np.int8), np.asarray(b["w2"], np.int8)
+    * pointwise constants ``[nt][kind][g][4]``: the same five kinds.  With the ADD the block's own term may be negative, so the form keeps
+      the sign term of the rounding shift: kinds (bias, M' = 2 m as a signed dword, (2^31, 2^(e-1)) pairs, packed shifts e) of
+      ``v = (hi + x + (x >> 31)) >> e`` with ``hi = (x M' + C) >> 32`` — because M' is read as 2 m - 2^32, ``hi = SRDHM(x, m) + 2^(e-1) - x``
+      (csrc/bn_i8_tail2.hip: rq_signed; ``tail2_constants`` checks the conditions).  A dead channel (vanishing scale, constant output q)
+      gets zero weights and bias, M' = 0, e = 1 and 2 q in place of 2^(e-1)."""
+    wd, w2 = np.asarray(b["wd"], np.int8), np.asarray(b["w2"], np.int8).copy()
+    b2 = np.asarray(b["b2"], np.int64).copy()
     C, N = b["C"], b["N"]
+    if b["add"][0]:
+        dead = np.asarray(rq_pw[0]) == 0
+        w2[dead, :] = 0
+        b2[dead] = 0
     KS, NCT, NT = C // 64, C // 16, N // 16
     lane = np.arange(64)
     m_, g_ = lane & 15, lane >> 4
@@ -454,10 +463,18 @@ def tail2_layer_section(b: dict, rq_dw, rq_pw, first: bool) -> np.ndarray:
             dwc[:, k] = (bdw + b["z_in"] * lost)[ch]
     cho = 16 * np.arange(NT)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :]  # [nt][g][r]
     pwc = np.zeros((NT, TAIL2_PW_KINDS, 4, 4), np.int32)
-    pwc[:, 0] = np.asarray(b["b2"], np.int32)[cho]
+    pwc[:, 0] = b2.astype(np.int32)[cho]
     if b["add"][0]:
-        for k in range(3):
-            pwc[:, 1 + k] = rq_pw[k][cho]
+        m, c1, e = (np.asarray(v, np.int64) for v in rq_pw)
+        dead = m == 0
+        m2 = np.where(dead, 0, 2 * m - (1 << 32)).astype(np.int32)            # 2 m read as a signed dword
+        half = np.where(dead, c1 - 1, np.int64(1) << (e - 1)).astype(np.int32)   # dead: c1 = 1 + 2 q, e = 1 (_strip_requant)
+        lo = np.full(N, -(1 << 31), np.int64).astype(np.int32)
+        pwc[:, 1] = m2[cho]
+        pwc[:, 2] = np.stack([lo[cho][..., 0], half[cho][..., 0], lo[cho][..., 1], half[cho][..., 1]], axis=-1)
+        pwc[:, 3] = np.stack([lo[cho][..., 2], half[cho][..., 2], lo[cho][..., 3], half[cho][..., 3]], axis=-1)
+        ec = e[cho]
+        pwc[:, 4, :, 0] = (ec[..., 0] | (ec[..., 1] << 8) | (ec[..., 2] << 16) | (ec[..., 3] << 24)).astype(np.int32)
     else:
         m, clo, chi, e1 = _rq_hi_consts(rq_pw)
         pwc[:, 1] = m[cho]
@@ -479,7 +496,8 @@ def tail2_constants(blocks: list[dict], head: dict):
 
     Descriptor words per block (32): H W Cin Cout S OH OW pt pl has_add zp_in dw_lo dw_hi pw_lo pw_hi add_m add_c1 add_e add_lo add_hi
     res_m res_c_lo res_c_hi res_k g_cst 0...; with the ADD the pointwise stage produces its value MINUS its zero point (clamp bounds
-    shifted accordingly).  Head words as in ``tail_constants``."""
+    shifted accordingly).  Head words as in ``tail_constants`` except g_w = the classifier as matrix-core fragments, g_bias = its
+    constants in lane order, g_mult = g_shift = 0."""
     sections, desc = [], []
     pos = 0
 
@@ -525,11 +543,28 @@ def tail2_constants(blocks: list[dict], head: dict):
             own = np.arange(-128, 128, dtype=np.int64) - b["z_pw"]
             if not np.array_equal(want, got) or not np.array_equal(qz.requantize(own << 20, m2, s2), own << 19) or np.abs(want).max() >= 2**29:
                 return None
+            # the own term v = MBQM(acc) is NOT clamped to int8 in the kernel: where the clamp would act, the sum saturates the output either
+            # way (checked on the table of the whole ADD), and v must stay small enough for (v << 19) + f to stay below 2^30
+            mq, _, eq = (np.asarray(v, np.int64) for v in rq_pw)
+            live = mq != 0
+            if (mq[live] == 1 << 30).any():
+                return None   # (sign of SRDHM(x, 2^30) differs from the sign of x at x = -1)
+            v_lo = qz.requantize(lo_pw, np.asarray(b["mu2"]), np.asarray(b["sh2"]))
+            v_hi = qz.requantize(hi_pw, np.asarray(b["mu2"]), np.asarray(b["sh2"]))
+            if max(np.abs(v_lo).max(), np.abs(v_hi).max()) >= 1 << 11:   # ((v << 19) + f stays inside int32)
+                return None
+            full = add_table(add, b["z_pw"])   # [residual byte pattern][own + 128]: columns beyond the int8 clamp of the own value must equal the edge columns
+            own_all = np.arange(-2048, 2048, dtype=np.int64)
+            sa = qz.requantize((np.arange(256).astype(np.uint8).view(np.int8).astype(np.int64) - z1) << 20, m1, s1)
+            unclamped = np.clip(qz.requantize(sa[:, None] + (own_all[None, :] << 19), mo, so) + zo, amin, amax)
+            clamped_cols = np.clip(own_all + b["z_pw"], b["pw_lo"], b["pw_hi"]) + 128
+            if not np.array_equal(unclamped, full[:, clamped_cols].astype(np.int64)):
+                return None
             res_m, res_c, res_k = m1, R << 24, 3 + e1
             add_m, add_e = mo, -so
             add_c1 = (1 << (add_e - 1)) + (zo << add_e)
             add_lo, add_hi = amin, amax
-            pw_lo, pw_hi = pw_lo - b["z_pw"], pw_hi - b["z_pw"]
+            pw_lo, pw_hi = -2048, 2048   # (not used by the kernel: see above)
         g_cst = put(tail2_layer_section(b, rq_dw, rq_pw, first=(i == 0)))
         row = [b["H"], b["W"], C, N, b["sh"], b["OH"], b["OW"], b["pt"], b["pl"], int(bool(add[0])), b["z_in"], b["dw_lo"], b["dw_hi"],
                pw_lo, pw_hi, add_m, add_c1, add_e, add_lo, add_hi, res_m, res_c & 0xFFFFFFFF, res_c >> 32, res_k, g_cst]
@@ -537,8 +572,27 @@ def tail2_constants(blocks: list[dict], head: dict):
     h = head
     if h["C"] != 256 or h["C"] != blocks[-1]["N"] or h["P"] != blocks[-1]["OH"] * blocks[-1]["OW"] or TAIL_G * h["NC"] > 1024:
         return None
+    # FULLY_CONNECTED on the matrix cores: A fragments [class tile][ks][lane][16 bytes] = W[16 ct + m][64 ks + 16 g + j] (classes padded to
+    # a multiple of 16 with zero rows), constants [class tile][kind: bias, multiplier, shift][g][4] for class 16 ct + 4 g + r
+    fcw = np.asarray(h["fc_w"], np.int8)
+    NC, Cfc = h["NC"], h["C"]
+    if fcw.shape != (NC, Cfc) or Cfc % 64:
+        return None
+    nct = (NC + 15) // 16
+    wpad = np.zeros((nct * 16, Cfc), np.int8)
+    wpad[:NC] = fcw
+    lane = np.arange(64)
+    m_, g_ = lane & 15, lane >> 4
+    fcf = np.zeros((nct, Cfc // 64, 64, 16), np.int8)
+    for ct in range(nct):
+        for ks in range(Cfc // 64):
+            for j in range(16):
+                fcf[ct, ks, :, j] = wpad[16 * ct + m_, 64 * ks + 16 * g_ + j]
+    cls = 16 * np.arange(nct)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :]   # [ct][g][r]
+    pad = lambda v: np.concatenate([np.asarray(v, np.int32), np.zeros(nct * 16 - NC, np.int32)])  # noqa: E731
+    fcc = np.stack([pad(h["fc_b"])[cls], pad(h["fc_m"])[cls], pad(h["fc_s"])[cls]], axis=1)   # [ct][kind][g][r]
     desc += [h["mean_zp_in"], h["mean_mult"], h["mean_shift"], h["mean_zp_out"], h["fc_zp_out"], h["fc_lo"], h["fc_hi"],
-             put(np.ascontiguousarray(np.asarray(h["fc_w"], np.int8)).view(np.int32)), put(h["fc_b"]), put(h["fc_m"]), put(h["fc_s"]),
+             put(fcf.view(np.int32)), put(fcc), 0, 0,
              put(np.asarray(h["lut"], np.int8).view(np.int32)) if h["lut"] is not None else -1, h["zp_fc"], h["zp_head"], h["P"], h["C"]]
     assert len(desc) == TAIL2_LAYER_WORDS * len(blocks) + TAIL_HEAD_WORDS
     return np.concatenate(sections).astype(np.int32), np.asarray(desc, np.int32)

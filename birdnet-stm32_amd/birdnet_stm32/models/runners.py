@@ -202,6 +202,13 @@ class HipRunner:
         _hip.check(self.lib.bn_debug_guard_stats(self.model.handle, B, out))
         return {"listed": int(out[0]), "listed_max": int(out[1]), "dirty_blocks": int(out[2]), "whole_minmax": int(out[3]), "whole_fix": int(out[4])}
 
+    def tail_form(self) -> tuple[int, int]:
+        """Test hook: (form, LDS bytes) of the fused INT8 tail operator this plan can run — 0 none, 1 ``i8_tail_kernel``, 2 also
+        ``i8_tail2_kernel`` (depthwise stage on the matrix cores)."""
+        form, lds = ctypes.c_int(0), ctypes.c_int(0)
+        _hip.check(self.lib.bn_debug_tail_form(self.model.handle, ctypes.byref(form), ctypes.byref(lds)))
+        return form.value, lds.value
+
     # -- per-operator timing (HIP events on the launch stream) ------------------------------------
     def profile(self, enable: bool) -> None:
         _hip.check(self.lib.bn_profile_enable(self.model.handle, int(bool(enable))))

@@ -1233,6 +1233,18 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     return rc;
 }
 
+int bn_debug_tail_form(const bn_model* m, int* form, int* lds_bytes) {
+    if (!m || !form || !lds_bytes) return fail(BN_ERR_ARG, "null argument");
+    *form = 0;
+    *lds_bytes = 0;
+    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+        if (m->ops[oi].kind != BN_OP_I8_TAIL || !m->tail_ok[oi]) continue;
+        *form = m->tail2_ok[oi] ? 2 : 1;
+        *lds_bytes = m->tail2_ok[oi] ? m->tails2[oi].lds_bytes : m->tails[oi].lds_bytes;
+    }
+    return BN_OK;
+}
+
 int bn_debug_guard_stats(bn_model* m, int B, int64_t* out) {
     if (!m || !out) return fail(BN_ERR_ARG, "null argument");
     if (int rc = check_device(m->ctx)) return rc;

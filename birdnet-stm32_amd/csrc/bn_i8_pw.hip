@@ -269,11 +269,19 @@ void launch_i8_pw_lds(const DwPw8Args& a, hipStream_t s) {
     g.walkers = (int)walkers;
     const unsigned blocks = (unsigned)(walkers * g.n_slices);
     g.tab = a.add.enabled && a.add_tab && g_opt.i8_add_tab && (a.rq_right & 4) && (size_t)g.ns * (a.Cin + 20) + 65536 <= kPwLdsBudget ? 1 : 0;
-    const size_t smem = (size_t)g.ns * (a.Cin + 20) + (g.tab ? 65536 : 0);
-    const bool hi = (a.rq_right & 2) && a.pw_amin >= a.pw_zp_out;
+    size_t smem = (size_t)g.ns * (a.Cin + 20) + (g.tab ? 65536 : 0);
+    // the sign-free form is for operators behind a ReLU only: with a residual ADD the block's own value is linear (any sign) and the kernel's
+    // epilogue applies the ADD in its other branch — ADD + HI would drop the residual; option i8_pw_forms = 0 forces the general form
+    const bool hi = g_opt.i8_pw_forms && (a.rq_right & 2) && a.pw_amin >= a.pw_zp_out && !a.add.enabled;
+    // a runtime that refuses the LDS limit with the ADD table gets the two-table form (64 KB less); a second refusal surfaces as the launch error
 #define BN_PWL1(ADDV, GATEV, KSV, NCTV, HIV)                                                                                    \
     do {                                                                                                                        \
-        if (smem > 64 * 1024) ensure_dynamic_lds((const void*)i8_pw_lds_kernel<ADDV, GATEV, KSV, NCTV, HIV>, smem);             \
+        const void* fn = (const void*)i8_pw_lds_kernel<ADDV, GATEV, KSV, NCTV, HIV>;                                            \
+        if (smem > 64 * 1024 && !ensure_dynamic_lds(fn, smem) && g.tab) {                                                       \
+            g.tab = 0;                                                                                                          \
+            smem -= 65536;                                                                                                      \
+            if (smem > 64 * 1024) (void)ensure_dynamic_lds(fn, smem);                                                           \
+        }                                                                                                                       \
         hipLaunchKernelGGL((i8_pw_lds_kernel<ADDV, GATEV, KSV, NCTV, HIV>), dim3(blocks), dim3(kPwLdsThreads), smem, s, a, g); \
     } while (0)
 #define BN_PWL(ADDV, GATEV, KSV, NCTV)                   \

@@ -60,32 +60,118 @@ __device__ long long* g_tail2_stamps = nullptr;   // [workgroup < 8][group < 4][
 
 __device__ __forceinline__ long upair(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
 
-// Constant parts travel global -> registers -> LDS in two halves so that the round trip hides behind a compute phase: part_load issues
-// range-checked 16-byte buffer loads (pieces past the part read 0 and are never stored), part_store writes them.
+// Constant parts travel global -> LDS without passing through registers (global_load_lds_dwordx4: every lane's 16 bytes land at the wave's
+// LDS base + 16 lane): requested before a compute phase, complete at the barrier behind it (__syncthreads waits for the wave's outstanding
+// vector-memory operations, which is what orders the LDS-DMA for the readers).  n16 = sixteen-byte pieces; MAXP rounds of kTail2Threads pieces.
 template <int MAXP>
-__device__ __forceinline__ void part_load(v4i (&r)[MAXP], const int32_t* src, int n16, int tid) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(src), 0, n16 * 16, 0x00020000);
+__device__ __forceinline__ void part_request(const int32_t* src, unsigned char* dst, int n16, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) r[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * kTail2Threads + tid) * 16, 0, 0));
-}
-template <int MAXP>
-__device__ __forceinline__ void part_store(const v4i (&r)[MAXP], unsigned char* dst, int n16, int tid) {
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i)
-        if (i * kTail2Threads + tid < n16) reinterpret_cast<v4i*>(dst)[i * kTail2Threads + tid] = r[i];
+    for (int i = 0; i < MAXP; ++i) {
+        const int idx = i * kTail2Threads + tid;
+        if (idx < n16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (size_t)idx),
+                                             (__attribute__((address_space(3))) void*)(dst + (i * kTail2Threads + wave * 64) * 16), 16, 0, 0);
+    }
 }
 constexpr int kTail2MaxDw16 = 7 * kTail2Threads;   // sixteen-byte pieces of the largest depthwise part a block may prefetch (256 channels: 3392)
 
-// what a block stages for its successor while its own pointwise phase runs
-struct Tail2Next {
-    const int32_t* g;   // the successor's depthwise part in the constant block (null: nothing follows)
-    int n16, dw_off;    // its size in 16-byte pieces, its place in LDS
-    int zp_off, zp_n4, zp4;  // the successor's zero-point row: place, dwords (0: none), value
-};
+__device__ __forceinline__ int tail2_dw_bytes(const Tail2Layer& L, bool first) { return (L.Cin / 16) * (3 * 1024 + (first ? 8 : 5) * 64); }
+
+// MultiplyByQuantizedMultiplier for either sign in four instructions (the block's own term of a residual ADD: no activation, no clamp):
+//   hi = (x M' + C) >> 32 with M' = the dword 2 m read as signed (= 2 m - 2^32) and C = (2^(e-1) << 32) + 2^31
+//      = SRDHM(x, m) + 2^(e-1) - x          (x M' = 2 x m - x 2^32; SRDHM(x, m) = (2 x m + 2^31) >> 32)
+//   v  = (hi + x + (x >> 31)) >> e          (the sign of SRDHM(x, m) is the sign of x for 2^30 < m < 2^31: tail2_constants checks)
+// The four shifts of a channel quad sit in the bytes of one register.
+__device__ __forceinline__ int rq_signed(int x, int m2, long c, int e_packed, int e) {
+    const int hi = (int)(((long)x * (long)m2 + c) >> 32);
+    const int s = hi + x + (x >> 31);
+    int r;
+    switch (e) {
+        case 0: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(e_packed), "v"(s)); break;
+        case 1: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(e_packed), "v"(s)); break;
+        case 2: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(e_packed), "v"(s)); break;
+        default: asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(e_packed), "v"(s)); break;
+    }
+    return r;
+}
+
+// MEAN -> FULLY_CONNECTED -> LOGISTIC / DEQUANTIZE for the workgroup's chunks (reference operators #52-#55).
+//   MEAN: thread (chunk slot, channel quad) walks the positions with one dword read each (waves 0-3);
+//   FULLY_CONNECTED on the matrix cores: wave w owns the class tile 16 w .., its A fragments come straight from memory (requested before the
+//   MEAN, 1 KB per k-step, contiguous), B = the pooled vectors from LDS (column n = chunk slot n & 3: columns 4..15 repeat, lanes n < 4 store).
+__device__ __forceinline__ void tail2_head(const Tail2Args& a_, unsigned char* lds, int chunk0) {
+    // (the head's dozen scalar arguments are read from the kernel-argument segment HERE, through a pointer the optimiser cannot see through:
+    // hoisted to the top of the kernel they stayed live across every block and the scalar registers spilled)
+    const Tail2Args* ap = (const Tail2Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const Tail2Args& a = *ap;
+    (void)a_;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const Tail2Layer& L = a.L[a.n_layers - 1];
+    const int C = a.C, KS = C / 64, nct = (a.NC + 15) / 16, pitch = C + 16;
+    const bool fc_wave = wave < nct;
+    // (waves without a class tile repeat the last tile's requests: uniform code, nothing stored)
+    const v4i* gw = reinterpret_cast<const v4i*>(a.cst + a.g_fcw) + (fc_wave ? wave : nct - 1) * KS * 64 + lane;
+    const v4i af0 = gw[0], af1 = KS > 1 ? gw[64] : af0, af2 = KS > 2 ? gw[128] : af0, af3 = KS > 3 ? gw[192] : af0;
+    const v4i* fc = reinterpret_cast<const v4i*>(a.cst + a.g_fcb) + (fc_wave ? wave : nct - 1) * 12 + g;   // [kind][g]
+    const v4i fc_b = fc[0], fc_mu = fc[4], fc_sh = fc[8];
+    for (int i = tid; i < kTailG * (C / 4); i += kTail2Threads) {
+        const int gq = i / (C / 4), cq = i - gq * (C / 4);
+        const int* src = reinterpret_cast<const int*>(lds + L.y_off + gq * a.P * pitch + 4 * cq);
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int k = 0;
+        for (; k + 8 <= a.P; k += 8) {   // eight independent reads in flight
+            int x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = src[(k + u) * (pitch / 4)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += (int)(int8_t)x[u]; s1 += (int)(int8_t)(x[u] >> 8); s2 += (int)(int8_t)(x[u] >> 16); s3 += x[u] >> 24; }
+        }
+        for (; k < a.P; ++k) {
+            const int x = src[k * (pitch / 4)];
+            s0 += (int)(int8_t)x; s1 += (int)(int8_t)(x >> 8); s2 += (int)(int8_t)(x >> 16); s3 += x >> 24;
+        }
+        const int q[4] = {mean_q(s0, a.P, a.mean_zp_in, a.mean_mult, a.mean_shift, a.mean_zp_out), mean_q(s1, a.P, a.mean_zp_in, a.mean_mult, a.mean_shift, a.mean_zp_out),
+                          mean_q(s2, a.P, a.mean_zp_in, a.mean_mult, a.mean_shift, a.mean_zp_out), mean_q(s3, a.P, a.mean_zp_in, a.mean_mult, a.mean_shift, a.mean_zp_out)};
+        reinterpret_cast<int*>(lds + a.mean_off)[i] = pack4(q);
+    }
+    __syncthreads();
+    if (fc_wave) {
+        v4i acc = fc_b;
+        const v4i mu = fc_mu, sh = fc_sh;
+        const unsigned char* mv = lds + a.mean_off + (n & (kTailG - 1)) * C + 16 * g;
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0, *reinterpret_cast<const v4i*>(mv), acc, 0, 0, 0);
+        if (KS > 1) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, *reinterpret_cast<const v4i*>(mv + 64), acc, 0, 0, 0);
+        if (KS > 2) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af2, *reinterpret_cast<const v4i*>(mv + 128), acc, 0, 0, 0);
+        if (KS > 3) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af3, *reinterpret_cast<const v4i*>(mv + 192), acc, 0, 0, 0);
+        const int chunk = chunk0 + n;
+        if (n < kTailG && chunk < a.B) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * wave + 4 * g + r;
+                if (j < a.NC) {
+                    const int qv = clampi(mbqm(acc[r], mu[r], sh[r]) + a.fc_zp_out, a.fc_lo, a.fc_hi);
+                    const size_t o = (size_t)chunk * a.NC + j;
+                    if (a.logits) a.logits[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
+                    if (a.g_hlut >= 0) {
+                        const int ov = reinterpret_cast<const int8_t*>(a.cst + a.g_hlut)[qv + 128];
+                        a.scores[o] = (float)(ov - a.head_zp_out) * a.s_head;
+                    } else {
+                        a.scores[o] = (float)(qv - a.head_zp_fc) * a.s_fc;
+                    }
+                }
+            }
+        }
+    }
+}
 
 // One block for the kTailG chunks of the workgroup; maps are [chunk][position][C + 16 bytes], input and output at the same place.
 template <int CIN, int COUT, int S, int H, int W, bool ADD, bool SRCG>
-__device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args& a, unsigned char* lds, int chunk0, const Tail2Next& nx, int stamp_slot = -1) {
+__device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args& a, unsigned char* lds, int chunk0, int nxi, int stamp_slot = -1) {
 #ifdef BN_TAIL_STAMPS
     long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -110,8 +196,7 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     const int n = lane & 15, g = lane >> 4;
 
     // ---- request the block's pointwise part (its depthwise part and zero-point row are in LDS already) ------------------------------
-    v4i pwr[PWP];
-    part_load(pwr, a.cst + L.g_cst + (DWA_BYTES + DWC_BYTES) / 4, PW16, tid);
+    part_request<PWP>(a.cst + L.g_cst + (DWA_BYTES + DWC_BYTES) / 4, lds + L.pw_off, PW16, tid);
     BN_T2STAMP(1);
     BN_T2STAMP(2);
 
@@ -146,8 +231,8 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     }
 
     // ---- depthwise 3x3 on the matrix cores: all CIN channels of this wave's positions -> B fragments of the pointwise stage -------
-    // (taps from memory: the rows of two channel tiles are in flight ahead of the one in use — the tiles' round trips overlap)
-    constexpr int AHEAD = 2;
+    // (taps from memory: the rows of up to four channel tiles — all of a 64-channel block — are requested before the first is used: one round trip)
+    constexpr int AHEAD = NCT < 4 ? NCT : 4;
     v4i grow[SRCG ? NCT : 1][SRCG ? NR : 1];
     if constexpr (SRCG) {
 #pragma unroll
@@ -211,11 +296,12 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
         __builtin_amdgcn_sched_barrier(0);
     }
     BN_T2STAMP(3);
-    part_store(pwr, lds + L.pw_off, PW16, tid);
-    __syncthreads();   // the pointwise part is in place, and every wave has read its taps: the map may be overwritten
+    __syncthreads();   // the pointwise part has landed, and every wave has read its taps: the map may be overwritten
     BN_T2STAMP(4);
-    v4i dwr[kTail2MaxDw16 / kTail2Threads];
-    if (nx.g) part_load(dwr, nx.g, nx.n16, tid);
+    // the successor's depthwise part (block 0 of the next group behind the last block): requested now, complete at the end barrier
+    const Tail2Layer& N = a.L[nxi < 0 ? 0 : nxi];
+    const int nx_n16 = nxi < 0 ? 0 : tail2_dw_bytes(N, nxi == 0) / 16;
+    part_request<kTail2MaxDw16 / kTail2Threads>(a.cst + N.g_cst, lds + N.dw_off, nx_n16, tid);
 
     // ---- pointwise 1x1 on the matrix cores, requantise, [ADD], store into the map -------------------------------------------------
     const int add_m = L.add_m, add_e1 = L.add_e - 1;
@@ -224,47 +310,70 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     const long res_c = upair((uint32_t)L.res_c_lo, (uint32_t)L.res_c_hi);
     const int res_k = L.res_k;
     const int pbase = tile0 * 16 + n;
-#pragma unroll 2
-    for (int nt = 0; nt < NT; ++nt) {
+    // Software pipeline over the tiles of 16 output channels, written out like the depthwise loop's: iteration nt requests the A fragments and
+    // start values of tile nt + 2 and the epilogue's operands (constants, residual bytes) of tile nt + 1, issues the matrix instructions of tile
+    // nt + 1 and runs the epilogue of tile nt — no LDS round trip and no matrix-pipe latency in front of the vector work.
+    v4i paf[2][KS], pb0[2], pacc[2][UPW], pm[2], pc01[2], pc23[2];
+    int pe1[2], pres[2][ADD ? UPW : 1];
+    auto request_a = [&](int nt) {
+        const int b = nt & 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) paf[b][ks] = wl[(nt * KS + ks) * 64];
+        pb0[b] = pwc[nt * 20];
+    };
+    auto request_e = [&](int nt) {
+        const int b = nt & 1;
         const v4i* pc = pwc + nt * 20;
-        v4i acc[UPW];
+        pm[b] = pc[4]; pc01[b] = pc[8]; pc23[b] = pc[12];   // (multiplier, C01, C23) + packed shifts; with the ADD: the signed form's operands (rq_signed)
+        pe1[b] = reinterpret_cast<const int*>(pc + 16)[0];
+        if constexpr (ADD) {
 #pragma unroll
-        for (int t = 0; t < UPW; ++t) acc[t] = pc[0];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const v4i af = wl[(nt * KS + ks) * 64];
-#pragma unroll
-            for (int t = 0; t < UPW; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[t][ks], acc[t], 0, 0, 0);
+            for (int t = 0; t < UPW; ++t) pres[b][t] = *reinterpret_cast<const int*>(lds + L.x_off + (pbase + 16 * t) * PIN + 4 * g + 16 * nt);
         }
-        const v4i m = pc[4], c1 = pc[8], sh = pc[12];  // ADD: (multiplier, c1, shift); else (multiplier, C01, C23) + packed shifts
-        const int e1 = ADD ? 0 : reinterpret_cast<const int*>(pc + 16)[0];
-        const long cc[4] = {pair(c1.x, c1.y), pair(c1.z, c1.w), pair(sh.x, sh.y), pair(sh.z, sh.w)};
+    };
+    auto matrix = [&](int nt) {
+        const int b = nt & 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < UPW; ++t) pacc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(paf[b][ks], bf[t][ks], ks ? pacc[b][t] : pb0[b], 0, 0, 0);
+    };
+    request_a(0);
+    request_e(0);
+    if (NT > 1) request_a(1);
+    matrix(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int b = nt & 1;
+        if (nt + 1 < NT) {
+            request_e(nt + 1);
+            matrix(nt + 1);
+        }
+        if (nt + 2 < NT) request_a(nt + 2);   // (into the fragments' slot of tile nt: its matrix instructions were issued an iteration ago)
+        const long cc[4] = {pair(pc01[b].x, pc01[b].y), pair(pc01[b].z, pc01[b].w), pair(pc23[b].x, pc23[b].y), pair(pc23[b].z, pc23[b].w)};
 #pragma unroll
         for (int t = 0; t < UPW; ++t) {
             const int p = pbase + 16 * t;
-            int xr = 0;
-            if constexpr (ADD) xr = *reinterpret_cast<const int*>(lds + L.x_off + p * PIN + 4 * g + 16 * nt) ^ (int)0x80808080u;  // residual bytes + 128
+            const int xr = ADD ? pres[b][t] ^ (int)0x80808080u : 0;  // residual bytes + 128
             int qv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if constexpr (ADD) {
-                    const int v = med3(rq(acc[t][e], m[e], c1[e], sh[e]), pw_lo, pw_hi);                 // the block's own value minus its zero point
+                    const int v = rq_signed(pacc[b][t][e], pm[b][e], cc[e], pe1[b], e);                       // the block's own value minus its zero point
                     const uint32_t xt = (uint32_t)perm(0, xr, ((uint32_t)e << 24) | 0x000c0c0cu);            // (b + 128) << 24
                     const int f = (int)((uint32_t)(((unsigned long)xt * (unsigned long)res_m + (unsigned long)res_c) >> 32) >> res_k);
                     const int total = (v << 19) + f;
                     qv[e] = med3((int)(((long)total * (long)add_m + add_c) >> 32) >> add_e1, L.add_lo, L.add_hi);
                 } else {
-                    qv[e] = med3(rq_hi(acc[t][e], m[e], cc[e], e1, e), pw_lo, pw_hi);
+                    qv[e] = med3(rq_hi(pacc[b][t][e], pm[b][e], cc[e], pe1[b], e), pw_lo, pw_hi);
                 }
             }
             *reinterpret_cast<int*>(lds + L.y_off + p * POUT + 4 * g + 16 * nt) = pack4(qv);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     BN_T2STAMP(5);
-    if (nx.g) {
-        part_store(dwr, lds + nx.dw_off, nx.n16, tid);
-        if (tid < nx.zp_n4) reinterpret_cast<int*>(lds + nx.zp_off)[tid] = nx.zp4;
-    }
+    if (nxi > 0 && tid < (N.Cin + 16) / 4) reinterpret_cast<int*>(lds + N.zp_off)[tid] = (N.zp_in & 0xff) * 0x01010101;   // (block 0 has no zero-point row)
     __syncthreads();
     BN_T2STAMP(6);
 #ifdef BN_TAIL_STAMPS
@@ -275,16 +384,11 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
 #endif
 }
 
-__device__ __forceinline__ int tail2_dw_bytes(const Tail2Layer& L, bool first) { return (L.Cin / 16) * (3 * 1024 + (first ? 8 : 5) * 64); }
-
 __global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int ngroups = (a.B + kTailG - 1) / kTailG;
     {   // the first block's depthwise part, once; afterwards every block finds its own staged by its predecessor
-        v4i r0[kTail2MaxDw16 / kTail2Threads];
-        const int n16 = tail2_dw_bytes(a.L[0], true) / 16;
-        part_load(r0, a.cst + a.L[0].g_cst, n16, (int)threadIdx.x);
-        part_store(r0, lds + a.L[0].dw_off, n16, (int)threadIdx.x);
+        part_request<kTail2MaxDw16 / kTail2Threads>(a.cst + a.L[0].g_cst, lds + a.L[0].dw_off, tail2_dw_bytes(a.L[0], true) / 16, (int)threadIdx.x);
         __syncthreads();
     }
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -294,13 +398,8 @@ __global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
             const Tail2Layer& L = a.L[li];
             const bool last = li == a.n_layers - 1;
             const Tail2Layer& N = a.L[last ? 0 : li + 1];
-            Tail2Next nx;
-            nx.g = last && !more ? nullptr : a.cst + N.g_cst;
-            nx.n16 = tail2_dw_bytes(N, last) / 16;
-            nx.dw_off = N.dw_off;
-            nx.zp_off = N.zp_off;
-            nx.zp_n4 = last ? 0 : (N.Cin + 16) / 4;   // (the first block reads its taps from memory: no zero-point row)
-            nx.zp4 = (N.zp_in & 0xff) * 0x01010101;
+            const int nx = last ? (more ? 0 : -1) : li + 1;   // whose depthwise part this block stages (-1: nothing follows)
+            (void)N;
             int slot = -1;
 #ifdef BN_TAIL_STAMPS
             const int gi = (grp - (int)blockIdx.x) / (int)gridDim.x;
@@ -311,7 +410,7 @@ __global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
             else if (L.Cin == 128) tail2_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0, nx, slot);
             else tail2_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0, nx, slot);
         }
-        tail_head<kTail2Threads, 16>(a, lds, chunk0);
+        tail2_head(a, lds, chunk0);
         __syncthreads();  // the next group overwrites the maps
     }
 }
@@ -370,10 +469,10 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
         if (i > 0 && (L.H != a.L[i - 1].OH || L.W != a.L[i - 1].OW || L.Cin != a.L[i - 1].Cout)) return false;
         if (L.g_cst < 0 || (L.g_cst & 3)) return false;
         if (first && L.zp_in != -128) return false;   // (zero-filled taps + border biases assume it; the packer checks the same)
-        // every clamp whose result is stored as a byte is an int8 range; with the ADD the pointwise value is kept minus its zero point
+        // every clamp whose result is stored as a byte is an int8 range (with the ADD the block's own term is not clamped: pw_lo / pw_hi unused)
         if (L.dw_lo < -128 || L.dw_hi > 127 || L.dw_lo > L.dw_hi || L.pw_lo > L.pw_hi) return false;
         if (!L.has_add && (L.pw_lo < -128 || L.pw_hi > 127)) return false;
-        if (L.has_add && (L.pw_lo < -255 || L.pw_hi > 255 || L.add_lo < -128 || L.add_hi > 127 || L.add_lo > L.add_hi || L.add_e < 1 || L.add_e > 22 || L.add_m < 0 ||
+        if (L.has_add && (L.add_lo < -128 || L.add_hi > 127 || L.add_lo > L.add_hi || L.add_e < 1 || L.add_e > 22 || L.add_m < 0 ||
                           L.res_m < 0 || L.res_k < 3 || L.res_k > 19))
             return false;
         if (tail2_dw_part(L, first) / 16 > kTail2MaxDw16) return false;
@@ -403,10 +502,10 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
     a.mean_zp_in = h[0]; a.mean_mult = h[1]; a.mean_shift = h[2]; a.mean_zp_out = h[3];
     a.fc_zp_out = h[4]; a.fc_lo = h[5]; a.fc_hi = h[6]; a.g_fcw = h[7]; a.g_fcb = h[8]; a.g_fcm = h[9]; a.g_fcs = h[10]; a.g_hlut = h[11];
     a.head_zp_fc = h[12]; a.head_zp_out = h[13]; a.P = h[14]; a.C = h[15];
-    if (a.g_fcw < 0 || a.g_fcb < 0 || a.g_fcm < 0 || a.g_fcs < 0 || a.g_hlut < -1 || (a.g_fcw & 3)) return false;
+    if (a.g_fcw < 0 || a.g_fcb < 0 || a.g_hlut < -1 || (a.g_fcw & 3) || (a.g_fcb & 3)) return false;
     if (a.fc_lo < -128 || a.fc_hi > 127 || a.fc_lo > a.fc_hi) return false;
     const Tail2Layer& last = a.L[n_layers - 1];
-    if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 4 || a.NC < 1 || kTailG * a.NC > kTail2Threads * 4) return false;
+    if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 64 || a.C > 256 || a.NC < 1 || (a.NC + 15) / 16 > kTail2Waves) return false;
     // the first block's depthwise part of the NEXT group is written behind the last block's pointwise phase and lies there through the head
     const Span2 dw0{a.L[0].dw_off, a.L[0].dw_off + tail2_dw_part(a.L[0], true)};
     const Span2 map_last{0, kTailG * last.OH * last.OW * (last.Cout + 16)};
@@ -416,13 +515,7 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
     if (a.mean_off < 0) return false;
     used.push_back({a.mean_off, a.mean_off + kTailG * last.Cout});
     grow(a.mean_off + kTailG * last.Cout);
-    // the head's LDS copy of the classifier matrix (nobody reads the last block's parts behind its end barrier)
-    const int fc_bytes = a.NC * (a.C / 4 + 1) * 4;
-    a.fcw_off = -1;
-    if (a.C % 16 == 0 && a.NC * (a.C / 16) <= 4096) {
-        a.fcw_off = first_fit2(used, fc_bytes, CAP);
-        if (a.fcw_off >= 0) grow(a.fcw_off + fc_bytes);
-    }
+    a.fcw_off = -1;   // (the classifier's fragments come straight from memory)
     a.lds_bytes = lds_need;
     return true;
 }
@@ -441,16 +534,14 @@ long tail2_const_words(const Tail2Args& a) {
     long need = 0;
     auto upto = [&](long off, long words) { need = off + words > need ? off + words : need; };
     for (int i = 0; i < a.n_layers; ++i) upto(a.L[i].g_cst, tail2_cst_bytes(a.L[i], i == 0) / 4);
-    upto(a.g_fcw, (long)a.NC * a.C / 4);
-    upto(a.g_fcb, a.NC);
-    upto(a.g_fcm, a.NC);
-    upto(a.g_fcs, a.NC);
+    const long nct = (a.NC + 15) / 16;
+    upto(a.g_fcw, nct * (a.C / 64) * 256);
+    upto(a.g_fcb, nct * 48);
     if (a.g_hlut >= 0) upto(a.g_hlut, 64);
     return need;
 }
 
 bool launch_i8_tail2(Tail2Args a, hipStream_t s) {
-    if (!g_opt.i8_tail_fclds) a.fcw_off = -1;
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(i8_tail2_kernel), 160 * 1024)) return false;
     const int ngroups = (a.B + kTailG - 1) / kTailG;
     const int grid = ngroups < 256 ? ngroups : 256;  // one workgroup per CU (its LDS), each walks over its share of the chunk groups

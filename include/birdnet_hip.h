@@ -247,6 +247,10 @@ BN_API int bn_debug_input_bytes(bn_model* model, int B, int8_t* d_out, void* str
  * out[0] elements listed as in doubt (sum over the B chunks), out[1] the largest count of one chunk, out[2] (chunk, 64-frame block) pairs
  * whose bytes changed, out[3] / out[4] chunks recomputed as whole float64 spectrograms behind the min / max pass and behind the fix pass. */
 BN_API int bn_debug_guard_stats(bn_model* model, int B, int64_t* out);
+/* Test hook: which form of the fused INT8 tail operator (BN_OP_I8_TAIL; reference operators #36-#55 of the shipped graph) this model's plan can
+ * run — *form = 0 none (per-block operators), 1 = i8_tail_kernel only, 2 = also i8_tail2_kernel (depthwise stage on the matrix cores, the
+ * default where available; option i8_tail_mfdw); *lds_bytes = the LDS that form's plan asks for. */
+BN_API int bn_debug_tail_form(const bn_model* model, int* form, int* lds_bytes);
 
 BN_API int bn_debug_requant(bn_ctx* ctx, const int32_t* d_x, const int32_t* d_mult, const int32_t* d_shift, int n, int mode,
                      int zero_point, int32_t* d_out, void* stream);

@@ -418,6 +418,7 @@ def test_i8_fused_tail_matches_per_block_kernels_and_oracle(torch_mod):
     # both forms of the fused kernel: depthwise stage on the matrix cores (i8_tail2_kernel, the default where the plan carries its
     # constants) and on the vector ALU (i8_tail_kernel)
     assert tail[0].t[2] >= 0 and tail[0].t[3] >= 0, "the shipped graph must take the matrix-core depthwise form"
+    assert runner.tail_form()[0] == 2, "the library refused the matrix-core form's LDS plan: the default path would silently be i8_tail_kernel"
     with _hip.options(i8_tail_mfdw=0):
         for nb in (261, 1, 3, 37):
             s, l = runner.predict_device(x[:nb], return_logits=True)

@@ -286,7 +286,15 @@ def test_balanced_bounds_are_contiguous_and_even():
     w = np.array([20] * 100 + [1] * 900)
     b = pl.balanced_bounds(w, 2)
     loads = [int(w[b[r] : b[r + 1]].sum()) for r in range(2)]
-    assert abs(loads[0] - loads[1]) <= 80  # (a few files of 20 chunks)
+    assert abs(loads[0] - loads[1]) <= 60  # (within a file of 20 chunks of the weighted target on each side: the per-file host cost counts too)
+    # the cut nearest to the target, not the first one past it: 20 | 28 chunks instead of 40 | 8
+    assert pl.balanced_bounds([20, 20, 1, 1, 1, 1, 1, 1, 1, 1], 2) == [0, 1, 10]
+    # eight ranks, 262 144 files' worth of metadata: disjoint, covering, and no rank more than one file's chunks away from the mean
+    w = rng.integers(1, 31, 262144)
+    b = pl.balanced_bounds(w, 8)
+    loads = np.array([int(w[b[r] : b[r + 1]].sum()) for r in range(8)])
+    assert b[0] == 0 and b[-1] == len(w) and all(x < y for x, y in zip(b, b[1:]))
+    assert np.abs(loads - w.sum() / 8).max() <= 30, loads
 
 
 def test_host_library_exports_every_declared_symbol():
