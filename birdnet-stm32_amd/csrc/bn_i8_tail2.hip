@@ -100,7 +100,11 @@ __device__ __forceinline__ int rq_signed(int x, int m2, long c, int e_packed, in
 //   MEAN: thread (chunk slot, channel quad) walks the positions with one dword read each (waves 0-3);
 //   FULLY_CONNECTED on the matrix cores: wave w owns the class tile 16 w .., its A fragments come straight from memory (requested before the
 //   MEAN, 1 KB per k-step, contiguous), B = the pooled vectors from LDS (column n = chunk slot n & 3: columns 4..15 repeat, lanes n < 4 store).
-__device__ __forceinline__ void tail2_head(const Tail2Args& a_, unsigned char* lds, int chunk0) {
+__device__ __forceinline__ void tail2_head(const Tail2Args& a_, unsigned char* lds, int chunk0, int stamp_slot = -1) {
+#ifdef BN_TAIL_STAMPS
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    st[0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     // (the head's dozen scalar arguments are read from the kernel-argument segment HERE, through a pointer the optimiser cannot see through:
     // hoisted to the top of the kernel they stayed live across every block and the scalar registers spilled)
     const Tail2Args* ap = (const Tail2Args*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -140,6 +144,9 @@ __device__ __forceinline__ void tail2_head(const Tail2Args& a_, unsigned char* l
         reinterpret_cast<int*>(lds + a.mean_off)[i] = pack4(q);
     }
     __syncthreads();
+#ifdef BN_TAIL_STAMPS
+    st[4] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     if (fc_wave) {
         v4i acc = fc_b;
         const v4i mu = fc_mu, sh = fc_sh;
@@ -167,6 +174,12 @@ __device__ __forceinline__ void tail2_head(const Tail2Args& a_, unsigned char* l
             }
         }
     }
+#ifdef BN_TAIL_STAMPS
+    if (stamp_slot >= 0 && g_tail2_stamps && (threadIdx.x & 63) == 0) {
+        long long* o = g_tail2_stamps + ((size_t)stamp_slot * kTail2Waves + (threadIdx.x >> 6)) * 8;
+        o[0] = st[0]; o[4] = st[4];
+    }
+#endif
 }
 
 // One block for the kTailG chunks of the workgroup; maps are [chunk][position][C + 16 bytes], input and output at the same place.
@@ -410,8 +423,16 @@ __global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
             else if (L.Cin == 128) tail2_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0, nx, slot);
             else tail2_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0, nx, slot);
         }
-        tail2_head(a, lds, chunk0);
+        int hslot = -1;
+#ifdef BN_TAIL_STAMPS
+        const int gi = (grp - (int)blockIdx.x) / (int)gridDim.x;
+        if ((int)blockIdx.x < 8 && gi < 4 && g_tail2_stamps) hslot = ((int)blockIdx.x * 4 + gi) * 8 + 6;
+#endif
+        tail2_head(a, lds, chunk0, hslot);
         __syncthreads();  // the next group overwrites the maps
+#ifdef BN_TAIL_STAMPS
+        if (hslot >= 0 && (threadIdx.x & 63) == 0) g_tail2_stamps[((size_t)hslot * kTail2Waves + (threadIdx.x >> 6)) * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
 

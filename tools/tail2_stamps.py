@@ -37,7 +37,7 @@ torch.cuda.synchronize()
 tail_ms = [q["ms"] for q in r.profile_collect() if q["kind"] == "i8_tail" and q["launches"]]
 st = buf.cpu().numpy().reshape(WG, GRP, BLK, WAVES, 8).astype(np.float64) * 0.01  # microseconds
 names = ["stage3_ds1 (64->128, s2, taps from HBM)", "stage3_ds2 (128->128 + ADD)", "stage3_ds3 (128->128 + ADD)", "stage3_ds4 (128->128 + ADD)",
-         "stage4_ds1 (128->256, s2)", "stage4_ds2 (256->256 + ADD)"]
+         "stage4_ds1 (128->256, s2)", "stage4_ds2 (256->256 + ADD)", "head: MEAN (-> barrier), then FULLY_CONNECTED + scores (-> group's end barrier)"]
 print("# `i8_tail2_kernel`: where a wave's time goes, per block (in-kernel stamps, `tools/tail2_stamps.py`)\n")
 print(f"INT8 B = {B}, stamped build; tail launch {tail_ms[0]:.3f} ms.  Means over 8 workgroups x 4 chunk groups x 8 waves.\n")
 print("| block | entry -> behind the middle barrier (depthwise phase) us | -> behind the end barrier (pointwise phase) us | block us |")
@@ -48,7 +48,7 @@ for li, nm in enumerate(names):
     pw = (st[:, :, li, :, 6] - st[:, :, li, :, 4]).mean()
     print(f"| {nm} | {dw:.2f} | {pw:.2f} | {dw + pw:.2f} |")
     tot += np.array([dw, pw, dw + pw])
-print(f"| all six blocks | {tot[0]:.2f} | {tot[1]:.2f} | {tot[2]:.2f} |")
+print(f"| all six blocks + head | {tot[0]:.2f} | {tot[1]:.2f} | {tot[2]:.2f} |")
 per_group = tail_ms[0] * 1e3 / (B / 4 / 256)
 print(f"\nA chunk group takes {per_group:.1f} us of the launch; the six blocks account for {tot[2]:.1f} us of it, the rest is MEAN + FULLY_CONNECTED + head.")
 # the group's full extent from the first block's entry to the next group's entry
