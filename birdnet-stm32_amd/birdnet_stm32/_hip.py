@@ -28,11 +28,11 @@ EXPORTS = (
     "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
     "bn_kernel_names", "bn_profile_enable", "bn_profile_collect", "bn_ingest_resample", "bn_ingest_chunks",
     "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize", "bn_set_option", "bn_get_option",
-    "bn_blob_check", "bn_debug_requant", "bn_stft_mag_exact", "bn_debug_input_bytes", "bn_debug_guard_stats", "bn_debug_tail_form",
+    "bn_blob_check", "bn_debug_requant", "bn_stft_mag_exact", "bn_debug_input_bytes", "bn_debug_guard_stats", "bn_debug_tail_form", "bn_debug_mid_form",
 )  # fmt: skip
 
 # launcher switches of bn_set_option (include/birdnet_hip.h); the production defaults are what a fresh process has
-OPTION_NAMES = ("f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th", "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw",
+OPTION_NAMES = ("f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th", "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw", "i8_mid",
                 "i8_mel_generic", "stft_rowmajor", "stft_exact", "stft_flagcap", "ingest_blk", "ingest_generic")
 
 
@@ -83,6 +83,7 @@ def load_library(path: str | None = None):
     lib.bn_debug_input_bytes.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
     lib.bn_debug_guard_stats.argtypes = [c_void_p, c_int, POINTER(c_int64)]
     lib.bn_debug_tail_form.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
+    lib.bn_debug_mid_form.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.bn_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     lib.bn_infer_audio.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.bn_debug_op_output.argtypes = [c_void_p, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]

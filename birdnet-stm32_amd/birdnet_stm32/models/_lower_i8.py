@@ -430,13 +430,15 @@ def tail2_layer_section(b: dict, rq_dw, rq_pw, first: bool) -> np.ndarray:
         dead = np.asarray(rq_pw[0]) == 0
         w2[dead, :] = 0
         b2[dead] = 0
-    KS, NCT, NT = C // 64, C // 16, N // 16
+    KS, NCT, NT = (C + 63) // 64, C // 16, N // 16   # (32 input channels: half of the k-step's contraction index stays zero)
     lane = np.arange(64)
     m_, g_ = lane & 15, lane >> 4
     frag = np.zeros((NT, KS, 64, 16), np.int8)
     for nt in range(NT):
         for ks in range(KS):
             for j in range(4):
+                if 4 * ks + j >= NCT:
+                    continue
                 for r in range(4):
                     frag[nt, ks, :, 4 * j + r] = w2[16 * nt + m_, 16 * (4 * ks + j) + 4 * g_ + r]
     dwa = np.zeros((NCT, 3, 64, 16), np.int8)
@@ -485,7 +487,7 @@ def tail2_layer_section(b: dict, rq_dw, rq_pw, first: bool) -> np.ndarray:
     return np.concatenate([dwa.view(np.int32).reshape(-1), dwc.reshape(-1), frag.view(np.int32).reshape(-1), pwc.reshape(-1)]).astype(np.int32)
 
 
-def tail2_constants(blocks: list[dict], head: dict):
+def tail2_constants(blocks: list[dict], head: dict | None):
     """Constant block and descriptor table of ``i8_tail2_kernel`` (csrc/bn_i8_tail2.hip: the fused tail with the depthwise stage on the
     matrix cores), or ``None`` when a block cannot take its forms (the plan then keeps ``i8_tail_kernel`` only).
 
@@ -512,7 +514,7 @@ def tail2_constants(blocks: list[dict], head: dict):
 
     for i, b in enumerate(blocks):
         C, N = b["C"], b["N"]
-        if C not in (64, 128, 256) or N % 64 or b["sh"] != b["sw"] or b["sh"] not in (1, 2) or (b["OH"] * b["OW"]) % 16 or b["OW"] not in (8, 16):
+        if C not in (32, 64, 128, 256) or N % 64 or b["sh"] != b["sw"] or b["sh"] not in (1, 2) or (b["OH"] * b["OW"]) % 16 or b["OW"] not in (8, 16, 32):
             return None
         wd64, w264 = np.asarray(b["wd"], np.int64), np.asarray(b["w2"], np.int64)
         lo_dw = np.minimum(-128 * wd64, 127 * wd64).sum(axis=(0, 1)) + np.asarray(b["bdw"], np.int64)
@@ -569,6 +571,8 @@ def tail2_constants(blocks: list[dict], head: dict):
         row = [b["H"], b["W"], C, N, b["sh"], b["OH"], b["OW"], b["pt"], b["pl"], int(bool(add[0])), b["z_in"], b["dw_lo"], b["dw_hi"],
                pw_lo, pw_hi, add_m, add_c1, add_e, add_lo, add_hi, res_m, res_c & 0xFFFFFFFF, res_c >> 32, res_k, g_cst]
         desc += [int(np.int64(v).astype(np.uint32).view(np.int32)) if v > 0x7FFFFFFF else int(v) for v in row] + [0] * (TAIL2_LAYER_WORDS - len(row))
+    if head is None:   # (the chain in front of the tail: its last map goes back to memory)
+        return np.concatenate(sections).astype(np.int32), np.asarray(desc, np.int32)
     h = head
     if h["C"] != 256 or h["C"] != blocks[-1]["N"] or h["P"] != blocks[-1]["OH"] * blocks[-1]["OW"] or TAIL_G * h["NC"] > 1024:
         return None
@@ -931,6 +935,8 @@ def lower_i8(model, keep_all: bool = False, fuse: bool = True, softmax_form: str
                       name=f"t{out_t}", out_shape=(OH, OW, Cout), out_dtype="int8")
                 val[out_t], shape[out_t] = v, (OH, OW, Cout)
                 i += 2
+                if fuse and not keep_all:   # (keep_all plans keep every operator's own tensor for the per-tensor tests)
+                    _add_mid_op(pb, plan, tail_blocks)
             else:
                 _expect_acc_range(wt_.data[0], b - z_i * wt_.data[0].astype(np.int64).sum(axis=(0, 1)), (0, 1), f"depthwise conv of operator #{op.index}", mu, sh)
                 v = pb.value(OH * OW * C)
@@ -1178,6 +1184,42 @@ def _tag_scale_pairs(pb: pk.PlanBuilder) -> None:
         b.p[pk.TAIL_TAG] = pk.SCALE_COVERED
         pb._extra_uses.append((i + 1, a.in0))  # the fused kernel reads the unscaled map and the gate while it writes the convolution's output
         pb._extra_uses.append((i + 1, a.in1))
+
+
+def _add_mid_op(pb, plan, blocks: list[dict]) -> None:
+    """Append the fused operator for the three blocks of stage 2 of the shipped topology (csrc/bn_i8_tail2.hip: i8_mid2_kernel) right behind
+    them: a stride-2 block 32 -> 64 channels onto a 16 x 32 map (taps from memory), then two residual blocks of 64 channels whose maps
+    stay in LDS (two chunks per workgroup), the last map written back.  The three operators stay in the plan tagged MID_COVERED (skipped
+    while the fused operator runs); the fused operator is tagged MID_OP (skipped when option ``i8_mid`` is off or the library refuses its
+    LDS plan).  Same constants and descriptor words as the fused tail's second form (``tail2_constants`` without head)."""
+    if len(blocks) < 3:
+        return
+    chain = blocks[-3:]
+    a, b, c = chain
+    if (a["C"], a["N"], a["sh"], a["H"], a["W"], bool(a["add"][0])) != (32, 64, 2, 32, 64, False):
+        return
+    for blk in (b, c):
+        if (blk["C"], blk["N"], blk["sh"], blk["H"], blk["W"], bool(blk["add"][0])) != (64, 64, 1, 16, 32, True) or not blk["res_is_input"]:
+            return
+    ops_idx = [blk["op"] for blk in chain]
+    if ops_idx != list(range(ops_idx[0], ops_idx[0] + 3)) or ops_idx[-1] != len(plan.ops) - 1:
+        return
+    for x, y in zip(chain, chain[1:]):
+        if y["src"] != plan.ops[x["op"]].out:
+            return
+    if any(plan.ops[k].p[pk.TAIL_TAG] for k in ops_idx):
+        return
+    packed = tail2_constants(chain, None)
+    if packed is None:
+        return
+    cst, desc = packed
+    for k in ops_idx:
+        plan.ops[k].p[pk.TAIL_TAG] = pk.MID_COVERED
+    last = plan.ops[ops_idx[-1]]
+    pb.op(pk.I8_MID, a["src"], last.out,
+          p=[a["H"] * a["W"] * a["C"], sum(blk["macs"][1] for blk in chain), sum(blk["macs"][0] for blk in chain), 0, 0, 3,
+             a["H"], a["W"], a["C"], c["OH"] * c["OW"], c["N"], *([0] * (pk.TAIL_TAG - 11)), pk.MID_OP],
+          t=[pb.tensor(cst, np.int32), pb.tensor(desc, np.int32)], name=last.name, out_shape=last.out_shape, out_dtype="int8")
 
 
 def _add_tail_op(pb, plan, blocks: list[dict], head: dict) -> None:

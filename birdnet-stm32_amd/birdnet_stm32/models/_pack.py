@@ -29,9 +29,10 @@ OP_NP, OP_NT, OP_NF = 40, 16, 8
 # operator kinds (enum BnOpKind)
 F32_MEL, F32_MAG, F32_RAWFE, F32_STEM, F32_DW, F32_PW = 1, 2, 3, 4, 5, 6
 F32_SEGATE, F32_SCALE, F32_GAP, F32_DENSE, F32_ATTNPOOL, F32_DWPW, F32_STFTMEL, F32_MELFIN, F32_FRONT, F32_GAPDENSE = 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
-I8_QUANT, I8_MEL, I8_STEM, I8_DW, I8_PW, I8_MEAN, I8_FC, I8_HEAD, I8_DWPW, I8_FRONT, I8_TAIL, I8_SCALE, I8_MAXNORM, I8_RAWFE, I8_ATTNPOOL = 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34
+I8_QUANT, I8_MEL, I8_STEM, I8_DW, I8_PW, I8_MEAN, I8_FC, I8_HEAD, I8_DWPW, I8_FRONT, I8_TAIL, I8_SCALE, I8_MAXNORM, I8_RAWFE, I8_ATTNPOOL, I8_MID = 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35
 TAIL_TAG = 38  # OpRec.p[TAIL_TAG] = TAIL_COVERED: the operator is covered by the plan's fused tail operator; TAIL_OP: it is that operator
 TAIL_COVERED, TAIL_OP = 0x7A110001, 0x7A110002  # (bn_blob.h; values no other use of p[38] can take)
+MID_COVERED, MID_OP = 0x7A11000E, 0x7A11000F    # the same for the fused stage-2 chain (i8_mid2_kernel)
 FRONT2_HEAD, FRONT2_COVERED = 0x7A110003, 0x7A110004  # front block + the residual block FRONT2_DIST operators further on may run as one kernel
 FRONT2_DIST = 37
 PWDW8_HEAD, PWDW8_COVERED = 0x7A11000C, 0x7A11000D  # the INT8 counterpart (i8_pwdw_kernel)
@@ -44,7 +45,7 @@ KIND_NAMES = {
     F32_MEL: "f32_mel", F32_MAG: "f32_mag", F32_RAWFE: "f32_rawfe", F32_STEM: "f32_stem", F32_DW: "f32_dw",
     F32_PW: "f32_pw", F32_SEGATE: "f32_segate", F32_SCALE: "f32_scale", F32_GAP: "f32_gap", F32_DENSE: "f32_dense",
     F32_ATTNPOOL: "f32_attnpool", F32_DWPW: "f32_dwpw", F32_STFTMEL: "f32_stftmel", F32_MELFIN: "f32_melfin", F32_FRONT: "f32_front", F32_GAPDENSE: "f32_gapdense", I8_QUANT: "i8_quant", I8_MEL: "i8_mel", I8_STEM: "i8_stem", I8_DW: "i8_dw",
-    I8_PW: "i8_pw", I8_DWPW: "i8_dwpw", I8_FRONT: "i8_front", I8_MEAN: "i8_mean", I8_FC: "i8_fc", I8_HEAD: "i8_head", I8_TAIL: "i8_tail", I8_SCALE: "i8_scale", I8_MAXNORM: "i8_maxnorm", I8_RAWFE: "i8_rawfe", I8_ATTNPOOL: "i8_attnpool",
+    I8_PW: "i8_pw", I8_DWPW: "i8_dwpw", I8_FRONT: "i8_front", I8_MEAN: "i8_mean", I8_FC: "i8_fc", I8_HEAD: "i8_head", I8_TAIL: "i8_tail", I8_SCALE: "i8_scale", I8_MAXNORM: "i8_maxnorm", I8_RAWFE: "i8_rawfe", I8_ATTNPOOL: "i8_attnpool", I8_MID: "i8_mid",
 }  # fmt: skip
 
 ACT_CODES = {"none": 0, "linear": 0, "relu": 1, "relu6": 2}

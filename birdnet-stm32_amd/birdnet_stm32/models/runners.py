@@ -209,6 +209,12 @@ class HipRunner:
         _hip.check(self.lib.bn_debug_tail_form(self.model.handle, ctypes.byref(form), ctypes.byref(lds)))
         return form.value, lds.value
 
+    def mid_form(self) -> tuple[int, int]:
+        """Test hook: (1, LDS bytes) when the plan's fused stage-2 chain (``i8_mid2_kernel``) passed the library's LDS plan, else (0, 0)."""
+        form, lds = ctypes.c_int(0), ctypes.c_int(0)
+        _hip.check(self.lib.bn_debug_mid_form(self.model.handle, ctypes.byref(form), ctypes.byref(lds)))
+        return form.value, lds.value
+
     # -- per-operator timing (HIP events on the launch stream) ------------------------------------
     def profile(self, enable: bool) -> None:
         _hip.check(self.lib.bn_profile_enable(self.model.handle, int(bool(enable))))

@@ -48,7 +48,7 @@ const OptName kOptions[] = {
     {"f32_strip", &bn::Options::f32_strip},       {"f32_strip_th", &bn::Options::f32_strip_th},
     {"f32_front_staged", &bn::Options::f32_front_staged}, {"f32_front2", &bn::Options::f32_front2}, {"f32_pwdw", &bn::Options::f32_pwdw}, {"f32_tile_slice", &bn::Options::f32_tile_slice}, {"f32_pw_ws", &bn::Options::f32_pw_ws}, {"i8_pwdw", &bn::Options::i8_pwdw}, {"i8_pw_lds", &bn::Options::i8_pw_lds}, {"i8_pw_forms", &bn::Options::i8_pw_forms}, {"i8_add_tab", &bn::Options::i8_add_tab}, {"front_tpw", &bn::Options::front_tpw},
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
-    {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail}, {"i8_tail_mfdw", &bn::Options::i8_tail_mfdw},
+    {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail}, {"i8_tail_mfdw", &bn::Options::i8_tail_mfdw}, {"i8_mid", &bn::Options::i8_mid},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
     {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap},
     {"ingest_blk", &bn::Options::ingest_blk},
@@ -98,6 +98,9 @@ struct bn_model {
     std::vector<uint8_t> tail_ok;        // per operator: BN_OP_I8_TAIL whose maps fit the kernel's LDS plan
     std::vector<bn::Tail2Args> tails2;   // per operator: the same for i8_tail2_kernel (depthwise stage on the matrix cores), when the plan carries its constants
     std::vector<uint8_t> tail2_ok;
+    std::vector<bn::Tail2Args> mids;     // per operator: arguments of the fused stage-2 chain (BN_OP_I8_MID operators only)
+    std::vector<uint8_t> mid_ok;
+    bool has_mid = false;
     std::vector<uint8_t> out_valid;      // per operator: it wrote its output slot in the last forward call (not when a fused kernel covered it)
     std::vector<uint8_t> slot_valid;     // per slot: some operator wrote it in the last forward call
     bool has_tail = false;               // the plan holds a usable fused tail operator
@@ -220,6 +223,7 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         return m->d_slots[id] + slot_b0 * m->slots[id].bytes_per_chunk;
     };
     const bool tail_on = m->has_tail && bn::g_opt.i8_tail;
+    const bool mid_on = m->has_mid && bn::g_opt.i8_mid && bn::g_opt.i8_strip;
     if (op_end > m->ops.size()) op_end = m->ops.size();
     // the pooling scratch is zero between uses (i8_segate_kernel clears what it reads); cleared here as well, so that a call that failed half-way
     // cannot leave sums behind for the next one
@@ -307,6 +311,8 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
         const int* p = o.p;
         if (p[BN_OP_PATH] != BN_PATH_BOTH && p[BN_OP_PATH] != mode) continue;
         if (oi == front2_done || oi == pwdw_done || oi == pwdw_head_done || oi == scale_done || oi == segate_done[0] || oi == segate_done[1]) continue;  // ran inside a preceding operator's kernel
+        if (p[BN_OP_TAIL_TAG] == BN_MID_COVERED && mid_on) continue;    // the fused stage-2 chain runs these blocks
+        if (p[BN_OP_TAIL_TAG] == BN_MID_OP && !(mid_on && m->mid_ok[oi])) continue;
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_COVERED && tail_on) continue;  // the fused tail operator runs these blocks
         if (p[BN_OP_TAIL_TAG] == BN_TAIL_OP && !(tail_on && m->tail_ok[oi])) continue;
         ProfScope prof(m, (int)oi, s);
@@ -598,6 +604,15 @@ int run_plan(bn_model* m, const float* d_input, const float* d_minmax, int B, fl
                 bn::launch_i8_front(q, (const int8_t*)in0, (int8_t*)out, B, s);
                 break;
             }
+            case BN_OP_I8_MID: {
+                bn::Tail2Args ma = m->mids[oi];
+                ma.x = (const int8_t*)in0;
+                ma.y = (int8_t*)out;
+                ma.cst = (const int32_t*)m->tensor(o.t[0]);
+                ma.B = B;
+                if (!bn::launch_i8_mid2(ma, s)) return fail(BN_ERR_DEVICE, "could not raise the LDS limit of the fused stage-2 kernel");
+                break;
+            }
             case BN_OP_I8_TAIL: {
                 if (bn::g_opt.i8_tail_mfdw && m->tail2_ok[oi]) {
                     bn::Tail2Args t2 = m->tails2[oi];
@@ -862,6 +877,21 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
     m->tail_ok.assign(h.n_ops, 0);
     m->tails2.resize(h.n_ops);
     m->tail2_ok.assign(h.n_ops, 0);
+    m->mids.resize(h.n_ops);
+    m->mid_ok.assign(h.n_ops, 0);
+    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+        const OpRec& o = m->ops[oi];
+        if (o.kind != BN_OP_I8_MID) continue;
+        bn::Tail2Args& ma = m->mids[oi];
+        ma = bn::Tail2Args{};
+        const TensorRec& td = m->tensors[o.t[1]];
+        const TensorRec& tc = m->tensors[o.t[0]];
+        const bool ok = (td.nbytes & 3) == 0 && bn::tail2_plan((const int32_t*)(base + td.offset), (int)(td.nbytes / 4), o.p[5], ma, true) &&
+                        ma.L[0].H == o.p[6] && ma.L[0].W == o.p[7] && ma.L[0].Cin == o.p[8] && bn::tail2_const_words(ma, true) * 4 <= (long)tc.nbytes &&
+                        ma.L[o.p[5] - 1].OH * ma.L[o.p[5] - 1].OW == o.p[9] && ma.L[o.p[5] - 1].Cout == o.p[10];
+        m->mid_ok[oi] = ok;
+        m->has_mid = m->has_mid || ok;
+    }
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const OpRec& o = m->ops[oi];
         if (o.kind != BN_OP_I8_TAIL) continue;
@@ -1245,6 +1275,18 @@ int bn_debug_tail_form(const bn_model* m, int* form, int* lds_bytes) {
     return BN_OK;
 }
 
+int bn_debug_mid_form(const bn_model* m, int* form, int* lds_bytes) {
+    if (!m || !form || !lds_bytes) return fail(BN_ERR_ARG, "null argument");
+    *form = 0;
+    *lds_bytes = 0;
+    for (size_t oi = 0; oi < m->ops.size(); ++oi)
+        if (m->ops[oi].kind == BN_OP_I8_MID && m->mid_ok[oi]) {
+            *form = 1;
+            *lds_bytes = m->mids[oi].lds_bytes;
+        }
+    return BN_OK;
+}
+
 int bn_debug_guard_stats(bn_model* m, int B, int64_t* out) {
     if (!m || !out) return fail(BN_ERR_ARG, "null argument");
     if (int rc = check_device(m->ctx)) return rc;
@@ -1454,7 +1496,7 @@ int bn_get_option(const char* name, int* value) {
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_pw_ws_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_tail2_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_pw_lds_kernel\ni8_attnpool_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_tail2_kernel\ni8_mid2_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_pw_lds_kernel\ni8_attnpool_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }
 

@@ -86,6 +86,9 @@ struct TensorRec {
 // the INT8 counterpart: BN_PWDW8_HEAD on a plain 1x1 BN_OP_I8_DWPW operator, BN_PWDW8_COVERED on the BN_OP_I8_DW operator behind it (i8_pwdw_kernel)
 #define BN_PWDW8_HEAD 0x7A11000C
 #define BN_PWDW8_COVERED 0x7A11000D
+// BN_MID_COVERED / BN_MID_OP: the same pair of tags as BN_TAIL_COVERED / BN_TAIL_OP for the fused stage-2 chain (BN_OP_I8_MID, option i8_mid)
+#define BN_MID_COVERED 0x7A11000E
+#define BN_MID_OP 0x7A11000F
 
 #define BN_OP_NP 40
 #define BN_OP_NT 16
@@ -193,5 +196,9 @@ enum BnOpKind : int32_t {
     // p: T W M stride pad_left q_zp zp_out act_min act_max has_lut   f: q_scale
     // t: weights [M][16] int8, bias (zero point of the input folded), multipliers, shifts, table [M][256] (has_lut)
     BN_OP_I8_RAWFE = 33,
+    // the three blocks of stage 2 of the shipped INT8 graph in one kernel (a stride-2 block from memory, two residual blocks in LDS, the last
+    // map back to memory): bn_i8_tail2.hip, i8_mid2_kernel.  p: in_bytes pw_macs dw_macs 0 0 n_layers H0 W0 C0 P_last C_last
+    // t: constant block (int32 words), descriptor table (32 words per block; models/_lower_i8.py: tail2_constants without head)
+    BN_OP_I8_MID = 35,
     BN_OP_I8_ATTNPOOL = 34,  // attention pooling of an exported graph: score FC + int8 SOFTMAX over the positions + MUL + SUM (bn_i8.hip)
 };

@@ -182,26 +182,34 @@ __device__ __forceinline__ void tail2_head(const Tail2Args& a_, unsigned char* l
 #endif
 }
 
-// One block for the kTailG chunks of the workgroup; maps are [chunk][position][C + 16 bytes], input and output at the same place.
-template <int CIN, int COUT, int S, int H, int W, bool ADD, bool SRCG>
+// One block for the G chunks of the workgroup; maps are [chunk][position][C + 16 bytes], input and output at the same place.
+// A wave owns TPW tiles of 16 positions stacked vertically in ONE column strip of ONE chunk (a 32-wide map has two strips; a tile of an
+// 8-wide map is two rows) and walks them in passes of at most four.
+template <int G, int CIN, int COUT, int S, int H, int W, bool ADD, bool SRCG>
 __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args& a, unsigned char* lds, int chunk0, int nxi, int stamp_slot = -1) {
 #ifdef BN_TAIL_STAMPS
     long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     BN_T2STAMP(0);
-    constexpr int KS = CIN / 64, NCT = CIN / 16, NT = COUT / 16;
+    constexpr int KS = (CIN + 63) / 64, NCT = CIN / 16, NT = COUT / 16;   // (32 input channels: the k-step is half empty, zero weights)
     constexpr int PIN = CIN + 16, POUT = COUT + 16;
     constexpr int OH = H / S, OW = W / S, PER_CHUNK = OH * OW;
-    constexpr int TILES = kTailG * PER_CHUNK / 16;
+    constexpr int TILES = G * PER_CHUNK / 16;
     static_assert(TILES % kTail2Waves == 0, "tiles per wave");
-    constexpr int UPW = TILES / kTail2Waves;
-    constexpr int TR = 16 / OW;                    // output rows of a tile
-    constexpr int NR = (UPW - 1) * TR * S + 3;     // input rows a wave reads per channel tile
+    constexpr int TPW = TILES / kTail2Waves;       // tiles of a wave
+    constexpr int UPW = TPW < 4 ? TPW : 4;         // ... of which it walks UPW at a time
+    constexpr int PASSES = TPW / UPW;
+    static_assert(TPW % UPW == 0, "passes");
+    constexpr int TR = OW == 8 ? 2 : 1;            // output rows of a tile
+    constexpr int STRIPS = OW == 8 ? 1 : OW / 16;  // column strips of the map
+    constexpr int WPC = kTail2Waves / G;           // waves per chunk
+    static_assert(kTail2Waves % G == 0 && WPC % STRIPS == 0 && (WPC / STRIPS) * TPW * TR == OH, "a wave's tiles: one strip of one chunk");
+    constexpr int PSTEP = TR * OW;                 // positions from a tile to the one below it
+    constexpr int NR = (UPW - 1) * TR * S + 3;     // input rows a wave reads per channel tile and pass
     constexpr int PT = S == 1 ? 1 : 0, PL = PT;    // TF SAME padding of a 3x3 window on even maps: 1 / 1 at stride 1, 0 / 1 at stride 2
     constexpr int DWK = SRCG ? 8 : 5;              // v4i per (channel tile, lane group) of depthwise constants
-    constexpr int W_BYTES = CIN * COUT, DWA_BYTES = NCT * 3 * 1024, DWC_BYTES = NCT * DWK * 64, PWC_BYTES = NT * 5 * 64;
+    constexpr int W_BYTES = KS * 64 * COUT, DWA_BYTES = NCT * 3 * 1024, DWC_BYTES = NCT * DWK * 64, PWC_BYTES = NT * 5 * 64;
     constexpr int PW16 = (W_BYTES + PWC_BYTES) / 16, PWP = (PW16 + kTail2Threads - 1) / kTail2Threads;
-    static_assert(PER_CHUNK % (16 * UPW) == 0, "a wave's tiles lie in one chunk");
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
@@ -220,12 +228,22 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     const int dw_lo = L.dw_lo, dw_hi = L.dw_hi, pw_lo = L.pw_lo, pw_hi = L.pw_hi;
 
     // ---- where this wave's tiles are --------------------------------------------------------------------------------------------
-    const int tile0 = wave * UPW;
-    const int gch = (tile0 * 16) / PER_CHUNK;                 // chunk slot of the wave's tiles
-    const int oy0 = ((tile0 * 16) % PER_CHUNK) / OW;          // first output row
-    const int lr = OW == 8 ? n >> 3 : 0, ox = OW == 8 ? n & 7 : n;
+    const int gch = wave / WPC, wi = wave % WPC;               // chunk slot; which of the chunk's vertical runs
+    const int cx0 = (wi % STRIPS) * 16;                        // first column of the strip
+    const int oy_base = (wi / STRIPS) * TPW * TR;              // first output row of the run
+    const int lr = OW == 8 ? n >> 3 : 0, ox = OW == 8 ? n & 7 : cx0 + n;
     int chunk = chunk0 + gch;
     if (chunk >= a.B) chunk = a.B - 1;                         // ragged last group: the spare slots repeat the last chunk
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * H * W * CIN : 0), 0, SRCG ? H * W * CIN : 0, 0x00020000);
+    v4i bf[TPW][KS];
+    if constexpr (CIN % 64 != 0) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) bf[t][KS - 1] = (v4i){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+    const int oy0 = oy_base + pass * UPW * TR;                 // first output row of the pass
     int raddr[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -234,8 +252,6 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
         if constexpr (SRCG) raddr[r] = ok ? (iy * W + ix) * CIN : 0x40000000;   // (past the buffer: the load returns 0)
         else raddr[r] = ok ? L.x_off + ((gch * H + iy) * W + ix) * PIN : L.zp_off;
     }
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t*>(a.x) + (SRCG ? (size_t)chunk * H * W * CIN : 0), 0, SRCG ? H * W * CIN : 0, 0x00020000);
     int bkind[UPW];   // first block: which bias a tile's lanes start from (0 inside, 5 right border, 6 bottom, 7 both)
 #pragma unroll
     for (int t = 0; t < UPW; ++t) {
@@ -255,7 +271,6 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     }
     // Software pipeline over the channel tiles, written out (left to itself the scheduler merges all iterations of this loop and runs out of
     // registers): iteration ct requests the operands of tile ct + 1, issues the matrix instructions of tile ct and requantises tile ct - 1.
-    v4i bf[UPW][KS];
     constexpr int NB0 = SRCG ? UPW : 1;   // start values (the folded bias): one per tile where the border decides which, else one for all
     v4i af[2][3], brow[2][NR], acc[2][UPW], b0[2][NB0], rqm[2], rq01[2], rq23[2];
     int rqe[2];
@@ -303,11 +318,12 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
                 int qv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qv[e] = med3(rq_hi(acc[b][t][e], rqm[c][e], cc[e], rqe[c], e), dw_lo, dw_hi);
-                bf[t][pt >> 2][pt & 3] = pack4(qv);
+                bf[pass * UPW + t][pt >> 2][pt & 3] = pack4(qv);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    }  // pass
     BN_T2STAMP(3);
     __syncthreads();   // the pointwise part has landed, and every wave has read its taps: the map may be overwritten
     BN_T2STAMP(4);
@@ -322,7 +338,9 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
     const uint32_t res_m = (uint32_t)L.res_m;
     const long res_c = upair((uint32_t)L.res_c_lo, (uint32_t)L.res_c_hi);
     const int res_k = L.res_k;
-    const int pbase = tile0 * 16 + n;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+    const int pbase = (gch * OH + oy_base + pass * UPW * TR) * OW + (OW == 8 ? 0 : cx0) + n;   // this lane's position in the first tile of the pass
     // Software pipeline over the tiles of 16 output channels, written out like the depthwise loop's: iteration nt requests the A fragments and
     // start values of tile nt + 2 and the epilogue's operands (constants, residual bytes) of tile nt + 1, issues the matrix instructions of tile
     // nt + 1 and runs the epilogue of tile nt — no LDS round trip and no matrix-pipe latency in front of the vector work.
@@ -341,7 +359,7 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
         pe1[b] = reinterpret_cast<const int*>(pc + 16)[0];
         if constexpr (ADD) {
 #pragma unroll
-            for (int t = 0; t < UPW; ++t) pres[b][t] = *reinterpret_cast<const int*>(lds + L.x_off + (pbase + 16 * t) * PIN + 4 * g + 16 * nt);
+            for (int t = 0; t < UPW; ++t) pres[b][t] = *reinterpret_cast<const int*>(lds + L.x_off + (pbase + PSTEP * t) * PIN + 4 * g + 16 * nt);
         }
     };
     auto matrix = [&](int nt) {
@@ -349,7 +367,7 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int t = 0; t < UPW; ++t) pacc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(paf[b][ks], bf[t][ks], ks ? pacc[b][t] : pb0[b], 0, 0, 0);
+            for (int t = 0; t < UPW; ++t) pacc[b][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(paf[b][ks], bf[pass * UPW + t][ks], ks ? pacc[b][t] : pb0[b], 0, 0, 0);
     };
     request_a(0);
     request_e(0);
@@ -366,7 +384,7 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
         const long cc[4] = {pair(pc01[b].x, pc01[b].y), pair(pc01[b].z, pc01[b].w), pair(pc23[b].x, pc23[b].y), pair(pc23[b].z, pc23[b].w)};
 #pragma unroll
         for (int t = 0; t < UPW; ++t) {
-            const int p = pbase + 16 * t;
+            const int p = pbase + PSTEP * t;
             const int xr = ADD ? pres[b][t] ^ (int)0x80808080u : 0;  // residual bytes + 128
             int qv[4];
 #pragma unroll
@@ -385,6 +403,7 @@ __device__ __forceinline__ void tail2_block(const Tail2Layer& L, const Tail2Args
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    }  // pass
     BN_T2STAMP(5);
     if (nxi > 0 && tid < (N.Cin + 16) / 4) reinterpret_cast<int*>(lds + N.zp_off)[tid] = (N.zp_in & 0xff) * 0x01010101;   // (block 0 has no zero-point row)
     __syncthreads();
@@ -418,10 +437,10 @@ __global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
             const int gi = (grp - (int)blockIdx.x) / (int)gridDim.x;
             if ((int)blockIdx.x < 8 && gi < 4 && li < 8 && g_tail2_stamps) slot = ((int)blockIdx.x * 4 + gi) * 8 + li;
 #endif
-            if (L.Cin == 64) tail2_block<64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0, nx, slot);
-            else if (L.Cin == 128 && L.Cout == 128) tail2_block<128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0, nx, slot);
-            else if (L.Cin == 128) tail2_block<128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0, nx, slot);
-            else tail2_block<256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0, nx, slot);
+            if (L.Cin == 64) tail2_block<kTailG, 64, 128, 2, 16, 32, false, true>(L, a, lds, chunk0, nx, slot);
+            else if (L.Cin == 128 && L.Cout == 128) tail2_block<kTailG, 128, 128, 1, 8, 16, true, false>(L, a, lds, chunk0, nx, slot);
+            else if (L.Cin == 128) tail2_block<kTailG, 128, 256, 2, 8, 16, false, false>(L, a, lds, chunk0, nx, slot);
+            else tail2_block<kTailG, 256, 256, 1, 4, 8, true, false>(L, a, lds, chunk0, nx, slot);
         }
         int hslot = -1;
 #ifdef BN_TAIL_STAMPS
@@ -436,8 +455,38 @@ __global__ __launch_bounds__(kTail2Threads) void i8_tail2_kernel(Tail2Args a) {
     }
 }
 
+// Stage 2 of the shipped graph with the same blocks: kMidG = 2 chunks per workgroup (a 16 x 32 map of 64 channels is 40 KB in LDS), the first
+// block's taps from memory, the last map written back for the tail kernel (coalesced 16-byte pieces).
+__global__ __launch_bounds__(kTail2Threads) void i8_mid2_kernel(Tail2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int ngroups = (a.B + kMidG - 1) / kMidG;
+    part_request<kTail2MaxDw16 / kTail2Threads>(a.cst + a.L[0].g_cst, lds + a.L[0].dw_off, tail2_dw_bytes(a.L[0], true) / 16, (int)threadIdx.x);
+    __syncthreads();
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int chunk0 = grp * kMidG;
+        const bool more = grp + (int)gridDim.x < ngroups;
+        for (int li = 0; li < a.n_layers; ++li) {
+            const Tail2Layer& L = a.L[li];
+            const bool last = li == a.n_layers - 1;
+            const int nx = last ? (more ? 0 : -1) : li + 1;
+            if (li == 0) tail2_block<kMidG, 32, 64, 2, 32, 64, false, true>(L, a, lds, chunk0, nx);
+            else tail2_block<kMidG, 64, 64, 1, 16, 32, true, false>(L, a, lds, chunk0, nx);
+        }
+        // the last map: [chunk slot][position][C + 16] in LDS -> [chunk][position][C] in memory
+        const Tail2Layer& L = a.L[a.n_layers - 1];
+        const int c16 = L.Cout / 16, per = a.P * c16;
+        for (int i = threadIdx.x; i < kMidG * per; i += kTail2Threads) {
+            const int gq = i / per, r = i - gq * per, pos = r / c16, c = r - pos * c16;
+            if (chunk0 + gq < a.B)
+                reinterpret_cast<v4i*>(a.y + ((size_t)(chunk0 + gq) * a.P + pos) * L.Cout)[c] =
+                    *reinterpret_cast<const v4i*>(lds + L.y_off + (gq * a.P + pos) * (L.Cout + 16) + 16 * c);
+        }
+        __syncthreads();  // the next group overwrites the map
+    }
+}
+
 int tail2_dw_part(const Tail2Layer& L, bool first) { return (L.Cin / 16) * (3 * 1024 + (first ? 8 : 5) * 64); }
-int tail2_pw_part(const Tail2Layer& L) { return L.Cin * L.Cout + (L.Cout / 16) * 5 * 64; }
+int tail2_pw_part(const Tail2Layer& L) { return (L.Cin + 63) / 64 * 64 * L.Cout + (L.Cout / 16) * 5 * 64; }
 
 struct Span2 {
     int b, e;
@@ -466,13 +515,20 @@ bool overlap2(int b0, int e0, int b1, int e1) { return b0 < e1 && b1 < e0; }
 // depthwise phase runs: it avoids the map, the zero-point row and the depthwise part.  The first block's depthwise part is written behind
 // the last block of the previous group and stays through the head: it avoids the last map, the last pointwise part, the pooled vector and
 // the head's copy of the classifier matrix.  false = not a topology / size the kernel takes (the plan keeps i8_tail_kernel).
-bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
-    constexpr int LW = kTail2LayerWords, HW = 16, CAP = 160 * 1024;
+bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a, bool mid) {
+    constexpr int LW = kTail2LayerWords, CAP = 160 * 1024;
+    const int HW = mid ? 0 : 16, G = mid ? kMidG : kTailG;
     if (n_layers < 1 || n_layers > 8 || n_words != LW * n_layers + HW) return false;
     a.n_layers = n_layers;
     int lds_need = 0;
     Span2 prev_pw{0, 0};
     auto grow = [&](int end) { lds_need = end > lds_need ? end : lds_need; };
+    // The first block's depthwise part is the one piece whose neighbours in time are at BOTH ends of the chain (it is written behind the last
+    // block's pointwise phase): placed by first fit like the others it can collide with the last block's parts, so a second attempt puts it at
+    // the top of the LDS.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    lds_need = 0;
+    prev_pw = {0, 0};
     for (int i = 0; i < n_layers; ++i) {
         const int32_t* d = desc + LW * i;
         Tail2Layer& L = a.L[i];
@@ -485,8 +541,9 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
             return L.Cin == cin && L.Cout == cout && L.S == st && L.H == hh && L.W == ww && L.has_add == add && L.pt == (st == 1) && L.pl == (st == 1) &&
                    L.OH == hh / st && L.OW == ww / st;
         };
-        // the four instantiations of tail2_block
-        if (!((first && is(64, 128, 2, 16, 32, 0)) || (!first && (is(128, 128, 1, 8, 16, 1) || is(128, 256, 2, 8, 16, 0) || is(256, 256, 1, 4, 8, 1))))) return false;
+        // the instantiations of tail2_block: four in i8_tail2_kernel, two in i8_mid2_kernel
+        if (!mid && !((first && is(64, 128, 2, 16, 32, 0)) || (!first && (is(128, 128, 1, 8, 16, 1) || is(128, 256, 2, 8, 16, 0) || is(256, 256, 1, 4, 8, 1))))) return false;
+        if (mid && !((first && is(32, 64, 2, 32, 64, 0)) || (!first && is(64, 64, 1, 16, 32, 1)))) return false;
         if (i > 0 && (L.H != a.L[i - 1].OH || L.W != a.L[i - 1].OW || L.Cin != a.L[i - 1].Cout)) return false;
         if (L.g_cst < 0 || (L.g_cst & 3)) return false;
         if (first && L.zp_in != -128) return false;   // (zero-filled taps + border biases assume it; the packer checks the same)
@@ -497,7 +554,7 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
                           L.res_m < 0 || L.res_k < 3 || L.res_k > 19))
             return false;
         if (tail2_dw_part(L, first) / 16 > kTail2MaxDw16) return false;
-        const int in_bytes = first ? 0 : kTailG * L.H * L.W * (L.Cin + 16), out_bytes = kTailG * L.OH * L.OW * (L.Cout + 16);
+        const int in_bytes = first ? 0 : G * L.H * L.W * (L.Cin + 16), out_bytes = G * L.OH * L.OW * (L.Cout + 16);
         const Span2 map{0, in_bytes > out_bytes ? in_bytes : out_bytes};
         L.x_off = first ? -1 : 0;
         L.y_off = 0;
@@ -509,7 +566,7 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
             if (L.zp_off < 0) return false;
             used.push_back({L.zp_off, L.zp_off + L.Cin + 16});
         }
-        L.dw_off = first_fit2(used, tail2_dw_part(L, first), CAP);
+        L.dw_off = first && attempt ? (CAP - tail2_dw_part(L, first)) & ~15 : first_fit2(used, tail2_dw_part(L, first), CAP);
         if (L.dw_off < 0) return false;
         const Span2 dw{L.dw_off, L.dw_off + tail2_dw_part(L, first)};
         used = {map, dw};
@@ -519,18 +576,33 @@ bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a) {
         prev_pw = {L.pw_off, L.pw_off + tail2_pw_part(L)};
         grow(map.e); grow(dw.e); grow(prev_pw.e);
     }
+    {
+        const Tail2Layer& lastL = a.L[n_layers - 1];
+        const Span2 dw0{a.L[0].dw_off, a.L[0].dw_off + tail2_dw_part(a.L[0], true)};
+        const Span2 map_lastL{0, G * lastL.OH * lastL.OW * (lastL.Cout + 16)};
+        if (!overlap2(dw0.b, dw0.e, map_lastL.b, map_lastL.e) && !overlap2(dw0.b, dw0.e, prev_pw.b, prev_pw.e)) break;
+        if (attempt) return false;
+    }
+    }  // attempt
+    const Tail2Layer& last = a.L[n_layers - 1];
+    // the first block's depthwise part of the NEXT group is written behind the last block's pointwise phase and lies there through the head
+    const Span2 dw0{a.L[0].dw_off, a.L[0].dw_off + tail2_dw_part(a.L[0], true)};
+    const Span2 map_last{0, G * last.OH * last.OW * (last.Cout + 16)};
+    if (overlap2(dw0.b, dw0.e, map_last.b, map_last.e) || overlap2(dw0.b, dw0.e, prev_pw.b, prev_pw.e)) return false;
+    if (mid) {
+        a.P = last.OH * last.OW;
+        a.C = last.Cout;
+        a.fcw_off = -1;
+        a.lds_bytes = lds_need;
+        return a.C % 16 == 0;
+    }
     const int32_t* h = desc + LW * n_layers;
     a.mean_zp_in = h[0]; a.mean_mult = h[1]; a.mean_shift = h[2]; a.mean_zp_out = h[3];
     a.fc_zp_out = h[4]; a.fc_lo = h[5]; a.fc_hi = h[6]; a.g_fcw = h[7]; a.g_fcb = h[8]; a.g_fcm = h[9]; a.g_fcs = h[10]; a.g_hlut = h[11];
     a.head_zp_fc = h[12]; a.head_zp_out = h[13]; a.P = h[14]; a.C = h[15];
     if (a.g_fcw < 0 || a.g_fcb < 0 || a.g_hlut < -1 || (a.g_fcw & 3) || (a.g_fcb & 3)) return false;
     if (a.fc_lo < -128 || a.fc_hi > 127 || a.fc_lo > a.fc_hi) return false;
-    const Tail2Layer& last = a.L[n_layers - 1];
     if (a.P != last.OH * last.OW || a.C != last.Cout || a.C % 64 || a.C > 256 || a.NC < 1 || (a.NC + 15) / 16 > kTail2Waves) return false;
-    // the first block's depthwise part of the NEXT group is written behind the last block's pointwise phase and lies there through the head
-    const Span2 dw0{a.L[0].dw_off, a.L[0].dw_off + tail2_dw_part(a.L[0], true)};
-    const Span2 map_last{0, kTailG * last.OH * last.OW * (last.Cout + 16)};
-    if (overlap2(dw0.b, dw0.e, map_last.b, map_last.e) || overlap2(dw0.b, dw0.e, prev_pw.b, prev_pw.e)) return false;
     std::vector<Span2> used{map_last, dw0};
     a.mean_off = first_fit2(used, kTailG * last.Cout, CAP);
     if (a.mean_off < 0) return false;
@@ -551,10 +623,11 @@ extern "C" __attribute__((visibility("default"))) int bn_debug_tail2_stamps(long
 }
 #endif
 
-long tail2_const_words(const Tail2Args& a) {
+long tail2_const_words(const Tail2Args& a, bool mid) {
     long need = 0;
     auto upto = [&](long off, long words) { need = off + words > need ? off + words : need; };
     for (int i = 0; i < a.n_layers; ++i) upto(a.L[i].g_cst, tail2_cst_bytes(a.L[i], i == 0) / 4);
+    if (mid) return need;
     const long nct = (a.NC + 15) / 16;
     upto(a.g_fcw, nct * (a.C / 64) * 256);
     upto(a.g_fcb, nct * 48);
@@ -567,6 +640,14 @@ bool launch_i8_tail2(Tail2Args a, hipStream_t s) {
     const int ngroups = (a.B + kTailG - 1) / kTailG;
     const int grid = ngroups < 256 ? ngroups : 256;  // one workgroup per CU (its LDS), each walks over its share of the chunk groups
     hipLaunchKernelGGL(i8_tail2_kernel, dim3(grid), dim3(kTail2Threads), (size_t)a.lds_bytes, s, a);
+    return true;
+}
+
+bool launch_i8_mid2(Tail2Args a, hipStream_t s) {
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(i8_mid2_kernel), 160 * 1024)) return false;
+    const int ngroups = (a.B + kMidG - 1) / kMidG;
+    const int grid = ngroups < 256 ? ngroups : 256;
+    hipLaunchKernelGGL(i8_mid2_kernel, dim3(grid), dim3(kTail2Threads), (size_t)a.lds_bytes, s, a);
     return true;
 }
 

@@ -40,6 +40,8 @@ struct Options {
                                // (1024-thread workgroups, one per CU); 0: two 256-entry rescale tables + the output requantisation on the vector ALU
     int i8_tail_fclds = 1;     // the fused tail's head reads the classifier matrix from an LDS copy (0: from memory, 64 dependent loads per thread)
     int i8_tail = 1;           // stage 3-4 + MEAN + FC + head of the INT8 graph as one kernel (0: one launch per block)
+    int i8_mid = 1;            // stage 2 of the shipped INT8 graph (a stride-2 block + two residual blocks on a 16 x 32 map) as one kernel with the maps of two
+                               // chunks in LDS (i8_mid2_kernel: depthwise stage on the matrix cores); 0: one strip kernel per block
     int i8_tail_mfdw = 1;      // ... with the depthwise stage on the matrix cores (i8_tail2_kernel) where the plan carries its constants; 0: i8_tail_kernel
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
     int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
@@ -386,8 +388,10 @@ struct Tail2Layer {
     int g_cst;                                    // word offset of the block's constants: depthwise part (A fragments | constants), then pointwise part (A fragments | constants)
     int x_off, y_off, dw_off, pw_off, zp_off;     // LDS byte offsets (x_off < 0: the input map is in global memory)
 };
+constexpr int kMidG = 2;   // chunks a workgroup of i8_mid2_kernel holds at a time
 struct Tail2Args {
     const int8_t* x;
+    int8_t* y;            // i8_mid2_kernel: where the last map goes, [B][P][C]
     float* scores;
     float* logits;
     const int32_t* cst;   // constant block (models/_lower_i8.py: tail2_constants)
@@ -399,9 +403,10 @@ struct Tail2Args {
     int fcw_off;
     Tail2Layer L[8];
 };
-bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a);  // a.NC must be set
-long tail2_const_words(const Tail2Args& a);
+bool tail2_plan(const int32_t* desc, int n_words, int n_layers, Tail2Args& a, bool mid = false);  // a.NC must be set (tail); mid: the stage-2 chain, no head
+long tail2_const_words(const Tail2Args& a, bool mid = false);
 bool launch_i8_tail2(Tail2Args a, hipStream_t s);
+bool launch_i8_mid2(Tail2Args a, hipStream_t s);
 
 // INT8 stem 3x3 + depthwise 3x3 stride 2 + pointwise in one kernel (bn_i8_fused.hip)
 struct I8FrontParams {

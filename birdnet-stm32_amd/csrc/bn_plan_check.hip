@@ -284,6 +284,11 @@ bool check_plan(const BlobHeader& h, const std::vector<SlotRec>& slots, const st
                     c.tensor(0, 16, "constant block") && c.tensor(1, 4LL * (24 * p[5] + 16), "descriptor table");
                 if (c.ok && (p[4] != (int)h.num_classes || p[5] > 8 || p[BN_OP_TAIL_TAG] != BN_TAIL_OP)) c.bad("fused tail header");
                 break;  // the descriptor table itself is validated by bn::tail_plan at load (bn_api.hip)
+            case BN_OP_I8_MID:  // in_bytes pw_macs dw_macs 0 0 n_layers H0 W0 C0 P_last C_last
+                c.dims({p[0], p[5], p[6], p[7], p[8], p[9], p[10]}, "fused stage-2 chain") && c.slot(o.in0, 1LL * p[6] * p[7] * p[8], "input map") &&
+                    c.slot(o.out, 1LL * p[9] * p[10], "output map") && c.tensor(0, 16, "constant block") && c.tensor(1, 4LL * 32 * p[5], "descriptor table");
+                if (c.ok && (p[5] > 8 || p[BN_OP_TAIL_TAG] != BN_MID_OP)) c.bad("fused stage-2 chain header");
+                break;  // (descriptor table: bn::tail2_plan at load)
             default:
                 c.bad("unknown operator kind");
                 break;

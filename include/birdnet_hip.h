@@ -251,6 +251,9 @@ BN_API int bn_debug_guard_stats(bn_model* model, int B, int64_t* out);
  * run — *form = 0 none (per-block operators), 1 = i8_tail_kernel only, 2 = also i8_tail2_kernel (depthwise stage on the matrix cores, the
  * default where available; option i8_tail_mfdw); *lds_bytes = the LDS that form's plan asks for. */
 BN_API int bn_debug_tail_form(const bn_model* model, int* form, int* lds_bytes);
+/* Test hook: *form = 1 when the plan's fused stage-2 chain (BN_OP_I8_MID: three blocks of the shipped graph as i8_mid2_kernel; option i8_mid)
+ * passed the library's LDS plan and runs by default, else 0 (its three strip kernels run instead). */
+BN_API int bn_debug_mid_form(const bn_model* model, int* form, int* lds_bytes);
 
 BN_API int bn_debug_requant(bn_ctx* ctx, const int32_t* d_x, const int32_t* d_mult, const int32_t* d_shift, int n, int mode,
                      int zero_point, int32_t* d_out, void* stream);
@@ -269,7 +272,7 @@ BN_API int bn_profile_collect(bn_model* model, double* total_ms, int64_t* launch
 
 /* Run-time switches of the kernel launchers, for A/B measurements and tests (process-wide; the defaults are the production
  * choices).  Names: "f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th",
- * "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_mel_generic", "stft_rowmajor", "stft_exact", "stft_flagcap", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
+ * "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw", "i8_mid", "i8_mel_generic", "stft_rowmajor", "stft_exact", "stft_flagcap", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
  * what each selects).  An environment variable BN_<NAME IN CAPITALS> seeds the value once when the library is loaded; no
  * launch reads the environment.  The reference has no counterpart (tf.lite.Interpreter's delegates / num_threads arguments,
  * birdnet_stm32/models/runners.py:57, are the closest thing).  Unknown name: BN_ERR_ARG. */

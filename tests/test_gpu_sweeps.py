@@ -433,6 +433,50 @@ def test_i8_fused_tail_matches_per_block_kernels_and_oracle(torch_mod):
     runner.close()
 
 
+def test_i8_fused_stage2_chain_matches_the_strip_kernels_and_oracle(torch_mod):
+    """Stage 2 of the shipped INT8 graph as one kernel (i8_mid2_kernel: a stride-2 block with its taps from memory, two residual blocks with
+    the maps of two chunks in LDS, depthwise stage on the matrix cores) against the three strip kernels it replaces (option i8_mid = 0):
+    the map it hands the tail (operator t110) and the scores bit for bit, for batch sizes that leave the last pair of chunks ragged,
+    repeated launches, and from audio; the oracle pins the scores."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models.runners import load_model_runner
+
+    path = _c_int8_path()
+    rng = np.random.default_rng(33)
+    S = np.empty((131, 257, 256, 1), np.float32)
+    S[:100] = path.spectrogram(synth_chunks(100, seed=6), 281, 256)
+    S[100:] = rng.random((31, 257, 256, 1), dtype=np.float32)
+    want = path.invoke(S)
+    runner = load_model_runner(TFLITE_PATH, max_batch=131)
+    mids = [i for i, o in enumerate(runner.plan.ops) if o.kind == pk.I8_MID]
+    assert len(mids) == 1 and sum(o.p[pk.TAIL_TAG] == pk.MID_COVERED for o in runner.plan.ops) == 3
+    assert runner.mid_form()[0] == 1, "the library refused the fused stage-2 chain's LDS plan: the default path would silently be the strip kernels"
+    x = torch.from_numpy(S.reshape(131, -1)).cuda()
+    with _hip.options(i8_mid=0, i8_tail=0):
+        base_s = runner.predict_device(x).clone()
+        base_map = runner.op_output(mids[0] - 1, 131)   # stage2_ds3 as its own strip kernel
+    assert np.array_equal(base_s.cpu().numpy(), want)
+    with _hip.options(i8_tail=0):
+        for rep in range(3):
+            for nb in (131, 1, 2, 3, 5, 37, 64):
+                s = runner.predict_device(x[:nb])
+                assert torch.equal(s, base_s[:nb]), f"batch {nb}, launch {rep}"
+                assert np.array_equal(runner.op_output(mids[0], nb), base_map[:nb]), f"stage-2 output map, batch {nb}"
+    runner.profile(True)
+    runner.predict_device(x)
+    rows = {r["kind"]: r["launches"] for r in runner.profile_collect() if r["launches"]}
+    runner.profile(False)
+    assert rows.get("i8_mid") == 1, rows
+    assert torch.equal(runner.predict_device(x), base_s)
+    audio = torch.from_numpy(synth_chunks(70, seed=9)).cuda()
+    a1 = runner.infer_audio_device(audio).clone()
+    with _hip.options(i8_mid=0):
+        assert torch.equal(runner.infer_audio_device(audio), a1)
+    runner.close()
+
+
 # --------------------------------------------------------------------------------------- float32: front block + stage1_ds2 as one kernel
 def test_f32_front2_fused_kernel_matches_the_two_strip_kernels(torch_mod):
     """``f32_front2_kernel`` (front block + the residual block behind it, the 32-channel map in LDS) does the arithmetic of

@@ -32,17 +32,22 @@ def test_fused_plan_structure():
     assert (f32.ops[2].p[9], f32.ops[3].p[9]) == (0, 1)
     assert sum(1 for o in f32.ops if o.kind == pk.F32_DWPW and o.p[12]) == 7  # residual blocks
     kinds = [pk.KIND_NAMES[o.kind] for o in i8.ops]
-    assert kinds == ["i8_dwpw", "i8_front"] + ["i8_dwpw"] * 10 + ["i8_mean", "i8_fc", "i8_head", "i8_tail"]
+    assert kinds == ["i8_dwpw", "i8_front"] + ["i8_dwpw"] * 4 + ["i8_mid"] + ["i8_dwpw"] * 6 + ["i8_mean", "i8_fc", "i8_head", "i8_tail"]
+    # the fused stage-2 chain covers stage2_ds1..ds3 (three operators, kept in the plan for the i8_mid = 0 path) and sits right behind them
+    mid = i8.ops[6]
+    assert mid.p[pk.TAIL_TAG] == pk.MID_OP and [o.p[pk.TAIL_TAG] == pk.MID_COVERED for o in i8.ops[:6]] == [False] * 3 + [True] * 3
+    assert mid.in0 == i8.ops[3].in0 and mid.out == i8.ops[5].out and mid.p[5:11] == [3, 32, 64, 32, 512, 64]
+    assert i8.tensors[mid.t[1]].size == 32 * 3
     # the fused tail operator covers stage 3-4 + MEAN + FC + head (9 operators, kept in the plan for the i8_tail = 0 path)
     tail = i8.ops[-1]
-    assert tail.p[pk.TAIL_TAG] == pk.TAIL_OP and [o.p[pk.TAIL_TAG] == pk.TAIL_COVERED for o in i8.ops[:-1]] == [False] * 6 + [True] * 9
-    assert tail.in0 == i8.ops[6].in0 and tail.out == pk.SLOT_SCORES and tail.p[:11] == [16 * 32 * 64, 10485760, 626688, 32 * 256 + 256 * 100, 100, 6, 16, 32, 64, 32, 256]
+    assert tail.p[pk.TAIL_TAG] == pk.TAIL_OP and [o.p[pk.TAIL_TAG] == pk.TAIL_COVERED for o in i8.ops[:-1]] == [False] * 7 + [True] * 9
+    assert tail.in0 == i8.ops[7].in0 and tail.out == pk.SLOT_SCORES and tail.p[:11] == [16 * 32 * 64, 10485760, 626688, 32 * 256 + 256 * 100, 100, 6, 16, 32, 64, 32, 256]
     desc = i8.tensors[tail.t[1]]
     assert desc.size == 24 * 6 + 16 and desc[:10].tolist() == [16, 32, 64, 128, 2, 8, 16, 0, 0, 0] and desc[24 * 5 : 24 * 5 + 10].tolist() == [4, 8, 256, 256, 1, 4, 8, 1, 1, 1]
     # pointwise A fragments of a tail block: lane (m, kq), byte b of k-step ks = W[16 nt + m][4 (base[kq] + 4 ks + (b >> 2)) + (b & 3)]
     from birdnet_stm32.models._lower_i8 import _tail_quad_base
 
-    blk = i8.ops[7]  # stage3_ds2: 128 -> 128
+    blk = i8.ops[8]  # stage3_ds2: 128 -> 128
     w2 = np.zeros((128, 128), np.int8)
     fr_old = i8.tensors[blk.t[4]].reshape(2, 8, 64, 16)  # generic fragment order [K/64][N/16][lane][16]: lane (q, c) -> W[16 ct + c][64 s + 16 q ..]
     for s_ in range(2):
@@ -286,7 +291,7 @@ def test_launcher_options_round_trip_without_a_device():
     from birdnet_stm32 import _hip
 
     defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "f32_front2": 1, "f32_pwdw": 2, "f32_tile_slice": 0, "f32_pw_ws": 1, "i8_pwdw": 0, "i8_pw_lds": 1, "i8_pw_forms": 1, "i8_add_tab": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_th": 0, "i8_dw_pool": 1, "i8_tail_fclds": 1,
-                "i8_tail": 1, "i8_tail_mfdw": 1, "i8_mel_generic": 0, "stft_rowmajor": 0, "stft_exact": 2, "stft_flagcap": 1022, "ingest_blk": 0, "ingest_generic": 0}
+                "i8_tail": 1, "i8_tail_mfdw": 1, "i8_mid": 1, "i8_mel_generic": 0, "stft_rowmajor": 0, "stft_exact": 2, "stft_flagcap": 1022, "ingest_blk": 0, "ingest_generic": 0}
     assert sorted(defaults) == sorted(_hip.OPTION_NAMES)
     hdr = open(os.path.join(REPO, "include", "birdnet_hip.h")).read()
     for name, want in defaults.items():
