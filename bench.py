@@ -85,7 +85,9 @@ def kernel_symbol(kind: str, p: list) -> str:
     if kind in ("stft512", "f32_stftmel"):
         return "stft512_mag_kernel"
     if kind == "i8_tail":
-        return "i8_tail_kernel"
+        return "i8_tail2_kernel"   # (the default form where the plan carries its constants: the shipped graph does)
+    if kind == "i8_mid":
+        return "i8_mid2_kernel"
     if kind == "i8_dwpw" and p[35]:
         return "i8_strip_kernel"
     if kind == "i8_dwpw" and p[30] and p[14] == 64:
@@ -143,6 +145,8 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float, f
         macs = p[6] * p[7] * p[2] * (p[14] + (9 if p[29] else 0))
         res = 1 if (p[18] and sym != "i8_strip_kernel") else 0
         return batch * 1.0 * (n_in + n_out * (1 + res)), batch * 2.0 * macs, batch * 2.0 * p[6] * p[7] * p[2] * p[14]
+    if k == "i8_mid":  # p: in_bytes pw_macs dw_macs 0 0 n_layers H0 W0 C0 P_last C_last
+        return batch * 1.0 * (p[0] + p[9] * p[10]), batch * 2.0 * (p[1] + p[2]), batch * 2.0 * p[1]
     if k == "i8_tail":  # p: in_bytes pw_macs dw_macs other_macs n_classes
         return batch * (p[0] + 4.0 * p[4]), batch * 2.0 * (p[1] + p[2] + p[3]), batch * 2.0 * p[1]
     if k == "f32_pw":
@@ -250,7 +254,7 @@ def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> t
     dom = picked[0] if picked else max(stages, key=lambda s: s["avg_ms"])
     ridge = peak_compute * 1e12 / (HBM_PEAK_GBS * 1e9)
     intensity = dom["ops"] / max(dom["bytes"], 1.0)
-    if intensity > ridge and (dom["kernel"].endswith("pw") or dom["kernel"] == "i8_tail"):
+    if intensity > ridge and (dom["kernel"].endswith("pw") or dom["kernel"] in ("i8_tail", "i8_mid")):
         # matrix-core work only (the 1x1 convolutions): depthwise / dense arithmetic runs on the vector ALU and does not count against this roof
         roof = {"bound": "mfma", "achieved": dom["mfma_Tops"], "peak": peak_compute, "unit": "TFLOP/s" if dtype == "f32" else "TOP/s",
                 "all_ops_Tops": dom["Tops"]}
@@ -269,7 +273,7 @@ def roofline_of(rows: list[dict], batch: int, dtype: str, dom_op: int = -1) -> t
     rest = sorted((s for s in stages if s is not dom), key=lambda s: -s["avg_ms"])
     if rest:
         ru = rest[0]
-        ru_mfma = ru["ops"] / max(ru["bytes"], 1.0) > ridge and (ru["kernel"].endswith("pw") or ru["kernel"] == "i8_tail")
+        ru_mfma = ru["ops"] / max(ru["bytes"], 1.0) > ridge and (ru["kernel"].endswith("pw") or ru["kernel"] in ("i8_tail", "i8_mid"))
         roof["runner_up"] = {"kernel": ru["symbol"], "avg_launch_ms": ru["avg_ms"], "bound": "mfma" if ru_mfma else "hbm",
                              "frac": ru["mfma_frac"] if ru_mfma else ru["hbm_frac"],
                              "timing": "warm-up profile (every operator bracketed by events)"}

@@ -64,27 +64,18 @@ def resolve_config_path(model_path: str, model_config: str = "") -> str:
     return path
 
 
-def save_benchmark_json(metrics: dict, classes: list[str], model_path: str, out_path: str, config: dict | None = None,
-                        species_data: list[dict] | None = None) -> None:
-    """Reference report shape (reference: birdnet_stm32/evaluation/reporting.py:192-236)."""
-    core = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in metrics.items() if k != "ap_per_class"}
-    report = {"model_path": model_path, "num_classes": len(classes), "num_files": metrics.get("total_chunks", 0), "metrics": core}
-    if species_data:
-        report["species"] = species_data
-    if config:
-        report["config"] = config
-    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
-    with open(out_path, "w") as fh:
-        json.dump(report, fh, indent=2, default=str)
-    print(f"Benchmark report saved to {out_path}")
+# The report writers live under the reference's module path (birdnet_stm32/evaluation/reporting.py); re-exported here for callers of earlier rounds.
+from birdnet_stm32.evaluation.reporting import (  # noqa: E402,F401
+    print_ascii_det_curve,
+    print_ascii_histogram,
+    print_ascii_pr_curve,
+    print_confusion_matrix,
+    save_benchmark_json,
+    save_predictions_csv,
+    save_species_report_csv,
+)
 
-
-def save_predictions_csv(per_file: list[dict], classes: list[str], out_path: str) -> None:
-    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
-    with open(out_path, "w") as fh:
-        fh.write("file,label," + ",".join(c.replace(",", " ") for c in classes) + "\n")
-        for row in per_file:
-            fh.write(f"{row['file']},{row['label']}," + ",".join(f"{s:.6f}" for s in row["scores"]) + "\n")
+print_det_curve = print_ascii_det_curve  # (name of rounds 1-4)
 
 
 PLOT_FLAGS = ("save_cm_plot", "save_det_plot", "report_html")  # matplotlib / HTML renderings: not part of this build
@@ -105,49 +96,6 @@ def _init_distributed(device_arg: int):
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     return rank, world, local
-
-
-def print_confusion_matrix(y_true, y_scores, classes, threshold: float = 0.5) -> None:
-    """Top-1 confusion matrix as text, predictions below ``threshold`` counted as no prediction (reference:
-    birdnet_stm32/evaluation/reporting.py:81-114)."""
-    import numpy as np
-
-    truth = np.argmax(y_true, axis=1)
-    pred = np.argmax(y_scores, axis=1)
-    pred[np.max(y_scores, axis=1) < threshold] = -1
-    n = len(classes)
-    cm = np.zeros((n, n), np.int64)
-    keep = pred >= 0
-    np.add.at(cm, (truth[keep], pred[keep]), 1)
-    w = min(12, max(len(c) for c in classes)) if classes else 6
-    names = [c[:w] for c in classes]
-    print("\nConfusion Matrix (rows=true, cols=predicted):\n" + " " * (w + 1) + " ".join(f"{x:>{w}}" for x in names))
-    for i, row in enumerate(cm):
-        print(f"{names[i]:>{w}} " + " ".join(f"{v:>{w}}" for v in row))
-    total = int(cm.sum())
-    print(f"\nAccuracy: {int(np.trace(cm))}/{total} ({100 * int(np.trace(cm)) / max(total, 1):.1f}%)")
-
-
-def save_species_report_csv(species_data: list[dict], out_path: str) -> None:
-    """Per-species AP with bootstrap interval, best first (reference: birdnet_stm32/evaluation/reporting.py:173-189)."""
-    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
-    with open(out_path, "w") as fh:
-        fh.write("class,ap,ci_lower,ci_upper,n_positive,n_total\n")
-        for r in sorted(species_data, key=lambda r: r["ap"], reverse=True):
-            fh.write(f"{r['class']},{r['ap']:.6f},{r['ci_lower']:.6f},{r['ci_upper']:.6f},{r['n_positive']},{r['n_total']}\n")
-    print(f"Species AP report saved to {out_path}")
-
-
-def print_det_curve(far, frr, bins: int = 10, width: int = 40) -> None:
-    """Text DET curve: lowest FAR reached inside each FRR bin (reference: birdnet_stm32/evaluation/reporting.py:239-256)."""
-    import numpy as np
-
-    print("\nASCII DET Curve (FRR down, FAR right):")
-    edges = np.linspace(0.0, 1.0, bins + 1)
-    for lo, hi in zip(edges[:-1], edges[1:]):
-        inside = (frr >= lo) & (frr < hi)
-        best = float(far[inside].min()) if inside.any() else 1.0
-        print(f"FRR {lo:4.2f}-{hi:4.2f} | {'#' * int(width * best)} (FAR={best:4.3f})")
 
 
 def main(argv=None, runner=None):
@@ -209,9 +157,12 @@ def main(argv=None, runner=None):
         print("\nBottom 10 classes by AP:")
         for name, ap in ranked[-10:]:
             print(f"  {name}: {ap:.4f}")
+    # what the reference prints after every run (reference cli/evaluate.py:149-150)
+    print_ascii_histogram(y_scores.ravel())
+    print_ascii_pr_curve(y_true, y_scores)
     if args.det_curve:
         far, frr, _ = compute_det_curve(y_true, y_scores)
-        print_det_curve(far, frr)
+        print_ascii_det_curve(far, frr)
     species = None
     if args.species_report or args.benchmark:
         species = bootstrap_ap_ci(y_true, y_scores, classes, n_bootstrap=args.n_bootstrap)

@@ -537,3 +537,44 @@ def test_ranking_metrics_are_bit_identical_to_scikit_learn():
     bad[3, 2] = np.nan
     got = ranking_metrics(cases[0][0], bad)
     assert np.isnan(got["roc-auc"]) and np.isnan(got["mAP"]) and all(np.isnan(a) for a in got["ap_per_class"])
+
+
+# ------------------------------------------------------------------------------------------ evaluation/reporting.py (reference module path)
+def test_reporting_module_exports_the_reference_names_and_forms(tmp_path, capsys):
+    """``birdnet_stm32.evaluation.reporting`` resolves every name the reference CLI imports from it (reference cli/evaluate.py:14-25); the text
+    curves and the CSV have the reference's form (reporting.py:10-78); the precision-recall points equal scikit-learn's (ties included); the
+    three plot / HTML writers refuse."""
+    from sklearn.metrics import precision_recall_curve
+
+    from birdnet_stm32.evaluation import reporting as rp
+
+    for name in ("print_ascii_det_curve", "print_ascii_histogram", "print_ascii_pr_curve", "print_confusion_matrix", "save_benchmark_json",
+                 "save_confusion_matrix_plot", "save_det_curve_plot", "save_html_report", "save_predictions_csv", "save_species_report_csv"):
+        assert callable(getattr(rp, name))
+    rng = np.random.default_rng(4)
+    for trial in range(6):
+        yt = (rng.random(400) < 0.2).astype(np.int64)
+        ys = np.round(rng.random(400), 1 if trial % 2 else 6)  # (one decimal: many ties)
+        p, r = rp._precision_recall(yt, ys)
+        ps, rs, _ = precision_recall_curve(yt, ys)
+        assert np.array_equal(p, ps[:-1]) and np.array_equal(r, rs[:-1])
+    rp.print_ascii_histogram(np.array([0.05, 0.05, 0.95, 0.5]), bins=10, width=40)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "0.00 - 0.10 | " + "#" * 40 + " (2)" and out[9] == "0.90 - 1.00 | " + "#" * 20 + " (1)" and len(out) == 10
+    y_true = np.eye(3)[[0, 1, 2, 0]]
+    y_sc = np.array([[0.9, 0.1, 0.0], [0.2, 0.7, 0.1], [0.3, 0.3, 0.4], [0.4, 0.5, 0.1]])
+    rp.print_ascii_pr_curve(y_true, y_sc)
+    out = capsys.readouterr().out.splitlines()
+    assert out[1] == "ASCII Precision-Recall Curve (precision down, recall right):" and out[2].startswith(" 1.0 | ") and len(out) == 12
+    rp.print_ascii_det_curve(np.array([0.0, 0.5, 1.0]), np.array([1.0, 0.05, 0.0]))
+    out = capsys.readouterr().out.splitlines()
+    assert out[1] == "ASCII DET Curve (FRR down, FAR right):" and out[2] == "FRR 0.00-0.10 | " + "#" * 20 + " (FAR=0.500)"
+    rp.print_confusion_matrix(y_true, y_sc, ["aa", "bb", "cc"], threshold=0.45)
+    out = capsys.readouterr().out
+    assert "Confusion Matrix (rows=true, cols=predicted):" in out and "Accuracy: 2/3 (66.7%)" in out   # (file 3 is below the threshold, file 4 is wrong)
+    csv = tmp_path / "p.csv"
+    rp.save_predictions_csv([{"file": "a.wav", "label": "aa", "scores": [0.25, 0.75, 0.0]}], ["aa", "bb", "cc"], str(csv))
+    assert csv.read_text() == "file,label,top1_label,top1_score,aa,bb,cc\na.wav,aa,bb,0.750,0.250,0.750,0.000\n"
+    for fn in (rp.save_confusion_matrix_plot, rp.save_det_curve_plot, rp.save_html_report):
+        with pytest.raises(NotImplementedError, match="does not include"):
+            fn()
