@@ -27,7 +27,7 @@ EXPORTS = (
     "bn_version", "bn_last_error", "bn_device_count", "bn_ctx_create", "bn_ctx_destroy", "bn_model_load",
     "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
     "bn_kernel_names", "bn_profile_enable", "bn_profile_collect", "bn_ingest_resample", "bn_ingest_chunks",
-    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize", "bn_set_option", "bn_get_option",
+    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize", "bn_set_option", "bn_get_option", "bn_ctx_set_option", "bn_ctx_get_option", "bn_ctx_reset_options",
     "bn_blob_check", "bn_debug_requant", "bn_stft_mag_exact", "bn_debug_input_bytes", "bn_debug_guard_stats", "bn_debug_tail_form", "bn_debug_mid_form",
 )  # fmt: skip
 
@@ -103,6 +103,9 @@ def load_library(path: str | None = None):
     lib.bn_debug_requant.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.bn_set_option.argtypes = [c_char_p, c_int]
     lib.bn_get_option.argtypes = [c_char_p, POINTER(c_int)]
+    lib.bn_ctx_set_option.argtypes = [c_void_p, c_char_p, c_int]
+    lib.bn_ctx_get_option.argtypes = [c_void_p, c_char_p, POINTER(c_int)]
+    lib.bn_ctx_reset_options.argtypes = [c_void_p]
     if lib.bn_version() != ABI_VERSION:
         raise RuntimeError(f"libbirdnet_hip ABI {lib.bn_version()} != binding ABI {ABI_VERSION}")
     _lib = lib
@@ -171,6 +174,19 @@ class Context:
         rts = loaded_hip_runtimes()
         if len(rts) != 1:
             raise RuntimeError(f"expected one HIP runtime in the process, found {rts}")
+
+    def set_option(self, name: str, value: int) -> None:
+        """``bn_ctx_set_option``: a launcher switch for this context only (``set_option`` of the module sets the process default)."""
+        check(self.lib.bn_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        """The value the launches through this context see: its own override, else the process default."""
+        v = c_int()
+        check(self.lib.bn_ctx_get_option(self.handle, name.encode(), byref(v)))
+        return v.value
+
+    def reset_options(self) -> None:
+        check(self.lib.bn_ctx_reset_options(self.handle))
 
     def close(self):
         if getattr(self, "handle", None):

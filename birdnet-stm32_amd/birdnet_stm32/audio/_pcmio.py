@@ -44,13 +44,78 @@ def _load():
     return _lib
 
 
+def local_world_size() -> int:
+    """Ranks of this job on THIS host (``LOCAL_WORLD_SIZE`` of torch.distributed.run; 1 outside it)."""
+    try:
+        return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        return 1
+
+
 def default_threads() -> int:
-    """Reader threads: the process's CPU share, at most 16 (one GPU's share of a host), at least 2."""
+    """Reader threads of this process: its share of the CPUs it may run on — the affinity mask divided by the ranks on this host — at most
+    16 (what one GPU's PCIe link can use), at least 2.  Eight ranks on a 128-thread host get 16 each, on a 64-thread host 8: the reader
+    pools of a node never oversubscribe it."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
         n = os.cpu_count() or 2
-    return max(2, min(16, n))
+    return max(2, min(16, n // local_world_size()))
+
+
+def _parse_cpulist(text: str) -> set[int]:
+    cpus: set[int] = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(pci_bus_id: str, sysfs: str = "/sys/bus/pci/devices") -> tuple[int, set[int]]:
+    """(NUMA node, CPUs local to it) of the PCI device ``pci_bus_id`` ("0000:c1:00.0") from sysfs; (-1, empty) when the host does not say."""
+    base = os.path.join(sysfs, pci_bus_id.lower())
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+        cpus = _parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except (OSError, ValueError):
+        return -1, set()
+    return node, cpus
+
+
+def rank_cpu_share(local_rank: int, nodes: list[int], node_cpus: list[set[int]], allowed: set[int]) -> set[int]:
+    """The CPUs local rank ``local_rank`` should run on: those of ITS GPU's NUMA node that the process may use, dealt evenly (in CPU order)
+    among the local ranks whose GPUs sit on the same node.  ``nodes[r]`` / ``node_cpus[r]`` = node and local CPUs of local rank r's GPU.
+    Empty = no information (leave the affinity alone)."""
+    if not (0 <= local_rank < len(nodes)) or nodes[local_rank] < 0:
+        return set()
+    mine = sorted(node_cpus[local_rank] & allowed)
+    peers = [r for r in range(len(nodes)) if nodes[r] == nodes[local_rank]]
+    if not mine or local_rank not in peers:
+        return set()
+    k, n = peers.index(local_rank), len(peers)
+    share = mine[k * len(mine) // n:(k + 1) * len(mine) // n]
+    return set(share)
+
+
+def pin_process_to_gpu_node(torch, local_rank: int, n_local: int) -> dict:
+    """Restrict this process (the reader threads it starts later inherit the mask, and the page-locked slabs it allocates are first touched
+    under it) to the CPUs of its GPU's NUMA node, shared fairly with the other local ranks on that node.  Called by the evaluate pipeline
+    when several ranks share a host; returns what it did (for the run's stats)."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+        ids = []
+        for r in range(n_local):
+            pr = torch.cuda.get_device_properties(r)
+            ids.append(f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0")
+        info = [gpu_numa_cpus(i) for i in ids]
+        share = rank_cpu_share(local_rank, [n for n, _ in info], [c for _, c in info], allowed)
+        if share:
+            os.sched_setaffinity(0, share)
+        return {"numa_node": info[local_rank][0], "cpus": len(share), "pinned": bool(share)}
+    except Exception as e:  # pragma: no cover - best effort: an unknown host layout must not stop the run
+        return {"numa_node": -1, "cpus": 0, "pinned": False, "error": str(e)}
 
 
 def _path_array(paths):

@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes
 import queue
+import os
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -327,13 +328,20 @@ class EvaluatePipeline:
 
     def __init__(self, runner, sample_rate: int, chunk_duration: float, chunk_overlap: float = 0.0, max_duration=60,
                  slab_bytes: int = 256 << 20, group_chunks: int | None = None, readers: int | None = None, pinned_slabs: int = 3,
-                 ramp: tuple = (8, 4, 2)):
+                 ramp: tuple = (8, 4, 2), numa_pin: bool | None = None):
         import torch
 
         self.torch = torch
         self.runner = runner
         self.ctx = runner.ctx
         self.dev = runner.device
+        # Several ranks on one host (torch.distributed.run sets LOCAL_WORLD_SIZE / LOCAL_RANK): every rank keeps its reader threads and the
+        # first touch of its page-locked slabs on the CPUs of ITS GPU's NUMA node and takes an even share of that node's CPUs — before the
+        # first thread starts and before the slabs exist.  (numa_pin: None = only when ranks share the host, True / False = force.)
+        n_local = _pcmio.local_world_size()
+        self.numa = {"numa_node": -1, "cpus": 0, "pinned": False}
+        if numa_pin if numa_pin is not None else n_local > 1:
+            self.numa = _pcmio.pin_process_to_gpu_node(torch, int(os.environ.get("LOCAL_RANK", "0")), n_local)
         self.sr, self.cd, self.ov, self.max_duration = int(sample_rate), float(chunk_duration), float(chunk_overlap), max_duration
         self.slab_bytes = int(slab_bytes)
         self.ramp = tuple(ramp)  # first groups cut at slab_bytes / ramp[i] (cut_groups)
@@ -541,7 +549,7 @@ class EvaluatePipeline:
         stats.update(files=len(paths), readable=int((tab.kind >= 0).sum()), chunks=row, groups=len(groups), read_s=read_s, h2d_s=h2d_ms / 1e3,
                      h2d_bytes=moved, h2d_gbps=(moved / 1e9) / (h2d_ms / 1e3) if h2d_ms > 0 else 0.0, ingest_s=ingest_ms / 1e3,
                      infer_s=infer_ms / 1e3, wall_s=time.perf_counter() - t_start, readers=self.readers, slab_bytes=self.slab_bytes,
-                     group_chunks=self.group_chunks)
+                     group_chunks=self.group_chunks, local_world=_pcmio.local_world_size(), numa=dict(self.numa))
         return scores[:row], counts.tolist(), stats, lat
 
 

@@ -50,6 +50,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--profile_memory", action="store_true", default=False, help="Report peak memory (RSS) during inference")
     p.add_argument("--device", type=int, default=0, help="MI355X index")
     p.add_argument("--max_batch", type=int, default=4096, help="Workspace size in chunks = inference slice of the device pipeline")
+    p.add_argument("--skip_undecodable", action="store_true", default=False,
+                   help="Evaluate the decodable files when the data set holds containers this build cannot read (Ogg / MP3 / M4A without soundfile) instead of refusing")
     return p
 
 
@@ -125,6 +127,20 @@ def main(argv=None, runner=None):
     files, _ = load_file_paths_from_directory(args.data_path_test, classes=classes, exts=SUPPORTED_AUDIO_EXTS, max_samples=args.max_files)
     if not files:
         raise RuntimeError(f"No test audio found in {args.data_path_test}")
+    # The reference reads whatever libsndfile opens (audio/io.py:90,114-116); this build decodes RIFF/WAVE and FLAC natively and hands every other
+    # container to the `soundfile` package when it is installed.  Without it an Ogg / MP3 / M4A data set would silently evaluate to fewer (or
+    # zero) files: refuse instead, unless the caller asks for the files to be skipped.
+    from birdnet_stm32.audio.io import have_soundfile
+
+    foreign: dict[str, int] = {}
+    for path in files:
+        ext = os.path.splitext(path)[1].lower()
+        if ext not in (".wav", ".flac"):
+            foreign[ext] = foreign.get(ext, 0) + 1
+    if foreign and not have_soundfile() and not args.skip_undecodable:
+        raise SystemExit("error: " + ", ".join(f"{n} x {e}" for e, n in sorted(foreign.items())) + f" of the {len(files)} discovered files cannot be decoded: only RIFF/WAVE and "
+                         "FLAC are read natively and the `soundfile` package is not installed.  Convert them (e.g. to FLAC), install soundfile, or pass "
+                         "--skip_undecodable to evaluate the remaining files")
     if runner is None:
         from birdnet_stm32.models.runners import load_model_runner
 

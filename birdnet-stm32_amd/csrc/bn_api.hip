@@ -69,10 +69,14 @@ bn::Options options_from_env() {
 }  // namespace
 
 namespace bn {
-Options g_opt = options_from_env();
+thread_local Options g_opt;
 }
 
+bn::Options g_opt_default = options_from_env();   // the process default (bn_set_option); copied into bn::g_opt per API call
+std::mutex g_opt_mu;
+
 struct bn_ctx {
+    std::vector<std::pair<int bn::Options::*, int>> opt_override;   // switches this context sets for itself (bn_ctx_set_option)
     int device = 0;
     int max_batch = 0;
     float* d_window = nullptr;
@@ -156,6 +160,11 @@ namespace {
 int check_device(bn_ctx* ctx) {
     if (!ctx) return fail(BN_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
+    {   // the switches this call's launchers see: the process default, then the context's own
+        std::lock_guard<std::mutex> lock(g_opt_mu);
+        bn::g_opt = g_opt_default;
+        for (const auto& ov : ctx->opt_override) bn::g_opt.*(ov.first) = ov.second;
+    }
     return BN_OK;
 }
 
@@ -1477,17 +1486,55 @@ int bn_set_option(const char* name, int value) {
     if (!name) return fail(BN_ERR_ARG, "null option name");
     for (const OptName& e : kOptions)
         if (strcmp(name, e.name) == 0) {
-            bn::g_opt.*(e.field) = value;
+            std::lock_guard<std::mutex> lock(g_opt_mu);
+            g_opt_default.*(e.field) = value;
             return BN_OK;
         }
     return fail(BN_ERR_ARG, "unknown option '%s'", name);
+}
+
+int bn_ctx_set_option(bn_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return fail(BN_ERR_ARG, "null argument");
+    for (const OptName& e : kOptions)
+        if (strcmp(name, e.name) == 0) {
+            std::lock_guard<std::mutex> lock(g_opt_mu);
+            for (auto& ov : ctx->opt_override)
+                if (ov.first == e.field) {
+                    ov.second = value;
+                    return BN_OK;
+                }
+            ctx->opt_override.emplace_back(e.field, value);
+            return BN_OK;
+        }
+    return fail(BN_ERR_ARG, "unknown option '%s'", name);
+}
+
+int bn_ctx_get_option(bn_ctx* ctx, const char* name, int* value) {
+    if (!ctx || !name || !value) return fail(BN_ERR_ARG, "null argument");
+    for (const OptName& e : kOptions)
+        if (strcmp(name, e.name) == 0) {
+            std::lock_guard<std::mutex> lock(g_opt_mu);
+            *value = g_opt_default.*(e.field);
+            for (const auto& ov : ctx->opt_override)
+                if (ov.first == e.field) *value = ov.second;
+            return BN_OK;
+        }
+    return fail(BN_ERR_ARG, "unknown option '%s'", name);
+}
+
+int bn_ctx_reset_options(bn_ctx* ctx) {
+    if (!ctx) return fail(BN_ERR_ARG, "null context");
+    std::lock_guard<std::mutex> lock(g_opt_mu);
+    ctx->opt_override.clear();
+    return BN_OK;
 }
 
 int bn_get_option(const char* name, int* value) {
     if (!name || !value) return fail(BN_ERR_ARG, "null argument");
     for (const OptName& e : kOptions)
         if (strcmp(name, e.name) == 0) {
-            *value = bn::g_opt.*(e.field);
+            std::lock_guard<std::mutex> lock(g_opt_mu);
+            *value = g_opt_default.*(e.field);
             return BN_OK;
         }
     return fail(BN_ERR_ARG, "unknown option '%s'", name);

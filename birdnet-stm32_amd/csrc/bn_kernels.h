@@ -13,8 +13,10 @@
 
 namespace bn {
 
-// Run-time switches of the launchers (A/B runs, tests).  Process-wide, set through the C ABI (bn_set_option); the BN_* environment
-// variables of the same names seed them ONCE when the library is loaded — nothing on a launch path reads the environment.
+// Run-time switches of the launchers (A/B runs, tests).  The process default is set through the C ABI (bn_set_option; the BN_* environment
+// variables of the same names seed it ONCE when the library is loaded — nothing on a launch path reads the environment); a context may
+// override single switches for itself (bn_ctx_set_option), so two models in one process can run under different options.  What the launchers
+// read is `g_opt`: a per-thread copy that every API entry point refreshes from the default and its context's overrides (bn_api.hip: check_device).
 struct Options {
     int f32_strip = 1;         // float32 row-streaming strip kernels (0: tile kernels everywhere)
     int f32_strip_th = 0;      // force the rows per strip (0: the launcher's choice)
@@ -52,7 +54,7 @@ struct Options {
     int ingest_blk = 0;        // outputs per workgroup of the resampler (0: auto)
     int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
 };
-extern Options g_opt;
+extern thread_local Options g_opt;
 
 // A kernel that needs more than the default 64 KB of dynamic LDS has its limit raised with hipFuncSetAttribute — per DEVICE (the attribute
 // belongs to the current device's copy of the function; bn_ctx_create takes a device index) and only when the request grows.  false: the

@@ -278,6 +278,13 @@ BN_API int bn_profile_collect(bn_model* model, double* total_ms, int64_t* launch
  * birdnet_stm32/models/runners.py:57, are the closest thing).  Unknown name: BN_ERR_ARG. */
 BN_API int bn_set_option(const char* name, int value);
 BN_API int bn_get_option(const char* name, int* value);
+/* The same switches per context: bn_set_option sets the PROCESS DEFAULT, bn_ctx_set_option overrides one switch for the launches made through
+ * this context (and the models loaded into it) only, so two models in one process can run under different options; bn_ctx_get_option reads the
+ * effective value, bn_ctx_reset_options drops the context's overrides.  (The reference's counterpart is per-interpreter state: every
+ * tf.lite.Interpreter of models/runners.py:57 carries its own settings.) */
+BN_API int bn_ctx_set_option(bn_ctx* ctx, const char* name, int value);
+BN_API int bn_ctx_get_option(bn_ctx* ctx, const char* name, int* value);
+BN_API int bn_ctx_reset_options(bn_ctx* ctx);
 
 /* Names of the HIP kernels a forward pass launches, '\n'-separated (for profiling tools). */
 BN_API const char* bn_kernel_names(void);

@@ -427,7 +427,7 @@ def test_exported_graphs_are_bit_exact_per_tensor_on_the_gpu(name):
     import torch
 
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("-m gpu tests need a ROCm device; the product has no CPU path to fall back to")
     from birdnet_stm32.models._lower_i8 import lower_i8
     from birdnet_stm32.models.runners import HipRunner
     from oracle.int8_graph import Int8Interpreter
@@ -501,7 +501,7 @@ def test_exported_graphs_of_other_geometries_match_the_oracle_on_the_gpu(name):
     import torch
 
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("-m gpu tests need a ROCm device; the product has no CPU path to fall back to")
     from birdnet_stm32.models._lower_i8 import lower_i8
     from birdnet_stm32.models.runners import HipRunner
     from oracle.int8_graph import Int8Interpreter
@@ -536,7 +536,7 @@ def test_dense_int8_pointwise_kernel_equals_the_tile_kernel_at_batch(batch):
     import torch
 
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("-m gpu tests need a ROCm device; the product has no CPU path to fall back to")
     from birdnet_stm32 import _hip
     from birdnet_stm32.models._lower_i8 import lower_i8
     from birdnet_stm32.models.runners import HipRunner

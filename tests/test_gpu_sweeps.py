@@ -26,7 +26,7 @@ def torch_mod():
     import torch
 
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("-m gpu tests need a ROCm device; the product has no CPU path to fall back to")
     return torch
 
 
@@ -101,7 +101,7 @@ def _c_int8_path():
     import os
 
     if not (os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB)):
-        pytest.skip("oracle/_build is missing: run __graft_entry__.build()")
+        pytest.fail("oracle/_build is missing: run __graft_entry__.build() (the checker of this test is the C port of the oracle)")
     return cport.CpuInt8Path(load_tflite(TFLITE_PATH))
 
 
@@ -475,6 +475,40 @@ def test_i8_fused_stage2_chain_matches_the_strip_kernels_and_oracle(torch_mod):
     with _hip.options(i8_mid=0):
         assert torch.equal(runner.infer_audio_device(audio), a1)
     runner.close()
+
+
+def test_two_models_in_one_process_run_under_their_own_options(torch_mod):
+    """Launcher switches are per context (bn_ctx_set_option) on top of the process default (bn_set_option): two runners of the same model in one
+    process, one with the fused kernels switched off for ITS context, give the same scores through different kernels, interleaved; the
+    default of the process is untouched; a later change of the process default reaches the context that did not override the switch."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models.runners import load_model_runner
+
+    a = load_model_runner(TFLITE_PATH, max_batch=16)
+    b = load_model_runner(TFLITE_PATH, max_batch=16)
+    b.ctx.set_option("i8_tail", 0)
+    b.ctx.set_option("i8_mid", 0)
+    assert (a.ctx.get_option("i8_tail"), b.ctx.get_option("i8_tail"), _hip.get_option("i8_tail")) == (1, 0, 1)
+    x = torch.rand((16, 257 * 256), device="cuda")
+    for r in (a, b):
+        r.profile(True)
+    sa, sb = a.predict_device(x).clone(), b.predict_device(x).clone()
+    sa2 = a.predict_device(x).clone()
+    ka = {q["kind"] for q in a.profile_collect() if q["launches"]}
+    kb = {q["kind"] for q in b.profile_collect() if q["launches"]}
+    assert torch.equal(sa, sb) and torch.equal(sa, sa2)
+    assert {"i8_tail", "i8_mid"} <= ka and not ({"i8_tail", "i8_mid"} & kb) and "i8_mean" in kb
+    with _hip.options(i8_tail=0):   # the process default: reaches a (no override), b keeps its own value
+        assert (a.ctx.get_option("i8_tail"), b.ctx.get_option("i8_tail")) == (0, 0)
+        a.predict_device(x)
+        assert "i8_tail" not in {q["kind"] for q in a.profile_collect() if q["launches"]}
+    b.ctx.reset_options()
+    assert b.ctx.get_option("i8_tail") == 1
+    b.predict_device(x)
+    assert "i8_tail" in {q["kind"] for q in b.profile_collect() if q["launches"]}
+    a.close()
+    b.close()
 
 
 # --------------------------------------------------------------------------------------- float32: front block + stage1_ds2 as one kernel

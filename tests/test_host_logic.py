@@ -578,3 +578,23 @@ def test_reporting_module_exports_the_reference_names_and_forms(tmp_path, capsys
     for fn in (rp.save_confusion_matrix_plot, rp.save_det_curve_plot, rp.save_html_report):
         with pytest.raises(NotImplementedError, match="does not include"):
             fn()
+
+
+def test_cli_refuses_a_data_set_of_containers_it_cannot_decode(tmp_path):
+    """A data set with Ogg / MP3 / M4A files must not silently evaluate to fewer files: without the soundfile package the CLI exits with a message
+    naming the containers (before any model is loaded); --skip_undecodable is the explicit way to go on."""
+    from birdnet_stm32.audio.io import have_soundfile
+    from birdnet_stm32.cli.evaluate import main
+
+    if have_soundfile():
+        pytest.skip("soundfile is installed: other containers decode through it")
+    from conftest import CKPT_DIR, TFLITE_PATH
+
+    cfg = json.load(open(os.path.join(CKPT_DIR, "birdnet_stm32n6_100_model_config.json")))
+    cls = cfg["class_names"][0]
+    d = tmp_path / "data" / cls
+    d.mkdir(parents=True)
+    (d / "a.ogg").write_bytes(b"OggS" + bytes(64))
+    (d / "b.mp3").write_bytes(b"ID3" + bytes(64))
+    with pytest.raises(SystemExit, match=r"1 x \.mp3, 1 x \.ogg of the 2 discovered files cannot be decoded"):
+        main(["--model_path", TFLITE_PATH, "--data_path_test", str(tmp_path / "data")], runner=object())

@@ -306,3 +306,38 @@ def test_host_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_pcmio._LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_reader_share_and_numa_placement_for_ranks_sharing_a_host(monkeypatch, tmp_path):
+    """Eight ranks on one host must not start 8 x 16 reader threads: a rank's readers are its share of the CPUs it may use (at most 16);
+    a rank's CPUs are those of ITS GPU's NUMA node, dealt evenly among the local ranks on that node (sysfs: numa_node / local_cpulist)."""
+    from birdnet_stm32.audio import _pcmio
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)), raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert _pcmio.local_world_size() == 1 and _pcmio.default_threads() == 16
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert _pcmio.local_world_size() == 8 and _pcmio.default_threads() == 16          # 128 / 8
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    assert _pcmio.default_threads() == 8                                                  # 64 / 8
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
+    assert _pcmio.default_threads() == 2                                                  # never below two
+    assert _pcmio._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    # sysfs of a two-socket host with four GPUs per socket
+    for i, (node, cpus) in enumerate([(0, "0-31,64-95")] * 4 + [(1, "32-63,96-127")] * 4):
+        d = tmp_path / f"0000:{0xc1 + i:02x}:00.0"
+        d.mkdir()
+        (d / "numa_node").write_text(f"{node}\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+    info = [_pcmio.gpu_numa_cpus(f"0000:{0xc1 + i:02X}:00.0", sysfs=str(tmp_path)) for i in range(8)]
+    assert [n for n, _ in info] == [0] * 4 + [1] * 4 and len(info[0][1]) == 64
+    assert _pcmio.gpu_numa_cpus("0000:ff:00.0", sysfs=str(tmp_path)) == (-1, set())
+    allowed = set(range(128))
+    shares = [_pcmio.rank_cpu_share(r, [n for n, _ in info], [c for _, c in info], allowed) for r in range(8)]
+    assert all(len(s) == 16 for s in shares)                                             # 64 CPUs of a node over its four ranks
+    assert all(shares[a].isdisjoint(shares[b]) for a in range(8) for b in range(a + 1, 8))
+    assert set().union(*shares[:4]) == info[0][1] and set().union(*shares[4:]) == info[4][1]
+    # a cgroup that leaves the process half of every node: the share shrinks with it; an unknown layout leaves the affinity alone
+    half = {c for c in allowed if c % 2 == 0}
+    assert len(_pcmio.rank_cpu_share(5, [n for n, _ in info], [c for _, c in info], half)) == 8
+    assert _pcmio.rank_cpu_share(0, [-1] * 8, [set()] * 8, allowed) == set()

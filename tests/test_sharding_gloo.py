@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: world_size-2 gloo processes shard a chunk stream and meet in one all-gather."""
+"""The N > 1 path on CPU: gloo processes (world size 2, 4 and 8) shard a chunk stream and meet in one all-gather."""
 
 import os
 import socket
@@ -118,19 +118,78 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n_items", [16, 13])
-def test_two_rank_sharding_and_all_gather(n_items, tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % PKG)
+def _run_world(script, world, *argv):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), str(n_items)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), *map(str, argv)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
-    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
+    for rank in range(world):
+        assert f"rank {rank} ok" in outs[rank]
+    return outs
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 16), (2, 13), (4, 37), (8, 64), (8, 61)])
+def test_sharding_and_all_gather(world, n_items, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % PKG)
+    _run_world(script, world, n_items)
+
+
+WORKER3 = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from birdnet_stm32.audio.pipeline import balanced_bounds
+from birdnet_stm32.audio import _pcmio
+from birdnet_stm32.evaluation.sharding import all_gather_ragged, score_files_sharded
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+assert _pcmio.local_world_size() == world and _pcmio.default_threads() <= max(2, len(os.sched_getaffinity(0)) // world)
+F, C = int(sys.argv[1]), 3
+per = np.random.default_rng(11).integers(0, 13, F)           # chunks per file (some files have none), the same on every rank
+per[:4] = [60, 1, 0, 45]                                      # long files at the head of the list
+bounds = balanced_bounds(per, world)
+assert bounds[0] == 0 and bounds[-1] == F and all(a <= b for a, b in zip(bounds, bounds[1:]))
+loads = np.array([int(per[bounds[r]:bounds[r + 1]].sum()) for r in range(world)])
+assert np.abs(loads - per.sum() / world).max() <= 60 + 1, loads     # nobody more than one file's chunks from the mean
+blocks = []
+def score_files(lo, hi):
+    blocks.append((lo, hi))
+    n = int(per[lo:hi].sum())
+    owner = np.repeat(np.arange(lo, hi), per[lo:hi])
+    rows = torch.from_numpy(np.stack([owner, owner * 2 + 1, np.full(n, rank)], axis=1).astype(np.float32)) if n else torch.zeros((0, C))
+    return rows, per[lo:hi].tolist()
+scores, counts = score_files_sharded(F, score_files, C, bounds=bounds)
+assert blocks == [(bounds[rank], bounds[rank + 1])] and counts == per.tolist() and scores.shape == (int(per.sum()), C)
+owner = np.repeat(np.arange(F), per)
+assert np.array_equal(scores[:, 0].numpy(), owner.astype(np.float32)) and np.array_equal(scores[:, 1].numpy(), (owner * 2 + 1).astype(np.float32))
+who = np.repeat(np.searchsorted(np.asarray(bounds[1:]), np.arange(F), side="right"), per)   # the rank whose block holds the file
+assert np.array_equal(scores[:, 2].numpy(), who.astype(np.float32))                         # every row came from the rank that owns it
+# ragged all-gather with an empty rank in the middle
+local = torch.full((0 if rank == 1 else 2 + rank, C), float(rank))
+allrows, cnt = all_gather_ragged(local)
+assert cnt == [0 if r == 1 else 2 + r for r in range(world)] and allrows.shape[0] == sum(cnt)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world,files", [(4, 1000), (8, 4096)])
+def test_file_sharding_by_chunk_count_on_four_and_eight_ranks(world, files, tmp_path):
+    """``evaluate``'s dealing on 4 and 8 ranks of one host: blocks of equal CHUNK count (disjoint, covering, nobody more than one file's
+    chunks from the mean), every rank scores exactly its block, the ragged all-gather returns the rows in file order on every rank, and the
+    reader-thread share follows LOCAL_WORLD_SIZE."""
+    script = tmp_path / "worker3.py"
+    script.write_text(WORKER3 % PKG)
+    _run_world(script, world, files)
 
 
 def test_shard_bounds_cover_the_range():
@@ -153,15 +212,7 @@ def test_bench_job_ragged_gather_and_file_sharding(tmp_path):
     the ragged all-gather and evaluate's file-level sharding — world size 2 on gloo."""
     script = tmp_path / "worker2.py"
     script.write_text(WORKER2 % (PKG, REPO))
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=180)[0] for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
-    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
+    _run_world(script, 2)
 
 
 def test_bench_self_launch_command(monkeypatch):
