@@ -114,11 +114,13 @@ class FileTable:
 
 
 def plan_files(paths: list[str], sample_rate: int, chunk_duration: float, chunk_overlap: float, max_duration=60,
-               n_threads: int | None = None) -> FileTable:
+               n_threads: int | None = None, keep_decoded: bool = True) -> FileTable:
     """Probe every file's container (threads, headers only) and derive window, resampled and chunk sizes.
 
     Plain WAV: exact, from the header.  FLAC: from STREAMINFO (the first 64 KB of the file); a stream that does not state its length,
-    and every other container, is decoded now (``read_pcm_window``) and kept until its group is staged."""
+    and every other container, is decoded now (``read_pcm_window``) and kept until its group is staged — unless ``keep_decoded`` is off
+    (the weights pass of the sharded ``evaluate``: every rank needs every file's chunk COUNT, not its samples; holding the decoded windows of
+    the whole data set on every rank only to throw them away was ADVICE r4)."""
     n = len(paths)
     lay = _pcmio.probe_wavs(paths, n_threads)
     kind = np.full(n, -1, np.int32)
@@ -168,7 +170,7 @@ def plan_files(paths: list[str], sample_rate: int, chunk_duration: float, chunk_
                 if r is None:
                     continue
                 kind[i], fmt[i], ch[i], sr0[i], frames[i] = 1, r[0], r[1], r[2], r[3]
-                if r[4] is not None:
+                if r[4] is not None and keep_decoded:
                     decoded[i] = r[4]
     good = kind >= 0
     ch = np.where(good, ch, 0)

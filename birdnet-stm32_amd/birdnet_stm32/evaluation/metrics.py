@@ -166,7 +166,7 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
     from birdnet_stm32.evaluation import sharding as _sh
 
     if world_info()[1] > 1 or not _sh._local_only(world_info()[1]):  # (the second clause: the collective path forced at world size 1, tests)
-        weights = plan_files(todo, sr, cd, overlap, 60, pipe.readers).n_chunks  # headers only; the same on every rank
+        weights = plan_files(todo, sr, cd, overlap, 60, pipe.readers, keep_decoded=False).n_chunks  # counts only (no decoded window is kept); the same on every rank
         bounds = balanced_bounds(weights, world_info()[1])
 
         def score_block(lo, hi):

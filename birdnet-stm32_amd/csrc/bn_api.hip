@@ -15,6 +15,7 @@
 #include "../../include/birdnet_hip.h"
 #include "bn_blob.h"
 #include "bn_kernels.h"
+#include "bn_quant_in.h"
 
 namespace {
 
@@ -50,7 +51,7 @@ const OptName kOptions[] = {
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail}, {"i8_tail_mfdw", &bn::Options::i8_tail_mfdw}, {"i8_mid", &bn::Options::i8_mid},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
-    {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap},
+    {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap}, {"stft_guard", &bn::Options::stft_guard}, {"stft_audit", &bn::Options::stft_audit},
     {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
@@ -121,6 +122,7 @@ struct bn_model {
     int last_B = 0;
     bool guard_now = false;              // set by bn_infer_audio: the first operator lists doubtful bytes, the float64 pass follows it
     const float* guard_audio = nullptr;
+    int* d_audit = nullptr;              // [2] exactness audit: elements audited, violations (option stft_audit; zeroed per bn_infer_audio call)
     int guard_T = 0, guard_hop = 0;
     float* d_smax = nullptr;             // [max_batch] per-sample maxima of the frontend
     float* d_gap_part = nullptr;         // [max_batch][gap_part_elems] channel sums per row block from f32_pwdw_kernel for the squeeze-excite gate behind it
@@ -213,6 +215,13 @@ bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
     g.hop = m->guard_hop;
     g.tabs = m->ctx->tables;
     g.flag_cap = bn::g_opt.stft_flagcap;
+    // the frame part of the bound (bn_quant_in.h): empirical, proven, or — tests only — far too small
+    const int gm = bn::g_opt.stft_guard;
+    g.k_l2 = gm == 1 ? bn::kGuardL2Proven : gm == 2 ? bn::kGuardL2 / 1024.0f : bn::kGuardL2;
+    g.k_peak = gm == 1 ? 0.0f : gm == 2 ? bn::kGuardPeak / 1024.0f : bn::kGuardPeak;
+    g.audit_scale = gm == 2 ? 1024.0f : 1.0f;
+    g.slack_scale = gm == 2 ? 0.0f : 1.0f;
+    g.audit = bn::g_opt.stft_audit ? m->d_audit : nullptr;
     return g;
 }
 
@@ -1015,12 +1024,13 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
         };
         const size_t o_eps = take(mb * W * 4), o_rec = take(mb * n_tiles * bn::kGuardRec * 4), o_list = take(16), o_cnt = take(mb * 4),
                      o_dirty = take(mb * 4), o_work = take(mb * t64 * 4), o_nw = take(4 * (mb / kMaxGridBatch + 1)), o_hard = take(2 * mb * 4),
-                     o_nh = take(8 * (mb / kMaxGridBatch + 1));
+                     o_nh = take(8 * (mb / kMaxGridBatch + 1)), o_audit = take(8);
         if (hipMalloc(&m->d_guard, off) != hipSuccess) return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu exactness-pass bytes failed", off));
         m->workspace_bytes += off;
         char* g = m->d_guard;
         m->guard = bn::StftGuard{(float*)(g + o_eps), (int*)(g + o_rec), (int*)(g + o_list), (int*)(g + o_cnt), cap, (int*)(g + o_dirty),
                                  (int*)(g + o_work), (int*)(g + o_nw), (int*)(g + o_hard), (int*)(g + o_nh), (int)mb};
+        m->d_audit = (int*)(g + o_audit);
     }
     if (hipMalloc(&m->d_minmax, mb * 2 * sizeof(float)) != hipSuccess ||
         hipMalloc(&m->d_smax, mb * sizeof(float)) != hipSuccess)
@@ -1237,6 +1247,7 @@ int bn_infer_audio(bn_model* m, const float* d_audio, int B, int T, int hop, flo
     if (guarded) {
         // profiling entries: n_ops = the float32 STFT kernel, n_ops + 1 = exact min / max, n_ops + 2 = the float64 pass behind the first operator
         if (T <= 0 || hop <= 0 || 1 + T / hop < W) rc = fail(BN_ERR_ARG, "T=%d hop=%d gives %d frames, fewer than spec_width=%d", T, hop, hop > 0 ? 1 + T / hop : 0, W);
+        if (m->d_audit) HIP_TRY(hipMemsetAsync(m->d_audit, 0, 2 * sizeof(int), s));
         for (int b0 = 0; rc == BN_OK && b0 < B; b0 += kMaxGridBatch) {
             const int nb = B - b0 < kMaxGridBatch ? B - b0 : kMaxGridBatch;
             bn::StftGuard g = guard_slice(m, (size_t)b0);
@@ -1317,6 +1328,10 @@ int bn_debug_guard_stats(bn_model* m, int B, int64_t* out) {
     out[2] = nw;
     out[3] = nh[0];
     out[4] = nh[1];
+    int au[2] = {0, 0};
+    if (m->d_audit) HIP_TRY(hipMemcpy(au, m->d_audit, sizeof au, hipMemcpyDeviceToHost));
+    out[5] = au[0];
+    out[6] = au[1];
     return BN_OK;
 }
 

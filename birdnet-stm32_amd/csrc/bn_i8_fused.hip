@@ -496,22 +496,27 @@ constexpr int kMelFlagCap = 1022;  // flagged elements a workgroup keeps in LDS 
 #ifdef BN_TAIL_STAMPS
 __device__ long long* g_mel_stamps = nullptr;   // [kMelStampWg][4 waves][8]
 constexpr int kMelStampWg = 1024;
-#define BN_MSTAMP(i) do { if (MODE == 1 && mstamp) mst[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define BN_MSTAMP(i) do { if ((MODE == 1 || MODE == 3) && mstamp) mst[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define BN_MSTAMP(i) do {} while (0)
 #endif
 
+// MODE 3 = MODE 1 + the audit (option stft_audit): elements that are NOT in doubt but lie within kAuditBands bounds of a rounding boundary are listed too
+// (bit 31 of the entry), re-evaluated with the flagged ones, and only COMPARED: a kept byte that differs from the exact one is a violation of the bound.
+constexpr float kAuditBands = 4.0f;
 template <bool QIN, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 4, 8))) void i8_mel_mfma_kernel(DwPw8Args a) {
+    constexpr bool GUARDED = MODE == 1 || MODE == 3, AUDIT = MODE == 3;
 #ifdef BN_TAIL_STAMPS
     long long mst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int mslot = (int)blockIdx.x - (int)gridDim.x / 2;
-    const bool mstamp = MODE == 1 && g_mel_stamps && mslot >= 0 && mslot < kMelStampWg;
+    const bool mstamp = GUARDED && g_mel_stamps && mslot >= 0 && mslot < kMelStampWg;
 #endif
     BN_MSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-    __shared__ int flag_n, flags[MODE == 1 ? kMelFlagCap : 1];
-    __shared__ std::conditional_t<MODE == 1, ExactTabsW, int> xtabs_s;  // float64 twiddles + window for the elements this workgroup re-evaluates itself
+    __shared__ int flag_n, flags[GUARDED ? kMelFlagCap : 1];
+    __shared__ int audit_n, audit_bad;
+    __shared__ std::conditional_t<GUARDED, ExactTabsW, int> xtabs_s;  // float64 twiddles + window for the elements this workgroup re-evaluates itself
     v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);
     const int Kp = a.Cin, W = a.W, M = a.Cout;
     const int S16 = (Kp >> 4) + 1;  // row stride in 16-byte units (one unit of padding: conflict-free 16-byte reads along rows)
@@ -521,7 +526,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     for (int item = MODE == 2 ? blockIdx.x : 0; item < n_items; item += MODE == 2 ? gridDim.x : 1) {
     const int bid = MODE == 2 ? a.qguard.work[item] : xcd_tile(blockIdx.x, gridDim.x);
     const int chunk = bid / tiles_x, t0 = (bid - chunk * tiles_x) << 6;
-    if (MODE == 1 && tid == 0) flag_n = 0;
+    if (GUARDED && tid == 0) {
+        flag_n = 0;
+        audit_n = audit_bad = 0;
+    }
     if (MODE != 0) __syncthreads();  // (MODE 2: the previous item's tile has been consumed)
     if constexpr (!QIN) {
         const v4i* src = reinterpret_cast<const v4i*>(a.x + ((size_t)chunk * W + t0) * Kp);
@@ -546,8 +554,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             const int ft = lane & 3, fr = lane >> 2;
             const float* Sb = a.qx + (size_t)chunk * a.qF * W + (size_t)(t0 / 16 + wv) * a.qF * 16 + 4 * ft;
             // half-width of the band around a rounding boundary inside which the reference's byte may differ (bn_quant_in.h)
-            float dband[4] = {0.f, 0.f, 0.f, 0.f}, crel = 0.f, inv_step = 0.f;
-            if (MODE == 1) {
+            float dband[4] = {0.f, 0.f, 0.f, 0.f}, aband[4] = {0.f, 0.f, 0.f, 0.f}, crel = 0.f, inv_step = 0.f;
+            if (GUARDED) {
                 inv_step = (float)(1.0 / ((double)qi.rng * (double)qi.scale));
                 crel = kBandRel * (qi.y_rng * qi.y_scale * 1.000001f);
                 const float4 e = *reinterpret_cast<const float4*>(a.qguard.eps + (size_t)chunk * W + t0 + 16 * wv + 4 * ft);
@@ -556,11 +564,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 // kept bytes come from the folded multiply-add, whose own error (kQuantSlackFolded + the S'-proportional term) can cross a
                 // rounding boundary — those elements are listed like any other and get the exact chain (found by tools/exact_soak.py: with
                 // "nothing to list" for exact frames 304 of 245 812 whole-float64 chunks ended with different scores).
-                const float slack = kQuantSlackFolded;
+                const float slack = kQuantSlackFolded * a.qguard.slack_scale;
                 dband[0] = 0.5f - (e.x * dsc + slack);
                 dband[1] = 0.5f - (e.y * dsc + slack);
                 dband[2] = 0.5f - (e.z * dsc + slack);
                 dband[3] = 0.5f - (e.w * dsc + slack);
+                if (AUDIT) {   // the audit's band: kAuditBands times as wide
+                    const float as = a.qguard.audit_scale * dsc;
+                    aband[0] = 0.5f - kAuditBands * (e.x * as + kQuantSlackFolded);
+                    aband[1] = 0.5f - kAuditBands * (e.y * as + kQuantSlackFolded);
+                    aband[2] = 0.5f - kAuditBands * (e.z * as + kQuantSlackFolded);
+                    aband[3] = 0.5f - kAuditBands * (e.w * as + kQuantSlackFolded);
+                }
             }
             // renormalisation and the zero-point fast path are wave-uniform: picked once, outside the per-element code
             int8_t* trow[4];  // the lane's four frames of the tile, at its frequency row
@@ -581,26 +596,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                         const int f = f0 + 16 * i + fr;
                         if (f0 + 16 * i >= Kp) break;
                         const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-                        if constexpr (MODE == 1 && RN.value && FAST.value) {
+                        if constexpr (GUARDED && RN.value && FAST.value) {
                             // Guarded form: every byte that is not provably the reference's is re-evaluated from the exact S below, so the
                             // bytes kept here only have to be right OUTSIDE the band — one multiply-add by RN(1 / (range scale)) with the zero
                             // point folded in stands for the two divisions (its error, u v + 128 u, is part of the band: bn_quant_in.h), and
                             // the four tests of a load share one branch.  Rows past the last frequency get the FILL byte behind the loop.
-                            float s[4];
+                            float s[4], sa[4] = {-1.f, -1.f, -1.f, -1.f};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 const float x = __builtin_fmaf(e[k] - qi.mn, inv_step, -128.0f);
                                 const float xr = __builtin_rintf(x);  // (nearest-even instead of half-away: they differ on ties only, and a tie is in doubt)
                                 trow[k][f0 + 16 * i] = (int8_t)min(max((int)xr, -128), 127);
                                 s[k] = __builtin_fmaf(e[k], crel, fabsf(x - xr)) - dband[k];  // |x - round(x)| >= 1/2 - band: within the band of a boundary
+                                if (AUDIT) sa[k] = __builtin_fmaf(e[k], kAuditBands * crel, fabsf(x - xr)) - aband[k];
                             }
-                            if (fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])) >= 0.0f) {
+                            if (fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])) >= 0.0f || (AUDIT && fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3])) >= 0.0f)) {
                                 if (f < a.qF) {
 #pragma unroll
                                     for (int k = 0; k < 4; ++k)
-                                        if (s[k] >= 0.0f) {
+                                        if (s[k] >= 0.0f || (AUDIT && sa[k] >= 0.0f)) {
                                             const int sl = atomicAdd(&flag_n, 1);
-                                            if (sl < kMelFlagCap) flags[sl] = ((t0 + 16 * wv + 4 * ft + k) << 16) | f;
+                                            // (a near miss of the audit carries bit 31: re-evaluated and compared, never replaced)
+                                            if (sl < kMelFlagCap) flags[sl] = ((t0 + 16 * wv + 4 * ft + k) << 16) | f | (s[k] >= 0.0f ? 0 : (int)0x80000000u);
                                         }
                                 }
                             }
@@ -613,7 +630,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                             x = div_by_const(x, qi.scale, qi.y_scale);
                             const int q = FAST.value ? quantise_i8_zp128(x) : quantise_i8_any(x, a.qzp);
                             tile[(16 * wv + 4 * ft + k) * stride + f] = (int8_t)(f < a.qF ? q : a.qfill);
-                            if (MODE == 1) {
+                            if (GUARDED) {
                                 // in doubt: distance of the quantiser's argument to the next rounding boundary <= what eps(S') = eps_f + kGuardRel S' moves it
                                 const float tt = x + 0.5f;
                                 if (__builtin_fmaf(e[k], crel, fabsf(__builtin_amdgcn_fractf(tt) - 0.5f)) >= dband[k] && f < a.qF) {
@@ -627,7 +644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             };
             using T = std::true_type;
             using F = std::false_type;
-            if constexpr (MODE == 1) {
+            if constexpr (GUARDED) {
                 run(T{}, T{});  // the guarded form exists for renormalised input with zero point -128 only (bn_api.hip: guard_form_ok)
                 for (int f = fr + ((a.qF - fr + 15) & ~15); f < Kp; f += 16) {  // padded frequency rows: the graph's FILL constant (same lane, same
 #pragma unroll                                                                 // addresses as the stores above: LDS keeps a wave's order)
@@ -660,7 +677,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     BN_MSTAMP(1);
     __syncthreads();
     BN_MSTAMP(2);
-    if constexpr (MODE == 1) {
+    if constexpr (GUARDED) {
         // The elements in doubt are settled HERE, before the tile is multiplied: a 16-lane row per element re-evaluates it the reference's way
         // (float64 DFT over the frame's 512 samples, complex64, numpy's |.|: bn_exact_dft.h), the byte in the tile and the value in the
         // spectrogram are replaced.  About 11 elements per workgroup (6.5e-4 of its 16 448): one round of 16.  (As a separate kernel over
@@ -697,14 +714,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             for (int i0 = 0; i0 < nf; i0 += 16) {
                 const bool act = i0 + grp < nf;
                 const int e = act ? flags[i0 + grp] : 0;
-                const int t = e >> 16, f = e & 0xffff;
+                const bool near_miss = AUDIT && e < 0;
+                const int t = (e & 0x7fffffff) >> 16, f = e & 0xffff;
                 const float ex = exact_mag_row(xt, lw, x, a.qguard.T, a.qguard.hop, t, f);
                 if (act && gl == 0) {
-                    tile[(t - t0) * stride + f] = (int8_t)qi.q(ex);
-                    Sc[(size_t)(t / 16) * a.qF * 16 + (size_t)f * 16 + (t % 16)] = ex;  // (tile-major; keeps bn_debug_input_bytes' view consistent)
+                    if (near_miss) {   // not in doubt by the bound: the kept byte must already be the exact one
+                        atomicAdd(&audit_n, 1);
+                        if (tile[(t - t0) * stride + f] != (int8_t)qi.q(ex)) atomicAdd(&audit_bad, 1);
+                    } else {
+                        tile[(t - t0) * stride + f] = (int8_t)qi.q(ex);
+                        Sc[(size_t)(t / 16) * a.qF * 16 + (size_t)f * 16 + (t % 16)] = ex;  // (tile-major; keeps bn_debug_input_bytes' view consistent)
+                    }
                 }
             }
             __syncthreads();
+            if (AUDIT && tid == 0 && a.qguard.audit && audit_n) {
+                atomicAdd(a.qguard.audit, audit_n);
+                if (audit_bad) atomicAdd(a.qguard.audit + 1, audit_bad);
+            }
         }
     }
     BN_MSTAMP(3);
@@ -1195,7 +1222,8 @@ void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
         const unsigned nb = (unsigned)(a.B * (a.W / 64));
         const size_t lds = (size_t)64 * (a.Cin + 16);
         if (a.qx && a.qmode == 1 && a.qtiled)
-            hipLaunchKernelGGL((i8_mel_mfma_kernel<true, 1>), dim3(nb), dim3(256), lds, s, a);
+            if (a.qguard.audit) hipLaunchKernelGGL((i8_mel_mfma_kernel<true, 3>), dim3(nb), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((i8_mel_mfma_kernel<true, 1>), dim3(nb), dim3(256), lds, s, a);
         else if (a.qx && a.qmode == 2 && a.qtiled)  // dirty blocks only: a modest grid walks the work list
             hipLaunchKernelGGL((i8_mel_mfma_kernel<true, 2>), dim3(nb < 2048u ? nb : 2048u), dim3(256), lds, s, a);
         else if (a.qx)

@@ -50,6 +50,11 @@ struct Options {
     int stft_exact = 2;        // INT8 plans from audio: 2 = float32 STFT + float64 pass over the doubtful elements (bit-exact input bytes,
                                // bn_stft_exact.hip; plans / options the guarded kernels do not cover take 1), 1 = every bin as a float64
                                // DFT (same bytes, ~10 x slower), 0 = plain float32 STFT (round 2: ~3e-6 of the input bytes off by one)
+    int stft_guard = 0;        // the bound |S' - S| <= eps the exactness pass works with (bn_quant_in.h): 0 = empirical (4 x the largest error seen over 2.2e11
+                               // elements), 1 = proven (the worst case over all rounding patterns, derived in docs/exactness.md: ~25 x wider, most chunks
+                               // end on the float64 routes), 2 = TEST ONLY: the empirical constants / 1024 and no quantiser slack — too small on purpose, so that the audit has something to find
+    int stft_audit = 0;        // 1: the guarded mel mixer also re-evaluates in float64 the elements it did NOT flag but that lie within 4 bounds of a rounding
+                               // boundary (the near misses) and counts those whose kept byte is wrong — bn_debug_guard_stats out[5] audited, out[6] violations
     int stft_flagcap = 1022;   // elements in doubt a workgroup of the INT8 mel mixer re-evaluates itself before it hands the chunk over (tests lower it)
     int ingest_blk = 0;        // outputs per workgroup of the resampler (0: auto)
     int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
@@ -117,6 +122,10 @@ struct StftGuard {
     const float* audio;  // [B][T] the chunks' samples, their geometry and the float64 tables: the mel mixer re-evaluates the elements it finds
     int T, hop;          // in doubt itself (set per call by bn_infer_audio)
     StftTables tabs;
+    float k_l2, k_peak;  // the frame part of the bound: eps_f = k_l2 ||x_t||_2 + k_peak max_k S'_tk (option stft_guard picks the constants)
+    int* audit;          // [2] elements audited, violations (option stft_audit; null: no audit)
+    float audit_scale;   // the audit's band = kAuditBands x (audit_scale eps + slack): 1, or what the test mode divided the constants by
+    float slack_scale;   // 1; 0 in the test mode (stft_guard = 2), which drops the quantiser's own slack as well so that real errors escape the band
     int flag_cap;        // elements in doubt a workgroup of the mel mixer keeps (<= its LDS list; option stft_flagcap: tests lower it to reach the give-up path)
 };
 

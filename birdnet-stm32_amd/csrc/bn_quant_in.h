@@ -90,6 +90,11 @@ __device__ __forceinline__ float numpy_cabsf(float re, float im) {
 // every bin in float64 for callers who want no bound at all.
 constexpr float kGuardU = 5.9604644775390625e-8f * 1.001f;  // (0.1 % on top for the float32 evaluation of the bound itself)
 constexpr float kGuardL2 = 48.0f * kGuardU, kGuardPeak = 8.0f * kGuardU, kGuardRel = 14.0f * kGuardU;
+// The PROVEN frame term (option stft_guard = 1; docs/exactness.md "A worst-case bound" derives it from the kernel's operation sequence: window
+// 2.5 u ||x||, eight addition levels u each, three twiddle levels (2 u per complex multiply-add + the twiddle's own error: u, 43 u for the
+// powers built by square-and-multiply, u), the split pass; element <= norm): |X'_k - X_k| <= 1148 u ||x_t||_2, taken as 1200 u for the
+// second-order terms.  No peak term: the norm-wise argument already covers every element.
+constexpr float kGuardL2Proven = 1200.0f * kGuardU;
 // ends of the interval [S' - eps(S'), S' + eps(S')] given the frame's part eps_f = kGuardL2 ||x|| + kGuardPeak peak (monotone in S')
 __device__ __forceinline__ float guard_hi(float s, float eps_f) { return __builtin_fmaf(s, kGuardRel, s) + eps_f; }
 __device__ __forceinline__ float guard_lo(float s, float eps_f) { return __builtin_fmaf(-s, kGuardRel, s) - eps_f; }

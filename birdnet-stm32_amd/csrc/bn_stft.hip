@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
         if constexpr (GUARD) {
             // the frame's bound on |S' - S| (bn_quant_in.h): eps(S') = eps_f + kGuardRel S' with eps_f = kGuardL2 ||x||_2 + kGuardPeak max_k S'
             const float peak = row16_max(tmax), low = row16_min(tmin);
-            const float eps_f = __builtin_amdgcn_sqrtf(frame_ss) * kGuardL2 + peak * kGuardPeak;
+            const float eps_f = __builtin_amdgcn_sqrtf(frame_ss) * guard.k_l2 + peak * guard.k_peak;
             if (j == 0) {
                 g_red[0][f] = live ? guard_lo(peak, eps_f) : 0.0f;
                 g_red[1][f] = live ? guard_hi(low, eps_f) : __uint_as_float(0x7f800000u);

@@ -399,13 +399,19 @@ __global__ void spec_bytes_kernel(const float* __restrict__ spec, const float* _
 
 // workgroups of the list kernel: exactly what the device keeps resident (registers and LDS allow two or three per CU) — the kernel strides over
 // its work list by gridDim.x, so a grid that needs a second scheduling round would leave the first round's workgroups idle for half the time
+// (cached per DEVICE under a mutex, like ensure_dynamic_lds: a process may drive several devices, from several threads)
 static int list_grid() {
-    static int grid = 0;
+    static std::mutex mu;
+    static std::map<int, int> grids;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    int& grid = grids[dev];
     if (!grid) {
-        int per_cu = 0, dev = 0;
+        int per_cu = 0;
         hipDeviceProp_t prop;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stft512_f64_list_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        if (dev < 0 || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         grid = per_cu * prop.multiProcessorCount;
     }
     return grid;

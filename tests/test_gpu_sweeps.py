@@ -477,6 +477,42 @@ def test_i8_fused_stage2_chain_matches_the_strip_kernels_and_oracle(torch_mod):
     runner.close()
 
 
+def test_exactness_guard_modes_and_audit(torch_mod):
+    """The bound behind "bit-exact from audio" as a switch (option stft_guard) with an audit (option stft_audit):
+    * empirical (default) and proven (worst case, docs/exactness.md) bounds give the bytes of the all-float64 STFT (stft_exact = 1) and its scores;
+      the proven bound puts many more elements in doubt;
+    * the audit re-evaluates the near misses — elements NOT in doubt but within four bounds of a rounding boundary — and finds none wrong
+      under either bound;
+    * a bound that is far too small on purpose (stft_guard = 2: the empirical constants / 1024, no quantiser slack) leaves wrong bytes behind, and the audit SEES them."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models.runners import load_model_runner
+
+    B = 96
+    runner = load_model_runner(TFLITE_PATH, max_batch=B)
+    audio = torch.from_numpy(synth_chunks(B, seed=17)).cuda()
+    with _hip.options(stft_exact=1):
+        want = runner.infer_audio_device(audio).clone()
+        want_bytes = runner.input_bytes(B)
+    stats = {}
+    for mode in (0, 1):
+        with _hip.options(stft_guard=mode, stft_audit=1):
+            got = runner.infer_audio_device(audio).clone()
+            stats[mode] = runner.guard_stats(B)
+            assert torch.equal(got, want), f"stft_guard = {mode}"
+            assert np.array_equal(runner.input_bytes(B), want_bytes), f"stft_guard = {mode}"
+            assert stats[mode]["audited"] > 0 and stats[mode]["audit_violations"] == 0, stats[mode]
+        with _hip.options(stft_guard=mode):   # without the audit: the same scores, nothing audited
+            assert torch.equal(runner.infer_audio_device(audio), want)
+            assert runner.guard_stats(B)["audited"] == 0
+    assert stats[1]["listed"] + B * stats[1]["whole_minmax"] > 4 * stats[0]["listed"], stats   # the proven bound doubts far more (or hands whole chunks over)
+    with _hip.options(stft_guard=2, stft_audit=1):
+        runner.infer_audio_device(audio)
+        small = runner.guard_stats(B)
+    assert small["audit_violations"] > 0, f"a bound 1024 x too small must leave wrong bytes among its near misses: {small}"
+    runner.close()
+
+
 def test_two_models_in_one_process_run_under_their_own_options(torch_mod):
     """Launcher switches are per context (bn_ctx_set_option) on top of the process default (bn_set_option): two runners of the same model in one
     process, one with the fused kernels switched off for ITS context, give the same scores through different kernels, interleaved; the
