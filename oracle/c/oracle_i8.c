@@ -292,3 +292,148 @@ void oi_fc(const int8_t* x, int8_t* y, int B, int Cin, int Cout, const int8_t* w
             y[(size_t)b * Cout + n] = (int8_t)clampi(mbqm(acc, mult[n], shift[n]) + zp_out, amin, amax);
         }
 }
+
+/* ---- the whole graph per chunk (CPU baseline: no interpreter between the operators) -------------------------------------------------------
+ * oracle/cport.py: CpuInt8Program traces the numpy interpreter ONCE (batch 1) and writes the graph down as a flat program: one record per
+ * operator with its shapes, quantisation parameters and constants; every pure data-movement operator (TRANSPOSE, STRIDED_SLICE,
+ * CONCATENATION with a constant, RESHAPE) as ONE gather map.  oi_program_run walks the program for every chunk, the chunks dealt to the
+ * OpenMP threads (a thread's activations — ~1.5 MB for the shipped graph — stay in its cache), the kernels above called with batch 1
+ * (their own parallel regions collapse to the calling thread inside this one).  1x1 convolutions take weights re-packed ONCE
+ * (oi_pack_1x1).  Same integers as the interpreter: tests/test_oracle_pinning.py compares every output and, through the records' tensor
+ * ids, every intermediate tensor. */
+enum { OI_QUANT = 1, OI_GATHER = 2, OI_CONV = 3, OI_DWCONV = 4, OI_ADD = 5, OI_MEAN = 6, OI_FC = 7, OI_LUT = 8, OI_DEQUANT = 9 };
+typedef struct {
+    int32_t kind, in0, in1, out;
+    int64_t n;           /* elements of the output */
+    int32_t p[24];
+    float f[4];
+    const void* ptr[6];
+} oi_op;
+
+#if OI_VEC
+/* weights [Cout][Cin] -> [K/4][N/16][16][4] + (bias - (128 + zp_in) sum w, mult, shift) per padded channel; returns bytes written to wp / cst */
+void oi_pack_1x1(const int8_t* w, const int32_t* bias, const int32_t* mult, const int32_t* shift, int Cin, int Cout, int zp_in, int8_t* wp, int32_t* cst) {
+    const int K4 = (Cin + 3) / 4, N16 = (Cout + 15) / 16;
+    memset(wp, 0, (size_t)K4 * N16 * 64);
+    for (int n = 0; n < N16 * 16; ++n) {
+        int32_t ws = 0;
+        if (n < Cout)
+            for (int c = 0; c < Cin; ++c) {
+                wp[((size_t)(c / 4) * N16 + n / 16) * 64 + (n % 16) * 4 + c % 4] = w[(size_t)n * Cin + c];
+                ws += w[(size_t)n * Cin + c];
+            }
+        cst[n] = n < Cout ? (bias ? bias[n] : 0) - (128 + zp_in) * ws : 0;
+        cst[N16 * 16 + n] = n < Cout ? mult[n] : 0;
+        cst[2 * N16 * 16 + n] = n < Cout ? shift[n] : 0;
+    }
+}
+static void conv1x1_packed(const int8_t* x, int8_t* y, long P, int Cin, int Cout, const int8_t* wp, const int32_t* cst, int zp_out, int amin, int amax) {
+    const int K4 = (Cin + 3) / 4, N16 = (Cout + 15) / 16;
+    for (long p = 0; p < P; ++p) {
+        uint32_t xu[K4];
+        uint8_t tmp[4 * K4];
+        memset(tmp, 0, sizeof tmp);
+        memcpy(tmp, x + p * Cin, Cin);
+        memcpy(xu, tmp, sizeof tmp);
+        for (int k = 0; k < K4; ++k) xu[k] ^= 0x80808080u;
+        for (int nb = 0; nb < N16; ++nb) {
+            __m512i acc = _mm512_load_si512(cst + 16 * nb);
+            for (int k = 0; k < K4; ++k)
+                acc = _mm512_dpbusd_epi32(acc, _mm512_set1_epi32((int)xu[k]), _mm512_load_si512(wp + ((size_t)k * N16 + nb) * 64));
+            store16_i8(y + p * Cout + 16 * nb, mbqm16(acc, _mm512_load_si512(cst + N16 * 16 + 16 * nb), _mm512_load_si512(cst + 2 * N16 * 16 + 16 * nb)),
+                       zp_out, amin, amax, live16(16 * nb, Cout));
+        }
+    }
+}
+#else
+void oi_pack_1x1(const int8_t* w, const int32_t* bias, const int32_t* mult, const int32_t* shift, int Cin, int Cout, int zp_in, int8_t* wp, int32_t* cst) {
+    (void)w; (void)bias; (void)mult; (void)shift; (void)Cin; (void)Cout; (void)zp_in; (void)wp; (void)cst;   /* (the portable build convolves from the plain weights) */
+}
+#endif
+
+static void run_one(const oi_op* ops, int n_ops, const float* xin, float* yout, int8_t* arena, const int64_t* off) {
+    for (int i = 0; i < n_ops; ++i) {
+        const oi_op* o = &ops[i];
+        const int32_t* p = o->p;
+        int8_t* y = arena + off[o->out];
+        const int8_t* a = o->in0 >= 0 ? arena + off[o->in0] : NULL;
+        switch (o->kind) {
+            case OI_QUANT: {   /* q = clamp(round_half_away(x / s) + zp): float32 division, like the interpreter */
+                const float s = o->f[0];
+                for (int64_t k = 0; k < o->n; ++k) {
+                    const float v = xin[k] / s;
+                    float r = (float)(int64_t)v;                                   /* trunc; |v - trunc| >= 0.5 -> one step away from zero (C round()) */
+                    const float d = v - r;
+                    if (d >= 0.5f) r += 1.0f; else if (d <= -0.5f) r -= 1.0f;
+                    int64_t q = (int64_t)r + p[0];
+                    y[k] = (int8_t)(q < -128 ? -128 : (q > 127 ? 127 : q));
+                }
+                break;
+            }
+            case OI_GATHER: {  /* out[k] = idx[k] >= 0 ? in[idx[k]] : fill[k] */
+                const int32_t* idx = (const int32_t*)o->ptr[0];
+                const int8_t* fill = (const int8_t*)o->ptr[1];
+                for (int64_t k = 0; k < o->n; ++k) y[k] = idx[k] >= 0 ? a[idx[k]] : fill[k];
+                break;
+            }
+            case OI_CONV:  /* p: H W Cin kh kw Cout sh sw OH OW pt pl zp_in zp_out amin amax packed */
+#if OI_VEC
+                if (p[16]) {
+                    conv1x1_packed(a, y, (long)p[0] * p[1], p[2], p[5], (const int8_t*)o->ptr[4], (const int32_t*)o->ptr[5], p[13], p[14], p[15]);
+                    break;
+                }
+#endif
+                oi_conv(a, y, 1, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], (const int8_t*)o->ptr[0], (const int32_t*)o->ptr[1], p[12], p[13],
+                        (const int32_t*)o->ptr[2], (const int32_t*)o->ptr[3], p[14], p[15]);
+                break;
+            case OI_DWCONV:  /* p: H W C kh kw - sh sw OH OW pt pl zp_in zp_out amin amax */
+                oi_dwconv(a, y, 1, p[0], p[1], p[2], p[3], p[4], p[6], p[7], p[8], p[9], p[10], p[11], (const int8_t*)o->ptr[0], (const int32_t*)o->ptr[1], p[12], p[13],
+                          (const int32_t*)o->ptr[2], (const int32_t*)o->ptr[3], p[14], p[15]);
+                break;
+            case OI_ADD: {   /* p: nb z1 m1 s1 z2 m2 s2 mo so zo amin amax const_b */
+                const int8_t* b = p[12] ? (const int8_t*)o->ptr[0] : arena + off[o->in1];
+                oi_add(a, b, y, (long)o->n, (long)p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11]);
+                break;
+            }
+            case OI_MEAN:  /* p: P C zp_in mult shift zp_out */
+                oi_mean(a, y, 1, p[0], p[1], p[2], p[3], p[4], p[5]);
+                break;
+            case OI_FC:    /* p: Cin Cout zp_in zp_out amin amax */
+                oi_fc(a, y, 1, p[0], p[1], (const int8_t*)o->ptr[0], (const int32_t*)o->ptr[1], p[2], p[3], (const int32_t*)o->ptr[2], (const int32_t*)o->ptr[3], p[4], p[5]);
+                break;
+            case OI_LUT: {
+                const int8_t* lut = (const int8_t*)o->ptr[0];
+                for (int64_t k = 0; k < o->n; ++k) y[k] = lut[(int)a[k] + 128];
+                break;
+            }
+            case OI_DEQUANT:
+                for (int64_t k = 0; k < o->n; ++k) yout[k] = (float)((int32_t)a[k] - p[0]) * o->f[0];
+                break;
+            default: break;
+        }
+    }
+}
+
+/* x [B][in_elems] float32 -> out [B][out_elems] float32; off[t] = byte offset of tensor t in a thread's arena of arena_bytes.
+ * keep (or NULL): [B][arena_bytes] — every chunk's arena copied out (the per-tensor comparison of the tests). */
+int oi_program_run(const oi_op* ops, int n_ops, const float* x, int B, int64_t in_elems, float* out, int64_t out_elems, const int64_t* off,
+                   int64_t arena_bytes, int8_t* keep) {
+    int failed = 0;
+#pragma omp parallel
+    {
+        int8_t* arena = (int8_t*)aligned_alloc(64, (size_t)((arena_bytes + 63) & ~63LL));
+        if (!arena) {
+#pragma omp atomic write
+            failed = 1;
+        }
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b) {
+            if (!arena) continue;
+            run_one(ops, n_ops, x + (size_t)b * in_elems, out + (size_t)b * out_elems, arena, off);
+            if (keep) memcpy(keep + (size_t)b * arena_bytes, arena, (size_t)arena_bytes);
+        }
+        free(arena);
+    }
+    return failed ? -1 : 0;
+}
+int oi_op_bytes(void) { return (int)sizeof(oi_op); }

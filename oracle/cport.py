@@ -300,3 +300,259 @@ class FirmwareRef:
         out = np.empty((n_mels, 257), np.float32)
         self.lib.mel_filterbank(_p(eye), ctypes.c_uint32(257), ctypes.c_uint32(257), ctypes.c_uint32(n_mels), _p(out))
         return out
+
+
+class CpuInt8Program:
+    """The INT8 graph as a flat per-chunk program run entirely inside ``oracle_i8.c`` (``oi_program_run``): the CPU baseline without an
+    interpreter between the operators.  ORACLE — test infrastructure and ``bench.py``'s ``cpu_baseline`` leg only.
+
+    Built by tracing ``CpuInt8Path``'s interpreter ONCE on a batch of one: every operator becomes a record (shapes, quantisation parameters,
+    constants prepared by the interpreter's own code, so there is one definition of the arithmetic); TRANSPOSE / STRIDED_SLICE / RESHAPE /
+    CONCATENATION with constants — pure data movement — become gather maps (found by pushing element indices through the numpy operator);
+    SHAPE / PACK / FILL fold into constants.  ``invoke`` then deals the chunks to the OpenMP threads, each walking the whole program on its own
+    activations.  Graphs with operators outside this set (squeeze-excite MUL, SOFTMAX heads, ...) raise ``NotImplementedError``: callers keep
+    ``CpuInt8Path`` for those."""
+
+    class _Op(ctypes.Structure):
+        _fields_ = [("kind", ctypes.c_int32), ("in0", ctypes.c_int32), ("in1", ctypes.c_int32), ("out", ctypes.c_int32), ("n", ctypes.c_int64),
+                    ("p", ctypes.c_int32 * 24), ("f", ctypes.c_float * 4), ("ptr", ctypes.c_void_p * 6)]
+
+    QUANT, GATHER, CONV, DWCONV, ADD, MEAN, FC, LUT, DEQUANT = range(1, 10)
+
+    def __init__(self, model, native: bool = False):
+        from oracle import int8_graph as ig
+
+        self.path = CpuInt8Path(model, native=native)
+        self.lib = self.path.lib
+        self.threads, self.vectorised = self.path.threads, self.path.vectorised
+        assert self.lib.oi_op_bytes() == ctypes.sizeof(self._Op), "oi_op layout"
+        interp = self.path.interp
+        m = model
+        in_shape = [1] + [int(v) for v in m.tensors[m.inputs[0]].shape[1:]]
+        x0 = np.random.default_rng(0).random(in_shape, dtype=np.float32)
+        _, env = interp.invoke(x0, return_all=True)
+        self._keep: list = []       # arrays the records point into
+        self.in_elems = int(np.prod(in_shape[1:]))
+        ops, off, pos = [], {}, 0
+        const_val: dict[int, np.ndarray] = {}   # tensors whose value does not depend on the input (folded)
+        src_map: dict[int, tuple[int, np.ndarray, np.ndarray]] = {}  # movement results not yet materialised: tensor -> (source tensor, idx, fill)
+
+        def place(t, nbytes):
+            nonlocal pos
+            off[t] = pos
+            pos += (int(nbytes) + 63) & ~63
+
+        def is_const(t):
+            return t in const_val or m.tensors[t].data is not None
+
+        def value(t):
+            return const_val[t] if t in const_val else m.tensors[t].data
+
+        def materialise(t):
+            """Make sure tensor t exists in the arena (emit the pending gather)."""
+            if t in src_map:
+                s, idx, fill = src_map.pop(t)
+                materialise(s)
+                idx = np.ascontiguousarray(idx.reshape(-1), np.int32)
+                fill = np.ascontiguousarray(fill.reshape(-1), np.int8)
+                self._keep += [idx, fill]
+                place(t, idx.size)
+                ops.append(self._rec(self.GATHER, s, -1, t, idx.size, ptr=[idx, fill]))
+            elif t not in off:
+                raise NotImplementedError(f"tensor {t} has no producer in the program")
+
+        def movement(op, fn):
+            """out = fn(inputs) is pure data movement: compose the index map of every dynamic input, constants become fill bytes."""
+            dyn = [t for t in op.inputs if not is_const(t) and np.asarray(env.get(t, 0)).dtype == np.int8]
+            if len(set(dyn)) != 1:
+                raise NotImplementedError(f"{op.name} with {len(set(dyn))} dynamic inputs")
+            d = dyn[0]
+            base_idx = src_map[d][1] if d in src_map else np.arange(int(np.prod(env[d].shape)), dtype=np.int64).reshape(env[d].shape)
+            base_fill = src_map[d][2] if d in src_map else np.zeros(env[d].shape, np.int8)
+            root = src_map[d][0] if d in src_map else d
+            args_i, args_f = [], []
+            for t in op.inputs:
+                if t == d:
+                    args_i.append(base_idx.reshape(env[d].shape))
+                    args_f.append(base_fill.reshape(env[d].shape))
+                elif is_const(t) and np.asarray(value(t)).dtype == np.int8 and np.asarray(env.get(t, value(t))).shape == np.asarray(value(t)).shape:
+                    args_i.append(np.full(np.asarray(value(t)).shape, -1, np.int64))
+                    args_f.append(np.asarray(value(t), np.int8))
+                else:
+                    args_i.append(None)
+                    args_f.append(None)
+            src_map[op.outputs[0]] = (root, fn(args_i), fn(args_f))
+
+        for op in m.ops:
+            n, o0 = op.name, op.outputs[0]
+            y = env[o0]
+            if all(is_const(t) for t in op.inputs) and n not in ("QUANTIZE",):
+                const_val[o0] = np.asarray(y)   # SHAPE / PACK / FILL and anything computed from constants only (batch 1: shapes are constants)
+                continue
+            if n == "SHAPE":
+                const_val[o0] = np.asarray(y)
+                continue
+            if n == "QUANTIZE":
+                s, zp = interp._q(o0)
+                place(o0, y.size)
+                ops.append(self._rec(self.QUANT, -1, -1, o0, y.size, p=[zp], f=[np.float32(s)]))
+            elif n == "DEQUANTIZE":
+                s, zp = interp._q(op.inputs[0])
+                materialise(op.inputs[0])
+                ops.append(self._rec(self.DEQUANT, op.inputs[0], -1, op.inputs[0], y.size, p=[zp], f=[np.float32(s)]))
+                self.out_elems = int(y.size)
+            elif n == "TRANSPOSE":
+                perm = [int(v) for v in value(op.inputs[1])]
+                movement(op, lambda a, perm=perm: np.transpose(a[0], perm))
+            elif n == "RESHAPE":
+                movement(op, lambda a, shp=y.shape: a[0].reshape(shp))
+            elif n == "STRIDED_SLICE":
+                class _E(dict):
+                    pass
+                def ss(a, op=op):
+                    e = {op.inputs[0]: a[0]}
+                    for t in op.inputs[1:]:
+                        e[t] = value(t)
+                    return interp._strided_slice(op, e)
+                movement(op, ss)
+            elif n == "CONCATENATION":
+                movement(op, lambda a, ax=op.options["axis"]: np.concatenate(a, axis=ax))
+            elif n in ("CONV_2D", "DEPTHWISE_CONV_2D"):
+                materialise(op.inputs[0])
+                dw = n == "DEPTHWISE_CONV_2D"
+                x = env[op.inputs[0]]
+                wt = m.tensors[op.inputs[1]]
+                w = np.ascontiguousarray(wt.data, np.int8)
+                bias = np.ascontiguousarray(m.tensors[op.inputs[2]].data, np.int32) if len(op.inputs) > 2 and op.inputs[2] >= 0 else None
+                s_in, zp_in = interp._q(op.inputs[0])
+                s_out, zp_out = interp._q(o0)
+                o = op.options
+                sh, sw = o["stride_h"], o["stride_w"]
+                _, H, W, Cin = x.shape
+                if dw:
+                    _, kh, kw, cout = w.shape
+                else:
+                    cout, kh, kw, _ = w.shape
+                pr = interp._prep[op.index]
+                oh, pt, _ = ig._same(H, kh, sh)
+                ow, pl, _ = ig._same(W, kw, sw)
+                lo, hi = (int(v) for v in pr["act"])
+                ptrs = [w, bias, pr["mult"], pr["shift"]]
+                packed = 0
+                if not dw and self.vectorised and (kh, kw, sh, sw, pt, pl) == (1, 1, 1, 1, 0, 0):
+                    K4, N16 = (Cin + 3) // 4, (cout + 15) // 16
+                    wp = _aligned(K4 * N16 * 64, np.int8)
+                    cst = _aligned(N16 * 16 * 3, np.int32)
+                    self.lib.oi_pack_1x1(_i8(w), _i32(bias), _i32(pr["mult"]), _i32(pr["shift"]), Cin, cout, zp_in, _i8(wp), _i32(cst))
+                    ptrs += [wp, cst]
+                    packed = 1
+                self._keep += [a for a in ptrs if a is not None]
+                place(o0, y.size)
+                ops.append(self._rec(self.DWCONV if dw else self.CONV, op.inputs[0], -1, o0, y.size,
+                                     p=[H, W, Cin, kh, kw, cout, sh, sw, oh, ow, pt, pl, zp_in, zp_out, lo, hi, packed], ptr=ptrs))
+            elif n == "ADD":
+                a_t, b_t = op.inputs
+                if is_const(a_t):
+                    raise NotImplementedError("ADD with a constant first operand")
+                materialise(a_t)
+                bconst = is_const(b_t)
+                if not bconst:
+                    materialise(b_t)
+                a, b = env[a_t], (np.asarray(value(b_t)) if bconst else env[b_t])
+                if b.shape != a.shape and (a.size % b.size or tuple(a.shape[a.ndim - b.ndim:]) != tuple(b.shape)):
+                    raise NotImplementedError("ADD broadcast that is not a trailing-axes period")
+                pr = interp._prep[op.index]
+                _, z1 = interp._q(a_t)
+                _, z2 = interp._q(b_t)
+                _, zo = interp._q(o0)
+                lo, hi = (int(v) for v in pr["act"])
+                bc = np.ascontiguousarray(b, np.int8) if bconst else None
+                if bc is not None:
+                    self._keep.append(bc)
+                place(o0, y.size)
+                ops.append(self._rec(self.ADD, a_t, -1 if bconst else b_t, o0, y.size,
+                                     p=[b.size, z1, int(pr["m1"][0]), int(pr["m1"][1]), z2, int(pr["m2"][0]), int(pr["m2"][1]), int(pr["mo"][0]), int(pr["mo"][1]), zo, lo, hi,
+                                        int(bconst)], ptr=[bc]))
+            elif n == "MEAN":
+                x = env[op.inputs[0]]
+                axes = sorted(int(a) % x.ndim for a in np.atleast_1d(value(op.inputs[1])))
+                if x.ndim != 4 or axes != [1, 2] or interp.mean_form != "int":
+                    raise NotImplementedError("MEAN other than the integer form over H, W")
+                materialise(op.inputs[0])
+                s_in, zp_in = interp._q(op.inputs[0])
+                s_out, zp_out = interp._q(o0)
+                npos = x.shape[1] * x.shape[2]
+                mult, shift = ig.quantize_multiplier(float(np.float32(s_in)) / float(np.float32(s_out)))
+                fold = min(npos.bit_length() - 1, 32, 31 + shift)
+                place(o0, y.size)
+                ops.append(self._rec(self.MEAN, op.inputs[0], -1, o0, y.size, p=[npos, x.shape[3], zp_in, int((mult << fold) // npos), shift - fold, zp_out]))
+            elif n == "FULLY_CONNECTED":
+                materialise(op.inputs[0])
+                wt = m.tensors[op.inputs[1]]
+                w = np.ascontiguousarray(wt.data, np.int8)
+                bias = np.ascontiguousarray(m.tensors[op.inputs[2]].data, np.int32) if len(op.inputs) > 2 and op.inputs[2] >= 0 else None
+                _, zp_in = interp._q(op.inputs[0])
+                _, zp_out = interp._q(o0)
+                pr = interp._prep[op.index]
+                lo, hi = (int(v) for v in pr["act"])
+                self._keep += [a for a in (w, bias, pr["mult"], pr["shift"]) if a is not None]
+                place(o0, y.size)
+                ops.append(self._rec(self.FC, op.inputs[0], -1, o0, y.size, p=[w.shape[1], w.shape[0], zp_in, zp_out, lo, hi], ptr=[w, bias, pr["mult"], pr["shift"]]))
+            elif n == "LOGISTIC":
+                if interp.logistic_form != "lut":
+                    raise NotImplementedError("fixed-point LOGISTIC")
+                materialise(op.inputs[0])
+                lut = np.ascontiguousarray(interp.logistic_lut(op), np.int8)
+                self._keep.append(lut)
+                place(o0, y.size)
+                ops.append(self._rec(self.LUT, op.inputs[0], -1, o0, y.size, ptr=[lut]))
+            else:
+                raise NotImplementedError(f"operator {n} is not part of the C program (use CpuInt8Path)")
+        if not hasattr(self, "out_elems"):
+            raise NotImplementedError("the graph does not end in DEQUANTIZE")
+        self.tensor_off = off
+        self.arena_bytes = pos
+        n_t = max(off) + 1
+        self._off = np.full(n_t, -1, np.int64)
+        for t, v in off.items():
+            self._off[t] = v
+        self._ops = (self._Op * len(ops))(*ops)
+        self.n_ops = len(ops)
+        self.lib.oi_program_run.restype = ctypes.c_int
+        self.shapes = {t: env[t].shape[1:] for t in off}
+
+    def _rec(self, kind, in0, in1, out, n, p=(), f=(), ptr=()):
+        r = self._Op()
+        r.kind, r.in0, r.in1, r.out, r.n = kind, in0, in1, out, int(n)
+        for i, v in enumerate(p):
+            r.p[i] = int(v)
+        for i, v in enumerate(f):
+            r.f[i] = float(v)
+        for i, a in enumerate(ptr):
+            r.ptr[i] = None if a is None else a.ctypes.data
+        return r
+
+    def invoke(self, x: np.ndarray, return_all: bool = False):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, self.in_elems)
+        B = x.shape[0]
+        out = np.empty((B, self.out_elems), np.float32)
+        keep = np.empty((B, self.arena_bytes), np.int8) if return_all else None
+        rc = self.lib.oi_program_run(self._ops, self.n_ops, _p(x), B, ctypes.c_int64(self.in_elems), _p(out), ctypes.c_int64(self.out_elems),
+                                     self._off.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(self.arena_bytes), _i8(keep) if keep is not None else None)
+        if rc != 0:
+            raise MemoryError("oi_program_run could not allocate a thread's arena")
+        if not return_all:
+            return out
+        env = {t: keep[:, o:o + int(np.prod(self.shapes[t]))].reshape((B,) + tuple(self.shapes[t])) for t, o in self.tensor_off.items()}
+        return out, env
+
+    def spectrogram(self, audio, hop, width):
+        return self.path.spectrogram(audio, hop, width)
+
+
+def _aligned(n: int, dtype):
+    """Zeroed array of n elements whose data is 64-byte aligned (vector loads of the packed weights)."""
+    item = np.dtype(dtype).itemsize
+    raw = np.zeros(n * item + 64, np.uint8)
+    o = (-raw.ctypes.data) % 64
+    return raw[o:o + n * item].view(dtype)

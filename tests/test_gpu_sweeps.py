@@ -102,7 +102,7 @@ def _c_int8_path():
 
     if not (os.path.isfile(cport.I8_LIB) and os.path.isfile(cport.CPU_LIB)):
         pytest.fail("oracle/_build is missing: run __graft_entry__.build() (the checker of this test is the C port of the oracle)")
-    return cport.CpuInt8Path(load_tflite(TFLITE_PATH))
+    return cport.CpuInt8Program(load_tflite(TFLITE_PATH))   # (the whole graph per chunk in C: pinned to the numpy interpreter by tests/test_oracle_pinning.py)
 
 
 def test_i8_runner_boundary_4096_spectrograms_bit_exact(torch_mod):

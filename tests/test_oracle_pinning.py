@@ -361,6 +361,16 @@ def test_c_int8_port_is_identical_to_the_numpy_interpreter(native):
     for k, v in env.items():
         assert np.array_equal(np.asarray(v), np.asarray(env_c[k])), f"tensor {k} differs"
     assert np.abs(port.spectrogram(x, 281, 256) - S).max() < 1e-6  # the C STFT of the float port
+    # the same graph as ONE C program per chunk (oi_program_run: bench.py's cpu_baseline since round 5): every materialised tensor and the
+    # scores, bit for bit, on tone + noise chunks and on random spectrograms, for a batch that gives every thread several chunks
+    prog = cport.CpuInt8Program(model, native=native)
+    S2 = np.concatenate([S, np.random.default_rng(5).random((29, 257, 256, 1), dtype=np.float32)])
+    ref2, env2 = Int8Interpreter(model).invoke(S2, return_all=True)
+    got2, env_p = prog.invoke(S2, return_all=True)
+    assert np.array_equal(got2, ref2) and len(env_p) >= 40
+    for k, v in env_p.items():
+        assert np.array_equal(v, np.asarray(env2[k]).reshape(v.shape)), f"tensor {k} differs in the C program"
+    assert np.array_equal(prog.invoke(S2[:1]), ref2[:1])
 
 
 def test_int8_primitives_match_gemmlowp_definitions_on_edge_cases():
