@@ -163,6 +163,9 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
     if not todo:
         return
     pipe = EvaluatePipeline(runner, sr, cd, overlap, max_duration=60, **(pipeline_options or {}))
+    # The ranking metrics behind the scores run two sorts on the GPU (evaluation/_ranking.py); their first launch in a process loads the sort
+    # kernels (0.17 s of BENCH_r04's cold metrics_s).  Done here, on a helper thread and its own stream, while the pipeline is busy reading files.
+    _warm_ranking_kernels(runner.device, runner.num_classes)
     from birdnet_stm32.evaluation import sharding as _sh
 
     if world_info()[1] > 1 or not _sh._local_only(world_info()[1]):  # (the second clause: the collective path forced at world size 1, tests)
@@ -191,6 +194,32 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
     for path, c, row in zip(todo, counts, pooled):
         if c:
             yield path, c, row, lat
+
+
+_ranking_warm: set = set()
+
+
+def _warm_ranking_kernels(device, n_classes: int) -> None:
+    """Load the GPU sort kernels ``ranking_metrics`` will use (once per process and device), off the caller's thread and stream."""
+    import threading
+
+    key = str(device)
+    if key in _ranking_warm:
+        return
+    _ranking_warm.add(key)
+
+    def warm():
+        try:
+            import torch
+
+            from birdnet_stm32.evaluation._ranking import descending_orders
+
+            with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
+                descending_orders(np.linspace(0.0, 1.0, 64 * n_classes, dtype=np.float32).reshape(64, n_classes), device)
+        except Exception:  # pragma: no cover - a warm-up must never fail the evaluation
+            pass
+
+    threading.Thread(target=warm, name="bn-warm-ranking", daemon=True).start()
 
 
 def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pooling: str = "average", batch_size: int = 64,
