@@ -376,7 +376,16 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
         # the whole graph per chunk inside the C port (oi_program_run: the chunks dealt to the OpenMP threads, every thread's activations in its
         # cache, 1x1 weights packed once) — no numpy graph walk between the operators (round 4: 0.8 k chunks/s on 128 threads under the walk)
         path = cport.CpuInt8Program(load_tflite(ckpt + ".tflite"), native=native)
-        out = timed(lambda x: path.invoke(path.spectrogram(x, HOP, W)), path.threads,
+        sbuf = {}
+
+        def run_i8(x):   # (the 270 MB spectrogram buffer of a 1024-chunk call is allocated once, not per call)
+            key = x.shape[0]
+            if key not in sbuf:
+                sbuf.clear()
+                sbuf[key] = np.empty((key, 257, W, 1), np.float32)
+            return path.invoke(path.spectrogram(x, HOP, W, out=sbuf[key]))
+
+        out = timed(run_i8, path.threads,
                     "C + OpenMP port of the TFLite int8 reference kernels, whole graph per chunk in C (oracle/c/oracle_i8.c: oi_program_run"
                     + (", -march=native" + (", AVX-512 VNNI paths" if path.vectorised else "") if native else "") + ") + C STFT")
         out["host"] = host_peaks()

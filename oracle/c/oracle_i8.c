@@ -421,7 +421,16 @@ int oi_program_run(const oi_op* ops, int n_ops, const float* x, int B, int64_t i
     int failed = 0;
 #pragma omp parallel
     {
-        int8_t* arena = (int8_t*)aligned_alloc(64, (size_t)((arena_bytes + 63) & ~63LL));
+        /* a thread's arena lives as long as the thread (OpenMP keeps its pool between calls): a fresh 1.2 MB allocation per call is 300 page
+         * faults per thread under one address-space lock — with 128 threads that, not the arithmetic, set the rate */
+        static _Thread_local int8_t* arena = NULL;
+        static _Thread_local int64_t arena_cap = 0;
+        if (arena_cap < arena_bytes) {
+            free(arena);
+            arena = (int8_t*)aligned_alloc(64, (size_t)((arena_bytes + 63) & ~63LL));
+            arena_cap = arena ? arena_bytes : 0;
+            if (arena) memset(arena, 0, (size_t)arena_bytes);
+        }
         if (!arena) {
 #pragma omp atomic write
             failed = 1;
@@ -432,7 +441,6 @@ int oi_program_run(const oi_op* ops, int n_ops, const float* x, int B, int64_t i
             run_one(ops, n_ops, x + (size_t)b * in_elems, out + (size_t)b * out_elems, arena, off);
             if (keep) memcpy(keep + (size_t)b * arena_bytes, arena, (size_t)arena_bytes);
         }
-        free(arena);
     }
     return failed ? -1 : 0;
 }
