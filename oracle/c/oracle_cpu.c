@@ -29,6 +29,14 @@ int oc_max_threads(void) {
     return 1;
 #endif
 }
+/* threads of the following parallel regions (oracle/cport.py sets the process's CPU SHARE — affinity mask and cgroup quota — not the host's CPU count) */
+void oc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* in-place radix-2 DIT complex FFT, double precision, n = 512 */
 static void fft512(double* re, double* im, const double* cs, const double* sn, const int* rev) {

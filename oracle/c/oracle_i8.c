@@ -37,6 +37,14 @@ int oi_max_threads(void) {
     return 1;
 #endif
 }
+/* threads of the following parallel regions (oracle/cport.py sets the process's CPU SHARE — affinity mask and cgroup quota — not the host's CPU count) */
+void oi_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 static inline int32_t srdhm(int32_t a, int32_t b) {
     if (a == b && a == INT32_MIN) return INT32_MAX;

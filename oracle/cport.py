@@ -18,6 +18,30 @@ I8_LIB = os.path.join(_HERE, "_build", "liboracle_i8.so")
 NATIVE_DIR = os.path.join(_HERE, "_build", "native")  # `make -C oracle native`: the same sources built -march=native on the host they are timed on
 
 
+def cpu_share() -> int:
+    """CPUs this process may actually use at once: its affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host with a
+    quota of 16 CPUs runs 256 OpenMP threads sixteen times slower than sixteen)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, -(-q // per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def build_native() -> bool:
     """Build the -march=native variants of the two C ports on THIS host (bench.py's cpu_baseline leg; seconds).  False if gcc / make fail."""
     import subprocess
@@ -42,6 +66,7 @@ class CpuFloatPath:
     def __init__(self, spec, native: bool = False):
         self.lib = ctypes.CDLL(os.path.join(NATIVE_DIR, "liboracle_cpu.so") if native else CPU_LIB)
         self.lib.oc_max_threads.restype = ctypes.c_int
+        self.lib.oc_set_threads(min(int(self.lib.oc_max_threads()), cpu_share()))
         self.threads = int(self.lib.oc_max_threads())
         self.spec = spec
         self.steps = self._fold(spec)
@@ -158,6 +183,7 @@ class CpuInt8Path:
         self.native = bool(native)
         self.lib = ctypes.CDLL(os.path.join(NATIVE_DIR, "liboracle_i8.so") if native else I8_LIB)
         self.lib.oi_max_threads.restype = ctypes.c_int
+        self.lib.oi_set_threads(min(int(self.lib.oi_max_threads()), cpu_share()))
         self.threads = int(self.lib.oi_max_threads())
         self.vectorised = bool(self.lib.oi_vectorised())  # the AVX-512 / VNNI paths of oracle_i8.c are compiled in
         outer = self
@@ -267,6 +293,8 @@ class CpuInt8Path:
         reuse (a fresh 270 MB array per 1024 chunks is 66 k page faults before the first butterfly)."""
         if getattr(self, "_stft_lib", None) is None:
             self._stft_lib = ctypes.CDLL(os.path.join(NATIVE_DIR, "liboracle_cpu.so") if getattr(self, "native", False) else CPU_LIB)
+            self._stft_lib.oc_max_threads.restype = ctypes.c_int
+            self._stft_lib.oc_set_threads(min(int(self._stft_lib.oc_max_threads()), cpu_share()))
         x = np.ascontiguousarray(audio, np.float32)
         if out is not None and out.shape == (x.shape[0], 257, width, 1) and out.dtype == np.float32 and out.flags.c_contiguous:
             S = out.reshape(x.shape[0], 257, width)
