@@ -295,7 +295,7 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
-def host_peaks() -> dict:
+def host_peaks(used_threads: int | None = None) -> dict:
     """What the host could do at best, for scale beside ``cpu_baseline.gops``: cores x max clock x int8 multiply-add lanes per cycle (two
     512-bit VNNI pipes = 256 ops per cycle and core with avx512_vnni, 128 with avx_vnni only, 64 with AVX2's vpmaddubsw) — an upper bound from
     the flags and the clock the kernel reports, not a measurement."""
@@ -314,8 +314,10 @@ def host_peaks() -> dict:
         pass
     per_cycle = 256 if " avx512_vnni" in flags else 128 if " avx_vnni" in flags else 64 if " avx2" in flags else 16
     cores = physical_cores()
+    share = min(cores, used_threads) if used_threads else cores   # (the baseline ran on the process's CPU share, not on the whole host)
     return {"cores": cores, "max_mhz": round(mhz, 1), "int8_ops_per_cycle_per_core": per_cycle,
-            "theoretical_int8_peak_gops": round(cores * mhz * 1e6 * per_cycle / 1e9, 1), "isa": "avx512_vnni" if per_cycle == 256 else "avx_vnni" if per_cycle == 128 else "avx2" if per_cycle == 64 else "scalar"}
+            "theoretical_int8_peak_gops": round(cores * mhz * 1e6 * per_cycle / 1e9, 1),
+            "cores_available_to_this_process": share, "theoretical_int8_peak_gops_of_that_share": round(share * mhz * 1e6 * per_cycle / 1e9, 1), "isa": "avx512_vnni" if per_cycle == 256 else "avx_vnni" if per_cycle == 128 else "avx2" if per_cycle == 64 else "scalar"}
 
 
 def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
@@ -361,7 +363,9 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
             fn(x)
             done += nb
         dt = time.perf_counter() - t0
-        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": physical_cores(), "threads": threads, "kind": "port", "gops": gops(done / dt),
+        # `cores` = the threads actually used (the process's CPU share: affinity mask capped by the cgroup quota — oracle/cport.py: cpu_share), not the host's count
+        return {"value": round(done / dt, 1), "unit": "chunks/s", "cores": threads, "threads": threads, "host_physical_cores": physical_cores(), "kind": "port",
+                "gops": gops(done / dt),
                 "sample": f"{done} synthetic 3 s @ 24 kHz chunks, {what}, {threads} threads, {dt:.1f} s"}
 
     # the C ports are rebuilt -march=native on THIS host first (oracle/Makefile: native; a few seconds): on AVX-512 / VNNI hosts the INT8 port then
@@ -388,7 +392,7 @@ def cpu_baseline(dtype: str, seconds_budget: float = 15.0) -> dict:
         out = timed(run_i8, path.threads,
                     "C + OpenMP port of the TFLite int8 reference kernels, whole graph per chunk in C (oracle/c/oracle_i8.c: oi_program_run"
                     + (", -march=native" + (", AVX-512 VNNI paths" if path.vectorised else "") if native else "") + ") + C STFT")
-        out["host"] = host_peaks()
+        out["host"] = host_peaks(path.threads)
         out["int8_vector_paths"] = bool(path.vectorised)
         return out
 
