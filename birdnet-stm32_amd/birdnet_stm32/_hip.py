@@ -27,7 +27,7 @@ EXPORTS = (
     "bn_version", "bn_last_error", "bn_device_count", "bn_ctx_create", "bn_ctx_destroy", "bn_model_load",
     "bn_model_free", "bn_model_get_info", "bn_stft_mag", "bn_forward", "bn_infer_audio", "bn_debug_op_output",
     "bn_kernel_names", "bn_profile_enable", "bn_profile_collect", "bn_ingest_resample", "bn_ingest_chunks",
-    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize", "bn_set_option", "bn_get_option", "bn_ctx_set_option", "bn_ctx_get_option", "bn_ctx_reset_options",
+    "bn_pool_scores", "bn_mel_spectrogram", "bn_profile_only", "bn_chunk_peak_normalize", "bn_set_option", "bn_get_option", "bn_ctx_set_option", "bn_ctx_get_option", "bn_ctx_reset_options", "bn_preload_kernels", "bn_host_alloc_pinned", "bn_host_free_pinned", "bn_rank_orders",
     "bn_blob_check", "bn_debug_requant", "bn_stft_mag_exact", "bn_debug_input_bytes", "bn_debug_guard_stats", "bn_debug_tail_form", "bn_debug_mid_form",
 )  # fmt: skip
 
@@ -106,6 +106,11 @@ def load_library(path: str | None = None):
     lib.bn_ctx_set_option.argtypes = [c_void_p, c_char_p, c_int]
     lib.bn_ctx_get_option.argtypes = [c_void_p, c_char_p, POINTER(c_int)]
     lib.bn_ctx_reset_options.argtypes = [c_void_p]
+    lib.bn_preload_kernels.argtypes = [c_void_p]
+    lib.bn_rank_orders.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.bn_host_alloc_pinned.argtypes = [c_void_p, ctypes.c_size_t]
+    lib.bn_host_alloc_pinned.restype = c_void_p
+    lib.bn_host_free_pinned.argtypes = [c_void_p]
     if lib.bn_version() != ABI_VERSION:
         raise RuntimeError(f"libbirdnet_hip ABI {lib.bn_version()} != binding ABI {ABI_VERSION}")
     _lib = lib
@@ -187,6 +192,20 @@ class Context:
 
     def reset_options(self) -> None:
         check(self.lib.bn_ctx_reset_options(self.handle))
+
+    def alloc_pinned(self, nbytes: int) -> int:
+        """Address of ``nbytes`` of page-locked host memory (``bn_host_alloc_pinned``; the GIL is released for the call); free with ``free_pinned``."""
+        p = self.lib.bn_host_alloc_pinned(self.handle, int(nbytes))
+        if not p:
+            raise HipError(f"bn_host_alloc_pinned({nbytes}): {self.lib.bn_last_error().decode()}")
+        return int(p)
+
+    def free_pinned(self, ptr: int) -> None:
+        check(self.lib.bn_host_free_pinned(c_void_p(int(ptr))))
+
+    def preload_kernels(self) -> None:
+        """Load every device code object of the library now instead of at each kernel's first launch (``bn_preload_kernels``)."""
+        check(self.lib.bn_preload_kernels(self.handle))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -20,7 +20,7 @@ _lib = None
 IO_OK, IO_OPEN, IO_NOT_WAVE, IO_NO_CHUNK, IO_SHORT = 0, -1, -2, -3, -4
 
 # every symbol include/bn_host.h declares
-EXPORTS = ("bn_wav_probe", "bn_wav_probe_many", "bn_file_read_many", "bn_copy_many", "bn_flac_info", "bn_flac_md5", "bn_flac_decode")
+EXPORTS = ("bn_wav_probe", "bn_wav_probe_many", "bn_file_read_many", "bn_file_read_many_mode", "bn_host_set_read_mode", "bn_copy_many", "bn_flac_info", "bn_flac_md5", "bn_flac_decode")
 
 LAYOUT_DTYPE = np.dtype([("status", "<i4"), ("format_tag", "<i4"), ("channels", "<i4"), ("sample_rate", "<i4"), ("bits", "<i4"),
                          ("reserved", "<i4"), ("data_offset", "<i8"), ("data_bytes", "<i8")])
@@ -39,6 +39,8 @@ def _load():
         lib.bn_wav_probe.argtypes = [ctypes.c_char_p, vp]
         lib.bn_wav_probe_many.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, vp, ctypes.c_int]
         lib.bn_file_read_many.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, i64p, i64p, vp, i64p, vp, ctypes.c_int]
+        lib.bn_file_read_many_mode.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, i64p, i64p, vp, i64p, vp, ctypes.c_int, ctypes.c_int]
+        lib.bn_host_set_read_mode.argtypes = [ctypes.c_int]
         lib.bn_copy_many.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, i64p, vp, i64p, ctypes.c_int]
         _lib = lib
     return _lib
@@ -132,8 +134,20 @@ def probe_wavs(paths: list[str], n_threads: int | None = None) -> np.ndarray:
     return out
 
 
+READ_MODES = {"pread": 0, "mmap": 1}
+
+
+def set_read_mode(mode: str | None) -> str:
+    """Process-wide way ``read_windows`` takes bytes out of the page cache: ``"mmap"`` (default: mmap + MADV_SEQUENTIAL + memcpy — the first
+    read of freshly written files is not slowed by LRU activation) or ``"pread"``; ``None`` only queries.  Returns the previous mode."""
+    if mode is not None and mode not in READ_MODES:
+        raise ValueError(f"read mode {mode!r}: expected one of {sorted(READ_MODES)}")
+    prev = _load().bn_host_set_read_mode(-1 if mode is None else READ_MODES[mode])
+    return "pread" if prev == 0 else "mmap"
+
+
 def read_windows(paths: list[str], file_off: np.ndarray, nbytes: np.ndarray, base_ptr: int, dst_off: np.ndarray,
-                 n_threads: int | None = None) -> np.ndarray:
+                 n_threads: int | None = None, mode: str | None = None) -> np.ndarray:
     """``nbytes[i]`` bytes from offset ``file_off[i]`` of ``paths[i]`` into ``base_ptr + dst_off[i]``; returns the per-file status.
 
     The caller owns the destination (a page-locked slab), guarantees ``dst_off[i] + nbytes[i]`` stays inside it and that ranges
@@ -147,8 +161,8 @@ def read_windows(paths: list[str], file_off: np.ndarray, nbytes: np.ndarray, bas
         do = np.ascontiguousarray(dst_off, np.int64)
         if not (fo.shape == nb.shape == do.shape == (n,)):
             raise ValueError("file_off, nbytes and dst_off need one entry per path")
-        _load().bn_file_read_many(_path_array(paths), n, fo.ctypes.data, nb.ctypes.data, ctypes.c_void_p(int(base_ptr)), do.ctypes.data,
-                                  status.ctypes.data, int(n_threads or default_threads()))
+        _load().bn_file_read_many_mode(_path_array(paths), n, fo.ctypes.data, nb.ctypes.data, ctypes.c_void_p(int(base_ptr)), do.ctypes.data,
+                                       status.ctypes.data, int(n_threads or default_threads()), -1 if mode is None else READ_MODES[mode])
     return status
 
 

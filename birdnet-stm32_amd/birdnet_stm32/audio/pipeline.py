@@ -222,7 +222,7 @@ class GroupLayout:
 
 
 def layout_group(tab: FileTable, lo: int, hi: int, base_ptr: int, capacity: int, table: np.ndarray, sample_rate: int, chunk_duration: float,
-                 chunk_overlap: float, max_duration=60, n_threads: int | None = None) -> GroupLayout:
+                 chunk_overlap: float, max_duration=60, n_threads: int | None = None, read_mode: str | None = None) -> GroupLayout:
     """Read the windows of files ``[lo, hi)`` into the slab at ``base_ptr`` and write the group's offset tables into ``table``.
 
     Windows are ordered by (format, channels, native rate) — each such *sub-group* is one ``bn_ingest_resample`` launch and lies
@@ -251,7 +251,7 @@ def layout_group(tab: FileTable, lo: int, hi: int, base_ptr: int, capacity: int,
         if used > capacity:
             raise RuntimeError(f"evaluate pipeline: a group of {used} bytes outgrew its slab of {capacity}")
         raw_w = np.flatnonzero(tab.kind[wfile] == 0)
-        status = _pcmio.read_windows([tab.paths[i] for i in wfile[raw_w]], tab.file_off[wfile[raw_w]], nb[raw_w], base_ptr, dst[raw_w], n_threads)
+        status = _pcmio.read_windows([tab.paths[i] for i in wfile[raw_w]], tab.file_off[wfile[raw_w]], nb[raw_w], base_ptr, dst[raw_w], n_threads, read_mode)
         failed = set(wfile[raw_w][status != 0].tolist())
         host_w = np.flatnonzero(tab.kind[wfile] == 1)
         if host_w.size:
@@ -322,6 +322,51 @@ class _Staged:
     read_s: float
 
 
+# Page-locked slabs no pipeline holds at the moment: (address, bytes).  A process keeps them (page-locking costs ~65 us per MiB; every `evaluate`
+# call builds its own EvaluatePipeline) until release_pinned_slabs().
+_SLAB_POOL: list = []
+_SLAB_LOCK = threading.Lock()
+_COPY_STREAMS: dict = {}   # str(device) -> the H2D stream every pipeline of this process uses on that device
+
+
+class _PinnedSlab:
+    """``nbytes`` of page-locked host memory from the library (``bn_host_alloc_pinned``) seen as a uint8 CPU tensor.
+
+    Not ``torch.empty(pin_memory=True)``: that call page-locks under the GIL (17 ms per 256 MiB on the timing box), and while the helper thread of
+    ``_ensure_slabs`` sat in it neither the reader thread nor the caller's thread ran a line of Python (tools/_cold_trace.py).  Through ctypes
+    the GIL is released; PyTorch recognises the memory as page-locked by its address (``is_pinned()``), so ``copy_(non_blocking=True)`` stays
+    asynchronous."""
+
+    def __init__(self, ctx, nbytes: int, torch):
+        self.ctx = ctx
+        self.ptr = 0
+        with _SLAB_LOCK:
+            for i, (ptr, size) in enumerate(_SLAB_POOL):
+                if size >= nbytes:
+                    self.ptr, self.nbytes = ptr, size
+                    del _SLAB_POOL[i]
+                    break
+        if not self.ptr:
+            self.ptr, self.nbytes = ctx.alloc_pinned(nbytes), int(nbytes)
+        self.tensor = torch.frombuffer((ctypes.c_uint8 * self.nbytes).from_address(self.ptr), dtype=torch.uint8)
+
+    def release(self) -> None:
+        if self.ptr:
+            with _SLAB_LOCK:
+                _SLAB_POOL.append((self.ptr, self.nbytes))
+            self.ptr, self.tensor = 0, None
+
+
+def release_pinned_slabs() -> int:
+    """Give the pooled page-locked slabs back to the system; returns the bytes freed."""
+    with _SLAB_LOCK:
+        pool, _SLAB_POOL[:] = list(_SLAB_POOL), []
+    lib = _hip.load_library()
+    for ptr, _ in pool:
+        _hip.check(lib.bn_host_free_pinned(ctypes.c_void_p(ptr)))
+    return sum(size for _, size in pool)
+
+
 class EvaluatePipeline:
     """Runs files of one rank through read -> H2D -> ingest + inference; see the module docstring.
 
@@ -330,7 +375,7 @@ class EvaluatePipeline:
 
     def __init__(self, runner, sample_rate: int, chunk_duration: float, chunk_overlap: float = 0.0, max_duration=60,
                  slab_bytes: int = 256 << 20, group_chunks: int | None = None, readers: int | None = None, pinned_slabs: int = 3,
-                 ramp: tuple = (8, 4, 2), numa_pin: bool | None = None):
+                 ramp: tuple = (8, 4, 2), numa_pin: bool | None = None, read_mode: str | None = None):
         import torch
 
         self.torch = torch
@@ -349,10 +394,13 @@ class EvaluatePipeline:
         self.ramp = tuple(ramp)  # first groups cut at slab_bytes / ramp[i] (cut_groups)
         self.group_chunks = int(group_chunks or max(runner.max_batch, 1024))
         self.readers = int(readers or _pcmio.default_threads())
+        if read_mode is not None:   # "mmap" (library default) | "pread": process-wide switch of the reader (csrc/host/bn_pcmio.c)
+            _pcmio.set_read_mode(read_mode)
         self.n_pinned = max(2, int(pinned_slabs))
         self.size = int(self.sr * self.cd)
         self._taps: dict[tuple[int, int], object] = {}
         self._pinned: list = []
+        self._slabs: list = []         # the _PinnedSlab behind every tensor of _pinned
         self._pinned_free: list = []   # per pinned slab: the event of the last H2D that read it
         self._dslab: list = []
         self._dslab_free: list = []    # per device slab: the event behind the last kernels that read it
@@ -362,6 +410,16 @@ class EvaluatePipeline:
         self.copy_stream = None
         self._slot_ready = [threading.Semaphore(1), threading.Semaphore(1)]
         self._stop = threading.Event()
+        self._trace = None
+        self._t0 = 0.0
+        self._preloaded = False
+
+    def _mark(self, name: str) -> None:
+        """Timeline of one run (``BN_PIPELINE_TRACE=1``: ``stats["trace"]`` = [(what, seconds since run() started, thread)]) — where a COLD call's
+        time goes cannot be read off per-stage busy times (tools/_cold_probe.py)."""
+        tr = self._trace
+        if tr is not None:
+            tr.append((name, round(time.perf_counter() - self._t0, 5), threading.current_thread().name))
 
     # -- buffers (grow only) ------------------------------------------------------------------------------------------------
     def _ensure_slabs(self, need: int, tab_words: int) -> None:
@@ -369,11 +427,17 @@ class EvaluatePipeline:
         cap = max(self.slab_bytes, need)
         for e in getattr(self, "_pinned_ready", []):   # (a helper thread of an earlier call is still allocating: let it finish before judging the sizes)
             e.wait()
+        if not self._tab_pinned or self._tab_pinned[0].numel() < tab_words:
+            words = max(tab_words, 1 << 16)
+            self._tab_pinned = [torch.empty(words, dtype=torch.int64, pin_memory=True) for _ in range(self.n_pinned)]
+            self._tab_dev = [torch.empty(words, dtype=torch.int64, device=self.dev) for _ in range(2)]
         if not self._pinned or self._pinned[0] is None or self._pinned[0].numel() < cap:
             # Page-locking 3 x 256 MiB costs ~0.14 s the first time (a one-shot `evaluate` call pays it: BENCH_r04 cold read_s 0.18 against
             # 0.04 warm).  The slabs are allocated by a helper thread, in the order the producer needs them; the producer waits for slab k only
             # when it gets to group k — the first (small, ramped) groups are read and copied while the other slabs are still being pinned.
+            self._release_slabs()
             self._pinned = [None] * self.n_pinned
+            self._slabs = [None] * self.n_pinned
             self._pinned_ready = [threading.Event() for _ in range(self.n_pinned)]
             self._pinned_free = [None] * self.n_pinned
 
@@ -381,21 +445,40 @@ class EvaluatePipeline:
                 try:
                     torch.cuda.set_device(self.dev)
                     for k in range(self.n_pinned):
-                        self._pinned[k] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                        self._slabs[k] = _PinnedSlab(self.ctx, cap, torch)
+                        self._pinned[k] = self._slabs[k].tensor
                         self._pinned_ready[k].set()
+                        self._mark(f"slab {k} page-locked")
                 except BaseException as exc:  # noqa: BLE001 - surfaces in the producer
                     self._pinned_error = exc
                     for e in self._pinned_ready:
                         e.set()
 
             self._pinned_error = None
-            threading.Thread(target=allocate, name="bn-pin-slabs", daemon=True).start()
+            # (device slabs first: behind the helper thread they wait for the runtime until every slab is page-locked — 44 ms of a cold call)
             self._dslab = [torch.empty(cap, dtype=torch.uint8, device=self.dev) for _ in range(2)]
             self._dslab_free = [None, None]
-        if not self._tab_pinned or self._tab_pinned[0].numel() < tab_words:
-            words = max(tab_words, 1 << 16)
-            self._tab_pinned = [torch.empty(words, dtype=torch.int64, pin_memory=True) for _ in range(self.n_pinned)]
-            self._tab_dev = [torch.empty(words, dtype=torch.int64, device=self.dev) for _ in range(2)]
+            threading.Thread(target=allocate, name="bn-pin-slabs", daemon=True).start()
+
+    def _release_slabs(self) -> None:
+        for e in getattr(self, "_pinned_ready", []):
+            e.wait()
+        for sl in self._slabs:
+            if sl is not None:
+                sl.release()
+        self._slabs, self._pinned = [], []
+
+    def close(self) -> None:
+        """Hand the page-locked slabs back to the process-wide pool (the next pipeline takes them without page-locking anything)."""
+        if self.copy_stream is not None:
+            self.copy_stream.synchronize()
+        self._release_slabs()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
 
     def _filter(self, sr0: int):
         """(device taps or None, up, down, taps per phase, leading outputs to drop) for one native rate."""
@@ -423,9 +506,15 @@ class EvaluatePipeline:
         if self._pinned_error is not None:
             raise self._pinned_error
         pinned = self._pinned[k]  # (sized for the largest group before the producer started: run())
+        self._mark(f"group {seq}: slab ready")
+        # While the helper thread of _ensure_slabs is still page-locking slabs the windows are taken with pread: registering a slab holds the
+        # process's mmap lock (17 ms per 256 MiB), a mapping needs that lock for every file and pread needs it for none (tools/_cold_trace.py: the
+        # first 32 MiB group of a cold call took 18 ms through mappings, 2 ms warm).
+        pinning = not all(e.is_set() for e in self._pinned_ready)
         lay = layout_group(tab, lo, hi, pinned.data_ptr(), pinned.numel(), self._tab_pinned[k].numpy(), self.sr, self.cd, self.ov,
-                           self.max_duration, self.readers)
+                           self.max_duration, self.readers, "pread" if pinning else None)
         read_s = time.perf_counter() - t0
+        self._mark(f"group {seq}: read")
         # ---- H2D on the copy stream ----
         slot = seq % 2
         while not self._slot_ready[slot].acquire(timeout=0.1):  # the consumer has launched the group that used this device slab
@@ -443,6 +532,7 @@ class EvaluatePipeline:
             self._tab_dev[slot][: lay.tab_len].copy_(self._tab_pinned[k][: lay.tab_len], non_blocking=True)
             e1.record(self.copy_stream)
         self._pinned_free[k] = e1
+        self._mark(f"group {seq}: H2D queued")
         return _Staged(lay, slot, e1, (e0, e1), read_s)
 
     # -- stage 3: consumer (caller's thread and stream) -----------------------------------------------------------------------
@@ -460,6 +550,7 @@ class EvaluatePipeline:
         if self._chunks is None or self._chunks.shape[0] < g.n_chunks:
             self._chunks = None
             self._chunks = torch.empty((max(g.n_chunks, self.group_chunks), self.size), dtype=torch.float32, device=self.dev)
+        self._mark("compute: buffers")
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record(cur)
         if g.n_windows:
@@ -479,6 +570,7 @@ class EvaluatePipeline:
         self._dslab_free[st.slot] = done  # slab and table may be overwritten once these launches have run
         self._slot_ready[st.slot].release()
         ev[1].record(cur)
+        self._mark("compute: ingest launched")
         n = g.n_chunks
         if n:
             if lat_events is None:
@@ -492,6 +584,7 @@ class EvaluatePipeline:
                     b.record(cur)
                     lat_events.append((a, b, nb))
         ev[2].record(cur)
+        self._mark("compute: inference launched")
         stats["_events"].append((st.h2d_events, ev, g.used + 8 * g.tab_len))
 
     def run(self, paths: list[str], batch_size: int | None = None, measure_latency: bool = False):
@@ -504,9 +597,17 @@ class EvaluatePipeline:
         torch = self.torch
         t_start = time.perf_counter()
         stats: dict = {"_events": []}
+        self._t0 = t_start
+        self._trace = [] if os.environ.get("BN_PIPELINE_TRACE") else None
         with torch.cuda.device(self.dev):
             if self.copy_stream is None:
-                self.copy_stream = torch.cuda.Stream(device=self.dev)
+                # one copy stream per device and PROCESS: every `evaluate` call builds its own pipeline, and the first copy on a new stream waits
+                # ~5 ms for its hardware queue (tools/_cold_trace.py: "group 0: H2D queued" of every warm call)
+                key = str(self.dev)
+                with _SLAB_LOCK:
+                    if key not in _COPY_STREAMS:
+                        _COPY_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+                    self.copy_stream = _COPY_STREAMS[key]
             tab = plan_files(paths, self.sr, self.cd, self.ov, self.max_duration, self.readers)
             stats["probe_s"] = time.perf_counter() - t_start
             groups = cut_groups(tab.nbytes, tab.n_chunks, self.slab_bytes, self.group_chunks, self.ramp)
@@ -516,7 +617,9 @@ class EvaluatePipeline:
             cc = np.concatenate([[0], np.cumsum(tab.n_chunks)])
             need_bytes = max((int(cb[b] - cb[a]) for a, b in groups), default=0)
             need_words = max((3 * (b - a) + 2 * int(cc[b] - cc[a]) + 16 for a, b in groups), default=16)
+            self._mark("planned")
             self._ensure_slabs(need_bytes, need_words)
+            self._mark("device slabs")
             self._slot_ready = [threading.Semaphore(1), threading.Semaphore(1)]
             self._dslab_free = [None, None]
             self._pinned_free = [None] * self.n_pinned
@@ -538,6 +641,11 @@ class EvaluatePipeline:
 
             th = threading.Thread(target=producer, name="bn-evaluate-reader", daemon=True)
             th.start()
+            if not self._preloaded:   # this thread has nothing to do until the first group is on the device: load the kernels' code objects meanwhile
+                self.ctx.preload_kernels()
+                torch.empty(64, dtype=torch.float32, device=self.dev).zero_()   # (and the one torch kernel of the compute stage: _peak.zero_())
+                self._preloaded = True
+                self._mark("kernels preloaded")
             counts = np.zeros(len(paths), np.int64)
             lat_events: list | None = [] if measure_latency else None
             row = 0
@@ -563,7 +671,9 @@ class EvaluatePipeline:
                         q.get_nowait()
                     except queue.Empty:
                         th.join(timeout=0.05)
+            self._mark("all launched")
             torch.cuda.current_stream(self.dev).synchronize()
+            self._mark("stream drained")
             h2d_ms = ingest_ms = infer_ms = 0.0
             moved = 0
             for (c0, c1), ev, nbytes in stats.pop("_events"):
@@ -578,8 +688,10 @@ class EvaluatePipeline:
         stats.update(files=len(paths), readable=int((tab.kind >= 0).sum()), chunks=row, groups=len(groups), read_s=read_s, h2d_s=h2d_ms / 1e3,
                      h2d_bytes=moved, h2d_gbps=(moved / 1e9) / (h2d_ms / 1e3) if h2d_ms > 0 else 0.0, ingest_s=ingest_ms / 1e3,
                      infer_s=infer_ms / 1e3, wall_s=time.perf_counter() - t_start, readers=self.readers, slab_bytes=self.slab_bytes,
-                     group_chunks=self.group_chunks, local_world=_pcmio.local_world_size(), numa=dict(self.numa), slab_wait_s=round(self._wait_s, 4),
+                     group_chunks=self.group_chunks, local_world=_pcmio.local_world_size(), numa=dict(self.numa), read_mode=_pcmio.set_read_mode(None), slab_wait_s=round(self._wait_s, 4),
                      read_s_per_group=read_groups[:32])
+        if self._trace is not None:
+            stats["trace"] = list(self._trace)
         return scores[:row], counts.tolist(), stats, lat
 
 

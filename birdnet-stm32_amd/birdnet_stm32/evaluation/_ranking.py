@@ -8,7 +8,7 @@ class and ``average_precision_score(y, s, average='micro')`` (reference: birdnet
 against scikit-learn on random, tied, degenerate inputs): the curves are built from integer counts and every floating-point expression
 (``tps / (tps + fps)``, ``tps / tps[-1]``, the step-function sum, the trapezoid sum) is evaluated with numpy in the same order on arrays
 of the same length, so even the pairwise summation agrees.  What changes is only who sorts: the order of tied scores does not matter
-(counts are read at the boundaries between distinct scores), so the argsort may come from ``torch`` on the GPU.
+(counts are read at the boundaries between distinct scores), so the argsort may come from the GPU (``bn_rank_orders``).
 """
 
 from __future__ import annotations
@@ -52,23 +52,33 @@ def roc_auc_desc(truth_desc: np.ndarray, score_desc: np.ndarray) -> float:
     return float((np.diff(fpr) * (tpr[1:] + tpr[:-1]) / 2.0).sum())
 
 
-def descending_orders(scores: np.ndarray, device=None):
+def descending_orders(scores: np.ndarray, ctx=None):
     """``(per-column order [N, C], order of the flattened matrix [N*C])`` — indices that sort the scores descending.
 
-    With ``device`` (a CUDA ``torch.device``) both sorts run on the GPU (the score matrix is 1.6 MB for 4096 files); otherwise numpy's
-    stable sort, reversed — what the library does per call."""
+    With ``ctx`` (the runner's ``_hip.Context``) and float32 scores both sorts run on that context's GPU through ``bn_rank_orders`` (the score
+    matrix is 1.6 MB for 4096 files) — the library's own sort kernels, not ``torch.argsort``, whose first call in a process loads PyTorch's sort
+    code object for 0.1-0.17 s (round 5); otherwise numpy's stable sort, reversed — what scikit-learn does per call."""
     s = np.ascontiguousarray(scores)
-    if device is not None:
+    if ctx is not None and s.dtype == np.float32 and s.ndim == 2 and 0 < s.size < (1 << 30):
+        import ctypes
+
         import torch
 
-        d = torch.from_numpy(s).to(device)
-        cols = torch.argsort(d, dim=0, descending=True, stable=True)
-        flat = torch.argsort(d.reshape(-1), descending=True, stable=True)
-        return cols.cpu().numpy(), flat.cpu().numpy()
+        from birdnet_stm32 import _hip
+
+        n, c = s.shape
+        dev = torch.device("cuda", ctx.device)
+        with torch.cuda.device(dev):
+            d = torch.from_numpy(s).to(dev)
+            cols = torch.empty((c, n), dtype=torch.int32, device=dev)
+            flat = torch.empty(n * c, dtype=torch.int32, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            _hip.check(ctx.lib.bn_rank_orders(ctx.handle, d.data_ptr(), n, c, cols.data_ptr(), flat.data_ptr(), ctypes.c_void_p(stream.cuda_stream)))
+            return cols.cpu().numpy().T, flat.cpu().numpy()
     return np.argsort(s, axis=0, kind="stable")[::-1], np.argsort(s.reshape(-1), kind="stable")[::-1]
 
 
-def ranking_metrics(y_true: np.ndarray, y_scores: np.ndarray, device=None) -> dict:
+def ranking_metrics(y_true: np.ndarray, y_scores: np.ndarray, ctx=None) -> dict:
     """``{'roc-auc', 'ap_per_class', 'mAP'}`` as ``evaluate`` reports them (NaN where the library call raises or is undefined)."""
     yt = np.asarray(y_true)
     ys = np.asarray(y_scores)
@@ -79,7 +89,7 @@ def ranking_metrics(y_true: np.ndarray, y_scores: np.ndarray, device=None) -> di
     truth = yt == 1
     if not np.logical_or(truth, yt == 0).all():  # not a 0/1 indicator matrix: the library takes other routes
         raise ValueError("y_true must be a 0/1 indicator matrix")
-    cols, flat = descending_orders(ys, device)
+    cols, flat = descending_orders(ys, ctx)
     aps = []
     lacking = 0
     for c in range(n_cls):

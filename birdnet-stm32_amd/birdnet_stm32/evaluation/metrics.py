@@ -77,6 +77,22 @@ def _label_of(path: str) -> str:
     return os.path.basename(os.path.dirname(path))
 
 
+def _with_known_label(files, classes) -> list[str]:
+    """The files whose directory name is one of ``classes`` (reference :104-110), one directory lookup per DIRECTORY instead of two path splits and a
+    list search per file (6 ms of a 72 ms warm ``evaluate`` call on 1024 files, tools/_warm_profile.py)."""
+    known = set(classes)
+    seen: dict[str, bool] = {}
+    out = []
+    for p in files:
+        d = os.path.dirname(p)
+        ok = seen.get(d)
+        if ok is None:
+            ok = seen[d] = os.path.basename(d) in known
+        if ok:
+            out.append(p)
+    return out
+
+
 def _score_files_reference(model_runner, files, classes, cfg, frontend, mag_scale, n_fft, overlap, batch_size, measure_latency,
                            spectrogram_fn, pooling, beta):
     """The reference loop: per file, batches of at most ``batch_size`` chunks, never across files."""
@@ -108,7 +124,7 @@ def _score_files_device_serial(runner, files, classes, cfg, overlap, batch_size,
     from birdnet_stm32.audio.ingest import load_audio_files_device, pool_scores_device
 
     sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
-    todo = [p for p in files if _label_of(p) in classes]
+    todo = _with_known_label(files, classes)
     lat: list[float] = []
     for g0 in range(0, len(todo), files_per_group):
         group = todo[g0 : g0 + files_per_group]
@@ -158,14 +174,11 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
     from birdnet_stm32.evaluation.sharding import score_files_sharded, world_info
 
     sr, cd = int(cfg["sample_rate"]), float(cfg["chunk_duration"])
-    todo = [p for p in files if _label_of(p) in classes]
+    todo = _with_known_label(files, classes)
     lat: list[float] = []
     if not todo:
         return
     pipe = EvaluatePipeline(runner, sr, cd, overlap, max_duration=60, **(pipeline_options or {}))
-    # The ranking metrics behind the scores run two sorts on the GPU (evaluation/_ranking.py); their first launch in a process loads the sort
-    # kernels (0.17 s of BENCH_r04's cold metrics_s).  Done here, on a helper thread and its own stream, while the pipeline is busy reading files.
-    _warm_ranking_kernels(runner.device, runner.num_classes)
     from birdnet_stm32.evaluation import sharding as _sh
 
     if world_info()[1] > 1 or not _sh._local_only(world_info()[1]):  # (the second clause: the collective path forced at world size 1, tests)
@@ -185,6 +198,7 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
         lat.extend(l)
         if stats is not None:
             stats.update(st)
+    pipe.close()   # (its page-locked slabs go back to the process-wide pool: the next call's pipeline page-locks nothing)
     if scores.shape[0] == 0:
         return
     t0 = time.perf_counter()
@@ -194,32 +208,6 @@ def _score_files_device(runner, files, classes, cfg, overlap, batch_size, measur
     for path, c, row in zip(todo, counts, pooled):
         if c:
             yield path, c, row, lat
-
-
-_ranking_warm: set = set()
-
-
-def _warm_ranking_kernels(device, n_classes: int) -> None:
-    """Load the GPU sort kernels ``ranking_metrics`` will use (once per process and device), off the caller's thread and stream."""
-    import threading
-
-    key = str(device)
-    if key in _ranking_warm:
-        return
-    _ranking_warm.add(key)
-
-    def warm():
-        try:
-            import torch
-
-            from birdnet_stm32.evaluation._ranking import descending_orders
-
-            with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
-                descending_orders(np.linspace(0.0, 1.0, 64 * n_classes, dtype=np.float32).reshape(64, n_classes), device)
-        except Exception:  # pragma: no cover - a warm-up must never fail the evaluation
-            pass
-
-    threading.Thread(target=warm, name="bn-warm-ranking", daemon=True).start()
 
 
 def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pooling: str = "average", batch_size: int = 64,
@@ -268,7 +256,7 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
         y_true.append(target)
         y_scores.append(pooled)
         per_file.append({"file": path, "label": label, "scores": pooled.tolist()})
-    known = [p for p in files if _label_of(p) in classes]
+    known = _with_known_label(files, classes)
     if len(per_file) < len(known):  # the reference skips such files silently (:112-116); say which kind they were
         import warnings
 
@@ -297,9 +285,10 @@ def evaluate(model_runner, files: list[str], classes: list[str], cfg: dict, pool
     from birdnet_stm32.evaluation._ranking import ranking_metrics
 
     metrics: dict = {}
-    rank_dev = getattr(model_runner, "device", None) if device_pipeline else None
+    # (with the device pipeline the sorts run on the GPU through the library's own sort kernels: bn_rank_orders)
+    rank_ctx = getattr(model_runner, "ctx", None) if device_pipeline else None
     try:
-        ranked = ranking_metrics(yt, ys, device=rank_dev)
+        ranked = ranking_metrics(yt, ys, ctx=rank_ctx)
     except Exception:
         ranked = {"roc-auc": float("nan"), "ap_per_class": [float("nan")] * n_cls, "mAP": float("nan")}
     metrics["roc-auc"] = ranked["roc-auc"]

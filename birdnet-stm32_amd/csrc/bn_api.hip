@@ -87,6 +87,8 @@ struct bn_ctx {
     bn::StftTables tables{};
     float* d_block_peaks = nullptr;  // bn_ingest_resample: per-workgroup maxima, grown on demand
     size_t block_peaks_elems = 0;
+    void* d_rank_work = nullptr;     // bn_rank_orders: transposed keys, index arrays, rocPRIM storage; grown on demand
+    size_t rank_work_bytes = 0;
 };
 
 struct bn_model {
@@ -823,6 +825,7 @@ void bn_ctx_destroy(bn_ctx* c) {
     (void)hipFree(c->d_tw512);
     (void)hipFree(c->d_f64tab);
     (void)hipFree(c->d_block_peaks);
+    if (c->d_rank_work) (void)hipFree(c->d_rank_work);
     delete c;
 }
 
@@ -1430,6 +1433,32 @@ int bn_pool_scores(bn_ctx* ctx, const float* d_scores, const int64_t* d_file_off
     return BN_OK;
 }
 
+int bn_rank_orders(bn_ctx* ctx, const float* d_scores, int n_rows, int n_classes, int32_t* d_cols, int32_t* d_flat, void* stream) {
+    if (int rc = check_device(ctx)) return rc;
+    if (n_rows < 0 || n_classes <= 0) return fail(BN_ERR_ARG, "bad score matrix %d x %d", n_rows, n_classes);
+    if (n_rows == 0) return BN_OK;
+    if (!d_scores || !d_cols || !d_flat) return fail(BN_ERR_ARG, "null device pointer");
+    if ((int64_t)n_rows * n_classes > 0x3fffffffLL) return fail(BN_ERR_ARG, "rows x classes exceeds 2^30");
+    const size_t need = bn::rank_orders_workspace(n_rows, n_classes);
+    if (need > ctx->rank_work_bytes) {   // (grown outside any capture: the call is made once per evaluation, behind the last inference)
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        if (ctx->d_rank_work) (void)hipFree(ctx->d_rank_work);
+        ctx->d_rank_work = nullptr;
+        ctx->rank_work_bytes = 0;
+        if (hipMalloc(&ctx->d_rank_work, need + need / 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(BN_ERR_DEVICE, "hipMalloc of %zu bytes for the sort workspace failed", need + need / 4);
+        }
+        ctx->rank_work_bytes = need + need / 4;
+    }
+    if (!bn::launch_rank_orders(d_scores, n_rows, n_classes, d_cols, d_flat, ctx->d_rank_work, ctx->rank_work_bytes, (hipStream_t)stream)) {
+        (void)hipGetLastError();
+        return fail(BN_ERR_DEVICE, "the device sort failed");
+    }
+    HIP_TRY(hipGetLastError());
+    return BN_OK;
+}
+
 int bn_debug_op_output(bn_model* m, int op_index, int B, void* d_dst, size_t dst_bytes, size_t* bytes_per_chunk,
                        void* stream) {
     if (!m) return fail(BN_ERR_ARG, "null model");
@@ -1541,6 +1570,40 @@ int bn_ctx_reset_options(bn_ctx* ctx) {
     if (!ctx) return fail(BN_ERR_ARG, "null context");
     std::lock_guard<std::mutex> lock(g_opt_mu);
     ctx->opt_override.clear();
+    return BN_OK;
+}
+
+void* bn_host_alloc_pinned(bn_ctx* ctx, size_t bytes) {
+    if (!ctx || bytes == 0) {
+        fail(BN_ERR_ARG, "null context or empty allocation");
+        return nullptr;
+    }
+    if (check_device(ctx) != BN_OK) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(BN_ERR_DEVICE, "hipHostMalloc of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+int bn_host_free_pinned(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(BN_ERR_DEVICE, "hipHostFree failed");
+    }
+    return BN_OK;
+}
+
+int bn_preload_kernels(bn_ctx* ctx) {
+    if (!ctx) return fail(BN_ERR_ARG, "null context");
+    if (int rc = check_device(ctx)) return rc;
+    // The runtime loads a device code object at the first launch of one of its kernels (a few ms each, and every other thread's launches and
+    // copies wait meanwhile).  A caller with idle time before its first batch — the evaluate pipeline while the first files are read — asks here.
+    bn::preload_ingest(); bn::preload_stft(); bn::preload_stft_exact(); bn::preload_i8_fused(); bn::preload_i8_strip(); bn::preload_i8_tail2();
+    bn::preload_i8_tail(); bn::preload_i8(); bn::preload_i8_pw(); bn::preload_f32(); bn::preload_f32_fused(); bn::preload_f32_strip();
+    bn::preload_f32_pw(); bn::preload_melspec(); bn::preload_sort();
     return BN_OK;
 }
 

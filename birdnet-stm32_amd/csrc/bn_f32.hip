@@ -615,4 +615,12 @@ void launch_f32_attnpool(const float* x, float* y, int B, int P, int C, const fl
     hipLaunchKernelGGL(f32_attnpool_kernel, dim3(B), dim3(256), P * sizeof(float), s, x, y, P, C, score);
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_f32() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&u32_fill_kernel));
+}
+
 }  // namespace bn

@@ -802,4 +802,12 @@ void launch_f32_dwpw(const DwPwArgs& a, hipStream_t s) {
     }
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_f32_fused() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&f32_front_kernel<2, 1>));
+}
+
 }  // namespace bn

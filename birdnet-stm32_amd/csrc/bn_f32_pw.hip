@@ -317,4 +317,11 @@ bool launch_f32_pw_ws(const DwPwArgs& d, hipStream_t s) {
     return false;
 }
 
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_f32_pw() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&f32_pw_ws_kernel<192, 3, false, false>));
+}
+
 }  // namespace bn

@@ -1253,4 +1253,12 @@ void launch_f32_strip(DwPwArgs a, hipStream_t s) {
 #undef BN_FSTRIP
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_f32_strip() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&f32_dw_stream_kernel<1>));
+}
+
 }  // namespace bn

@@ -795,4 +795,12 @@ void launch_debug_requant(const int32_t* x, const int32_t* mult, const int32_t* 
     hipLaunchKernelGGL(debug_requant_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, mult, shift, n, mode, zp, out);
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_i8() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&i8_quant_kernel));
+}
+
 }  // namespace bn

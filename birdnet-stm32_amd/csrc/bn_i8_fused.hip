@@ -1255,11 +1255,19 @@ void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s) {
     }
 }
 
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_i8_fused() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&i8_mel_mfma_kernel<true, 1>));
+}
+
 }  // namespace bn
 
 #ifdef BN_TAIL_STAMPS
 // debug export of the stamps build only: where the guarded mel mixer writes its stamps ([1024][4][8] int64, zeroed by the caller)
 extern "C" __attribute__((visibility("default"))) int bn_debug_mel_stamps(long long* d_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(bn::g_mel_stamps), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
+
 }
 #endif

@@ -318,4 +318,11 @@ void launch_i8_pw_lds(const DwPw8Args& a, hipStream_t s) {
 #undef BN_PWL1
 }
 
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_i8_pw() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&i8_pw_lds_kernel<false, false, 3, 4, false>));
+}
+
 }  // namespace bn

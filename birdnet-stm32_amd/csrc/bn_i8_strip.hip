@@ -1268,6 +1268,13 @@ bool launch_i8_stem_stream(const int8_t* x, int8_t* y, int B, const I8ConvGeom& 
     return true;
 }
 
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_i8_strip() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&i8_front_strip_kernel));
+}
+
 }  // namespace bn
 
 #ifdef BN_TAIL_STAMPS
@@ -1276,5 +1283,6 @@ extern "C" __attribute__((visibility("default"))) int bn_debug_dw_stamps(long lo
     const int sel[2] = {C, H};
     if (hipMemcpyToSymbol(HIP_SYMBOL(bn::g_dw_sel), sel, sizeof sel) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(bn::g_dw_stamps), &d_buf, sizeof d_buf) == hipSuccess ? 0 : -1;
+
 }
 #endif

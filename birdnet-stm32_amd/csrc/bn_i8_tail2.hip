@@ -651,4 +651,12 @@ bool launch_i8_mid2(Tail2Args a, hipStream_t s) {
     return true;
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_i8_tail2() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&i8_tail2_kernel));
+}
+
 }  // namespace bn

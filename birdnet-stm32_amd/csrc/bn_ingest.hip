@@ -543,4 +543,12 @@ void launch_pool_scores(const float* scores, const long* seg, int F, int C, int 
     hipLaunchKernelGGL(pool_scores_kernel, dim3((total + 255) / 256), dim3(256), 0, s, scores, seg, F, C, method, beta, out);
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_ingest() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&ingest_chunks_kernel));
+}
+
 }  // namespace bn

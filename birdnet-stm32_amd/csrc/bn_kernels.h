@@ -432,4 +432,13 @@ bool i8_front_supported(int H0, int W0, int C, int N, int OH, int OW);
 void launch_i8_front(const I8FrontParams& q, const int8_t* fe, int8_t* y, int B, hipStream_t s);
 void launch_i8_dwpw(const DwPw8Args& a, hipStream_t s);
 
+// One per source file with kernels: load that file's device code object now (bn_preload_kernels)
+void preload_f32(); void preload_f32_fused(); void preload_f32_pw(); void preload_f32_strip(); void preload_i8(); void preload_i8_fused();
+void preload_i8_pw(); void preload_i8_strip(); void preload_i8_tail(); void preload_i8_tail2(); void preload_ingest(); void preload_melspec();
+void preload_stft(); void preload_stft_exact(); void preload_sort();
+
+// bn_sort.hip: descending orders of the score matrix for the ranking metrics (per class [C][N] row indices, flattened [N*C] flat indices)
+size_t rank_orders_workspace(int N, int C);
+bool launch_rank_orders(const float* d_scores, int N, int C, int* d_cols, int* d_flat, void* d_work, size_t work_bytes, hipStream_t s);
+
 }  // namespace bn

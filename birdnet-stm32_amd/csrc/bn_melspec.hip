@@ -159,4 +159,12 @@ bool launch_melspec_finish(const float* mel, float* out, const float* dct, int B
     return true;
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_melspec() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&melspec_finish_kernel));
+}
+
 }  // namespace bn

@@ -491,4 +491,12 @@ void launch_spec_normalize(float* spec, const float* minmax, int B, int per_chun
     hipLaunchKernelGGL(spec_normalize_kernel, dim3(32, B), dim3(256), 0, s, spec, minmax, per_chunk);
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_stft() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&minmax_init_kernel));
+}
+
 }  // namespace bn

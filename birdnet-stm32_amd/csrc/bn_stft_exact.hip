@@ -449,4 +449,12 @@ void launch_stft_fix(const StftTables& tb, const float* audio, int B, int T, int
                        g.hard + g.hard_cap, g.n_hard + 1, (float*)nullptr);
 }
 
+
+// bn_preload_kernels (bn_api.hip): asking for one kernel's attributes makes the runtime load this file's device code object now instead of at the
+// first launch of one of its kernels.
+void preload_stft_exact() {
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&stft_minmax_exact_kernel));
+}
+
 }  // namespace bn

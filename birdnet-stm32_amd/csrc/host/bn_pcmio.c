@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -159,7 +160,54 @@ typedef struct {
     unsigned char* base;
     const int64_t* dst_off;
     int32_t* status;
+    int mode; /* BN_READ_* of this call */
 } read_args;
+
+/* How a window leaves the page cache (bn_host_set_read_mode):
+ *   BN_READ_PREAD  pread() into the slab;
+ *   BN_READ_MMAP   (default) mmap(MAP_SHARED) + madvise(MADV_SEQUENTIAL) + memcpy + munmap.
+ * Why the second is the default: pread (and an ordinary mapping, when it is torn down) calls folio_mark_accessed on every page, and the SECOND
+ * touch of a page — the first read of a freshly written file, a data set just unpacked or generated — moves it to the active LRU list under the
+ * one lru lock all reader threads share: 17-20 GB/s on 16 threads against 75+ GB/s once the pages are active (tools/probe/cold_read_probe.c,
+ * profiles/r05_evaluate_cold_probe.md).  A VM_SEQ_READ mapping is exempt from that bookkeeping (mm: vma_has_recency): 65-70 GB/s on the first read
+ * and on every later one, and a one-pass read of a data set no longer pushes it onto the active list.  Windows below 64 KB, files that cannot be
+ * mapped and windows running past the end of the file take pread (same status codes).  A file truncated by someone else WHILE it is being copied
+ * raises SIGBUS under mmap where pread would return short: data sets are not rewritten under a running evaluation; BN_READ_MODE=pread is there. */
+#define BN_READ_PREAD 0
+#define BN_READ_MMAP 1
+static int g_read_mode = -1; /* -1: not yet seeded from the environment */
+
+static int read_mode(void) {
+    int m = __atomic_load_n(&g_read_mode, __ATOMIC_RELAXED);
+    if (m < 0) {
+        const char* e = getenv("BN_READ_MODE");
+        m = (e && (strcmp(e, "pread") == 0 || strcmp(e, "0") == 0)) ? BN_READ_PREAD : BN_READ_MMAP;
+        __atomic_store_n(&g_read_mode, m, __ATOMIC_RELAXED);
+    }
+    return m;
+}
+
+/* Sets the process-wide read mode (BN_READ_*), returns the previous one; any other value only queries. */
+BN_HOST_API int bn_host_set_read_mode(int mode) {
+    int prev = read_mode();
+    if (mode == BN_READ_PREAD || mode == BN_READ_MMAP) __atomic_store_n(&g_read_mode, mode, __ATOMIC_RELAXED);
+    return prev;
+}
+
+/* 1 = copied, 0 = not applicable here (the caller takes pread) */
+static int mmap_window(int fd, void* dst, size_t n, off_t off) {
+    static long page = 0;
+    if (!page) page = sysconf(_SC_PAGESIZE);
+    struct stat st;
+    if (n < 65536 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (int64_t)off + (int64_t)n > (int64_t)st.st_size) return 0;
+    const off_t lead = off & (off_t)(page - 1);
+    void* m = mmap(NULL, n + (size_t)lead, PROT_READ, MAP_SHARED, fd, off - lead);
+    if (m == MAP_FAILED) return 0;
+    (void)madvise(m, n + (size_t)lead, MADV_SEQUENTIAL);
+    memcpy(dst, (const char*)m + lead, n);
+    munmap(m, n + (size_t)lead);
+    return 1;
+}
 
 static void read_item(void* a, int i) {
     read_args* r = (read_args*)a;
@@ -172,6 +220,11 @@ static void read_item(void* a, int i) {
         r->status[i] = BN_IO_OPEN;
         return;
     }
+    if (r->mode == BN_READ_MMAP && mmap_window(fd, r->base + r->dst_off[i], (size_t)r->nbytes[i], (off_t)r->file_off[i])) {
+        close(fd);
+        r->status[i] = BN_IO_OK;
+        return;
+    }
     ssize_t got = pread_full(fd, r->base + r->dst_off[i], (size_t)r->nbytes[i], (off_t)r->file_off[i]);
     close(fd);
     r->status[i] = got == (ssize_t)r->nbytes[i] ? BN_IO_OK : (got < 0 ? BN_IO_OPEN : BN_IO_SHORT);
@@ -180,14 +233,19 @@ static void read_item(void* a, int i) {
 /* nbytes[i] bytes from offset file_off[i] of paths[i] into base + dst_off[i], for n files on n_threads threads.
  * The destination ranges must not overlap and must lie inside the caller's buffer (the caller sized it).
  * Returns the number of items whose status is not OK. */
-BN_HOST_API int bn_file_read_many(const char* const* paths, int n, const int64_t* file_off, const int64_t* nbytes, void* base,
-                                  const int64_t* dst_off, int32_t* status, int n_threads) {
+BN_HOST_API int bn_file_read_many_mode(const char* const* paths, int n, const int64_t* file_off, const int64_t* nbytes, void* base,
+                                       const int64_t* dst_off, int32_t* status, int n_threads, int mode) {
     if (n <= 0) return 0;
-    read_args a = {paths, file_off, nbytes, (unsigned char*)base, dst_off, status};
+    read_args a = {paths, file_off, nbytes, (unsigned char*)base, dst_off, status, (mode == BN_READ_PREAD || mode == BN_READ_MMAP) ? mode : read_mode()};
     pool_run(read_item, &a, n, n_threads < 1 ? 1 : n_threads);
     int bad = 0;
     for (int i = 0; i < n; i++) bad += status[i] != BN_IO_OK;
     return bad;
+}
+
+BN_HOST_API int bn_file_read_many(const char* const* paths, int n, const int64_t* file_off, const int64_t* nbytes, void* base,
+                                  const int64_t* dst_off, int32_t* status, int n_threads) {
+    return bn_file_read_many_mode(paths, n, file_off, nbytes, base, dst_off, status, n_threads, -1);
 }
 
 /* memcpy on the pool (pinned <- pageable staging of decoded FLAC windows and the like): n ranges. */

@@ -177,6 +177,13 @@ BN_API int bn_ingest_chunks(bn_ctx* ctx, const float* d_mono, const float* d_pea
                      const int32_t* d_chunk_valid, const int32_t* d_chunk_window, int n_chunks, int chunk_len,
                      float* d_chunks, void* stream);
 
+/* The sorts behind the ranking metrics (reference: sklearn roc_auc_score / average_precision_score, birdnet_stm32/evaluation/metrics.py:155-190,
+ * each of which argsorts on the host): descending, stable orders of the [n_rows, n_classes] float32 score matrix, on the device it lives on.
+ *   d_cols [n_classes, n_rows] int32 — for class c the row indices by descending score of column c
+ *   d_flat [n_rows * n_classes] int32 — flat indices (row * n_classes + class) by descending score
+ * Scores must be finite (the caller checks, as the metrics do).  The workspace lives in the context and grows on demand. */
+BN_API int bn_rank_orders(bn_ctx* ctx, const float* d_scores, int n_rows, int n_classes, int32_t* d_cols, int32_t* d_flat, void* stream);
+
 /* Per-chunk peak normalisation y = x / (max|x| + eps) of the raw frontend's model input (reference:
  * birdnet_stm32/evaluation/metrics.py:62-69, with eps = 1e-6): d_x, d_y [B, T] float32 (may alias). */
 BN_API int bn_chunk_peak_normalize(bn_ctx* ctx, const float* d_x, int B, int T, float eps, float* d_y, void* stream);
@@ -288,6 +295,19 @@ BN_API int bn_get_option(const char* name, int* value);
 BN_API int bn_ctx_set_option(bn_ctx* ctx, const char* name, int value);
 BN_API int bn_ctx_get_option(bn_ctx* ctx, const char* name, int* value);
 BN_API int bn_ctx_reset_options(bn_ctx* ctx);
+
+/* Page-locked host memory for the staging buffers a caller copies audio from (hipHostMalloc / hipHostFree).  Through a foreign-function binding
+ * the call runs WITHOUT the host language's interpreter lock: page-locking 256 MiB takes ~17 ms, and an allocation made through PyTorch's
+ * pinned allocator holds the GIL for all of it — the reader thread of the evaluate pipeline stood still meanwhile (tools/_cold_trace.py).
+ * NULL on failure (bn_last_error).  (Reference counterpart: none — it hands numpy arrays to tf.lite.Interpreter.set_tensor, runners.py:84.) */
+BN_API void* bn_host_alloc_pinned(bn_ctx* ctx, size_t bytes);
+BN_API int bn_host_free_pinned(void* p);
+
+/* Loads every device code object of the library now.  The HIP runtime loads one at the first launch of any of its kernels (a few ms each; launches
+ * and copies of OTHER threads wait meanwhile), which a first batch otherwise pays one file after the other on its critical path; a caller with idle
+ * time before that batch (the evaluate pipeline while the first files are being read) calls this instead.  Idempotent.  (Reference counterpart:
+ * tf.lite.Interpreter.allocate_tensors(), models/runners.py:58 — the one-off preparation before the first invoke.) */
+BN_API int bn_preload_kernels(bn_ctx* ctx);
 
 /* Names of the HIP kernels a forward pass launches, '\n'-separated (for profiling tools). */
 BN_API const char* bn_kernel_names(void);

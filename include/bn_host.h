@@ -51,6 +51,15 @@ int bn_wav_probe_many(const char* const* paths, int n, bn_wav_layout* out, int n
 int bn_file_read_many(const char* const* paths, int n, const int64_t* file_off, const int64_t* nbytes, void* base,
                       const int64_t* dst_off, int32_t* status, int n_threads);
 
+/* How bn_file_read_many takes a window out of the page cache: 0 = pread(), 1 = mmap + MADV_SEQUENTIAL + memcpy (default; the first read of
+ * freshly written files runs 3-4 x faster: no LRU activation under the shared lru lock, csrc/host/bn_pcmio.c).  Process-wide; seeded from
+ * BN_READ_MODE (pread | mmap).  Returns the previous mode; any other argument only queries.  (The reference has one path: libsndfile's read.) */
+int bn_host_set_read_mode(int mode);
+/* bn_file_read_many with the mode of THIS call (0 / 1; anything else = the process default).  The evaluate pipeline reads with pread while
+ * its page-locked slabs are still being registered (that holds the process's mmap lock, which a mapping needs and pread does not). */
+int bn_file_read_many_mode(const char* const* paths, int n, const int64_t* file_off, const int64_t* nbytes, void* base,
+                           const int64_t* dst_off, int32_t* status, int n_threads, int mode);
+
 /* n memcpy()s into the same kind of slab on the same pool (windows that had to be decoded on the host first: FLAC). */
 int bn_copy_many(const void* const* src, int n, const int64_t* nbytes, void* base, const int64_t* dst_off, int n_threads);
 

@@ -129,3 +129,74 @@ def test_pipeline_run_reports_counts_for_unreadable_files(torch_mod, dataset):  
     s0, c0, st0, _ = pipe.run([])
     assert s0.shape[0] == 0 and c0 == [] and st0["chunks"] == 0
     runner.close()
+
+
+def test_pinned_slabs_come_from_the_library_and_are_pooled(torch_mod):
+    """The pipeline's staging slabs: ``bn_host_alloc_pinned`` memory (PyTorch sees it as page-locked, so H2D copies stay asynchronous), handed back to
+    a process-wide pool instead of being freed, reused by the next pipeline, freed by ``release_pinned_slabs``; ``bn_preload_kernels`` is idempotent."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.audio import pipeline as pl
+
+    pl.release_pinned_slabs()
+    ctx = _hip.Context(0, 16)
+    try:
+        ctx.preload_kernels()
+        ctx.preload_kernels()
+        a = pl._PinnedSlab(ctx, 3 << 20, torch)
+        assert a.tensor.is_pinned() and a.tensor.numel() == 3 << 20 and a.tensor.data_ptr() == a.ptr
+        a.tensor[:1024] = torch.arange(1024, dtype=torch.int64).to(torch.uint8)
+        d = torch.empty(1024, dtype=torch.uint8, device="cuda:0")
+        d.copy_(a.tensor[:1024], non_blocking=True)
+        torch.cuda.synchronize()
+        assert torch.equal(d.cpu(), a.tensor[:1024])
+        ptr = a.ptr
+        a.release()
+        assert a.tensor is None and pl._SLAB_POOL == [(ptr, 3 << 20)]
+        b = pl._PinnedSlab(ctx, 1 << 20, torch)      # a pooled slab that is large enough is taken as it is
+        assert b.ptr == ptr and b.nbytes == 3 << 20 and pl._SLAB_POOL == []
+        c = pl._PinnedSlab(ctx, 1 << 20, torch)
+        assert c.ptr != ptr
+        b.release()
+        c.release()
+        assert pl.release_pinned_slabs() == (3 << 20) + (1 << 20) and pl._SLAB_POOL == []
+        with pytest.raises(_hip.HipError):
+            ctx.alloc_pinned(0)
+    finally:
+        ctx.close()
+
+
+def test_rank_orders_sort_like_numpy_and_give_the_librarys_metrics(torch_mod):
+    """``bn_rank_orders`` (the sorts behind ROC-AUC / average precision, reference evaluation/metrics.py:155-190): per class and for the flattened
+    matrix the scores read through the returned orders are non-increasing and every index occurs once; ``ranking_metrics`` through the device sorts
+    equals the host route (numpy's stable sort, which tests/test_host_logic.py holds against scikit-learn) BIT FOR BIT — random scores, heavy ties,
+    constant columns, one row, sizes that are no multiple of anything."""
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.evaluation._ranking import descending_orders, ranking_metrics
+
+    rng = np.random.default_rng(11)
+    ctx = _hip.Context(0, 16)
+    try:
+        for n, c, ties in ((1, 3, False), (257, 7, False), (1024, 100, False), (513, 33, True), (4096, 100, True)):
+            ys = rng.random((n, c), dtype=np.float32)
+            if ties:
+                ys = np.round(ys * 7).astype(np.float32) / 7
+                ys[:, 0] = 0.25
+            yt = (rng.random((n, c)) < 0.1).astype(np.float32)
+            yt[:, -1] = 0                                   # a class without positives
+            cols, flat = descending_orders(ys, ctx)
+            assert cols.shape == (n, c) and flat.shape == (n * c,)
+            for k in range(c):
+                assert np.array_equal(np.sort(cols[:, k]), np.arange(n)) and (np.diff(ys[cols[:, k], k]) <= 0).all()
+            assert np.array_equal(np.sort(flat), np.arange(n * c)) and (np.diff(ys.reshape(-1)[flat]) <= 0).all()
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                host, dev = ranking_metrics(yt, ys), ranking_metrics(yt, ys, ctx=ctx)
+            assert np.array_equal(np.array([host["roc-auc"], host["mAP"], *host["ap_per_class"]]), np.array([dev["roc-auc"], dev["mAP"], *dev["ap_per_class"]]),
+                                  equal_nan=True), (n, c, ties)
+        assert ctx.lib.bn_rank_orders(ctx.handle, None, 4, 0, None, None, None) != 0 and b"score matrix" in ctx.lib.bn_last_error()
+        assert ctx.lib.bn_rank_orders(ctx.handle, None, 4, 3, None, None, None) != 0 and b"null" in ctx.lib.bn_last_error()
+    finally:
+        ctx.close()

@@ -251,6 +251,37 @@ def test_read_windows_and_copy_into_fill_exact_ranges(tmp_path):
     assert np.array_equal(dst[10:343], blobs[4]) and dst[500] == blobs[0][0] and dst[:10].sum() == 0
 
 
+def test_read_modes_give_the_same_bytes_and_status(tmp_path):
+    """The reader's two ways out of the page cache (pread | mmap + MADV_SEQUENTIAL, csrc/host/bn_pcmio.c) fill the same bytes and report the same
+    status: page-unaligned offsets, windows ending exactly at / running past the end of the file, windows below the mmap threshold."""
+    rng = np.random.default_rng(5)
+    sizes = (300000, 65536 + 4097, 1 << 20, 70000, 100)
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8) for n in sizes]
+    paths = []
+    for i, b in enumerate(blobs):
+        (tmp_path / f"m{i}.bin").write_bytes(b.tobytes())
+        paths.append(str(tmp_path / f"m{i}.bin"))
+    foff = np.array([4097, 1, 123457, 3, 0], np.int64)
+    nb = np.array([290000, 65536 + 4096, (1 << 20) - 123457, 70000, 100], np.int64)   # [3] runs 3 bytes past the end: short
+    off = np.concatenate([[0], np.cumsum(nb + 64)[:-1]]).astype(np.int64)
+    prev = _pcmio.set_read_mode(None)
+    try:
+        out = {}
+        for mode in ("pread", "mmap"):
+            assert _pcmio.set_read_mode(mode) in ("pread", "mmap") and _pcmio.set_read_mode(None) == mode
+            buf = np.full(int(off[-1] + nb[-1] + 64), 0xEE, np.uint8)
+            st = _pcmio.read_windows(paths, foff, nb, buf.ctypes.data, off, 3)
+            out[mode] = (st.tolist(), buf)
+        assert out["pread"][0] == out["mmap"][0] == [0, 0, 0, _pcmio.IO_SHORT, 0]
+        assert np.array_equal(out["pread"][1], out["mmap"][1])
+        for i in (0, 1, 2, 4):
+            assert np.array_equal(out["mmap"][1][off[i] : off[i] + nb[i]], blobs[i][foff[i] : foff[i] + nb[i]])
+        with pytest.raises(ValueError):
+            _pcmio.set_read_mode("direct")
+    finally:
+        _pcmio.set_read_mode(prev)
+
+
 def test_cut_groups_limits_and_ramp():
     """Groups are contiguous, respect the slab / chunk limits, and the first three are cut at 1/8, 1/4, 1/2 of a slab (the copy stream starts on a
     small slab); ``ramp=()`` gives full slabs from the start; a file larger than a limit is a group of its own."""

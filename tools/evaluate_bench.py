@@ -114,6 +114,7 @@ def main(argv=None) -> int:
     ap.add_argument("--slab_mb", type=int, default=256)
     ap.add_argument("--no_ramp", action="store_true", help="every group a full slab (A/B of the small first groups)")
     ap.add_argument("--readers", type=int, default=0)
+    ap.add_argument("--read_mode", choices=["mmap", "pread"], default=None, help="A/B of the reader's two ways out of the page cache")
     ap.add_argument("--batch_size", type=int, default=16)
     ap.add_argument("--latency", action="store_true", help="one more run with measure_latency (slices of --batch_size)")
     args = ap.parse_args(argv)
@@ -153,6 +154,8 @@ def main(argv=None) -> int:
             opts["ramp"] = ()
         if args.readers:
             opts["readers"] = args.readers
+        if args.read_mode:
+            opts["read_mode"] = args.read_mode
         runs = []
         ys_ref = None
         for r in range(args.repeats):

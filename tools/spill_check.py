@@ -16,6 +16,8 @@ import sys
 NON_PRODUCTION = [
     r"i8_pwdw_kernel",  # option i8_pwdw (off: measured slower)
     r"i8_mel_mfma_kernel<true, 3>",  # option stft_audit (off: the guarded mixer with the audit of its near misses)
+    r"rocprim::",  # bn_sort.hip: rocPRIM's radix sorts behind the ranking metrics (once per evaluation, not on the per-chunk path); their
+                   # onesweep kernel keeps a 48-byte local array in scratch by design
 ]
 
 
