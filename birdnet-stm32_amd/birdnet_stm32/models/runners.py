@@ -198,10 +198,10 @@ class HipRunner:
 
     def guard_stats(self, B: int) -> dict:
         """Test hook: counters of the exactness pass of the last ``infer_audio_device`` call (INT8 plans)."""
-        out = (ctypes.c_int64 * 7)()
+        out = (ctypes.c_int64 * 8)()
         _hip.check(self.lib.bn_debug_guard_stats(self.model.handle, B, out))
         return {"listed": int(out[0]), "listed_max": int(out[1]), "dirty_blocks": int(out[2]), "whole_minmax": int(out[3]), "whole_fix": int(out[4]),
-                "audited": int(out[5]), "audit_violations": int(out[6])}
+                "audited": int(out[5]), "audit_violations": int(out[6]), "interval_min": int(out[7])}
 
     def tail_form(self) -> tuple[int, int]:
         """Test hook: (form, LDS bytes) of the fused INT8 tail operator this plan can run — 0 none, 1 ``i8_tail_kernel``, 2 also

@@ -51,7 +51,7 @@ const OptName kOptions[] = {
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail}, {"i8_tail_mfdw", &bn::Options::i8_tail_mfdw}, {"i8_mid", &bn::Options::i8_mid},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
-    {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap}, {"stft_guard", &bn::Options::stft_guard}, {"stft_audit", &bn::Options::stft_audit},
+    {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap}, {"stft_guard", &bn::Options::stft_guard}, {"stft_audit", &bn::Options::stft_audit}, {"stft_minint", &bn::Options::stft_minint},
     {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
@@ -206,6 +206,8 @@ bn::StftGuard guard_slice(const bn_model* m, size_t b0) {
     g.rec += b0 * ((W + 15) / 16) * bn::kGuardRec;
     g.count += b0;
     g.dirty += b0;
+    g.mn_lo += b0;
+    g.min_interval = bn::g_opt.stft_minint;
     // every launch group has its own lists and counters (a batch beyond kMaxGridBatch runs the STFT stage of all groups before the plan of the first)
     const size_t group = b0 / kMaxGridBatch;
     g.work += b0 * ((W + 63) / 64);
@@ -1025,13 +1027,13 @@ int bn_model_load(bn_ctx* ctx, const void* blob, size_t nbytes, bn_model** out) 
             off += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_eps = take(mb * W * 4), o_rec = take(mb * n_tiles * bn::kGuardRec * 4), o_list = take(16), o_cnt = take(mb * 4),
+        const size_t o_eps = take(mb * W * 4), o_rec = take(mb * n_tiles * bn::kGuardRec * 4), o_list = take(mb * 4), o_cnt = take(mb * 4),
                      o_dirty = take(mb * 4), o_work = take(mb * t64 * 4), o_nw = take(4 * (mb / kMaxGridBatch + 1)), o_hard = take(2 * mb * 4),
                      o_nh = take(8 * (mb / kMaxGridBatch + 1)), o_audit = take(8);
         if (hipMalloc(&m->d_guard, off) != hipSuccess) return cleanup_fail(fail(BN_ERR_NOMEM, "hipMalloc of %zu exactness-pass bytes failed", off));
         m->workspace_bytes += off;
         char* g = m->d_guard;
-        m->guard = bn::StftGuard{(float*)(g + o_eps), (int*)(g + o_rec), (int*)(g + o_list), (int*)(g + o_cnt), cap, (int*)(g + o_dirty),
+        m->guard = bn::StftGuard{(float*)(g + o_eps), (int*)(g + o_rec), (float*)(g + o_list), (int*)(g + o_cnt), cap, (int*)(g + o_dirty),
                                  (int*)(g + o_work), (int*)(g + o_nw), (int*)(g + o_hard), (int*)(g + o_nh), (int)mb};
         m->d_audit = (int*)(g + o_audit);
     }
@@ -1323,6 +1325,7 @@ int bn_debug_guard_stats(bn_model* m, int B, int64_t* out) {
     HIP_TRY(hipMemcpy(nh, m->guard.n_hard, 2 * sizeof(int), hipMemcpyDeviceToHost));
     int64_t total = 0, mx = 0;
     for (int c : cnt) {
+        c %= m->guard.cap + 1;   // (every workgroup of the mixer that hands its chunk over adds cap + 1: a marker, not elements)
         total += c;
         if (c > mx) mx = c;
     }
@@ -1335,6 +1338,11 @@ int bn_debug_guard_stats(bn_model* m, int B, int64_t* out) {
     if (m->d_audit) HIP_TRY(hipMemcpy(au, m->d_audit, sizeof au, hipMemcpyDeviceToHost));
     out[5] = au[0];
     out[6] = au[1];
+    std::vector<float> lo((size_t)B);   // chunks whose minimum was enclosed in an interval instead of settled (option stft_minint)
+    HIP_TRY(hipMemcpy(lo.data(), m->guard.mn_lo, (size_t)B * sizeof(float), hipMemcpyDeviceToHost));
+    int64_t wide = 0;
+    for (float v : lo) wide += v >= 0.0f;
+    out[7] = wide;
     return BN_OK;
 }
 

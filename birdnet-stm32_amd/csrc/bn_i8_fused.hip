@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     BN_MSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) int lds_raw[];
     __shared__ int flag_n, flags[GUARDED ? kMelFlagCap : 1];
-    __shared__ int audit_n, audit_bad;
+    __shared__ int audit_n, audit_bad, undecided;
     __shared__ std::conditional_t<GUARDED, ExactTabsW, int> xtabs_s;  // float64 twiddles + window for the elements this workgroup re-evaluates itself
     v4i* lds16 = reinterpret_cast<v4i*>(lds_raw);
     const int Kp = a.Cin, W = a.W, M = a.Cout;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     const int chunk = bid / tiles_x, t0 = (bid - chunk * tiles_x) << 6;
     if (GUARDED && tid == 0) {
         flag_n = 0;
-        audit_n = audit_bad = 0;
+        audit_n = audit_bad = undecided = 0;
     }
     if (MODE != 0) __syncthreads();  // (MODE 2: the previous item's tile has been consumed)
     if constexpr (!QIN) {
@@ -560,21 +560,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 crel = kBandRel * (qi.y_rng * qi.y_scale * 1.000001f);
                 const float4 e = *reinterpret_cast<const float4*>(a.qguard.eps + (size_t)chunk * W + t0 + 16 * wv + 4 * ft);
                 const float dsc = qi.y_rng * qi.y_scale * 1.000001f;
+                // The chunk's minimum may be known as an interval only (stft_minmax_exact_kernel: qi.mn is its upper end, mn_lo the lower one).  Moving
+                // the minimum by d moves a quantiser argument by at most d / (range scale) through the difference S - min and by as much again through
+                // the range (v <= 255): the band grows by 2 d / (range scale), evaluated with the smaller range of the upper end (docs/exactness.md).
+                const float mlo = a.qguard.mn_lo[chunk];
+                const float mterm = mlo >= 0.0f ? 2.0f * (qi.mn - mlo) * dsc : 0.0f;
                 // A bound of 0 = the frame's values are exact (zeros, or a chunk recomputed as a whole in float64).  Its band is NOT empty: the
                 // kept bytes come from the folded multiply-add, whose own error (kQuantSlackFolded + the S'-proportional term) can cross a
                 // rounding boundary — those elements are listed like any other and get the exact chain (found by tools/exact_soak.py: with
                 // "nothing to list" for exact frames 304 of 245 812 whole-float64 chunks ended with different scores).
-                const float slack = kQuantSlackFolded * a.qguard.slack_scale;
+                const float slack = kQuantSlackFolded * a.qguard.slack_scale + mterm;
                 dband[0] = 0.5f - (e.x * dsc + slack);
                 dband[1] = 0.5f - (e.y * dsc + slack);
                 dband[2] = 0.5f - (e.z * dsc + slack);
                 dband[3] = 0.5f - (e.w * dsc + slack);
                 if (AUDIT) {   // the audit's band: kAuditBands times as wide
                     const float as = a.qguard.audit_scale * dsc;
-                    aband[0] = 0.5f - kAuditBands * (e.x * as + kQuantSlackFolded);
-                    aband[1] = 0.5f - kAuditBands * (e.y * as + kQuantSlackFolded);
-                    aband[2] = 0.5f - kAuditBands * (e.z * as + kQuantSlackFolded);
-                    aband[3] = 0.5f - kAuditBands * (e.w * as + kQuantSlackFolded);
+                    aband[0] = 0.5f - (kAuditBands * (e.x * as + kQuantSlackFolded) + mterm);
+                    aband[1] = 0.5f - (kAuditBands * (e.y * as + kQuantSlackFolded) + mterm);
+                    aband[2] = 0.5f - (kAuditBands * (e.z * as + kQuantSlackFolded) + mterm);
+                    aband[3] = 0.5f - (kAuditBands * (e.w * as + kQuantSlackFolded) + mterm);
                 }
             }
             // renormalisation and the zero-point fast path are wave-uniform: picked once, outside the per-element code
@@ -707,6 +712,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             const int stride = S16 * 16;
             QuantIn qi;
             qi.set(a.qminmax + 2 * chunk, a.qscale, a.qzp);
+            // interval minimum: the reference's chain v = RN(RN(RN(S - min) / range) / scale), range = RN(RN(max - min) + 1e-10), is made of float32
+            // operations that are each MONOTONE in their operands.  For every float32 minimum inside [lo, hi] the difference lies between the
+            // differences at the two ends and so does the range, hence the quotient lies between the quotients of the four (difference, range)
+            // corner pairs, and so on down the chain: an element whose byte is the same for the smallest and the largest corner value has that byte
+            // whatever the minimum is — no rounding margin involved.  One that has not makes the workgroup hand the chunk over like one with too
+            // many elements in doubt (stft512_f64_list_kernel finds the exact minimum, mode 2 redoes the chunk's blocks).
+            const float mlo = a.qguard.mn_lo[chunk];
+            const bool mint = mlo >= 0.0f;
+            QuantIn qil = qi;
+            if (mint) {
+                const float ends[2] = {mlo, a.qminmax[2 * chunk + 1]};
+                qil.set(ends, a.qscale, a.qzp);
+            }
+            auto decide = [&](float ex, int& q) {
+                if (!mint) {
+                    q = qi.q(ex);
+                    return true;
+                }
+                const float th = ex - qi.mn, tl = ex - qil.mn;   // (qi: the interval's upper end = the smaller difference and range)
+                const float c0 = div_by_const(div_by_const(th, qil.rng, qil.y_rng), qi.scale, qi.y_scale);
+                const float c1 = div_by_const(div_by_const(tl, qi.rng, qi.y_rng), qi.scale, qi.y_scale);
+                const float c2 = div_by_const(div_by_const(th, qi.rng, qi.y_rng), qi.scale, qi.y_scale);
+                const float c3 = div_by_const(div_by_const(tl, qil.rng, qil.y_rng), qi.scale, qi.y_scale);
+                q = quantise_i8(fminf(fminf(c0, c1), fminf(c2, c3)), a.qzp);
+                return q == quantise_i8(fmaxf(fmaxf(c0, c1), fmaxf(c2, c3)), a.qzp);
+            };
             const float* x = a.qguard.audio + (size_t)chunk * a.qguard.T;
             float* Sc = const_cast<float*>(a.qx) + (size_t)chunk * a.qF * W;
             const LdsWindow lw{xt.hann};
@@ -718,16 +749,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 const int t = (e & 0x7fffffff) >> 16, f = e & 0xffff;
                 const float ex = exact_mag_row(xt, lw, x, a.qguard.T, a.qguard.hop, t, f);
                 if (act && gl == 0) {
+                    int qex;
+                    const bool decided = decide(ex, qex);
                     if (near_miss) {   // not in doubt by the bound: the kept byte must already be the exact one
-                        atomicAdd(&audit_n, 1);
-                        if (tile[(t - t0) * stride + f] != (int8_t)qi.q(ex)) atomicAdd(&audit_bad, 1);
+                        if (decided) {
+                            atomicAdd(&audit_n, 1);
+                            if (tile[(t - t0) * stride + f] != (int8_t)qex) atomicAdd(&audit_bad, 1);
+                        }
                     } else {
-                        tile[(t - t0) * stride + f] = (int8_t)qi.q(ex);
+                        if (!decided) undecided = 1;   // (a benign race: every writer stores 1)
+                        tile[(t - t0) * stride + f] = (int8_t)qex;
                         Sc[(size_t)(t / 16) * a.qF * 16 + (size_t)f * 16 + (t % 16)] = ex;  // (tile-major; keeps bn_debug_input_bytes' view consistent)
                     }
                 }
             }
             __syncthreads();
+            if (tid == 0 && undecided) {   // an element whose byte depends on where in its interval the minimum lies: the chunk as a whole in float64
+                atomicAdd(a.qguard.count + chunk, a.qguard.cap + 1);
+                const int all = tiles_x >= 32 ? -1 : (1 << tiles_x) - 1;
+                if (atomicOr(a.qguard.dirty + chunk, all) == 0) {
+                    a.qguard.hard[a.qguard.hard_cap + atomicAdd(a.qguard.n_hard + 1, 1)] = chunk;
+                    for (int i = 0; i < tiles_x; ++i) a.qguard.work[atomicAdd(a.qguard.n_work, 1)] = chunk * tiles_x + i;
+                }
+            }
             if (AUDIT && tid == 0 && a.qguard.audit && audit_n) {
                 atomicAdd(a.qguard.audit, audit_n);
                 if (audit_bad) atomicAdd(a.qguard.audit + 1, audit_bad);

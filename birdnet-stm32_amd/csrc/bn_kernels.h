@@ -55,6 +55,9 @@ struct Options {
                                // end on the float64 routes), 2 = TEST ONLY: the empirical constants / 1024 and no quantiser slack — too small on purpose, so that the audit has something to find
     int stft_audit = 0;        // 1: the guarded mel mixer also re-evaluates in float64 the elements it did NOT flag but that lie within 4 bounds of a rounding
                                // boundary (the near misses) and counts those whose kept byte is wrong — bn_debug_guard_stats out[5] audited, out[6] violations
+    int stft_minint = 1;       // 1: a chunk whose MINIMUM has too many candidates to settle one by one (noise-free tones, chirps, flat spectra: every near-zero bin
+                               // is one) keeps the fast path with the minimum ENCLOSED in an interval that widens the band of doubt (docs/exactness.md);
+                               // 0: such a chunk is recomputed as a whole float64 spectrogram (rounds 3-4)
     int stft_flagcap = 1022;   // elements in doubt a workgroup of the INT8 mel mixer re-evaluates itself before it hands the chunk over (tests lower it)
     int ingest_blk = 0;        // outputs per workgroup of the resampler (0: auto)
     int ingest_generic = 0;    // generic polyphase kernel instead of the phase-per-thread form
@@ -104,13 +107,14 @@ struct StftTables {
 };
 
 // Exactness pass of the INT8 audio path (bn_stft_exact.hip explains the five kernels).
-constexpr int kGuardRec = 128;   // ints per (chunk, 16-frame tile) record: L bits, U bits, n_max, n_min, 30 + 30 thread ids, 4 unused, 30 + 30 values
+constexpr int kGuardRec = 128;   // ints per (chunk, 16-frame tile) record: L bits, U bits, n_max, n_min, 30 + 30 thread ids, lower end of the tile's minimum, 3 unused, 30 + 30 values
 constexpr int kGuardCand = 30;
 constexpr int kGuardBudget = 48;  // float64 re-evaluations stft_minmax_exact_kernel spends on one chunk's extrema before it gives the chunk up
 struct StftGuard {
     float* eps;    // [B][W] per-frame bound on |S' - S|
     int* rec;      // [B][ceil(W / 16)][kGuardRec]
-    int* list;     // (unused since the mel mixer re-evaluates its own elements)
+    float* mn_lo;  // [B] >= 0: stft_minmax_exact_kernel could only ENCLOSE the chunk's minimum (flat / noise-free spectra: too many candidates) —
+                   // minmax[2 b] is an upper end, this the lower end; -1: minmax[2 b] is the exact minimum
     int* count;    // [B] elements found in doubt; > cap: a workgroup of the mixer gave up on the chunk
     int cap;
     int* dirty;    // [B] bit per 64-frame block whose quantised bytes changed
@@ -126,6 +130,7 @@ struct StftGuard {
     int* audit;          // [2] elements audited, violations (option stft_audit; null: no audit)
     float audit_scale;   // the audit's band = kAuditBands x (audit_scale eps + slack): 1, or what the test mode divided the constants by
     float slack_scale;   // 1; 0 in the test mode (stft_guard = 2), which drops the quantiser's own slack as well so that real errors escape the band
+    int min_interval;    // option stft_minint: enclose the minimum instead of giving the chunk up (0: round-4 behaviour)
     int flag_cap;        // elements in doubt a workgroup of the mel mixer keeps (<= its LDS list; option stft_flagcap: tests lower it to reach the give-up path)
 };
 

@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
     float (*mag)[kFT + 1] = reinterpret_cast<float (*)[kFT + 1]>(&xch[0][0]);
     static_assert(sizeof(float) * 257 * (kFT + 1) <= sizeof(float) * kFT * kFS, "magnitude tile must fit the exchange buffer");
     __shared__ float red_min[4], red_max[4];
-    __shared__ float g_red[2][kFT], g_eps[kFT];  // GUARD: per-frame (lower end of the largest, upper end of the smallest element), eps (-1: frame beyond W)
-    __shared__ int g_cnt[2], g_rec[2 * kGuardCand];
-    __shared__ float g_recv[2 * kGuardCand], g_LU[2];
+    __shared__ float g_red[3][kFT], g_eps[kFT];  // GUARD: per-frame (lower end of the largest, upper end of the smallest, lower end of the smallest element), eps (-1: frame beyond W)
+    __shared__ int g_cnt[2], g_rec[2 * kGuardCand], g_arg;
+    __shared__ float g_recv[2 * kGuardCand], g_LU[3];
     // mel mixer tables (MEL_OUT): up to 1024 band-sparse values and 3 x 128 band entries (the launcher refuses more mel bins)
     constexpr int kMelW = MEL_OUT ? 1024 : 1, kMelT = MEL_OUT ? 384 : 1;
     __shared__ float mel_w[kMelW];
@@ -334,16 +334,19 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
             if (j == 0) {
                 g_red[0][f] = live ? guard_lo(peak, eps_f) : 0.0f;
                 g_red[1][f] = live ? guard_hi(low, eps_f) : __uint_as_float(0x7f800000u);
+                g_red[2][f] = live ? guard_lo(low, eps_f) : __uint_as_float(0x7f800000u);   // (guard_lo is monotone: the lower end of the frame's smallest element)
                 g_eps[f] = live ? eps_f : -1.0f;
                 if (live) guard.eps[(size_t)b * W + t] = eps_f;
             }
             if (threadIdx.x < 2) g_cnt[threadIdx.x] = 0;
+            if (threadIdx.x == 2) g_arg = -1;
         }
         __syncthreads();
         if constexpr (GUARD) {
             const float Lt = fmaxf(row16_max(g_red[0][threadIdx.x & 15]), 0.0f), Ut = row16_min(g_red[1][threadIdx.x & 15]);
-            g_LU[0] = Lt;  // (every thread writes the same two values: read back for the record below)
+            g_LU[0] = Lt;  // (every thread writes the same values: read back for the record below)
             g_LU[1] = Ut;
+            g_LU[2] = fmaxf(row16_min(g_red[2][threadIdx.x & 15]), 0.0f);  // no element of the tile lies below this (stft_minmax_exact_kernel: interval minimum)
             // candidates for the chunk's extrema: a THREAD whose largest (smallest) of its 16 bins j + 16 k2 of frame f comes within the
             // bound of the tile's extremum is recorded as (j, f) with the upper (lower) end of what that element can be;
             // stft_minmax_exact_kernel looks at its bins (re-reading the tile here, even only in the waves with a hit, cost 30 us of
@@ -358,6 +361,9 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
                         g_recv[sl] = top;
                     }
                 }
+                // the thread whose smallest element gives the tile's upper end Ut is recorded on its own as well: an overflowing record keeps the first
+                // kGuardCand candidates it meets, and the interval form of the minimum wants THE candidate most likely to be it (any writer will do)
+                if (guard_hi(tmin, e_f) <= Ut) g_arg = threadIdx.x;
                 if (bot <= Ut) {
                     const int sl = atomicAdd(&g_cnt[1], 1);
                     if (sl < kGuardCand) {
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
                 __syncthreads();
                 if (threadIdx.x < kGuardRec) {
                     const int i = threadIdx.x;
-                    const int v = i < 2 ? __float_as_int(g_LU[i]) : i < 4 ? g_cnt[i - 2] : i < 64 ? g_rec[i - 4] : i < 68 ? 0 : __float_as_int(g_recv[i - 68]);
+                    const int v = i < 2 ? __float_as_int(g_LU[i]) : i < 4 ? g_cnt[i - 2] : i < 64 ? g_rec[i - 4] : i == 64 ? __float_as_int(g_LU[2]) : i == 65 ? g_arg : i < 68 ? 0 : __float_as_int(g_recv[i - 68]);
                     guard.rec[((size_t)b * gridDim.x + blockIdx.x) * kGuardRec + i] = v;
                 }
                 return;  // min / max of the chunk: stft_minmax_exact_kernel

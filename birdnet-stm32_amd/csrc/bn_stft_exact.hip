@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
             g.n_hard[1] = 0;
         }
     }
-    float L = 0.0f, U = __uint_as_float(0x7f800000u);
+    float L = 0.0f, U = __uint_as_float(0x7f800000u), Lm = __uint_as_float(0x7f800000u);
     int n_max = 0, n_min = 0;  // lane = tile
     if (lane < n_tiles) {
         const int4 h = *reinterpret_cast<const int4*>(rec + lane * kGuardRec);
@@ -301,36 +301,71 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         U = __int_as_float(h.y);
         n_max = h.z;
         n_min = h.w;
+        Lm = __int_as_float(rec[lane * kGuardRec + 64]);  // no element of the tile lies below this
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         L = fmaxf(L, __shfl_xor(L, off));
         U = fminf(U, __shfl_xor(U, off));
+        Lm = fminf(Lm, __shfl_xor(Lm, off));
     }
     const bool min_is_zero = U == 0.0f;
     if (min_is_zero) n_min = 0;
-    bool hard = __ballot(n_max > kGuardCand || n_min > kGuardCand) != 0;
-    // 1. collect the recorded threads: lane = tile, slot s of its record per step
+    bool hard = __ballot(n_max > kGuardCand) != 0;
+    // The MINIMUM of noise-free or flat spectra has hundreds of candidates (every near-zero bin lies within the bound of every other): settling
+    // them one by one is the whole chunk in float64 (rounds 3-4 did that).  With option stft_minint the minimum is ENCLOSED instead:
+    //     Lm <= min <= Um,   Lm = the smallest lower end guard_lo(S') of any element (K1's records),
+    //                        Um = min(U, the exact values of the few candidates evaluated here)   (the minimum is <= every exact value).
+    // minmax[2 b] = Um, g.mn_lo[b] = Lm; the mel mixer widens its band of doubt by what Um - Lm can move a quantiser argument and decides the
+    // elements it re-evaluates for BOTH ends (i8_mel_mfma_kernel; docs/exactness.md "The minimum as an interval").
+    const bool may_wide = g.min_interval != 0 && !min_is_zero;
+    bool wide = may_wide && __ballot(n_min > kGuardCand) != 0;
+    if (!may_wide && __ballot(n_min > kGuardCand) != 0) hard = true;
+    if (n_min > kGuardCand) n_min = kGuardCand;   // (an overflowing record still holds its first kGuardCand threads: any of them gives an upper end)
+    constexpr int kWideEval = 64;                 // candidates of the minimum evaluated in interval mode: every lane's best — the smallest exact value among
+                                                  // them is the interval's upper end, and the narrower the interval the fewer elements the mixer cannot decide
+    // 1. collect the recorded threads: lane = tile, slot s of its record per step.  Threads of the maximum first (their overflow gives the chunk up),
+    //    then those of the minimum (their overflow only makes the minimum an interval).
     int n_thr = 0;
     for (int s_ = 0; s_ < kGuardCand && !hard; ++s_) {
         // (the record holds, per thread, the upper / lower end of what its extreme element can be: most tiles' entries stop here)
-        if (!__ballot(s_ < n_max || s_ < n_min)) break;
+        if (!__ballot(s_ < n_max)) break;
         const bool p_max = s_ < n_max && __int_as_float(rec[lane * kGuardRec + 68 + s_]) >= L;
-        const bool p_min = s_ < n_min && __int_as_float(rec[lane * kGuardRec + 68 + kGuardCand + s_]) <= U;
-        const unsigned long long m_max = __ballot(p_max), m_min = __ballot(p_min);
+        const unsigned long long m_max = __ballot(p_max);
         const unsigned long long below = (1ull << lane) - 1;
-        if (n_thr + __popcll(m_max) + __popcll(m_min) > kK2Thr) {
+        if (n_thr + __popcll(m_max) > kK2Thr / 2) {
             hard = true;
             break;
         }
         if (p_max) thr[n_thr + __popcll(m_max & below)] = (int)0x80000000 | (lane << 8) | rec[lane * kGuardRec + 4 + s_];
         n_thr += __popcll(m_max);
+    }
+    if (wide && !hard) {   // the threads that gave their tiles' upper ends first (lane = tile): the likeliest holders of the minimum
+        const int arg = lane < n_tiles ? rec[lane * kGuardRec + 65] : -1;
+        const bool p = arg >= 0 && __int_as_float(rec[lane * kGuardRec + 1]) <= U + 4.0f * (U - fmaxf(Lm, 0.0f));   // (tiles whose upper end is near the chunk's)
+        const unsigned long long m = __ballot(p);
+        if (p) thr[n_thr + __popcll(m & ((1ull << lane) - 1))] = (lane << 8) | arg;
+        n_thr += __popcll(m);
+    }
+    for (int s_ = 0; s_ < kGuardCand && !hard; ++s_) {
+        if (!__ballot(s_ < n_min)) break;
+        const bool p_min = s_ < n_min && __int_as_float(rec[lane * kGuardRec + 68 + kGuardCand + s_]) <= U;
+        const unsigned long long m_min = __ballot(p_min);
+        const unsigned long long below = (1ull << lane) - 1;
+        if (n_thr + __popcll(m_min) > kK2Thr) {
+            if (!may_wide) hard = true;
+            wide = may_wide;   // (the threads collected so far are candidates enough)
+            break;
+        }
         if (p_min) thr[n_thr + __popcll(m_min & below)] = (lane << 8) | rec[lane * kGuardRec + 4 + kGuardCand + s_];
         n_thr += __popcll(m_min);
     }
     wave_sync();
-    // 2. their bins against L / U
-    int n_cand = 0;
+    // 2. their bins against L / U: candidates of the maximum from the front of cand[], those of the minimum from the back
+    int n_cmax = 0, n_cmin = 0;
+    constexpr int kCandCap = kGuardBudget + 64;
+    float best_s = __uint_as_float(0x7f800000u);   // interval mode: this lane's candidate of the minimum with the smallest S'
+    int best_code = -1;
     for (int e0 = 0; e0 < n_thr * 17 && !hard; e0 += 64) {
         const int e = e0 + lane;
         bool pred = false;
@@ -343,21 +378,44 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
                 const float s1 = S[spec_offset(W, tile_major != 0, k, t)], ee = eps[t];
                 pred = c < 0 ? (guard_hi(s1, ee) >= L) : (guard_lo(s1, ee) <= U);
                 code = (c & (int)0x80000000) | (t << 16) | k;
+                if (pred && c >= 0 && s1 < best_s) {
+                    best_s = s1;
+                    best_code = code;
+                }
             }
         }
-        const unsigned long long mask = __ballot(pred);
-        const int pos = n_cand + __popcll(mask & ((1ull << lane) - 1));
-        n_cand += __popcll(mask);
-        if (n_cand > kGuardBudget) hard = true;
-        else if (pred) cand[pos] = code;
+        const unsigned long long m_max = __ballot(pred && code < 0), m_min = __ballot(pred && code >= 0);
+        const unsigned long long below = (1ull << lane) - 1;
+        if (n_cmax + __popcll(m_max) > kGuardBudget / 2) hard = true;
+        else if (pred && code < 0) cand[n_cmax + __popcll(m_max & below)] = code;
+        n_cmax += __popcll(m_max);
+        if (!hard && n_cmin < kGuardBudget / 2) {   // (beyond the budget nothing more is kept: the minimum becomes an interval below)
+            const int pos = n_cmin + __popcll(m_min & below);
+            if (pred && code >= 0 && pos < kGuardBudget / 2) cand[kCandCap - 1 - pos] = code;
+        }
+        n_cmin += __popcll(m_min);
+    }
+    if (!hard && n_cmin > kGuardBudget / 2) {
+        if (may_wide) wide = true; else hard = true;
     }
     wave_sync();
+    if (wide && !hard) {
+        // interval mode: every lane's best candidate instead of the first ones met — the smaller the exact values evaluated below, the narrower the
+        // interval, the fewer elements the mel mixer cannot decide (tone + 0.01 % noise: 16 % of the chunks handed over with the first 8, 2 % so)
+        const unsigned long long m = __ballot(best_code >= 0);
+        if (best_code >= 0) cand[kCandCap - 1 - __popcll(m & ((1ull << lane) - 1))] = best_code;
+        n_cmin = __popcll(m);
+        wave_sync();
+    }
     float mx = 0.0f, mn = min_is_zero ? 0.0f : __uint_as_float(0x7f800000u);
     if (!hard) {
         const int grp = lane >> 4, gl = lane & 15;
+        const int keep_min = wide ? (n_cmin < kWideEval ? n_cmin : kWideEval) : n_cmin;   // (interval mode: a few candidates are enough for an upper end)
+        const int n_cand = n_cmax + keep_min;
         for (int c0 = 0; c0 < n_cand; c0 += 4) {
-            const bool act = c0 + grp < n_cand;
-            const int code = act ? cand[c0 + grp] : 0;
+            const int ci = c0 + grp;
+            const bool act = ci < n_cand;
+            const int code = act ? (ci < n_cmax ? cand[ci] : cand[kCandCap - 1 - (ci - n_cmax)]) : 0;
             const int t = (code >> 16) & 0x7fff, k = code & 0xffff;
             const float ex = exact_mag_row(tl, lw, x, T, hop, t, k);
             if (act) {
@@ -370,6 +428,7 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
             mx = fmaxf(mx, __shfl_xor(mx, off));
             mn = fminf(mn, __shfl_xor(mn, off));
         }
+        if (wide) mn = fminf(mn, U);   // U bounds the minimum from above as well
     }
     if (lane == 0) {
         if (hard) {  // the whole chunk in float64 (stft512_f64_list_kernel reduces into minmax)
@@ -379,6 +438,8 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         }
         minmax[2 * b] = mn;
         minmax[2 * b + 1] = mx;
+        // (an interval of width 0 is an exact minimum)
+        g.mn_lo[b] = (!hard && wide && fmaxf(Lm, 0.0f) < mn) ? fmaxf(Lm, 0.0f) : -1.0f;
     }
 }
 

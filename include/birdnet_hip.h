@@ -254,8 +254,9 @@ BN_API int bn_debug_input_bytes(bn_model* model, int B, int8_t* d_out, void* str
  * out[0] elements listed as in doubt (sum over the B chunks), out[1] the largest count of one chunk, out[2] (chunk, 64-frame block) pairs
  * whose bytes changed, out[3] / out[4] chunks recomputed as whole float64 spectrograms behind the min / max pass and behind the fix pass,
  * out[5] / out[6] (option stft_audit = 1) elements the audit re-evaluated although the bound did not put them in doubt — the near misses within
- * four bounds of a rounding boundary — and how many of them had a kept byte different from the exact one (violations of the bound: must be 0).
- * `out` holds 7 values. */
+ * four bounds of a rounding boundary — and how many of them had a kept byte different from the exact one (violations of the bound: must be 0),
+ * out[7] chunks whose minimum the min / max pass enclosed in an interval instead of settling it (option stft_minint; noise-free and flat spectra).
+ * `out` holds 8 values. */
 BN_API int bn_debug_guard_stats(bn_model* model, int B, int64_t* out);
 /* Test hook: which form of the fused INT8 tail operator (BN_OP_I8_TAIL; reference operators #36-#55 of the shipped graph) this model's plan can
  * run — *form = 0 none (per-block operators), 1 = i8_tail_kernel only, 2 = also i8_tail2_kernel (depthwise stage on the matrix cores, the
@@ -282,7 +283,7 @@ BN_API int bn_profile_collect(bn_model* model, double* total_ms, int64_t* launch
 
 /* Run-time switches of the kernel launchers, for A/B measurements and tests (process-wide; the defaults are the production
  * choices).  Names: "f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th",
- * "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw", "i8_mid", "i8_mel_generic", "stft_rowmajor", "stft_exact", "stft_flagcap", "stft_guard", "stft_audit", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
+ * "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw", "i8_mid", "i8_mel_generic", "stft_rowmajor", "stft_exact", "stft_flagcap", "stft_guard", "stft_audit", "stft_minint", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
  * what each selects).  An environment variable BN_<NAME IN CAPITALS> seeds the value once when the library is loaded; no
  * launch reads the environment.  The reference has no counterpart (tf.lite.Interpreter's delegates / num_threads arguments,
  * birdnet_stm32/models/runners.py:57, are the closest thing).  Unknown name: BN_ERR_ARG. */

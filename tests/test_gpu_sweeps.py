@@ -687,13 +687,67 @@ def test_i8_from_audio_whole_float64_chunks_keep_the_exact_bytes(torch_mod):
         with _hip.options(stft_exact=1):
             s1 = runner.infer_audio_device(x).clone()
             q1 = runner.input_bytes(B)
-        s2 = runner.infer_audio_device(x)
-        q2 = runner.input_bytes(B)
-        st = runner.guard_stats(B)
+        with _hip.options(stft_minint=0):   # (the whole-chunk route is what is under test: the interval minimum would keep family 2 off it)
+            s2 = runner.infer_audio_device(x)
+            q2 = runner.input_bytes(B)
+            st = runner.guard_stats(B)
         whole += st["whole_minmax"] + st["whole_fix"]
         assert np.array_equal(q1, q2), f"family {kind}: {int((q1 != q2).sum())} input bytes differ"
         assert torch.equal(s1, s2), f"family {kind}: {int((s1 != s2).any(dim=1).sum())} chunks with different scores"
     assert whole > 500, whole  # (the case under test occurred)
+    runner.close()
+
+
+def test_interval_minimum_keeps_noise_free_chunks_on_the_fast_path(torch_mod):
+    """Chunks whose minimum has hundreds of candidates (noise-free chirps and tones: every near-zero bin is one; a tone 80 dB above its noise) went
+    to the float64 STFT as a whole in rounds 3-4.  With option ``stft_minint`` (default) ``stft_minmax_exact_kernel`` ENCLOSES the minimum
+    (lower end from the error bound, upper end = the smallest exact value among every lane's best candidate), the mel mixer widens its band
+    of doubt by what that interval can move a quantiser argument and decides the elements it re-evaluates at the four corner values of the
+    reference's monotone float32 chain; an element the corners disagree on hands the chunk over (docs/exactness.md).  Checked here: identical
+    input bytes and scores against the all-float64 STFT with the option on and off, the interval form taken by (nearly) every such chunk, and
+    the whole-chunk route by a few per cent of them at most — while ordinary audio never sees an interval."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models.runners import load_model_runner
+
+    B, T, sr = 2048, 72000, 24000
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(2025)
+    t = torch.arange(T, device=dev, dtype=torch.float64) / sr
+
+    def rnd(*shape, lo=0.0, hi=1.0):
+        return lo + (hi - lo) * torch.rand(shape, generator=g, device=dev, dtype=torch.float64)
+
+    runner = load_model_runner(TFLITE_PATH, max_batch=B)
+    for kind in range(3):
+        f0 = rnd(B, 1, lo=60.0, hi=11000.0)
+        noise = torch.randn((B, T), generator=g, device=dev, dtype=torch.float64)
+        if kind == 0:    # linear chirp, noise-free
+            f1 = rnd(B, 1, lo=60.0, hi=11000.0)
+            x = torch.sin(2 * np.pi * (f0 * t[None, :] + (f1 - f0) / (2 * 3.0) * t[None, :] ** 2) + rnd(B, 1, hi=6.28))
+        elif kind == 1:  # tone 80 dB above white noise
+            x = torch.sin(2 * np.pi * f0 * t[None, :] + rnd(B, 1, hi=6.28)) + 1e-4 * noise
+        else:            # ordinary: tone in noise
+            x = torch.sin(2 * np.pi * f0 * t[None, :]) + 0.3 * noise
+        x = (x * 10.0 ** rnd(B, 1, lo=-4.0, hi=0.0)).to(torch.float32).contiguous()
+        with _hip.options(stft_exact=1):
+            s1 = runner.infer_audio_device(x).clone()
+            q1 = runner.input_bytes(B)
+        for minint in (1, 0):
+            with _hip.options(stft_minint=minint):
+                s2 = runner.infer_audio_device(x)
+                q2 = runner.input_bytes(B)
+                st = runner.guard_stats(B)
+            assert np.array_equal(q1, q2), f"family {kind}, stft_minint {minint}: {int((q1 != q2).sum())} input bytes differ"
+            assert torch.equal(s1, s2), f"family {kind}, stft_minint {minint}: {int((s1 != s2).any(dim=1).sum())} chunks with different scores"
+            whole = st["whole_minmax"] + st["whole_fix"]
+            if minint == 0:
+                assert st["interval_min"] == 0
+                assert (whole > 0.9 * B) if kind < 2 else (whole < 0.01 * B), (kind, st)
+            elif kind < 2:
+                assert st["interval_min"] > 0.9 * B and whole < 0.08 * B, (kind, st)
+            else:
+                assert st["interval_min"] < 0.01 * B and whole < 0.01 * B, (kind, st)
     runner.close()
 
 

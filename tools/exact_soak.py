@@ -36,7 +36,8 @@ def batch(kind: int):
 
 
 runner = load_model_runner(TFLITE_PATH, max_batch=B)
-bad_bytes = bad_scores = total = listed = whole = audited = violations = 0
+bad_bytes = bad_scores = total = listed = whole = audited = violations = interval = 0
+whole_by_family = {}
 for i in range(n_batches):
     x = batch(i % 12)
     with _hip.options(stft_exact=1):
@@ -54,9 +55,14 @@ for i in range(n_batches):
     total += B
     listed += st["listed"]
     whole += st["whole_minmax"] + st["whole_fix"]
+    interval += st.get("interval_min", 0)
+    f = whole_by_family.setdefault(i % 12, [0, 0, 0, 0])
+    f[0] += B; f[1] += st["whole_minmax"]; f[2] += st["whole_fix"]; f[3] += st.get("interval_min", 0)
     if d:
         print(f"batch {i} (family {i % 12}): {d} bytes differ", flush=True)
 print(f"exactness soak (seed {seed}, {'proven' if guard == 1 else 'empirical'} bound{', audit on' if audit else ''}): {total} chunks of 12 signal families, {bad_bytes} differing input bytes, {bad_scores} chunks with differing scores; "
       f"{listed / (total * 257 * 256):.2e} of the elements re-evaluated in float64, {whole} chunks as whole float64 spectrograms"
+      + f", {interval} chunks with the minimum as an interval"
       + (f"; audit: {audited} near misses re-evaluated, {violations} violations of the bound" if audit else ""))
+print("per family (chunks, whole float64 behind min/max, behind the mixer, interval minimum):", {k: tuple(v) for k, v in sorted(whole_by_family.items())})
 sys.exit(1 if bad_bytes or bad_scores or violations else 0)
