@@ -107,9 +107,18 @@ struct StftTables {
 };
 
 // Exactness pass of the INT8 audio path (bn_stft_exact.hip explains the five kernels).
-constexpr int kGuardRec = 128;   // ints per (chunk, 16-frame tile) record: L bits, U bits, n_max, n_min, 30 + 30 thread ids, lower end of the tile's minimum, 3 unused, 30 + 30 values
-constexpr int kGuardCand = 30;
-constexpr int kGuardBudget = 48;  // float64 re-evaluations stft_minmax_exact_kernel spends on one chunk's extrema before it gives the chunk up
+// Record of one (chunk, 16-frame tile) of stft512_mag_kernel<., GUARD> for stft_minmax_exact_kernel, in ints:
+//   [0] L bits  [1] U bits  [2] n_max  [3] n_min   (lower end of the tile's largest element, upper end of its smallest, candidate threads counted)
+//   [kRecIds ..)   kGuardCand thread ids of the maximum, then kGuardCand of the minimum
+//   [kRecExtra ..) lower end of the tile's smallest element (bits), the thread that gave U, 2 unused
+//   [kRecVals ..)  per recorded thread the upper (maximum) / lower (minimum) end of what its extreme element can be
+// kGuardCand = 62 (round 5; 30 before): a STATIONARY tone has every frame's peak within the bound of every other's — 16 frames x 2-4 threads of a
+// tile are candidates of the maximum, and an overflowing record gave such chunks to the float64 STFT as a whole.
+constexpr int kGuardCand = 62;
+constexpr int kRecIds = 4, kRecExtra = kRecIds + 2 * kGuardCand, kRecVals = kRecExtra + 4;
+constexpr int kGuardRec = kRecVals + 2 * kGuardCand;   // 256
+constexpr int kGuardBudget = 48;    // candidates of the MINIMUM stft_minmax_exact_kernel settles one by one (half of it) before it encloses the minimum in an interval
+constexpr int kGuardMaxBudget = 1024;   // float64 re-evaluations it spends on a chunk's MAXIMUM before it gives the chunk up (a wave per chunk: ~1.3 us per four)
 struct StftGuard {
     float* eps;    // [B][W] per-frame bound on |S' - S|
     int* rec;      // [B][ceil(W / 16)][kGuardRec]

@@ -390,9 +390,11 @@ __global__ __launch_bounds__(256) void stft512_mag_kernel(StftTables tb, const f
             }
             if constexpr (GUARD) {
                 __syncthreads();
+                static_assert(kGuardRec <= 256, "one record entry per thread");
                 if (threadIdx.x < kGuardRec) {
                     const int i = threadIdx.x;
-                    const int v = i < 2 ? __float_as_int(g_LU[i]) : i < 4 ? g_cnt[i - 2] : i < 64 ? g_rec[i - 4] : i == 64 ? __float_as_int(g_LU[2]) : i == 65 ? g_arg : i < 68 ? 0 : __float_as_int(g_recv[i - 68]);
+                    const int v = i < 2 ? __float_as_int(g_LU[i]) : i < kRecIds ? g_cnt[i - 2] : i < kRecExtra ? g_rec[i - kRecIds]
+                                : i == kRecExtra ? __float_as_int(g_LU[2]) : i == kRecExtra + 1 ? g_arg : i < kRecVals ? 0 : __float_as_int(g_recv[i - kRecVals]);
                     guard.rec[((size_t)b * gridDim.x + blockIdx.x) * kGuardRec + i] = v;
                 }
                 return;  // min / max of the chunk: stft_minmax_exact_kernel

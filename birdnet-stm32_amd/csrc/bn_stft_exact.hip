@@ -265,15 +265,16 @@ __global__ __launch_bounds__(256, 3) void stft512_f64_list_kernel(StftTables tb,
 // came within the bound of the tile's extremum; the lanes test those threads' bins against L / U in parallel and the few that pass
 // are re-evaluated in float64 four at a time.  A chunk with more than kGuardBudget of them (or an overflowing record: flat spectra,
 // pure stationary tones, signals far below the bound) goes to stft512_f64_list_kernel as a whole.
-constexpr int kK2Thr = 192;  // candidate threads a wave keeps
+constexpr int kK2Thr = 192;      // candidate threads of the minimum a wave keeps
+constexpr int kK2MaxThr = 1024;  // ... of the maximum (64 tiles x kGuardCand at most)
 __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
                                                                 float* __restrict__ spec, int tile_major, StftGuard g, int n_tiles,
                                                                 float* __restrict__ minmax, int B) {
     __shared__ ExactTabs tl;
     LaneWindow lw;
     lw.load(tb);
-    __shared__ int cand_s[4][kGuardBudget + 64];  // passing candidates: is_max << 31 | frame << 16 | bin
-    __shared__ int thr_s[4][kK2Thr + 64];         // candidate threads: is_max << 31 | tile << 8 | thread id
+    __shared__ int cand_s[4][kGuardMaxBudget + 64 + 64];  // passing candidates: is_max << 31 | frame << 16 | bin (maximum from the front, minimum from the back)
+    __shared__ int thr_s[4][kK2MaxThr + kK2Thr + 64];     // candidate threads: is_max << 31 | tile << 8 | thread id
     stage_tabs(tl, tb);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         U = __int_as_float(h.y);
         n_max = h.z;
         n_min = h.w;
-        Lm = __int_as_float(rec[lane * kGuardRec + 64]);  // no element of the tile lies below this
+        Lm = __int_as_float(rec[lane * kGuardRec + kRecExtra]);  // no element of the tile lies below this
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -330,18 +331,19 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
     for (int s_ = 0; s_ < kGuardCand && !hard; ++s_) {
         // (the record holds, per thread, the upper / lower end of what its extreme element can be: most tiles' entries stop here)
         if (!__ballot(s_ < n_max)) break;
-        const bool p_max = s_ < n_max && __int_as_float(rec[lane * kGuardRec + 68 + s_]) >= L;
+        const bool p_max = s_ < n_max && __int_as_float(rec[lane * kGuardRec + kRecVals + s_]) >= L;
         const unsigned long long m_max = __ballot(p_max);
         const unsigned long long below = (1ull << lane) - 1;
-        if (n_thr + __popcll(m_max) > kK2Thr / 2) {
+        if (n_thr + __popcll(m_max) > kK2MaxThr) {
             hard = true;
             break;
         }
-        if (p_max) thr[n_thr + __popcll(m_max & below)] = (int)0x80000000 | (lane << 8) | rec[lane * kGuardRec + 4 + s_];
+        if (p_max) thr[n_thr + __popcll(m_max & below)] = (int)0x80000000 | (lane << 8) | rec[lane * kGuardRec + kRecIds + s_];
         n_thr += __popcll(m_max);
     }
+    const int n_thr_max = n_thr;
     if (wide && !hard) {   // the threads that gave their tiles' upper ends first (lane = tile): the likeliest holders of the minimum
-        const int arg = lane < n_tiles ? rec[lane * kGuardRec + 65] : -1;
+        const int arg = lane < n_tiles ? rec[lane * kGuardRec + kRecExtra + 1] : -1;
         const bool p = arg >= 0 && __int_as_float(rec[lane * kGuardRec + 1]) <= U + 4.0f * (U - fmaxf(Lm, 0.0f));   // (tiles whose upper end is near the chunk's)
         const unsigned long long m = __ballot(p);
         if (p) thr[n_thr + __popcll(m & ((1ull << lane) - 1))] = (lane << 8) | arg;
@@ -349,21 +351,21 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
     }
     for (int s_ = 0; s_ < kGuardCand && !hard; ++s_) {
         if (!__ballot(s_ < n_min)) break;
-        const bool p_min = s_ < n_min && __int_as_float(rec[lane * kGuardRec + 68 + kGuardCand + s_]) <= U;
+        const bool p_min = s_ < n_min && __int_as_float(rec[lane * kGuardRec + kRecVals + kGuardCand + s_]) <= U;
         const unsigned long long m_min = __ballot(p_min);
         const unsigned long long below = (1ull << lane) - 1;
-        if (n_thr + __popcll(m_min) > kK2Thr) {
+        if (n_thr - n_thr_max + __popcll(m_min) > kK2Thr) {
             if (!may_wide) hard = true;
             wide = may_wide;   // (the threads collected so far are candidates enough)
             break;
         }
-        if (p_min) thr[n_thr + __popcll(m_min & below)] = (lane << 8) | rec[lane * kGuardRec + 4 + kGuardCand + s_];
+        if (p_min) thr[n_thr + __popcll(m_min & below)] = (lane << 8) | rec[lane * kGuardRec + kRecIds + kGuardCand + s_];
         n_thr += __popcll(m_min);
     }
     wave_sync();
     // 2. their bins against L / U: candidates of the maximum from the front of cand[], those of the minimum from the back
     int n_cmax = 0, n_cmin = 0;
-    constexpr int kCandCap = kGuardBudget + 64;
+    constexpr int kCandCap = kGuardMaxBudget + 64 + 64;
     float best_s = __uint_as_float(0x7f800000u);   // interval mode: this lane's candidate of the minimum with the smallest S'
     int best_code = -1;
     for (int e0 = 0; e0 < n_thr * 17 && !hard; e0 += 64) {
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         }
         const unsigned long long m_max = __ballot(pred && code < 0), m_min = __ballot(pred && code >= 0);
         const unsigned long long below = (1ull << lane) - 1;
-        if (n_cmax + __popcll(m_max) > kGuardBudget / 2) hard = true;
+        if (n_cmax + __popcll(m_max) > kGuardMaxBudget) hard = true;
         else if (pred && code < 0) cand[n_cmax + __popcll(m_max & below)] = code;
         n_cmax += __popcll(m_max);
         if (!hard && n_cmin < kGuardBudget / 2) {   // (beyond the budget nothing more is kept: the minimum becomes an interval below)

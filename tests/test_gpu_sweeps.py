@@ -201,13 +201,19 @@ def test_i8_from_audio_2048_chunks_bit_exact(torch_mod):
                 st = runner.guard_stats(N)
                 print(f"exactness pass, {N} chunks: {st['listed'] / (N * q_gpu.shape[1]):.2e} of the elements recomputed in float64, "
                       f"{st['dirty_blocks']} (chunk, 64-frame block) pairs changed, {st['whole_minmax']} + {st['whole_fix']} chunks as whole float64 spectrograms")
-                assert st["whole_minmax"] >= 3 and st["listed"] < 2e-3 * N * q_gpu.shape[1]
+                # (the pathological chunks: their minimum enclosed in an interval since round 5 — the whole-chunk route is taken below, with stft_minint = 0)
+                assert st["interval_min"] + st["whole_minmax"] >= 3 and st["listed"] < 2e-3 * N * q_gpu.shape[1]
         flipped = int((q_gpu != ref_q).sum())
         assert flipped == 0, f"stft_exact={mode}: {flipped} quantised input bytes differ from the oracle's"
         got_fc = np.rint(logits / np.float32(s_fc)).astype(np.int32) + z_fc
         assert np.array_equal(got_fc, ref_fc), f"stft_exact={mode}: pre-sigmoid bytes differ"
         assert np.array_equal(scores, ref_scores), f"stft_exact={mode}: scores differ"
         assert (got_fc.argmax(axis=1) == ref_fc.argmax(axis=1)).all()
+    with _hip.options(stft_minint=0):  # rounds 3-4: chunks whose extrema have too many candidates as whole float64 spectrograms — same bytes, same scores
+        scores = runner.infer_audio_device(d_audio).cpu().numpy()
+        st = runner.guard_stats(N)
+        assert st["whole_minmax"] >= 3 and st["interval_min"] == 0
+        assert int((runner.input_bytes(N).reshape(N, -1) != ref_q).sum()) == 0 and np.array_equal(scores, ref_scores)
     # the give-up route of the mixer (a workgroup with more elements in doubt than it keeps — here forced by keeping at most 2): those chunks
     # are recomputed as whole float64 spectrograms and all their blocks run through the mixer once more; same bytes, same scores
     with _hip.options(stft_flagcap=2):
