@@ -274,14 +274,16 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
     LaneWindow lw;
     lw.load(tb);
     __shared__ int cand_s[4][kGuardMaxBudget + 64 + 64];  // passing candidates: is_max << 31 | frame << 16 | bin (maximum from the front, minimum from the back)
-    __shared__ int thr_s[4][kK2MaxThr + kK2Thr + 64];     // candidate threads: is_max << 31 | tile << 8 | thread id
+    __shared__ unsigned short thr_s[4][kK2MaxThr + kK2Thr + 64];   // candidate threads: tile << 8 | thread id; those of the maximum first (n_thr_max of them).
+                                                                   // 16 bits each: with 32 the arrays of this kernel left room for three workgroups per CU —
+                                                                   // 768 of a 4096-chunk launch's 1024, i.e. a second scheduling round (22 -> 27 us)
     stage_tabs(tl, tb);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;
     int* cand = cand_s[wave];
-    int* thr = thr_s[wave];
+    unsigned short* thr = thr_s[wave];
     const float* x = audio + (size_t)b * T;
     float* S = spec + (size_t)b * 257 * W;
     const float* eps = g.eps + (size_t)b * W;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
             hard = true;
             break;
         }
-        if (p_max) thr[n_thr + __popcll(m_max & below)] = (int)0x80000000 | (lane << 8) | rec[lane * kGuardRec + kRecIds + s_];
+        if (p_max) thr[n_thr + __popcll(m_max & below)] = (unsigned short)((lane << 8) | rec[lane * kGuardRec + kRecIds + s_]);
         n_thr += __popcll(m_max);
     }
     const int n_thr_max = n_thr;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         const int arg = lane < n_tiles ? rec[lane * kGuardRec + kRecExtra + 1] : -1;
         const bool p = arg >= 0 && __int_as_float(rec[lane * kGuardRec + 1]) <= U + 4.0f * (U - fmaxf(Lm, 0.0f));   // (tiles whose upper end is near the chunk's)
         const unsigned long long m = __ballot(p);
-        if (p) thr[n_thr + __popcll(m & ((1ull << lane) - 1))] = (lane << 8) | arg;
+        if (p) thr[n_thr + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)((lane << 8) | arg);
         n_thr += __popcll(m);
     }
     for (int s_ = 0; s_ < kGuardCand && !hard; ++s_) {
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
             wide = may_wide;   // (the threads collected so far are candidates enough)
             break;
         }
-        if (p_min) thr[n_thr + __popcll(m_min & below)] = (lane << 8) | rec[lane * kGuardRec + kRecIds + kGuardCand + s_];
+        if (p_min) thr[n_thr + __popcll(m_min & below)] = (unsigned short)((lane << 8) | rec[lane * kGuardRec + kRecIds + kGuardCand + s_]);
         n_thr += __popcll(m_min);
     }
     wave_sync();
@@ -374,13 +376,14 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         int code = 0;
         if (e < n_thr * 17) {
             const int c = thr[e / 17], k2 = e % 17;
-            const int id = c & 0xff, tile = (c >> 8) & 0x7fff, j = id & 15, t = tile * kFT + (id >> 4);
+            const bool is_max = e / 17 < n_thr_max;
+            const int id = c & 0xff, tile = c >> 8, j = id & 15, t = tile * kFT + (id >> 4);
             const int k = j + 16 * k2;
             if (k2 < 16 || j == 0) {
                 const float s1 = S[spec_offset(W, tile_major != 0, k, t)], ee = eps[t];
-                pred = c < 0 ? (guard_hi(s1, ee) >= L) : (guard_lo(s1, ee) <= U);
-                code = (c & (int)0x80000000) | (t << 16) | k;
-                if (pred && c >= 0 && s1 < best_s) {
+                pred = is_max ? (guard_hi(s1, ee) >= L) : (guard_lo(s1, ee) <= U);
+                code = (is_max ? (int)0x80000000 : 0) | (t << 16) | k;
+                if (pred && !is_max && s1 < best_s) {
                     best_s = s1;
                     best_code = code;
                 }
