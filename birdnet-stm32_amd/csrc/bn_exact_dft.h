@@ -75,38 +75,55 @@ struct GlobalWindow {
     __device__ __forceinline__ double at(int i) const { return fma(-0.5, cs2[(threadIdx.x & 15) + 16 * i].x, 0.5); }
 };
 
-template <class Tabs, class Window>
-__device__ __forceinline__ float exact_mag_row(const Tabs& tl, const Window& lw, const float* __restrict__ x, int T, int hop, int t, int k) {
-#pragma clang fp contract(off)
+// The frame's samples a lane needs: n = gl + 16 i and their mirror partners 512 - n (n = 0 pairs with 256).
+struct RowSamples {
+    float xa[16], xb[16];
+};
+__device__ __forceinline__ void exact_row_load(RowSamples& r, const float* __restrict__ x, int T, int hop, int t) {
     const int gl = threadIdx.x & 15;
     // range-checked raw buffer loads over exactly this chunk: samples before / behind it read as 0 (librosa's centre padding) with no
     // branch around the load, so all 32 loads of a lane are in flight together (as conditional loads they ran one round trip at a time:
     // 20 us per element)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, T * 4, 0x00020000);
     const int base = (t * hop - 256) * 4;  // byte offset of the frame's first sample (negative = out of range as unsigned)
-    float xa[16], xb[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int n = gl + 16 * i;
-        xa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * n, 0, 0));
-        xb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * (n == 0 ? 256 : 512 - n), 0, 0));
+        r.xa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * n, 0, 0));
+        r.xb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4 * (n == 0 ? 256 : 512 - n), 0, 0));
     }
+}
+// SPLIT: the sixteen terms in two groups of eight as far as the scheduler is concerned (half the twiddles and window values in flight at a time:
+// for a caller that keeps a second sample set in registers); same operations in the same order.
+template <bool SPLIT = false, class Tabs, class Window>
+__device__ __forceinline__ float exact_row_value(const Tabs& tl, const Window& lw, const RowSamples& r, int k) {
+#pragma clang fp contract(off)
+    const int gl = threadIdx.x & 15;
     double re = 0.0, im = 0.0;
     int idx = k * gl;  // k n mod 512, n = gl + 16 i
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const double w = lw.at(i);
-        const double va = (double)xa[i] * w;
-        double vb = (double)xb[i] * ((i == 0 && gl == 0) ? 1.0 : w);  // n = 0 pairs with n = 256: hann[256] = 1
+        const double va = (double)r.xa[i] * w;
+        double vb = (double)r.xb[i] * ((i == 0 && gl == 0) ? 1.0 : w);  // n = 0 pairs with n = 256: hann[256] = 1
         if (i == 0 && gl == 0 && (k & 1)) vb = -vb;
         const double2 c = twiddle(tl, idx & 511);
         re = fma(va + vb, c.x, re);
         im = fma(va - vb, c.y, im);
         idx += 16 * k;
+        if (SPLIT && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     re = row16_sum_d(re);
     im = row16_sum_d(im);
     return numpy_cabsf((float)re, (float)im);
+}
+// (load + value in one: the callers that evaluate a handful of elements; stft_minmax_exact_kernel, which may walk hundreds, requests the next
+// element's samples before it evaluates the current one)
+template <class Tabs, class Window>
+__device__ __forceinline__ float exact_mag_row(const Tabs& tl, const Window& lw, const float* __restrict__ x, int T, int hop, int t, int k) {
+    RowSamples r;
+    exact_row_load(r, x, T, hop, t);
+    return exact_row_value(tl, lw, r, k);
 }
 
 }  // namespace bn

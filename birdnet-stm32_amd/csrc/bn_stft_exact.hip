@@ -267,12 +267,11 @@ __global__ __launch_bounds__(256, 3) void stft512_f64_list_kernel(StftTables tb,
 // pure stationary tones, signals far below the bound) goes to stft512_f64_list_kernel as a whole.
 constexpr int kK2Thr = 192;      // candidate threads of the minimum a wave keeps
 constexpr int kK2MaxThr = 1024;  // ... of the maximum (64 tiles x kGuardCand at most)
-__global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_minmax_exact_kernel(StftTables tb, const float* __restrict__ audio, int T, int hop, int W,
                                                                 float* __restrict__ spec, int tile_major, StftGuard g, int n_tiles,
                                                                 float* __restrict__ minmax, int B) {
-    __shared__ ExactTabs tl;
-    LaneWindow lw;
-    lw.load(tb);
+    __shared__ ExactTabsW tl;          // (the window from LDS at each use: in registers it costs the 32 that the second sample set below needs)
+    const LdsWindow lw{tl.hann};
     __shared__ int cand_s[4][kGuardMaxBudget + 64 + 64];  // passing candidates: is_max << 31 | frame << 16 | bin (maximum from the front, minimum from the back)
     __shared__ unsigned short thr_s[4][kK2MaxThr + kK2Thr + 64];   // candidate threads: tile << 8 | thread id; those of the maximum first (n_thr_max of them).
                                                                    // 16 bits each: with 32 the arrays of this kernel left room for three workgroups per CU —
@@ -312,6 +311,10 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         U = fminf(U, __shfl_xor(U, off));
         Lm = fminf(Lm, __shfl_xor(Lm, off));
     }
+    // (wave-uniform after the reductions: kept in scalar registers — the evaluation loop below runs at the register cap)
+    L = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(L)));
+    U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(U)));
+    Lm = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Lm)));
     const bool min_is_zero = U == 0.0f;
     if (min_is_zero) n_min = 0;
     bool hard = __ballot(n_max > kGuardCand) != 0;
@@ -417,21 +420,38 @@ __global__ __launch_bounds__(256) void stft_minmax_exact_kernel(StftTables tb, c
         const int grp = lane >> 4, gl = lane & 15;
         const int keep_min = wide ? (n_cmin < kWideEval ? n_cmin : kWideEval) : n_cmin;   // (interval mode: a few candidates are enough for an upper end)
         const int n_cand = n_cmax + keep_min;
-        for (int c0 = 0; c0 < n_cand; c0 += 4) {
-            const int ci = c0 + grp;
-            const bool act = ci < n_cand;
-            const int code = act ? (ci < n_cmax ? cand[ci] : cand[kCandCap - 1 - (ci - n_cmax)]) : 0;
-            const int t = (code >> 16) & 0x7fff, k = code & 0xffff;
-            const float ex = exact_mag_row(tl, lw, x, T, hop, t, k);
-            if (act) {
-                if (gl == 0) S[spec_offset(W, tile_major != 0, k, t)] = ex;
-                if (code < 0) mx = fmaxf(mx, ex); else mn = fminf(mn, ex);
+        // Four candidates per round (a 16-lane row each).  A stationary tone has hundreds of candidates of the maximum and a round is one dependent
+        // round trip to memory: the samples of round r + 1 are requested before round r is evaluated (two sample sets, alternating; the values and
+        // their summation order are those of exact_mag_row).
+        auto code_of = [&](int ci) { return ci < n_cand ? (ci < n_cmax ? cand[ci] : cand[kCandCap - 1 - (ci - n_cmax)]) : 0; };
+        RowSamples rs[2];
+        exact_row_load(rs[0], x, T, hop, (code_of(grp) >> 16) & 0x7fff);
+        for (int c0 = 0; c0 < n_cand; c0 += 8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ci = c0 + 4 * h + grp;
+                if (c0 + 4 * h >= n_cand) break;   // (wave-uniform)
+                const bool act = ci < n_cand;
+                const int code = code_of(ci);
+                const int t = (code >> 16) & 0x7fff, k = code & 0xffff;
+                if (c0 + 4 * h + 4 < n_cand) exact_row_load(rs[h ^ 1], x, T, hop, (code_of(ci + 4) >> 16) & 0x7fff);
+                __builtin_amdgcn_sched_barrier(0);   // (requests first, then this round's arithmetic: merged, the two rounds need 167 registers)
+                const float ex = exact_row_value<true>(tl, lw, rs[h], k);
+                __builtin_amdgcn_sched_barrier(0);
+                if (act) {
+                    if (gl == 0) S[spec_offset(W, tile_major != 0, k, t)] = ex;
+                    if (code < 0) mx = fmaxf(mx, ex); else mn = fminf(mn, ex);
+                }
             }
         }
+        // (the permute addresses of this reduction are rebuilt from an opaque copy of the lane id: shared with the reduction at the top of the
+        // kernel they stay live across the loop above and are the three registers that spill at the cap)
+        int lane_b = lane;
+        asm volatile("" : "+v"(lane_b));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            mx = fmaxf(mx, __shfl_xor(mx, off));
-            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_ds_bpermute((lane_b ^ off) << 2, __float_as_int(mx))));
+            mn = fminf(mn, __int_as_float(__builtin_amdgcn_ds_bpermute((lane_b ^ off) << 2, __float_as_int(mn))));
         }
         if (wide) mn = fminf(mn, U);   // U bounds the minimum from above as well
     }
