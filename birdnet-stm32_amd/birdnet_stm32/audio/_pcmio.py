@@ -54,14 +54,33 @@ def local_world_size() -> int:
         return 1
 
 
+def cgroup_cpu_quota(root: str = "/sys/fs/cgroup") -> int | None:
+    """CPUs the container's cgroup lets this process use at once (``cpu.max`` of cgroup v2, ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us`` of v1,
+    rounded up), or None without a quota.  The affinity mask does not show it: the timing box of round 5 lists 256 CPUs and grants 16."""
+    try:
+        quota, period = open(os.path.join(root, "cpu.max")).read().split()[:2]
+        return None if quota == "max" else max(1, -(-int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open(os.path.join(root, "cpu", "cpu.cfs_quota_us")).read())
+        period = int(open(os.path.join(root, "cpu", "cpu.cfs_period_us")).read())
+        return max(1, -(-quota // period)) if quota > 0 and period > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def default_threads() -> int:
-    """Reader threads of this process: its share of the CPUs it may run on — the affinity mask divided by the ranks on this host — at most
-    16 (what one GPU's PCIe link can use), at least 2.  Eight ranks on a 128-thread host get 16 each, on a 64-thread host 8: the reader
-    pools of a node never oversubscribe it."""
+    """Reader threads of this process: its share of the CPUs it may run on — the affinity mask, capped by the cgroup's CPU quota, divided by the
+    ranks on this host — at most 16 (what one GPU's PCIe link can use), at least 2.  Eight ranks on a 128-thread host get 16 each, on a
+    64-thread host (or under a 64-CPU quota) 8: the reader pools of a node never oversubscribe it."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
         n = os.cpu_count() or 2
+    quota = cgroup_cpu_quota()
+    if quota is not None:
+        n = min(n, quota)
     return max(2, min(16, n // local_world_size()))
 
 

@@ -251,6 +251,33 @@ def test_read_windows_and_copy_into_fill_exact_ranges(tmp_path):
     assert np.array_equal(dst[10:343], blobs[4]) and dst[500] == blobs[0][0] and dst[:10].sum() == 0
 
 
+def test_reader_share_honours_the_cgroup_cpu_quota(tmp_path, monkeypatch):
+    """A container's CPU quota does not show in the affinity mask (the timing box: 256 CPUs listed, 16 granted): ``cgroup_cpu_quota`` reads it from
+    cgroup v2's ``cpu.max`` or v1's ``cpu.cfs_*`` (rounded up; no quota = None) and ``default_threads`` divides min(affinity, quota) by the ranks
+    on the host."""
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("1600000 100000\n")
+    assert _pcmio.cgroup_cpu_quota(str(v2)) == 16
+    (v2 / "cpu.max").write_text("150000 100000\n")
+    assert _pcmio.cgroup_cpu_quota(str(v2)) == 2
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert _pcmio.cgroup_cpu_quota(str(v2)) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("800000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert _pcmio.cgroup_cpu_quota(str(v1)) == 8
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert _pcmio.cgroup_cpu_quota(str(v1)) is None
+    assert _pcmio.cgroup_cpu_quota(str(tmp_path / "none")) is None
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    for quota, world, want in ((16, 1, 16), (16, 8, 2), (64, 8, 8), (None, 8, 16), (None, 64, 4), (4, 1, 4)):
+        monkeypatch.setattr(_pcmio, "cgroup_cpu_quota", lambda root="": quota)
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(world))
+        assert _pcmio.default_threads() == want, (quota, world)
+
+
 def test_read_modes_give_the_same_bytes_and_status(tmp_path):
     """The reader's two ways out of the page cache (pread | mmap + MADV_SEQUENTIAL, csrc/host/bn_pcmio.c) fill the same bytes and report the same
     status: page-unaligned offsets, windows ending exactly at / running past the end of the file, windows below the mmap threshold."""
