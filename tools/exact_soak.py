@@ -60,6 +60,8 @@ for i in range(n_batches):
     f[0] += B; f[1] += st["whole_minmax"]; f[2] += st["whole_fix"]; f[3] += st.get("interval_min", 0)
     if d:
         print(f"batch {i} (family {i % 12}): {d} bytes differ", flush=True)
+    if i % 60 == 59:   # (a long soak shows it is alive: the GPU runner takes several silent minutes for a hang)
+        print(f"... {total} chunks, {bad_bytes} differing bytes so far", flush=True)
 print(f"exactness soak (seed {seed}, {'proven' if guard == 1 else 'empirical'} bound{', audit on' if audit else ''}): {total} chunks of 12 signal families, {bad_bytes} differing input bytes, {bad_scores} chunks with differing scores; "
       f"{listed / (total * 257 * 256):.2e} of the elements re-evaluated in float64, {whole} chunks as whole float64 spectrograms"
       + f", {interval} chunks with the minimum as an interval"
