@@ -89,7 +89,8 @@ def kernel_symbol(kind: str, p: list) -> str:
     if kind == "i8_mid":
         return "i8_mid2_kernel"
     if kind == "i8_dwpw" and p[35]:
-        return "i8_strip_kernel"
+        # (32 -> 32 channels, stride 1, residual ADD — stage1_ds2 of the shipped graph: the strip kernel with the depthwise stage on the matrix cores)
+        return "i8_strip_mf_kernel" if (p[2] == 32 and p[14] == 32 and p[3] == 1 and p[18]) else "i8_strip_kernel"
     if kind == "i8_dwpw" and p[30] and p[14] == 64:
         return "i8_mel_mfma_kernel"
     if kind == "i8_front" and p[16]:
@@ -143,7 +144,7 @@ def algorithmic_work(row: dict, batch: int, dtype: str) -> tuple[float, float, f
     if k == "i8_dwpw":
         n_in, n_out = p[0] * p[1] * p[2], p[6] * p[7] * p[14]
         macs = p[6] * p[7] * p[2] * (p[14] + (9 if p[29] else 0))
-        res = 1 if (p[18] and sym != "i8_strip_kernel") else 0
+        res = 1 if (p[18] and sym not in ("i8_strip_kernel", "i8_strip_mf_kernel")) else 0
         return batch * 1.0 * (n_in + n_out * (1 + res)), batch * 2.0 * macs, batch * 2.0 * p[6] * p[7] * p[2] * p[14]
     if k == "i8_mid":  # p: in_bytes pw_macs dw_macs 0 0 n_layers H0 W0 C0 P_last C_last
         return batch * 1.0 * (p[0] + p[9] * p[10]), batch * 2.0 * (p[1] + p[2]), batch * 2.0 * p[1]

@@ -32,7 +32,7 @@ EXPORTS = (
 )  # fmt: skip
 
 # launcher switches of bn_set_option (include/birdnet_hip.h); the production defaults are what a fresh process has
-OPTION_NAMES = ("f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th", "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw", "i8_mid",
+OPTION_NAMES = ("f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_mfdw", "i8_strip_th", "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw", "i8_mid",
                 "i8_mel_generic", "stft_rowmajor", "stft_exact", "stft_flagcap", "stft_guard", "stft_audit", "stft_minint", "ingest_blk", "ingest_generic")
 
 

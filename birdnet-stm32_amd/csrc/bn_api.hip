@@ -51,7 +51,7 @@ const OptName kOptions[] = {
     {"wave_dwpw", &bn::Options::wave_dwpw},       {"i8_strip", &bn::Options::i8_strip},
     {"i8_strip_th", &bn::Options::i8_strip_th}, {"i8_dw_pool", &bn::Options::i8_dw_pool}, {"i8_tail_fclds", &bn::Options::i8_tail_fclds},   {"i8_tail", &bn::Options::i8_tail}, {"i8_tail_mfdw", &bn::Options::i8_tail_mfdw}, {"i8_mid", &bn::Options::i8_mid},
     {"i8_mel_generic", &bn::Options::i8_mel_generic}, {"stft_rowmajor", &bn::Options::stft_rowmajor},
-    {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap}, {"stft_guard", &bn::Options::stft_guard}, {"stft_audit", &bn::Options::stft_audit}, {"stft_minint", &bn::Options::stft_minint},
+    {"i8_strip_mfdw", &bn::Options::i8_strip_mfdw}, {"stft_exact", &bn::Options::stft_exact}, {"stft_flagcap", &bn::Options::stft_flagcap}, {"stft_guard", &bn::Options::stft_guard}, {"stft_audit", &bn::Options::stft_audit}, {"stft_minint", &bn::Options::stft_minint},
     {"ingest_blk", &bn::Options::ingest_blk},
     {"ingest_generic", &bn::Options::ingest_generic},
 };
@@ -1629,7 +1629,7 @@ int bn_get_option(const char* name, int* value) {
 const char* bn_kernel_names(void) {
     return "ingest_resample_kernel\ningest_decimate_kernel\ningest_peak_kernel\ningest_chunks_kernel\nchunk_peaknorm_kernel\npool_scores_kernel\nstft512_mag_kernel\nspec_normalize_kernel\nmelspec_finish_kernel\nf32_mel_kernel\nf32_melfin_kernel\nf32_mag_kernel\nf32_rawfe_kernel\nf32_stem_kernel\nf32_dw_kernel\n"
            "f32_pw_kernel\nf32_pw_ws_kernel\nf32_dwpw_kernel\nf32_dwpw_wave_kernel\nf32_strip_kernel\nf32_front_strip_kernel\nf32_front2_kernel\nf32_pwdw_kernel\nf32_dw_stream_kernel\nf32_front_kernel\nf32_gap_kernel\nf32_gap_dense_kernel\nf32_dense_kernel\nf32_segate_kernel\nf32_scale_kernel\nf32_attnpool_kernel\n"
-           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_tail2_kernel\ni8_mid2_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_pw_lds_kernel\ni8_attnpool_kernel\n"
+           "i8_quant_kernel\ni8_mel_kernel\ni8_stem_kernel\ni8_dw_kernel\ni8_pw_kernel\ni8_dwpw_kernel\ni8_mel_mfma_kernel\ni8_strip_kernel\ni8_strip_mf_kernel\ni8_front_strip_kernel\ni8_front_kernel\ni8_tail_kernel\ni8_tail2_kernel\ni8_mid2_kernel\ni8_mean_kernel\ni8_fc_kernel\ni8_scale_kernel\ni8_maxnorm_kernel\ni8_rawfe_kernel\ni8_pwdw_kernel\ni8_dw_stream_kernel\ni8_stem_stream_kernel\ni8_segate_kernel\ni8_pw_wave_kernel\ni8_pw_lds_kernel\ni8_attnpool_kernel\n"
            "i8_head_kernel\ni8_head_softmax_kernel";
 }
 

@@ -440,6 +440,199 @@ void i8_strip_kernel(Strip8Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// stage1_ds2 of the shipped graph (32 -> 32 channels, stride 1, residual ADD) with the DEPTHWISE 3x3 ON THE MATRIX CORES — the streaming sibling
+// of bn_i8_tail2.hip's blocks (round 5).  Same constant block, same strip walk, same pointwise stage / ADD table / store as
+// i8_strip_kernel<32, 1, 32, 1, true>; what changes is the depthwise stage:
+//   * the B operand of v_mfma_i32_16x16x64_i8 is the NHWC input as it lies in memory: lane (n, g) loads the 16 channels of channel tile ct at
+//     column n + g - 1 of the input row (two 16-byte loads per row instead of three 8-byte ones; g = 3 meets zero weights), contraction index
+//     16 * (window column) + channel; the A operand is the row's taps as a block-diagonal matrix (lane (m, g): byte m of its 16 = w[row][g][16 ct + m]),
+//     built from the packer's tap dwords at kernel start: 2 channel tiles x 3 window rows = 24 registers, what the tap dwords took;
+//   * three accumulating matrix instructions per channel tile and output row replace 6 byte permutes + 12 v_dot4 + the transposed window
+//     (66 -> 30 vector instructions per row for the depthwise stage; the requantisation stays);
+//   * the results — lane (n, g): channels 16 ct + 4 g .. + 3 — are the pointwise product's B fragment with its K order permuted
+//     (slot 8 g + j <-> channel 4 g + j, 8 g + 4 + j <-> 16 + 4 g + j); the A fragments are gathered from the packer's in that order;
+//   * padding is explicit: rows outside the map are a register of zero points (wave-uniform), the two border lanes of the outer strips select
+//     the zero point for their outside column (eight selects per row, in the outer strips only) — no bias variants;
+//   * the residual of the ADD is no longer a tap the lane holds: one more 8-byte load per row (the lines are in L1).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void i8_strip_mf_kernel(Strip8Args a) {
+    constexpr int CIN = 32, COUT = 32, QL = 2, NT = 2, NW = 1, SPB = 8, NTHREADS = 512;
+    constexpr int nDWW = 4 * QL * 12, nDWB = 4 * QL * 4, nDWC = 4 * QL * 12, nPWA = NT * NW * 64 * QL, nPWB = 4 * NT * 4;
+    constexpr int kDWW = 0, kDWB = kDWW + nDWW, kDWC = kDWB + nDWB, kPWA = kDWC + nDWC, kPWB = kPWA + nPWA, kPWC = kPWB + nPWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    const unsigned char* add_tab = lds_all;
+    v4i* c_dw = reinterpret_cast<v4i*>(lds_all + 65536);   // per channel quad: multiplier, (C lo, C hi) x 4, packed shifts - 1 (rq_hi)
+    v4i* c_pw = c_dw + nDWC / 3;                            // per output quad: multiplier, c1, shift (rq: the value + 128 indexes the ADD table)
+    const int tid = threadIdx.x;
+    {
+        const v4i* src = reinterpret_cast<const v4i*>(a.cst);
+        for (int i = tid; i < nDWC / 12; i += NTHREADS) {
+            const v4i m = src[kDWC / 4 + 3 * i], c1 = src[kDWC / 4 + 3 * i + 1], sh = src[kDWC / 4 + 3 * i + 2];
+            const long c[4] = {rq64(c1.x), rq64(c1.y), rq64(c1.z), rq64(c1.w)};
+            c_dw[4 * i] = m;
+            c_dw[4 * i + 1] = (v4i){(int)c[0], (int)(c[0] >> 32), (int)c[1], (int)(c[1] >> 32)};
+            c_dw[4 * i + 2] = (v4i){(int)c[2], (int)(c[2] >> 32), (int)c[3], (int)(c[3] >> 32)};
+            c_dw[4 * i + 3] = (v4i){pack_shifts(sh - 1), 0, 0, 0};
+        }
+        for (int i = tid; i < 4 * NT; i += NTHREADS) {
+            c_pw[4 * i] = src[kPWC / 4 + 3 * i];
+            c_pw[4 * i + 1] = src[kPWC / 4 + 3 * i + 1];
+            c_pw[4 * i + 2] = src[kPWC / 4 + 3 * i + 2];
+            c_pw[4 * i + 3] = (v4i){0, 0, 0, 0};
+        }
+        const v4i* tsrc = reinterpret_cast<const v4i*>(a.add_tab);
+        v4i* tdst = reinterpret_cast<v4i*>(lds_all);
+        for (int i = tid; i < 4096; i += NTHREADS) tdst[i] = tsrc[i];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int strips_x = a.OW >> 4;
+    const int rblocks = (a.OH + a.TH - 1) / a.TH;
+    int wid = xcd_tile(blockIdx.x, gridDim.x) * SPB + wave;
+    if (wid >= a.B * strips_x * rblocks) return;  // no barrier after this point
+    const int sx = wid % strips_x;
+    wid /= strips_x;
+    const int ry = wid % rblocks;
+    const int chunk = wid / rblocks;
+    const int oh0 = ry * a.TH;
+    const int steps = (a.OH - oh0) < a.TH ? (a.OH - oh0) : a.TH;
+    const int ow = sx * 16 + n;
+
+    // depthwise A operands: lane (m = n, g) of channel tile ct, window row dy: w[dy][g][16 ct + m] at byte m, zeros elsewhere (g = 3: all zero)
+    v4i dwa[2][3];
+    v4i dwb[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int c = 16 * ct + n;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int taps = a.cst[kDWW + (((c >> 3) * QL + ((c >> 2) & 1)) * 3 + dy) * 4 + (c & 3)];   // bytes (tap0, tap1, tap2, 0) of channel c
+            const int b = g < 3 ? ((taps >> (8 * g)) & 0xff) << (8 * (n & 3)) : 0;
+            dwa[ct][dy] = (v4i){(n >> 2) == 0 ? b : 0, (n >> 2) == 1 ? b : 0, (n >> 2) == 2 ? b : 0, (n >> 2) == 3 ? b : 0};
+        }
+        dwb[ct] = reinterpret_cast<const v4i*>(a.cst + kDWB)[4 * ct + g];   // channels 16 ct + 4 g .. + 3
+    }
+    // pointwise A fragments in the K order of the depthwise results (see above); bias as in i8_strip_kernel
+    long pwa[NT];
+    v4i pwb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint32_t lo = (uint32_t)a.cst[kPWA + (t * 64 + (n + 16 * (g >> 1))) * QL + (g & 1)];
+        const uint32_t hi = (uint32_t)a.cst[kPWA + (t * 64 + (n + 16 * (2 + (g >> 1)))) * QL + (g & 1)];
+        pwa[t] = (long)(((unsigned long)hi << 32) | lo);
+        pwb[t] = reinterpret_cast<const v4i*>(a.cst + kPWB)[g * NT + t];
+    }
+
+    const int zp4 = (a.zp_in & 0xff) * 0x01010101;
+    const v4i zrow = {zp4, zp4, zp4, zp4};
+    const int icol = ow + g - 1;                                     // the input column this lane reads (g = 3: as g = 2, weights are zero)
+    const bool outside = g < 3 && (icol < 0 || icol >= a.W);         // only lanes (0, 0) of the first and (15, 2) of the last strip
+    const bool outer = sx == 0 || sx == strips_x - 1;                // (wave-uniform)
+    const int in_chunk_bytes = a.H * a.W * CIN, row_bytes = a.W * CIN;
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.x) + (size_t)chunk * in_chunk_bytes, 0, in_chunk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)chunk * a.OH * a.OW * COUT, 0, a.OH * a.OW * COUT, 0x00020000);
+    const int ccol = g == 3 ? icol - 1 : icol;
+    const int voff_b = (ccol < 0 ? 0 : (ccol >= a.W ? a.W - 1 : ccol)) * CIN;   // (an outside column loads a valid neighbour, replaced below)
+    const int voff_r = ow * CIN + 8 * g;                                        // residual: the lane's own 8 output channels of its column
+    const int voff_out = ow * COUT + 8 * g;
+    const int ir0 = oh0 - a.pt;
+    const int rows_needed = steps + 2;
+
+    v4i rawb[2][2];   // rows requested two ahead: [slot][channel tile]
+    v2i rawr[2];
+    v4i brow[3][2];   // the 3-row window of B operands
+    v2i cen[3];
+    auto row_ok = [&](int rr) { const int ir = ir0 + rr; return rr < rows_needed && ir >= 0 && ir < a.H; };
+    auto issue = [&](int slot, int rr) {
+        if (row_ok(rr)) {
+            const int so = (ir0 + rr) * row_bytes;
+            rawb[slot][0] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff_b, so, 0));
+            rawb[slot][1] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff_b + 16, so, 0));
+            rawr[slot] = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rs_in, voff_r, so, 0));
+        }
+    };
+    auto consume = [&](int slot, int rr, int ti) {
+        if (row_ok(rr)) {
+            brow[ti][0] = rawb[slot][0];
+            brow[ti][1] = rawb[slot][1];
+            if (outer) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) brow[ti][ct][e] = outside ? zp4 : brow[ti][ct][e];
+            }
+            cen[ti] = rawr[slot];
+        } else {
+            brow[ti][0] = zrow;
+            brow[ti][1] = zrow;
+            cen[ti] = (v2i){zp4, zp4};
+        }
+    };
+    auto emit = [&](int i0, int i1, int i2, int oh) {
+        asm volatile("" ::: "memory");  // (the per-channel constants are re-read from LDS every row instead of pinning ~48 registers)
+        int bfrag[2];
+        v4i acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(dwa[ct][0], brow[i0][ct], dwb[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(dwa[ct][1], brow[i1][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(dwa[ct][2], brow[i2][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int q = 4 * ct + g;
+            const v4i m = c_dw[q * 4 + 0], c01 = c_dw[q * 4 + 1], c23 = c_dw[q * 4 + 2];
+            const int e1 = reinterpret_cast<const int*>(c_dw + q * 4 + 3)[0];
+            const long cc[4] = {__builtin_bit_cast(long, (v2i){c01.x, c01.y}), __builtin_bit_cast(long, (v2i){c01.z, c01.w}),
+                                __builtin_bit_cast(long, (v2i){c23.x, c23.y}), __builtin_bit_cast(long, (v2i){c23.z, c23.w})};
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[e] = med3(rq_hi(acc[ct][e], m[e], cc[e], e1, e), a.dw_lo, a.dw_hi);
+            bfrag[ct] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+        }
+        const long bf = ((long)(uint32_t)bfrag[1] << 32) | (uint32_t)bfrag[0];
+        int outw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const v4i pacc = __builtin_amdgcn_mfma_i32_16x16x32_i8(pwa[t], bf, pwb[t], 0, 0, 0);
+            const v4i m = c_pw[(g * NT + t) * 4 + 0], c1 = c_pw[(g * NT + t) * 4 + 1], sh = c_pw[(g * NT + t) * 4 + 2];
+            int qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = med3(rq(pacc[e], m[e], c1[e], sh[e]), a.pw_lo, a.pw_hi);   // value + 128: the table's column
+                qv[e] = add_tab[(uint32_t)perm(cen[i1][t], v, 0x0c0c0400u + (e << 8))];
+            }
+            outw[t] = perm(perm(qv[3], qv[2], 0x0c0c0400u), perm(qv[1], qv[0], 0x0c0c0400u), 0x05040100u);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(int)))) int, (v2i){outw[0], outw[1]}), rs_out, voff_out,
+                                              oh * a.OW * COUT, 0);
+    };
+
+    // relative row rr lives in raw slot rr & 1 and window slot rr % 3; two rows are consumed before the first output row, one per step afterwards
+    issue(0, 0);
+    issue(1, 1);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        consume(rr & 1, rr, rr % 3);
+        issue(rr & 1, rr + 2);
+    }
+    for (int k = 0; k < steps; k += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            if (k + u >= steps) break;
+            const int rs = 2 + u;
+            consume(rs & 1, k + rs, rs % 3);
+            issue(rs & 1, k + rs + 2);
+            emit(u % 3, (u + 1) % 3, (u + 2) % 3, oh0 + k + u);
+        }
+    }
+}
+
 template <int CW, int NW, int COUT, int S, bool ADD, bool W8 = false>
 void launch_strip(const Strip8Args& a, hipStream_t s) {
     constexpr int SPB = ADD ? 8 / NW : (NW == 1 ? 4 : 1);
@@ -961,6 +1154,15 @@ void launch_i8_strip(Strip8Args a, int Cin, int Cout, int stride, hipStream_t s)
     a.TH = th;
 #define BN_STRIP(CW, NW, CO, ST, AD) \
     if (Cin == CW * NW && nw == NW && Cout == CO && stride == ST && add == AD) return launch_strip<CW, NW, CO, ST, AD>(a, s);
+    if (Cin == 32 && nw == 1 && Cout == 32 && stride == 1 && add && g_opt.i8_strip_mfdw && a.pt == 1 && a.pl == 1 && a.OW % 16 == 0 && a.W == a.OW && a.H == a.OH) {
+        // stage1_ds2 of the shipped graph: the depthwise stage on the matrix cores (i8_strip_mf_kernel)
+        const long per_chunk = (long)(a.OW / 16) * ((a.OH + a.TH - 1) / a.TH);
+        const long blocks = (a.B * per_chunk + 7) / 8;
+        const size_t smem = 65536 + (size_t)(4 * 2 * 16 + 4 * 2 * 16) * 4;
+        (void)ensure_dynamic_lds(reinterpret_cast<const void*>(i8_strip_mf_kernel), smem);
+        hipLaunchKernelGGL(i8_strip_mf_kernel, dim3((unsigned)blocks), dim3(512), smem, s, a);
+        return;
+    }
     BN_STRIP(32, 1, 32, 1, true)
     BN_STRIP(32, 4, 128, 1, true)
     BN_STRIP(32, 2, 64, 1, true)

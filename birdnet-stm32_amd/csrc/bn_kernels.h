@@ -47,6 +47,7 @@ struct Options {
     int i8_tail_mfdw = 1;      // ... with the depthwise stage on the matrix cores (i8_tail2_kernel) where the plan carries its constants; 0: i8_tail_kernel
     int i8_mel_generic = 0;    // run the mel mixer through the generic fused block
     int stft_rowmajor = 0;     // keep the reference spectrogram layout inside bn_infer_audio (default: tile-major)
+    int i8_strip_mfdw = 1;     // stage1_ds2-shaped blocks (32 -> 32 channels, stride 1, residual ADD): depthwise 3x3 on the matrix cores (i8_strip_mf_kernel); 0: i8_strip_kernel
     int stft_exact = 2;        // INT8 plans from audio: 2 = float32 STFT + float64 pass over the doubtful elements (bit-exact input bytes,
                                // bn_stft_exact.hip; plans / options the guarded kernels do not cover take 1), 1 = every bin as a float64
                                // DFT (same bytes, ~10 x slower), 0 = plain float32 STFT (round 2: ~3e-6 of the input bytes off by one)

@@ -282,7 +282,7 @@ BN_API int bn_profile_only(bn_model* model, int op_index);
 BN_API int bn_profile_collect(bn_model* model, double* total_ms, int64_t* launches, int n);
 
 /* Run-time switches of the kernel launchers, for A/B measurements and tests (process-wide; the defaults are the production
- * choices).  Names: "f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_th",
+ * choices).  Names: "f32_strip", "f32_strip_th", "f32_front_staged", "f32_front2", "f32_pwdw", "f32_tile_slice", "f32_pw_ws", "i8_pwdw", "i8_pw_lds", "i8_pw_forms", "i8_add_tab", "front_tpw", "wave_dwpw", "i8_strip", "i8_strip_mfdw", "i8_strip_th",
  * "i8_dw_pool", "i8_tail_fclds", "i8_tail", "i8_tail_mfdw", "i8_mid", "i8_mel_generic", "stft_rowmajor", "stft_exact", "stft_flagcap", "stft_guard", "stft_audit", "stft_minint", "ingest_blk", "ingest_generic" (csrc/bn_kernels.h: Options says
  * what each selects).  An environment variable BN_<NAME IN CAPITALS> seeds the value once when the library is loaded; no
  * launch reads the environment.  The reference has no counterpart (tf.lite.Interpreter's delegates / num_threads arguments,

@@ -830,6 +830,44 @@ def test_i8_dw_stream_kernel_matches_the_baseline_kernel(torch_mod):
         runner.close()
 
 
+# --------------------------------------------------------------------------------------- INT8: strip kernel with the depthwise stage on the matrix cores
+def test_i8_strip_mf_kernel_matches_the_strip_kernel_and_the_oracle(torch_mod):
+    """``i8_strip_mf_kernel`` (stage1_ds2 of the shipped graph: 32 -> 32 channels, stride 1, residual ADD; depthwise 3x3 as block-diagonal
+    matrix products straight from the NHWC map) against ``i8_strip_kernel<32, 1, 32, 1, true>`` (option ``i8_strip_mfdw`` = 0) and the oracle's
+    tensor: bit for bit, for strip heights that move the row-block borders (the top / bottom padding rows become a register of zero points, the
+    border columns of the outer strips a select), odd batch sizes, repeated launches."""
+    torch = torch_mod
+    from birdnet_stm32 import _hip
+    from birdnet_stm32.models import _pack as pk
+    from birdnet_stm32.models._lower_i8 import lower_i8
+    from birdnet_stm32.models._tflite_reader import load_tflite
+    from birdnet_stm32.models.runners import HipRunner
+    from oracle.int8_graph import Int8Interpreter
+
+    model = load_tflite(TFLITE_PATH)
+    rng = np.random.default_rng(12)
+    B = 21
+    x = rng.random((B, 257, 256, 1), dtype=np.float32)
+    runner = HipRunner(lower_i8(model, keep_all=True), max_batch=B)
+    ops = [oi for oi, op in enumerate(runner.plan.ops) if op.kind == pk.I8_DWPW and op.p[35] and op.p[2] == 32 and op.p[14] == 32 and op.p[3] == 1 and op.p[18]]
+    assert len(ops) == 1, ops
+    oi = ops[0]
+    _, env = Int8Interpreter(model).invoke(x, return_all=True)
+    with _hip.options(i8_strip_mfdw=0):
+        want_scores = runner.predict(x)
+        want = runner.op_output(oi, B)
+    tensor = [t for t, v in env.items() if np.asarray(v).size == want.size and np.array_equal(np.asarray(v).reshape(-1), want.reshape(-1))]
+    assert tensor, "the strip kernel's output is none of the oracle's tensors"
+    for th in (0, 1, 3, 5, 7, 32) * 3:
+        with _hip.options(i8_strip_mfdw=1, i8_strip_th=th):
+            got_scores = runner.predict(x)
+            assert np.array_equal(runner.op_output(oi, B), want), f"rows per strip {th or 'auto'}"
+            assert np.array_equal(got_scores, want_scores)
+    for nb in (1, 2, 9):
+        assert np.array_equal(runner.predict(x[:nb]), want_scores[:nb])
+    runner.close()
+
+
 # --------------------------------------------------------------------------------------- the remaining launcher options
 def test_every_other_launcher_option_reproduces_the_default_results(torch_mod):
     """The A/B switches that no other test flips (older kernel variants kept for measurements): ``f32_front_staged``, ``front_tpw``,

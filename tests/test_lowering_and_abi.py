@@ -290,7 +290,7 @@ def test_launcher_options_round_trip_without_a_device():
     default, values round-trip, unknown names are refused, and no launcher reads the environment any more."""
     from birdnet_stm32 import _hip
 
-    defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "f32_front2": 1, "f32_pwdw": 2, "f32_tile_slice": 0, "f32_pw_ws": 1, "i8_pwdw": 0, "i8_pw_lds": 1, "i8_pw_forms": 1, "i8_add_tab": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_th": 0, "i8_dw_pool": 1, "i8_tail_fclds": 1,
+    defaults = {"f32_strip": 1, "f32_strip_th": 0, "f32_front_staged": 1, "f32_front2": 1, "f32_pwdw": 2, "f32_tile_slice": 0, "f32_pw_ws": 1, "i8_pwdw": 0, "i8_pw_lds": 1, "i8_pw_forms": 1, "i8_add_tab": 1, "front_tpw": 0, "wave_dwpw": 1, "i8_strip": 1, "i8_strip_mfdw": 1, "i8_strip_th": 0, "i8_dw_pool": 1, "i8_tail_fclds": 1,
                 "i8_tail": 1, "i8_tail_mfdw": 1, "i8_mid": 1, "i8_mel_generic": 0, "stft_rowmajor": 0, "stft_exact": 2, "stft_flagcap": 1022, "stft_guard": 0, "stft_audit": 0, "stft_minint": 1, "ingest_blk": 0, "ingest_generic": 0}
     assert sorted(defaults) == sorted(_hip.OPTION_NAMES)
     hdr = open(os.path.join(REPO, "include", "birdnet_hip.h")).read()
