@@ -350,6 +350,15 @@ class _PinnedSlab:
             self.ptr, self.nbytes = ctx.alloc_pinned(nbytes), int(nbytes)
         self.tensor = torch.frombuffer((ctypes.c_uint8 * self.nbytes).from_address(self.ptr), dtype=torch.uint8)
 
+    @classmethod
+    def fresh(cls, ctx, nbytes: int, torch):
+        """A newly page-locked slab (never one taken from the pool): what tops the pool up."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.ptr, self.nbytes = ctx.alloc_pinned(nbytes), int(nbytes)
+        self.tensor = torch.frombuffer((ctypes.c_uint8 * self.nbytes).from_address(self.ptr), dtype=torch.uint8)
+        return self
+
     def release(self) -> None:
         if self.ptr:
             with _SLAB_LOCK:
@@ -397,6 +406,8 @@ class EvaluatePipeline:
         if read_mode is not None:   # "mmap" (library default) | "pread": process-wide switch of the reader (csrc/host/bn_pcmio.c)
             _pcmio.set_read_mode(read_mode)
         self.n_pinned = max(2, int(pinned_slabs))
+        self._n_ring = self.n_pinned       # slabs in use by the current ring (a process's first call: 2, see _ensure_slabs)
+        self._top_up = (0, 0)              # (bytes, count) of slabs to page-lock behind the call for the pool
         self.size = int(self.sr * self.cd)
         self._taps: dict[tuple[int, int], object] = {}
         self._pinned: list = []
@@ -436,15 +447,21 @@ class EvaluatePipeline:
             # 0.04 warm).  The slabs are allocated by a helper thread, in the order the producer needs them; the producer waits for slab k only
             # when it gets to group k — the first (small, ramped) groups are read and copied while the other slabs are still being pinned.
             self._release_slabs()
-            self._pinned = [None] * self.n_pinned
-            self._slabs = [None] * self.n_pinned
-            self._pinned_ready = [threading.Event() for _ in range(self.n_pinned)]
-            self._pinned_free = [None] * self.n_pinned
+            # A process without pooled slabs (its first call) runs on a ring of TWO: the third one's 19 ms of page-locking sat in front of the first
+            # H2D copy (the runtime serialises the two); it is page-locked behind the call instead and pooled for the next one (_top_up_pool).
+            with _SLAB_LOCK:
+                pooled = sum(1 for _, size in _SLAB_POOL if size >= cap)
+            self._n_ring = self.n_pinned if pooled >= self.n_pinned else max(2, pooled)
+            self._top_up = (cap, self.n_pinned - self._n_ring)
+            self._pinned = [None] * self._n_ring
+            self._slabs = [None] * self._n_ring
+            self._pinned_ready = [threading.Event() for _ in range(self._n_ring)]
+            self._pinned_free = [None] * self._n_ring
 
             def allocate():
                 try:
                     torch.cuda.set_device(self.dev)
-                    for k in range(self.n_pinned):
+                    for k in range(self._n_ring):
                         self._slabs[k] = _PinnedSlab(self.ctx, cap, torch)
                         self._pinned[k] = self._slabs[k].tensor
                         self._pinned_ready[k].set()
@@ -473,6 +490,23 @@ class EvaluatePipeline:
         if self.copy_stream is not None:
             self.copy_stream.synchronize()
         self._release_slabs()
+        cap, count = self._top_up
+        self._top_up = (0, 0)
+        if count > 0 and cap > 0:   # the slabs a first call did without: page-locked now, off everybody's critical path, for the next call's ring
+            ctx, torch, want = self.ctx, self.torch, self.n_pinned
+
+            def top_up():
+                try:
+                    for _ in range(count):
+                        with _SLAB_LOCK:   # (an earlier call's top-up may have got there first)
+                            if sum(1 for _, size in _SLAB_POOL if size >= cap) >= want:
+                                return
+                        slab = _PinnedSlab.fresh(ctx, cap, torch)
+                        slab.release()
+                except Exception:  # pragma: no cover - the next call simply runs on a shorter ring
+                    pass
+
+            threading.Thread(target=top_up, name="bn-pin-top-up", daemon=True).start()
 
     def __del__(self):
         try:
@@ -497,7 +531,7 @@ class EvaluatePipeline:
     def _stage_group(self, tab: FileTable, lo: int, hi: int, seq: int) -> _Staged:
         torch = self.torch
         t0 = time.perf_counter()
-        k = seq % self.n_pinned
+        k = seq % self._n_ring
         prev = self._pinned_free[k]
         if prev is not None:
             prev.synchronize()  # the H2D that last read this pinned slab has finished
@@ -622,10 +656,10 @@ class EvaluatePipeline:
             self._mark("device slabs")
             self._slot_ready = [threading.Semaphore(1), threading.Semaphore(1)]
             self._dslab_free = [None, None]
-            self._pinned_free = [None] * self.n_pinned
+            self._pinned_free = [None] * self._n_ring
             self._stop.clear()
             scores = torch.empty((max(planned, 1), self.runner.num_classes), dtype=torch.float32, device=self.dev)
-            q: queue.Queue = queue.Queue(maxsize=max(1, self.n_pinned - 1))
+            q: queue.Queue = queue.Queue(maxsize=max(1, self._n_ring - 1))
             stop = self._stop
 
             def producer():
