@@ -86,6 +86,24 @@ def _wav_layout(raw: bytes):
     return (*fmt, *data)
 
 
+def _g711_tables() -> tuple[np.ndarray, np.ndarray]:
+    """(A-law, mu-law) byte -> 16-bit sample tables of ITU-T G.711, the values libsndfile's decoders hold (it reads such WAVE files — format
+    tags 6 and 7 — as those int16 samples, scaled by 1 / 32768 like 16-bit PCM)."""
+    b = np.arange(256, dtype=np.int32)
+    a = b ^ 0x55
+    exp, man = (a >> 4) & 7, a & 0x0F
+    mag = np.where(exp == 0, (man << 4) + 8, ((man << 4) + 0x108) << np.maximum(exp - 1, 0))
+    alaw = np.where(a & 0x80, mag, -mag)              # (bit 7 set = positive, after the 0x55 toggle)
+    u = ~b & 0xFF
+    exp, man = (u >> 4) & 7, u & 0x0F
+    mag = (((man << 3) + 0x84) << exp) - 0x84
+    ulaw = np.where(u & 0x80, -mag, mag)
+    return alaw.astype(np.int16), ulaw.astype(np.int16)
+
+
+_G711 = None
+
+
 def _decode_frames(raw: bytes, code: int, ch: int, bits: int, offset: int, nbytes: int, first: int, count: int) -> np.ndarray:
     """Frames [first, first+count) as float32 ``[count, ch]`` with libsndfile's integer scaling."""
     width = bits // 8
@@ -108,6 +126,11 @@ def _decode_frames(raw: bytes, code: int, ch: int, bits: int, offset: int, nbyte
             x = (np.frombuffer(buf, "<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
         else:
             raise ValueError(f"unsupported PCM width {bits}")
+    elif code in (6, 7) and bits == 8:  # G.711 A-law / mu-law: one byte per sample, companded 13- / 14-bit PCM
+        global _G711
+        if _G711 is None:
+            _G711 = _g711_tables()
+        x = _G711[0 if code == 6 else 1][np.frombuffer(buf, np.uint8)].astype(np.float32) / 32768.0
     else:
         raise ValueError(f"unsupported WAVE format tag {code}")
     return x.reshape(-1, ch)

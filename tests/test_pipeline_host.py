@@ -65,6 +65,9 @@ def dataset(tmp_path_factory):
         else:
             _write_wav(p, rng.integers(-20000, 20000, (n, ch)), sr, 16, extra=odd_chunk, data_size=(1 << 31) if i % 11 == 4 else None)
         paths.append(p)
+    for tag, name in ((7, "g711_mu.wav"), (6, "g711_a.wav")):   # G.711 (libsndfile reads them): decoded on the host like 8-bit PCM
+        _write_wav(str(d / name), rng.integers(0, 256, (8000 * 7, 1 + tag % 2)), 8000, 8, code=tag)
+        paths.append(str(d / name))
     (d / "bad.wav").write_bytes(b"nope")
     (d / "empty.wav").write_bytes(b"")
     _write_wav(str(d / "nodata.wav"), np.zeros((0, 1)), 24000)
@@ -249,6 +252,41 @@ def test_read_windows_and_copy_into_fill_exact_ranges(tmp_path):
     dst = np.zeros(1000, np.uint8)
     _pcmio.copy_into([blobs[4], blobs[0]], dst.ctypes.data, np.array([10, 500], np.int64), 2)
     assert np.array_equal(dst[10:343], blobs[4]) and dst[500] == blobs[0][0] and dst[:10].sum() == 0
+
+
+def test_g711_wave_files_decode_like_the_standards_tables(tmp_path):
+    """WAVE format tags 6 (A-law) and 7 (mu-law), which libsndfile — the reference's reader, audio/io.py:90,114-116 — opens as 16-bit samples: the
+    byte -> sample tables against ITU-T G.711's known answers and an independent bit-level decoder written here, a stereo file through
+    ``load_audio_window`` (mono mean, scaling by 1 / 32768), and the evaluate pipeline's planner taking such files as host-decoded windows."""
+    alaw, ulaw = aio._g711_tables()
+    assert [int(ulaw[b]) for b in (0xFF, 0x7F, 0x00, 0x80, 0x0F, 0x8F)] == [0, 0, -32124, 32124, -16764, 16764]
+    assert [int(alaw[b]) for b in (0xD5, 0x55, 0xAA, 0x2A, 0x80, 0x00)] == [8, -8, 32256, -32256, 5504, -5504]
+
+    def ulaw_ref(b):   # G.711 section 3: invert, then sign | 3-bit exponent | 4-bit mantissa with the bias of 33 (<< 2 in 16-bit terms)
+        u = ~b & 0xFF
+        t = (((u & 0x0F) << 3) + 0x84) << ((u >> 4) & 7)
+        return (0x84 - t) if u & 0x80 else (t - 0x84)
+
+    def alaw_ref(b):   # G.711 section 2: toggle the even bits, then sign | exponent | mantissa, the lowest segment linear
+        a = b ^ 0x55
+        e, m = (a >> 4) & 7, a & 0x0F
+        t = (m << 4) + 8 if e == 0 else ((m << 4) + 0x108) << (e - 1)
+        return t if a & 0x80 else -t
+
+    assert [ulaw_ref(b) for b in range(256)] == ulaw.tolist() and [alaw_ref(b) for b in range(256)] == alaw.tolist()
+    assert sorted(set(ulaw.tolist())) == sorted(set((-ulaw).tolist())) and len(set(alaw.tolist())) == 256   # symmetric; A-law has no zero
+    rng = np.random.default_rng(8)
+    sr, n = 8000, 8000 * 4
+    codes = rng.integers(0, 256, (n, 2))
+    for tag, table, name in ((7, ulaw, "mu.wav"), (6, alaw, "a.wav")):
+        path = str(tmp_path / name)
+        _write_wav(path, codes, sr, 8, code=tag)
+        y = aio.load_audio_window(path, sample_rate=sr, max_duration=60, chunk_duration=3.0, random_offset=False)
+        want = table[codes].astype(np.float32).mean(axis=1) / np.float32(32768.0)
+        want = want / (np.abs(want).max() + 1e-12)
+        assert y.shape == want.shape and np.allclose(y, want, atol=1e-6), name
+        tab = pl.plan_files([path], sr, 3.0, 0.0, 60, 2)
+        assert tab.kind[0] == 1 and tab.frames[0] == n and tab.channels[0] == 2 and tab.n_chunks[0] > 0   # decoded on the host, like 8-bit PCM
 
 
 def test_reader_share_honours_the_cgroup_cpu_quota(tmp_path, monkeypatch):
