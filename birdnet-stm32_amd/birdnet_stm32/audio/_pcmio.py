@@ -20,7 +20,7 @@ _lib = None
 IO_OK, IO_OPEN, IO_NOT_WAVE, IO_NO_CHUNK, IO_SHORT = 0, -1, -2, -3, -4
 
 # every symbol include/bn_host.h declares
-EXPORTS = ("bn_wav_probe", "bn_wav_probe_many", "bn_file_read_many", "bn_file_read_many_mode", "bn_host_set_read_mode", "bn_copy_many", "bn_flac_info", "bn_flac_md5", "bn_flac_decode")
+EXPORTS = ("bn_wav_probe", "bn_wav_probe_many", "bn_file_read_many", "bn_file_read_many_mode", "bn_host_set_read_mode", "bn_host_selftest_truncated_map", "bn_copy_many", "bn_flac_info", "bn_flac_md5", "bn_flac_decode")
 
 LAYOUT_DTYPE = np.dtype([("status", "<i4"), ("format_tag", "<i4"), ("channels", "<i4"), ("sample_rate", "<i4"), ("bits", "<i4"),
                          ("reserved", "<i4"), ("data_offset", "<i8"), ("data_bytes", "<i8")])
@@ -41,6 +41,7 @@ def _load():
         lib.bn_file_read_many.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, i64p, i64p, vp, i64p, vp, ctypes.c_int]
         lib.bn_file_read_many_mode.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, i64p, i64p, vp, i64p, vp, ctypes.c_int, ctypes.c_int]
         lib.bn_host_set_read_mode.argtypes = [ctypes.c_int]
+        lib.bn_host_selftest_truncated_map.argtypes = [ctypes.c_char_p]
         lib.bn_copy_many.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, i64p, vp, i64p, ctypes.c_int]
         _lib = lib
     return _lib

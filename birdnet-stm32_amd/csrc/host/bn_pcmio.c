@@ -14,6 +14,8 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <setjmp.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -172,7 +174,7 @@ typedef struct {
  * profiles/r05_evaluate_cold_probe.md).  A VM_SEQ_READ mapping is exempt from that bookkeeping (mm: vma_has_recency): 65-70 GB/s on the first read
  * and on every later one, and a one-pass read of a data set no longer pushes it onto the active list.  Windows below 64 KB, files that cannot be
  * mapped and windows running past the end of the file take pread (same status codes).  A file truncated by someone else WHILE it is being copied
- * raises SIGBUS under mmap where pread would return short: data sets are not rewritten under a running evaluation; BN_READ_MODE=pread is there. */
+ * raises SIGBUS under mmap where pread would return short: caught (bus_guard below) and handed to pread. */
 #define BN_READ_PREAD 0
 #define BN_READ_MMAP 1
 static int g_read_mode = -1; /* -1: not yet seeded from the environment */
@@ -194,7 +196,58 @@ BN_HOST_API int bn_host_set_read_mode(int mode) {
     return prev;
 }
 
-/* 1 = copied, 0 = not applicable here (the caller takes pread) */
+/* A file that shrinks while it is mapped turns the copy's page fault into SIGBUS.  While bn_file_read_many runs in mmap mode a SIGBUS handler is
+ * installed (reference-counted across concurrent calls, the previous disposition restored afterwards): a fault INSIDE one of our copies jumps back
+ * into mmap_window, which reports the window as not copied — the caller's pread then returns short like it always did; any other SIGBUS goes to the
+ * handler that was there before (or the default action). */
+static __thread sigjmp_buf* tl_copy_jmp = NULL;
+static struct sigaction g_old_bus;
+static int g_bus_users = 0;
+static pthread_mutex_t g_bus_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void bus_handler(int sig, siginfo_t* si, void* uc) {
+    if (tl_copy_jmp) siglongjmp(*tl_copy_jmp, 1);
+    if (g_old_bus.sa_flags & SA_SIGINFO) {
+        if (g_old_bus.sa_sigaction) g_old_bus.sa_sigaction(sig, si, uc);
+    } else if (g_old_bus.sa_handler == SIG_DFL || g_old_bus.sa_handler == SIG_IGN) {
+        signal(SIGBUS, SIG_DFL);
+        raise(SIGBUS);
+    } else {
+        g_old_bus.sa_handler(sig);
+    }
+}
+
+static void bus_guard(int on) {
+    pthread_mutex_lock(&g_bus_mu);
+    if (on) {
+        if (g_bus_users++ == 0) {
+            struct sigaction sa;
+            memset(&sa, 0, sizeof sa);
+            sa.sa_sigaction = bus_handler;
+            sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+            sigemptyset(&sa.sa_mask);
+            sigaction(SIGBUS, &sa, &g_old_bus);
+        }
+    } else if (--g_bus_users == 0) {
+        sigaction(SIGBUS, &g_old_bus, NULL);
+    }
+    pthread_mutex_unlock(&g_bus_mu);
+}
+
+/* memcpy out of a mapping under the guard: 1 = copied, -1 = the mapping faulted (file truncated under us) */
+static int guarded_copy(void* dst, const void* src, size_t n) {
+    sigjmp_buf jb;
+    int ok = -1;
+    tl_copy_jmp = &jb;
+    if (sigsetjmp(jb, 1) == 0) {
+        memcpy(dst, src, n);
+        ok = 1;
+    }
+    tl_copy_jmp = NULL;
+    return ok;
+}
+
+/* 1 = copied, 0 = not applicable here or the mapping faulted (the caller takes pread, which reports a short file as it always did) */
 static int mmap_window(int fd, void* dst, size_t n, off_t off) {
     static long page = 0;
     if (!page) page = sysconf(_SC_PAGESIZE);
@@ -204,9 +257,34 @@ static int mmap_window(int fd, void* dst, size_t n, off_t off) {
     void* m = mmap(NULL, n + (size_t)lead, PROT_READ, MAP_SHARED, fd, off - lead);
     if (m == MAP_FAILED) return 0;
     (void)madvise(m, n + (size_t)lead, MADV_SEQUENTIAL);
-    memcpy(dst, (const char*)m + lead, n);
+    const int ok = guarded_copy(dst, (const char*)m + lead, n);
     munmap(m, n + (size_t)lead);
-    return 1;
+    return ok == 1;
+}
+
+/* Self-test of the guard (tests/test_pipeline_host.py): maps `path` (at least 64 KB), truncates it to nothing through a second descriptor and
+ * copies out of the mapping under the guard.  Returns -1 when the fault was caught (expected), 1 if the copy went through, 0 if the set-up failed. */
+BN_HOST_API int bn_host_selftest_truncated_map(const char* path) {
+    int fd = open(path, O_RDWR | O_CLOEXEC);
+    if (fd < 0) return 0;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 65536) {
+        close(fd);
+        return 0;
+    }
+    const size_t n = (size_t)st.st_size;
+    void* m = mmap(NULL, n, PROT_READ, MAP_SHARED, fd, 0);
+    char* dst = (char*)malloc(n);
+    int rc = 0;
+    if (m != MAP_FAILED && dst && ftruncate(fd, 0) == 0) {
+        bus_guard(1);
+        rc = guarded_copy(dst, m, n);
+        bus_guard(0);
+    }
+    if (m != MAP_FAILED) munmap(m, n);
+    free(dst);
+    close(fd);
+    return rc;
 }
 
 static void read_item(void* a, int i) {
@@ -237,7 +315,9 @@ BN_HOST_API int bn_file_read_many_mode(const char* const* paths, int n, const in
                                        const int64_t* dst_off, int32_t* status, int n_threads, int mode) {
     if (n <= 0) return 0;
     read_args a = {paths, file_off, nbytes, (unsigned char*)base, dst_off, status, (mode == BN_READ_PREAD || mode == BN_READ_MMAP) ? mode : read_mode()};
+    if (a.mode == BN_READ_MMAP) bus_guard(1);
     pool_run(read_item, &a, n, n_threads < 1 ? 1 : n_threads);
+    if (a.mode == BN_READ_MMAP) bus_guard(0);
     int bad = 0;
     for (int i = 0; i < n; i++) bad += status[i] != BN_IO_OK;
     return bad;

@@ -60,6 +60,11 @@ int bn_host_set_read_mode(int mode);
 int bn_file_read_many_mode(const char* const* paths, int n, const int64_t* file_off, const int64_t* nbytes, void* base,
                            const int64_t* dst_off, int32_t* status, int n_threads, int mode);
 
+/* Self-test of the mapped reader's SIGBUS guard (a file truncated while it is being copied out of a mapping must end as a short read, not as a
+ * signal): maps `path` (>= 64 KB), truncates it to nothing, copies under the guard.  -1 = the fault was caught (expected), 1 = the copy went
+ * through, 0 = the set-up failed.  The file is left empty. */
+int bn_host_selftest_truncated_map(const char* path);
+
 /* n memcpy()s into the same kind of slab on the same pool (windows that had to be decoded on the host first: FLAC). */
 int bn_copy_many(const void* const* src, int n, const int64_t* nbytes, void* base, const int64_t* dst_off, int n_threads);
 

@@ -289,6 +289,31 @@ def test_g711_wave_files_decode_like_the_standards_tables(tmp_path):
         assert tab.kind[0] == 1 and tab.frames[0] == n and tab.channels[0] == 2 and tab.n_chunks[0] > 0   # decoded on the host, like 8-bit PCM
 
 
+def test_a_file_truncated_under_the_mapped_reader_is_a_short_read_not_a_signal(tmp_path):
+    """mmap mode: a file that shrinks while it is being copied out of its mapping raises SIGBUS in the copying thread.  The reader installs a
+    guard for the duration of a call (csrc/host/bn_pcmio.c: bus_guard): the fault unwinds the copy, the window goes to pread, which reports it
+    short.  The library's self-test provokes exactly that (map, truncate through a second descriptor, copy); afterwards ordinary reads work and
+    the process's SIGBUS disposition is what it was."""
+    import signal
+
+    before = signal.getsignal(signal.SIGBUS)
+    p = tmp_path / "shrinks.bin"
+    p.write_bytes(os.urandom(1 << 20))
+    assert _pcmio._load().bn_host_selftest_truncated_map(str(p).encode()) == -1 and p.stat().st_size == 0
+    assert _pcmio._load().bn_host_selftest_truncated_map(str(p).encode()) == 0          # (nothing to map any more: set-up fails, no signal)
+    assert signal.getsignal(signal.SIGBUS) == before
+    blob = np.frombuffer(os.urandom(300000), np.uint8)
+    q = tmp_path / "fine.bin"
+    q.write_bytes(blob.tobytes())
+    buf = np.zeros(300000, np.uint8)
+    prev = _pcmio.set_read_mode("mmap")
+    try:
+        st = _pcmio.read_windows([str(q), str(p)], np.array([0, 0]), np.array([300000, 70000]), buf.ctypes.data, np.array([0, 0]), 2)
+    finally:
+        _pcmio.set_read_mode(prev)
+    assert st.tolist() == [0, _pcmio.IO_SHORT] and np.array_equal(buf, blob)
+
+
 def test_reader_share_honours_the_cgroup_cpu_quota(tmp_path, monkeypatch):
     """A container's CPU quota does not show in the affinity mask (the timing box: 256 CPUs listed, 16 granted): ``cgroup_cpu_quota`` reads it from
     cgroup v2's ``cpu.max`` or v1's ``cpu.cfs_*`` (rounded up; no quota = None) and ``default_threads`` divides min(affinity, quota) by the ranks
