@@ -366,6 +366,40 @@ class _PinnedSlab:
             self.ptr, self.tensor = 0, None
 
 
+_PREPARE: list = []   # helper threads of prepare_for_evaluate that may still be page-locking (a pipeline waits for them before it judges the pool)
+_PRELOADED: set = set()   # str(device) whose code objects prepare_for_evaluate has loaded
+
+
+def prepare_for_evaluate(ctx, torch, slabs: int = 3, slab_bytes: int = 256 << 20) -> None:
+    """What a first ``evaluate`` call of a process otherwise does on its critical path, started NOW on a helper thread: the library's code objects
+    loaded (``bn_preload_kernels``), ``slabs`` page-locked staging slabs put into the process-wide pool (19 ms each), the copy stream created.
+    ``load_model_runner(..., prepare_pipeline=True)`` calls this as soon as it has a context — before it parses and lowers the model file, which
+    takes longer than all of it — so a one-shot ``python -m birdnet_stm32 evaluate`` finds everything in place (the reference's counterpart is the
+    interpreter's ``allocate_tensors()`` at load, models/runners.py:58).  Idempotent; ``release_pinned_slabs()`` gives the memory back."""
+    dev = torch.device("cuda", ctx.device)
+
+    def work():
+        try:
+            torch.cuda.set_device(dev)
+            ctx.preload_kernels()
+            _PRELOADED.add(str(dev))
+            key = str(dev)
+            with _SLAB_LOCK:
+                if key not in _COPY_STREAMS:
+                    _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+            for _ in range(slabs):
+                with _SLAB_LOCK:
+                    if sum(1 for _, size in _SLAB_POOL if size >= slab_bytes) >= slabs:
+                        break
+                _PinnedSlab.fresh(ctx, slab_bytes, torch).release()
+        except Exception:  # pragma: no cover - the first evaluate call then does what is missing itself
+            pass
+
+    th = threading.Thread(target=work, name="bn-prepare-evaluate", daemon=True)
+    _PREPARE.append(th)
+    th.start()
+
+
 def release_pinned_slabs() -> int:
     """Give the pooled page-locked slabs back to the system; returns the bytes freed."""
     with _SLAB_LOCK:
@@ -436,6 +470,8 @@ class EvaluatePipeline:
     def _ensure_slabs(self, need: int, tab_words: int) -> None:
         torch = self.torch
         cap = max(self.slab_bytes, need)
+        while _PREPARE:   # (prepare_for_evaluate still page-locking: its slabs are the ones this call wants)
+            _PREPARE.pop().join()
         for e in getattr(self, "_pinned_ready", []):   # (a helper thread of an earlier call is still allocating: let it finish before judging the sizes)
             e.wait()
         if not self._tab_pinned or self._tab_pinned[0].numel() < tab_words:
@@ -675,6 +711,8 @@ class EvaluatePipeline:
 
             th = threading.Thread(target=producer, name="bn-evaluate-reader", daemon=True)
             th.start()
+            if str(self.dev) in _PRELOADED:
+                self._preloaded = True
             if not self._preloaded:   # this thread has nothing to do until the first group is on the device: load the kernels' code objects meanwhile
                 self.ctx.preload_kernels()
                 torch.empty(64, dtype=torch.float32, device=self.dev).zero_()   # (and the one torch kernel of the compute stage: _peak.zero_())

@@ -144,7 +144,7 @@ def main(argv=None, runner=None):
     if runner is None:
         from birdnet_stm32.models.runners import load_model_runner
 
-        runner = load_model_runner(args.model_path, device=device, max_batch=args.max_batch)
+        runner = load_model_runner(args.model_path, device=device, max_batch=args.max_batch, prepare_pipeline=True)
 
     metrics, per_file, y_true, y_scores = evaluate(
         model_runner=runner, files=files, classes=classes, cfg=cfg, pooling=args.pooling, batch_size=args.batch_size,

@@ -31,7 +31,7 @@ from birdnet_stm32.models import _pack as pk
 class HipRunner:
     """Executes a lowered plan on one MI355X."""
 
-    def __init__(self, plan: pk.Plan, device: int = 0, max_batch: int = 1024):
+    def __init__(self, plan: pk.Plan, device: int = 0, max_batch: int = 1024, ctx: "_hip.Context | None" = None):
         import torch
 
         if not torch.cuda.is_available():
@@ -39,7 +39,7 @@ class HipRunner:
         self._torch = torch
         self.plan = plan
         self.device = torch.device("cuda", device)
-        self.ctx = _hip.Context(device, max_batch)
+        self.ctx = ctx if ctx is not None else _hip.Context(device, max_batch)   # (load_model_runner creates it early when it prepares the pipeline)
         self.model = _hip.Model(self.ctx, plan.to_blob())
         self.lib = self.ctx.lib
         info = self.model.info
@@ -242,6 +242,12 @@ class HipRunner:
         return rows
 
     def close(self):
+        import sys
+
+        pl = sys.modules.get("birdnet_stm32.audio.pipeline")
+        if pl is not None:   # (a helper thread of prepare_for_evaluate may still be page-locking through this context)
+            while pl._PREPARE:
+                pl._PREPARE.pop().join()
         self.model.close()
         self.ctx.close()
 
@@ -280,7 +286,21 @@ def lower_model_file(model_path: str, keep_all: bool = False, frontend_norm: boo
 
 
 def load_model_runner(model_path: str, device: int = 0, max_batch: int = 1024, keep_all: bool = False,
-                      frontend_norm: bool | None = None, fuse: bool = True) -> HipRunner:
-    """Load a `.keras` or `.tflite` model and return a runner with ``predict()`` (reference :98-114)."""
+                      frontend_norm: bool | None = None, fuse: bool = True, prepare_pipeline: bool = False) -> HipRunner:
+    """Load a `.keras` or `.tflite` model and return a runner with ``predict()`` (reference :98-114).
+
+    ``prepare_pipeline``: the caller is going to ``evaluate`` files with this runner (the CLI does) — the context is created first and, while the
+    model file is parsed and lowered, a helper thread loads the library's code objects and page-locks the evaluate pipeline's staging slabs
+    (``audio.pipeline.prepare_for_evaluate``: 768 MiB of page-locked memory, kept until ``release_pinned_slabs()``)."""
+    ctx = None
+    if prepare_pipeline:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device visible: HipRunner has no CPU fallback")
+        from birdnet_stm32.audio.pipeline import prepare_for_evaluate
+
+        ctx = _hip.Context(device, max_batch)
+        prepare_for_evaluate(ctx, torch)
     plan = lower_model_file(model_path, keep_all=keep_all, frontend_norm=frontend_norm, fuse=fuse)
-    return HipRunner(plan, device=device, max_batch=max_batch)
+    return HipRunner(plan, device=device, max_batch=max_batch, ctx=ctx)

@@ -200,3 +200,32 @@ def test_rank_orders_sort_like_numpy_and_give_the_librarys_metrics(torch_mod):
         assert ctx.lib.bn_rank_orders(ctx.handle, None, 4, 3, None, None, None) != 0 and b"null" in ctx.lib.bn_last_error()
     finally:
         ctx.close()
+
+
+def test_prepare_pipeline_fills_the_pool_while_the_model_is_lowered(torch_mod):
+    """``load_model_runner(..., prepare_pipeline=True)`` (what the evaluate CLI passes): the context exists before the model file is parsed, a helper
+    thread loads the library's code objects and page-locks three staging slabs into the process-wide pool meanwhile; the runner works as any other,
+    a pipeline built afterwards takes its ring from the pool without page-locking anything, closing the runner waits for the helper."""
+    torch = torch_mod
+    from birdnet_stm32.audio import pipeline as pl
+    from birdnet_stm32.models.runners import load_model_runner
+
+    pl.release_pinned_slabs()
+    runner = load_model_runner(TFLITE_PATH, max_batch=64, prepare_pipeline=True)
+    try:
+        while pl._PREPARE:
+            pl._PREPARE.pop().join()
+        assert len(pl._SLAB_POOL) == 3 and all(size >= 256 << 20 for _, size in pl._SLAB_POOL) and str(runner.device) in pl._PRELOADED
+        before = sorted(p for p, _ in pl._SLAB_POOL)
+        pipe = pl.EvaluatePipeline(runner, 24000, 3.0)
+        pipe._ensure_slabs(1 << 20, 1 << 10)
+        for e in pipe._pinned_ready:
+            e.wait()
+        assert pipe._n_ring == 3 and sorted(sl.ptr for sl in pipe._slabs) == before and pl._SLAB_POOL == []
+        pipe.close()
+        assert sorted(p for p, _ in pl._SLAB_POOL) == before
+        x = torch.zeros((2, 72000), device=runner.device)
+        assert torch.isfinite(runner.infer_audio_device(x)).all()
+    finally:
+        runner.close()
+        pl.release_pinned_slabs()

@@ -114,6 +114,7 @@ def main(argv=None) -> int:
     ap.add_argument("--slab_mb", type=int, default=256)
     ap.add_argument("--no_ramp", action="store_true", help="every group a full slab (A/B of the small first groups)")
     ap.add_argument("--readers", type=int, default=0)
+    ap.add_argument("--no_prepare", action="store_true", help="load the runner without prepare_pipeline (the first call then page-locks its slabs itself)")
     ap.add_argument("--read_mode", choices=["mmap", "pread"], default=None, help="A/B of the reader's two ways out of the page cache")
     ap.add_argument("--batch_size", type=int, default=16)
     ap.add_argument("--latency", action="store_true", help="one more run with measure_latency (slices of --batch_size)")
@@ -148,7 +149,8 @@ def main(argv=None) -> int:
         rate = pinned_copy_rate(torch)
         out["pinned_copy_gbps"] = round(rate, 2)
         log(f"pinned H2D copy: {rate:.1f} GB/s")
-        runner = load_model_runner(ckpt + (".tflite" if args.dtype == "i8" else ".keras"), max_batch=args.max_batch)
+        # (as the CLI creates it: `python -m birdnet_stm32 evaluate` passes prepare_pipeline=True; --no_prepare times the bare runner)
+        runner = load_model_runner(ckpt + (".tflite" if args.dtype == "i8" else ".keras"), max_batch=args.max_batch, prepare_pipeline=not args.no_prepare)
         opts = {"slab_bytes": args.slab_mb << 20}
         if args.no_ramp:
             opts["ramp"] = ()
